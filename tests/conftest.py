@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def closed_form(n, salt):
+    """Same closed-form generator as tests/golden/make_golden.py (inputs that are not stored)."""
+    i = np.arange(n, dtype=np.float64)
+    x = np.sin(i * 12.9898 + salt * 78.233) * 43758.5453
+    return x - np.floor(x)
+
+
+def load_msda_fixture(name):
+    """-> dict with inputs (value, shapes, level_start, loc, attn, grad_out) and reference results."""
+    z = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    if "value_recipe" in z:  # big-D test.py cases: regenerate value / grad_out from the recipe
+        D = int(z["channels"])
+        shapes = z["shapes"]
+        S = int((shapes[:, 0] * shapes[:, 1]).sum())
+        N, Lq, M = z["loc"].shape[:3]
+        salt, scale = z["value_recipe"]
+        z["value"] = closed_form(N * S * M * D, salt).reshape(N, S, M, D) * scale
+        z["grad_out"] = closed_form(N * Lq * M * D, int(z["grad_out_recipe"][0])).reshape(N, Lq, M * D)
+    return z
+
+
+MSDA_TESTPY = ["msda_testpy_double", "msda_testpy_float"] + [
+    f"msda_testpy_grad_D{d}" for d in (30, 32, 64, 71, 1025, 2048, 3096)]
+MSDA_CFG = ["msda_cfg_A_square", "msda_cfg_E_wide", "msda_cfg_D_odd"]
+
+
+@pytest.fixture(scope="session")
+def oracle_msda():
+    from oracle import msda_oracle
+    msda_oracle.build()
+    return msda_oracle
+
+
+def smooth_points(z, eps=1e-4):
+    """Boolean [N,Lq,M,L,P] mask of sampling points that are NOT within eps of an integer pixel
+    coordinate.  d(out)/d(loc) is discontinuous there (floor()), so a reduced-precision run may
+    legitimately land on the other side; grad_loc comparisons in fp32 skip those points."""
+    loc = z["loc"].astype(np.float64)
+    shapes = z["shapes"].astype(np.float64)
+    x = loc[..., 0] * shapes[None, None, None, :, None, 1] - 0.5
+    y = loc[..., 1] * shapes[None, None, None, :, None, 0] - 0.5
+    H = shapes[None, None, None, :, None, 0]
+    W = shapes[None, None, None, :, None, 1]
+    near = (np.abs(x - np.round(x)) < eps) | (np.abs(y - np.round(y)) < eps)
+    # the in/out-of-range cut-offs (-1, H, W) are integers too, covered by `near`
+    del H, W
+    return ~near
