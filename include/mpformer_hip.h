@@ -1,0 +1,95 @@
+/*
+ * mpformer_hip.h — C ABI of libmpformer_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the native hot path of IDEA-Research/MP-Former.  Every entry point takes
+ * plain device pointers and sizes (no torch types), runs asynchronously on the HIP stream passed
+ * as `stream` (a hipStream_t cast to void*; NULL = the null stream), never synchronises, never
+ * allocates, and returns 0 on success, a positive hipError_t value if the launch failed, or a
+ * negative MPF_E_* code if an argument was rejected.  Unlike the reference, which only printf()s
+ * kernel-launch errors (ops/src/cuda/ms_deform_im2col_cuda.cuh:953-957,1326-1330), errors are
+ * returned to the caller; mpf_last_error() gives a human-readable message for the calling thread.
+ *
+ * All tensors are contiguous, row-major, in the reference's layouts.
+ */
+#ifndef MPFORMER_HIP_H
+#define MPFORMER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types of the floating-point buffers */
+enum { MPF_F32 = 0, MPF_F64 = 1 };
+
+/* argument errors */
+enum {
+    MPF_OK = 0,
+    MPF_E_DTYPE = -1,    /* unsupported dtype code */
+    MPF_E_SHAPE = -2,    /* non-positive / inconsistent sizes */
+    MPF_E_NULL = -3,     /* NULL pointer for a required buffer */
+    MPF_E_TOO_LARGE = -4 /* tensor exceeds the 2^31-element indexing limit of the kernels */
+};
+
+/* ABI version of this header (bumped on any signature change). */
+int mpf_abi_version(void);
+/* Message for the last non-zero return value on the calling thread ("" if none). */
+const char* mpf_last_error(void);
+
+/*
+ * Multi-scale deformable attention, forward.
+ * Replaces ms_deform_attn_forward (pybind: ops/src/vision.cpp:19; dispatcher
+ * ops/src/ms_deform_attn.h:25-44; host ops/src/cuda/ms_deform_attn_cuda.cu:25-85; kernel
+ * ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304).
+ *
+ *   value        [batch, spatial_size, num_heads, channels]            dtype
+ *   spatial_shapes [num_levels, 2] int64 (H_l, W_l)                     DEVICE memory
+ *   level_start_index [num_levels] int64                                DEVICE memory
+ *   sampling_loc [batch, num_query, num_heads, num_levels, num_point, 2] dtype, (x, y) in [0,1]
+ *   attn_weight  [batch, num_query, num_heads, num_levels, num_point]   dtype
+ *   output       [batch, num_query, num_heads*channels]                 dtype, fully overwritten
+ *
+ * The reference's `im2col_step` batch chunking (ms_deform_attn_cuda.cu:53-80) has no numerical
+ * effect and is not part of this ABI: the whole batch is one launch.
+ */
+int mpf_msda_forward(const void* value, const int64_t* spatial_shapes,
+                     const int64_t* level_start_index, const void* sampling_loc,
+                     const void* attn_weight, void* output,
+                     int batch, int spatial_size, int num_heads, int channels,
+                     int num_levels, int num_query, int num_point,
+                     int dtype, void* stream);
+
+/*
+ * Multi-scale deformable attention, backward.
+ * Replaces ms_deform_attn_backward (pybind: ops/src/vision.cpp:20; host
+ * ops/src/cuda/ms_deform_attn_cuda.cu:88-158; kernels ms_deform_im2col_cuda.cuh:306-925,
+ * dispatch :961-1331).
+ *
+ *   grad_output      [batch, num_query, num_heads*channels]
+ *   grad_value       like value         (zero-filled by this call, then accumulated with atomics)
+ *   grad_sampling_loc like sampling_loc (fully overwritten)
+ *   grad_attn_weight like attn_weight   (fully overwritten)
+ */
+int mpf_msda_backward(const void* value, const int64_t* spatial_shapes,
+                      const int64_t* level_start_index, const void* sampling_loc,
+                      const void* attn_weight, const void* grad_output,
+                      void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
+                      int batch, int spatial_size, int num_heads, int channels,
+                      int num_levels, int num_query, int num_point,
+                      int dtype, void* stream);
+
+/*
+ * Tuning / introspection knobs (process-wide; for benchmarks and tests).
+ *   mpf_set_option("msda_fwd_variant", v): 0 = auto, 1 = generic kernel, 2 = tiled V4, 3 = tiled V1
+ *   mpf_set_option("msda_bwd_variant", v): same numbering
+ * Returns 0, or MPF_E_SHAPE for an unknown key/value.
+ */
+int mpf_set_option(const char* key, int value);
+/* Name of the kernel the last mpf_msda_forward / _backward call on this thread launched. */
+const char* mpf_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPFORMER_HIP_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of libmpformer_hip.so — the C-ABI boundary (include/mpformer_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C mp_former_amd/csrc`` and is
+loaded lazily on first use.  A missing library is a hard error: there is no fallback path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpformer_hip.so")
+ABI_VERSION = 1
+
+MPF_F32, MPF_F64 = 0, 1
+
+_lib = None
+
+_c_int = ctypes.c_int
+_c_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/mpformer_hip.h
+SIGNATURES = {
+    "mpf_abi_version": (_c_int, []),
+    "mpf_last_error": (ctypes.c_char_p, []),
+    "mpf_last_kernel": (ctypes.c_char_p, []),
+    "mpf_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
+    "mpf_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
+    "mpf_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (raises NativeLibraryError if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mp_former_amd/csrc`.  mp_former_amd has no CPU / eager fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError as e:
+                raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        v = l.mpf_abi_version()
+        if v != ABI_VERSION:
+            raise NativeLibraryError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
+        _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().mpf_last_error().decode()
+        raise RuntimeError(f"{what} failed with code {code}: {msg}")
+
+
+def set_option(key, value):
+    check(lib().mpf_set_option(key.encode(), int(value)), f"mpf_set_option({key})")
+
+
+def last_kernel():
+    return lib().mpf_last_kernel().decode()

@@ -1,0 +1,194 @@
+"""Host-side mirror of the reference's MSDeformAttn operator interface, backed by the HIP kernels.
+
+Mirrors (same names, argument meaning and error behaviour):
+  * the pybind op module ``MultiScaleDeformableAttention`` — ``ms_deform_attn_forward`` /
+    ``ms_deform_attn_backward`` (reference: mask2former/modeling/pixel_decoder/ops/src/vision.cpp:18-21,
+    ops/src/ms_deform_attn.h:25-66, ops/src/cuda/ms_deform_attn_cuda.cu:25-158);
+  * ``MSDeformAttnFunction`` (ops/functions/ms_deform_attn_func.py:32-49);
+  * ``MSDeformAttn`` (ops/modules/ms_deform_attn.py:34-125) — but WITHOUT the reference's bare
+    ``except:`` fallback to the grid_sample path (:119-121): a failing native op raises.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.init import constant_, xavier_uniform_
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.MPF_F32, torch.float64: _lib.MPF_F64}
+
+
+def _check_inputs(named):
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")  # ms_deform_attn_cuda.cu:33-37
+        if not t.is_cuda:
+            if name == "value":
+                raise RuntimeError("Not implemented on the CPU")  # ms_deform_attn.h:43,65
+            raise RuntimeError(f"{name} must be a CUDA tensor")  # ms_deform_attn_cuda.cu:39-43
+
+
+def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    if value.dtype not in _DTYPES:
+        # AT_DISPATCH_FLOATING_TYPES: float / double only (ms_deform_attn_cuda.cu:69)
+        raise RuntimeError(f'"ms_deform_attn" not implemented for \'{value.dtype}\'')
+    for name, t in (("sampling_loc", sampling_loc), ("attn_weight", attn_weight)):
+        if t.dtype != value.dtype:
+            raise RuntimeError(f"{name} dtype {t.dtype} does not match value dtype {value.dtype}")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64 tensors")
+    batch, spatial_size, num_heads, channels = value.shape
+    num_levels = spatial_shapes.shape[0]
+    num_query, num_point = sampling_loc.shape[1], sampling_loc.shape[4]
+    if tuple(sampling_loc.shape) != (batch, num_query, num_heads, num_levels, num_point, 2):
+        raise RuntimeError(f"sampling_loc has shape {tuple(sampling_loc.shape)}")
+    if tuple(attn_weight.shape) != (batch, num_query, num_heads, num_levels, num_point):
+        raise RuntimeError(f"attn_weight has shape {tuple(attn_weight.shape)}")
+    if tuple(level_start_index.shape) != (num_levels,) or tuple(spatial_shapes.shape) != (num_levels, 2):
+        raise RuntimeError("spatial_shapes must be [L,2] and level_start_index [L]")
+    im2col_step_ = min(batch, int(im2col_step))
+    if im2col_step_ <= 0 or batch % im2col_step_ != 0:  # ms_deform_attn_cuda.cu:55-57
+        raise RuntimeError(f"batch({batch}) must divide im2col_step({im2col_step_})")
+    return batch, spatial_size, num_heads, channels, num_levels, num_query, num_point
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """-> output [N, Lq, M*D]; freshly allocated, computed on the current stream."""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight)])
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        code = _lib.lib().mpf_msda_forward(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
+            N, S, M, D, L, Lq, P, _DTYPES[value.dtype], _stream(value))
+    _lib.check(code, "mpf_msda_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                            grad_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight]"""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight), ("grad_output", grad_output)])
+    N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("grad_output must be [N, Lq, M*D] in the dtype of value")
+    gv = torch.empty_like(value)           # zero-filled by the native call
+    gl = torch.empty_like(sampling_loc)
+    ga = torch.empty_like(attn_weight)
+    with torch.cuda.device(value.device):
+        code = _lib.lib().mpf_msda_backward(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+            gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
+            N, S, M, D, L, Lq, P, _DTYPES[value.dtype], _stream(value))
+    _lib.check(code, "mpf_msda_backward")
+    return [gv, gl, ga]
+
+
+class MSDeformAttnFunction(Function):
+    """ops/functions/ms_deform_attn_func.py:32-49."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                        sampling_locations, attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                              sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, attn = ctx.saved_tensors
+        gv, gl, ga = ms_deform_attn_backward(value, shapes, lsi, loc, attn,
+                                             grad_output.contiguous(), ctx.im2col_step)
+        return gv, None, None, gl, ga, None
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+class MSDeformAttn(nn.Module):
+    """Multi-scale deformable attention module; parameter names / init / forward signature of
+    ops/modules/ms_deform_attn.py:34-125 so reference checkpoints load unchanged."""
+
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a per-head dimension that is not 32 takes the generic (slow) kernels")
+        self.im2col_step = 128
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        constant_(self.sampling_offsets.weight.data, 0.0)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2)
+        grid_init = grid_init.repeat(1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid_init[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
+        constant_(self.attention_weights.weight.data, 0.0)
+        constant_(self.attention_weights.bias.data, 0.0)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.0)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.0)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None):
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        sampling_offsets = self.sampling_offsets(query).view(
+            N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        attention_weights = self.attention_weights(query).view(
+            N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        attention_weights = F.softmax(attention_weights, -1).view(
+            N, Len_q, self.n_heads, self.n_levels, self.n_points)
+        if reference_points.shape[-1] == 2:
+            offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            sampling_locations = reference_points[:, :, None, :, None, :] \
+                + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+        # strict: no silent fallback
+        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                            sampling_locations.contiguous(), attention_weights,
+                                            self.im2col_step)
+        return self.output_proj(output)
