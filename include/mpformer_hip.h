@@ -81,7 +81,8 @@ int mpf_msda_backward(const void* value, const int64_t* spatial_shapes,
 
 /*
  * Tuning / introspection knobs (process-wide; for benchmarks and tests).
- *   mpf_set_option("msda_fwd_variant", v): 0 = auto, 1 = generic kernel, 2 = tiled V4, 3 = tiled V1
+ *   mpf_set_option("msda_fwd_variant", v): 0 = auto, 1 = generic kernel, 2 = tiled V4 (8 lanes x 16 B per row), 3 = tiled V1 (32 lanes x 4 B),
+ *                                           4 = tiled V2 (16 lanes x 8 B)
  *   mpf_set_option("msda_bwd_variant", v): same numbering
  * Returns 0, or MPF_E_SHAPE for an unknown key/value.
  */

@@ -508,10 +508,16 @@ extern "C" int mpf_msda_forward(const void* value, const int64_t* spatial_shapes
     hipStream_t st = (hipStream_t)stream;
     hipError_t err;
     int variant = g_fwd_variant;
-    if (variant == 0) variant = 2;
+    if (variant == 0) variant = 3;  // measured: 32 lanes x 4 B beats 8 lanes x 16 B (profiles/)
     if (variant == 2 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 4)) variant = 1;
     if (variant == 3 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 1)) variant = 1;
-    if (variant == 2) {
+    if (variant == 4 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 2)) variant = 1;
+    if (variant == 4) {
+        mpf::set_kernel("msda_fwd_tiled_f32<32,2>");
+        err = launch_fwd_tiled<32, 2>((const float*)value, spatial_shapes, level_start_index,
+                                      (const float*)sampling_loc, (const float*)attn_weight,
+                                      (float*)output, N, S, M, L, Lq, P, st);
+    } else if (variant == 2) {
         mpf::set_kernel("msda_fwd_tiled_f32<32,4>");
         err = launch_fwd_tiled<32, 4>((const float*)value, spatial_shapes, level_start_index,
                                       (const float*)sampling_loc, (const float*)attn_weight,
@@ -561,10 +567,18 @@ extern "C" int mpf_msda_backward(const void* value, const int64_t* spatial_shape
     hipError_t err = hipMemsetAsync(grad_value, 0, (size_t)N * S * M * D * esz, st);
     if (err != hipSuccess) return mpf::check(err, "mpf_msda_backward(memset)");
     int variant = g_bwd_variant;
-    if (variant == 0) variant = 2;
+    if (variant == 0) variant = 3;  // atomics cost per (instruction, 128-B row): keep rows whole
     if (variant == 2 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 4)) variant = 1;
     if (variant == 3 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 1)) variant = 1;
-    if (variant == 2) {
+    if (variant == 4 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 2)) variant = 1;
+    if (variant == 4) {
+        mpf::set_kernel("msda_bwd_tiled_f32<32,2>");
+        err = launch_bwd_tiled<32, 2>((const float*)value, spatial_shapes, level_start_index,
+                                      (const float*)sampling_loc, (const float*)attn_weight,
+                                      (const float*)grad_output, (float*)grad_value,
+                                      (float*)grad_sampling_loc, (float*)grad_attn_weight,
+                                      N, S, M, L, Lq, P, st);
+    } else if (variant == 2) {
         mpf::set_kernel("msda_bwd_tiled_f32<32,4>");
         err = launch_bwd_tiled<32, 4>((const float*)value, spatial_shapes, level_start_index,
                                       (const float*)sampling_loc, (const float*)attn_weight,
@@ -607,7 +621,7 @@ extern "C" int mpf_msda_backward(const void* value, const int64_t* spatial_shape
 namespace mpf {
 int set_msda_option(const char* key, int v)
 {
-    if (v < 0 || v > 3) return MPF_E_SHAPE;
+    if (v < 0 || v > 4) return MPF_E_SHAPE;
     if (!strcmp(key, "msda_fwd_variant")) { g_fwd_variant = v; return 0; }
     if (!strcmp(key, "msda_bwd_variant")) { g_bwd_variant = v; return 0; }
     return 1;  // not mine

@@ -14,7 +14,7 @@ from conftest import MSDA_CFG, MSDA_TESTPY, load_msda_fixture, smooth_points
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {"auto": 0, "generic": 1, "tiled_v4": 2, "tiled_v1": 3}
+VARIANTS = {"auto": 0, "generic": 1, "tiled_v4": 2, "tiled_v1": 3, "tiled_v2": 4}
 
 
 @pytest.fixture(scope="module")
@@ -69,7 +69,7 @@ def test_fp64_matches_reference_golden(dev, name):
     np.testing.assert_allclose(ga, z["grad_attn"], rtol=1e-8, atol=1e-11)
 
 
-@pytest.mark.parametrize("variant", ["generic", "tiled_v4", "tiled_v1"])
+@pytest.mark.parametrize("variant", ["generic", "tiled_v4", "tiled_v1", "tiled_v2"])
 @pytest.mark.parametrize("name", ["msda_testpy_float", "msda_testpy_grad_D32"] + MSDA_CFG)
 def test_fp32_matches_reference_golden(dev, name, variant):
     """fp32: tolerance of the reference's own float test (test.py:59): rtol 1e-2, atol 1e-3;
@@ -105,7 +105,7 @@ def _random_problem(N, lv, M=8, D=32, P=4, seed=0, oob=True):
                 attn=attn.numpy(), grad_out=go.numpy())
 
 
-@pytest.mark.parametrize("variant", ["tiled_v4", "tiled_v1", "generic"])
+@pytest.mark.parametrize("variant", ["tiled_v4", "tiled_v1", "tiled_v2", "generic"])
 def test_fp32_vs_oracle_config_A(dev, oracle_msda, variant):
     """config A (256x256 -> levels 8,16,32; S=1344), N=2, vs the C oracle on the same seeded input."""
     z = _random_problem(2, [(8, 8), (16, 16), (32, 32)], seed=1)
@@ -138,7 +138,7 @@ def test_fp32_full_size_config_B_vs_oracle_and_properties(dev, oracle_msda):
     ok = smooth_points(z)
     np.testing.assert_allclose(gl[ok], rgl[ok], rtol=1e-3, atol=5e-3)
     # variants agree
-    (out1, gv1, gl1, ga1), _ = _run(z, torch.float32, dev, "tiled_v1")
+    (out1, gv1, gl1, ga1), _ = _run(z, torch.float32, dev, "tiled_v4")
     np.testing.assert_allclose(out1, out, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(gv1, gv, rtol=1e-3, atol=2e-4)
     # linearity in value
