@@ -61,3 +61,28 @@ def smooth_points(z, eps=1e-4):
     # the in/out-of-range cut-offs (-1, H, W) are integers too, covered by `near`
     del H, W
     return ~near
+
+
+# ---- head fixtures (tests/golden/head_*.npz) ----------------------------------------------------
+HEAD_FIXTURES = ["head_small", "head_ragged", "head_nogt"]
+
+
+def load_head_fixture(name):
+    """-> (z, cfg, pix_params, dec_params, features, targets, rng_replay)"""
+    import json
+    import torch
+    sys.path.insert(0, GOLDEN)
+    import det_params as DP
+    z = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    cfg = json.loads(str(z["cfg"]))
+    pix_shapes = json.loads(str(z["pix_keys"]))
+    dec_shapes = json.loads(str(z["dec_keys"]))
+    pp = DP.det_state_dict(pix_shapes, "pix.")
+    dp = DP.det_state_dict(dec_shapes, "dec.")
+    feats = DP.det_features(cfg["N"], cfg["size"])
+    targets = DP.det_targets(cfg["N"], cfg["size"], cfg["counts"], cfg["num_classes"])
+    replay = []
+    for i in range(int(z["n_rng"])):
+        key = [k for k in z if k.startswith(f"rng_{i:03d}_")][0]
+        replay.append(torch.from_numpy(z[key]))
+    return z, cfg, pp, dp, feats, targets, replay

@@ -139,6 +139,131 @@ def gen_msda():
               grad_attn=ga.numpy())
 
 
+# =================================================================================================
+# Head fixtures (F2-F9 of SURVEY.md §8(c)): pixel decoder, MP decoder, matcher, criterion.
+# Parameters and inputs are closed-form (det_params.py), so only reference OUTPUTS are stored.
+# =================================================================================================
+HEAD_CFGS = {
+    # name: dict(size, N, counts (GT per image), queries, classes, enc_layers, dec_layers, points)
+    "small": dict(size=64, N=2, counts=[3, 1], num_queries=10, num_classes=7, enc_layers=2, dec_layers=3,
+                  num_points=112),
+    # one image without GT and one with many (padding rows that become all-False; T > pad of others)
+    "ragged": dict(size=64, N=3, counts=[0, 5, 2], num_queries=6, num_classes=4, enc_layers=1, dec_layers=4,
+                   num_points=64),
+    # no GT anywhere -> prepare_for_normal path, dn losses are zeros
+    "nogt": dict(size=64, N=1, counts=[0], num_queries=5, num_classes=3, enc_layers=1, dec_layers=2,
+                 num_points=32),
+}
+
+
+def build_reference_head(cfg):
+    import det_params as DP
+    pd = R.pixel_decoder()
+    dec = R.decoder()
+    shapes = {"res2": R.ShapeSpec(256, stride=4), "res3": R.ShapeSpec(512, stride=8),
+              "res4": R.ShapeSpec(1024, stride=16), "res5": R.ShapeSpec(2048, stride=32)}
+    pix = pd.MSDeformAttnPixelDecoder(
+        shapes, transformer_dropout=0.0, transformer_nheads=8, transformer_dim_feedforward=1024,
+        transformer_enc_layers=cfg["enc_layers"], conv_dim=256, mask_dim=256, norm="GN",
+        transformer_in_features=["res3", "res4", "res5"], common_stride=4)
+    d = dec.MultiScaleMaskedTransformerDecoderMaskDN(
+        256, True, num_classes=cfg["num_classes"], hidden_dim=256, num_queries=cfg["num_queries"], nheads=8,
+        dim_feedforward=2048, dec_layers=cfg["dec_layers"], pre_norm=False, mask_dim=256,
+        enforce_input_project=False, dn_mode="points", head_dn=False, all_lys=True, dn_ratio=0.5,
+        dn_label_noise_ratio=0.2)
+    pix.load_state_dict(DP.det_state_dict({k: v.shape for k, v in pix.state_dict().items()}, "pix."), strict=False)
+    d.load_state_dict(DP.det_state_dict({k: v.shape for k, v in d.state_dict().items()}, "dec."), strict=False)
+    m = R.matcher().HungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=5.0, num_points=cfg["num_points"])
+    wd = {"loss_ce": 2.0, "loss_mask": 5.0, "loss_dice": 5.0}
+    wd.update({k + "_dn": v for k, v in list(wd.items())})
+    aux = {}
+    for i in range(cfg["dec_layers"]):
+        aux.update({k + f"_{i}": v for k, v in wd.items()})
+    wd.update(aux)
+    crit = R.criterion().SetCriterion(cfg["num_classes"], matcher=m, weight_dict=wd, eos_coef=0.1,
+                                      losses=["labels", "masks"], num_points=cfg["num_points"],
+                                      oversample_ratio=3.0, importance_sample_ratio=0.75)
+    crit.train()
+    return pix, d, crit, wd
+
+
+def _sub(t, step):
+    return t.detach().reshape(-1)[::step].clone().numpy()
+
+
+def gen_head():
+    import det_params as DP
+    for name, cfg in HEAD_CFGS.items():
+        torch.manual_seed(1234)
+        pix, d, crit, wd = build_reference_head(cfg)
+        feats = DP.det_features(cfg["N"], cfg["size"])
+        for v in feats.values():
+            v.requires_grad_(True)
+        targets = DP.det_targets(cfg["N"], cfg["size"], cfg["counts"], cfg["num_classes"])
+        out = {}
+        import json
+        out["pix_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in pix.state_dict().items()}))
+        out["dec_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in d.state_dict().items()}))
+        out["cfg"] = np.array(json.dumps(cfg))
+        # ---- pixel decoder (F3) ----------------------------------------------------------------
+        mf, o0, ms = pix.forward_features(feats)
+        out["mask_features_s5"] = _sub(mf, 5)
+        out["mask_features_absmean"] = np.array(mf.abs().mean().item())
+        for i, z in enumerate(ms):
+            out[f"multi_scale_{i}_s3"] = _sub(z, 3)
+        # ---- decoder with MP queries (F4-F6, F9) -------------------------------------------------
+        captured_masks = []
+        orig_heads = d.forward_prediction_heads
+        with R.RandCapture() as cap:
+            dn_args = {"tgt": targets, "scalar": 1, "noise_scale": 0.0}
+            dout = d(ms, mf, None, dn_args)
+            n_dec_draws = len(cap.log)
+            losses = crit(dout, targets)
+        draws = cap.log
+        # drop the mask-noise draws (rand_like of the bool GT rows; NOISE_SCALE = 0 makes them no-ops)
+        keep = []
+        for i, (fn, t) in enumerate(draws):
+            is_mask_noise = (i < n_dec_draws and fn == "rand_like" and t.dim() == 2)
+            if not is_mask_noise:
+                keep.append((fn, t))
+        for i, (fn, t) in enumerate(keep):
+            out[f"rng_{i:03d}_{fn}"] = t.numpy()
+        out["n_rng"] = np.array(len(keep))
+        out["pred_logits"] = dout["pred_logits"].detach().numpy()
+        out["pred_masks"] = dout["pred_masks"].detach().numpy()
+        for i, a in enumerate(dout["aux_outputs"]):
+            out[f"aux{i}_pred_logits"] = a["pred_logits"].detach().numpy()
+            out[f"aux{i}_pred_masks_s3"] = _sub(a["pred_masks"], 3)
+        if dout["dn_out"] is not None:
+            out["dn_pred_logits"] = dout["dn_out"]["pred_logits"].detach().numpy()
+            out["dn_pred_masks"] = dout["dn_out"]["pred_masks"].detach().numpy()
+            out["dn_pad_size"] = np.array(dout["dn_out"]["dn_args"]["pad_size"])
+            out["dn_max_num"] = np.array(dout["dn_out"]["dn_args"]["max_num"])
+        # ---- criterion (F7, F8) ------------------------------------------------------------------
+        for k, v in losses.items():
+            out["loss." + k] = np.array(float(v))
+        total = sum(losses[k] * wd[k] for k in losses if k in wd)
+        out["total_loss"] = np.array(float(total))
+        total.backward()
+        for k, v in feats.items():
+            out[f"grad_feat_{k}_s7"] = _sub(v.grad, 7)
+            out[f"grad_feat_{k}_norm"] = np.array(v.grad.norm().item())
+        sd_p = dict(pix.named_parameters())
+        sd_d = dict(d.named_parameters())
+        for k in ["transformer.level_embed", "transformer.encoder.layers.0.self_attn.sampling_offsets.bias",
+                  "transformer.encoder.layers.0.self_attn.attention_weights.bias", "mask_features.bias",
+                  "transformer.encoder.layers.0.norm2.weight"]:
+            out["grad_pix." + k] = sd_p[k].grad.numpy()
+        out["grad_pix.value_proj0_s11"] = _sub(sd_p["transformer.encoder.layers.0.self_attn.value_proj.weight"].grad, 11)
+        for k in ["query_feat.weight", "level_embed.weight", "class_embed.bias", "decoder_norm.weight",
+                  "label_enc.weight", "mask_embed.layers.2.bias",
+                  "transformer_cross_attention_layers.0.multihead_attn.in_proj_bias"]:
+            g = sd_d[k].grad
+            out["grad_dec." + k] = (g if g is not None else torch.zeros_like(sd_d[k])).numpy()
+        _save(f"head_{name}", **out)
+        print(f"    total_loss={float(total):.6f}  rng draws kept={len(keep)} of {len(draws)}")
+
+
 def main():
     what = sys.argv[1:] or ["msda", "head"]
     torch.set_num_threads(4)
