@@ -87,7 +87,7 @@ int mpf_msda_backward(const void* value, const int64_t* spatial_shapes,
  * Returns 0, or MPF_E_SHAPE for an unknown key/value.
  */
 int mpf_set_option(const char* key, int value);
-/* Name of the kernel the last mpf_msda_forward / _backward call on this thread launched. */
+/* Name of the kernel the most recent native call in this process launched (any thread). */
 const char* mpf_last_kernel(void);
 
 #ifdef __cplusplus

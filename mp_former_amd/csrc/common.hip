@@ -3,9 +3,12 @@
 
 #include <stdio.h>
 
+#include <atomic>
+
 namespace {
 thread_local char t_err[256] = "";
-thread_local const char* t_kernel = "";
+// process-wide (autograd runs backward on its own thread)
+std::atomic<const char*> g_kernel{""};
 }  // namespace
 
 namespace mpf {
@@ -22,12 +25,12 @@ int check(hipError_t err, const char* where)
     return (int)err;
 }
 
-void set_kernel(const char* name) { t_kernel = name; }
+void set_kernel(const char* name) { g_kernel.store(name, std::memory_order_relaxed); }
 }  // namespace mpf
 
 extern "C" int mpf_abi_version(void) { return 1; }
 extern "C" const char* mpf_last_error(void) { return t_err; }
-extern "C" const char* mpf_last_kernel(void) { return t_kernel; }
+extern "C" const char* mpf_last_kernel(void) { return g_kernel.load(std::memory_order_relaxed); }
 
 extern "C" int mpf_set_option(const char* key, int value)
 {

@@ -1,0 +1,310 @@
+"""Masked-attention transformer decoder with mask-piloted (MP) queries — host-side mirror of
+``MultiScaleMaskedTransformerDecoderMaskDN`` (dn_mode="points"), reference:
+mask2former/modeling/transformer_decoder/mask2former_transformer_decoder.py
+  :19-206   SelfAttentionLayer / CrossAttentionLayer / FFNLayer / MLP
+  :558-727  constructor, from_config          :729-735  prepare_for_normal
+  :968-1060 prepare_for_dn_v5 (MP queries)    :1584-1622 gen_mask_dn
+  :1706-1857 forward                           :1859-1877 forward_prediction_heads
+
+Same parameter names (checkpoints load unchanged), same forward signature and output dict.
+Differences that do not change results:
+  * the boolean attention mask is kept as ONE [N, Qtot, HW] tensor shared by the 8 heads (the
+    reference materialises the 8x repeat, :1873); with HEAD_DN False the rows are identical;
+  * the "all-masked row -> unmask" rule (:1780) and the MP-row overwrite (:1814-1816) are applied
+    by the attention-mask builder instead of by in-place edits of the repeated tensor;
+  * ground-truth masks are OR-reduced to the 3 level sizes once per forward (A.5: area <= 1e-8 is
+    "no GT pixel in the block") instead of 10 area-interpolations;
+  * hard-coded .cuda() / 8 heads of the reference become the module's device / num_heads.
+Only dn_mode "points" with NOISE_SCALE 0 (the shipped run script) is implemented; other modes raise.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import _rng
+from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
+
+
+def masked_mha(q_in, k_in, v_in, mha: nn.MultiheadAttention, mask: Optional[Tensor]):
+    """Multi-head attention with packed in-proj (nn.MultiheadAttention parameters), seq-first.
+    q_in [Lq,N,E]; k_in, v_in [Lk,N,E]; mask bool, True = masked: [N,Lq,Lk] (shared by heads) or
+    [Lq,Lk]; returns [Lq,N,E].  Softmax in fp32."""
+    Lq, N, E = q_in.shape
+    Lk = k_in.shape[0]
+    h = mha.num_heads
+    hd = E // h
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    q = F.linear(q_in, w[:E], b[:E])
+    k = F.linear(k_in, w[E:2 * E], b[E:2 * E])
+    v = F.linear(v_in, w[2 * E:], b[2 * E:])
+    q = q.reshape(Lq, N, h, hd).permute(1, 2, 0, 3)      # [N,h,Lq,hd]
+    k = k.reshape(Lk, N, h, hd).permute(1, 2, 0, 3)
+    v = v.reshape(Lk, N, h, hd).permute(1, 2, 0, 3)
+    s = torch.matmul(q, k.transpose(-1, -2)).float() * (1.0 / math.sqrt(hd))
+    if mask is not None:
+        m = mask[:, None] if mask.dim() == 3 else mask[None, None]
+        s = s.masked_fill(m, float("-inf"))
+    p = torch.softmax(s, -1).to(v.dtype)
+    o = torch.matmul(p, v).permute(2, 0, 1, 3).reshape(Lq, N, E)
+    return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
+
+
+class SelfAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert not normalize_before and dropout == 0.0, "post-norm, dropout 0 (PRE_NORM False) only"
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt, tgt_mask=None, tgt_key_padding_mask=None, query_pos=None):
+        assert tgt_key_padding_mask is None and query_pos is None
+        return self.norm(tgt + masked_mha(tgt, tgt, tgt, self.self_attn, tgt_mask))
+
+
+class CrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert not normalize_before and dropout == 0.0
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
+                memory_plus_pos=None):
+        assert memory_key_padding_mask is None and query_pos is None
+        k_in = memory_plus_pos if memory_plus_pos is not None else (memory if pos is None else memory + pos)
+        return self.norm(tgt + masked_mha(tgt, k_in, memory, self.multihead_attn, memory_mask))
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert not normalize_before and dropout == 0.0
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt):
+        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))))
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+        return x
+
+
+def gt_block_or(masks: Tensor, size):
+    """A.5: 'masked' rows of the MP queries = no ground-truth pixel inside the (H/h)x(W/w) block
+    (== F.interpolate(mode='area') <= 1e-8 of :986-987 when H % h == 0).  masks [T,H,W] bool/float
+    -> [T, h*w] bool, True = do not attend."""
+    T, H, W = masks.shape
+    h, w = size
+    if H % h or W % w:
+        return F.interpolate(masks.float().unsqueeze(1), size=size, mode="area").flatten(1) <= 1e-8
+    m = masks if masks.dtype == torch.bool else masks > 0
+    any_ = m.view(T, h, H // h, w, W // w).any(dim=4).any(dim=2)
+    return ~any_.flatten(1)
+
+
+class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
+    _version = 2
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        version = local_metadata.get("version", None)
+        if version is None or version < 2:   # decoder :562-583
+            for k in list(state_dict.keys()):
+                if "static_query" in k:
+                    state_dict[k.replace("static_query", "query_feat")] = state_dict.pop(k)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    def __init__(self, in_channels, mask_classification=True, *, num_classes: int, hidden_dim: int,
+                 num_queries: int, nheads: int, dim_feedforward: int, dec_layers: int, pre_norm: bool,
+                 mask_dim: int, enforce_input_project: bool, dn_mode="base", head_dn=False, all_lys=False,
+                 dn_ratio=0.5, dn_label_noise_ratio=-1.0):
+        super().__init__()
+        assert mask_classification, "Only support mask classification model"
+        if dn_mode != "points":
+            raise NotImplementedError("only dn_mode='points' (the shipped MP-Former configuration) is implemented")
+        if head_dn:
+            raise NotImplementedError("HEAD_DN True is not part of the shipped configuration")
+        self.mask_classification = mask_classification
+        self.head_dn, self.dn_ratio = head_dn, dn_ratio
+        self.pe_layer = PositionEmbeddingSine(hidden_dim // 2, normalize=True)
+        self.dn_label_noise_ratio = dn_label_noise_ratio
+        self.num_heads, self.num_classes, self.num_layers = nheads, num_classes, dec_layers
+        self.dn_mode = dn_mode
+        self.transformer_self_attention_layers = nn.ModuleList()
+        self.transformer_cross_attention_layers = nn.ModuleList()
+        self.transformer_ffn_layers = nn.ModuleList()
+        for _ in range(self.num_layers):
+            self.transformer_self_attention_layers.append(SelfAttentionLayer(hidden_dim, nheads, 0.0, normalize_before=pre_norm))
+            self.transformer_cross_attention_layers.append(CrossAttentionLayer(hidden_dim, nheads, 0.0, normalize_before=pre_norm))
+            self.transformer_ffn_layers.append(FFNLayer(hidden_dim, dim_feedforward, 0.0, normalize_before=pre_norm))
+        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.num_queries = num_queries
+        self.query_feat = nn.Embedding(num_queries, hidden_dim)
+        self.num_feature_levels = 3
+        self.level_embed = nn.Embedding(self.num_feature_levels, hidden_dim)
+        self.input_proj = nn.ModuleList()
+        for _ in range(self.num_feature_levels):
+            if in_channels != hidden_dim or enforce_input_project:
+                self.input_proj.append(_ConvNorm(in_channels, hidden_dim, kernel_size=1))
+                _c2_xavier_fill(self.input_proj[-1])
+            else:
+                self.input_proj.append(nn.Sequential())
+        self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
+        self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
+        self.label_enc = nn.Embedding(num_classes, hidden_dim)
+        self.all_lys = all_lys
+
+    @classmethod
+    def from_config(cls, cfg, in_channels, mask_classification):
+        """decoder :697-727 (detectron2 CfgNode)."""
+        mf = cfg.MODEL.MASK_FORMER
+        assert mf.DEC_LAYERS >= 1
+        return dict(in_channels=in_channels, mask_classification=mask_classification,
+                    num_classes=cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES, hidden_dim=mf.HIDDEN_DIM,
+                    num_queries=mf.NUM_OBJECT_QUERIES, nheads=mf.NHEADS, dim_feedforward=mf.DIM_FEEDFORWARD,
+                    dec_layers=mf.DEC_LAYERS - 1, pre_norm=mf.PRE_NORM, enforce_input_project=mf.ENFORCE_INPUT_PROJ,
+                    mask_dim=cfg.MODEL.SEM_SEG_HEAD.MASK_DIM, dn_mode=mf.DN_MODE, head_dn=mf.HEAD_DN,
+                    all_lys=mf.ALL_LY_DN, dn_ratio=mf.DN_RATIO, dn_label_noise_ratio=mf.LB_NOISE_RATIO)
+
+    # ---------------------------------------------------------------------------------------------
+    def _mp_setup(self, dn_args, bs, size_list, device):
+        """prepare_for_dn_v5 (:968-1060) minus the prediction-head call.  Returns None when there is
+        no ground truth in the batch (-> prepare_for_normal)."""
+        targets, scalar, noise_scale = dn_args["tgt"], dn_args["scalar"], dn_args["noise_scale"]
+        if noise_scale != 0:
+            raise NotImplementedError("point-noise on MP masks (NOISE_SCALE > 0) is not in the shipped configuration")
+        num = [len(t["boxes"]) for t in targets]
+        max_num = max(num)
+        if scalar >= 100:
+            scalar = scalar // max_num if max_num else 0
+        if max_num == 0 or scalar == 0:
+            return None
+        pad = scalar * max_num
+        labels = torch.cat([t["labels"] for t in targets]).repeat(scalar, 1).view(-1)
+        if self.dn_label_noise_ratio > 0:
+            prob = _rng.rand("label_prob", tuple(labels.shape), device)
+            chosen = prob < self.dn_label_noise_ratio
+            new_label = _rng.randint("label_new", (int(chosen.sum()),), self.num_classes, device)
+            labels = labels.clone()
+            labels[chosen] = new_label.to(labels.dtype)
+        feats = self.label_enc(labels)
+        bid = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(num)]).repeat(scalar, 1).view(-1)
+        slot = torch.cat([torch.arange(n) for n in num])
+        slot = torch.cat([slot + max_num * i for i in range(scalar)]).long()
+        bid, slot = bid.to(device), slot.to(device)
+        padding = torch.zeros(bs, pad, feats.shape[-1], device=device, dtype=feats.dtype)
+        padding[(bid, slot)] = feats
+        # GT rows per level, computed once per forward (the reference re-derives them every layer)
+        rows = []
+        for size in size_list:
+            pm = torch.ones(bs, pad, size[0] * size[1], dtype=torch.bool, device=device)
+            gt = [gt_block_or(t["masks"], size) for t in targets if len(t["masks"]) > 0]
+            pm[(bid, slot)] = torch.cat(gt).repeat(scalar, 1)
+            rows.append(pm)
+        tgt_size = pad + self.num_queries
+        tgt_mask = torch.zeros(tgt_size, tgt_size, dtype=torch.bool, device=device)
+        tgt_mask[pad:, :pad] = True
+        for i in range(scalar):
+            tgt_mask[max_num * i:max_num * (i + 1), max_num * (i + 1):pad] = True
+            tgt_mask[max_num * i:max_num * (i + 1), :max_num * i] = True
+        return dict(padding=padding, rows=rows, tgt_mask=tgt_mask, dn_args={"max_num": max_num, "pad_size": pad})
+
+    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, mp_rows=None):
+        """:1859-1877.  Returns (outputs_class, outputs_mask, attn_mask[N,Qtot,HW] bool) where the
+        attention mask already has the MP rows written (:1814-1816) and all-masked rows cleared (:1780)."""
+        decoder_output = self.decoder_norm(output).transpose(0, 1)
+        outputs_class = self.class_embed(decoder_output)
+        mask_embed = self.mask_embed(decoder_output)
+        outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features.to(mask_embed.dtype))
+        am = F.interpolate(outputs_mask.detach().float(), size=attn_mask_target_size, mode="bilinear",
+                           align_corners=False)
+        am = am.flatten(2) < 0          # sigmoid(x) < 0.5  <=>  x < 0
+        if mp_rows is not None:
+            am = torch.cat([mp_rows, am[:, mp_rows.shape[1]:]], 1)
+        am = am & ~am.all(-1, keepdim=True)
+        return outputs_class, outputs_mask, am
+
+    def forward(self, x, mask_features, mask=None, dn_args=None):
+        assert len(x) == self.num_feature_levels
+        del mask
+        src, pos, kin, size_list = [], [], [], []
+        for i in range(self.num_feature_levels):
+            size_list.append(tuple(x[i].shape[-2:]))
+            p = self.pe_layer(x[i]).flatten(2).permute(2, 0, 1)
+            s = (self.input_proj[i](x[i]).flatten(2) + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1)
+            pos.append(p)
+            src.append(s)
+            kin.append(s + p)            # key input, shared by the 3 layers that use this level
+        bs = src[0].shape[1]
+        device = src[0].device
+        mp = self._mp_setup(dn_args, bs, size_list, device) if dn_args is not None else None
+        query = self.query_feat.weight.unsqueeze(1).repeat(1, bs, 1)
+        if mp is not None:
+            output = torch.cat([mp["padding"].transpose(0, 1).to(query.dtype), query], dim=0)
+            tgt_mask = mp["tgt_mask"]
+        else:
+            output, tgt_mask = query, None
+
+        def rows(level, i=None):
+            if mp is None:
+                return None
+            if i is not None and not (self.all_lys or i < 3):
+                return None
+            return mp["rows"][level]
+
+        outputs_class, outputs_mask, attn_mask = self.forward_prediction_heads(output, mask_features, size_list[0], rows(0))
+        predictions_class, predictions_mask = [outputs_class], [outputs_mask]
+        for i in range(self.num_layers):
+            level = i % self.num_feature_levels
+            output = self.transformer_cross_attention_layers[i](output, src[level], memory_mask=attn_mask,
+                                                                pos=pos[level], memory_plus_pos=kin[level])
+            output = self.transformer_self_attention_layers[i](output, tgt_mask=tgt_mask)
+            output = self.transformer_ffn_layers[i](output)
+            nxt = (i + 1) % self.num_feature_levels
+            outputs_class, outputs_mask, attn_mask = self.forward_prediction_heads(
+                output, mask_features, size_list[nxt], rows(nxt, i))
+            predictions_class.append(outputs_class)
+            predictions_mask.append(outputs_mask)
+
+        nq = self.num_queries
+        if tgt_mask is not None:
+            dn_c = [c[:, :-nq] for c in predictions_class]
+            dn_m = [m[:, :-nq] for m in predictions_mask]
+            predictions_class = [c[:, -nq:] for c in predictions_class]
+            predictions_mask = [m[:, -nq:] for m in predictions_mask]
+            dn_out = {"pred_logits": dn_c[-1], "pred_masks": dn_m[-1], "aux_outputs": self._set_aux_loss(dn_c, dn_m),
+                      "dn_args": mp["dn_args"]}
+        else:
+            dn_out = None
+            # keeps label_enc in the autograd graph so DDP sees every parameter used (:1846)
+            predictions_class[-1] = predictions_class[-1] + self.label_enc.weight[0, 0] * 0.0
+        return {"pred_logits": predictions_class[-1], "pred_masks": predictions_mask[-1],
+                "aux_outputs": self._set_aux_loss(predictions_class, predictions_mask), "dn_out": dn_out}
+
+    @staticmethod
+    def _set_aux_loss(outputs_class, outputs_seg_masks):
+        return [{"pred_logits": a, "pred_masks": b} for a, b in zip(outputs_class[:-1], outputs_seg_masks[:-1])]

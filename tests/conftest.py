@@ -86,3 +86,28 @@ def load_head_fixture(name):
         key = [k for k in z if k.startswith(f"rng_{i:03d}_")][0]
         replay.append(torch.from_numpy(z[key]))
     return z, cfg, pp, dp, feats, targets, replay
+
+
+def fifo_to_tags(replay, cfg, use_dn, label_noise=True):
+    """Map the reference's FIFO draw order (see make_golden.gen_head) onto the tagged draws of
+    mp_former_amd._rng: decoder label noise first, then per output (final, aux 0..): N matcher point
+    sets, the loss's oversampled + random points, and the same pair for the MP (`_dn`) loss."""
+    q = list(replay)
+    tags = {}
+
+    def put(tag):
+        tags.setdefault(tag, []).append(q.pop(0))
+
+    if use_dn and label_noise:
+        put("label_prob")
+        put("label_new")
+    for suffix in [""] + [f"_{i}" for i in range(cfg["dec_layers"])]:
+        for _ in range(cfg["N"]):
+            put("match" + suffix)
+        put("loss" + suffix + "_over")
+        put("loss" + suffix + "_rand")
+        if use_dn:
+            put("loss_dn" + suffix + "_over")
+            put("loss_dn" + suffix + "_rand")
+    assert not q, f"{len(q)} unconsumed reference draws"
+    return tags

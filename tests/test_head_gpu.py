@@ -1,0 +1,125 @@
+"""GPU parity of the product head (mp_former_amd: pixel decoder + MP decoder + criterion, native
+MSDA kernels inside) against the golden vectors of the imported reference modules and against the
+oracle, in fp32 with the reference's random draws replayed."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import HEAD_FIXTURES, fifo_to_tags, load_head_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def _sub(t, step):
+    return t.detach().float().reshape(-1)[::step].cpu().numpy()
+
+
+def _build(cfg, pp, dp, dev):
+    from mp_former_amd.head import MPFormerHead
+    h = MPFormerHead(num_classes=cfg["num_classes"], num_queries=cfg["num_queries"], enc_layers=cfg["enc_layers"],
+                     dec_layers=cfg["dec_layers"], num_points=cfg["num_points"])
+    h.pixel_decoder.load_state_dict(pp, strict=True)
+    h.predictor.load_state_dict(dp, strict=True)
+    return h.to(dev).train()
+
+
+@pytest.mark.parametrize("name", HEAD_FIXTURES)
+def test_head_matches_reference_golden_fp32(name):
+    from mp_former_amd import _lib, _rng
+    dev = torch.device("cuda:0")
+    z, cfg, pp, dp, feats, targets, replay = load_head_fixture(name)
+    # state-dict key names / shapes are part of the boundary (SURVEY.md §5 checkpoint row)
+    h = _build(cfg, pp, dp, dev)
+    assert {k: list(v.shape) for k, v in h.pixel_decoder.state_dict().items()} == json.loads(str(z["pix_keys"]))
+    assert {k: list(v.shape) for k, v in h.predictor.state_dict().items()} == json.loads(str(z["dec_keys"]))
+    use_dn = "dn_pred_logits" in z
+    _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
+    try:
+        feats = {k: v.to(dev).requires_grad_(True) for k, v in feats.items()}
+        targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+        mf, _, ms = h.pixel_decoder.forward_features(feats)
+        assert "msda_fwd_tiled" in _lib.last_kernel(), _lib.last_kernel()
+        np.testing.assert_allclose(_sub(mf, 5), z["mask_features_s5"], rtol=2e-3, atol=5e-4)
+        for i, t in enumerate(ms):
+            np.testing.assert_allclose(_sub(t, 3), z[f"multi_scale_{i}_s3"], rtol=2e-3, atol=5e-4)
+        out = h.predictor(ms, mf, None, {"tgt": targets, "scalar": 1, "noise_scale": 0.0})
+        np.testing.assert_allclose(out["pred_logits"].detach().cpu().numpy(), z["pred_logits"], rtol=5e-3, atol=2e-3)
+        np.testing.assert_allclose(out["pred_masks"].detach().cpu().numpy(), z["pred_masks"], rtol=5e-3, atol=5e-3)
+        for i, a in enumerate(out["aux_outputs"]):
+            np.testing.assert_allclose(a["pred_logits"].detach().cpu().numpy(), z[f"aux{i}_pred_logits"], rtol=5e-3, atol=2e-3)
+            np.testing.assert_allclose(_sub(a["pred_masks"], 3), z[f"aux{i}_pred_masks_s3"], rtol=5e-3, atol=5e-3)
+        if use_dn:
+            assert out["dn_out"]["dn_args"] == {"max_num": int(z["dn_max_num"]), "pad_size": int(z["dn_pad_size"])}
+            np.testing.assert_allclose(out["dn_out"]["pred_masks"].detach().cpu().numpy(), z["dn_pred_masks"], rtol=5e-3, atol=5e-3)
+        else:
+            assert out["dn_out"] is None
+        losses = h.criterion(out, targets)
+        assert _rng.remaining() == 0
+        ref_keys = sorted(k[5:] for k in z if k.startswith("loss."))
+        assert sorted(losses) == ref_keys
+        for k in ref_keys:
+            np.testing.assert_allclose(float(losses[k]), float(z["loss." + k]), rtol=2e-3, atol=1e-4, err_msg=k)
+        wd = h.criterion.weight_dict
+        total = sum(losses[k] * wd[k] for k in losses if k in wd)
+        np.testing.assert_allclose(float(total), float(z["total_loss"]), rtol=5e-4)
+        total.backward()
+        assert "msda_bwd_tiled" in _lib.last_kernel(), _lib.last_kernel()
+        for k, v in feats.items():
+            n = float(z[f"grad_feat_{k}_norm"])
+            np.testing.assert_allclose(v.grad.norm().item(), n, rtol=5e-3)
+            np.testing.assert_allclose(_sub(v.grad, 7), z[f"grad_feat_{k}_s7"], rtol=1e-2, atol=5e-3 * n / np.sqrt(v.numel()))
+        pg = dict(h.pixel_decoder.named_parameters())
+        for k in [k for k in z if k.startswith("grad_pix.") and "_s11" not in k]:
+            np.testing.assert_allclose(pg[k[9:]].grad.cpu().numpy(), z[k], rtol=1e-2, atol=1e-4 + 5e-3 * np.abs(z[k]).max(), err_msg=k)
+        dg = dict(h.predictor.named_parameters())
+        for k in [k for k in z if k.startswith("grad_dec.")]:
+            g = dg[k[9:]].grad
+            g = torch.zeros_like(dg[k[9:]]) if g is None else g
+            np.testing.assert_allclose(g.cpu().numpy(), z[k], rtol=1e-2, atol=1e-4 + 5e-3 * np.abs(z[k]).max(), err_msg=k)
+    finally:
+        _rng.install_replay(None)
+
+
+def test_head_bf16_autocast_close_to_fp32():
+    """AMP (bf16 autocast for the decoder; pixel decoder stays fp32 like the reference,
+    msdeformattn.py:314): weighted total loss within 2 % of the fp32 run on identical draws."""
+    from mp_former_amd import _rng
+    dev = torch.device("cuda:0")
+    z, cfg, pp, dp, feats, targets, replay = load_head_fixture("head_small")
+    h = _build(cfg, pp, dp, dev)
+    feats = {k: v.to(dev) for k, v in feats.items()}
+    targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+    _rng.install_replay(fifo_to_tags(replay, cfg, True))
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            losses, _ = h(feats, targets)
+        total = float(sum(losses.values()))
+    finally:
+        _rng.install_replay(None)
+    assert abs(total - float(z["total_loss"])) / float(z["total_loss"]) < 0.02, (total, float(z["total_loss"]))
+
+
+def test_head_config_A_runs_and_is_finite():
+    """config A: 256x256, N=1, 100 queries, 80 classes, full depth; fresh draws; loss finite, all
+    parameters receive a gradient (DDP needs every parameter used, decoder :1846)."""
+    from mp_former_amd.head import MPFormerHead
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    h = MPFormerHead().to(dev).train()
+    feats = {k: torch.randn(1, c, 256 // s, 256 // s, device=dev) for k, (c, s) in
+             {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}.items()}
+    masks = torch.zeros(3, 256, 256, dtype=torch.bool, device=dev)
+    masks[0, 10:100, 20:120] = True
+    masks[1, 150:250, 100:200] = True
+    masks[2, 60:90, 200:250] = True
+    targets = [{"labels": torch.tensor([1, 5, 7], device=dev), "masks": masks, "boxes": torch.zeros(3, 4, device=dev)}]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        losses, _ = h(feats, targets)
+    assert len(losses) == 60
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    missing = [n for n, p in h.named_parameters() if p.grad is None]
+    assert not missing, missing
