@@ -90,6 +90,16 @@ int mpf_set_option(const char* key, int value);
 /* Name of the kernel the most recent native call in this process launched (any thread). */
 const char* mpf_last_kernel(void);
 
+/*
+ * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
+ * events recorded on the launch stream (kernel only: memsets and host work are outside the
+ * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events
+ * and returns, for all launches whose kernel name contains `name_substr`, their number, summed
+ * duration in milliseconds and summed ALGORITHMIC bytes (the figures of DESIGN.md).
+ */
+int mpf_profile_enable(int on);
+int mpf_profile_get(const char* name_substr, int* count, double* total_ms, double* total_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,9 @@ SIGNATURES = {
     "mpf_last_error": (ctypes.c_char_p, []),
     "mpf_last_kernel": (ctypes.c_char_p, []),
     "mpf_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
+    "mpf_profile_enable": (_c_int, [_c_int]),
+    "mpf_profile_get": (_c_int, [ctypes.c_char_p, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_double),
+                                 ctypes.POINTER(ctypes.c_double)]),
     "mpf_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),
 }
@@ -67,3 +70,15 @@ def set_option(key, value):
 
 def last_kernel():
     return lib().mpf_last_kernel().decode()
+
+
+def profile_enable(on=True):
+    check(lib().mpf_profile_enable(1 if on else 0), "mpf_profile_enable")
+
+
+def profile_get(name_substr):
+    """-> (launch count, total ms, total algorithmic bytes) of the logged launches matching the name."""
+    n, ms, by = _c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+    check(lib().mpf_profile_get(name_substr.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)),
+          "mpf_profile_get")
+    return n.value, ms.value, by.value

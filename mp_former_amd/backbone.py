@@ -1,0 +1,76 @@
+"""ResNet-50 feature extractor used ONLY to complete the training step in bench.py (res2..res5 at
+strides 4/8/16/32, channels 256/512/1024/2048; detectron2 `build_resnet_backbone` layout with
+STRIDE_IN_1X1 False and FrozenBN, configs/coco/instance-segmentation/Base-COCO-InstanceSegmentation.yaml:2-15).
+Stock PyTorch-ROCm ops (MIOpen convolutions) — the backbone is outside the native hot path
+('backbone stays stock PyTorch-ROCm')."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm with fixed statistics and affine parameters (detectron2 FrozenBatchNorm2d)."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def forward(self, x):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        bias = self.bias - self.running_mean * scale
+        return x * scale.to(x.dtype).view(1, -1, 1, 1) + bias.to(x.dtype).view(1, -1, 1, 1)
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, cmid, cout, stride):
+        super().__init__()
+        self.shortcut = None
+        if cin != cout or stride != 1:
+            self.shortcut = nn.Conv2d(cin, cout, 1, stride=stride, bias=False)
+            self.shortcut_norm = FrozenBatchNorm2d(cout)
+        self.conv1 = nn.Conv2d(cin, cmid, 1, bias=False)
+        self.norm1 = FrozenBatchNorm2d(cmid)
+        self.conv2 = nn.Conv2d(cmid, cmid, 3, stride=stride, padding=1, bias=False)   # stride in the 3x3
+        self.norm2 = FrozenBatchNorm2d(cmid)
+        self.conv3 = nn.Conv2d(cmid, cout, 1, bias=False)
+        self.norm3 = FrozenBatchNorm2d(cout)
+
+    def forward(self, x):
+        out = F.relu(self.norm1(self.conv1(x)))
+        out = F.relu(self.norm2(self.conv2(out)))
+        out = self.norm3(self.conv3(out))
+        sc = x if self.shortcut is None else self.shortcut_norm(self.shortcut(x))
+        return F.relu(out + sc)
+
+
+class ResNet50(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.stem_conv = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.stem_norm = FrozenBatchNorm2d(64)
+        cfg = [("res2", 3, 64, 256, 1), ("res3", 4, 128, 512, 2), ("res4", 6, 256, 1024, 2), ("res5", 3, 512, 2048, 2)]
+        cin = 64
+        self.stage_names = []
+        for name, n, cmid, cout, stride in cfg:
+            blocks = []
+            for i in range(n):
+                blocks.append(Bottleneck(cin, cmid, cout, stride if i == 0 else 1))
+                cin = cout
+            setattr(self, name, nn.Sequential(*blocks))
+            self.stage_names.append(name)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = F.relu(self.stem_norm(self.stem_conv(x)))
+        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        out = {}
+        for name in self.stage_names:
+            x = getattr(self, name)(x)
+            out[name] = x
+        return out

@@ -4,6 +4,9 @@
 #include <stdio.h>
 
 #include <atomic>
+#include <mutex>
+#include <string>
+#include <vector>
 
 namespace {
 thread_local char t_err[256] = "";
@@ -26,7 +29,63 @@ int check(hipError_t err, const char* where)
 }
 
 void set_kernel(const char* name) { g_kernel.store(name, std::memory_order_relaxed); }
+
+// ---- in-library launch profiler: HIP events recorded on the launch stream around each kernel ----
+namespace {
+struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+std::atomic<int> g_prof_on{0};
+thread_local hipEvent_t t_e0 = nullptr;
+}  // namespace
+
+bool prof_enabled() { return g_prof_on.load(std::memory_order_relaxed) != 0; }
+
+void prof_begin(hipStream_t st)
+{
+    if (!prof_enabled()) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { t_e0 = nullptr; return; }
+    (void)hipEventRecord(e, st);
+    t_e0 = e;
+}
+
+void prof_end(const char* name, hipStream_t st, double algorithmic_bytes)
+{
+    if (!prof_enabled() || !t_e0) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back({name, t_e0, e, algorithmic_bytes});
+    t_e0 = nullptr;
+}
 }  // namespace mpf
+
+extern "C" int mpf_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(mpf::g_prof_mu);
+    for (auto& r : mpf::g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    mpf::g_prof.clear();
+    mpf::g_prof_on.store(on ? 1 : 0);
+    return 0;
+}
+
+extern "C" int mpf_profile_get(const char* name_substr, int* count, double* total_ms, double* total_bytes)
+{
+    if (!name_substr || !count || !total_ms || !total_bytes) return MPF_E_NULL;
+    std::lock_guard<std::mutex> lk(mpf::g_prof_mu);
+    int n = 0; double ms = 0, by = 0;
+    for (auto& r : mpf::g_prof) {
+        if (!strstr(r.name, name_substr)) continue;
+        if (hipEventSynchronize(r.e1) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) continue;
+        ms += t; by += r.bytes; ++n;
+    }
+    *count = n; *total_ms = ms; *total_bytes = by;
+    return 0;
+}
 
 extern "C" int mpf_abi_version(void) { return 1; }
 extern "C" const char* mpf_last_error(void) { return t_err; }

@@ -512,6 +512,10 @@ extern "C" int mpf_msda_forward(const void* value, const int64_t* spatial_shapes
     if (variant == 2 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 4)) variant = 1;
     if (variant == 3 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 1)) variant = 1;
     if (variant == 4 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 2)) variant = 1;
+    const double esz_f = dtype == MPF_F32 ? 4.0 : 8.0;
+    // algorithmic bytes: value + loc + attn read once, out written once
+    const double alg_bytes = esz_f * ((double)N * S * M * D + (double)N * Lq * M * L * P * 3 + (double)N * Lq * M * D);
+    mpf::prof_begin(st);
     if (variant == 4) {
         mpf::set_kernel("msda_fwd_tiled_f32<32,2>");
         err = launch_fwd_tiled<32, 2>((const float*)value, spatial_shapes, level_start_index,
@@ -545,6 +549,7 @@ extern "C" int mpf_msda_forward(const void* value, const int64_t* spatial_shapes
         }
         err = hipGetLastError();
     }
+    mpf::prof_end(mpf_last_kernel(), st, alg_bytes);
     return mpf::check(err, "mpf_msda_forward");
 }
 
@@ -571,6 +576,9 @@ extern "C" int mpf_msda_backward(const void* value, const int64_t* spatial_shape
     if (variant == 2 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 4)) variant = 1;
     if (variant == 3 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 1)) variant = 1;
     if (variant == 4 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 2)) variant = 1;
+    // algorithmic bytes: value, loc, attn, grad_out read once; the three gradients written once
+    const double alg_bytes = (double)esz * (2.0 * N * S * M * D + 2.0 * N * Lq * M * L * P * 3 + (double)N * Lq * M * D);
+    mpf::prof_begin(st);
     if (variant == 4) {
         mpf::set_kernel("msda_bwd_tiled_f32<32,2>");
         err = launch_bwd_tiled<32, 2>((const float*)value, spatial_shapes, level_start_index,
@@ -615,6 +623,7 @@ extern "C" int mpf_msda_backward(const void* value, const int64_t* spatial_shape
         }
         err = hipGetLastError();
     }
+    mpf::prof_end(mpf_last_kernel(), st, alg_bytes);
     return mpf::check(err, "mpf_msda_backward");
 }
 

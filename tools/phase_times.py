@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-phase GPU time of the training step (events on the current stream) — optimisation guide."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = bench.TrainModel().to(dev).train()
+    model.backbone.to(memory_format=torch.channels_last)
+    opt = bench.build_optimizer(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    batches = [bench.synth_batch(2, 1024, 80, i, dev) for i in range(2)]
+    names = ["backbone_fwd", "pixdec_fwd", "decoder_fwd", "criterion_fwd", "backward", "clip", "adamw"]
+    acc = {n: 0.0 for n in names}
+    wall = 0.0
+    iters = 6
+    for it in range(iters):
+        images, targets = batches[it % 2]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        ev[0].record()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            feats = model.backbone(images.contiguous(memory_format=torch.channels_last))
+            ev[1].record()
+            mf, _, ms = model.head.pixel_decoder.forward_features(feats)
+            ev[2].record()
+            out = model.head.predictor(ms, mf, None, {"tgt": targets, "scalar": 1, "noise_scale": 0.0})
+            ev[3].record()
+            losses = model.head.criterion(out, targets)
+            wd = model.head.criterion.weight_dict
+            loss = sum(v * wd[k] for k, v in losses.items() if k in wd)
+        ev[4].record()
+        loss.backward()
+        ev[5].record()
+        torch.nn.utils.clip_grad_norm_(params, 0.01, foreach=True)
+        ev[6].record()
+        opt.step()
+        ev[7].record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            wall += time.perf_counter() - t0
+            for i, n in enumerate(names):
+                acc[n] += ev[i].elapsed_time(ev[i + 1])
+    n = iters - 2
+    print("phase times (ms / step, 2 images):")
+    for k in names:
+        print(f"  {k:14s} {acc[k] / n:8.2f}")
+    print(f"  {'sum':14s} {sum(acc.values()) / n:8.2f}   wall {wall / n * 1e3:8.2f}")
+
+
+if __name__ == "__main__":
+    main()
