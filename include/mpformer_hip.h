@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 /* element types of the floating-point buffers */
-enum { MPF_F32 = 0, MPF_F64 = 1 };
+enum { MPF_F32 = 0, MPF_F64 = 1, MPF_BF16 = 2, MPF_U8 = 3 };
 
 /* argument errors */
 enum {
@@ -89,6 +89,46 @@ int mpf_msda_backward(const void* value, const int64_t* spatial_shapes,
 int mpf_set_option(const char* key, int value);
 /* Name of the kernel the most recent native call in this process launched (any thread). */
 const char* mpf_last_kernel(void);
+
+/*
+ * Bilinear point sampling: out[i, p] = bilinear(src[rows[i]], coords[coord_rows[i], p]) with zero
+ * padding and align_corners=False — detectron2 `point_sample` as called at
+ * mask2former/modeling/matcher.py:122-132 (matching cost: one point set per image shared by all of
+ * its masks -> coord_rows[i] = image of row i) and mask2former/modeling/criterion.py:164-170
+ * (importance sampling of the loss points: coord_rows = NULL, i.e. one point set per row).
+ *   src   [R, h, w] maps of dtype MPF_F32 / MPF_BF16 / MPF_U8 (bool ground-truth masks, 0/1 bytes)
+ *   rows  [n] int32 map index per output row        coords [C, P, 2] f32 (x, y) in [0,1]
+ *   coord_rows [n] int32 or NULL (= identity)       out [n, P] f32, fully overwritten
+ */
+int mpf_point_sample(const void* src, int src_dtype, int h, int w, const int32_t* rows,
+                     const float* coords, const int32_t* coord_rows, float* out, int n, int P, void* stream);
+
+/*
+ * Fused point-sampled mask loss, forward: for every (prediction, target) pair i and point p,
+ *   x = bilinear(pred[pred_rows[i]], c), t = bilinear(gt[gt_rows[i]], c),
+ * and partial[i, chunk, :] = sums over the chunk's points of
+ *   { BCEWithLogits(x, t), sigmoid(x)*t, sigmoid(x), t }
+ * from which loss_mask and loss_dice follow (mask2former/modeling/criterion.py:21-65, :172-191:
+ * sigmoid_ce_loss = mean_p BCE, dice_loss = 1 - (2*sum(s*t)+1)/(sum(s)+sum(t)+1)).  Replaces the
+ * gather of src_masks, the float copy of the GT masks, two point_sample calls and the element-wise
+ * loss tensors of the reference.
+ *   pred [R, h, w] MPF_F32 / MPF_BF16      gt [Rt, H, W] bytes (0/1)
+ *   coords [n, P, 2] f32                   partial [n, chunks, 4] f32, fully overwritten
+ */
+int mpf_mask_loss_forward(const void* pred, int pred_dtype, int h, int w, const int32_t* pred_rows,
+                          const uint8_t* gt, int H, int W, const int32_t* gt_rows,
+                          const float* coords, float* partial, int n, int P, int chunks, void* stream);
+
+/*
+ * Backward of the above wrt pred: grad_pred [R, h, w] f32 (caller zero-fills; accumulated with
+ * atomics) += d/dx of  grad_sums[i,0]*sum BCE + grad_sums[i,1]*sum(s*t) + grad_sums[i,2]*sum(s),
+ * scattered to the four bilinear corners (autograd of point_sample + the losses,
+ * criterion.py:178-187).  grad_sums [n, 4] f32 (column 3 ignored: sum t has no gradient).
+ */
+int mpf_mask_loss_backward(const void* pred, int pred_dtype, int h, int w, const int32_t* pred_rows,
+                           const uint8_t* gt, int H, int W, const int32_t* gt_rows,
+                           const float* coords, const float* grad_sums, float* grad_pred,
+                           int n, int P, void* stream);
 
 /*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpformer_hip.so")
 ABI_VERSION = 1
 
-MPF_F32, MPF_F64 = 0, 1
+MPF_F32, MPF_F64, MPF_BF16, MPF_U8 = 0, 1, 2, 3
 
 _lib = None
 
@@ -26,6 +26,11 @@ SIGNATURES = {
     "mpf_profile_enable": (_c_int, [_c_int]),
     "mpf_profile_get": (_c_int, [ctypes.c_char_p, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(ctypes.c_double)]),
+    "mpf_point_sample": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
+    "mpf_mask_loss_forward": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp,
+                                       _c_vp, _c_int, _c_int, _c_int, _c_vp]),
+    "mpf_mask_loss_backward": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp,
+                                        _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
     "mpf_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),
 }

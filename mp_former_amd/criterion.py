@@ -12,7 +12,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .point_sample import get_uncertain_point_coords_with_randomness, point_sample
+from .matcher import GTMasks
+from .point_sample import MaskLossSums, map_rows, uncertain_point_coords
 
 
 def dice_loss(inputs, targets, num_masks: float):
@@ -43,6 +44,7 @@ class SetCriterion(nn.Module):
         self.register_buffer("empty_weight", empty_weight)
         self.num_points, self.oversample_ratio = num_points, oversample_ratio
         self.importance_sample_ratio = importance_sample_ratio
+        self._gt = None   # per-forward cache of the batch's byte GT masks
 
     # ---- losses ----------------------------------------------------------------------------------
     def loss_labels(self, outputs, targets, indices, num_masks, tag=None):
@@ -55,20 +57,23 @@ class SetCriterion(nn.Module):
         return {"loss_ce": loss_ce}
 
     def loss_masks(self, outputs, targets, indices, num_masks, tag="loss"):
+        """criterion.py:141-191 on the fused native kernels: the matched prediction maps and the byte
+        ground-truth masks are sampled in place (no gather / float copies)."""
         src_masks = outputs["pred_masks"]
         dev = src_masks.device
-        src_idx = self._get_src_permutation_idx(indices, dev)
-        src_masks = src_masks[src_idx]
-        target_masks = torch.cat([t["masks"][J.to(dev)] for t, (_, J) in zip(targets, indices)]).to(src_masks)
-        src_masks = src_masks[:, None]
-        target_masks = target_masks[:, None]
+        gt = self._gt if self._gt is not None else GTMasks(targets)
+        b_idx, q_idx = self._get_src_permutation_idx(indices, dev)
+        pred_rows = map_rows(src_masks, (b_idx, q_idx))
+        off = torch.tensor(gt.offsets[:-1], dtype=torch.int64)
+        gt_rows = torch.cat([J + off[i] for i, (_, J) in enumerate(indices)]).to(dev).to(torch.int32)
         with torch.no_grad():
-            point_coords = get_uncertain_point_coords_with_randomness(
-                src_masks.float(), self.num_points, self.oversample_ratio, self.importance_sample_ratio, tag)
-            point_labels = point_sample(target_masks.float(), point_coords).squeeze(1)
-        point_logits = point_sample(src_masks.float(), point_coords).squeeze(1)
-        return {"loss_mask": sigmoid_ce_loss(point_logits, point_labels, num_masks),
-                "loss_dice": dice_loss(point_logits, point_labels, num_masks)}
+            coords = uncertain_point_coords(src_masks, pred_rows, self.num_points, self.oversample_ratio,
+                                            self.importance_sample_ratio, tag)
+        sums = MaskLossSums.apply(src_masks, pred_rows, gt.u8, gt_rows, coords)
+        P = self.num_points
+        loss_mask = (sums[:, 0] / P).sum() / num_masks
+        loss_dice = (1 - (2 * sums[:, 1] + 1) / (sums[:, 2] + sums[:, 3] + 1)).sum() / num_masks
+        return {"loss_mask": loss_mask, "loss_dice": loss_dice}
 
     @staticmethod
     def _get_src_permutation_idx(indices, device):
@@ -97,9 +102,10 @@ class SetCriterion(nn.Module):
         num_masks = max(num_masks / ws, 1.0)
 
         # all matchings first: one D2H copy for (1 + #aux) x N cost matrices
-        cost_lists = [self.matcher.cost_matrices(outputs_without_aux, targets, "match")]
+        self._gt = GTMasks(targets)
+        cost_lists = [self.matcher.cost_matrices(outputs_without_aux, targets, "match", self._gt)]
         for i, a in enumerate(aux):
-            cost_lists.append(self.matcher.cost_matrices(a, targets, f"match_{i}"))
+            cost_lists.append(self.matcher.cost_matrices(a, targets, f"match_{i}", self._gt))
         all_indices = self.matcher.solve(cost_lists)
 
         use_dn = bool(self.training and dn_out)
@@ -129,6 +135,7 @@ class SetCriterion(nn.Module):
               all_indices[0], "")
         for i, a in enumerate(aux):
             block(a, dn_out["aux_outputs"][i] if use_dn else None, all_indices[i + 1], f"_{i}")
+        self._gt = None
         if self.dn_no_lb:
             losses = {k: v for k, v in losses.items() if not k.startswith("loss_ce_dn")}
         return losses

@@ -1,0 +1,245 @@
+// Point-sampled mask loss kernels (matcher cost sampling, importance sampling, BCE + dice sums and
+// their backward) for MI355X.
+//
+// Reference semantics: detectron2 point_sample(x, c) = grid_sample(x, 2c-1, bilinear, zeros,
+// align_corners=False), used at mask2former/modeling/criterion.py:164-182 (loss) and
+// mask2former/modeling/matcher.py:122-132 (matching cost); sigmoid_ce_loss / dice_loss at
+// criterion.py:21-65.
+//
+// The reference materialises, per loss call: a gathered copy of the matched prediction maps, a
+// float copy of the full-resolution ground-truth masks, three grid_sample outputs, and the
+// element-wise BCE / sigmoid tensors.  Here one kernel reads the prediction map (f32 or bf16) and
+// the BYTE ground-truth mask directly at the sampled corners and emits four sums per (prediction,
+// target) pair; the backward scatters d(loss)/d(logit) to the four corners with fp32 atomics.
+// All of it is HBM/L2-latency bound gather work: one thread per point, coalesced coordinate reads.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "mpf_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float ld(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float ld(const __hip_bfloat16* p, int64_t i) { return __bfloat162float(p[i]); }
+__device__ __forceinline__ float ld(const uint8_t* p, int64_t i) { return p[i] ? 1.f : 0.f; }
+
+struct Bilin {
+    int x0, y0;
+    float lx, ly;
+};
+
+// align_corners=False: pixel coordinate = c * size - 0.5
+__device__ __forceinline__ Bilin bilin(float cx, float cy, int h, int w)
+{
+    const float x = cx * (float)w - 0.5f, y = cy * (float)h - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    Bilin b;
+    b.x0 = (int)xf; b.y0 = (int)yf; b.lx = x - xf; b.ly = y - yf;
+    return b;
+}
+
+template <typename T>
+__device__ __forceinline__ float sample(const T* map, int h, int w, const Bilin& b)
+{
+    const bool x0v = b.x0 >= 0 && b.x0 < w, x1v = b.x0 + 1 >= 0 && b.x0 + 1 < w;
+    const bool y0v = b.y0 >= 0 && b.y0 < h, y1v = b.y0 + 1 >= 0 && b.y0 + 1 < h;
+    const int64_t o = (int64_t)b.y0 * w + b.x0;
+    const float v00 = (y0v && x0v) ? ld(map, o) : 0.f;
+    const float v01 = (y0v && x1v) ? ld(map, o + 1) : 0.f;
+    const float v10 = (y1v && x0v) ? ld(map, o + w) : 0.f;
+    const float v11 = (y1v && x1v) ? ld(map, o + w + 1) : 0.f;
+    const float hx = 1.f - b.lx, hy = 1.f - b.ly;
+    return hy * (hx * v00 + b.lx * v01) + b.ly * (hx * v10 + b.lx * v11);
+}
+
+// out[i, p] = bilinear(src[rows[i]], coords[coord_rows ? coord_rows[i] : i, p])
+template <typename T>
+__global__ __launch_bounds__(kThreads) void point_sample_kernel(
+    const T* __restrict__ src, int h, int w, const int32_t* __restrict__ rows,
+    const float* __restrict__ coords, const int32_t* __restrict__ coord_rows, float* __restrict__ out, int n, int P)
+{
+    const int i = blockIdx.y;
+    const T* map = src + (int64_t)rows[i] * h * w;
+    const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)(coord_rows ? coord_rows[i] : i) * P;
+    for (int p = blockIdx.x * kThreads + threadIdx.x; p < P; p += gridDim.x * kThreads) {
+        const float2 xy = c[p];
+        out[(int64_t)i * P + p] = sample(map, h, w, bilin(xy.x, xy.y, h, w));
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kThreads / 64; ++k) s += red[k];
+    return s;
+}
+
+// partial[i, chunk, 0..3] = sum over the chunk's points of {bce(x,t), sigmoid(x)*t, sigmoid(x), t}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mask_loss_fwd_kernel(
+    const T* __restrict__ pred, int h, int w, const int32_t* __restrict__ pred_rows,
+    const uint8_t* __restrict__ gt, int H, int W, const int32_t* __restrict__ gt_rows,
+    const float* __restrict__ coords, float* __restrict__ partial, int n, int P, int chunks)
+{
+    __shared__ float red[kThreads / 64];
+    const int i = blockIdx.y, ch = blockIdx.x;
+    const T* pm = pred + (int64_t)pred_rows[i] * h * w;
+    const uint8_t* gm = gt + (int64_t)gt_rows[i] * H * W;
+    const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)i * P;
+    const int per = (P + chunks - 1) / chunks;
+    const int p0 = ch * per, p1 = min(P, p0 + per);
+    float s_bce = 0.f, s_pt = 0.f, s_p = 0.f, s_t = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += kThreads) {
+        const float2 xy = c[p];
+        const float x = sample(pm, h, w, bilin(xy.x, xy.y, h, w));
+        const float t = sample(gm, H, W, bilin(xy.x, xy.y, H, W));
+        const float sg = 1.f / (1.f + __expf(-x));
+        s_bce += fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));   // BCE-with-logits, stable form
+        s_pt += sg * t;
+        s_p += sg;
+        s_t += t;
+    }
+    s_bce = block_sum(s_bce, red);
+    s_pt = block_sum(s_pt, red);
+    s_p = block_sum(s_p, red);
+    s_t = block_sum(s_t, red);
+    if (threadIdx.x == 0) {
+        float* o = partial + ((int64_t)i * chunks + ch) * 4;
+        o[0] = s_bce; o[1] = s_pt; o[2] = s_p; o[3] = s_t;
+    }
+}
+
+// grad_pred (fp32, same [R,h,w] indexing as pred) += d/dx of  g[i,0]*bce + g[i,1]*sum(s*t) + g[i,2]*sum(s)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mask_loss_bwd_kernel(
+    const T* __restrict__ pred, int h, int w, const int32_t* __restrict__ pred_rows,
+    const uint8_t* __restrict__ gt, int H, int W, const int32_t* __restrict__ gt_rows,
+    const float* __restrict__ coords, const float* __restrict__ gsum, float* __restrict__ grad_pred,
+    int n, int P)
+{
+    const int i = blockIdx.y;
+    const int64_t base = (int64_t)pred_rows[i] * h * w;
+    const T* pm = pred + base;
+    float* gp = grad_pred + base;
+    const uint8_t* gm = gt + (int64_t)gt_rows[i] * H * W;
+    const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)i * P;
+    const float g_bce = gsum[4 * i], g_pt = gsum[4 * i + 1], g_p = gsum[4 * i + 2];
+    for (int p = blockIdx.x * kThreads + threadIdx.x; p < P; p += gridDim.x * kThreads) {
+        const float2 xy = c[p];
+        const Bilin b = bilin(xy.x, xy.y, h, w);
+        const float x = sample(pm, h, w, b);
+        const float t = sample(gm, H, W, bilin(xy.x, xy.y, H, W));
+        const float sg = 1.f / (1.f + __expf(-x));
+        const float dx = g_bce * (sg - t) + (g_pt * t + g_p) * sg * (1.f - sg);
+        const bool x0v = b.x0 >= 0 && b.x0 < w, x1v = b.x0 + 1 >= 0 && b.x0 + 1 < w;
+        const bool y0v = b.y0 >= 0 && b.y0 < h, y1v = b.y0 + 1 >= 0 && b.y0 + 1 < h;
+        const int64_t o = (int64_t)b.y0 * w + b.x0;
+        const float hx = 1.f - b.lx, hy = 1.f - b.ly;
+        if (y0v && x0v) atomicAdd(gp + o, dx * hy * hx);
+        if (y0v && x1v) atomicAdd(gp + o + 1, dx * hy * b.lx);
+        if (y1v && x0v) atomicAdd(gp + o + w, dx * b.ly * hx);
+        if (y1v && x1v) atomicAdd(gp + o + w + 1, dx * b.ly * b.lx);
+    }
+}
+
+int check_common(const void* a, const void* b, const void* c, const void* d, int n, int P, int h, int w)
+{
+    if (!a || !b || !c || !d) return mpf::fail(MPF_E_NULL, "point-sample: NULL buffer");
+    if (n < 0 || P <= 0 || h <= 0 || w <= 0) return mpf::fail(MPF_E_SHAPE, "point-sample: bad sizes");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mpf_point_sample(const void* src, int src_dtype, int h, int w, const int32_t* rows,
+                                const float* coords, const int32_t* coord_rows, float* out, int n, int P,
+                                void* stream)
+{
+    if (int e = check_common(src, rows, coords, out, n, P, h, w)) return e;
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((P + kThreads - 1) / kThreads, n);
+    mpf::prof_begin(st);
+    if (src_dtype == MPF_F32) {
+        mpf::set_kernel("point_sample_kernel<float>");
+        hipLaunchKernelGGL(point_sample_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)src, h, w,
+                           rows, coords, coord_rows, out, n, P);
+    } else if (src_dtype == MPF_BF16) {
+        mpf::set_kernel("point_sample_kernel<bf16>");
+        hipLaunchKernelGGL(point_sample_kernel<__hip_bfloat16>, grid, dim3(kThreads), 0, st,
+                           (const __hip_bfloat16*)src, h, w, rows, coords, coord_rows, out, n, P);
+    } else if (src_dtype == MPF_U8) {
+        mpf::set_kernel("point_sample_kernel<u8>");
+        hipLaunchKernelGGL(point_sample_kernel<uint8_t>, grid, dim3(kThreads), 0, st, (const uint8_t*)src, h, w,
+                           rows, coords, coord_rows, out, n, P);
+    } else {
+        return mpf::fail(MPF_E_DTYPE, "mpf_point_sample: dtype must be MPF_F32, MPF_BF16 or MPF_U8");
+    }
+    mpf::prof_end(mpf_last_kernel(), st, (double)n * P * (8.0 + 4.0 + 16.0));
+    return mpf::check(hipGetLastError(), "mpf_point_sample");
+}
+
+extern "C" int mpf_mask_loss_forward(const void* pred, int pred_dtype, int h, int w, const int32_t* pred_rows,
+                                     const uint8_t* gt, int H, int W, const int32_t* gt_rows,
+                                     const float* coords, float* partial, int n, int P, int chunks,
+                                     void* stream)
+{
+    if (int e = check_common(pred, pred_rows, coords, partial, n, P, h, w)) return e;
+    if (!gt || !gt_rows) return mpf::fail(MPF_E_NULL, "mask_loss_forward: NULL buffer");
+    if (H <= 0 || W <= 0 || chunks <= 0) return mpf::fail(MPF_E_SHAPE, "mask_loss_forward: bad sizes");
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(chunks, n);
+    mpf::prof_begin(st);
+    if (pred_dtype == MPF_F32) {
+        mpf::set_kernel("mask_loss_fwd_kernel<float>");
+        hipLaunchKernelGGL(mask_loss_fwd_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)pred, h, w,
+                           pred_rows, gt, H, W, gt_rows, coords, partial, n, P, chunks);
+    } else if (pred_dtype == MPF_BF16) {
+        mpf::set_kernel("mask_loss_fwd_kernel<bf16>");
+        hipLaunchKernelGGL(mask_loss_fwd_kernel<__hip_bfloat16>, grid, dim3(kThreads), 0, st,
+                           (const __hip_bfloat16*)pred, h, w, pred_rows, gt, H, W, gt_rows, coords, partial, n, P, chunks);
+    } else {
+        return mpf::fail(MPF_E_DTYPE, "mpf_mask_loss_forward: pred dtype must be MPF_F32 or MPF_BF16");
+    }
+    mpf::prof_end(mpf_last_kernel(), st, (double)n * P * (8.0 + 16.0 + 4.0));
+    return mpf::check(hipGetLastError(), "mpf_mask_loss_forward");
+}
+
+extern "C" int mpf_mask_loss_backward(const void* pred, int pred_dtype, int h, int w, const int32_t* pred_rows,
+                                      const uint8_t* gt, int H, int W, const int32_t* gt_rows,
+                                      const float* coords, const float* grad_sums, float* grad_pred,
+                                      int n, int P, void* stream)
+{
+    if (int e = check_common(pred, pred_rows, coords, grad_pred, n, P, h, w)) return e;
+    if (!gt || !gt_rows || !grad_sums) return mpf::fail(MPF_E_NULL, "mask_loss_backward: NULL buffer");
+    if (H <= 0 || W <= 0) return mpf::fail(MPF_E_SHAPE, "mask_loss_backward: bad sizes");
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((P + kThreads * 4 - 1) / (kThreads * 4), n);
+    mpf::prof_begin(st);
+    if (pred_dtype == MPF_F32) {
+        mpf::set_kernel("mask_loss_bwd_kernel<float>");
+        hipLaunchKernelGGL(mask_loss_bwd_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)pred, h, w,
+                           pred_rows, gt, H, W, gt_rows, coords, grad_sums, grad_pred, n, P);
+    } else if (pred_dtype == MPF_BF16) {
+        mpf::set_kernel("mask_loss_bwd_kernel<bf16>");
+        hipLaunchKernelGGL(mask_loss_bwd_kernel<__hip_bfloat16>, grid, dim3(kThreads), 0, st,
+                           (const __hip_bfloat16*)pred, h, w, pred_rows, gt, H, W, gt_rows, coords, grad_sums,
+                           grad_pred, n, P);
+    } else {
+        return mpf::fail(MPF_E_DTYPE, "mpf_mask_loss_backward: pred dtype must be MPF_F32 or MPF_BF16");
+    }
+    mpf::prof_end(mpf_last_kernel(), st, (double)n * P * (8.0 + 16.0 + 4.0 + 32.0));
+    return mpf::check(hipGetLastError(), "mpf_mask_loss_backward");
+}
