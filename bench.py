@@ -78,8 +78,7 @@ class TrainModel(torch.nn.Module):
     def forward(self, images, targets):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             feats = self.backbone(images.contiguous(memory_format=torch.channels_last))
-            losses, _ = self.head(feats, targets)
-        return sum(losses.values())
+            return self.head.total_loss(feats, targets)
 
 
 def build_optimizer(model):

@@ -96,11 +96,13 @@ const char* mpf_last_kernel(void);
  * mask2former/modeling/matcher.py:122-132 (matching cost: one point set per image shared by all of
  * its masks -> coord_rows[i] = image of row i) and mask2former/modeling/criterion.py:164-170
  * (importance sampling of the loss points: coord_rows = NULL, i.e. one point set per row).
- *   src   [R, h, w] maps of dtype MPF_F32 / MPF_BF16 / MPF_U8 (bool ground-truth masks, 0/1 bytes)
- *   rows  [n] int32 map index per output row        coords [C, P, 2] f32 (x, y) in [0,1]
- *   coord_rows [n] int32 or NULL (= identity)       out [n, P] f32, fully overwritten
+ *   src   base pointer of dense [h, w] maps of dtype MPF_F32 / MPF_BF16 / MPF_U8 (bool ground-truth
+ *         masks, 0/1 bytes); rows [n] int64 = ELEMENT offset of each row's map from `src` (maps of
+ *         several tensors can be addressed in one launch from a common base)
+ *   coords [C, P, 2] f32 (x, y) in [0,1]            coord_rows [n] int32 or NULL (= identity)
+ *   out   [n, P] f32, fully overwritten
  */
-int mpf_point_sample(const void* src, int src_dtype, int h, int w, const int32_t* rows,
+int mpf_point_sample(const void* src, int src_dtype, int h, int w, const int64_t* rows,
                      const float* coords, const int32_t* coord_rows, float* out, int n, int P, void* stream);
 
 /*
@@ -112,23 +114,47 @@ int mpf_point_sample(const void* src, int src_dtype, int h, int w, const int32_t
  * sigmoid_ce_loss = mean_p BCE, dice_loss = 1 - (2*sum(s*t)+1)/(sum(s)+sum(t)+1)).  Replaces the
  * gather of src_masks, the float copy of the GT masks, two point_sample calls and the element-wise
  * loss tensors of the reference.
- *   pred [R, h, w] MPF_F32 / MPF_BF16      gt [Rt, H, W] bytes (0/1)
- *   coords [n, P, 2] f32                   partial [n, chunks, 4] f32, fully overwritten
+ *   pred  base pointer, MPF_F32 / MPF_BF16; pred_rows [n] int64 element offsets of the [h,w] maps
+ *   gt [Rt, H, W] bytes (0/1), gt_rows [n] int32    coords [n, P, 2] f32
+ *   partial [n, chunks, 4] f32, fully overwritten
  */
-int mpf_mask_loss_forward(const void* pred, int pred_dtype, int h, int w, const int32_t* pred_rows,
+int mpf_mask_loss_forward(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows,
                           const uint8_t* gt, int H, int W, const int32_t* gt_rows,
                           const float* coords, float* partial, int n, int P, int chunks, void* stream);
 
 /*
- * Backward of the above wrt pred: grad_pred [R, h, w] f32 (caller zero-fills; accumulated with
- * atomics) += d/dx of  grad_sums[i,0]*sum BCE + grad_sums[i,1]*sum(s*t) + grad_sums[i,2]*sum(s),
- * scattered to the four bilinear corners (autograd of point_sample + the losses,
- * criterion.py:178-187).  grad_sums [n, 4] f32 (column 3 ignored: sum t has no gradient).
+ * Backward of the above wrt pred: the f32 map at grad_pred + grad_offs[i] (caller zero-fills;
+ * accumulated with atomics) += d/dx of  grad_sums[i,0]*sum BCE + grad_sums[i,1]*sum(s*t) +
+ * grad_sums[i,2]*sum(s), scattered to the four bilinear corners (autograd of point_sample + the
+ * losses, criterion.py:178-187).  grad_sums [n, 4] f32 (column 3 ignored: sum t has no gradient).
  */
-int mpf_mask_loss_backward(const void* pred, int pred_dtype, int h, int w, const int32_t* pred_rows,
+int mpf_mask_loss_backward(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows,
                            const uint8_t* gt, int H, int W, const int32_t* gt_rows,
                            const float* coords, const float* grad_sums, float* grad_pred,
-                           int n, int P, void* stream);
+                           const int64_t* grad_offs, int n, int P, void* stream);
+
+/*
+ * Importance selection of the loss points (detectron2 get_uncertain_point_coords_with_randomness
+ * with uncertainty = -|logit|, mask2former/modeling/criterion.py:73-87,164-170): for each of the n
+ * rows keep the k entries of vals[row, 0:M] with the smallest |value| and write their coordinates to
+ * coords_out[row, 0:k] (P_out >= k points per output row; the caller fills [k:P_out] with fresh
+ * uniform points).  Replaces torch.topk + gather; ties at the threshold are broken by index.
+ */
+int mpf_select_uncertain(const float* vals, const float* coords_in, float* coords_out,
+                         int n, int M, int k, int P_out, void* stream);
+
+/*
+ * Matching cost, mask + dice part (mask2former/modeling/matcher.py:15-62,122-148), for n_rows
+ * (layer, image, query) prediction maps against the ground-truth masks of their image:
+ *   cost[row, t] = w_mask*(sum softplus(x) - sum x*t)/P + w_dice*(1 - (2 sum s*t + 1)/(sum s + sum t + 1))
+ * x = prediction sampled at coords[coord_rows[row]] on the fly, t = tsamp[t_first[row] + t, :]
+ * (ground-truth masks pre-sampled at the same points with mpf_point_sample), t < t_count[row].
+ *   cost [n_rows, Tmax] f32; entries t >= t_count[row] are left untouched.
+ */
+int mpf_match_cost(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_offs,
+                   const float* coords, const int32_t* coord_rows, const float* tsamp,
+                   const int32_t* t_first, const int32_t* t_count, float* cost,
+                   int n_rows, int Tmax, int P, float w_mask, float w_dice, void* stream);
 
 /*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP

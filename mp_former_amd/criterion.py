@@ -3,30 +3,24 @@
 same `forward(outputs, targets) -> dict` with the reference's 6 x (1 + #aux) keys, same `weight_dict`
 attribute read by the caller (maskformer_model.py:226-231).
 
-Scheduling difference (results identical for identical random draws): the Hungarian matchings of the
-final and all auxiliary outputs are computed FIRST, with a single device->host copy of all cost
-matrices, then the losses; the reference interleaves matcher and losses per output and blocks on a
-`.cpu()` per image per output (matcher.py:149) plus `num_masks.item()` (criterion.py:237).
+Scheduling (results identical for identical random draws): the reference walks the 10 outputs one
+by one — matcher, CE, point-sampled BCE/dice, then the same for the MP (`_dn`) queries — with a
+blocking `.cpu()` per image per output (matcher.py:149) and ~100 small kernels per output.  Here a
+step is three batched stages over ALL outputs at once:
+  1. matching: native GT sampling + native mask/dice cost + one D2H copy + SciPy (matcher.py);
+  2. mask losses: one importance-sampling pass (native sampling + native radix selection) and one
+     fused native BCE/dice kernel over every matched / MP (prediction, target) pair of every output;
+     its backward is one scatter kernel;
+  3. class losses: one batched log-softmax over all outputs.
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _rng
 from .matcher import GTMasks
-from .point_sample import MaskLossSums, map_rows, uncertain_point_coords
-
-
-def dice_loss(inputs, targets, num_masks: float):
-    inputs = inputs.sigmoid().flatten(1)
-    numerator = 2 * (inputs * targets).sum(-1)
-    denominator = inputs.sum(-1) + targets.sum(-1)
-    loss = 1 - (numerator + 1) / (denominator + 1)
-    return loss.sum() / num_masks
-
-
-def sigmoid_ce_loss(inputs, targets, num_masks: float):
-    loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
-    return loss.mean(1).sum() / num_masks
+from .point_sample import MapSet, MaskLossSums, point_sample_offsets, select_uncertain
 
 
 def _world_size():
@@ -44,101 +38,158 @@ class SetCriterion(nn.Module):
         self.register_buffer("empty_weight", empty_weight)
         self.num_points, self.oversample_ratio = num_points, oversample_ratio
         self.importance_sample_ratio = importance_sample_ratio
-        self._gt = None   # per-forward cache of the batch's byte GT masks
+        for loss in losses:
+            assert loss in ("labels", "masks"), f"do you really want to compute {loss} loss?"
 
-    # ---- losses ----------------------------------------------------------------------------------
-    def loss_labels(self, outputs, targets, indices, num_masks, tag=None):
-        src_logits = outputs["pred_logits"].float()
-        idx = self._get_src_permutation_idx(indices, src_logits.device)
-        target_classes_o = torch.cat([t["labels"][J.to(t["labels"].device)] for t, (_, J) in zip(targets, indices)])
-        target_classes = torch.full(src_logits.shape[:2], self.num_classes, dtype=torch.int64, device=src_logits.device)
-        target_classes[idx] = target_classes_o
-        loss_ce = F.cross_entropy(src_logits.transpose(1, 2), target_classes, self.empty_weight)
-        return {"loss_ce": loss_ce}
+    # ---------------------------------------------------------------------------------------------
+    def _class_losses(self, logits, target_classes):
+        """logits [L,N,Q,K+1], target_classes [L,N,Q] (or [N,Q], shared) -> per-output weighted CE [L]
+        (F.cross_entropy with class weights = sum w_y nll / sum w_y, criterion.py:123-139)."""
+        L = logits.shape[0]
+        if target_classes.dim() == 2:
+            target_classes = target_classes[None].expand(L, -1, -1)
+        lsm = F.log_softmax(logits.float(), -1)
+        nll = -torch.gather(lsm, 3, target_classes[..., None]).squeeze(3)
+        w = self.empty_weight[target_classes]
+        return (nll * w).flatten(1).sum(1) / w.flatten(1).sum(1)
 
-    def loss_masks(self, outputs, targets, indices, num_masks, tag="loss"):
-        """criterion.py:141-191 on the fused native kernels: the matched prediction maps and the byte
-        ground-truth masks are sampled in place (no gather / float copies)."""
-        src_masks = outputs["pred_masks"]
-        dev = src_masks.device
-        gt = self._gt if self._gt is not None else GTMasks(targets)
-        b_idx, q_idx = self._get_src_permutation_idx(indices, dev)
-        pred_rows = map_rows(src_masks, (b_idx, q_idx))
-        off = torch.tensor(gt.offsets[:-1], dtype=torch.int64)
-        gt_rows = torch.cat([J + off[i] for i, (_, J) in enumerate(indices)]).to(dev).to(torch.int32)
-        with torch.no_grad():
-            coords = uncertain_point_coords(src_masks, pred_rows, self.num_points, self.oversample_ratio,
-                                            self.importance_sample_ratio, tag)
-        sums = MaskLossSums.apply(src_masks, pred_rows, gt.u8, gt_rows, coords)
-        P = self.num_points
-        loss_mask = (sums[:, 0] / P).sum() / num_masks
-        loss_dice = (1 - (2 * sums[:, 1] + 1) / (sums[:, 2] + sums[:, 3] + 1)).sum() / num_masks
-        return {"loss_mask": loss_mask, "loss_dice": loss_dice}
-
-    @staticmethod
-    def _get_src_permutation_idx(indices, device):
-        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
-        src_idx = torch.cat([src for (src, _) in indices])
-        return batch_idx.to(device), src_idx.to(device)
-
-    def get_loss(self, loss, outputs, targets, indices, num_masks, tag):
-        loss_map = {"labels": self.loss_labels, "masks": self.loss_masks}
-        assert loss in loss_map, f"do you really want to compute {loss} loss?"
-        return loss_map[loss](outputs, targets, indices, num_masks, tag)
-
-    # ---- forward ---------------------------------------------------------------------------------
     def forward(self, outputs, targets):
-        outputs_without_aux = {k: v for k, v in outputs.items() if k != "aux_outputs" and k != "dn_out"}
         dn_out = outputs["dn_out"]
-        aux = outputs.get("aux_outputs", [])
-        device = outputs["pred_logits"].device
-        losses = {}
+        outs = [{"pred_logits": outputs["pred_logits"], "pred_masks": outputs["pred_masks"]}] + list(outputs.get("aux_outputs", []))
+        L = len(outs)
+        suffixes = [""] + [f"_{i}" for i in range(L - 1)]
+        N, Q = outs[0]["pred_logits"].shape[:2]
+        dev = outs[0]["pred_logits"].device
+        K = self.num_classes
+        P = self.num_points
         num_masks = sum(len(t["labels"]) for t in targets)
         ws = _world_size()
         if ws > 1:   # criterion.py:235-237
-            nm = torch.as_tensor([num_masks], dtype=torch.float, device=device)
+            nm = torch.as_tensor([num_masks], dtype=torch.float, device=dev)
             torch.distributed.all_reduce(nm)
             num_masks = nm.item()
         num_masks = max(num_masks / ws, 1.0)
 
-        # all matchings first: one D2H copy for (1 + #aux) x N cost matrices
-        self._gt = GTMasks(targets)
-        cost_lists = [self.matcher.cost_matrices(outputs_without_aux, targets, "match", self._gt)]
-        for i, a in enumerate(aux):
-            cost_lists.append(self.matcher.cost_matrices(a, targets, f"match_{i}", self._gt))
-        all_indices = self.matcher.solve(cost_lists)
-
         use_dn = bool(self.training and dn_out)
+        dn_outs = []
         if use_dn:
-            dn_args = dn_out["dn_args"]
-            scalar = dn_args["pad_size"] // dn_args["max_num"]
-            dn_indices = []
-            for t in targets:    # criterion.py:249-258: slot j of every DN group <-> GT j
-                n = len(t["labels"])
-                tt = torch.arange(n).unsqueeze(0).repeat(scalar, 1)
-                oi = (torch.arange(scalar) * dn_args["max_num"]).unsqueeze(1) + tt
-                dn_indices.append((oi.flatten().long(), tt.flatten().long()))
+            dn_outs = [{"pred_logits": dn_out["pred_logits"], "pred_masks": dn_out["pred_masks"]}] + list(dn_out["aux_outputs"])
+            max_num = dn_out["dn_args"]["max_num"]
+            scalar = dn_out["dn_args"]["pad_size"] // max_num
+            pad = dn_out["dn_args"]["pad_size"]
 
-        def block(out, dn, indices, suffix):
-            for loss in self.losses:
-                l_dict = self.get_loss(loss, out, targets, indices, num_masks, "loss" + suffix)
-                losses.update({k + suffix: v for k, v in l_dict.items()})
+        gt = GTMasks(targets)
+        # every prediction-map tensor of the step in one address space: [main_0..main_{L-1}, dn_0..dn_{L-1}]
+        map_tensors = [o["pred_masks"] for o in outs] + [o["pred_masks"] for o in dn_outs]
+        ms = MapSet(map_tensors)
+
+        # ---- stage 1: all matchings -----------------------------------------------------------------
+        indices = self.matcher.match_many(outs, targets, gt=gt, tags=["match" + s for s in suffixes],
+                                          mapset=ms, map_index=list(range(L)))
+
+        # ---- pair lists (host): order = for each output: matched pairs, then MP pairs ----------------
+        firsts = gt.offsets
+        ti, bi, qi, gr, gid, over_parts, rand_parts = [], [], [], [], [], [], []
+        num_uncertain = int(self.importance_sample_ratio * P)
+        num_sampled = int(P * self.oversample_ratio)
+        tc_main = np.full((L, N, Q), K, dtype=np.int64)
+        if gt.total:   # one D2H copy for all labels (the stream was just drained by the matcher's copy)
+            lab = torch.cat([t["labels"] for t in targets]).cpu().numpy()
+            labels_host = [lab[firsts[b]:firsts[b + 1]] for b in range(N)]
+        else:
+            labels_host = [np.zeros(0, np.int64)] * N
+        for l in range(L):
+            n_l = 0
+            for b, (src, tgt) in enumerate(indices[l]):
+                src, tgt = src.numpy(), tgt.numpy()
+                ti.append(np.full(len(src), l)); bi.append(np.full(len(src), b)); qi.append(src)
+                gr.append(firsts[b] + tgt); gid.append(np.full(len(src), l))
+                tc_main[l, b, src] = labels_host[b][tgt]
+                n_l += len(src)
+            over_parts.append(("loss" + suffixes[l] + "_over", (n_l, num_sampled, 2)))
+            rand_parts.append(("loss" + suffixes[l] + "_rand", (n_l, P - num_uncertain, 2)))
             if use_dn:
-                for loss in self.losses:
-                    l_dict = self.get_loss(loss, dn, targets, dn_indices, num_masks * scalar, "loss_dn" + suffix)
-                    losses.update({k + "_dn" + suffix: v for k, v in l_dict.items()})
-            else:
-                z = torch.as_tensor(0.0, device=device)
-                losses.update({"loss_mask_dn" + suffix: z, "loss_dice_dn" + suffix: z, "loss_ce_dn" + suffix: z})
+                n_d = 0
+                for b in range(N):
+                    T = gt.counts[b]
+                    j = np.tile(np.arange(T), scalar)
+                    slot = np.repeat(np.arange(scalar) * max_num, T) + j
+                    ti.append(np.full(len(j), L + l)); bi.append(np.full(len(j), b)); qi.append(slot)
+                    gr.append(firsts[b] + j); gid.append(np.full(len(j), L + l))
+                    n_d += len(j)
+                over_parts.append(("loss_dn" + suffixes[l] + "_over", (n_d, num_sampled, 2)))
+                rand_parts.append(("loss_dn" + suffixes[l] + "_rand", (n_d, P - num_uncertain, 2)))
+        cat = lambda xs: np.concatenate(xs).astype(np.int64) if xs else np.zeros(0, np.int64)  # noqa: E731
+        ti, bi, qi, gr, gid = cat(ti), cat(bi), cat(qi), cat(gr), cat(gid)
+        n_pairs = len(ti)
+        G = 2 * L if use_dn else L
+        losses = {}
 
-        block(outputs_without_aux, {k: v for k, v in dn_out.items() if k != "aux_outputs"} if use_dn else None,
-              all_indices[0], "")
-        for i, a in enumerate(aux):
-            block(a, dn_out["aux_outputs"][i] if use_dn else None, all_indices[i + 1], f"_{i}")
-        self._gt = None
+        # ---- stage 2: mask losses ----------------------------------------------------------------------
+        if "masks" in self.losses:
+            if n_pairs:
+                up = torch.from_numpy(np.concatenate([ms.offsets(ti, bi, qi), ms.grad_offsets(ti, bi, qi), gid])).to(dev, non_blocking=True)
+                pred_offs, grad_offs, gid_d = up[:n_pairs], up[n_pairs:2 * n_pairs], up[2 * n_pairs:]
+                gt_rows = torch.from_numpy(gr.astype(np.int32)).to(dev, non_blocking=True)
+                with torch.no_grad():   # criterion.py:162-176: point selection carries no gradient
+                    coords_over = _rng.rand_cat(over_parts, dev)
+                    logits_over = point_sample_offsets(ms.base_ptr, ms.dtype, ms.h, ms.w, pred_offs, coords_over, None, dev)
+                    coords = select_uncertain(logits_over, coords_over, num_uncertain, P)
+                    if P - num_uncertain > 0:
+                        coords[:, num_uncertain:] = _rng.rand_cat(rand_parts, dev)
+                sums = MaskLossSums.apply(ms, pred_offs, grad_offs, gt.u8, gt_rows, coords, *map_tensors)
+                per_mask = sums[:, 0] / P                                                  # mean_p BCE (criterion.py:48-65)
+                per_dice = 1 - (2 * sums[:, 1] + 1) / (sums[:, 2] + sums[:, 3] + 1)        # criterion.py:21-40
+                z = torch.zeros(G, dtype=torch.float32, device=dev)
+                norm = torch.full((G,), float(num_masks), device=dev)
+                if use_dn:
+                    norm[L:] = float(num_masks * scalar)
+                g_mask = z.index_add(0, gid_d, per_mask) / norm
+                g_dice = z.index_add(0, gid_d, per_dice) / norm
+            else:
+                # no ground truth anywhere: sums over empty sets (still consume the draws for RNG parity)
+                _rng.rand_cat(over_parts, dev)
+                _rng.rand_cat(rand_parts, dev)
+                zero = sum(t.sum() * 0.0 for t in map_tensors).float()
+                g_mask = g_dice = zero.expand(G)
+            for l in range(L):
+                losses["loss_mask" + suffixes[l]] = g_mask[l]
+                losses["loss_dice" + suffixes[l]] = g_dice[l]
+                if use_dn:
+                    losses["loss_mask_dn" + suffixes[l]] = g_mask[L + l]
+                    losses["loss_dice_dn" + suffixes[l]] = g_dice[L + l]
+
+        # ---- stage 3: class losses ---------------------------------------------------------------------
+        if "labels" in self.losses:
+            ce = self._class_losses(torch.stack([o["pred_logits"] for o in outs]),
+                                    torch.from_numpy(tc_main).to(dev, non_blocking=True))
+            for l in range(L):
+                losses["loss_ce" + suffixes[l]] = ce[l]
+            if use_dn:
+                tc_dn = np.full((N, pad), K, dtype=np.int64)     # criterion.py:249-258: slot j of every group <-> GT j
+                for b in range(N):
+                    T = gt.counts[b]
+                    for s in range(scalar):
+                        tc_dn[b, s * max_num:s * max_num + T] = labels_host[b]
+                ce_dn = self._class_losses(torch.stack([o["pred_logits"] for o in dn_outs]),
+                                           torch.from_numpy(tc_dn).to(dev, non_blocking=True))
+                for l in range(L):
+                    losses["loss_ce_dn" + suffixes[l]] = ce_dn[l]
+        if not use_dn:
+            z = torch.as_tensor(0.0, device=dev)
+            for s in suffixes:
+                losses.update({"loss_mask_dn" + s: z, "loss_dice_dn" + s: z, "loss_ce_dn" + s: z})
         if self.dn_no_lb:
             losses = {k: v for k, v in losses.items() if not k.startswith("loss_ce_dn")}
         return losses
+
+    def weighted_total(self, losses):
+        """sum_k weight_dict[k] * losses[k] in two kernels (the caller-side loop of
+        maskformer_model.py:226-231 costs one multiply and one add per key)."""
+        keys = [k for k in losses if k in self.weight_dict]
+        vec = torch.stack([losses[k] for k in keys])
+        w = torch.tensor([self.weight_dict[k] for k in keys], dtype=vec.dtype, device=vec.device)
+        return (vec * w).sum()
 
     def __repr__(self):
         body = [f"matcher: {self.matcher.__repr__(_repr_indent=8)}", f"losses: {self.losses}",

@@ -55,14 +55,14 @@ __device__ __forceinline__ float sample(const T* map, int h, int w, const Bilin&
     return hy * (hx * v00 + b.lx * v01) + b.ly * (hx * v10 + b.lx * v11);
 }
 
-// out[i, p] = bilinear(src[rows[i]], coords[coord_rows ? coord_rows[i] : i, p])
+// out[i, p] = bilinear(map at src + offs[i], coords[coord_rows ? coord_rows[i] : i, p])
 template <typename T>
 __global__ __launch_bounds__(kThreads) void point_sample_kernel(
-    const T* __restrict__ src, int h, int w, const int32_t* __restrict__ rows,
+    const T* __restrict__ src, int h, int w, const int64_t* __restrict__ offs,
     const float* __restrict__ coords, const int32_t* __restrict__ coord_rows, float* __restrict__ out, int n, int P)
 {
     const int i = blockIdx.y;
-    const T* map = src + (int64_t)rows[i] * h * w;
+    const T* map = src + offs[i];
     const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)(coord_rows ? coord_rows[i] : i) * P;
     for (int p = blockIdx.x * kThreads + threadIdx.x; p < P; p += gridDim.x * kThreads) {
         const float2 xy = c[p];
@@ -87,13 +87,13 @@ __device__ __forceinline__ float block_sum(float v, float* red)
 // partial[i, chunk, 0..3] = sum over the chunk's points of {bce(x,t), sigmoid(x)*t, sigmoid(x), t}
 template <typename T>
 __global__ __launch_bounds__(kThreads) void mask_loss_fwd_kernel(
-    const T* __restrict__ pred, int h, int w, const int32_t* __restrict__ pred_rows,
+    const T* __restrict__ pred, int h, int w, const int64_t* __restrict__ pred_offs,
     const uint8_t* __restrict__ gt, int H, int W, const int32_t* __restrict__ gt_rows,
     const float* __restrict__ coords, float* __restrict__ partial, int n, int P, int chunks)
 {
     __shared__ float red[kThreads / 64];
     const int i = blockIdx.y, ch = blockIdx.x;
-    const T* pm = pred + (int64_t)pred_rows[i] * h * w;
+    const T* pm = pred + pred_offs[i];
     const uint8_t* gm = gt + (int64_t)gt_rows[i] * H * W;
     const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)i * P;
     const int per = (P + chunks - 1) / chunks;
@@ -119,18 +119,17 @@ __global__ __launch_bounds__(kThreads) void mask_loss_fwd_kernel(
     }
 }
 
-// grad_pred (fp32, same [R,h,w] indexing as pred) += d/dx of  g[i,0]*bce + g[i,1]*sum(s*t) + g[i,2]*sum(s)
+// grad map (fp32, at grad_pred + grad_offs[i]) += d/dx of  g[i,0]*bce + g[i,1]*sum(s*t) + g[i,2]*sum(s)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void mask_loss_bwd_kernel(
-    const T* __restrict__ pred, int h, int w, const int32_t* __restrict__ pred_rows,
+    const T* __restrict__ pred, int h, int w, const int64_t* __restrict__ pred_offs,
     const uint8_t* __restrict__ gt, int H, int W, const int32_t* __restrict__ gt_rows,
     const float* __restrict__ coords, const float* __restrict__ gsum, float* __restrict__ grad_pred,
-    int n, int P)
+    const int64_t* __restrict__ grad_offs, int n, int P)
 {
     const int i = blockIdx.y;
-    const int64_t base = (int64_t)pred_rows[i] * h * w;
-    const T* pm = pred + base;
-    float* gp = grad_pred + base;
+    const T* pm = pred + pred_offs[i];
+    float* gp = grad_pred + grad_offs[i];
     const uint8_t* gm = gt + (int64_t)gt_rows[i] * H * W;
     const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)i * P;
     const float g_bce = gsum[4 * i], g_pt = gsum[4 * i + 1], g_p = gsum[4 * i + 2];
@@ -161,7 +160,7 @@ int check_common(const void* a, const void* b, const void* c, const void* d, int
 
 }  // namespace
 
-extern "C" int mpf_point_sample(const void* src, int src_dtype, int h, int w, const int32_t* rows,
+extern "C" int mpf_point_sample(const void* src, int src_dtype, int h, int w, const int64_t* rows,
                                 const float* coords, const int32_t* coord_rows, float* out, int n, int P,
                                 void* stream)
 {
@@ -189,7 +188,7 @@ extern "C" int mpf_point_sample(const void* src, int src_dtype, int h, int w, co
     return mpf::check(hipGetLastError(), "mpf_point_sample");
 }
 
-extern "C" int mpf_mask_loss_forward(const void* pred, int pred_dtype, int h, int w, const int32_t* pred_rows,
+extern "C" int mpf_mask_loss_forward(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows,
                                      const uint8_t* gt, int H, int W, const int32_t* gt_rows,
                                      const float* coords, float* partial, int n, int P, int chunks,
                                      void* stream)
@@ -216,13 +215,13 @@ extern "C" int mpf_mask_loss_forward(const void* pred, int pred_dtype, int h, in
     return mpf::check(hipGetLastError(), "mpf_mask_loss_forward");
 }
 
-extern "C" int mpf_mask_loss_backward(const void* pred, int pred_dtype, int h, int w, const int32_t* pred_rows,
+extern "C" int mpf_mask_loss_backward(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows,
                                       const uint8_t* gt, int H, int W, const int32_t* gt_rows,
                                       const float* coords, const float* grad_sums, float* grad_pred,
-                                      int n, int P, void* stream)
+                                      const int64_t* grad_offs, int n, int P, void* stream)
 {
     if (int e = check_common(pred, pred_rows, coords, grad_pred, n, P, h, w)) return e;
-    if (!gt || !gt_rows || !grad_sums) return mpf::fail(MPF_E_NULL, "mask_loss_backward: NULL buffer");
+    if (!gt || !gt_rows || !grad_sums || !grad_offs) return mpf::fail(MPF_E_NULL, "mask_loss_backward: NULL buffer");
     if (H <= 0 || W <= 0) return mpf::fail(MPF_E_SHAPE, "mask_loss_backward: bad sizes");
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -231,15 +230,213 @@ extern "C" int mpf_mask_loss_backward(const void* pred, int pred_dtype, int h, i
     if (pred_dtype == MPF_F32) {
         mpf::set_kernel("mask_loss_bwd_kernel<float>");
         hipLaunchKernelGGL(mask_loss_bwd_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)pred, h, w,
-                           pred_rows, gt, H, W, gt_rows, coords, grad_sums, grad_pred, n, P);
+                           pred_rows, gt, H, W, gt_rows, coords, grad_sums, grad_pred, grad_offs, n, P);
     } else if (pred_dtype == MPF_BF16) {
         mpf::set_kernel("mask_loss_bwd_kernel<bf16>");
         hipLaunchKernelGGL(mask_loss_bwd_kernel<__hip_bfloat16>, grid, dim3(kThreads), 0, st,
                            (const __hip_bfloat16*)pred, h, w, pred_rows, gt, H, W, gt_rows, coords, grad_sums,
-                           grad_pred, n, P);
+                           grad_pred, grad_offs, n, P);
     } else {
         return mpf::fail(MPF_E_DTYPE, "mpf_mask_loss_backward: pred dtype must be MPF_F32 or MPF_BF16");
     }
     mpf::prof_end(mpf_last_kernel(), st, (double)n * P * (8.0 + 16.0 + 4.0 + 32.0));
     return mpf::check(hipGetLastError(), "mpf_mask_loss_backward");
+}
+
+// ================================================================================================
+// Importance selection: per row keep the k points with the SMALLEST |logit| (= the most uncertain,
+// uncertainty = -|logit|, criterion.py:73-87 + detectron2 get_uncertain_point_coords_with_randomness)
+// and emit their coordinates.  MSB-first 8-bit radix select on the bit pattern of |x| (monotonic for
+// non-negative floats) with an LDS histogram, then an order-preserving compaction — replaces
+// torch.topk (a full sort of 37632 keys per row) + gather.
+// ================================================================================================
+namespace {
+
+constexpr int kSelThreads = 1024;
+
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* red, int* total)
+{
+    // exclusive scan of one int per thread over 1024 threads (16 waves)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) red[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < kSelThreads / 64; ++k) {
+        const int r = red[k];
+        if (k < wave) base += r;
+        tot += r;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kSelThreads) void select_uncertain_kernel(
+    const float* __restrict__ vals, const float* __restrict__ coords_in, float* __restrict__ coords_out,
+    int M, int k, int P_out)
+{
+    __shared__ int hist[256];
+    __shared__ int red[kSelThreads / 64];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_krem;
+    const int row = blockIdx.x;
+    const float* v = vals + (int64_t)row * M;
+    const float2* cin = reinterpret_cast<const float2*>(coords_in) + (int64_t)row * M;
+    float2* cout = reinterpret_cast<float2*>(coords_out) + (int64_t)row * P_out;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_prefix = 0u; s_krem = k; }
+    unsigned prefix = 0u, mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        prefix = s_prefix;
+        for (int i = tid; i < M; i += kSelThreads) {
+            const unsigned key = __float_as_uint(fabsf(v[i]));
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int krem = s_krem, d = 0;
+            for (; d < 256; ++d) {
+                const int c = hist[d];
+                if (krem <= c) break;
+                krem -= c;
+            }
+            if (d > 255) d = 255;
+            s_krem = krem;                       // how many of the threshold digit's bucket are needed
+            s_prefix = prefix | ((unsigned)d << shift);
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const unsigned thr = s_prefix;               // exact k-th smallest key
+    const int need_eq = s_krem;                  // number of == thr elements to take
+    // order-preserving compaction: contiguous slices per thread
+    const int per = (M + kSelThreads - 1) / kSelThreads;
+    const int i0 = tid * per, i1 = min(M, i0 + per);
+    int n_less = 0, n_eq = 0;
+    for (int i = i0; i < i1; ++i) {
+        const unsigned key = __float_as_uint(fabsf(v[i]));
+        n_less += key < thr;
+        n_eq += key == thr;
+    }
+    int tot_less, tot_eq;
+    const int off_less = block_excl_scan_1024(n_less, red, &tot_less);
+    const int off_eq = block_excl_scan_1024(n_eq, red, &tot_eq);
+    int pl = off_less, pe = off_eq;
+    for (int i = i0; i < i1; ++i) {
+        const unsigned key = __float_as_uint(fabsf(v[i]));
+        if (key < thr) {
+            cout[pl++] = cin[i];
+        } else if (key == thr) {
+            if (pe < need_eq) cout[tot_less + pe] = cin[i];
+            ++pe;
+        }
+    }
+}
+
+// ================================================================================================
+// Matching cost (matcher.py:105-148, mask + dice part): for every (layer, image, query) row and every
+// ground-truth mask t of that image,
+//   cost[row, t] = w_mask * (sum_p softplus(x_p) - sum_p x_p t_p) / P
+//                + w_dice * (1 - (2 sum_p s_p t_p + 1) / (sum_p s_p + sum_p t_p + 1))
+// x sampled on the fly from the prediction map, t from the pre-sampled [.., P] ground-truth points.
+// One workgroup per row; TT targets at a time in registers.
+// ================================================================================================
+constexpr int kTT = 8;
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void match_cost_kernel(
+    const T* __restrict__ pred, int h, int w, const int64_t* __restrict__ pred_offs,
+    const float* __restrict__ coords, const int32_t* __restrict__ coord_rows,
+    const float* __restrict__ tsamp, const int32_t* __restrict__ t_first, const int32_t* __restrict__ t_count,
+    float* __restrict__ cost, int Tmax, int P, float w_mask, float w_dice)
+{
+    __shared__ float red[kThreads / 64];
+    const int row = blockIdx.x;
+    const T* pm = pred + pred_offs[row];
+    const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)coord_rows[row] * P;
+    const int T0 = t_first[row], Tn = t_count[row];
+    float* out = cost + (int64_t)row * Tmax;
+    for (int tb = 0; tb < Tn; tb += kTT) {
+        float ax[kTT], as[kTT], at[kTT], sp = 0.f, sg_sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < kTT; ++j) { ax[j] = 0.f; as[j] = 0.f; at[j] = 0.f; }
+        for (int p = threadIdx.x; p < P; p += kThreads) {
+            const float2 xy = c[p];
+            const float x = sample(pm, h, w, bilin(xy.x, xy.y, h, w));
+            const float sg = 1.f / (1.f + __expf(-x));
+            sp += fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));      // softplus(x)
+            sg_sum += sg;
+#pragma unroll
+            for (int j = 0; j < kTT; ++j) {
+                if (tb + j < Tn) {
+                    const float tv = tsamp[(int64_t)(T0 + tb + j) * P + p];
+                    ax[j] += x * tv; as[j] += sg * tv; at[j] += tv;
+                }
+            }
+        }
+        sp = block_sum(sp, red);
+        sg_sum = block_sum(sg_sum, red);
+#pragma unroll
+        for (int j = 0; j < kTT; ++j) {
+            const float sx = block_sum(ax[j], red), ss = block_sum(as[j], red), st = block_sum(at[j], red);
+            if (threadIdx.x == 0 && tb + j < Tn) {
+                const float cm = (sp - sx) / (float)P;
+                const float cd = 1.f - (2.f * ss + 1.f) / (sg_sum + st + 1.f);
+                out[tb + j] = w_mask * cm + w_dice * cd;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mpf_select_uncertain(const float* vals, const float* coords_in, float* coords_out,
+                                    int n, int M, int k, int P_out, void* stream)
+{
+    if (!vals || !coords_in || !coords_out) return mpf::fail(MPF_E_NULL, "select_uncertain: NULL buffer");
+    if (n < 0 || M <= 0 || k < 0 || k > M || P_out < k) return mpf::fail(MPF_E_SHAPE, "select_uncertain: bad sizes");
+    if (n == 0 || k == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    mpf::prof_begin(st);
+    mpf::set_kernel("select_uncertain_kernel");
+    hipLaunchKernelGGL(select_uncertain_kernel, dim3(n), dim3(kSelThreads), 0, st, vals, coords_in, coords_out, M, k, P_out);
+    mpf::prof_end(mpf_last_kernel(), st, (double)n * M * 12.0 * 2 + (double)n * k * 8.0);
+    return mpf::check(hipGetLastError(), "mpf_select_uncertain");
+}
+
+extern "C" int mpf_match_cost(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_offs,
+                              const float* coords, const int32_t* coord_rows, const float* tsamp,
+                              const int32_t* t_first, const int32_t* t_count, float* cost,
+                              int n_rows, int Tmax, int P, float w_mask, float w_dice, void* stream)
+{
+    if (!pred || !pred_offs || !coords || !coord_rows || !tsamp || !t_first || !t_count || !cost)
+        return mpf::fail(MPF_E_NULL, "match_cost: NULL buffer");
+    if (n_rows < 0 || Tmax <= 0 || P <= 0 || h <= 0 || w <= 0) return mpf::fail(MPF_E_SHAPE, "match_cost: bad sizes");
+    if (n_rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    mpf::prof_begin(st);
+    if (pred_dtype == MPF_F32) {
+        mpf::set_kernel("match_cost_kernel<float>");
+        hipLaunchKernelGGL(match_cost_kernel<float>, dim3(n_rows), dim3(kThreads), 0, st, (const float*)pred, h, w,
+                           pred_offs, coords, coord_rows, tsamp, t_first, t_count, cost, Tmax, P, w_mask, w_dice);
+    } else if (pred_dtype == MPF_BF16) {
+        mpf::set_kernel("match_cost_kernel<bf16>");
+        hipLaunchKernelGGL(match_cost_kernel<__hip_bfloat16>, dim3(n_rows), dim3(kThreads), 0, st,
+                           (const __hip_bfloat16*)pred, h, w, pred_offs, coords, coord_rows, tsamp, t_first, t_count,
+                           cost, Tmax, P, w_mask, w_dice);
+    } else {
+        return mpf::fail(MPF_E_DTYPE, "mpf_match_cost: pred dtype must be MPF_F32 or MPF_BF16");
+    }
+    mpf::prof_end(mpf_last_kernel(), st, (double)n_rows * P * (8.0 + 16.0 + 4.0 * Tmax));
+    return mpf::check(hipGetLastError(), "mpf_match_cost");
 }

@@ -1,17 +1,22 @@
 """Hungarian matcher — mirror of mask2former/modeling/matcher.py (:15-62 cost functions, :70-179
-HungarianMatcher).  The point samples of predictions and byte ground-truth masks come from the native
-sampling kernel (csrc/loss.hip); the [Q,T] cost matrices are small fp32 GEMMs; the assignment is
-SciPy's linear_sum_assignment on the host exactly as in the reference (:149-151), but ALL cost
-matrices of a step travel in ONE device->host copy instead of one blocking `.cpu()` per image per
-decoder layer — assignments are unchanged.
+HungarianMatcher).
+
+The matchings of ALL decoder outputs of a step (final + auxiliary) are computed together:
+  * one native sampling launch evaluates every ground-truth byte mask at every output's point set,
+  * one native launch (mpf_match_cost) produces the mask + dice cost of every (output, image, query,
+    target) from the prediction maps in place — no gathered / float copies, no [Q,P] temporaries,
+  * the class cost is one batched softmax + gather,
+  * ONE device->host copy carries all cost matrices to SciPy's linear_sum_assignment, which runs on
+    the host exactly as in the reference (:149-151) — assignments are unchanged, the 10*N blocking
+    `.cpu()` calls per step are gone.
 """
+import numpy as np
 import torch
-import torch.nn.functional as F
 from scipy.optimize import linear_sum_assignment
 from torch import nn
 
 from . import _rng
-from .point_sample import map_rows, point_sample_rows
+from .point_sample import MapSet, match_cost, point_sample_offsets
 
 
 class GTMasks:
@@ -20,10 +25,14 @@ class GTMasks:
 
     def __init__(self, targets):
         dev = targets[0]["masks"].device
+        if not dev.type == "cuda":
+            raise RuntimeError("mp_former_amd criterion / matcher run on the GPU only (no CPU fallback)")
         self.counts = [int(t["masks"].shape[0]) for t in targets]
         self.offsets = [0]
         for c in self.counts:
             self.offsets.append(self.offsets[-1] + c)
+        self.total = self.offsets[-1]
+        self.tmax = max(self.counts) if self.counts else 0
         ms = [t["masks"] for t in targets if t["masks"].shape[0] > 0]
         if ms:
             m = torch.cat([x if x.dtype == torch.bool else (x > 0) for x in ms]).contiguous()
@@ -32,10 +41,9 @@ class GTMasks:
             H, W = targets[0]["masks"].shape[-2:]
             self.u8 = torch.zeros((0, H, W), dtype=torch.uint8, device=dev)
         self.H, self.W = self.u8.shape[-2:]
-        total = self.offsets[-1]
-        self.rows = torch.arange(total, dtype=torch.int32, device=dev)
-        self.image_of_row = torch.cat([torch.full((c,), b, dtype=torch.int32) for b, c in enumerate(self.counts)]).to(dev) \
-            if total else torch.zeros(0, dtype=torch.int32, device=dev)
+        self.image_of_row = np.concatenate([np.full(c, b, dtype=np.int64) for b, c in enumerate(self.counts)]) \
+            if self.total else np.zeros(0, dtype=np.int64)
+        self.device = dev
 
 
 class HungarianMatcher(nn.Module):
@@ -46,58 +54,72 @@ class HungarianMatcher(nn.Module):
         self.num_points = num_points
 
     @torch.no_grad()
-    def cost_matrices(self, outputs, targets, tag="match", gt=None):
-        """[C_b of shape [Q, T_b]] on the device (matcher.py:103-148)."""
-        logits, masks = outputs["pred_logits"], outputs["pred_masks"]
-        bs, Q = logits.shape[:2]
-        dev = masks.device
-        h, w = masks.shape[-2:]
+    def match_many(self, outs, targets, gt=None, tags=None, mapset=None, map_index=None):
+        """outs: list of {"pred_logits" [N,Q,K+1], "pred_masks" [N,Q,h,w]}  ->  list (per output) of
+        list (per image) of (index_i, index_j) int64 CPU tensors (matcher.py:95-156).
+        `mapset` / `map_index` optionally give a MapSet that already contains the mask tensors."""
+        L = len(outs)
+        N, Q = outs[0]["pred_logits"].shape[:2]
         gt = gt or GTMasks(targets)
+        dev = gt.device
         P = self.num_points
-        # one point set per image, shared by all of its masks (matcher.py:120)
-        coords = torch.cat([_rng.rand(tag, (1, P, 2), dev) for _ in range(bs)], 0)
-        bq = torch.arange(bs * Q, device=dev)
-        rows = map_rows(masks, (bq // Q, bq % Q))
-        out_pts = point_sample_rows(masks, h, w, rows, coords, (bq // Q).to(torch.int32)).view(bs, Q, P)
-        tgt_pts = point_sample_rows(gt.u8, gt.H, gt.W, gt.rows, coords, gt.image_of_row)
-        prob = logits.float().softmax(-1)
-        costs = []
-        for b in range(bs):
-            o = out_pts[b]
-            t = tgt_pts[gt.offsets[b]:gt.offsets[b + 1]]
-            cost_class = -prob[b][:, targets[b]["labels"]]
-            # softplus(-o) = softplus(o) - o  =>  BCE cost = (sum softplus(o) - o.t) / P   (matcher.py:38-62)
-            sp = F.softplus(o).sum(-1, keepdim=True)
-            s = o.sigmoid()
-            both = torch.cat([o, s], 0) @ t.T
-            cost_mask = (sp - both[:Q]) / P
-            cost_dice = 1 - (2 * both[Q:] + 1) / (s.sum(-1)[:, None] + t.sum(-1)[None, :] + 1)
-            C = self.cost_mask * cost_mask + self.cost_class * cost_class + self.cost_dice * cost_dice
-            costs.append(C.reshape(Q, -1))
-        return costs
-
-    @staticmethod
-    def solve(cost_lists):
-        """cost_lists: list (per call) of list (per image) of device tensors -> same nesting of
-        (index_i, index_j) int64 CPU tensors.  One D2H transfer for everything."""
-        flat = [c for cl in cost_lists for c in cl]
-        sizes = [c.numel() for c in flat]
-        host = torch.cat([c.reshape(-1).float() for c in flat]).cpu() if sum(sizes) > 0 else torch.zeros(0)
-        res, off, k = [], 0, 0
-        for cl in cost_lists:
+        tags = tags or ["match"] + [f"match_{i}" for i in range(L - 1)]
+        empty = (torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64))
+        # one point set per (output, image), shared by all of that image's masks (matcher.py:120)
+        coords = _rng.rand_cat([(tags[l], (1, P, 2)) for l in range(L) for _ in range(N)], dev)   # [L*N,P,2]
+        if gt.tmax == 0:
+            return [[empty for _ in range(N)] for _ in range(L)]
+        if mapset is None:
+            mapset = MapSet([o["pred_masks"] for o in outs])
+            map_index = list(range(L))
+        Tt, Tmax = gt.total, gt.tmax
+        # ---- index arrays (host) -> one upload ---------------------------------------------------
+        l_idx, b_idx, q_idx = np.meshgrid(np.arange(L), np.arange(N), np.arange(Q), indexing="ij")
+        l_idx, b_idx, q_idx = l_idx.reshape(-1), b_idx.reshape(-1), q_idx.reshape(-1)
+        pred_offs = mapset.offsets(np.asarray(map_index, dtype=np.int64)[l_idx], b_idx, q_idx)
+        gt_offs = np.tile(np.arange(Tt, dtype=np.int64) * (gt.H * gt.W), L)
+        i64 = torch.from_numpy(np.concatenate([pred_offs, gt_offs])).to(dev, non_blocking=True)
+        counts = np.asarray(gt.counts, dtype=np.int64)
+        firsts = np.asarray(gt.offsets[:-1], dtype=np.int64)
+        i32 = np.concatenate([
+            (l_idx * N + b_idx),                                        # coord row of every prediction row
+            (l_idx * Tt + firsts[b_idx]),                               # first tsamp row of its image
+            counts[b_idx],                                              # number of targets of its image
+            (np.repeat(np.arange(L), Tt) * N + np.tile(gt.image_of_row, L)),   # coord row of every GT sample row
+        ]).astype(np.int32)
+        i32 = torch.from_numpy(i32).to(dev, non_blocking=True)
+        n_rows = L * N * Q
+        pred_offs_d, gt_offs_d = i64[:n_rows], i64[n_rows:]
+        crow_d, tfirst_d, tcount_d, gcrow_d = i32[:n_rows], i32[n_rows:2 * n_rows], i32[2 * n_rows:3 * n_rows], i32[3 * n_rows:]
+        # ---- ground-truth samples [L*Tt, P], then mask + dice cost [L*N*Q, Tmax] ------------------
+        tsamp = point_sample_offsets(gt.u8.data_ptr(), torch.uint8, gt.H, gt.W, gt_offs_d, coords, gcrow_d, dev)
+        C = match_cost(mapset, pred_offs_d, coords, crow_d, tsamp, tfirst_d, tcount_d, Tmax,
+                       self.cost_mask, self.cost_dice).view(L, N, Q, Tmax)
+        # ---- class cost: -softmax(logits)[:, labels]  (matcher.py:105-111) ------------------------
+        logits = torch.stack([o["pred_logits"] for o in outs]).float()                  # [L,N,Q,K+1]
+        labels = torch.zeros((N, Tmax), dtype=torch.int64, device=dev)
+        for b, t in enumerate(targets):
+            if gt.counts[b]:
+                labels[b, :gt.counts[b]] = t["labels"]
+        prob = logits.softmax(-1)
+        C = C - self.cost_class * torch.gather(prob, 3, labels[None, :, None, :].expand(L, N, Q, Tmax))
+        host = C.cpu().numpy()                                                           # the one D2H copy
+        res = []
+        for l in range(L):
             cur = []
-            for c in cl:
-                C = host[off:off + sizes[k]].view(c.shape)
-                off += sizes[k]
-                k += 1
-                i, j = linear_sum_assignment(C.numpy())
+            for b in range(N):
+                if gt.counts[b] == 0:
+                    cur.append(empty)
+                    continue
+                i, j = linear_sum_assignment(host[l, b, :, :gt.counts[b]])
                 cur.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
             res.append(cur)
         return res
 
     @torch.no_grad()
     def forward(self, outputs, targets):
-        return self.solve([self.cost_matrices(outputs, targets)])[0]
+        """Reference interface: one output dict -> list of (index_i, index_j) per image."""
+        return self.match_many([{"pred_logits": outputs["pred_logits"], "pred_masks": outputs["pred_masks"]}], targets)[0]
 
     def __repr__(self, _repr_indent=4):
         body = [f"cost_class: {self.cost_class}", f"cost_mask: {self.cost_mask}", f"cost_dice: {self.cost_dice}"]

@@ -7,112 +7,142 @@ Semantics (third-party, restated): detectron2.projects.point_rend.point_features
   remaining fresh uniform points
 as used at mask2former/modeling/criterion.py:164-182 and matcher.py:122-132.
 
-All functions need CUDA tensors; there is no CPU path.
+Maps of SEVERAL tensors (the prediction maps of all decoder layers) are addressed in one launch as
+int64 element offsets from a common base pointer (`MapSet`).  CUDA tensors only; no CPU path.
 """
+import numpy as np
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from . import _lib, _rng
+from . import _lib
 
 _DT = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16, torch.uint8: _lib.MPF_U8, torch.bool: _lib.MPF_U8}
 _CHUNKS = 8
 
 
-def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
-def _need_cuda(*ts):
-    for t in ts:
-        if t is not None and not t.is_cuda:
+class MapSet:
+    """A list of [N, Q_i, h, w] tensors (dense [h,w] planes, arbitrary strides on dims 0/1) seen as one
+    address space: offset(i, b, q) = element offset of that plane from the lowest data pointer."""
+
+    def __init__(self, tensors):
+        t0 = tensors[0]
+        if not t0.is_cuda:
             raise RuntimeError("mp_former_amd point sampling is implemented on the GPU only (no CPU fallback)")
+        self.tensors = list(tensors)
+        self.h, self.w = t0.shape[-2:]
+        self.dtype, self.device = t0.dtype, t0.device
+        self.esize = t0.element_size()
+        if self.dtype not in _DT:
+            raise RuntimeError(f"unsupported map dtype {self.dtype}")
+        ptrs = []
+        for t in tensors:
+            if t.dtype != self.dtype or tuple(t.shape[-2:]) != (self.h, self.w) or t.device != self.device:
+                raise RuntimeError("all maps of a MapSet must share dtype, device and [h, w]")
+            if t.stride(3) != 1 or t.stride(2) != self.w:
+                raise RuntimeError("maps must be dense [h, w] planes")
+            ptrs.append(t.data_ptr())
+        self.base_ptr = min(ptrs)
+        self.t_off = np.array([(p - self.base_ptr) // self.esize for p in ptrs], dtype=np.int64)
+        self.s0 = np.array([t.stride(0) for t in tensors], dtype=np.int64)
+        self.s1 = np.array([t.stride(1) for t in tensors], dtype=np.int64)
+        # layout of one flat fp32 gradient buffer holding a CONTIGUOUS copy of every tensor
+        numels = np.array([t.numel() for t in tensors], dtype=np.int64)
+        self.g_start = np.concatenate([[0], np.cumsum(numels)[:-1]])
+        self.g_total = int(numels.sum())
+        self.g_s0 = np.array([t.shape[1] * self.h * self.w for t in tensors], dtype=np.int64)
+
+    def offsets(self, ti, b, q):
+        """numpy int64 arrays (tensor index, image, query row) -> element offsets of the planes."""
+        return self.t_off[ti] + b * self.s0[ti] + q * self.s1[ti]
+
+    def grad_offsets(self, ti, b, q):
+        return self.g_start[ti] + b * self.g_s0[ti] + q * (self.h * self.w)
 
 
-def map_rows(maps, index):
-    """Row indices (in units of one h*w map, relative to maps.data_ptr()) of maps[index] for a 4-d
-    [N,Q,h,w] tensor that may be a slice of a larger contiguous tensor along dim 1.
-    index = (b[n], q[n]) int64 tensors on the same device."""
-    N, Q, h, w = maps.shape
-    s0, s1, s2, s3 = maps.stride()
-    if s3 != 1 or s2 != w or s0 % (h * w) or s1 % (h * w):
-        raise RuntimeError("prediction maps must be dense [*, *, h, w] planes")
-    b, q = index
-    return (b * (s0 // (h * w)) + q * (s1 // (h * w))).to(torch.int32)
-
-
-def point_sample_rows(src, h, w, rows, coords, coord_rows=None):
-    """out[i] = bilinear samples of map rows[i] of `src` (any tensor whose memory is [*, h, w] planes
-    starting at src.data_ptr()) at coords[coord_rows[i]] -> [n, P] f32.  No autograd."""
-    _need_cuda(src, rows, coords, coord_rows)
-    if src.dtype not in _DT:
-        raise RuntimeError(f"point_sample: unsupported dtype {src.dtype}")
-    coords = coords.contiguous().float()
-    n, P = rows.numel(), coords.shape[-2]
-    out = torch.empty((n, P), dtype=torch.float32, device=src.device)
+def point_sample_offsets(base_ptr, dtype, h, w, offs, coords, coord_rows, device):
+    """out[i] = samples of the [h,w] plane at base_ptr + offs[i] (elements) at coords[coord_rows[i]]
+    -> [n, P] f32.  No autograd."""
+    n, P = offs.numel(), coords.shape[-2]
+    out = torch.empty((n, P), dtype=torch.float32, device=device)
     if n == 0:
         return out
-    with torch.cuda.device(src.device):
-        code = _lib.lib().mpf_point_sample(src.data_ptr(), _DT[src.dtype], h, w, rows.data_ptr(), coords.data_ptr(),
+    with torch.cuda.device(device):
+        code = _lib.lib().mpf_point_sample(base_ptr, _DT[dtype], h, w, offs.data_ptr(), coords.data_ptr(),
                                            coord_rows.data_ptr() if coord_rows is not None else None,
-                                           out.data_ptr(), n, P, _stream(src))
+                                           out.data_ptr(), n, P, _stream(device))
     _lib.check(code, "mpf_point_sample")
     return out
 
 
+def select_uncertain(vals, coords_in, k, P_out):
+    """coords_out[:, :k] = coordinates of the k smallest-|value| entries per row (criterion.py:164-170)."""
+    n, M = vals.shape
+    out = torch.empty((n, P_out, 2), dtype=torch.float32, device=vals.device)
+    if n and k:
+        with torch.cuda.device(vals.device):
+            code = _lib.lib().mpf_select_uncertain(vals.data_ptr(), coords_in.data_ptr(), out.data_ptr(), n, M, k, P_out,
+                                                   _stream(vals.device))
+        _lib.check(code, "mpf_select_uncertain")
+    return out
+
+
+def match_cost(ms, offs, coords, coord_rows, tsamp, t_first, t_count, Tmax, w_mask, w_dice):
+    n = offs.numel()
+    P = coords.shape[-2]
+    cost = torch.zeros((n, Tmax), dtype=torch.float32, device=ms.device)
+    if n:
+        with torch.cuda.device(ms.device):
+            code = _lib.lib().mpf_match_cost(ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, offs.data_ptr(), coords.data_ptr(),
+                                             coord_rows.data_ptr(), tsamp.data_ptr(), t_first.data_ptr(),
+                                             t_count.data_ptr(), cost.data_ptr(), n, Tmax, P, float(w_mask),
+                                             float(w_dice), _stream(ms.device))
+        _lib.check(code, "mpf_match_cost")
+    return cost
+
+
 class MaskLossSums(Function):
     """sums[i] = (sum_p BCE(x,t), sum_p sigmoid(x)*t, sum_p sigmoid(x), sum_p t) over the P points of
-    pair i, x / t sampled from pred[pred_rows[i]] / gt[gt_rows[i]]  (criterion.py:172-191)."""
+    pair i; x sampled from the plane at ms.base + pred_offs[i], t from gt_u8[gt_rows[i]]
+    (criterion.py:172-191).  Differentiable wrt every tensor of the MapSet."""
 
     @staticmethod
-    def forward(ctx, pred, pred_rows, gt_u8, gt_rows, coords):
-        _need_cuda(pred, pred_rows, gt_u8, gt_rows, coords)
-        h, w = pred.shape[-2:]
-        H, W = gt_u8.shape[-2:]
+    def forward(ctx, ms, pred_offs, grad_offs, gt_u8, gt_rows, coords, *tensors):
         n, P = coords.shape[0], coords.shape[1]
-        partial = torch.empty((n, _CHUNKS, 4), dtype=torch.float32, device=pred.device)
+        H, W = gt_u8.shape[-2:]
+        partial = torch.empty((n, _CHUNKS, 4), dtype=torch.float32, device=ms.device)
         if n:
-            with torch.cuda.device(pred.device):
+            with torch.cuda.device(ms.device):
                 code = _lib.lib().mpf_mask_loss_forward(
-                    pred.data_ptr(), _DT[pred.dtype], h, w, pred_rows.data_ptr(), gt_u8.data_ptr(), H, W,
-                    gt_rows.data_ptr(), coords.data_ptr(), partial.data_ptr(), n, P, _CHUNKS, _stream(pred))
+                    ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), H, W,
+                    gt_rows.data_ptr(), coords.data_ptr(), partial.data_ptr(), n, P, _CHUNKS, _stream(ms.device))
             _lib.check(code, "mpf_mask_loss_forward")
-        ctx.save_for_backward(pred, pred_rows, gt_u8, gt_rows, coords)
+        ctx.ms = ms
+        ctx.save_for_backward(pred_offs, grad_offs, gt_u8, gt_rows, coords, *tensors)   # keeps the maps alive
         return partial.sum(1)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_sums):
-        pred, pred_rows, gt_u8, gt_rows, coords = ctx.saved_tensors
-        h, w = pred.shape[-2:]
-        H, W = gt_u8.shape[-2:]
+        ms = ctx.ms
+        pred_offs, grad_offs, gt_u8, gt_rows, coords = ctx.saved_tensors[:5]
         n, P = coords.shape[0], coords.shape[1]
-        # fp32 accumulation buffer with pred's memory layout (pred may be a strided slice)
-        gbuf = torch.zeros(pred.shape, dtype=torch.float32, device=pred.device) if pred.is_contiguous() else \
-            torch.empty_strided(pred.shape, pred.stride(), dtype=torch.float32, device=pred.device).zero_()
+        H, W = gt_u8.shape[-2:]
+        gbuf = torch.zeros(ms.g_total, dtype=torch.float32, device=ms.device)
         if n:
             g = grad_sums.contiguous().float()
-            with torch.cuda.device(pred.device):
+            with torch.cuda.device(ms.device):
                 code = _lib.lib().mpf_mask_loss_backward(
-                    pred.data_ptr(), _DT[pred.dtype], h, w, pred_rows.data_ptr(), gt_u8.data_ptr(), H, W,
-                    gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), gbuf.data_ptr(), n, P, _stream(pred))
+                    ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), H, W,
+                    gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), gbuf.data_ptr(), grad_offs.data_ptr(), n, P,
+                    _stream(ms.device))
             _lib.check(code, "mpf_mask_loss_backward")
-        return gbuf.to(pred.dtype), None, None, None, None
-
-
-def uncertain_point_coords(pred, pred_rows, num_points, oversample_ratio, importance_sample_ratio, tag):
-    """criterion.py:164-170 -> coords [n, num_points, 2] (no grad)."""
-    assert oversample_ratio >= 1 and 0 <= importance_sample_ratio <= 1
-    n = pred_rows.numel()
-    dev = pred.device
-    h, w = pred.shape[-2:]
-    num_sampled = int(num_points * oversample_ratio)
-    coords = _rng.rand(tag + "_over", (n, num_sampled, 2), dev)
-    logits = point_sample_rows(pred, h, w, pred_rows, coords)
-    num_uncertain = int(importance_sample_ratio * num_points)
-    num_random = num_points - num_uncertain
-    idx = torch.topk(-logits.abs(), k=num_uncertain, dim=1)[1]
-    picked = torch.gather(coords, 1, idx[:, :, None].expand(-1, -1, 2))
-    if num_random > 0:
-        picked = torch.cat([picked, _rng.rand(tag + "_rand", (n, num_random, 2), dev)], dim=1)
-    return picked.contiguous()
+        grads = []
+        for i, t in enumerate(ms.tensors):
+            s = int(ms.g_start[i])
+            grads.append(gbuf[s:s + t.numel()].view(t.shape).to(t.dtype))
+        return (None, None, None, None, None, None, *grads)

@@ -37,8 +37,7 @@ def main():
             out = model.head.predictor(ms, mf, None, {"tgt": targets, "scalar": 1, "noise_scale": 0.0})
             ev[3].record()
             losses = model.head.criterion(out, targets)
-            wd = model.head.criterion.weight_dict
-            loss = sum(v * wd[k] for k, v in losses.items() if k in wd)
+            loss = model.head.criterion.weighted_total(losses)
         ev[4].record()
         loss.backward()
         ev[5].record()
