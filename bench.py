@@ -202,10 +202,15 @@ def main():
         dt = float(t.item())
     final_loss = float(loss)
 
-    # roofline of the dominant native kernel (MSDA backward; HBM-bound), from the launch log
-    n_b, ms_b, by_b = _lib.profile_get("msda_bwd")
+    # roofline of the dominant native op (MSDA backward = push + fill + pull kernels; HBM-bound), from
+    # the in-library launch log: HIP events on the launch stream around every kernel of the timed region
+    n_k, ms_b, _ = _lib.profile_get("msda_bwd_")
+    n_pull, _, _ = _lib.profile_get("msda_bwd_pull")
+    n_b = n_pull if n_pull else n_k          # calls (binned: 3 kernels per call; atomic path: 1)
     n_f, ms_f, by_f = _lib.profile_get("msda_fwd")
     _lib.profile_enable(False)
+    S_tok = sum((a.size // s) ** 2 for s in (8, 16, 32))
+    by_b = 1344.0 * 4 * S_tok * a.batch * n_b     # algorithmic bytes: SURVEY.md §8(d), fp32, per call
 
     if rank == 0:
         ips = a.batch * world * a.steps / dt
@@ -223,7 +228,7 @@ def main():
                                    % (a.size, a.size),
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "tokens_per_image_S": S, "final_loss": round(final_loss, 4)},
-            "roofline": {"kernel": "msda_bwd_tiled_f32 (grad_value scatter + grad_loc/grad_attn)", "bound": "hbm",
+            "roofline": {"kernel": "MSDA backward (msda_bwd_push + msda_bwd_fill + msda_bwd_pull, atomics-free)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "launches": n_b, "avg_us": round(ms_b * 1e3 / max(n_b, 1), 1),

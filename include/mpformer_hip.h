@@ -14,6 +14,7 @@
 #ifndef MPFORMER_HIP_H
 #define MPFORMER_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -78,6 +79,26 @@ int mpf_msda_backward(const void* value, const int64_t* spatial_shapes,
                       int batch, int spatial_size, int num_heads, int channels,
                       int num_levels, int num_query, int num_point,
                       int dtype, void* stream);
+
+/*
+ * Multi-scale deformable attention, backward, atomics-free ("binned") formulation for fp32 with 32
+ * channels per head — the production path of the pixel decoder.  Same results as mpf_msda_backward
+ * (grad_value sums are reassociated; no floating-point atomics are used), different contract:
+ *   - spatial_shapes is passed from HOST memory (the launch geometry depends on it) and
+ *     level_start_index is implied (levels are stored back to back);
+ *   - the caller provides a device workspace of at least mpf_msda_backward_workspace_bytes(...);
+ *   - grad_value needs no zero-fill: every element is written exactly once.
+ * Restrictions: dtype MPF_F32, channels == 32, num_levels <= 8, num_levels*num_point <= 32.
+ * See mp_former_amd/csrc/msda_bwd_binned.hip for the algorithm.
+ */
+size_t mpf_msda_backward_workspace_bytes(int batch, int num_heads, int num_levels, int num_query,
+                                         int num_point, const int64_t* host_spatial_shapes);
+int mpf_msda_backward_ws(const void* value, const int64_t* host_spatial_shapes,
+                         const void* sampling_loc, const void* attn_weight, const void* grad_output,
+                         void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
+                         int batch, int spatial_size, int num_heads, int channels,
+                         int num_levels, int num_query, int num_point, int dtype,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Tuning / introspection knobs (process-wide; for benchmarks and tests).

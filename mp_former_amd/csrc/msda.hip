@@ -630,9 +630,10 @@ extern "C" int mpf_msda_backward(const void* value, const int64_t* spatial_shape
 namespace mpf {
 int set_msda_option(const char* key, int v)
 {
+    const bool mine = !strcmp(key, "msda_fwd_variant") || !strcmp(key, "msda_bwd_variant");
+    if (!mine) return 1;
     if (v < 0 || v > 4) return MPF_E_SHAPE;
-    if (!strcmp(key, "msda_fwd_variant")) { g_fwd_variant = v; return 0; }
-    if (!strcmp(key, "msda_bwd_variant")) { g_bwd_variant = v; return 0; }
-    return 1;  // not mine
+    if (!strcmp(key, "msda_fwd_variant")) g_fwd_variant = v; else g_bwd_variant = v;
+    return 0;
 }
 }  // namespace mpf

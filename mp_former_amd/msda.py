@@ -77,8 +77,47 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+# backward formulation: "auto" = atomics-free binned kernels when applicable, else the atomic kernels;
+# "atomic" forces the reference-style scatter with hardware fp32 atomics; "binned" requires the binned path.
+BWD_MODE = "auto"
+
+_workspaces = {}
+
+
+def attach_host_shapes(spatial_shapes, shapes_list):
+    """Remember the host-side (H, W) list on a device `spatial_shapes` tensor so that the binned
+    backward needs no device->host copy (the pixel decoder builds the tensor from python ints)."""
+    spatial_shapes._mpf_host = torch.as_tensor(shapes_list, dtype=torch.int64).contiguous()
+    return spatial_shapes
+
+
+def _host_shapes(spatial_shapes, level_start_index):
+    """Host copy of spatial_shapes: the attached copy if the caller provided one, else a (blocking)
+    device->host copy — the price of the reference's all-device signature.  Returns None when the
+    levels are not stored back to back (then the binned path does not apply)."""
+    hs = getattr(spatial_shapes, "_mpf_host", None)
+    if hs is not None:
+        return hs
+    hs = spatial_shapes.cpu().contiguous()
+    lsi = level_start_index.cpu()
+    expect = torch.cat((hs.new_zeros(1), (hs[:, 0] * hs[:, 1]).cumsum(0)[:-1]))
+    return hs if torch.equal(lsi, expect) else None
+
+
+def _workspace(device, nbytes):
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
+def _binned_applicable(value, D, L, P):
+    return value.dtype == torch.float32 and D == 32 and L <= 8 and L * P <= 32
+
+
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                            grad_output, im2col_step):
+                            grad_output, im2col_step, host_shapes=None):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight]"""
     _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
@@ -86,9 +125,27 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     if grad_output.dtype != value.dtype or grad_output.numel() != N * Lq * M * D:
         raise RuntimeError("grad_output must be [N, Lq, M*D] in the dtype of value")
-    gv = torch.empty_like(value)           # zero-filled by the native call
+    gv = torch.empty_like(value)           # fully written by the native call
     gl = torch.empty_like(sampling_loc)
     ga = torch.empty_like(attn_weight)
+    hs = None
+    if BWD_MODE != "atomic" and _binned_applicable(value, D, L, P):
+        hs = host_shapes if host_shapes is not None else _host_shapes(spatial_shapes, level_start_index)
+    if BWD_MODE == "binned" and hs is None:
+        raise RuntimeError("MSDA binned backward requested but not applicable (needs fp32, D=32, L<=8, L*P<=32, contiguous levels)")
+    if hs is not None:
+        lib = _lib.lib()
+        need = lib.mpf_msda_backward_workspace_bytes(N, M, L, Lq, P, hs.data_ptr())
+        if need == 0:
+            raise RuntimeError("mpf_msda_backward_workspace_bytes rejected the level geometry")
+        ws = _workspace(value.device, need)
+        with torch.cuda.device(value.device):
+            code = lib.mpf_msda_backward_ws(
+                value.data_ptr(), hs.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                grad_output.data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
+                N, S, M, D, L, Lq, P, _DTYPES[value.dtype], ws.data_ptr(), ws.numel(), _stream(value))
+        _lib.check(code, "mpf_msda_backward_ws")
+        return [gv, gl, ga]
     with torch.cuda.device(value.device):
         code = _lib.lib().mpf_msda_backward(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
@@ -110,6 +167,7 @@ class MSDeformAttnFunction(Function):
                                         sampling_locations, attention_weights, ctx.im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
+        ctx.host_shapes = getattr(value_spatial_shapes, "_mpf_host", None)
         return output
 
     @staticmethod
@@ -117,7 +175,7 @@ class MSDeformAttnFunction(Function):
     def backward(ctx, grad_output):
         value, shapes, lsi, loc, attn = ctx.saved_tensors
         gv, gl, ga = ms_deform_attn_backward(value, shapes, lsi, loc, attn,
-                                             grad_output.contiguous(), ctx.im2col_step)
+                                             grad_output.contiguous(), ctx.im2col_step, ctx.host_shapes)
         return gv, None, None, gl, ga, None
 
 

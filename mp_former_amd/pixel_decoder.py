@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import normal_
 
-from .msda import MSDeformAttn
+from .msda import MSDeformAttn, attach_host_shapes
 
 
 class ShapeSpec:
@@ -134,7 +134,7 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         key = (tuple(shapes_list), srcs[0].device)
         cached = self._shape_cache.get(key)
         if cached is None:
-            ss = torch.as_tensor(shapes_list, dtype=torch.long, device=srcs[0].device)
+            ss = attach_host_shapes(torch.as_tensor(shapes_list, dtype=torch.long, device=srcs[0].device), shapes_list)
             lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
             cached = (ss, lsi)
             self._shape_cache[key] = cached

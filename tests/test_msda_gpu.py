@@ -14,7 +14,7 @@ from conftest import MSDA_CFG, MSDA_TESTPY, load_msda_fixture, smooth_points
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {"auto": 0, "generic": 1, "tiled_v4": 2, "tiled_v1": 3, "tiled_v2": 4}
+VARIANTS = {"auto": 0, "binned": 0, "generic": 1, "tiled_v4": 2, "tiled_v1": 3, "tiled_v2": 4}
 
 
 @pytest.fixture(scope="module")
@@ -25,16 +25,19 @@ def dev():
 
 @pytest.fixture(autouse=True)
 def _reset_variants():
-    from mp_former_amd import _lib
+    from mp_former_amd import _lib, msda
     yield
     _lib.set_option("msda_fwd_variant", 0)
     _lib.set_option("msda_bwd_variant", 0)
+    msda.BWD_MODE = "auto"
 
 
 def _run(z, dtype, dev, variant="auto"):
-    from mp_former_amd import _lib, ms_deform_attn_backward, ms_deform_attn_forward
+    from mp_former_amd import _lib, ms_deform_attn_backward, ms_deform_attn_forward, msda
     _lib.set_option("msda_fwd_variant", VARIANTS[variant])
     _lib.set_option("msda_bwd_variant", VARIANTS[variant])
+    # "auto": atomics-free binned backward where applicable; "binned": require it; else hardware atomics
+    msda.BWD_MODE = variant if variant in ("auto", "binned") else "atomic"
     t = lambda k: torch.from_numpy(np.ascontiguousarray(z[k])).to(dtype).to(dev)  # noqa: E731
     shapes = torch.from_numpy(z["shapes"]).to(dev)
     lsi = torch.from_numpy(z["level_start"]).to(dev)
@@ -69,7 +72,7 @@ def test_fp64_matches_reference_golden(dev, name):
     np.testing.assert_allclose(ga, z["grad_attn"], rtol=1e-8, atol=1e-11)
 
 
-@pytest.mark.parametrize("variant", ["generic", "tiled_v4", "tiled_v1", "tiled_v2"])
+@pytest.mark.parametrize("variant", ["generic", "tiled_v4", "tiled_v1", "tiled_v2", "auto"])
 @pytest.mark.parametrize("name", ["msda_testpy_float", "msda_testpy_grad_D32"] + MSDA_CFG)
 def test_fp32_matches_reference_golden(dev, name, variant):
     """fp32: tolerance of the reference's own float test (test.py:59): rtol 1e-2, atol 1e-3;
@@ -78,7 +81,9 @@ def test_fp32_matches_reference_golden(dev, name, variant):
     (out, gv, gl, ga), (kf, kb) = _run(z, torch.float32, dev, variant)
     D = z["value"].shape[-1]
     if D == 32 and variant != "generic":
-        assert "tiled" in kf and "tiled" in kb, (kf, kb)
+        assert "tiled" in kf and ("tiled" in kb or "binned" in kb), (kf, kb)
+        if variant == "auto":
+            assert "binned" in kb, kb
     else:
         assert "generic<float>" in kf and "generic<float>" in kb
     for got, key in ((out, "out"), (ga, "grad_attn")):
@@ -105,7 +110,7 @@ def _random_problem(N, lv, M=8, D=32, P=4, seed=0, oob=True):
                 attn=attn.numpy(), grad_out=go.numpy())
 
 
-@pytest.mark.parametrize("variant", ["tiled_v4", "tiled_v1", "tiled_v2", "generic"])
+@pytest.mark.parametrize("variant", ["binned", "tiled_v4", "tiled_v1", "tiled_v2", "generic"])
 def test_fp32_vs_oracle_config_A(dev, oracle_msda, variant):
     """config A (256x256 -> levels 8,16,32; S=1344), N=2, vs the C oracle on the same seeded input."""
     z = _random_problem(2, [(8, 8), (16, 16), (32, 32)], seed=1)
@@ -128,7 +133,7 @@ def test_fp32_full_size_config_B_vs_oracle_and_properties(dev, oracle_msda):
     from mp_former_amd import ms_deform_attn_forward
     z = _random_problem(1, [(32, 32), (64, 64), (128, 128)], seed=2)
     (out, gv, gl, ga), (kf, kb) = _run(z, torch.float32, dev)
-    assert "tiled" in kf and "tiled" in kb
+    assert "tiled" in kf and "binned" in kb
     ref = oracle_msda.msda_forward(z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"])
     np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5)
     rgv, rgl, rga = oracle_msda.msda_backward(z["value"], z["shapes"], z["level_start"], z["loc"],
@@ -137,10 +142,16 @@ def test_fp32_full_size_config_B_vs_oracle_and_properties(dev, oracle_msda):
     np.testing.assert_allclose(ga, rga, rtol=1e-4, atol=1e-4)
     ok = smooth_points(z)
     np.testing.assert_allclose(gl[ok], rgl[ok], rtol=1e-3, atol=5e-3)
-    # variants agree
-    (out1, gv1, gl1, ga1), _ = _run(z, torch.float32, dev, "tiled_v4")
+    # the atomics-free and the atomic formulations agree
+    (out1, gv1, gl1, ga1), (_, kb1) = _run(z, torch.float32, dev, "tiled_v1")
+    assert "tiled" in kb1
     np.testing.assert_allclose(out1, out, rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(gv1, gv, rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(ga1, ga, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gl1[ok], gl[ok], rtol=1e-3, atol=1e-3)
+    # the binned backward is deterministic up to the order of entries inside a tile
+    (_, gv2, _, _), _ = _run(z, torch.float32, dev)
+    np.testing.assert_allclose(gv2, gv, rtol=1e-4, atol=1e-4)
     # linearity in value
     t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
     v2 = torch.randn(z["value"].shape, generator=torch.Generator().manual_seed(9)).to(dev)

@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--mode", default="init", choices=["init", "trained", "uniform"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--variants", default="2,3,1")
+    ap.add_argument("--variants", default="5,3", help="1 generic, 2/3/4 tiled V4/V1/V2 (atomics), 5 binned bwd")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     value, shapes, lsi, loc, attn, go, S = problem(a.cfg, a.batch, dev, a.mode)
@@ -80,8 +80,12 @@ def main():
     bwd_bytes = 1344 * 4 * S * N
     res = {}
     variants = [int(v) for v in a.variants.split(",")]
+    from mp_former_amd import msda as msda_mod
     for rnd in range(a.rounds + 1):
         for v in variants:
+            msda_mod.BWD_MODE = "binned" if v == 5 else "atomic"
+            if v == 5:
+                v = 3
             _lib.set_option("msda_fwd_variant", v)
             _lib.set_option("msda_bwd_variant", v)
             f = lambda: ms_deform_attn_forward(value, shapes, lsi, loc, attn, 128)  # noqa: E731
