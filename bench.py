@@ -154,9 +154,8 @@ def main():
     assert world == a.gpus, f"WORLD_SIZE {world} != --gpus {a.gpus}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+    from mp_former_amd import dist as mdist
+    mdist.init_from_env("nccl", dev)                     # nccl == RCCL on ROCm
 
     from mp_former_amd import _lib
     _lib.lib()   # fail loudly if the native library is missing
@@ -164,11 +163,7 @@ def main():
     torch.manual_seed(rank)
     model = TrainModel().to(dev).train()
     model.backbone.to(memory_format=torch.channels_last)
-    if world > 1:
-        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True)
-    else:
-        ddp = model
+    ddp = mdist.wrap_ddp(model, [local_rank])
     opt = build_optimizer(model)
     params = [p for p in model.parameters() if p.requires_grad]
     batches = [synth_batch(a.batch, a.size, 80, 1000 * rank + i, dev) for i in range(4)]
@@ -196,10 +191,7 @@ def main():
         loss = step(a.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = mdist.max_over_ranks(dt, dev)
     final_loss = float(loss)
 
     # roofline of the dominant native op (MSDA backward = push + fill + pull kernels; HBM-bound), from

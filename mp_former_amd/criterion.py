@@ -19,12 +19,9 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _rng
+from .dist import global_num_masks
 from .matcher import GTMasks
 from .point_sample import MapSet, MaskLossSums, point_sample_offsets, select_uncertain
-
-
-def _world_size():
-    return torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
 
 
 class SetCriterion(nn.Module):
@@ -62,13 +59,7 @@ class SetCriterion(nn.Module):
         dev = outs[0]["pred_logits"].device
         K = self.num_classes
         P = self.num_points
-        num_masks = sum(len(t["labels"]) for t in targets)
-        ws = _world_size()
-        if ws > 1:   # criterion.py:235-237
-            nm = torch.as_tensor([num_masks], dtype=torch.float, device=dev)
-            torch.distributed.all_reduce(nm)
-            num_masks = nm.item()
-        num_masks = max(num_masks / ws, 1.0)
+        num_masks = global_num_masks(sum(len(t["labels"]) for t in targets), dev)   # criterion.py:224-237
 
         use_dn = bool(self.training and dn_out)
         dn_outs = []
