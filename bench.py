@@ -101,12 +101,15 @@ def build_optimizer(model):
     return torch.optim.AdamW(groups, lr=1e-4, fused=True)
 
 
-def cpu_baseline(size, seconds_budget=30.0):
+def cpu_baseline(size, seconds_budget=30.0, threads=None):
     """Oracle (CPU restatement, kind 'port') of the hot path on this box's host cores:
     pixel decoder + MP decoder + criterion, forward + backward, fp32, N=1, config-B shapes."""
     from oracle import head_ref as O
     from mp_former_amd.head import MPFormerHead
-    cores = os.cpu_count() or 1
+    # the oracle is many small/medium fp32 ops: beyond ~16 threads OpenMP fork/join dominates (measured on
+    # the 256-CPU GPU box at 1024x1024: 8 thr 6.6 s/step, 16 thr 4.3, 32 thr 5.4, 256 thr > 300), so cap
+    # the thread count and report the number actually used
+    cores = threads or min(len(os.sched_getaffinity(0)), 16)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     ref = MPFormerHead()   # parameter container only (CPU tensors); the math below is the oracle's
