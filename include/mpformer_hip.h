@@ -178,6 +178,19 @@ int mpf_match_cost(const void* pred, int pred_dtype, int h, int w, const int64_t
                    int n_rows, int Tmax, int P, float w_mask, float w_dice, void* stream);
 
 /*
+ * Attention mask of the next decoder layer, fused (mask2former_transformer_decoder.py:1869-1875 +
+ * :1814-1816 + :1780): out[n, q, i] (bytes, 1 = do not attend) =
+ *   q <  pad : mp_rows[n, q, i]                       (mask-piloted queries: ground-truth rows)
+ *   q >= pad : bilinear_resize(masks[n, q], hl x wl)[i] < 0   (align_corners=False; sigmoid(x) < 0.5)
+ * and a row that is entirely 1 is written as all 0 ("attend everywhere").  One mask for all heads.
+ *   masks: base pointer of [N, Q, h, w] logits (MPF_F32 / MPF_BF16), element strides stride_n /
+ *          stride_q between images / queries, dense [h, w] planes
+ *   mp_rows [N, pad, hl*wl] bytes or NULL when pad == 0       out [N, Q, hl*wl] bytes, fully written
+ */
+int mpf_attn_mask(const void* masks, int dtype, int64_t stride_n, int64_t stride_q, int h, int w,
+                  const uint8_t* mp_rows, int pad, uint8_t* out, int N, int Q, int hl, int wl, void* stream);
+
+/*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
  * events recorded on the launch stream (kernel only: memsets and host work are outside the
  * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events

@@ -19,10 +19,22 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
 
-    def forward(self, x):
+    def scale_bias(self):
         scale = self.weight * (self.running_var + self.eps).rsqrt()
-        bias = self.bias - self.running_mean * scale
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, bias = self.scale_bias()
         return x * scale.to(x.dtype).view(1, -1, 1, 1) + bias.to(x.dtype).view(1, -1, 1, 1)
+
+
+def conv_bn(conv, bn, x):
+    """FrozenBN(conv(x)) with the fixed per-channel affine folded into the convolution
+    (w' = w * scale, bias' = bias): same function and same gradient wrt w, without two extra
+    element-wise passes over the activation per BN (forward and backward)."""
+    scale, bias = bn.scale_bias()
+    w = conv.weight * scale.view(-1, 1, 1, 1)
+    return F.conv2d(x, w, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 class Bottleneck(nn.Module):
@@ -40,10 +52,10 @@ class Bottleneck(nn.Module):
         self.norm3 = FrozenBatchNorm2d(cout)
 
     def forward(self, x):
-        out = F.relu(self.norm1(self.conv1(x)))
-        out = F.relu(self.norm2(self.conv2(out)))
-        out = self.norm3(self.conv3(out))
-        sc = x if self.shortcut is None else self.shortcut_norm(self.shortcut(x))
+        out = F.relu(conv_bn(self.conv1, self.norm1, x))
+        out = F.relu(conv_bn(self.conv2, self.norm2, out))
+        out = conv_bn(self.conv3, self.norm3, out)
+        sc = x if self.shortcut is None else conv_bn(self.shortcut, self.shortcut_norm, x)
         return F.relu(out + sc)
 
 
@@ -67,7 +79,7 @@ class ResNet50(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
-        x = F.relu(self.stem_norm(self.stem_conv(x)))
+        x = F.relu(conv_bn(self.stem_conv, self.stem_norm, x))
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
         out = {}
         for name in self.stage_names:

@@ -360,22 +360,32 @@ __global__ __launch_bounds__(kThreads) void match_cost_kernel(
     const float* __restrict__ tsamp, const int32_t* __restrict__ t_first, const int32_t* __restrict__ t_count,
     float* __restrict__ cost, int Tmax, int P, float w_mask, float w_dice)
 {
+    extern __shared__ float xs[];                    // [P] sampled logits of this row (gathered ONCE)
     __shared__ float red[kThreads / 64];
     const int row = blockIdx.x;
+    const int Tn = t_count[row];
+    if (Tn == 0) return;
     const T* pm = pred + pred_offs[row];
     const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)coord_rows[row] * P;
-    const int T0 = t_first[row], Tn = t_count[row];
+    const int T0 = t_first[row];
     float* out = cost + (int64_t)row * Tmax;
+    float sp = 0.f, sg_sum = 0.f;
+    for (int p = threadIdx.x; p < P; p += kThreads) {
+        const float2 xy = c[p];
+        const float x = sample(pm, h, w, bilin(xy.x, xy.y, h, w));
+        xs[p] = x;
+        sp += fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));          // softplus(x)
+        sg_sum += 1.f / (1.f + __expf(-x));
+    }
+    sp = block_sum(sp, red);
+    sg_sum = block_sum(sg_sum, red);                               // (block_sum's barriers publish xs)
     for (int tb = 0; tb < Tn; tb += kTT) {
-        float ax[kTT], as[kTT], at[kTT], sp = 0.f, sg_sum = 0.f;
+        float ax[kTT], as[kTT], at[kTT];
 #pragma unroll
         for (int j = 0; j < kTT; ++j) { ax[j] = 0.f; as[j] = 0.f; at[j] = 0.f; }
         for (int p = threadIdx.x; p < P; p += kThreads) {
-            const float2 xy = c[p];
-            const float x = sample(pm, h, w, bilin(xy.x, xy.y, h, w));
+            const float x = xs[p];
             const float sg = 1.f / (1.f + __expf(-x));
-            sp += fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));      // softplus(x)
-            sg_sum += sg;
 #pragma unroll
             for (int j = 0; j < kTT; ++j) {
                 if (tb + j < Tn) {
@@ -384,8 +394,6 @@ __global__ __launch_bounds__(kThreads) void match_cost_kernel(
                 }
             }
         }
-        sp = block_sum(sp, red);
-        sg_sum = block_sum(sg_sum, red);
 #pragma unroll
         for (int j = 0; j < kTT; ++j) {
             const float sx = block_sum(ax[j], red), ss = block_sum(as[j], red), st = block_sum(at[j], red);
@@ -422,16 +430,17 @@ extern "C" int mpf_match_cost(const void* pred, int pred_dtype, int h, int w, co
     if (!pred || !pred_offs || !coords || !coord_rows || !tsamp || !t_first || !t_count || !cost)
         return mpf::fail(MPF_E_NULL, "match_cost: NULL buffer");
     if (n_rows < 0 || Tmax <= 0 || P <= 0 || h <= 0 || w <= 0) return mpf::fail(MPF_E_SHAPE, "match_cost: bad sizes");
+    if ((size_t)P * 4 > 150 * 1024) return mpf::fail(MPF_E_TOO_LARGE, "match_cost: more than 38400 points per row");
     if (n_rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     mpf::prof_begin(st);
     if (pred_dtype == MPF_F32) {
         mpf::set_kernel("match_cost_kernel<float>");
-        hipLaunchKernelGGL(match_cost_kernel<float>, dim3(n_rows), dim3(kThreads), 0, st, (const float*)pred, h, w,
+        hipLaunchKernelGGL(match_cost_kernel<float>, dim3(n_rows), dim3(kThreads), (size_t)P * 4, st, (const float*)pred, h, w,
                            pred_offs, coords, coord_rows, tsamp, t_first, t_count, cost, Tmax, P, w_mask, w_dice);
     } else if (pred_dtype == MPF_BF16) {
         mpf::set_kernel("match_cost_kernel<bf16>");
-        hipLaunchKernelGGL(match_cost_kernel<__hip_bfloat16>, dim3(n_rows), dim3(kThreads), 0, st,
+        hipLaunchKernelGGL(match_cost_kernel<__hip_bfloat16>, dim3(n_rows), dim3(kThreads), (size_t)P * 4, st,
                            (const __hip_bfloat16*)pred, h, w, pred_offs, coords, coord_rows, tsamp, t_first, t_count,
                            cost, Tmax, P, w_mask, w_dice);
     } else {

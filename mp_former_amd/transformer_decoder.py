@@ -24,8 +24,33 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-from . import _rng
+from . import _lib, _rng
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
+
+
+def native_attn_mask(masks, size, mp_rows=None):
+    """[N,Qtot,h,w] mask logits (f32/bf16) -> bool [N,Qtot,hl*wl] attention mask of the next layer:
+    bilinear resize + (< 0) + MP-row overwrite + all-masked-row rule in one native kernel
+    (csrc/decoder.hip; decoder :1869-1875, :1814-1816, :1780)."""
+    if not masks.is_cuda:
+        raise RuntimeError("mp_former_amd decoder runs on the GPU only (no CPU fallback)")
+    N, Q, h, w = masks.shape
+    hl, wl = size
+    if masks.stride(3) != 1 or masks.stride(2) != w:
+        masks = masks.contiguous()
+    dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}.get(masks.dtype)
+    if dt is None:
+        masks, dt = masks.float(), _lib.MPF_F32
+    pad = 0 if mp_rows is None else mp_rows.shape[1]
+    if pad:
+        mp_rows = mp_rows.contiguous()
+    out = torch.empty((N, Q, hl * wl), dtype=torch.bool, device=masks.device)
+    with torch.cuda.device(masks.device):
+        code = _lib.lib().mpf_attn_mask(masks.data_ptr(), dt, masks.stride(0), masks.stride(1), h, w,
+                                        mp_rows.data_ptr() if pad else None, pad, out.data_ptr(), N, Q, hl, wl,
+                                        torch.cuda.current_stream(masks.device).cuda_stream)
+    _lib.check(code, "mpf_attn_mask")
+    return out
 
 
 def masked_mha(q_in, k_in, v_in, mha: nn.MultiheadAttention, mask: Optional[Tensor]):
@@ -240,12 +265,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         outputs_class = self.class_embed(decoder_output)
         mask_embed = self.mask_embed(decoder_output)
         outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features.to(mask_embed.dtype))
-        am = F.interpolate(outputs_mask.detach().float(), size=attn_mask_target_size, mode="bilinear",
-                           align_corners=False)
-        am = am.flatten(2) < 0          # sigmoid(x) < 0.5  <=>  x < 0
-        if mp_rows is not None:
-            am = torch.cat([mp_rows, am[:, mp_rows.shape[1]:]], 1)
-        am = am & ~am.all(-1, keepdim=True)
+        am = native_attn_mask(outputs_mask.detach(), attn_mask_target_size, mp_rows)
         return outputs_class, outputs_mask, am
 
     def forward(self, x, mask_features, mask=None, dn_args=None):
