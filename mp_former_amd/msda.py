@@ -19,6 +19,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.init import constant_, xavier_uniform_
 
 from . import _lib
+from .linear import linear_tall
 
 _DTYPES = {torch.float32: _lib.MPF_F32, torch.float64: _lib.MPF_F64}
 
@@ -225,13 +226,13 @@ class MSDeformAttn(nn.Module):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
-        value = self.value_proj(input_flatten)
+        value = linear_tall(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        sampling_offsets = self.sampling_offsets(query).view(
+        sampling_offsets = linear_tall(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        attention_weights = self.attention_weights(query).view(
+        attention_weights = linear_tall(query, self.attention_weights.weight, self.attention_weights.bias).view(
             N, Len_q, self.n_heads, self.n_levels * self.n_points)
         attention_weights = F.softmax(attention_weights, -1).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points)
@@ -249,4 +250,4 @@ class MSDeformAttn(nn.Module):
         output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                             sampling_locations.contiguous(), attention_weights,
                                             self.im2col_step)
-        return self.output_proj(output)
+        return linear_tall(output, self.output_proj.weight, self.output_proj.bias)

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import normal_
 
+from .linear import linear_tall
 from .msda import MSDeformAttn, attach_host_shapes
 
 
@@ -78,7 +79,8 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         src2 = self.self_attn(src if pos is None else src + pos, reference_points, src, spatial_shapes,
                               level_start_index, padding_mask)
         src = self.norm1(src + self.dropout1(src2))
-        src2 = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        src2 = linear_tall(self.dropout2(F.relu(linear_tall(src, self.linear1.weight, self.linear1.bias))),
+                           self.linear2.weight, self.linear2.bias)
         return self.norm2(src + self.dropout3(src2))
 
 
