@@ -191,6 +191,35 @@ int mpf_attn_mask(const void* masks, int dtype, int64_t stride_n, int64_t stride
                   const uint8_t* mp_rows, int pad, uint8_t* out, int N, int Q, int hl, int wl, void* stream);
 
 /*
+ * Masked multi-head attention core, forward (bf16 MFMA tiles; head_dim 32):
+ *   out[q, n, h*32+d] = sum_k softmax_k(mask(scale * Q[q,n,h,:].K[k,n,h,:]))[k] * V[k,n,h,d]
+ * — the softmax(QK^T)V of nn.MultiheadAttention as used by CrossAttentionLayer / SelfAttentionLayer
+ * (mask2former_transformer_decoder.py:42-52, :100-112) between the packed in-projection and out_proj.
+ *   q  [Lq, N, H*32] bf16      k [Lk, N, H*32] bf16      vt [N, H*32, Lk] bf16 (V transposed)
+ *   mask: bytes, 1 = masked (-inf): [N, Lq, Lk] if mask_per_image else [Lq, Lk]; NULL = no mask.
+ *         One mask for all heads.  A fully masked row yields zeros (the decoder never produces one).
+ *   out [Lq, N, H*32] bf16     lse [N, H, Lq] f32 (log-sum-exp of the scaled scores; may be NULL)
+ *   workspace: >= mpf_attn_workspace_bytes(Lq, Lk, N, H) bytes of device memory
+ */
+size_t mpf_attn_workspace_bytes(int Lq, int Lk, int N, int H);
+int mpf_attn_forward(const void* q, const void* k, const void* vt, const uint8_t* mask, int mask_per_image,
+                     void* out, float* lse, int Lq, int Lk, int N, int H, int head_dim, float scale,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Backward of mpf_attn_forward (autograd of the nn.MultiheadAttention core): dq [Lq,N,E], dk, dv
+ * [Lk,N,E] bf16 (fully written) from the upstream gradient dout [Lq,N,E] bf16, the saved lse and
+ * delta[n,h,q] = sum_d dout*out.  Besides the key-major q, k, v the kernels read the transposed
+ * companions qT, doutT [N, E, LqP] (LqP = Lq rounded up to a multiple of 32, zero padded) and kT
+ * [N, E, Lk] (the contraction index of an MFMA has to be contiguous in a lane's fragment).
+ */
+int mpf_attn_backward(const void* q, const void* k, const void* v, const void* kT, const void* qT,
+                      const void* dout, const void* doutT, const uint8_t* mask, int mask_per_image,
+                      const float* lse, const float* delta, void* dq, void* dk, void* dv,
+                      int Lq, int LqP, int Lk, int N, int H, int head_dim, float scale,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
  * events recorded on the launch stream (kernel only: memsets and host work are outside the
  * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events

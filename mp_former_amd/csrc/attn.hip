@@ -1,0 +1,516 @@
+// Masked multi-head attention (cross- and self-attention of the decoder) as bf16 MFMA tiles for
+// MI355X (gfx950): softmax(mask(Q K^T / sqrt(hd))) V per (image, head), head dim 32.
+// Reference semantics: nn.MultiheadAttention inside CrossAttentionLayer / SelfAttentionLayer
+// (mask2former_transformer_decoder.py:42-52, :100-112) with a boolean attn_mask (True = -inf).
+//
+// Shapes of this workload: few queries (Qtot = 100..300), many keys (HW up to 16 384 per level),
+// 8 heads x 32 dims.  The work is bound by streaming K / V and the byte mask, not by MFMA, so the
+// design is flash-decoding-like:
+//   * one WAVE per (16*QS query rows, head, image, key split); keys are split across waves so that the
+//     chip is filled although there are only ~14 query tiles; partial (max, sum, O) per split are merged
+//     by a small combine kernel;
+//   * S^T = K Q^T with v_mfma_f32_16x16x32_bf16: K = head dim = 32 in ONE instruction per 16 keys x 16
+//     queries.  Operands come straight from global memory in MFMA layout: a lane loads 16 contiguous
+//     bytes of a K row (A operand) / of a Q row (B operand) — no LDS staging, every K byte is read once
+//     per query tile;
+//   * the transposed product puts the queries on the lane axis (C layout: col = lane&15 = query), so a
+//     lane owns ONE query row of P: the online-softmax scale factors are per-lane scalars and the row
+//     max needs two cross-lane steps (xor 16, 32) per 32 keys;
+//   * O^T = V^T P^T: the 8 probabilities a lane holds after two 16-key tiles ARE its B fragment once
+//     the 32 keys of the block are relabelled (k = 8g+j <-> key 4g+j / 16+4g+j-4; sums do not care),
+//     and V is consumed as V^T [N, 256, Lk] (what the 1x1 projection of the NCHW feature map produces
+//     anyway), so the A fragment is two 8-byte loads per lane;
+//   * the byte attention mask [N, Lq, Lk] (one copy for all heads) is read as one dword per lane per
+//     16-key tile.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "mpf_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kHD = 32;          // head dim
+constexpr float kNegInf = -INFINITY;
+
+__device__ __forceinline__ float xmax(float v)
+{
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ float xsum(float v)
+{
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+struct AttnParams {
+    const __hip_bfloat16* q;      // [Lq, N, E]   (E = heads*32)
+    const __hip_bfloat16* k;      // [Lk, N, E]
+    const __hip_bfloat16* vt;     // [N, E, Lk]
+    const uint8_t* mask;          // [N or 1, Lq, Lk] bytes (1 = masked) or nullptr
+    int64_t mask_stride_n;        // 0 for a mask shared by all images
+    float* part_o;                // [splits, N, H, Lq, 32]   unnormalised partial O
+    float* part_ml;               // [splits, N, H, Lq, 2]    (max, sum)
+    int Lq, Lk, N, H, E, splits, keys_per_split;
+    float scale;
+};
+
+// QS = number of 16-row query sub-tiles per wave
+template <int QS>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p)
+{
+    const int lane = threadIdx.x, c16 = lane & 15, g = lane >> 4;
+    const int qtiles = (p.Lq + 16 * QS - 1) / (16 * QS);
+    const int qt = blockIdx.x % qtiles, split = blockIdx.x / qtiles;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int q0 = qt * 16 * QS;
+    const int kb0 = split * p.keys_per_split;
+    const int kb1 = min(p.Lk, kb0 + p.keys_per_split);
+    const int64_t rowE = (int64_t)p.N * p.E;                       // stride between sequence positions
+    const __hip_bfloat16* qb = p.q + (int64_t)n * p.E + h * kHD;
+    const __hip_bfloat16* kb = p.k + (int64_t)n * p.E + h * kHD;
+    const __hip_bfloat16* vb = p.vt + ((int64_t)n * p.E + h * kHD) * p.Lk;
+    const bool mask_aligned = (p.Lk & 3) == 0;
+
+    bf16x8 bq[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        const int qi = q0 + 16 * s + c16;
+        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        bq[s] = qi < p.Lq ? *reinterpret_cast<const bf16x8*>(qb + (int64_t)qi * rowE + 8 * g) : z;
+    }
+    f32x4 o[QS][2];
+    float m[QS], l[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        o[s][0] = f32x4{0, 0, 0, 0}; o[s][1] = f32x4{0, 0, 0, 0};
+        m[s] = kNegInf; l[s] = 0.f;
+    }
+
+    for (int kk = kb0; kk < kb1; kk += 32) {
+        // ---- S^T tiles: keys kk+16t .. +15 ----------------------------------------------------------
+        bf16x8 ak[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = kk + 16 * t + c16;
+            bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            ak[t] = key < kb1 ? *reinterpret_cast<const bf16x8*>(kb + (int64_t)key * rowE + 8 * g) : z;
+        }
+        // V^T fragments: rows d = 16*dt + c16, keys {kk+4g..+3} and {kk+16+4g..+3}
+        bf16x8 av[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const __hip_bfloat16* vr = vb + (int64_t)(16 * dt + c16) * p.Lk;
+            bf16x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+            const int k0 = kk + 4 * g, k1 = kk + 16 + 4 * g;
+            if (mask_aligned) {          // Lk % 4 == 0: 8-byte aligned, whole quads in range or not
+                if (k0 < kb1) lo = *reinterpret_cast<const bf16x4*>(vr + k0);
+                if (k1 < kb1) hi = *reinterpret_cast<const bf16x4*>(vr + k1);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (k0 + j < kb1) lo[j] = *reinterpret_cast<const __bf16*>(vr + k0 + j);
+                    if (k1 + j < kb1) hi[j] = *reinterpret_cast<const __bf16*>(vr + k1 + j);
+                }
+            }
+            av[dt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const int qi = q0 + 16 * s + c16;
+            float sc[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 acc = {0, 0, 0, 0};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[t], bq[s], acc, 0, 0, 0);
+                // lane (query c16, group g) holds keys kk + 16t + 4g + r
+                const int key0 = kk + 16 * t + 4 * g;
+                uint32_t mw = 0;
+                if (p.mask && qi < p.Lq) {
+                    const uint8_t* mr = p.mask + (int64_t)n * p.mask_stride_n + (int64_t)qi * p.Lk + key0;
+                    if (mask_aligned) { if (key0 < kb1) mw = *reinterpret_cast<const uint32_t*>(mr); }
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (key0 + r < kb1 && mr[r]) mw |= 0xFFu << (8 * r);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool dead = (key0 + r >= kb1) || ((mw >> (8 * r)) & 0xFFu);
+                    sc[4 * t + r] = dead ? kNegInf : acc[r] * p.scale;
+                }
+            }
+            float mx = sc[0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc[j]);
+            mx = xmax(mx);
+            const float m_new = fmaxf(m[s], mx);
+            const float alpha = (m_new == kNegInf) ? 1.f : __expf(m[s] - m_new);
+            float ps = 0.f;
+            bf16x8 bp;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float e = (m_new == kNegInf) ? 0.f : __expf(sc[j] - m_new);
+                ps += e;
+                bp[j] = (__bf16)e;
+            }
+            l[s] = l[s] * alpha + ps;
+            m[s] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                o[s][dt] *= alpha;
+                o[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[dt], bp, o[s][dt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- write the partial result of this split -------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        const int qi = q0 + 16 * s + c16;
+        const float lt = xsum(l[s]);
+        if (qi < p.Lq) {
+            const int64_t row = (((int64_t)split * p.N + n) * p.H + h) * p.Lq + qi;
+            // O^T C layout: lane (query c16, g) holds d = 16*dt + 4g + r
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                *reinterpret_cast<f32x4*>(p.part_o + row * kHD + 16 * dt + 4 * g) = o[s][dt];
+            if (g == 0) { p.part_ml[row * 2] = m[s]; p.part_ml[row * 2 + 1] = lt; }
+        }
+    }
+}
+
+// merge the key splits: out[q, n, h*32+d] (bf16) and lse[n, h, q]
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                            __hip_bfloat16* __restrict__ out, float* __restrict__ lse,
+                                                            int Lq, int N, int H, int E, int splits)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;       // over N*H*Lq*32
+    const int total = N * H * Lq * kHD;
+    if (idx >= total) return;
+    const int d = idx & 31;
+    const int row = idx >> 5;                              // (n*H + h)*Lq + q
+    const int q = row % Lq, nh = row / Lq, h = nh % H, n = nh / H;
+    const int64_t sstride = (int64_t)N * H * Lq;
+    float M = kNegInf;
+    for (int s = 0; s < splits; ++s) M = fmaxf(M, part_ml[(s * sstride + row) * 2]);
+    float L = 0.f, O = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float ms = part_ml[(s * sstride + row) * 2];
+        const float w = (ms == kNegInf) ? 0.f : __expf(ms - M);
+        L += w * part_ml[(s * sstride + row) * 2 + 1];
+        O += w * part_o[(s * sstride + row) * kHD + d];
+    }
+    out[((int64_t)q * N + n) * E + h * kHD + d] = __float2bfloat16(L > 0.f ? O / L : 0.f);
+    if (d == 0 && lse) lse[row] = (L > 0.f) ? M + __logf(L) : kNegInf;
+}
+
+
+// ================================================================================================
+// Backward.  dV = P^T dO, dP = dO V^T, dS = P o (dP - delta), dQ = scale dS K, dK = scale dS^T Q with
+// P recomputed from Q, K and the saved log-sum-exp, delta[q] = sum_d dO[q,d] O[q,d].
+//   attn_bwd_kv_kernel: one wave per (32 keys, head, image) loops over ALL queries and owns its
+//                       dK / dV rows (no atomics).  S = Q K^T puts the keys on the lane axis, so the
+//                       C tiles of dV^T / dK^T (rows = d, cols = keys) are stored key-major directly.
+//   attn_bwd_q_kernel : one wave per (32 queries, head, image, key split) loops over its keys like
+//                       the forward (queries on the lane axis) and accumulates dQ^T; splits are summed
+//                       by attn_sum_splits_kernel.
+// The contraction index of every MFMA must be contiguous in a lane's fragment, hence the transposed
+// companions Q^T, dO^T [N, E, LqP] (tiny) and K^T [N, E, Lk] next to the key-major K, V.
+// ================================================================================================
+struct AttnBwdParams {
+    const __hip_bfloat16 *q, *k, *v, *dout;        // [Lq|Lk, N, E]
+    const __hip_bfloat16 *qT, *doT;                // [N, E, LqP]  (LqP = Lq rounded up to 32, zero padded)
+    const __hip_bfloat16* kT;                      // [N, E, Lk]
+    const uint8_t* mask; int64_t mask_stride_n;
+    const float *lse, *delta;                      // [N, H, Lq]
+    __hip_bfloat16 *dk, *dv;                       // [Lk, N, E]
+    float* part_dq;                                // [splits, N, H, Lq, 32]
+    int Lq, LqP, Lk, N, H, E, splits, keys_per_split;
+    float scale;
+};
+
+__device__ __forceinline__ bf16x8 load8(const __hip_bfloat16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+
+// two 8-byte pieces (4 + 4 consecutive elements) of a row -> one MFMA fragment
+__device__ __forceinline__ bf16x8 load4x2(const __hip_bfloat16* row, int i0, int i1, int limit, bool aligned)
+{
+    bf16x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+    if (aligned) {
+        if (i0 < limit) lo = *reinterpret_cast<const bf16x4*>(row + i0);
+        if (i1 < limit) hi = *reinterpret_cast<const bf16x4*>(row + i1);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j < limit) lo[j] = *reinterpret_cast<const __bf16*>(row + i0 + j);
+            if (i1 + j < limit) hi[j] = *reinterpret_cast<const __bf16*>(row + i1 + j);
+        }
+    }
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
+{
+    const int lane = threadIdx.x, c16 = lane & 15, g = lane >> 4;
+    const int kb = blockIdx.x * 32, h = blockIdx.y, n = blockIdx.z;
+    const int64_t rowE = (int64_t)p.N * p.E;
+    const int64_t hoff = (int64_t)n * p.E + h * kHD;
+    bf16x8 bk[2], bv[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = kb + 16 * kt + c16;
+        bk[kt] = key < p.Lk ? load8(p.k + hoff + (int64_t)key * rowE + 8 * g) : zero8();
+        bv[kt] = key < p.Lk ? load8(p.v + hoff + (int64_t)key * rowE + 8 * g) : zero8();
+    }
+    f32x4 dkt[2][2], dvt[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { dkt[a][b] = f32x4{0, 0, 0, 0}; dvt[a][b] = f32x4{0, 0, 0, 0}; }
+    const float* lse = p.lse + ((int64_t)n * p.H + h) * p.Lq;
+    const float* dl = p.delta + ((int64_t)n * p.H + h) * p.Lq;
+    const __hip_bfloat16* qTb = p.qT + ((int64_t)n * p.E + h * kHD) * p.LqP;
+    const __hip_bfloat16* doTb = p.doT + ((int64_t)n * p.E + h * kHD) * p.LqP;
+
+    for (int qq = 0; qq < p.Lq; qq += 32) {
+        bf16x8 aq[2], ado[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qi = qq + 16 * qt + c16;
+            aq[qt] = qi < p.Lq ? load8(p.q + hoff + (int64_t)qi * rowE + 8 * g) : zero8();
+            ado[qt] = qi < p.Lq ? load8(p.dout + hoff + (int64_t)qi * rowE + 8 * g) : zero8();
+        }
+        float ls[2][4], de[2][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = qq + 16 * qt + 4 * g + r;
+                ls[qt][r] = qi < p.Lq ? lse[qi] : 0.f;
+                de[qt][r] = qi < p.Lq ? dl[qi] : 0.f;
+            }
+        bf16x8 bp[2], bds[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = kb + 16 * kt + c16;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 z = {0, 0, 0, 0};
+                const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[qt], bk[kt], z, 0, 0, 0);
+                const f32x4 dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado[qt], bv[kt], z, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = qq + 16 * qt + 4 * g + r;
+                    bool dead = (qi >= p.Lq) || (key >= p.Lk) || (ls[qt][r] == kNegInf);
+                    if (!dead && p.mask) dead = p.mask[(int64_t)n * p.mask_stride_n + (int64_t)qi * p.Lk + key] != 0;
+                    const float pr = dead ? 0.f : __expf(sacc[r] * p.scale - ls[qt][r]);
+                    const float ds = pr * (dpacc[r] - de[qt][r]) * p.scale;
+                    bp[kt][4 * qt + r] = (__bf16)pr;
+                    bds[kt][4 * qt + r] = (__bf16)ds;
+                }
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int64_t ro = (int64_t)(16 * dt + c16) * p.LqP;
+            const bf16x8 adoT = load4x2(doTb + ro, qq + 4 * g, qq + 16 + 4 * g, p.LqP, true);
+            const bf16x8 aqT = load4x2(qTb + ro, qq + 4 * g, qq + 16 + 4 * g, p.LqP, true);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                dvt[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adoT, bp[kt], dvt[kt][dt], 0, 0, 0);
+                dkt[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqT, bds[kt], dkt[kt][dt], 0, 0, 0);
+            }
+        }
+    }
+    // C tiles: rows d = 16dt + 4g + r, cols = key c16  ->  key-major 8-byte stores
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = kb + 16 * kt + c16;
+        if (key < p.Lk) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x4 kk = {(__bf16)dkt[kt][dt][0], (__bf16)dkt[kt][dt][1], (__bf16)dkt[kt][dt][2], (__bf16)dkt[kt][dt][3]};
+                const bf16x4 vv = {(__bf16)dvt[kt][dt][0], (__bf16)dvt[kt][dt][1], (__bf16)dvt[kt][dt][2], (__bf16)dvt[kt][dt][3]};
+                *reinterpret_cast<bf16x4*>(p.dk + hoff + (int64_t)key * rowE + 16 * dt + 4 * g) = kk;
+                *reinterpret_cast<bf16x4*>(p.dv + hoff + (int64_t)key * rowE + 16 * dt + 4 * g) = vv;
+            }
+        }
+    }
+}
+
+template <int QS>
+__global__ __launch_bounds__(64) void attn_bwd_q_kernel(AttnBwdParams p)
+{
+    const int lane = threadIdx.x, c16 = lane & 15, g = lane >> 4;
+    const int qtiles = (p.Lq + 16 * QS - 1) / (16 * QS);
+    const int qt = blockIdx.x % qtiles, split = blockIdx.x / qtiles;
+    const int h = blockIdx.y, n = blockIdx.z;
+    const int q0 = qt * 16 * QS;
+    const int kb0 = split * p.keys_per_split;
+    const int kb1 = min(p.Lk, kb0 + p.keys_per_split);
+    const int64_t rowE = (int64_t)p.N * p.E;
+    const int64_t hoff = (int64_t)n * p.E + h * kHD;
+    const __hip_bfloat16* kTb = p.kT + ((int64_t)n * p.E + h * kHD) * p.Lk;
+    const bool aligned = (p.Lk & 3) == 0;
+    bf16x8 bq[QS], bdo[QS];
+    float ls[QS], de[QS];
+    f32x4 dq[QS][2];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        const int qi = q0 + 16 * s + c16;
+        bq[s] = qi < p.Lq ? load8(p.q + hoff + (int64_t)qi * rowE + 8 * g) : zero8();
+        bdo[s] = qi < p.Lq ? load8(p.dout + hoff + (int64_t)qi * rowE + 8 * g) : zero8();
+        ls[s] = qi < p.Lq ? p.lse[((int64_t)n * p.H + h) * p.Lq + qi] : kNegInf;
+        de[s] = qi < p.Lq ? p.delta[((int64_t)n * p.H + h) * p.Lq + qi] : 0.f;
+        dq[s][0] = f32x4{0, 0, 0, 0}; dq[s][1] = f32x4{0, 0, 0, 0};
+    }
+    for (int kk = kb0; kk < kb1; kk += 32) {
+        bf16x8 ak[2], av[2], akT[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = kk + 16 * t + c16;
+            ak[t] = key < kb1 ? load8(p.k + hoff + (int64_t)key * rowE + 8 * g) : zero8();
+            av[t] = key < kb1 ? load8(p.v + hoff + (int64_t)key * rowE + 8 * g) : zero8();
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            akT[dt] = load4x2(kTb + (int64_t)(16 * dt + c16) * p.Lk, kk + 4 * g, kk + 16 + 4 * g, kb1, aligned);
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            const int qi = q0 + 16 * s + c16;
+            bf16x8 bds;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 z = {0, 0, 0, 0};
+                const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[t], bq[s], z, 0, 0, 0);
+                const f32x4 dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[t], bdo[s], z, 0, 0, 0);
+                const int key0 = kk + 16 * t + 4 * g;
+                uint32_t mw = 0;
+                if (p.mask && qi < p.Lq) {
+                    const uint8_t* mr = p.mask + (int64_t)n * p.mask_stride_n + (int64_t)qi * p.Lk + key0;
+                    if (aligned) { if (key0 < kb1) mw = *reinterpret_cast<const uint32_t*>(mr); }
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (key0 + r < kb1 && mr[r]) mw |= 0xFFu << (8 * r);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool dead = (key0 + r >= kb1) || ((mw >> (8 * r)) & 0xFFu) || (ls[s] == kNegInf);
+                    const float pr = dead ? 0.f : __expf(sacc[r] * p.scale - ls[s]);
+                    bds[4 * t + r] = (__bf16)(pr * (dpacc[r] - de[s]) * p.scale);
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                dq[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(akT[dt], bds, dq[s][dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        const int qi = q0 + 16 * s + c16;
+        if (qi < p.Lq) {
+            const int64_t row = (((int64_t)split * p.N + n) * p.H + h) * p.Lq + qi;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                *reinterpret_cast<f32x4*>(p.part_dq + row * kHD + 16 * dt + 4 * g) = dq[s][dt];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_sum_splits_kernel(const float* __restrict__ part, __hip_bfloat16* __restrict__ out,
+                                                               int Lq, int N, int H, int E, int splits)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = N * H * Lq * kHD;
+    if (idx >= total) return;
+    const int d = idx & 31, row = idx >> 5;
+    const int q = row % Lq, nh = row / Lq, h = nh % H, n = nh / H;
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += part[((int64_t)s * N * H * Lq + row) * kHD + d];
+    out[((int64_t)q * N + n) * E + h * kHD + d] = __float2bfloat16(acc);
+}
+
+}  // namespace
+
+extern "C" size_t mpf_attn_workspace_bytes(int Lq, int Lk, int N, int H)
+{
+    if (Lq <= 0 || Lk <= 0 || N <= 0 || H <= 0) return 0;
+    const int splits = (Lk + 1023) / 1024;
+    return (size_t)splits * N * H * Lq * (kHD + 2) * sizeof(float);
+}
+
+extern "C" int mpf_attn_forward(const void* q, const void* k, const void* vt, const uint8_t* mask, int mask_per_image,
+                                void* out, float* lse, int Lq, int Lk, int N, int H, int head_dim, float scale,
+                                void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!q || !k || !vt || !out || !workspace) return mpf::fail(MPF_E_NULL, "attn_forward: NULL buffer");
+    if (head_dim != kHD) return mpf::fail(MPF_E_SHAPE, "attn_forward: head_dim must be 32");
+    if (Lq <= 0 || Lk <= 0 || N <= 0 || H <= 0) return mpf::fail(MPF_E_SHAPE, "attn_forward: bad sizes");
+    if (workspace_bytes < mpf_attn_workspace_bytes(Lq, Lk, N, H)) return mpf::fail(MPF_E_SHAPE, "attn_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    AttnParams p;
+    p.q = (const __hip_bfloat16*)q; p.k = (const __hip_bfloat16*)k; p.vt = (const __hip_bfloat16*)vt;
+    p.mask = mask; p.mask_stride_n = mask_per_image ? (int64_t)Lq * Lk : 0;
+    p.Lq = Lq; p.Lk = Lk; p.N = N; p.H = H; p.E = H * kHD; p.scale = scale;
+    p.splits = (Lk + 1023) / 1024;
+    p.keys_per_split = (((Lk + p.splits - 1) / p.splits) + 31) & ~31;
+    p.part_o = (float*)workspace;
+    p.part_ml = p.part_o + (size_t)p.splits * N * H * Lq * kHD;
+    constexpr int QS = 2;
+    const int qtiles = (Lq + 16 * QS - 1) / (16 * QS);
+    mpf::prof_begin(st);
+    mpf::set_kernel("attn_fwd_kernel<2>");
+    hipLaunchKernelGGL(attn_fwd_kernel<QS>, dim3(qtiles * p.splits, H, N), dim3(64), 0, st, p);
+    mpf::prof_end("attn_fwd_kernel<2>", st, 2.0 * ((double)Lk * N * p.E * 2 + (double)Lq * N * p.E) + (mask ? (double)N * Lq * Lk : 0.0));
+    const int total = N * H * Lq * kHD;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p.part_o, p.part_ml,
+                       (__hip_bfloat16*)out, lse, Lq, N, H, p.E, p.splits);
+    return mpf::check(hipGetLastError(), "mpf_attn_forward");
+}
+
+extern "C" int mpf_attn_backward(const void* q, const void* k, const void* v, const void* kT, const void* qT,
+                                 const void* dout, const void* doutT, const uint8_t* mask, int mask_per_image,
+                                 const float* lse, const float* delta, void* dq, void* dk, void* dv,
+                                 int Lq, int LqP, int Lk, int N, int H, int head_dim, float scale,
+                                 void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!q || !k || !v || !kT || !qT || !dout || !doutT || !lse || !delta || !dq || !dk || !dv || !workspace)
+        return mpf::fail(MPF_E_NULL, "attn_backward: NULL buffer");
+    if (head_dim != kHD) return mpf::fail(MPF_E_SHAPE, "attn_backward: head_dim must be 32");
+    if (Lq <= 0 || Lk <= 0 || N <= 0 || H <= 0 || LqP < Lq || (LqP & 31)) return mpf::fail(MPF_E_SHAPE, "attn_backward: bad sizes");
+    if (workspace_bytes < mpf_attn_workspace_bytes(Lq, Lk, N, H)) return mpf::fail(MPF_E_SHAPE, "attn_backward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    AttnBwdParams p;
+    p.q = (const __hip_bfloat16*)q; p.k = (const __hip_bfloat16*)k; p.v = (const __hip_bfloat16*)v;
+    p.kT = (const __hip_bfloat16*)kT; p.qT = (const __hip_bfloat16*)qT;
+    p.dout = (const __hip_bfloat16*)dout; p.doT = (const __hip_bfloat16*)doutT;
+    p.mask = mask; p.mask_stride_n = mask_per_image ? (int64_t)Lq * Lk : 0;
+    p.lse = lse; p.delta = delta;
+    p.dk = (__hip_bfloat16*)dk; p.dv = (__hip_bfloat16*)dv; p.part_dq = (float*)workspace;
+    p.Lq = Lq; p.LqP = LqP; p.Lk = Lk; p.N = N; p.H = H; p.E = H * kHD; p.scale = scale;
+    p.splits = (Lk + 1023) / 1024;
+    p.keys_per_split = (((Lk + p.splits - 1) / p.splits) + 31) & ~31;
+    const double bytes = 2.0 * (4.0 * Lk * N * p.E + 4.0 * Lq * N * p.E) + (mask ? 2.0 * N * Lq * Lk : 0.0);
+    mpf::prof_begin(st);
+    mpf::set_kernel("attn_bwd_kv_kernel");
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((Lk + 31) / 32, H, N), dim3(64), 0, st, p);
+    mpf::prof_end("attn_bwd_kv_kernel", st, bytes * 0.5);
+    constexpr int QS = 2;
+    const int qtiles = (Lq + 16 * QS - 1) / (16 * QS);
+    mpf::prof_begin(st);
+    mpf::set_kernel("attn_bwd_q_kernel<2>");
+    hipLaunchKernelGGL(attn_bwd_q_kernel<QS>, dim3(qtiles * p.splits, H, N), dim3(64), 0, st, p);
+    mpf::prof_end("attn_bwd_q_kernel<2>", st, bytes * 0.5);
+    const int total = N * H * Lq * kHD;
+    hipLaunchKernelGGL(attn_sum_splits_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p.part_dq,
+                       (__hip_bfloat16*)dq, Lq, N, H, p.E, p.splits);
+    return mpf::check(hipGetLastError(), "mpf_attn_backward");
+}

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import _lib, _rng
+from .attention import attention_core
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
 
 
@@ -56,24 +57,14 @@ def native_attn_mask(masks, size, mp_rows=None):
 def masked_mha(q_in, k_in, v_in, mha: nn.MultiheadAttention, mask: Optional[Tensor]):
     """Multi-head attention with packed in-proj (nn.MultiheadAttention parameters), seq-first.
     q_in [Lq,N,E]; k_in, v_in [Lk,N,E]; mask bool, True = masked: [N,Lq,Lk] (shared by heads) or
-    [Lq,Lk]; returns [Lq,N,E].  Softmax in fp32."""
-    Lq, N, E = q_in.shape
-    Lk = k_in.shape[0]
-    h = mha.num_heads
-    hd = E // h
+    [Lq,Lk]; returns [Lq,N,E].  The projections are library GEMMs; softmax(QK^T/sqrt(hd))V runs on the
+    native bf16 MFMA kernels (csrc/attn.hip), fp32 softmax."""
+    E = q_in.shape[-1]
     w, b = mha.in_proj_weight, mha.in_proj_bias
     q = F.linear(q_in, w[:E], b[:E])
     k = F.linear(k_in, w[E:2 * E], b[E:2 * E])
     v = F.linear(v_in, w[2 * E:], b[2 * E:])
-    q = q.reshape(Lq, N, h, hd).permute(1, 2, 0, 3)      # [N,h,Lq,hd]
-    k = k.reshape(Lk, N, h, hd).permute(1, 2, 0, 3)
-    v = v.reshape(Lk, N, h, hd).permute(1, 2, 0, 3)
-    s = torch.matmul(q, k.transpose(-1, -2)).float() * (1.0 / math.sqrt(hd))
-    if mask is not None:
-        m = mask[:, None] if mask.dim() == 3 else mask[None, None]
-        s = s.masked_fill(m, float("-inf"))
-    p = torch.softmax(s, -1).to(v.dtype)
-    o = torch.matmul(p, v).permute(2, 0, 1, 3).reshape(Lq, N, E)
+    o = attention_core(q, k, v, mask, mha.num_heads)
     return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
 
 

@@ -98,7 +98,22 @@ def test_head_bf16_autocast_close_to_fp32():
         total = float(sum(losses.values()))
     finally:
         _rng.install_replay(None)
+    from mp_former_amd import _lib
     assert abs(total - float(z["total_loss"])) / float(z["total_loss"]) < 0.02, (total, float(z["total_loss"]))
+    # under AMP the decoder's attention runs on the native MFMA kernels
+    _lib.profile_enable(True)
+    _rng.install_replay(fifo_to_tags(replay, cfg, True))
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            losses, _ = h(feats, targets)
+            sum(losses.values()).backward()
+    finally:
+        _rng.install_replay(None)
+    torch.cuda.synchronize()
+    nf, _, _ = _lib.profile_get("attn_fwd_kernel")
+    nb, _, _ = _lib.profile_get("attn_bwd_kv_kernel")
+    _lib.profile_enable(False)
+    assert nf == 2 * cfg["dec_layers"] and nb == 2 * cfg["dec_layers"], (nf, nb)
 
 
 def test_head_config_A_runs_and_is_finite():
