@@ -181,7 +181,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if mdist.distributed():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -236,7 +236,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if mdist.distributed():
         dist.barrier()
         dist.destroy_process_group()
 

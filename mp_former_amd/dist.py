@@ -12,12 +12,17 @@ def world_size():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def distributed():
+    return dist.is_available() and dist.is_initialized()
+
+
 def init_from_env(backend=None, device=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
     (torch.distributed.run sets them).  Returns (rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("MPF_FORCE_DIST", "0") == "1" and "MASTER_ADDR" in os.environ   # 1-GPU test of the N>1 path
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kwargs = {"device_id": device} if (backend == "nccl" and device is not None) else {}
@@ -29,7 +34,7 @@ def global_num_masks(local_count, device):
     """clamp(all_reduce_sum(#GT masks) / world_size, min=1) as a python float (criterion.py:224-237)."""
     ws = world_size()
     n = float(local_count)
-    if ws > 1:
+    if distributed():
         t = torch.as_tensor([n], dtype=torch.float, device=device)
         dist.all_reduce(t)
         n = t.item()
@@ -38,7 +43,7 @@ def global_num_masks(local_count, device):
 
 def max_over_ranks(value, device):
     """MAX all-reduce of a python float (bench.py: step time = slowest rank)."""
-    if world_size() == 1:
+    if not distributed():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -48,7 +53,7 @@ def max_over_ranks(value, device):
 def wrap_ddp(model, device_ids=None):
     """DistributedDataParallel as Detectron2's DefaultTrainer builds it (broadcast_buffers=False) with
     gradients as bucket views; identity at world size 1."""
-    if world_size() == 1:
+    if not distributed():
         return model
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, broadcast_buffers=False,
                                                      gradient_as_bucket_view=True)
