@@ -206,6 +206,14 @@ def main():
     _lib.profile_enable(False)
     S_tok = sum((a.size // s) ** 2 for s in (8, 16, 32))
     by_b = 1344.0 * 4 * S_tok * a.batch * n_b     # algorithmic bytes: SURVEY.md §8(d), fp32, per call
+    # HBM traffic per call from rocprofv3 PMC passes (tools/pmc_msda.sh; FETCH_SIZE + WRITE_SIZE, KiB units),
+    # measured offline on the same shape — counters cannot be read from inside the process
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_msda_bwd_pmc_configB_N2.json")
+    if a.size == 1024 and a.batch == 2 and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+        traffic = round(1024.0 * sum(v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for k, v in pmc.items()
+                                     if k.startswith("msda_bwd") or k == "tile_scan_kernel"))
 
     if rank == 0:
         ips = a.batch * world * a.steps / dt
@@ -225,7 +233,7 @@ def main():
                        "tokens_per_image_S": S, "final_loss": round(final_loss, 4)},
             "roofline": {"kernel": "MSDA backward (msda_bwd_push + msda_bwd_fill + msda_bwd_pull, atomics-free)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "launches": n_b, "avg_us": round(ms_b * 1e3 / max(n_b, 1), 1),
                          "algorithmic_bytes_per_launch": round(by_b / max(n_b, 1)),
                          "also": {"kernel": "msda_fwd_tiled_f32", "launches": n_f,
