@@ -52,6 +52,24 @@ __device__ __forceinline__ void vec_store(float* p, const float (&r)[2]) {
 }
 __device__ __forceinline__ void vec_store(float* p, const float (&r)[1]) { *p = r[0]; }
 
+// Gather through a buffer descriptor: the element offset comes from the sample descriptor, and a corner
+// that contributes nothing is encoded as offset -1, which becomes a byte offset beyond num_records —
+// the hardware bounds check returns 0 for it, so the four corner loads need no branch / exec masking.
+__device__ __forceinline__ void buf_load(float (&r)[4], __amdgpu_buffer_rsrc_t rs, int elem_off, int lane_bytes) {
+    const unsigned vo = elem_off < 0 ? 0x80000000u : (unsigned)elem_off * 4u + (unsigned)lane_bytes;
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)vo, 0, 0);
+    r[0] = __int_as_float(v[0]); r[1] = __int_as_float(v[1]); r[2] = __int_as_float(v[2]); r[3] = __int_as_float(v[3]);
+}
+__device__ __forceinline__ void buf_load(float (&r)[2], __amdgpu_buffer_rsrc_t rs, int elem_off, int lane_bytes) {
+    const unsigned vo = elem_off < 0 ? 0x80000000u : (unsigned)elem_off * 4u + (unsigned)lane_bytes;
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)vo, 0, 0);
+    r[0] = __int_as_float(v[0]); r[1] = __int_as_float(v[1]);
+}
+__device__ __forceinline__ void buf_load(float (&r)[1], __amdgpu_buffer_rsrc_t rs, int elem_off, int lane_bytes) {
+    const unsigned vo = elem_off < 0 ? 0x80000000u : (unsigned)elem_off * 4u + (unsigned)lane_bytes;
+    r[0] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, 0, 0));
+}
+
 // XCD-aware tile index: workgroup b is observed to run on XCD b % 8 (speed only, never
 // correctness); give each XCD a contiguous run of tiles.  Bijective for any ntiles because the
 // grid is rounded up to a multiple of 8 and surplus workgroups exit.
@@ -83,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_tiled_f32(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ level_start, const float* __restrict__ loc,
     const float* __restrict__ attn, float* __restrict__ out,
-    int S, int M, int L, int Lq, int P, int total_qm, int ntiles)
+    int S, int M, int L, int Lq, int P, int total_qm, int ntiles, unsigned value_bytes)
 {
     constexpr int G = D / V;               // lanes per qm
     constexpr int QMB = kThreads / G;      // qm per workgroup
@@ -148,19 +166,18 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_tiled_f32(
     float acc[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) acc[i] = 0.f;
-    const float* vbase = value + j * V;
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(value), 0, value_bytes, 0x00020000);
+    const int lane_bytes = j * V * 4;
     const int it0 = g * LP;
 #pragma unroll 4
     for (int lp = 0; lp < LP; ++lp) {
         const int4 off = s_off[it0 + lp];
         const float4 w = s_w[it0 + lp];
         float v0[V], v1[V], v2[V], v3[V];
-#pragma unroll
-        for (int i = 0; i < V; ++i) { v0[i] = 0.f; v1[i] = 0.f; v2[i] = 0.f; v3[i] = 0.f; }
-        if (off.x >= 0) vec_load(v0, vbase + off.x);
-        if (off.y >= 0) vec_load(v1, vbase + off.y);
-        if (off.z >= 0) vec_load(v2, vbase + off.z);
-        if (off.w >= 0) vec_load(v3, vbase + off.w);
+        buf_load(v0, vrs, off.x, lane_bytes);
+        buf_load(v1, vrs, off.y, lane_bytes);
+        buf_load(v2, vrs, off.z, lane_bytes);
+        buf_load(v3, vrs, off.w, lane_bytes);
 #pragma unroll
         for (int i = 0; i < V; ++i)
             acc[i] += w.x * v0[i] + w.y * v1[i] + w.z * v2[i] + w.w * v3[i];
@@ -451,7 +468,8 @@ hipError_t launch_fwd_tiled(const float* value, const int64_t* shapes, const int
     const int grid = ((ntiles + 7) / 8) * 8;
     const size_t lds = (size_t)QMB * L * P * 32;
     hipLaunchKernelGGL((msda_fwd_tiled_f32<D, V>), dim3(grid), dim3(kThreads), lds, st,
-                       value, shapes, lsi, loc, attn, out, S, M, L, Lq, P, total_qm, ntiles);
+                       value, shapes, lsi, loc, attn, out, S, M, L, Lq, P, total_qm, ntiles,
+                       (unsigned)((size_t)N * S * M * D * 4));
     return hipGetLastError();
 }
 
@@ -486,7 +504,7 @@ bool tiled_ok(int batch, int S, int M, int D, int L, int Lq, int P, int dtype, i
     if (dtype != MPF_F32 || D != 32) return false;
     const int64_t nv = (int64_t)batch * S * M * D;
     const int64_t nq = (int64_t)batch * Lq * M * L * P * 2;
-    if (nv >= (1ll << 31) || nq >= (1ll << 31)) return false;
+    if (nv * 4 >= (1ll << 31) || nq >= (1ll << 31)) return false;   // value bytes < 2 GiB: byte offsets in buffer loads
     const size_t lds = (size_t)(kThreads / (D / V)) * L * P * 52;
     return lds <= 64 * 1024;
 }

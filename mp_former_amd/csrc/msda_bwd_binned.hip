@@ -49,10 +49,10 @@ struct Geom {
     int tiles_per_bm;
 };
 
-struct Entry {          // 16 bytes
-    int g_row;          // row of grad_out: (b*Lq + q)*M + m
+struct Entry {          // 16 bytes; everything the pull kernel needs is precomputed by the fill kernel
+    unsigned g_off;     // BYTE offset of the grad_out row: ((b*Lq + q)*M + m) * 128
     float w0, w1;       // weight (bilinear * attention) of pixel (y, x) and (y, x+1)
-    unsigned packed;    // yl | xl << 8 | has1 << 16     (coordinates inside the tile)
+    unsigned packed;    // bits 0..30: byte offset of pixel (y, x) in the bin's LDS image, bit 31: has1
 };
 
 // pixel coordinate of a sampling location; identical in every kernel (no contraction)
@@ -162,7 +162,7 @@ __device__ __forceinline__ float half_sum32(float v)
 __global__ __launch_bounds__(kThreads) void msda_bwd_push_kernel(
     const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
     const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
-    int* __restrict__ tile_count, Geom g, int nchunks, int nblocks, int ablate)
+    int* __restrict__ tile_count, Geom g, int nchunks, int nblocks, int ablate, unsigned value_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LP = g.L * g.P;
@@ -233,6 +233,12 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_push_kernel(
     const int lane = tid & 63, c = lane & 31;
     const int sub = tid >> 5;                         // 0..7: half-wave index in the workgroup
     const int nq2 = (ablate & 2) ? 0 : nq;
+    // corner offsets of -1 turn into an out-of-range byte offset: the buffer bounds check returns 0
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(value), 0, value_bytes, 0x00020000);
+    auto ldv = [&](int elem_off) {
+        const unsigned vo = elem_off < 0 ? 0x80000000u : (unsigned)elem_off * 4u + (unsigned)c * 4u;
+        return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(vrs, (int)vo, 0, 0));
+    };
     for (int ql = sub; ql < nq2; ql += 8) {
         const float go = grad_out[((int64_t)(b * g.Lq + q0 + ql) * g.M + m) * kD + c];
         for (int lp0 = 0; lp0 < LP; lp0 += 4) {
@@ -247,10 +253,10 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_push_kernel(
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                v[k][0] = off[k].x >= 0 ? value[off[k].x + c] : 0.f;
-                v[k][1] = off[k].y >= 0 ? value[off[k].y + c] : 0.f;
-                v[k][2] = off[k].z >= 0 ? value[off[k].z + c] : 0.f;
-                v[k][3] = off[k].w >= 0 ? value[off[k].w + c] : 0.f;
+                v[k][0] = ldv(off[k].x);
+                v[k][1] = ldv(off[k].y);
+                v[k][2] = ldv(off[k].z);
+                v[k][3] = ldv(off[k].w);
             }
             float ra[4], rx[4], ry[4];
 #pragma unroll
@@ -390,10 +396,11 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_fill_kernel(
             const int pos = tile_start[tile * 4 + (y & 3)] + (slot >= 0 ? s_base[slot] : 0) + my_idx[it][e];
             const float wy = ((e >> 1) ? sm.ly : 1.f - sm.ly) * a;
             Entry en;
-            en.g_row = g_row;
+            en.g_off = (unsigned)g_row * (unsigned)(kD * 4);
             en.w0 = wy * (wsel ? sm.lx : hx);
             en.w1 = has1 ? wy * sm.lx : 0.f;
-            en.packed = (unsigned)(y % ts) | ((unsigned)(xs % ts) << 8) | ((unsigned)has1 << 16);
+            // pixel (y, xs) inside the bin's LDS image [(ts/4) rows][ts pixels][32 ch] (rows of class y&3)
+            en.packed = (unsigned)((((y % ts) >> 2) * ts + (xs % ts)) * (kD * 4)) | ((unsigned)has1 << 31);
             entries[pos] = en;
         }
     }
@@ -404,59 +411,49 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_fill_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int kPF = 16;      // grad_out rows per load group
 
-// load the grad_out rows of entries [i0, i0+kPF) of the wave's current chunk (one entry per lane)
-__device__ __forceinline__ void pull_load(float (&gv)[kPF], const float* __restrict__ grad_out, int g_row_lane, int i0, int c)
+// load the grad_out rows of entries [i0, i0+kPF) of the wave's current chunk (one entry per lane):
+// buffer loads with the row's byte offset in an SGPR (soffset) and the channel in the VGPR offset —
+// no per-entry vector address arithmetic
+__device__ __forceinline__ void pull_load(float (&gv)[kPF], __amdgpu_buffer_rsrc_t rsrc, unsigned g_off_lane, int i0, int c4)
 {
 #pragma unroll
     for (int k = 0; k < kPF; ++k) {
-        const int gr = __builtin_amdgcn_readlane(g_row_lane, (i0 + k) & 63);   // padding lanes name row 0
-        gv[k] = grad_out[(int64_t)gr * kD + c];
+        const unsigned go = (unsigned)__builtin_amdgcn_readlane((int)g_off_lane, (i0 + k) & 63);   // padding lanes name row 0
+        gv[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, c4, (int)go, 0));
     }
 }
 
-constexpr int kCopies = 1;   // accumulator copies per bin (round-robin over entries); >1 buys LDS-level
-                             // parallelism at kCopies x the LDS footprint — measured slower (occupancy), kept at 1
-
-// LDS read-modify-writes of entries [i0, i0+kPF) (only those < cntw), four at a time: entry k goes to
-// accumulator copy k%4, so the four updates of a batch can never alias and their LDS reads are issued
-// back to back (one LDS round trip per 4 entries); batches stay in program order (same-copy updates of
-// consecutive batches may alias; the LDS executes a wave's accesses in order).
-__device__ __forceinline__ void pull_rmw(const float (&gv)[kPF], float* acc, int copy_stride, const Entry& mine,
-                                         int i0, int cntw, int ts, int c, int half)
+// ordered LDS read-modify-writes of entries [i0, i0+kPF) (only those < cntw).  Lanes 0-31 update pixel
+// (y, x) with w0, lanes 32-63 pixel (y, x+1) with w1; when the entry has no second pixel the upper half
+// is steered to a per-lane dummy slot (address select instead of an exec-mask branch).
+__device__ __forceinline__ void pull_rmw(const float (&gv)[kPF], char* acc_bytes, int dummy_off, int lane_off,
+                                         const Entry& mine, int i0, int cntw, bool upper)
 {
 #pragma unroll
-    for (int k0 = 0; k0 < kPF; k0 += kCopies) {
-        float cur[kCopies], wgt[kCopies];
-        float* addr[kCopies];
-        bool on[kCopies];
-#pragma unroll
-        for (int j = 0; j < kCopies; ++j) {
-            const int e = (i0 + k0 + j) & 63;
+    for (int k = 0; k < kPF; ++k) {
+        const int e = (i0 + k) & 63;
+        if (i0 + k < cntw) {                                          // wave-uniform
             const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.w0), e));
             const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.w1), e));
             const unsigned p = (unsigned)__builtin_amdgcn_readlane((int)mine.packed, e);
-            const int yl = p & 255u, xl = (p >> 8) & 255u, has1 = (p >> 16) & 1u;
-            on[j] = (i0 + k0 + j < cntw) && (!half || has1);
-            wgt[j] = half ? w1 : w0;
-            addr[j] = &acc[j * copy_stride + (((yl >> 2) * ts + xl + half) * kD) + c];
+            const int real = (int)(p & 0x7FFFFFFFu) + lane_off;
+            const int off = (upper && !(p >> 31)) ? dummy_off : real;
+            float* a = reinterpret_cast<float*>(acc_bytes + off);
+            *a += (upper ? w1 : w0) * gv[k];
         }
-#pragma unroll
-        for (int j = 0; j < kCopies; ++j) cur[j] = on[j] ? *addr[j] : 0.f;
-#pragma unroll
-        for (int j = 0; j < kCopies; ++j) if (on[j]) *addr[j] = cur[j] + wgt[j] * gv[k0 + j];
         __builtin_amdgcn_wave_barrier();
-        asm volatile("" ::: "memory");        // batches in program order
+        asm volatile("" ::: "memory");        // keep the read-modify-writes in program order
     }
 }
 
 __global__ __launch_bounds__(64) void msda_bwd_pull_kernel(
     const float* __restrict__ grad_out, const int* __restrict__ bin_start, const int* __restrict__ bin_count,
-    const Entry* __restrict__ entries, float* __restrict__ grad_value, Geom g)
+    const Entry* __restrict__ entries, float* __restrict__ grad_value, Geom g, unsigned grad_out_bytes)
 {
     // One single-wave workgroup per bin (tile x pixel-row class): the wave owns (ts/4) rows x ts pixels
     // x 32 channels in LDS and is the only writer, so plain read-modify-write needs no atomics and no
     // barriers; lanes 0-31 / 32-63 hit the two neighbouring pixels of an entry.
-    extern __shared__ __attribute__((aligned(16))) float acc[];      // [kCopies][(ts/4)*ts][32]
+    extern __shared__ __attribute__((aligned(16))) float acc[];      // [(ts/4)*ts][32] + 64 dummy floats
     const int bin = blockIdx.x;
     const int tile = bin >> 2, wave = bin & 3;         // pixel rows of this bin: y mod 4 == wave
     const int bm = tile / g.tiles_per_bm;
@@ -470,29 +467,34 @@ __global__ __launch_bounds__(64) void msda_bwd_pull_kernel(
     const int b = bm / g.M, m = bm % g.M;
     const int lane = threadIdx.x, c = lane & 31, half = lane >> 5;
     const int npix = (ts >> 2) * ts;
-    const int cstride = npix * kD;
-    for (int i = lane; i < kCopies * cstride; i += 64) acc[i] = 0.f;
+    for (int i = lane; i < npix * kD + 64; i += 64) acc[i] = 0.f;
     const int e0 = bin_start[bin], n = bin_count[bin];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_out), 0, grad_out_bytes, 0x00020000);
+    const int c4 = c * 4;
+    const int lane_off = half * (kD * 4) + c4;         // this lane's byte offset inside a pixel pair
+    const int dummy_off = (npix * kD + lane) * 4;
+    const bool upper = half != 0;
+    char* acc_bytes = reinterpret_cast<char*>(acc);
     Entry nxt;
-    nxt.g_row = 0; nxt.w0 = 0.f; nxt.w1 = 0.f; nxt.packed = 0u;
+    nxt.g_off = 0; nxt.w0 = 0.f; nxt.w1 = 0.f; nxt.packed = 0u;
     if (lane < n) nxt = entries[e0 + lane];
     for (int base = 0; base < n; base += 64) {
         const Entry mine = nxt;                        // 64 entries, one per lane; next chunk prefetched
-        nxt.g_row = 0; nxt.w0 = 0.f; nxt.w1 = 0.f; nxt.packed = 0u;
+        nxt.g_off = 0; nxt.w0 = 0.f; nxt.w1 = 0.f; nxt.packed = 0u;
         if (base + 64 + lane < n) nxt = entries[e0 + base + 64 + lane];
         const int cntw = min(64, n - base);
         // software pipeline over the 4 groups of 16: the loads of group j+1 fly during the RMWs of group j
         float ga[kPF], gb[kPF];
-        pull_load(ga, grad_out, mine.g_row, 0, c);
-        pull_load(gb, grad_out, mine.g_row, 16, c);
-        pull_rmw(ga, acc, cstride, mine, 0, cntw, ts, c, half);
+        pull_load(ga, rsrc, mine.g_off, 0, c4);
+        pull_load(gb, rsrc, mine.g_off, 16, c4);
+        pull_rmw(ga, acc_bytes, dummy_off, lane_off, mine, 0, cntw, upper);
         if (cntw > 16) {
-            pull_load(ga, grad_out, mine.g_row, 32, c);
-            pull_rmw(gb, acc, cstride, mine, 16, cntw, ts, c, half);
+            pull_load(ga, rsrc, mine.g_off, 32, c4);
+            pull_rmw(gb, acc_bytes, dummy_off, lane_off, mine, 16, cntw, upper);
             if (cntw > 32) {
-                pull_load(gb, grad_out, mine.g_row, 48, c);
-                pull_rmw(ga, acc, cstride, mine, 32, cntw, ts, c, half);
-                pull_rmw(gb, acc, cstride, mine, 48, cntw, ts, c, half);
+                pull_load(gb, rsrc, mine.g_off, 48, c4);
+                pull_rmw(ga, acc_bytes, dummy_off, lane_off, mine, 32, cntw, upper);
+                pull_rmw(gb, acc_bytes, dummy_off, lane_off, mine, 48, cntw, upper);
             }
         }
     }
@@ -502,12 +504,8 @@ __global__ __launch_bounds__(64) void msda_bwd_pull_kernel(
     const int H = g.H[l], W = g.W[l];
     for (int p = half; p < npix; p += 2) {
         const int y = ty0 + wave + 4 * (p / ts), x = tx0 + p % ts;
-        if (y < H && x < W) {
-            float v = 0.f;
-#pragma unroll
-            for (int j = 0; j < kCopies; ++j) v += acc[j * cstride + p * kD + c];
-            grad_value[(((int64_t)b * g.S + g.start[l] + (int64_t)y * W + x) * g.M + m) * kD + c] = v;
-        }
+        if (y < H && x < W)
+            grad_value[(((int64_t)b * g.S + g.start[l] + (int64_t)y * W + x) * g.M + m) * kD + c] = acc[p * kD + c];
     }
 }
 
@@ -574,7 +572,8 @@ extern "C" int mpf_msda_backward_ws(const void* value, const int64_t* host_spati
     Geom g;
     if (!build_geom(g, host_spatial_shapes, N, S, M, L, Lq, P))
         return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: unsupported level geometry (L <= 8, L*P <= 32, sum HW == S)");
-    if ((int64_t)N * S * M * D >= (1ll << 31) || (int64_t)N * Lq * M * L * P * 4 >= (1ll << 31))
+    if ((int64_t)N * S * M * D * 4 >= (1ll << 31) || (int64_t)N * Lq * M * L * P * 4 >= (1ll << 31) ||
+        (int64_t)N * Lq * M * D * 4 >= (1ll << 32))
         return mpf::fail(MPF_E_TOO_LARGE, "msda_backward_ws: tensor too large for 32-bit indexing");
     const size_t need = mpf_msda_backward_workspace_bytes(N, M, L, Lq, P, host_spatial_shapes);
     if (workspace_bytes < need) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: workspace too small");
@@ -600,7 +599,7 @@ extern "C" int mpf_msda_backward_ws(const void* value, const int64_t* host_spati
     hipLaunchKernelGGL(msda_bwd_push_kernel, dim3(grid), dim3(kThreads), lds_push, st,
                        (const float*)value, (const float*)sampling_loc, (const float*)attn_weight,
                        (const float*)grad_output, (float*)grad_sampling_loc, (float*)grad_attn_weight,
-                       tile_count, g, nchunks, nblocks, g_push_ablate);
+                       tile_count, g, nchunks, nblocks, g_push_ablate, (unsigned)((size_t)N * S * M * D * 4));
     mpf::prof_end("msda_bwd_push_kernel", st, bytes_push);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, tile_start, total, T);
     mpf::prof_begin(st);
@@ -612,8 +611,9 @@ extern "C" int mpf_msda_backward_ws(const void* value, const int64_t* host_spati
     mpf::set_kernel("msda_bwd_pull_kernel");
     int ts_max = 4;
     for (int l = 0; l < L; ++l) ts_max = g.ts[l] > ts_max ? g.ts[l] : ts_max;
-    hipLaunchKernelGGL(msda_bwd_pull_kernel, dim3(T), dim3(64), (size_t)kCopies * (ts_max / 4) * ts_max * kD * 4, st,
-                       (const float*)grad_output, tile_start, tile_count, entries, (float*)grad_value, g);
+    hipLaunchKernelGGL(msda_bwd_pull_kernel, dim3(T), dim3(64), (size_t)(ts_max / 4) * ts_max * kD * 4 + 256, st,
+                       (const float*)grad_output, tile_start, tile_count, entries, (float*)grad_value, g,
+                       (unsigned)((size_t)N * Lq * M * D * 4));
     mpf::prof_end("msda_bwd_pull_kernel", st, esz * ((double)N * Lq * M * D + (double)N * S * M * D));
     mpf::set_kernel("msda_bwd_binned(push+fill+pull)");
     return mpf::check(hipGetLastError(), "mpf_msda_backward_ws");
