@@ -220,6 +220,14 @@ int mpf_attn_backward(const void* q, const void* k, const void* v, const void* k
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Layout helpers of the attention kernels (bf16): aT, bT [N, E, LP] = transposes of a, b [L, N, E],
+ * zero padded to LP >= L (K^T and V^T for the forward / backward, Q^T and dO^T for the backward), and
+ * delta[n, h, q] = sum_d dout[q, n, h*32+d] * out[q, n, h*32+d].
+ */
+int mpf_attn_transpose2(const void* a, const void* b, void* aT, void* bT, int L, int LP, int N, int E, void* stream);
+int mpf_attn_delta(const void* dout, const void* out, float* delta, int Lq, int N, int H, void* stream);
+
+/*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
  * events recorded on the launch stream (kernel only: memsets and host work are outside the
  * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events

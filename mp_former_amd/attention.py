@@ -37,54 +37,58 @@ class _AttnCore(Function):
         if hd != 32:
             raise RuntimeError("native attention supports head_dim 32 (NHEADS 8 x HIDDEN_DIM 256)")
         qb, kb, vb = (t.to(torch.bfloat16).contiguous() for t in (q, k, v))
-        vt = vb.permute(1, 2, 0).contiguous()                      # [N, E, Lk]
+        lib = _lib.lib()
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        kt = torch.empty((N, E, Lk), dtype=torch.bfloat16, device=q.device)      # K^T is for the backward
+        vt = torch.empty((N, E, Lk), dtype=torch.bfloat16, device=q.device)
+        with torch.cuda.device(q.device):
+            _lib.check(lib.mpf_attn_transpose2(kb.data_ptr(), vb.data_ptr(), kt.data_ptr(), vt.data_ptr(), Lk, Lk, N, E, stream),
+                       "mpf_attn_transpose2")
         m = None
         if mask is not None:
             m = mask.contiguous()
             assert m.dtype == torch.bool and m.shape[-2:] == (Lq, Lk)
         out = torch.empty((Lq, N, E), dtype=torch.bfloat16, device=q.device)
         lse = torch.empty((N, nheads, Lq), dtype=torch.float32, device=q.device)
-        lib = _lib.lib()
         ws = _workspace(q.device, lib.mpf_attn_workspace_bytes(Lq, Lk, N, nheads))
         with torch.cuda.device(q.device):
             code = lib.mpf_attn_forward(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), m.data_ptr() if m is not None else None,
                                         1 if (m is not None and m.dim() == 3) else 0, out.data_ptr(), lse.data_ptr(),
-                                        Lq, Lk, N, nheads, hd, 1.0 / math.sqrt(hd), ws.data_ptr(), ws.numel(),
-                                        torch.cuda.current_stream(q.device).cuda_stream)
+                                        Lq, Lk, N, nheads, hd, 1.0 / math.sqrt(hd), ws.data_ptr(), ws.numel(), stream)
         _lib.check(code, "mpf_attn_forward")
-        ctx.save_for_backward(qb, kb, vb, m, out, lse)
+        ctx.save_for_backward(qb, kb, vb, kt, m, out, lse)
         ctx.nheads = nheads
         ctx.in_dtypes = (q.dtype, k.dtype, v.dtype)
         return out.to(q.dtype)
 
     @staticmethod
     def backward(ctx, go):
-        qb, kb, vb, m, out, lse = ctx.saved_tensors
+        qb, kb, vb, kT, m, out, lse = ctx.saved_tensors
         H = ctx.nheads
         Lq, N, E = qb.shape
         Lk = kb.shape[0]
         hd = E // H
         dev = qb.device
         gob = go.to(torch.bfloat16).contiguous()
-        delta = (gob.float() * out.float()).view(Lq, N, H, hd).sum(-1).permute(1, 2, 0).contiguous()   # [N,H,Lq]
+        lib = _lib.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream
         LqP = (Lq + 31) // 32 * 32
-        qT = torch.zeros((N, E, LqP), dtype=torch.bfloat16, device=dev)
-        doT = torch.zeros((N, E, LqP), dtype=torch.bfloat16, device=dev)
-        qT[:, :, :Lq] = qb.permute(1, 2, 0)
-        doT[:, :, :Lq] = gob.permute(1, 2, 0)
-        kT = kb.permute(1, 2, 0).contiguous()
+        delta = torch.empty((N, H, Lq), dtype=torch.float32, device=dev)
+        qT = torch.empty((N, E, LqP), dtype=torch.bfloat16, device=dev)
+        doT = torch.empty((N, E, LqP), dtype=torch.bfloat16, device=dev)
         dq = torch.empty_like(qb)
         dk = torch.empty_like(kb)
         dv = torch.empty_like(vb)
-        lib = _lib.lib()
         ws = _workspace(dev, lib.mpf_attn_workspace_bytes(Lq, Lk, N, H))
         with torch.cuda.device(dev):
+            _lib.check(lib.mpf_attn_delta(gob.data_ptr(), out.data_ptr(), delta.data_ptr(), Lq, N, H, stream), "mpf_attn_delta")
+            _lib.check(lib.mpf_attn_transpose2(qb.data_ptr(), gob.data_ptr(), qT.data_ptr(), doT.data_ptr(), Lq, LqP, N, E, stream),
+                       "mpf_attn_transpose2")
             code = lib.mpf_attn_backward(qb.data_ptr(), kb.data_ptr(), vb.data_ptr(), kT.data_ptr(), qT.data_ptr(),
                                          gob.data_ptr(), doT.data_ptr(), m.data_ptr() if m is not None else None,
                                          1 if (m is not None and m.dim() == 3) else 0, lse.data_ptr(), delta.data_ptr(),
                                          dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), Lq, LqP, Lk, N, H, hd,
-                                         1.0 / math.sqrt(hd), ws.data_ptr(), ws.numel(),
-                                         torch.cuda.current_stream(dev).cuda_stream)
+                                         1.0 / math.sqrt(hd), ws.data_ptr(), ws.numel(), stream)
         _lib.check(code, "mpf_attn_backward")
         tq, tk, tv = ctx.in_dtypes
         return dq.to(tq), dk.to(tk), dv.to(tv), None, None

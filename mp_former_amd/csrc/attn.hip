@@ -438,6 +438,54 @@ __global__ __launch_bounds__(256) void attn_sum_splits_kernel(const float* __res
     out[((int64_t)q * N + n) * E + h * kHD + d] = __float2bfloat16(acc);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Layout helpers (one launch each instead of a handful of permute / pad / reduce kernels):
+//   transpose2: [L, N, E] -> [N, E, LP] for two tensors at once (K and V in the forward; Q and dO in
+//               the backward), zero padded to LP >= L;
+//   delta     : delta[n, h, q] = sum_d dO[q, n, h*32+d] * O[q, n, h*32+d].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_transpose2_kernel(const __hip_bfloat16* __restrict__ a, const __hip_bfloat16* __restrict__ b,
+                                                               __hip_bfloat16* __restrict__ aT, __hip_bfloat16* __restrict__ bT,
+                                                               int L, int LP, int NE)
+{
+    // tile of 64 sequence positions x 64 columns through LDS
+    __shared__ __hip_bfloat16 ta[64][66], tb[64][66];
+    const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 4 rows per pass
+    const __hip_bfloat16 zero = __float2bfloat16(0.f);
+    for (int r = ty; r < 64; r += 4) {
+        const int l = l0 + r, c = c0 + tx;
+        const bool ok = l < L && c < NE;
+        ta[r][tx] = ok ? a[(int64_t)l * NE + c] : zero;
+        tb[r][tx] = ok ? b[(int64_t)l * NE + c] : zero;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, l = l0 + tx;
+        if (c < NE && l < LP) {
+            aT[(int64_t)c * LP + l] = ta[tx][r];
+            bT[(int64_t)c * LP + l] = tb[tx][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_delta_kernel(const __hip_bfloat16* __restrict__ dout, const __hip_bfloat16* __restrict__ out,
+                                                          float* __restrict__ delta, int Lq, int N, int H)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;               // over Lq*N*H*32, 32 lanes per (q,n,h)
+    const int d = idx & 31, row = idx >> 5;
+    const int total = Lq * N * H;
+    float v = 0.f;
+    if (row < total) v = __bfloat162float(dout[(int64_t)row * kHD + d]) * __bfloat162float(out[(int64_t)row * kHD + d]);
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o, 64);
+    if (row < total && d == 0) {
+        const int h = row % H, n = (row / H) % N, q = row / (H * N);
+        delta[((int64_t)n * H + h) * Lq + q] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t mpf_attn_workspace_bytes(int Lq, int Lk, int N, int H)
@@ -513,4 +561,28 @@ extern "C" int mpf_attn_backward(const void* q, const void* k, const void* v, co
     hipLaunchKernelGGL(attn_sum_splits_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p.part_dq,
                        (__hip_bfloat16*)dq, Lq, N, H, p.E, p.splits);
     return mpf::check(hipGetLastError(), "mpf_attn_backward");
+}
+
+extern "C" int mpf_attn_transpose2(const void* a, const void* b, void* aT, void* bT, int L, int LP, int N, int E, void* stream)
+{
+    if (!a || !b || !aT || !bT) return mpf::fail(MPF_E_NULL, "attn_transpose2: NULL buffer");
+    if (L <= 0 || LP < L || N <= 0 || E <= 0) return mpf::fail(MPF_E_SHAPE, "attn_transpose2: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int NE = N * E;
+    mpf::set_kernel("attn_transpose2_kernel");
+    hipLaunchKernelGGL(attn_transpose2_kernel, dim3((LP + 63) / 64, (NE + 63) / 64), dim3(256), 0, st,
+                       (const __hip_bfloat16*)a, (const __hip_bfloat16*)b, (__hip_bfloat16*)aT, (__hip_bfloat16*)bT, L, LP, NE);
+    return mpf::check(hipGetLastError(), "mpf_attn_transpose2");
+}
+
+extern "C" int mpf_attn_delta(const void* dout, const void* out, float* delta, int Lq, int N, int H, void* stream)
+{
+    if (!dout || !out || !delta) return mpf::fail(MPF_E_NULL, "attn_delta: NULL buffer");
+    if (Lq <= 0 || N <= 0 || H <= 0) return mpf::fail(MPF_E_SHAPE, "attn_delta: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int total = Lq * N * H * kHD;
+    mpf::set_kernel("attn_delta_kernel");
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const __hip_bfloat16*)dout,
+                       (const __hip_bfloat16*)out, delta, Lq, N, H);
+    return mpf::check(hipGetLastError(), "mpf_attn_delta");
 }

@@ -138,3 +138,38 @@ def test_head_config_A_runs_and_is_finite():
     total.backward()
     missing = [n for n, p in h.named_parameters() if p.grad is None]
     assert not missing, missing
+
+
+@pytest.mark.parametrize("name,size,chans,classes,queries,n", [
+    ("D_ade20k_swinB_640", (640, 640), (128, 256, 512, 1024), 150, 100, 2),
+    ("E_cityscapes_swinL_1024x2048", (1024, 2048), (192, 384, 768, 1536), 19, 200, 1),
+])
+def test_head_baseline_config_shapes_run(name, size, chans, classes, queries, n):
+    """BASELINE.json configs D and E (Swin channel counts, 200 queries, non-square high-resolution input):
+    one AMP forward + backward of the whole head; finite loss, every parameter gets a gradient, native
+    kernels on the path."""
+    from mp_former_amd import _lib
+    from mp_former_amd.head import MPFormerHead
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    H, W = size
+    shapes = {f"res{i + 2}": (c, s) for i, (c, s) in enumerate(zip(chans, (4, 8, 16, 32)))}
+    h = MPFormerHead(num_classes=classes, num_queries=queries, feature_shapes=shapes).to(dev).train()
+    feats = {k: torch.randn(n, c, H // s, W // s, device=dev) for k, (c, s) in shapes.items()}
+    targets = []
+    for b in range(n):
+        T = 4 + 3 * b
+        m = torch.zeros(T, H, W, dtype=torch.bool, device=dev)
+        for t in range(T):
+            m[t, 40 * t:40 * t + 200, 60 * t:60 * t + 300] = True
+        targets.append({"labels": torch.arange(T, device=dev) % classes, "masks": m, "boxes": torch.zeros(T, 4, device=dev)})
+    _lib.profile_enable(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = h.total_loss(feats, targets)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    assert not [k for k, p in h.named_parameters() if p.grad is None]
+    for kern in ("msda_fwd_tiled", "msda_bwd_pull", "attn_fwd_kernel", "attn_bwd_kv", "match_cost", "mask_loss_fwd", "attn_mask"):
+        assert _lib.profile_get(kern)[0] > 0, kern
+    _lib.profile_enable(False)
