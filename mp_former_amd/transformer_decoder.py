@@ -18,6 +18,7 @@ Differences that do not change results:
 Only dn_mode "points" with NOISE_SCALE 0 (the shipped run script) is implemented; other modes raise.
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -27,6 +28,31 @@ from torch import Tensor, nn
 from . import _lib, _rng
 from .attention import attention_core
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
+
+
+class _CastParams(torch.autograd.Function):
+    """bf16 working copies of a list of fp32 parameters in ONE multi-tensor launch (and one for the
+    gradients on the way back) instead of one cast kernel per parameter per use, which is what
+    autocast does (~280 cast launches forward and ~630 backward per decoder step).  Same numerics as
+    autocast: weights rounded to bf16 for the GEMMs, weight gradients produced in bf16 and accumulated
+    into the fp32 .grad."""
+
+    @staticmethod
+    def forward(ctx, dtype, *params):
+        outs = [torch.empty_like(p, dtype=dtype) for p in params]
+        torch._foreach_copy_(outs, [p.detach() for p in params])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        idx = [i for i, g in enumerate(grads) if g is not None]
+        outs = [torch.empty_like(grads[i], dtype=torch.float32) for i in idx]
+        if idx:
+            torch._foreach_copy_(outs, [grads[i] for i in idx])
+        res = [None] * len(grads)
+        for i, o in zip(idx, outs):
+            res[i] = o
+        return (None, *res)
 
 
 def native_attn_mask(masks, size, mp_rows=None):
@@ -54,18 +80,22 @@ def native_attn_mask(masks, size, mp_rows=None):
     return out
 
 
-def masked_mha(q_in, k_in, v_in, mha: nn.MultiheadAttention, mask: Optional[Tensor]):
-    """Multi-head attention with packed in-proj (nn.MultiheadAttention parameters), seq-first.
-    q_in [Lq,N,E]; k_in, v_in [Lk,N,E]; mask bool, True = masked: [N,Lq,Lk] (shared by heads) or
-    [Lq,Lk]; returns [Lq,N,E].  The projections are library GEMMs; softmax(QK^T/sqrt(hd))V runs on the
-    native bf16 MFMA kernels (csrc/attn.hip), fp32 softmax."""
+def masked_mha_w(q_in, k_in, v_in, w, b, wo, bo, nheads, mask: Optional[Tensor]):
+    """Multi-head attention with a packed in-projection (w [3E,E], b [3E]) and out-projection (wo, bo),
+    seq-first.  q_in [Lq,N,E]; k_in, v_in [Lk,N,E]; mask bool, True = masked: [N,Lq,Lk] (shared by
+    heads) or [Lq,Lk]; returns [Lq,N,E].  The projections are library GEMMs; softmax(QK^T/sqrt(hd))V
+    runs on the native bf16 MFMA kernels (csrc/attn.hip), fp32 softmax."""
     E = q_in.shape[-1]
-    w, b = mha.in_proj_weight, mha.in_proj_bias
     q = F.linear(q_in, w[:E], b[:E])
     k = F.linear(k_in, w[E:2 * E], b[E:2 * E])
     v = F.linear(v_in, w[2 * E:], b[2 * E:])
-    o = attention_core(q, k, v, mask, mha.num_heads)
-    return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
+    o = attention_core(q, k, v, mask, nheads)
+    return F.linear(o, wo, bo)
+
+
+def masked_mha(q_in, k_in, v_in, mha: nn.MultiheadAttention, mask: Optional[Tensor]):
+    return masked_mha_w(q_in, k_in, v_in, mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight,
+                        mha.out_proj.bias, mha.num_heads, mask)
 
 
 class SelfAttentionLayer(nn.Module):
@@ -249,27 +279,54 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             tgt_mask[max_num * i:max_num * (i + 1), :max_num * i] = True
         return dict(padding=padding, rows=rows, tgt_mask=tgt_mask, dn_args={"max_num": max_num, "pad_size": pad})
 
-    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, mp_rows=None):
-        """:1859-1877.  Returns (outputs_class, outputs_mask, attn_mask[N,Qtot,HW] bool) where the
-        attention mask already has the MP rows written (:1814-1816) and all-masked rows cleared (:1780)."""
-        decoder_output = self.decoder_norm(output).transpose(0, 1)
-        outputs_class = self.class_embed(decoder_output)
-        mask_embed = self.mask_embed(decoder_output)
+    # ---------------------------------------------------------------------------------------------
+    def _weights(self):
+        """name -> tensor for every GEMM weight / bias of the decoder.  Under autocast these are bf16
+        working copies made by ONE grouped cast (_CastParams); LayerNorm / embedding parameters stay
+        fp32 modules (autocast runs them in fp32 anyway)."""
+        named = [(n, p) for n, p in self.named_parameters()
+                 if not (".norm." in n or n.startswith("decoder_norm") or n.startswith(("query_feat", "level_embed", "label_enc")))]
+        if torch.is_autocast_enabled() and named and named[0][1].is_cuda and os.environ.get("MPF_GROUPED_CAST", "1") == "1":
+            cast = _CastParams.apply(torch.get_autocast_dtype("cuda"), *[p for _, p in named])
+            return {n: c for (n, _), c in zip(named, cast)}
+        return dict(named)
+
+    def _heads(self, W, output, mask_features, attn_mask_target_size, mp_rows=None):
+        """forward_prediction_heads (:1859-1877).  Returns (outputs_class, outputs_mask,
+        attn_mask[N,Qtot,HW] bool) where the attention mask already has the MP rows written (:1814-1816)
+        and all-masked rows cleared (:1780)."""
+        x = self.decoder_norm(output).transpose(0, 1)
+        outputs_class = F.linear(x, W["class_embed.weight"], W["class_embed.bias"])
+        e = F.relu(F.linear(x, W["mask_embed.layers.0.weight"], W["mask_embed.layers.0.bias"]))
+        e = F.relu(F.linear(e, W["mask_embed.layers.1.weight"], W["mask_embed.layers.1.bias"]))
+        mask_embed = F.linear(e, W["mask_embed.layers.2.weight"], W["mask_embed.layers.2.bias"])
         outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features.to(mask_embed.dtype))
         am = native_attn_mask(outputs_mask.detach(), attn_mask_target_size, mp_rows)
         return outputs_class, outputs_mask, am
 
+    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, mp_rows=None):
+        return self._heads(self._weights(), output, mask_features, attn_mask_target_size, mp_rows)
+
     def forward(self, x, mask_features, mask=None, dn_args=None):
         assert len(x) == self.num_feature_levels
         del mask
+        W = self._weights()
+        amp = torch.is_autocast_enabled() and x[0].is_cuda
+        adt = torch.get_autocast_dtype("cuda") if amp else None
         src, pos, kin, size_list = [], [], [], []
         for i in range(self.num_feature_levels):
             size_list.append(tuple(x[i].shape[-2:]))
             p = self.pe_layer(x[i]).flatten(2).permute(2, 0, 1)
-            s = (self.input_proj[i](x[i]).flatten(2) + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1)
+            xi = x[i]
+            if len(self.input_proj[i]._modules) or isinstance(self.input_proj[i], nn.Conv2d):   # 1x1 conv when channels differ
+                xi = F.conv2d(xi, W[f"input_proj.{i}.weight"], W[f"input_proj.{i}.bias"])
+            s = (xi.flatten(2) + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1)
+            k_in = s + p                 # key input, shared by the 3 layers that use this level
+            if amp:                      # one cast per level instead of one per use (9 uses each)
+                s, k_in = s.to(adt), k_in.to(adt)
             pos.append(p)
             src.append(s)
-            kin.append(s + p)            # key input, shared by the 3 layers that use this level
+            kin.append(k_in)
         bs = src[0].shape[1]
         device = src[0].device
         mp = self._mp_setup(dn_args, bs, size_list, device) if dn_args is not None else None
@@ -287,17 +344,28 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
                 return None
             return mp["rows"][level]
 
-        outputs_class, outputs_mask, attn_mask = self.forward_prediction_heads(output, mask_features, size_list[0], rows(0))
+        H = self.num_heads
+        outputs_class, outputs_mask, attn_mask = self._heads(W, output, mask_features, size_list[0], rows(0))
         predictions_class, predictions_mask = [outputs_class], [outputs_mask]
         for i in range(self.num_layers):
             level = i % self.num_feature_levels
-            output = self.transformer_cross_attention_layers[i](output, src[level], memory_mask=attn_mask,
-                                                                pos=pos[level], memory_plus_pos=kin[level])
-            output = self.transformer_self_attention_layers[i](output, tgt_mask=tgt_mask)
-            output = self.transformer_ffn_layers[i](output)
+            # cross-attention first (:1784-1789), post-norm
+            pre = f"transformer_cross_attention_layers.{i}.multihead_attn."
+            t2 = masked_mha_w(output, kin[level], src[level], W[pre + "in_proj_weight"], W[pre + "in_proj_bias"],
+                              W[pre + "out_proj.weight"], W[pre + "out_proj.bias"], H, attn_mask)
+            output = self.transformer_cross_attention_layers[i].norm(output + t2)
+            # self-attention (:1791-1795)
+            pre = f"transformer_self_attention_layers.{i}.self_attn."
+            t2 = masked_mha_w(output, output, output, W[pre + "in_proj_weight"], W[pre + "in_proj_bias"],
+                              W[pre + "out_proj.weight"], W[pre + "out_proj.bias"], H, tgt_mask)
+            output = self.transformer_self_attention_layers[i].norm(output + t2)
+            # FFN (:1798-1800)
+            pre = f"transformer_ffn_layers.{i}."
+            t2 = F.linear(F.relu(F.linear(output, W[pre + "linear1.weight"], W[pre + "linear1.bias"])),
+                          W[pre + "linear2.weight"], W[pre + "linear2.bias"])
+            output = self.transformer_ffn_layers[i].norm(output + t2)
             nxt = (i + 1) % self.num_feature_levels
-            outputs_class, outputs_mask, attn_mask = self.forward_prediction_heads(
-                output, mask_features, size_list[nxt], rows(nxt, i))
+            outputs_class, outputs_mask, attn_mask = self._heads(W, output, mask_features, size_list[nxt], rows(nxt, i))
             predictions_class.append(outputs_class)
             predictions_mask.append(outputs_mask)
 
