@@ -28,13 +28,38 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.to(x.dtype).view(1, -1, 1, 1) + bias.to(x.dtype).view(1, -1, 1, 1)
 
 
-def conv_bn(conv, bn, x):
+def conv_bn(conv, bn, x, folded=None):
     """FrozenBN(conv(x)) with the fixed per-channel affine folded into the convolution
     (w' = w * scale, bias' = bias): same function and same gradient wrt w, without two extra
     element-wise passes over the activation per BN (forward and backward)."""
-    scale, bias = bn.scale_bias()
-    w = conv.weight * scale.view(-1, 1, 1, 1)
+    if folded is not None:
+        w, bias = folded
+    else:
+        scale, bias = bn.scale_bias()
+        w = conv.weight * scale.view(-1, 1, 1, 1)
     return F.conv2d(x, w, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+class _FoldCast(torch.autograd.Function):
+    """All folded conv weights of the network in a few multi-tensor launches: w'_i = w_i * scale_i, cast to
+    the autocast dtype; the backward casts the gradients back to fp32 and multiplies by scale_i."""
+
+    @staticmethod
+    def forward(ctx, dtype, scales, *weights):
+        ctx.scales = scales
+        w = torch._foreach_mul([p.detach() for p in weights], scales)
+        if dtype is None:
+            return tuple(w)
+        outs = [torch.empty_like(t, dtype=dtype) for t in w]
+        torch._foreach_copy_(outs, w)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g32 = [torch.empty_like(g, dtype=torch.float32) for g in grads]
+        torch._foreach_copy_(g32, list(grads))
+        torch._foreach_mul_(g32, ctx.scales)
+        return (None, None, *g32)
 
 
 class Bottleneck(nn.Module):
@@ -51,11 +76,18 @@ class Bottleneck(nn.Module):
         self.conv3 = nn.Conv2d(cmid, cout, 1, bias=False)
         self.norm3 = FrozenBatchNorm2d(cout)
 
-    def forward(self, x):
-        out = F.relu(conv_bn(self.conv1, self.norm1, x))
-        out = F.relu(conv_bn(self.conv2, self.norm2, out))
-        out = conv_bn(self.conv3, self.norm3, out)
-        sc = x if self.shortcut is None else conv_bn(self.shortcut, self.shortcut_norm, x)
+    def pairs(self):
+        p = [(self.conv1, self.norm1), (self.conv2, self.norm2), (self.conv3, self.norm3)]
+        if self.shortcut is not None:
+            p.append((self.shortcut, self.shortcut_norm))
+        return p
+
+    def forward(self, x, fw=None):
+        f = fw if fw is not None else [None] * 4
+        out = F.relu(conv_bn(self.conv1, self.norm1, x, f[0]))
+        out = F.relu(conv_bn(self.conv2, self.norm2, out, f[1]))
+        out = conv_bn(self.conv3, self.norm3, out, f[2])
+        sc = x if self.shortcut is None else conv_bn(self.shortcut, self.shortcut_norm, x, f[3])
         return F.relu(out + sc)
 
 
@@ -79,10 +111,23 @@ class ResNet50(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
-        x = F.relu(conv_bn(self.stem_conv, self.stem_norm, x))
+        # fold + cast every conv weight of the network in a few multi-tensor launches
+        pairs = [(self.stem_conv, self.stem_norm)]
+        blocks = [b for name in self.stage_names for b in getattr(self, name)]
+        for b in blocks:
+            pairs += b.pairs()
+        sb = [bn.scale_bias() for _, bn in pairs]
+        scales = [s_.view(-1, 1, 1, 1) for s_, _ in sb]
+        dtype = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled() and x.is_cuda) else None
+        ws = _FoldCast.apply(dtype, scales, *[c.weight for c, _ in pairs])
+        folded = [(w, b_) for w, (_, b_) in zip(ws, sb)]
+        x = F.relu(conv_bn(self.stem_conv, self.stem_norm, x, folded[0]))
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
-        out = {}
+        out, k = {}, 1
         for name in self.stage_names:
-            x = getattr(self, name)(x)
+            for b in getattr(self, name):
+                n = len(b.pairs())
+                x = b(x, folded[k:k + n])
+                k += n
             out[name] = x
         return out
