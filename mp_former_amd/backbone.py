@@ -110,22 +110,26 @@ class ResNet50(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
-    def forward(self, x):
-        # fold + cast every conv weight of the network in a few multi-tensor launches
-        pairs = [(self.stem_conv, self.stem_norm)]
-        blocks = [b for name in self.stage_names for b in getattr(self, name)]
-        for b in blocks:
-            pairs += b.pairs()
+    def _fold_group(self, pairs, dtype):
+        """Fold + cast the conv weights of one stage in grouped launches.  One group per stage (not one for
+        the whole network) so that, in backward, the stage's weight gradients become ready as soon as
+        the stage has been back-propagated and DDP can start all-reducing them under the earlier stages."""
         sb = [bn.scale_bias() for _, bn in pairs]
         scales = [s_.view(-1, 1, 1, 1) for s_, _ in sb]
-        dtype = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled() and x.is_cuda) else None
         ws = _FoldCast.apply(dtype, scales, *[c.weight for c, _ in pairs])
-        folded = [(w, b_) for w, (_, b_) in zip(ws, sb)]
-        x = F.relu(conv_bn(self.stem_conv, self.stem_norm, x, folded[0]))
+        return [(w, b_) for w, (_, b_) in zip(ws, sb)]
+
+    def forward(self, x):
+        dtype = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled() and x.is_cuda) else None
+        stem = self._fold_group([(self.stem_conv, self.stem_norm)], dtype)
+        x = F.relu(conv_bn(self.stem_conv, self.stem_norm, x, stem[0]))
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
-        out, k = {}, 1
+        out = {}
         for name in self.stage_names:
-            for b in getattr(self, name):
+            blocks = list(getattr(self, name))
+            folded = self._fold_group([p for b in blocks for p in b.pairs()], dtype)
+            k = 0
+            for b in blocks:
                 n = len(b.pairs())
                 x = b(x, folded[k:k + n])
                 k += n
