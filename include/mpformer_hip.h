@@ -228,6 +228,27 @@ int mpf_attn_transpose2(const void* a, const void* b, void* aT, void* bT, int L,
 int mpf_attn_delta(const void* dout, const void* out, float* delta, int Lq, int N, int H, void* stream);
 
 /*
+ * fp32 GEMM of the pixel-decoder encoder's Linear layers (reference: nn.Linear inside
+ * ops/modules/ms_deform_attn.py:58-62,98-106 and msdeformattn.py:103-131, fp32 because
+ * msdeformattn.py:314 disables autocast) on the bf16 matrix cores: every fp32 operand is split
+ * error-free into three bf16 pieces and the six products of weight >= 2^-16 are accumulated in fp32
+ * (fp32-accurate: the dropped terms are below one fp32 rounding of the product).
+ *
+ *   C[M,N] = (A[M,K] + A2[m % a2_rows, K]) . B[N,K]^T + bias[N] + Cin[M,N] + Cin2[M,N],
+ *   then optional ReLU, then optional gate (C = gate[M,N] > 0 ? C : 0, the ReLU backward)
+ *
+ * B is passed pre-split: mpf_gemm3_split writes planes[3][rows][cols] bf16 of w[rows, cols]
+ * (transpose = 0) or planes[3][cols][rows] of its transpose (transpose = 1, for dX = dY . W).
+ * a2, bias, c_in, c_in2, gate may be NULL.  K % 32 == 0; N and all leading dimensions % 4 == 0; a2 rows
+ * have stride K.  c_in / c_in2 may alias c.
+ */
+int mpf_gemm3_split(const float* w, int rows, int cols, int transpose, void* planes, void* stream);
+int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2_rows, const void* b_planes,
+                 const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
+                 const float* gate, int64_t ldgate, float* c, int64_t ldc, int M, int N, int K,
+                 int relu, void* stream);
+
+/*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
  * events recorded on the launch stream (kernel only: memsets and host work are outside the
  * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events

@@ -42,6 +42,9 @@ SIGNATURES = {
     "mpf_attn_backward": (_c_int, [_c_vp] * 8 + [_c_int] + [_c_vp] * 5 + [_c_int] * 6 + [ctypes.c_float, _c_vp, ctypes.c_size_t, _c_vp]),
     "mpf_attn_transpose2": (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp]),
     "mpf_attn_delta": (_c_int, [_c_vp] * 3 + [_c_int] * 3 + [_c_vp]),
+    "mpf_gemm3_split": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "mpf_gemm3_tn": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64,
+                           _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward_workspace_bytes": (ctypes.c_size_t, [_c_int] * 5 + [_c_vp]),

@@ -1,0 +1,131 @@
+"""The six MSDeformAttn encoder layers of the pixel decoder as ONE autograd node.
+
+Same math as ``MSDeformAttnTransformerEncoderLayer`` x num_layers (reference
+mask2former/modeling/pixel_decoder/msdeformattn.py:92-161 with ops/modules/ms_deform_attn.py:82-125
+inside, dropout inactive, no padding mask, valid_ratios == 1), scheduled by hand:
+
+* every Linear (forward and input gradient) runs on the split-bf16 fp32 GEMM (csrc/gemm3.hip) with
+  its neighbours folded into the prologue / epilogue: ``src + pos`` is added while the A tile is
+  staged, bias / ReLU / the residual add / the ReLU-backward gate / gradient accumulation are
+  epilogues, ``sampling_offsets`` and ``attention_weights`` are one 288-wide GEMM;
+* weight gradients use the split-K batched GEMM of ``linear.py``;
+* the positional term is ``pos + level_embed[level]``: its gradient only reaches ``level_embed``, so
+  it is obtained from per-level column sums of the 288-wide gradient instead of accumulating a
+  [N, S, 256] tensor over the layers.
+
+Used by ``MSDeformAttnTransformerEncoderOnly`` when the inputs are fp32 CUDA tensors and dropout is
+inactive; ``MPF_FUSED_ENCODER=0`` selects the layer-by-layer modules (same results to fp32 round-off;
+tests/test_encoder_fused_gpu.py).
+"""
+import torch
+from torch.autograd import Function
+
+from .gemm3 import gemm3, split_weight
+from .linear import _pick_chunks
+from .msda import ms_deform_attn_backward, ms_deform_attn_forward
+
+PARAMS_PER_LAYER = 16
+_EPS = 1e-5
+
+
+def layer_params(layer):
+    a = layer.self_attn
+    return [a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,
+            a.value_proj.weight, a.value_proj.bias, a.output_proj.weight, a.output_proj.bias,
+            layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,
+            layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias]
+
+
+def _wgrad(g2, x2):
+    """dW[out, in] = g2^T . x2 as a split-K batched GEMM (see linear.py)."""
+    rows = g2.shape[0]
+    c = _pick_chunks(rows)
+    if c > 1:
+        return torch.bmm(g2.view(c, rows // c, -1).transpose(1, 2), x2.view(c, rows // c, -1)).sum(0)
+    return g2.t() @ x2
+
+
+class EncoderFn(Function):
+    @staticmethod
+    def forward(ctx, src, pos_const, level_embed, meta, *params):
+        # src [N, S, C] fp32; pos_const [S, C] (sine embedding, constant); level_embed [L, C]
+        N, S, C = src.shape
+        R = N * S
+        nl = len(params) // PARAMS_PER_LAYER
+        M, L, P = meta["n_heads"], meta["n_levels"], meta["n_points"]
+        shapes, lsi, ref, normalizer, level_idx = meta["shapes"], meta["lsi"], meta["ref"], meta["normalizer"], meta["level_idx"]
+        pos_full = pos_const + level_embed.index_select(0, level_idx)           # [S, C]
+        x = src.reshape(R, C)
+        saved = []
+        no = M * L * P * 2
+        for i in range(nl):
+            (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
+            w288 = torch.cat((wso, waw), 0)
+            b288 = torch.cat((bso, baw), 0)
+            value = gemm3(x, split_weight(wv), bv)
+            raw = gemm3(x, split_weight(w288), b288, a2=pos_full)
+            off = raw[:, :no].view(N, S, M, L, P, 2)
+            attn = torch.softmax(raw[:, no:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
+            loc = ref[None, :, None, None, None, :] + off / normalizer[None, None, None, :, None, :]
+            ao = ms_deform_attn_forward(value.view(N, S, M, C // M), shapes, lsi, loc, attn, 128).view(R, C)
+            s1 = gemm3(ao, split_weight(wo), bo, cin=x)
+            x1, mean1, rstd1 = torch.native_layer_norm(s1, [C], g1, b1, _EPS)
+            h = gemm3(x1, split_weight(w1), bb1, relu=True)
+            s2 = gemm3(h, split_weight(w2), bb2, cin=x1)
+            x2, mean2, rstd2 = torch.native_layer_norm(s2, [C], g2, b2, _EPS)
+            saved += [x, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2]
+            x = x2
+        ctx.save_for_backward(pos_full, level_embed, *params, *saved)
+        ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
+        return x.view(N, S, C)
+
+    @staticmethod
+    def backward(ctx, gout):
+        N, S, C = ctx.dims
+        R = N * S
+        meta, nl = ctx.meta, ctx.nl
+        M, L, P = meta["n_heads"], meta["n_levels"], meta["n_points"]
+        shapes, lsi, normalizer, sizes = meta["shapes"], meta["lsi"], meta["normalizer"], meta["sizes"]
+        host_shapes = getattr(shapes, "_mpf_host", None)
+        t = ctx.saved_tensors
+        pos_full, level_embed = t[0], t[1]
+        params = t[2:2 + nl * PARAMS_PER_LAYER]
+        saved = t[2 + nl * PARAMS_PER_LAYER:]
+        g = gout.reshape(R, C).contiguous()
+        no = M * L * P * 2
+        d_level = torch.zeros_like(level_embed)
+        dparams = [None] * (nl * PARAMS_PER_LAYER)
+        for i in reversed(range(nl)):
+            (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
+            (x, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2) = saved[i * 13:(i + 1) * 13]
+            dp = [None] * PARAMS_PER_LAYER
+            # norm2 <- ffn
+            ds2, dp[14], dp[15] = torch.ops.aten.native_layer_norm_backward(g, s2, [C], mean2, rstd2, g2, b2, [True, True, True])
+            dh = gemm3(ds2, split_weight(w2, transpose=True), gate=h)
+            dp[12], dp[13] = _wgrad(ds2, h), ds2.sum(0)
+            dx1 = gemm3(dh, split_weight(w1, transpose=True), cin=ds2)
+            dp[10], dp[11] = _wgrad(dh, x1), dh.sum(0)
+            # norm1 <- attention
+            ds1, dp[8], dp[9] = torch.ops.aten.native_layer_norm_backward(dx1, s1, [C], mean1, rstd1, g1, b1, [True, True, True])
+            dao = gemm3(ds1, split_weight(wo, transpose=True))
+            dp[6], dp[7] = _wgrad(ds1, ao), ds1.sum(0)
+            gv, gl, ga = ms_deform_attn_backward(value.view(N, S, M, C // M), shapes, lsi, loc, attn,
+                                                 dao.view(N, S, C), 128, host_shapes)
+            draw = torch.empty((R, no + M * L * P), dtype=torch.float32, device=g.device)
+            torch.div(gl, normalizer[None, None, None, :, None, :], out=draw[:, :no].view(N, S, M, L, P, 2))
+            draw[:, no:] = torch._softmax_backward_data(ga.view(N, S, M, L * P), attn.view(N, S, M, L * P), -1,
+                                                        torch.float32).view(R, M * L * P)
+            w288 = torch.cat((wso, waw), 0)
+            dq = gemm3(draw, split_weight(w288, transpose=True))
+            q = (x.view(N, S, C) + pos_full).view(R, C)
+            dw288 = _wgrad(draw, q)
+            # per-level column sums of draw: bias gradient and the level_embed gradient
+            lvl = torch.stack([sl.sum((0, 1)) for sl in draw.view(N, S, -1).split(sizes, 1)])       # [L, 288]
+            db288 = lvl.sum(0)
+            d_level += lvl @ w288
+            dp[0], dp[1], dp[2], dp[3] = dw288[:no], db288[:no], dw288[no:], db288[no:]
+            gv2 = gv.view(R, C)
+            g = gemm3(gv2, split_weight(wv, transpose=True), cin=ds1, cin2=dq)
+            dp[4], dp[5] = _wgrad(gv2, x), gv2.sum(0)
+            dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp
+        return (g.view(N, S, C), None, d_level, None, *dparams)

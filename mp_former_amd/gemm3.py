@@ -1,0 +1,53 @@
+"""Host binding of the split-bf16 fp32 GEMM (csrc/gemm3.hip; include/mpformer_hip.h mpf_gemm3_*).
+
+``split_weight`` turns an fp32 weight [out, in] into the three bf16 planes the kernel consumes
+(``transpose=True``: planes of W^T, the operand of dX = dY . W); ``gemm3`` runs
+C = (A + A2) . B^T + bias + Cin + Cin2, optional ReLU / ReLU-backward gate.  GPU only, fp32 only.
+"""
+import torch
+
+from . import _lib
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def split_weight(w, transpose=False):
+    assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.is_contiguous()
+    r, c = w.shape
+    out = torch.empty((3, c, r) if transpose else (3, r, c), dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.lib().mpf_gemm3_split(w.data_ptr(), r, c, 1 if transpose else 0, out.data_ptr(), _stream(w)),
+               "mpf_gemm3_split")
+    return out
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _rows(t, n):
+    assert t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.shape[1] == n
+    return t.stride(0)
+
+
+def gemm3(a, planes, bias=None, a2=None, cin=None, cin2=None, gate=None, relu=False, out=None):
+    """a [M, K] fp32 (row stride free), planes [3, N, K] bf16 -> [M, N] fp32."""
+    assert a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
+    M, K = a.shape
+    N = planes.shape[1]
+    assert planes.shape[2] == K and planes.dtype == torch.bfloat16 and planes.is_contiguous()
+    c = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert c.shape == (M, N) and c.stride(1) == 1
+    if a2 is not None:
+        assert a2.dtype == torch.float32 and a2.dim() == 2 and a2.is_contiguous() and a2.shape[1] == K
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
+    with torch.cuda.device(a.device):
+        code = _lib.lib().mpf_gemm3_tn(
+            a.data_ptr(), a.stride(0), _p(a2), a2.shape[0] if a2 is not None else 0, planes.data_ptr(), _p(bias),
+            _p(cin), _rows(cin, N) if cin is not None else 0, _p(cin2), _rows(cin2, N) if cin2 is not None else 0,
+            _p(gate), _rows(gate, N) if gate is not None else 0, c.data_ptr(), c.stride(0), M, N, K,
+            1 if relu else 0, _stream(a))
+    _lib.check(code, "mpf_gemm3_tn")
+    return c

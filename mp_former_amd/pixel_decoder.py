@@ -8,6 +8,7 @@ keyword arguments.
 GPU only: MSDeformAttn raises on CPU tensors (no fallback).
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -16,6 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import normal_
 
+from . import encoder_fused
 from .linear import linear_tall
 from .msda import MSDeformAttn, attach_host_shapes
 
@@ -131,6 +133,39 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
                 m._reset_parameters()
         normal_(self.level_embed)
 
+    def _fused_ok(self, srcs, pos_embeds):
+        """The single-node encoder (encoder_fused.py) applies: fp32 CUDA inputs, inactive dropout, a
+        batch-invariant positional embedding, 32 channels per head."""
+        if os.environ.get("MPF_FUSED_ENCODER", "1") == "0":
+            return False
+        lay = self.encoder.layers[0]
+        if self.training and (lay.dropout1.p > 0 or lay.dropout2.p > 0 or lay.dropout3.p > 0):
+            return False
+        if self.d_model // self.nhead != 32 or self.d_model % 32 != 0:
+            return False
+        for s_, p_ in zip(srcs, pos_embeds):
+            if not (s_.is_cuda and s_.dtype == torch.float32 and p_.dtype == torch.float32):
+                return False
+            if p_.shape[0] != 1 and p_.stride(0) != 0:
+                return False
+        return True
+
+    def _fused_meta(self, shapes_list, spatial_shapes, level_start_index, device):
+        key = ("meta", tuple(shapes_list), device)
+        meta = self._shape_cache.get(key)
+        if meta is None:
+            lay = self.encoder.layers[0].self_attn
+            ref = MSDeformAttnTransformerEncoder.get_reference_points(shapes_list, 1, device)[0, :, 0, :].contiguous()
+            sizes = [h * w for h, w in shapes_list]
+            meta = dict(
+                n_heads=lay.n_heads, n_levels=lay.n_levels, n_points=lay.n_points, shapes=spatial_shapes,
+                lsi=level_start_index, ref=ref, sizes=sizes,
+                normalizer=torch.tensor([[w, h] for h, w in shapes_list], dtype=torch.float32, device=device),
+                level_idx=torch.repeat_interleave(torch.arange(len(sizes), device=device),
+                                                  torch.tensor(sizes, device=device)))
+            self._shape_cache[key] = meta
+        return meta
+
     def forward(self, srcs, pos_embeds):
         shapes_list = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
         key = (tuple(shapes_list), srcs[0].device)
@@ -142,6 +177,12 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             self._shape_cache[key] = cached
         spatial_shapes, level_start_index = cached
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        if self._fused_ok(srcs, pos_embeds):
+            meta = self._fused_meta(shapes_list, spatial_shapes, level_start_index, srcs[0].device)
+            pos_const = torch.cat([p[0].flatten(1).t() for p in pos_embeds], 0).contiguous()
+            params = [t for layer in self.encoder.layers for t in encoder_fused.layer_params(layer)]
+            memory = encoder_fused.EncoderFn.apply(src_flatten, pos_const, self.level_embed, meta, *params)
+            return memory, spatial_shapes, level_start_index
         lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
                              for l, p in enumerate(pos_embeds)], 1)
         memory = self.encoder(src_flatten, spatial_shapes, level_start_index, shapes_list, lvl_pos, None)
