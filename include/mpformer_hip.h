@@ -249,6 +249,18 @@ int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2_rows, cons
                  int relu, void* stream);
 
 /*
+ * Weight-gradient form of the same GEMM (contraction over the rows of two row-major activations):
+ *   c_part[s][m][n] = sum_{r in split s} A[r, m] * (B[r, n] + B2[r % b2_rows, n]),   s = r / rows_per_split
+ * (c_part[s][n][m] if transpose_out), and optionally the per-split column sums
+ *   csum_a[s][m] = sum_r A[r, m],  csum_b[s][n] = sum_r (B + B2)[r, n]
+ * (bias gradients; summed per level they give the level_embed gradient).  The caller sums the splits.
+ * rows_per_split % 32 == 0; b2_rows >= 32 if b2 is given; Ndim % 4 == 0 unless transpose_out.
+ */
+int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t ldb, const float* b2, int64_t ldb2, int b2_rows,
+                 float* c_part, float* csum_a, float* csum_b, int R, int Mdim, int Ndim, int rows_per_split,
+                 int transpose_out, void* stream);
+
+/*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
  * events recorded on the launch stream (kernel only: memsets and host work are outside the
  * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events

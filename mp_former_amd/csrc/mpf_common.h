@@ -17,4 +17,5 @@ void prof_end(const char* name, hipStream_t st, double algorithmic_bytes);
 // per-subsystem option hooks: return 0 if handled, 1 if the key is not theirs, <0 on bad value
 int set_msda_option(const char* key, int v);
 int set_binned_option(const char* key, int v);
+int set_gemm3_option(const char* key, int v);
 }  // namespace mpf

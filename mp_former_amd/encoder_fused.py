@@ -5,10 +5,10 @@ mask2former/modeling/pixel_decoder/msdeformattn.py:92-161 with ops/modules/ms_de
 inside, dropout inactive, no padding mask, valid_ratios == 1), scheduled by hand:
 
 * every Linear (forward and input gradient) runs on the split-bf16 fp32 GEMM (csrc/gemm3.hip) with
-  its neighbours folded into the prologue / epilogue: ``src + pos`` is added while the A tile is
-  staged, bias / ReLU / the residual add / the ReLU-backward gate / gradient accumulation are
-  epilogues, ``sampling_offsets`` and ``attention_weights`` are one 288-wide GEMM;
-* weight gradients use the split-K batched GEMM of ``linear.py``;
+  its neighbours folded into the epilogue: bias / ReLU / the residual add / the ReLU-backward gate /
+  gradient accumulation; ``sampling_offsets`` and ``attention_weights`` are one 288-wide GEMM;
+* weight gradients use the split-K "NT" form of the same GEMM, which also returns the column sums of
+  the gradient operand (the bias gradients) from its staging loop;
 * the positional term is ``pos + level_embed[level]``: its gradient only reaches ``level_embed``, so
   it is obtained from per-level column sums of the 288-wide gradient instead of accumulating a
   [N, S, 256] tensor over the layers.
@@ -17,11 +17,12 @@ Used by ``MSDeformAttnTransformerEncoderOnly`` when the inputs are fp32 CUDA ten
 inactive; ``MPF_FUSED_ENCODER=0`` selects the layer-by-layer modules (same results to fp32 round-off;
 tests/test_encoder_fused_gpu.py).
 """
+import math
+
 import torch
 from torch.autograd import Function
 
-from .gemm3 import gemm3, split_weight
-from .linear import _pick_chunks
+from .gemm3 import gemm3, gemm3_nt, split_weight
 from .msda import ms_deform_attn_backward, ms_deform_attn_forward
 
 PARAMS_PER_LAYER = 16
@@ -36,13 +37,23 @@ def layer_params(layer):
             layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias]
 
 
-def _wgrad(g2, x2):
-    """dW[out, in] = g2^T . x2 as a split-K batched GEMM (see linear.py)."""
-    rows = g2.shape[0]
-    c = _pick_chunks(rows)
-    if c > 1:
-        return torch.bmm(g2.view(c, rows // c, -1).transpose(1, 2), x2.view(c, rows // c, -1)).sum(0)
-    return g2.t() @ x2
+def rows_per_split(sizes):
+    """Rows per split of the weight-gradient GEMMs: 512 measured best at config B; a divisor of every
+    level size when one exists (then no split straddles a level and the per-level column sums of the
+    288-wide gradient fall out of the per-split sums), else 512 and ``aligned`` is False."""
+    g = 0
+    for s_ in sizes:
+        g = math.gcd(g, s_)
+    for r in (512, 256, 128, 1024, 64, 32):
+        if g % r == 0:
+            return r, True
+    return 512, False
+
+
+def _wgrad(g2, x2, rps):
+    """dW[out, in] = g2^T . x2 and the bias gradient colsum(g2), both from the split-K NT GEMM."""
+    c, ca, _ = gemm3_nt(g2, x2, rps, want_csum_a=True)
+    return c.sum(0), ca.sum(0)
 
 
 class EncoderFn(Function):
@@ -63,7 +74,8 @@ class EncoderFn(Function):
             w288 = torch.cat((wso, waw), 0)
             b288 = torch.cat((bso, baw), 0)
             value = gemm3(x, split_weight(wv), bv)
-            raw = gemm3(x, split_weight(w288), b288, a2=pos_full)
+            q = (x.view(N, S, C) + pos_full).view(R, C)
+            raw = gemm3(q, split_weight(w288), b288)
             off = raw[:, :no].view(N, S, M, L, P, 2)
             attn = torch.softmax(raw[:, no:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
             loc = ref[None, :, None, None, None, :] + off / normalizer[None, None, None, :, None, :]
@@ -73,7 +85,7 @@ class EncoderFn(Function):
             h = gemm3(x1, split_weight(w1), bb1, relu=True)
             s2 = gemm3(h, split_weight(w2), bb2, cin=x1)
             x2, mean2, rstd2 = torch.native_layer_norm(s2, [C], g2, b2, _EPS)
-            saved += [x, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2]
+            saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2]
             x = x2
         ctx.save_for_backward(pos_full, level_embed, *params, *saved)
         ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
@@ -94,21 +106,29 @@ class EncoderFn(Function):
         g = gout.reshape(R, C).contiguous()
         no = M * L * P * 2
         d_level = torch.zeros_like(level_embed)
+        rps, aligned = rows_per_split(sizes)
+        split_level = None
+        if aligned:
+            key = ("split_level", rps, N)
+            split_level = meta.get(key)
+            if split_level is None:
+                split_level = meta["level_idx"][::rps].repeat(N)          # level of every split's rows
+                meta[key] = split_level
         dparams = [None] * (nl * PARAMS_PER_LAYER)
         for i in reversed(range(nl)):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            (x, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2) = saved[i * 13:(i + 1) * 13]
+            (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2) = saved[i * 14:(i + 1) * 14]
             dp = [None] * PARAMS_PER_LAYER
             # norm2 <- ffn
             ds2, dp[14], dp[15] = torch.ops.aten.native_layer_norm_backward(g, s2, [C], mean2, rstd2, g2, b2, [True, True, True])
             dh = gemm3(ds2, split_weight(w2, transpose=True), gate=h)
-            dp[12], dp[13] = _wgrad(ds2, h), ds2.sum(0)
+            dp[12], dp[13] = _wgrad(ds2, h, rps)
             dx1 = gemm3(dh, split_weight(w1, transpose=True), cin=ds2)
-            dp[10], dp[11] = _wgrad(dh, x1), dh.sum(0)
+            dp[10], dp[11] = _wgrad(dh, x1, rps)
             # norm1 <- attention
             ds1, dp[8], dp[9] = torch.ops.aten.native_layer_norm_backward(dx1, s1, [C], mean1, rstd1, g1, b1, [True, True, True])
             dao = gemm3(ds1, split_weight(wo, transpose=True))
-            dp[6], dp[7] = _wgrad(ds1, ao), ds1.sum(0)
+            dp[6], dp[7] = _wgrad(ds1, ao, rps)
             gv, gl, ga = ms_deform_attn_backward(value.view(N, S, M, C // M), shapes, lsi, loc, attn,
                                                  dao.view(N, S, C), 128, host_shapes)
             draw = torch.empty((R, no + M * L * P), dtype=torch.float32, device=g.device)
@@ -117,15 +137,19 @@ class EncoderFn(Function):
                                                         torch.float32).view(R, M * L * P)
             w288 = torch.cat((wso, waw), 0)
             dq = gemm3(draw, split_weight(w288, transpose=True))
-            q = (x.view(N, S, C) + pos_full).view(R, C)
-            dw288 = _wgrad(draw, q)
-            # per-level column sums of draw: bias gradient and the level_embed gradient
-            lvl = torch.stack([sl.sum((0, 1)) for sl in draw.view(N, S, -1).split(sizes, 1)])       # [L, 288]
+            # dW288^T = q^T . draw (288 on the 96-wide tile side) + per-split column sums of draw: the
+            # bias gradient and, summed per level, the level_embed gradient
+            cpart, _, cs = gemm3_nt(q, draw, rps, want_csum_b=True, transpose_out=True)
+            dw288 = cpart.sum(0)
+            if aligned:
+                lvl = torch.zeros((L, draw.shape[1]), dtype=torch.float32, device=g.device).index_add_(0, split_level, cs)
+            else:
+                lvl = torch.stack([sl.sum((0, 1)) for sl in draw.view(N, S, -1).split(sizes, 1)])   # [L, 288]
             db288 = lvl.sum(0)
             d_level += lvl @ w288
             dp[0], dp[1], dp[2], dp[3] = dw288[:no], db288[:no], dw288[no:], db288[no:]
             gv2 = gv.view(R, C)
             g = gemm3(gv2, split_weight(wv, transpose=True), cin=ds1, cin2=dq)
-            dp[4], dp[5] = _wgrad(gv2, x), gv2.sum(0)
+            dp[4], dp[5] = _wgrad(gv2, x, rps)
             dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp
         return (g.view(N, S, C), None, d_level, None, *dparams)

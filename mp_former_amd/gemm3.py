@@ -51,3 +51,39 @@ def gemm3(a, planes, bias=None, a2=None, cin=None, cin2=None, gate=None, relu=Fa
             1 if relu else 0, _stream(a))
     _lib.check(code, "mpf_gemm3_tn")
     return c
+
+
+def pick_rows_per_split(R, out_tiles, align=None):
+    """Rows per split of the weight-gradient GEMM: enough (tile, split) blocks to fill the chip
+    (>= ~400), a multiple of 32, and — if ``align`` is given — a divisor of it (so that no split
+    straddles a segment boundary, e.g. a feature level)."""
+    want = max(1, 400 // max(out_tiles, 1))
+    rps = max(32, (R // want) // 32 * 32)
+    if align:
+        while rps > 32 and align % rps != 0:
+            rps -= 32
+        if align % rps != 0:
+            return None
+    return rps
+
+
+def gemm3_nt(a, b, rows_per_split, b2=None, want_csum_a=False, want_csum_b=False, transpose_out=False):
+    """a [R, M], b [R, N] fp32 (row strides free) -> (c_part [nsplit, M, N] (or [nsplit, N, M]),
+    csum_a [nsplit, M] or None, csum_b [nsplit, N] or None)."""
+    assert a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] == b.shape[0]
+    R, M = a.shape
+    N = b.shape[1]
+    ns = (R + rows_per_split - 1) // rows_per_split
+    c = torch.empty((ns, N, M) if transpose_out else (ns, M, N), dtype=torch.float32, device=a.device)
+    ca = torch.empty((ns, M), dtype=torch.float32, device=a.device) if want_csum_a else None
+    cb = torch.empty((ns, N), dtype=torch.float32, device=a.device) if want_csum_b else None
+    if b2 is not None:
+        assert b2.dtype == torch.float32 and b2.dim() == 2 and b2.stride(1) == 1 and b2.shape[1] == N
+    with torch.cuda.device(a.device):
+        code = _lib.lib().mpf_gemm3_nt(
+            a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(b2), b2.stride(0) if b2 is not None else 0,
+            b2.shape[0] if b2 is not None else 0, c.data_ptr(), _p(ca), _p(cb), R, M, N, rows_per_split,
+            1 if transpose_out else 0, _stream(a))
+    _lib.check(code, "mpf_gemm3_nt")
+    return c, ca, cb

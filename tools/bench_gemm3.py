@@ -86,5 +86,97 @@ def main():
               flush=True)
 
 
+def main_nt():
+    from mp_former_amd.gemm3 import gemm3_nt, pick_rows_per_split
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    for (R, m, n, rps, b2r) in ((300, 288, 64, 64, 40), (129, 100, 36, 32, None), (672, 256, 256, 96, 336)):
+        a = torch.randn(R, m, device=dev)
+        b = torch.randn(R, n, device=dev)
+        b2 = torch.randn(b2r, n, device=dev) if b2r else None
+        bb = b.double() + (b2.double()[torch.arange(R, device=dev) % b2r] if b2r else 0)
+        ref = a.double().t() @ bb
+        for tr in (False, True):
+            c, ca, cb = gemm3_nt(a, b, rps, b2=b2, want_csum_a=True, want_csum_b=True, transpose_out=tr)
+            got = c.sum(0).double()
+            got = got.t() if tr else got
+            print(f"nt {R}x{m}x{n} tr={tr}: err {(got - ref).abs().max().item():.3e} torch {((a.t() @ bb.float()).double() - ref).abs().max().item():.3e}"
+                  f"  csum_a {(ca.sum(0).double() - a.double().sum(0)).abs().max().item():.2e} csum_b {(cb.sum(0).double() - bb.sum(0)).abs().max().item():.2e}")
+    R = 43008
+    for (m, n, name) in ((256, 256, "dW value/out"), (256, 288, "dW offsets (q x draw)"), (1024, 256, "dW ffn1"), (256, 1024, "dW ffn2")):
+        a = torch.randn(R, m, device=dev)
+        b = torch.randn(R, n, device=dev)
+        tiles = ((m + 127) // 128) * ((n + 127) // 128)
+        rps = pick_rows_per_split(R, tiles, 1024)
+        ref = a.double().t() @ b.double()
+        c, _, cb = gemm3_nt(a, b, rps, want_csum_b=True)
+        e3 = (c.sum(0).double() - ref).abs()
+        chunks = 32
+        lib = torch.bmm(a.view(chunks, R // chunks, -1).transpose(1, 2), b.view(chunks, R // chunks, -1)).sum(0)
+        el = (lib.double() - ref).abs()
+        t3 = timeit(lambda: (gemm3_nt(a, b, rps, want_csum_b=True)[0].sum(0)))
+        tl = timeit(lambda: (torch.bmm(a.view(chunks, R // chunks, -1).transpose(1, 2), b.view(chunks, R // chunks, -1)).sum(0), b.sum(0)))
+        fl = 2.0 * R * m * n
+        print(f"{name:22s} {m}x{n} rps={rps}: gemm3_nt+sum {t3:7.1f} us ({fl / t3 / 1e6:6.1f} TF)  bmm+sums {tl:7.1f} us ({fl / tl / 1e6:6.1f} TF)"
+              f"  err gemm3 {e3.max().item():.2e} torch {el.max().item():.2e}", flush=True)
+
+
+def main_ablate():
+    dev = torch.device("cuda:0")
+    M = 43008
+    for (n, k) in ((256, 256), (256, 1024), (1024, 256)):
+        a = torch.randn(M, k, device=dev)
+        w = torch.randn(n, k, device=dev)
+        planes = split(w)
+        out = []
+        for ab in (0, 1, 2, 4, 5, 6, 7):
+            _lib.set_option("gemm3_ablate", ab)
+            out.append(f"ab{ab}:{timeit(lambda: gemm3(a, planes)):6.1f}")
+        _lib.set_option("gemm3_ablate", 0)
+        print(f"N={n} K={k}: " + "  ".join(out) + " us", flush=True)
+
+
+def main_rps():
+    from mp_former_amd.gemm3 import gemm3_nt
+    dev = torch.device("cuda:0")
+    R = 43008
+    pos = torch.randn(21504, 256, device=dev)
+    for (m, n, name, b2) in ((256, 256, "dW value/out", None), (288, 256, "dW288 (draw x q, b2)", pos), (1024, 256, "dW ffn1", None),
+                             (256, 1024, "dW ffn2", None)):
+        a = torch.randn(R, m, device=dev)
+        b = torch.randn(R, n, device=dev)
+        out = []
+        for rps in (256, 512, 1024, 2048):
+            t3 = timeit(lambda: (gemm3_nt(a, b, rps, b2=b2, want_csum_a=True)[0].sum(0)))
+            out.append(f"rps{rps}:{t3:6.1f}")
+        print(f"{name:22s} {m}x{n}: " + "  ".join(out) + " us", flush=True)
+
+
+def main_one():
+    from mp_former_amd.gemm3 import gemm3_nt
+    dev = torch.device("cuda:0")
+    M = 43008
+    a = torch.randn(M, 1024, device=dev)
+    w = torch.randn(256, 1024, device=dev)
+    planes = split(w)
+    b = torch.randn(M, 256, device=dev)
+    for _ in range(3):
+        gemm3(a, planes)
+        gemm3_nt(a, b, 1024, want_csum_b=True)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
+    if "--rps" in sys.argv:
+        main_rps()
+        sys.exit(0)
+    if "--one" in sys.argv:
+        main_one()
+        sys.exit(0)
+    if "--ablate" in sys.argv:
+        main_ablate()
+        sys.exit(0)
+    if "--nt" in sys.argv:
+        main_nt()
+        sys.exit(0)
     main()
