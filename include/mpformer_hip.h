@@ -261,6 +261,16 @@ int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t ldb, const
                  int transpose_out, void* stream);
 
 /*
+ * y = relu?(x + bias[c] + res) over a dense channel-last activation (channel = fastest dimension,
+ * C % 8 == 0): the folded FrozenBatchNorm shift, the residual add and the ReLU of a ResNet
+ * bottleneck (detectron2 BottleneckBlock, used by configs/coco/instance-segmentation/Base-COCO-
+ * InstanceSegmentation.yaml:2-15) in one pass.  x, res, y: dtype MPF_BF16 or MPF_F32; bias fp32;
+ * res may be NULL; y may alias x.  Rounding points of the unfused bf16 ops are kept.
+ */
+int mpf_bias_act(const void* x, const float* bias, const void* res, void* y, int64_t numel, int C, int dtype,
+                 int relu, void* stream);
+
+/*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
  * events recorded on the launch stream (kernel only: memsets and host work are outside the
  * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events

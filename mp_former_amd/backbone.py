@@ -7,6 +7,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib
+
 
 class FrozenBatchNorm2d(nn.Module):
     """BatchNorm with fixed statistics and affine parameters (detectron2 FrozenBatchNorm2d)."""
@@ -20,24 +22,72 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
 
     def scale_bias(self):
-        scale = self.weight * (self.running_var + self.eps).rsqrt()
-        return scale, self.bias - self.running_mean * scale
+        """(scale, shift) of the fixed affine; cached — the statistics are buffers that only change
+        through load_state_dict / .to(), which bump the tensors' version counters or replace them."""
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
+               self.weight.data_ptr(), self.running_var.data_ptr(), self.weight.device)
+        c = getattr(self, "_sb_cache", None)
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                scale = self.weight * (self.running_var + self.eps).rsqrt()
+                c = (key, scale, (self.bias - self.running_mean * scale).float().contiguous())
+            self._sb_cache = c
+        return c[1], c[2]
 
     def forward(self, x):
         scale, bias = self.scale_bias()
         return x * scale.to(x.dtype).view(1, -1, 1, 1) + bias.to(x.dtype).view(1, -1, 1, 1)
 
 
-def conv_bn(conv, bn, x, folded=None):
-    """FrozenBN(conv(x)) with the fixed per-channel affine folded into the convolution
-    (w' = w * scale, bias' = bias): same function and same gradient wrt w, without two extra
-    element-wise passes over the activation per BN (forward and backward)."""
+class _BiasAct(torch.autograd.Function):
+    """relu?(x + shift[c] + res) over a channel-last activation in one native pass (csrc/elementwise.hip);
+    the shift comes from frozen buffers (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, shift, res, relu):
+        y = torch.empty_like(x)
+        C = x.shape[1]
+        code = _lib.lib().mpf_bias_act(x.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None,
+                                       y.data_ptr(), x.numel(), C, _lib.MPF_BF16 if x.dtype == torch.bfloat16 else _lib.MPF_F32,
+                                       1 if relu else 0, torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(code, "mpf_bias_act")
+        ctx.relu, ctx.has_res = relu, res is not None
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        return g, None, (g if ctx.has_res else None), None
+
+
+def bias_act(x, shift, res=None, relu=True):
+    """FrozenBN shift (+ residual) (+ ReLU) after a bias-free folded convolution."""
+    ok = (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] % 8 == 0
+          and x.is_contiguous(memory_format=torch.channels_last)
+          and (res is None or (res.dtype == x.dtype and res.shape == x.shape
+                               and res.is_contiguous(memory_format=torch.channels_last))))
+    if ok:
+        return _BiasAct.apply(x, shift, res, relu)
+    y = x + shift.to(x.dtype).view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res
+    return F.relu(y) if relu else y
+
+
+def conv_bn(conv, bn, x, folded=None, res=None, relu=True):
+    """relu?(FrozenBN(conv(x)) + res) with the fixed per-channel scale folded into the convolution
+    weight (w' = w * scale: same function, same gradient wrt w) and shift / residual / ReLU as ONE
+    element-wise pass over the activation instead of MIOpen's bias kernel + add + ReLU."""
     if folded is not None:
-        w, bias = folded
+        w, shift = folded
     else:
-        scale, bias = bn.scale_bias()
+        scale, shift = bn.scale_bias()
         w = conv.weight * scale.view(-1, 1, 1, 1)
-    return F.conv2d(x, w, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return bias_act(F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups), shift, res, relu)
 
 
 class _FoldCast(torch.autograd.Function):
@@ -84,11 +134,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x, fw=None):
         f = fw if fw is not None else [None] * 4
-        out = F.relu(conv_bn(self.conv1, self.norm1, x, f[0]))
-        out = F.relu(conv_bn(self.conv2, self.norm2, out, f[1]))
-        out = conv_bn(self.conv3, self.norm3, out, f[2])
-        sc = x if self.shortcut is None else conv_bn(self.shortcut, self.shortcut_norm, x, f[3])
-        return F.relu(out + sc)
+        out = conv_bn(self.conv1, self.norm1, x, f[0])
+        out = conv_bn(self.conv2, self.norm2, out, f[1])
+        sc = x if self.shortcut is None else conv_bn(self.shortcut, self.shortcut_norm, x, f[3], relu=False)
+        return conv_bn(self.conv3, self.norm3, out, f[2], res=sc)
 
 
 class ResNet50(nn.Module):
@@ -122,7 +171,7 @@ class ResNet50(nn.Module):
     def forward(self, x):
         dtype = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled() and x.is_cuda) else None
         stem = self._fold_group([(self.stem_conv, self.stem_norm)], dtype)
-        x = F.relu(conv_bn(self.stem_conv, self.stem_norm, x, stem[0]))
+        x = conv_bn(self.stem_conv, self.stem_norm, x, stem[0])
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
         out = {}
         for name in self.stage_names:

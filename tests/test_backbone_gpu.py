@@ -1,0 +1,64 @@
+"""Bench backbone pieces: the fused shift/residual/ReLU epilogue (csrc/elementwise.hip) against the torch
+ops it replaces (bit-exact: same rounding points of the activation), and a folded bottleneck against
+conv -> FrozenBN -> ReLU composed from torch ops (fp32), forward and gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False)])
+def test_bias_act_matches_torch(dtype, with_res, relu):
+    from mp_former_amd.backbone import bias_act
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    x = torch.randn(2, 64, 9, 7, device=dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    res = torch.randn(2, 64, 9, 7, device=dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True) if with_res else None
+    shift = torch.randn(64, device=dev)
+    y = bias_act(x, shift, res, relu)
+    # the shift stays fp32 inside the kernel (the torch composition would round it to bf16 first);
+    # the activation is rounded where the unfused ops round it
+    ref = (x.detach().float() + shift.view(1, -1, 1, 1)).to(dtype)
+    if with_res:
+        ref = (ref.float() + res.detach().float()).to(dtype)
+    ref = F.relu(ref) if relu else ref
+    assert torch.equal(y, ref)
+    g = torch.randn_like(y)
+    y.backward(g)
+    gref = g * (ref > 0) if relu else g
+    assert torch.equal(x.grad, gref)
+    if with_res:
+        assert torch.equal(res.grad, gref)
+
+
+def test_folded_bottleneck_matches_unfolded_fp32():
+    from mp_former_amd.backbone import Bottleneck
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    blk = Bottleneck(64, 32, 128, 2).to(dev)
+    for m in blk.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 2.0); m.running_mean.normal_(); m.weight.uniform_(0.5, 1.5); m.bias.normal_()
+    x = torch.randn(2, 64, 16, 16, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = blk(x)
+    y.sum().backward()
+    gx = x.grad.clone()
+    gw = {n: p.grad.clone() for n, p in blk.named_parameters()}
+    x.grad = None
+    for p in blk.parameters():
+        p.grad = None
+
+    def bn(m, t):
+        return F.batch_norm(t, m.running_mean, m.running_var, m.weight, m.bias, False, 0.0, m.eps)
+
+    o = F.relu(bn(blk.norm1, F.conv2d(x, blk.conv1.weight)))
+    o = F.relu(bn(blk.norm2, F.conv2d(o, blk.conv2.weight, None, 2, 1)))
+    o = bn(blk.norm3, F.conv2d(o, blk.conv3.weight))
+    ref = F.relu(o + bn(blk.shortcut_norm, F.conv2d(x, blk.shortcut.weight, None, 2)))
+    ref.sum().backward()
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gx, x.grad, rtol=1e-3, atol=1e-3)
+    for n, p in blk.named_parameters():
+        torch.testing.assert_close(gw[n], p.grad, rtol=1e-3, atol=1e-3)

@@ -20,6 +20,7 @@ def main():
     batches = [bench.synth_batch(2, 1024, 80, i, dev) for i in range(2)]
     names = ["backbone_fwd", "pixdec_fwd", "decoder_fwd", "criterion_fwd", "backward", "clip", "adamw"]
     acc = {n: 0.0 for n in names}
+    cpu = {n: 0.0 for n in names}
     wall = 0.0
     iters = 6
     for it in range(iters):
@@ -28,32 +29,34 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        ev[0].record()
+        ct = [0.0] * (len(names) + 1)
+        ev[0].record(); ct[0] = time.perf_counter()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             feats = model.backbone(images.contiguous(memory_format=torch.channels_last))
-            ev[1].record()
+            ev[1].record(); ct[1] = time.perf_counter()
             mf, _, ms = model.head.pixel_decoder.forward_features(feats)
-            ev[2].record()
+            ev[2].record(); ct[2] = time.perf_counter()
             out = model.head.predictor(ms, mf, None, {"tgt": targets, "scalar": 1, "noise_scale": 0.0})
-            ev[3].record()
+            ev[3].record(); ct[3] = time.perf_counter()
             losses = model.head.criterion(out, targets)
             loss = model.head.criterion.weighted_total(losses)
-        ev[4].record()
+        ev[4].record(); ct[4] = time.perf_counter()
         loss.backward()
-        ev[5].record()
+        ev[5].record(); ct[5] = time.perf_counter()
         torch.nn.utils.clip_grad_norm_(params, 0.01, foreach=True)
-        ev[6].record()
+        ev[6].record(); ct[6] = time.perf_counter()
         opt.step()
-        ev[7].record()
+        ev[7].record(); ct[7] = time.perf_counter()
         torch.cuda.synchronize()
         if it >= 2:
             wall += time.perf_counter() - t0
             for i, n in enumerate(names):
                 acc[n] += ev[i].elapsed_time(ev[i + 1])
+                cpu[n] += (ct[i + 1] - ct[i]) * 1e3
     n = iters - 2
-    print("phase times (ms / step, 2 images):")
+    print("phase times (ms / step, 2 images):    GPU-timeline   host (launch) time")
     for k in names:
-        print(f"  {k:14s} {acc[k] / n:8.2f}")
+        print(f"  {k:14s} {acc[k] / n:8.2f}   {cpu[k] / n:8.2f}")
     print(f"  {'sum':14s} {sum(acc.values()) / n:8.2f}   wall {wall / n * 1e3:8.2f}")
 
 

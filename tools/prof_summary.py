@@ -5,6 +5,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 def cat(n):
     if 'msda' in n or 'tile_scan' in n: return 'native: msda'
+    if 'gemm3' in n: return 'native: gemm3 (fp32 as 3xbf16)'
     if 'attn_' in n and 'anonymous' in n: return 'native: attention'
     if 'anonymous namespace)::' in n and any(k in n for k in ('match_cost', 'mask_loss', 'point_sample', 'select_unc')): return 'native: loss'
     if n.startswith('Cijk') and '_S_B_' in n: return 'gemm_fp32'
