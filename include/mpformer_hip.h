@@ -271,6 +271,14 @@ int mpf_bias_act(const void* x, const float* bias, const void* res, void* y, int
                  int relu, void* stream);
 
 /*
+ * dst[dst_offs[i] + p] = (dst dtype) src[i * plane + p], i < n, p < plane (plane % 4 == 0; dst_offs in
+ * elements, 4-element aligned): moves the fp32 gradient planes accumulated by mpf_mask_loss_backward
+ * (grad_offs[i] = i * plane) into the dense gradient of the prediction maps (criterion.py:172-191's
+ * backward through point_sample), casting to the maps' dtype.
+ */
+int mpf_planes_scatter(const float* src, const int64_t* dst_offs, void* dst, int dst_dtype, int n, int plane, void* stream);
+
+/*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
  * events recorded on the launch stream (kernel only: memsets and host work are outside the
  * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events

@@ -24,6 +24,20 @@ from .matcher import GTMasks
 from .point_sample import MapSet, MaskLossSums, point_sample_offsets, select_uncertain
 
 
+class LossDict(dict):
+    """The 60-entry loss dict of the reference interface; the entries are views of a few per-output
+    vectors, which ``SetCriterion.weighted_total`` weights directly."""
+
+    def __init__(self):
+        super().__init__()
+        self.groups = []
+
+    def add_group(self, names, vec):
+        self.groups.append((list(names), vec))
+        for i, k in enumerate(names):
+            self[k] = vec[i]
+
+
 class SetCriterion(nn.Module):
     def __init__(self, num_classes, matcher, weight_dict, eos_coef, losses, num_points, oversample_ratio,
                  importance_sample_ratio, dn_no_lb=False):
@@ -114,12 +128,14 @@ class SetCriterion(nn.Module):
         ti, bi, qi, gr, gid = cat(ti), cat(bi), cat(qi), cat(gr), cat(gid)
         n_pairs = len(ti)
         G = 2 * L if use_dn else L
-        losses = {}
+        losses = LossDict()
 
         # ---- stage 2: mask losses ----------------------------------------------------------------------
         if "masks" in self.losses:
             if n_pairs:
-                up = torch.from_numpy(np.concatenate([ms.offsets(ti, bi, qi), ms.grad_offsets(ti, bi, qi), gid])).to(dev, non_blocking=True)
+                g_offs = ms.grad_offsets(ti, bi, qi)
+                assert len(np.unique(g_offs)) == n_pairs, "a prediction plane is paired twice in one step"
+                up = torch.from_numpy(np.concatenate([ms.offsets(ti, bi, qi), g_offs, gid])).to(dev, non_blocking=True)
                 pred_offs, grad_offs, gid_d = up[:n_pairs], up[n_pairs:2 * n_pairs], up[2 * n_pairs:]
                 gt_rows = torch.from_numpy(gr.astype(np.int32)).to(dev, non_blocking=True)
                 with torch.no_grad():   # criterion.py:162-176: point selection carries no gradient
@@ -128,7 +144,7 @@ class SetCriterion(nn.Module):
                     coords = select_uncertain(logits_over, coords_over, num_uncertain, P)
                     if P - num_uncertain > 0:
                         coords[:, num_uncertain:] = _rng.rand_cat(rand_parts, dev)
-                sums = MaskLossSums.apply(ms, pred_offs, grad_offs, gt.u8, gt_rows, coords, *map_tensors)
+                sums = MaskLossSums.apply(ms, pred_offs, grad_offs, gt.u8, gt_rows, coords, *ms.bases)
                 per_mask = sums[:, 0] / P                                                  # mean_p BCE (criterion.py:48-65)
                 per_dice = 1 - (2 * sums[:, 1] + 1) / (sums[:, 2] + sums[:, 3] + 1)        # criterion.py:21-40
                 z = torch.zeros(G, dtype=torch.float32, device=dev)
@@ -143,19 +159,16 @@ class SetCriterion(nn.Module):
                 _rng.rand_cat(rand_parts, dev)
                 zero = sum(t.sum() * 0.0 for t in map_tensors).float()
                 g_mask = g_dice = zero.expand(G)
-            for l in range(L):
-                losses["loss_mask" + suffixes[l]] = g_mask[l]
-                losses["loss_dice" + suffixes[l]] = g_dice[l]
-                if use_dn:
-                    losses["loss_mask_dn" + suffixes[l]] = g_mask[L + l]
-                    losses["loss_dice_dn" + suffixes[l]] = g_dice[L + l]
+            names_m = ["loss_mask" + s_ for s_ in suffixes] + (["loss_mask_dn" + s_ for s_ in suffixes] if use_dn else [])
+            names_d = ["loss_dice" + s_ for s_ in suffixes] + (["loss_dice_dn" + s_ for s_ in suffixes] if use_dn else [])
+            losses.add_group(names_m, g_mask)
+            losses.add_group(names_d, g_dice)
 
         # ---- stage 3: class losses ---------------------------------------------------------------------
         if "labels" in self.losses:
             ce = self._class_losses(torch.stack([o["pred_logits"] for o in outs]),
                                     torch.from_numpy(tc_main).to(dev, non_blocking=True))
-            for l in range(L):
-                losses["loss_ce" + suffixes[l]] = ce[l]
+            losses.add_group(["loss_ce" + s_ for s_ in suffixes], ce)
             if use_dn:
                 tc_dn = np.full((N, pad), K, dtype=np.int64)     # criterion.py:249-258: slot j of every group <-> GT j
                 for b in range(N):
@@ -164,19 +177,34 @@ class SetCriterion(nn.Module):
                         tc_dn[b, s * max_num:s * max_num + T] = labels_host[b]
                 ce_dn = self._class_losses(torch.stack([o["pred_logits"] for o in dn_outs]),
                                            torch.from_numpy(tc_dn).to(dev, non_blocking=True))
-                for l in range(L):
-                    losses["loss_ce_dn" + suffixes[l]] = ce_dn[l]
+                losses.add_group(["loss_ce_dn" + s_ for s_ in suffixes], ce_dn)
         if not use_dn:
             z = torch.as_tensor(0.0, device=dev)
             for s in suffixes:
                 losses.update({"loss_mask_dn" + s: z, "loss_dice_dn" + s: z, "loss_ce_dn" + s: z})
         if self.dn_no_lb:
-            losses = {k: v for k, v in losses.items() if not k.startswith("loss_ce_dn")}
+            for k in [k for k in losses if k.startswith("loss_ce_dn")]:
+                del losses[k]
         return losses
 
     def weighted_total(self, losses):
         """sum_k weight_dict[k] * losses[k] in two kernels (the caller-side loop of
         maskformer_model.py:226-231 costs one multiply and one add per key)."""
+        groups = getattr(losses, "groups", None)
+        if groups:
+            # the dict entries are views of a few vectors: weight the vectors (the per-key route costs a
+            # select-backward = zeros + copy + add per key, ~180 launches per step)
+            covered = {k for names, _ in groups for k in names}
+            total = None
+            for names, vec in groups:
+                w = torch.tensor([self.weight_dict.get(k, 0.0) if k in losses else 0.0 for k in names],
+                                 dtype=vec.dtype, device=vec.device)
+                part = (vec * w).sum()
+                total = part if total is None else total + part
+            rest = [k for k in losses if k in self.weight_dict and k not in covered]
+            for k in rest:
+                total = total + losses[k] * self.weight_dict[k]
+            return total
         keys = [k for k in losses if k in self.weight_dict]
         vec = torch.stack([losses[k] for k in keys])
         w = torch.tensor([self.weight_dict[k] for k in keys], dtype=vec.dtype, device=vec.device)

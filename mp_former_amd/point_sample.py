@@ -25,9 +25,25 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+def _row_slice_of(t):
+    """(base, first row) if ``t`` is a dim-1 slice view of a 4-D tensor (e.g. the MP / matching halves
+    of a layer's mask predictions), else (t, 0)."""
+    b = t._base
+    if (b is not None and b.dim() == 4 and t.dim() == 4 and b.shape[0] == t.shape[0] and b.shape[2:] == t.shape[2:]
+            and b.stride() == t.stride() and b.stride(1) > 0):
+        d = t.storage_offset() - b.storage_offset()
+        if d >= 0 and d % b.stride(1) == 0 and d // b.stride(1) + t.shape[1] <= b.shape[1]:
+            return b, d // b.stride(1)
+    return t, 0
+
+
 class MapSet:
     """A list of [N, Q_i, h, w] tensors (dense [h,w] planes, arbitrary strides on dims 0/1) seen as one
-    address space: offset(i, b, q) = element offset of that plane from the lowest data pointer."""
+    address space: offset(i, b, q) = element offset of that plane from the lowest data pointer.
+
+    Tensors that are row-range views of a common parent (dim-1 slices) are addressed through the
+    parent (``bases``): the gradient then goes to the parent in one piece instead of through one
+    zero-padded slice-backward per view."""
 
     def __init__(self, tensors):
         t0 = tensors[0]
@@ -39,29 +55,42 @@ class MapSet:
         self.esize = t0.element_size()
         if self.dtype not in _DT:
             raise RuntimeError(f"unsupported map dtype {self.dtype}")
-        ptrs = []
+        self.bases, self.base_of, self.q0 = [], [], []
+        seen = {}
         for t in tensors:
             if t.dtype != self.dtype or tuple(t.shape[-2:]) != (self.h, self.w) or t.device != self.device:
                 raise RuntimeError("all maps of a MapSet must share dtype, device and [h, w]")
             if t.stride(3) != 1 or t.stride(2) != self.w:
                 raise RuntimeError("maps must be dense [h, w] planes")
-            ptrs.append(t.data_ptr())
+            b, q0 = _row_slice_of(t)
+            k = id(b)
+            if k not in seen:
+                seen[k] = len(self.bases)
+                self.bases.append(b)
+            self.base_of.append(seen[k])
+            self.q0.append(q0)
+        self.base_of = np.array(self.base_of, dtype=np.int64)
+        self.q0 = np.array(self.q0, dtype=np.int64)
+        ptrs = [b.data_ptr() for b in self.bases]
         self.base_ptr = min(ptrs)
         self.t_off = np.array([(p - self.base_ptr) // self.esize for p in ptrs], dtype=np.int64)
-        self.s0 = np.array([t.stride(0) for t in tensors], dtype=np.int64)
-        self.s1 = np.array([t.stride(1) for t in tensors], dtype=np.int64)
-        # layout of one flat fp32 gradient buffer holding a CONTIGUOUS copy of every tensor
-        numels = np.array([t.numel() for t in tensors], dtype=np.int64)
+        self.s0 = np.array([b.stride(0) for b in self.bases], dtype=np.int64)
+        self.s1 = np.array([b.stride(1) for b in self.bases], dtype=np.int64)
+        # layout of one flat gradient buffer holding a CONTIGUOUS copy of every base tensor
+        numels = np.array([b.numel() for b in self.bases], dtype=np.int64)
         self.g_start = np.concatenate([[0], np.cumsum(numels)[:-1]])
         self.g_total = int(numels.sum())
-        self.g_s0 = np.array([t.shape[1] * self.h * self.w for t in tensors], dtype=np.int64)
+        self.g_s0 = np.array([b.shape[1] * self.h * self.w for b in self.bases], dtype=np.int64)
 
     def offsets(self, ti, b, q):
         """numpy int64 arrays (tensor index, image, query row) -> element offsets of the planes."""
-        return self.t_off[ti] + b * self.s0[ti] + q * self.s1[ti]
+        bi = self.base_of[ti]
+        return self.t_off[bi] + b * self.s0[bi] + (q + self.q0[ti]) * self.s1[bi]
 
     def grad_offsets(self, ti, b, q):
-        return self.g_start[ti] + b * self.g_s0[ti] + q * (self.h * self.w)
+        """element offsets of the same planes inside the flat gradient buffer of the bases"""
+        bi = self.base_of[ti]
+        return self.g_start[bi] + b * self.g_s0[bi] + (q + self.q0[ti]) * (self.h * self.w)
 
 
 def point_sample_offsets(base_ptr, dtype, h, w, offs, coords, coord_rows, device):
@@ -108,7 +137,11 @@ def match_cost(ms, offs, coords, coord_rows, tsamp, t_first, t_count, Tmax, w_ma
 class MaskLossSums(Function):
     """sums[i] = (sum_p BCE(x,t), sum_p sigmoid(x)*t, sum_p sigmoid(x), sum_p t) over the P points of
     pair i; x sampled from the plane at ms.base + pred_offs[i], t from gt_u8[gt_rows[i]]
-    (criterion.py:172-191).  Differentiable wrt every tensor of the MapSet."""
+    (criterion.py:172-191).  Differentiable wrt every base tensor of the MapSet (pass ``*ms.bases``).
+
+    Backward: the bilinear scatter accumulates in fp32 into one scratch plane per pair (the planes of a
+    step's pairs are distinct: a query is matched once per output), which are then cast into a dense
+    zero-initialised gradient of the maps' dtype — instead of an fp32 image of every map plus a cast."""
 
     @staticmethod
     def forward(ctx, ms, pred_offs, grad_offs, gt_u8, gt_rows, coords, *tensors):
@@ -132,17 +165,37 @@ class MaskLossSums(Function):
         pred_offs, grad_offs, gt_u8, gt_rows, coords = ctx.saved_tensors[:5]
         n, P = coords.shape[0], coords.shape[1]
         H, W = gt_u8.shape[-2:]
-        gbuf = torch.zeros(ms.g_total, dtype=torch.float32, device=ms.device)
+        plane = ms.h * ms.w
+        if plane % 4 != 0:      # odd plane sizes: fp32 image of every map, then a cast (the simple route)
+            gbuf = torch.zeros(ms.g_total, dtype=torch.float32, device=ms.device)
+            if n:
+                g = grad_sums.contiguous().float()
+                with torch.cuda.device(ms.device):
+                    code = _lib.lib().mpf_mask_loss_backward(
+                        ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), H, W,
+                        gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), gbuf.data_ptr(), grad_offs.data_ptr(), n, P,
+                        _stream(ms.device))
+                _lib.check(code, "mpf_mask_loss_backward")
+            gbuf = gbuf.to(ms.dtype)
+            return (None, None, None, None, None, None,
+                    *[gbuf[int(ms.g_start[i]):int(ms.g_start[i]) + t.numel()].view(t.shape) for i, t in enumerate(ms.bases)])
+        gbuf = torch.zeros(ms.g_total, dtype=ms.dtype, device=ms.device)
         if n:
             g = grad_sums.contiguous().float()
+            scratch = torch.zeros((n, plane), dtype=torch.float32, device=ms.device)
+            plane_offs = torch.arange(n, dtype=torch.int64, device=ms.device) * plane
+            lib = _lib.lib()
             with torch.cuda.device(ms.device):
-                code = _lib.lib().mpf_mask_loss_backward(
+                code = lib.mpf_mask_loss_backward(
                     ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), H, W,
-                    gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), gbuf.data_ptr(), grad_offs.data_ptr(), n, P,
+                    gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), scratch.data_ptr(), plane_offs.data_ptr(), n, P,
                     _stream(ms.device))
-            _lib.check(code, "mpf_mask_loss_backward")
+                _lib.check(code, "mpf_mask_loss_backward")
+                code = lib.mpf_planes_scatter(scratch.data_ptr(), grad_offs.data_ptr(), gbuf.data_ptr(), _DT[ms.dtype], n, plane,
+                                              _stream(ms.device))
+            _lib.check(code, "mpf_planes_scatter")
         grads = []
-        for i, t in enumerate(ms.tensors):
+        for i, t in enumerate(ms.bases):
             s = int(ms.g_start[i])
-            grads.append(gbuf[s:s + t.numel()].view(t.shape).to(t.dtype))
+            grads.append(gbuf[s:s + t.numel()].view(t.shape))
         return (None, None, None, None, None, None, *grads)

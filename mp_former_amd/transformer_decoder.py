@@ -35,24 +35,48 @@ class _CastParams(torch.autograd.Function):
     gradients on the way back) instead of one cast kernel per parameter per use, which is what
     autocast does (~280 cast launches forward and ~630 backward per decoder step).  Same numerics as
     autocast: weights rounded to bf16 for the GEMMs, weight gradients produced in bf16 and accumulated
-    into the fp32 .grad."""
+    into the fp32 .grad.
+
+    ``chunks[i]`` > 1 returns parameter i as that many separate row blocks (the q / k / v parts of a
+    packed in-projection): the consumer never slices, so the backward has no zero-fill + copy + add
+    per slice — the block gradients are copied straight into one fp32 gradient."""
 
     @staticmethod
-    def forward(ctx, dtype, *params):
-        outs = [torch.empty_like(p, dtype=dtype) for p in params]
-        torch._foreach_copy_(outs, [p.detach() for p in params])
+    def forward(ctx, dtype, chunks, *params):
+        srcs, outs = [], []
+        for p, c in zip(params, chunks):
+            d = p.detach()
+            parts = [d] if c == 1 else list(d.chunk(c, 0))
+            srcs += parts
+            outs += [torch.empty_like(t, dtype=dtype if dtype is not None else t.dtype) for t in parts]
+        torch._foreach_copy_(outs, srcs)
+        ctx.chunks = chunks
+        ctx.shapes = [p.shape for p in params]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
-        idx = [i for i, g in enumerate(grads) if g is not None]
-        outs = [torch.empty_like(grads[i], dtype=torch.float32) for i in idx]
-        if idx:
-            torch._foreach_copy_(outs, [grads[i] for i in idx])
-        res = [None] * len(grads)
-        for i, o in zip(idx, outs):
-            res[i] = o
-        return (None, *res)
+        res, dsts, srcs = [], [], []
+        k = 0
+        for shape, c in zip(ctx.shapes, ctx.chunks):
+            gs = grads[k:k + c]
+            k += c
+            if all(g is None for g in gs):
+                res.append(None)
+                continue
+            dev = next(g for g in gs if g is not None).device
+            full = torch.empty(shape, dtype=torch.float32, device=dev)
+            parts = [full] if c == 1 else list(full.chunk(c, 0))
+            for part, g in zip(parts, gs):
+                if g is None:
+                    part.zero_()
+                else:
+                    dsts.append(part)
+                    srcs.append(g)
+            res.append(full)
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)
+        return (None, None, *res)
 
 
 def native_attn_mask(masks, size, mp_rows=None):
@@ -81,14 +105,21 @@ def native_attn_mask(masks, size, mp_rows=None):
 
 
 def masked_mha_w(q_in, k_in, v_in, w, b, wo, bo, nheads, mask: Optional[Tensor]):
-    """Multi-head attention with a packed in-projection (w [3E,E], b [3E]) and out-projection (wo, bo),
-    seq-first.  q_in [Lq,N,E]; k_in, v_in [Lk,N,E]; mask bool, True = masked: [N,Lq,Lk] (shared by
-    heads) or [Lq,Lk]; returns [Lq,N,E].  The projections are library GEMMs; softmax(QK^T/sqrt(hd))V
-    runs on the native bf16 MFMA kernels (csrc/attn.hip), fp32 softmax."""
+    """Multi-head attention with in-projection (w, b) and out-projection (wo, bo), seq-first.
+    q_in [Lq,N,E]; k_in, v_in [Lk,N,E]; mask bool, True = masked: [N,Lq,Lk] (shared by heads) or
+    [Lq,Lk]; returns [Lq,N,E].  ``w`` / ``b`` are either the packed [3E,E] / [3E] parameters or
+    3-tuples of their q / k / v row blocks (see _CastParams).  Self-attention (q_in is k_in is v_in)
+    with packed weights runs ONE in-projection GEMM.  The projections are library GEMMs;
+    softmax(QK^T/sqrt(hd))V runs on the native bf16 MFMA kernels (csrc/attn.hip), fp32 softmax."""
     E = q_in.shape[-1]
-    q = F.linear(q_in, w[:E], b[:E])
-    k = F.linear(k_in, w[E:2 * E], b[E:2 * E])
-    v = F.linear(v_in, w[2 * E:], b[2 * E:])
+    if not isinstance(w, (tuple, list)) and q_in is k_in and k_in is v_in:
+        q, k, v = F.linear(q_in, w, b).split(E, dim=-1)
+    else:
+        if not isinstance(w, (tuple, list)):
+            w, b = (w[:E], w[E:2 * E], w[2 * E:]), (b[:E], b[E:2 * E], b[2 * E:])
+        q = F.linear(q_in, w[0], b[0])
+        k = F.linear(k_in, w[1], b[1])
+        v = F.linear(v_in, w[2], b[2])
     o = attention_core(q, k, v, mask, nheads)
     return F.linear(o, wo, bo)
 
@@ -282,13 +313,19 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
     # ---------------------------------------------------------------------------------------------
     def _weights(self):
         """name -> tensor for every GEMM weight / bias of the decoder.  Under autocast these are bf16
-        working copies made by ONE grouped cast (_CastParams); LayerNorm / embedding parameters stay
-        fp32 modules (autocast runs them in fp32 anyway)."""
+        working copies made by ONE grouped cast (_CastParams); the packed in-projections come back as
+        (q, k, v) row-block tuples.  LayerNorm / embedding
+        parameters stay fp32 modules (autocast runs them in fp32 anyway)."""
         named = [(n, p) for n, p in self.named_parameters()
                  if not (".norm." in n or n.startswith("decoder_norm") or n.startswith(("query_feat", "level_embed", "label_enc")))]
         if torch.is_autocast_enabled() and named and named[0][1].is_cuda and os.environ.get("MPF_GROUPED_CAST", "1") == "1":
-            cast = _CastParams.apply(torch.get_autocast_dtype("cuda"), *[p for _, p in named])
-            return {n: c for (n, _), c in zip(named, cast)}
+            chunks = [3 if "in_proj" in n else 1 for n, _ in named]
+            cast = _CastParams.apply(torch.get_autocast_dtype("cuda"), chunks, *[p for _, p in named])
+            out, k = {}, 0
+            for (n, _), c in zip(named, chunks):
+                out[n] = cast[k] if c == 1 else tuple(cast[k:k + c])
+                k += c
+            return out
         return dict(named)
 
     def _heads(self, W, output, mask_features, attn_mask_target_size, mp_rows=None):
@@ -300,12 +337,13 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         e = F.relu(F.linear(x, W["mask_embed.layers.0.weight"], W["mask_embed.layers.0.bias"]))
         e = F.relu(F.linear(e, W["mask_embed.layers.1.weight"], W["mask_embed.layers.1.bias"]))
         mask_embed = F.linear(e, W["mask_embed.layers.2.weight"], W["mask_embed.layers.2.bias"])
-        outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features.to(mask_embed.dtype))
+        outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
         am = native_attn_mask(outputs_mask.detach(), attn_mask_target_size, mp_rows)
         return outputs_class, outputs_mask, am
 
     def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, mp_rows=None):
-        return self._heads(self._weights(), output, mask_features, attn_mask_target_size, mp_rows)
+        W = self._weights()
+        return self._heads(W, output, mask_features.to(W["class_embed.weight"].dtype), attn_mask_target_size, mp_rows)
 
     def forward(self, x, mask_features, mask=None, dn_args=None):
         assert len(x) == self.num_feature_levels
@@ -327,6 +365,8 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             pos.append(p)
             src.append(s)
             kin.append(k_in)
+        if amp:                          # one cast for the 10 prediction heads
+            mask_features = mask_features.to(adt)
         bs = src[0].shape[1]
         device = src[0].device
         mp = self._mp_setup(dn_args, bs, size_list, device) if dn_args is not None else None
