@@ -279,6 +279,20 @@ int mpf_bias_act(const void* x, const float* bias, const void* res, void* y, int
 int mpf_planes_scatter(const float* src, const int64_t* dst_offs, void* dst, int dst_dtype, int n, int plane, void* stream);
 
 /*
+ * Post-norm residual block of the decoder layers (mask2former_transformer_decoder.py:42-52, :100-112,
+ * :165-169: tgt = LayerNorm(tgt + tgt2)) for 256 channels, one pass:
+ *   s = x + t;  y = (s - mean) * rstd * gamma + beta      x fp32 [rows,256]; t fp32/bf16 or NULL
+ * y is written as fp32 (y32, the next residual) and/or bf16 (y16, the next GEMM operand); s_out
+ * (optional), mean, rstd [rows] are what the backward needs.
+ * Backward: g = gy32 + gy16 (either may be NULL) -> ds32 / ds16 (same values, fp32 / bf16; either may
+ * be NULL) and dgamma / dbeta ACCUMULATED with float atomics (zero them before the first call).
+ */
+int mpf_res_ln256_forward(const float* x, const void* t, int t_dtype, const float* gamma, const float* beta,
+                          float* s_out, float* y32, void* y16, float* mean, float* rstd, int rows, float eps, void* stream);
+int mpf_res_ln256_backward(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                           const void* gy16, float* ds32, void* ds16, float* dgamma, float* dbeta, int rows, void* stream);
+
+/*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
  * events recorded on the launch stream (kernel only: memsets and host work are outside the
  * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events

@@ -12,6 +12,10 @@ def install_replay(by_tag):
     _replay = {k: list(v) for k, v in by_tag.items()} if by_tag is not None else None
 
 
+def replaying():
+    return _replay is not None
+
+
 def remaining():
     return 0 if _replay is None else sum(len(v) for v in _replay.values())
 

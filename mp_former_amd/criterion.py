@@ -21,6 +21,7 @@ from torch import nn
 from . import _rng
 from .dist import global_num_masks
 from .matcher import GTMasks
+from ._h2d import upload
 from .point_sample import MapSet, MaskLossSums, point_sample_offsets, select_uncertain
 
 
@@ -135,9 +136,9 @@ class SetCriterion(nn.Module):
             if n_pairs:
                 g_offs = ms.grad_offsets(ti, bi, qi)
                 assert len(np.unique(g_offs)) == n_pairs, "a prediction plane is paired twice in one step"
-                up = torch.from_numpy(np.concatenate([ms.offsets(ti, bi, qi), g_offs, gid])).to(dev, non_blocking=True)
+                up = upload(np.concatenate([ms.offsets(ti, bi, qi), g_offs, gid]), dev)
                 pred_offs, grad_offs, gid_d = up[:n_pairs], up[n_pairs:2 * n_pairs], up[2 * n_pairs:]
-                gt_rows = torch.from_numpy(gr.astype(np.int32)).to(dev, non_blocking=True)
+                gt_rows = upload(gr.astype(np.int32), dev)
                 with torch.no_grad():   # criterion.py:162-176: point selection carries no gradient
                     coords_over = _rng.rand_cat(over_parts, dev)
                     logits_over = point_sample_offsets(ms.base_ptr, ms.dtype, ms.h, ms.w, pred_offs, coords_over, None, dev)
@@ -167,7 +168,7 @@ class SetCriterion(nn.Module):
         # ---- stage 3: class losses ---------------------------------------------------------------------
         if "labels" in self.losses:
             ce = self._class_losses(torch.stack([o["pred_logits"] for o in outs]),
-                                    torch.from_numpy(tc_main).to(dev, non_blocking=True))
+                                    upload(tc_main, dev))
             losses.add_group(["loss_ce" + s_ for s_ in suffixes], ce)
             if use_dn:
                 tc_dn = np.full((N, pad), K, dtype=np.int64)     # criterion.py:249-258: slot j of every group <-> GT j
@@ -176,7 +177,7 @@ class SetCriterion(nn.Module):
                     for s in range(scalar):
                         tc_dn[b, s * max_num:s * max_num + T] = labels_host[b]
                 ce_dn = self._class_losses(torch.stack([o["pred_logits"] for o in dn_outs]),
-                                           torch.from_numpy(tc_dn).to(dev, non_blocking=True))
+                                           upload(tc_dn, dev))
                 losses.add_group(["loss_ce_dn" + s_ for s_ in suffixes], ce_dn)
         if not use_dn:
             z = torch.as_tensor(0.0, device=dev)
@@ -197,8 +198,7 @@ class SetCriterion(nn.Module):
             covered = {k for names, _ in groups for k in names}
             total = None
             for names, vec in groups:
-                w = torch.tensor([self.weight_dict.get(k, 0.0) if k in losses else 0.0 for k in names],
-                                 dtype=vec.dtype, device=vec.device)
+                w = upload([self.weight_dict.get(k, 0.0) if k in losses else 0.0 for k in names], vec.device, vec.dtype)
                 part = (vec * w).sum()
                 total = part if total is None else total + part
             rest = [k for k in losses if k in self.weight_dict and k not in covered]
@@ -207,7 +207,7 @@ class SetCriterion(nn.Module):
             return total
         keys = [k for k in losses if k in self.weight_dict]
         vec = torch.stack([losses[k] for k in keys])
-        w = torch.tensor([self.weight_dict[k] for k in keys], dtype=vec.dtype, device=vec.device)
+        w = upload([self.weight_dict[k] for k in keys], vec.device, vec.dtype)
         return (vec * w).sum()
 
     def __repr__(self):

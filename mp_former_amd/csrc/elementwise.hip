@@ -125,3 +125,137 @@ extern "C" int mpf_planes_scatter(const float* src, const int64_t* dst_offs, voi
     }
     return mpf::check(hipGetLastError(), "mpf_planes_scatter");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Post-norm residual block of the decoder (mask2former_transformer_decoder.py:42-52, :100-112,
+// :165-169: tgt = LayerNorm(tgt + tgt2)), C = 256:  s = x + t (x fp32 residual stream, t bf16 or fp32
+// branch output, may be NULL), y = LN(s) * gamma + beta, written as fp32 (next residual) and/or bf16
+// (next GEMM operand) in ONE pass; mean / rstd saved for the backward.  One wave per row, 4 columns
+// per lane.  Backward: g = gy32 + gy16 -> ds (fp32 and/or bf16 copies) and per-block partial sums of
+// dgamma / dbeta accumulated with float atomics into zero-initialised vectors.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename TT>
+__device__ __forceinline__ float4 load4(const TT* p)
+{
+    if constexpr (sizeof(TT) == 4) {
+        return *reinterpret_cast<const float4*>(p);
+    } else {
+        const bf16x4v v = *reinterpret_cast<const bf16x4v*>(p);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void res_ln256_fwd_kernel(const float* __restrict__ x, const TT* __restrict__ t,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ s_out, float* __restrict__ y32, __bf16* __restrict__ y16,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int c = (threadIdx.x & 63) * 4;
+    float4 v = *reinterpret_cast<const float4*>(x + (int64_t)row * 256 + c);
+    if (t) {
+        const float4 u = load4(t + (int64_t)row * 256 + c);
+        v = make_float4(v.x + u.x, v.y + u.y, v.z + u.z, v.w + u.w);
+    }
+    if (s_out) *reinterpret_cast<float4*>(s_out + (int64_t)row * 256 + c) = v;
+    const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    const float4 d = make_float4(v.x - mu, v.y - mu, v.z - mu, v.w - mu);
+    const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.f / 256.f);
+    const float rs = rsqrtf(var + eps);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+    const float4 o = make_float4(d.x * rs * g.x + b.x, d.y * rs * g.y + b.y, d.z * rs * g.z + b.z, d.w * rs * g.w + b.w);
+    if (y32) *reinterpret_cast<float4*>(y32 + (int64_t)row * 256 + c) = o;
+    if (y16) *reinterpret_cast<bf16x4v*>(y16 + (int64_t)row * 256 + c) = bf16x4v{(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+    if ((threadIdx.x & 63) == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+__global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restrict__ s, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ gy32, const __bf16* __restrict__ gy16,
+                                                            float* __restrict__ ds32, __bf16* __restrict__ ds16,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int rows_per_block)
+{
+    __shared__ float red[2][4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy32) dy = *reinterpret_cast<const float4*>(gy32 + (int64_t)row * 256 + c);
+        if (gy16) {
+            const float4 u = load4(gy16 + (int64_t)row * 256 + c);
+            dy = make_float4(dy.x + u.x, dy.y + u.y, dy.z + u.z, dy.w + u.w);
+        }
+        const float4 sv = *reinterpret_cast<const float4*>(s + (int64_t)row * 256 + c);
+        const float mu = mean[row], rs = rstd[row];
+        const float4 xh = make_float4((sv.x - mu) * rs, (sv.y - mu) * rs, (sv.z - mu) * rs, (sv.w - mu) * rs);
+        const float4 dg = make_float4(dy.x * g.x, dy.y * g.y, dy.z * g.z, dy.w * g.w);
+        const float s1 = wave_sum(dg.x + dg.y + dg.z + dg.w) * (1.f / 256.f);
+        const float s2 = wave_sum(dg.x * xh.x + dg.y * xh.y + dg.z * xh.z + dg.w * xh.w) * (1.f / 256.f);
+        const float4 o = make_float4(rs * (dg.x - s1 - xh.x * s2), rs * (dg.y - s1 - xh.y * s2), rs * (dg.z - s1 - xh.z * s2),
+                                     rs * (dg.w - s1 - xh.w * s2));
+        if (ds32) *reinterpret_cast<float4*>(ds32 + (int64_t)row * 256 + c) = o;
+        if (ds16) *reinterpret_cast<bf16x4v*>(ds16 + (int64_t)row * 256 + c) = bf16x4v{(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+        ag = make_float4(ag.x + dy.x * xh.x, ag.y + dy.y * xh.y, ag.z + dy.z * xh.z, ag.w + dy.w * xh.w);
+        ab = make_float4(ab.x + dy.x, ab.y + dy.y, ab.z + dy.z, ab.w + dy.w);
+    }
+    *reinterpret_cast<float4*>(&red[0][wave][c]) = ag;
+    *reinterpret_cast<float4*>(&red[1][wave][c]) = ab;
+    __syncthreads();
+    const int col = threadIdx.x;
+    atomicAdd(dgamma + col, red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]);
+    atomicAdd(dbeta + col, red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col]);
+}
+
+}  // namespace
+
+extern "C" int mpf_res_ln256_forward(const float* x, const void* t, int t_dtype, const float* gamma, const float* beta,
+                                     float* s_out, float* y32, void* y16, float* mean, float* rstd, int rows, float eps,
+                                     void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) return 0;
+    if (!x || !gamma || !beta || !mean || !rstd || (!y32 && !y16)) return mpf::fail(MPF_E_NULL, "res_ln256_forward: NULL buffer");
+    if (rows < 0) return mpf::fail(MPF_E_SHAPE, "res_ln256_forward: bad rows");
+    const dim3 grid((rows + 3) / 4);
+    mpf::set_kernel("res_ln256_fwd_kernel");
+    if (t && t_dtype == MPF_BF16)
+        hipLaunchKernelGGL(res_ln256_fwd_kernel<__bf16>, grid, dim3(256), 0, st, x, (const __bf16*)t, gamma, beta, s_out, y32, (__bf16*)y16, mean, rstd, rows, eps);
+    else if (!t || t_dtype == MPF_F32)
+        hipLaunchKernelGGL(res_ln256_fwd_kernel<float>, grid, dim3(256), 0, st, x, (const float*)t, gamma, beta, s_out, y32, (__bf16*)y16, mean, rstd, rows, eps);
+    else
+        return mpf::fail(MPF_E_DTYPE, "res_ln256_forward: t dtype must be MPF_F32 or MPF_BF16");
+    return mpf::check(hipGetLastError(), "mpf_res_ln256_forward");
+}
+
+extern "C" int mpf_res_ln256_backward(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                                      const void* gy16, float* ds32, void* ds16, float* dgamma, float* dbeta, int rows, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) return 0;
+    if (!s || !mean || !rstd || !gamma || (!gy32 && !gy16) || (!ds32 && !ds16) || !dgamma || !dbeta)
+        return mpf::fail(MPF_E_NULL, "res_ln256_backward: NULL buffer");
+    if (rows < 0) return mpf::fail(MPF_E_SHAPE, "res_ln256_backward: bad rows");
+    // ~1024 blocks at most; each block reduces its rows' dgamma / dbeta before the atomics
+    int rpb = (rows + 1023) / 1024;
+    rpb = ((rpb + 3) / 4) * 4;
+    const dim3 grid((rows + rpb - 1) / rpb);
+    mpf::set_kernel("res_ln256_bwd_kernel");
+    hipLaunchKernelGGL(res_ln256_bwd_kernel, grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16, ds32,
+                       (__bf16*)ds16, dgamma, dbeta, rows, rpb);
+    return mpf::check(hipGetLastError(), "mpf_res_ln256_backward");
+}

@@ -16,6 +16,7 @@ from scipy.optimize import linear_sum_assignment
 from torch import nn
 
 from . import _rng
+from ._h2d import upload
 from .point_sample import MapSet, match_cost, point_sample_offsets
 
 
@@ -78,7 +79,7 @@ class HungarianMatcher(nn.Module):
         l_idx, b_idx, q_idx = l_idx.reshape(-1), b_idx.reshape(-1), q_idx.reshape(-1)
         pred_offs = mapset.offsets(np.asarray(map_index, dtype=np.int64)[l_idx], b_idx, q_idx)
         gt_offs = np.tile(np.arange(Tt, dtype=np.int64) * (gt.H * gt.W), L)
-        i64 = torch.from_numpy(np.concatenate([pred_offs, gt_offs])).to(dev, non_blocking=True)
+        i64 = upload(np.concatenate([pred_offs, gt_offs]), dev)
         counts = np.asarray(gt.counts, dtype=np.int64)
         firsts = np.asarray(gt.offsets[:-1], dtype=np.int64)
         i32 = np.concatenate([
@@ -87,7 +88,7 @@ class HungarianMatcher(nn.Module):
             counts[b_idx],                                              # number of targets of its image
             (np.repeat(np.arange(L), Tt) * N + np.tile(gt.image_of_row, L)),   # coord row of every GT sample row
         ]).astype(np.int32)
-        i32 = torch.from_numpy(i32).to(dev, non_blocking=True)
+        i32 = upload(i32, dev)
         n_rows = L * N * Q
         pred_offs_d, gt_offs_d = i64[:n_rows], i64[n_rows:]
         crow_d, tfirst_d, tcount_d, gcrow_d = i32[:n_rows], i32[n_rows:2 * n_rows], i32[2 * n_rows:3 * n_rows], i32[3 * n_rows:]

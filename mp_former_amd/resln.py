@@ -1,0 +1,78 @@
+"""Post-norm residual block ``LayerNorm(x + t)`` of the decoder layers as one native pass
+(csrc/elementwise.hip, mpf_res_ln256_*): the fp32 residual stream ``x`` plus the (bf16 under AMP)
+branch output ``t``, normalised, written as the next fp32 residual and/or as the bf16 operand of the
+next GEMMs — instead of add + LayerNorm + cast kernels forward and five kernels backward.
+Reference: mask2former_transformer_decoder.py:42-52, :100-112, :165-169 (forward_post), :1861
+(decoder_norm).  256 channels, CUDA; other cases use the torch ops."""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+
+_DT = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _ResLN(Function):
+    @staticmethod
+    def forward(ctx, x, t, gamma, beta, eps, want32, want16):
+        rows = x.numel() // 256
+        s = torch.empty_like(x) if t is not None else x
+        y32 = torch.empty_like(x) if want32 else None
+        y16 = torch.empty_like(x, dtype=torch.bfloat16) if want16 else None
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            code = _lib.lib().mpf_res_ln256_forward(
+                x.data_ptr(), t.data_ptr() if t is not None else None, _DT[t.dtype] if t is not None else 0,
+                gamma.data_ptr(), beta.data_ptr(), s.data_ptr() if t is not None else None,
+                y32.data_ptr() if want32 else None, y16.data_ptr() if want16 else None, mean.data_ptr(), rstd.data_ptr(),
+                rows, float(eps), _stream(x))
+        _lib.check(code, "mpf_res_ln256_forward")
+        ctx.save_for_backward(s, mean, rstd, gamma)
+        ctx.t_dtype = t.dtype if t is not None else None
+        ctx.rows = rows
+        return y32, y16
+
+    @staticmethod
+    def backward(ctx, g32, g16):
+        s, mean, rstd, gamma = ctx.saved_tensors
+        need_x, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and ctx.t_dtype is not None
+        t16 = need_t and ctx.t_dtype == torch.bfloat16
+        want32 = need_x or (need_t and not t16) or not t16
+        ds32 = torch.empty_like(s) if want32 else None
+        ds16 = torch.empty_like(s, dtype=torch.bfloat16) if t16 else None
+        dgb = torch.zeros((2, 256), dtype=torch.float32, device=s.device)
+        if g32 is not None:
+            g32 = g32.contiguous()
+        if g16 is not None:
+            g16 = g16.contiguous()
+        with torch.cuda.device(s.device):
+            code = _lib.lib().mpf_res_ln256_backward(
+                s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                g32.data_ptr() if g32 is not None else None, g16.data_ptr() if g16 is not None else None,
+                ds32.data_ptr() if ds32 is not None else None, ds16.data_ptr() if ds16 is not None else None,
+                dgb[0].data_ptr(), dgb[1].data_ptr(), ctx.rows, _stream(s))
+        _lib.check(code, "mpf_res_ln256_backward")
+        dt = None
+        if need_t:
+            dt = ds16 if t16 else ds32
+        return (ds32 if need_x else None), dt, dgb[0], dgb[1], None, None, None
+
+
+def res_ln(norm, x, t=None, want32=True, want16=False):
+    """(y32, y16) = LayerNorm(x + t) with the parameters of ``norm`` (an nn.LayerNorm).  x: fp32
+    residual stream; t: branch output (fp32 / bf16) or None.  y32 (fp32) / y16 (bf16) are None unless
+    requested."""
+    C = x.shape[-1]
+    ok = (x.is_cuda and C == 256 and x.dtype == torch.float32 and x.is_contiguous() and norm.elementwise_affine
+          and norm.bias is not None and (t is None or (t.shape == x.shape and t.dtype in _DT and t.is_contiguous())))
+    if ok:
+        return _ResLN.apply(x, t, norm.weight, norm.bias, norm.eps, want32, want16)
+    s = x if t is None else x + t
+    y = F.layer_norm(s.float(), (C,), norm.weight, norm.bias, norm.eps)
+    return (y if want32 else None), (y.to(torch.bfloat16) if want16 else None)

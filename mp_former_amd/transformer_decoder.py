@@ -26,7 +26,9 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import _lib, _rng
+from ._h2d import upload
 from .attention import attention_core
+from .resln import res_ln
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
 
 
@@ -285,14 +287,21 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         if self.dn_label_noise_ratio > 0:
             prob = _rng.rand("label_prob", tuple(labels.shape), device)
             chosen = prob < self.dn_label_noise_ratio
-            new_label = _rng.randint("label_new", (int(chosen.sum()),), self.num_classes, device)
-            labels = labels.clone()
-            labels[chosen] = new_label.to(labels.dtype)
+            if _rng.replaying():
+                # tests replay the reference's draws, which has one new label per CHOSEN position
+                # (:1003-1007: nonzero -> randint_like -> scatter_, a device->host sync)
+                new_label = _rng.randint("label_new", (int(chosen.sum()),), self.num_classes, device)
+                labels = labels.clone()
+                labels[chosen] = new_label.to(labels.dtype)
+            else:
+                # same distribution without the sync: draw a candidate for every position, keep the chosen
+                cand = torch.randint(0, self.num_classes, tuple(labels.shape), device=device, dtype=labels.dtype)
+                labels = torch.where(chosen, cand, labels)
         feats = self.label_enc(labels)
         bid = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(num)]).repeat(scalar, 1).view(-1)
         slot = torch.cat([torch.arange(n) for n in num])
         slot = torch.cat([slot + max_num * i for i in range(scalar)]).long()
-        bid, slot = bid.to(device), slot.to(device)
+        bid, slot = upload(bid, device), upload(slot, device)
         padding = torch.zeros(bs, pad, feats.shape[-1], device=device, dtype=feats.dtype)
         padding[(bid, slot)] = feats
         # GT rows per level, computed once per forward (the reference re-derives them every layer)
@@ -331,12 +340,15 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
     def _heads(self, W, output, mask_features, attn_mask_target_size, mp_rows=None):
         """forward_prediction_heads (:1859-1877).  Returns (outputs_class, outputs_mask,
         attn_mask[N,Qtot,HW] bool) where the attention mask already has the MP rows written (:1814-1816)
-        and all-masked rows cleared (:1780)."""
-        x = self.decoder_norm(output).transpose(0, 1)
-        outputs_class = F.linear(x, W["class_embed.weight"], W["class_embed.bias"])
+        and all-masked rows cleared (:1780).  ``output`` is the fp32 residual stream [Qtot, N, C]; the
+        heads run sequence-first and only the (small) results are viewed batch-first."""
+        amp = W["class_embed.weight"].dtype == torch.bfloat16
+        d32, d16 = res_ln(self.decoder_norm, output, None, want32=not amp, want16=amp)
+        x = d16 if amp else d32
+        outputs_class = F.linear(x, W["class_embed.weight"], W["class_embed.bias"]).transpose(0, 1)
         e = F.relu(F.linear(x, W["mask_embed.layers.0.weight"], W["mask_embed.layers.0.bias"]))
         e = F.relu(F.linear(e, W["mask_embed.layers.1.weight"], W["mask_embed.layers.1.bias"]))
-        mask_embed = F.linear(e, W["mask_embed.layers.2.weight"], W["mask_embed.layers.2.bias"])
+        mask_embed = F.linear(e, W["mask_embed.layers.2.weight"], W["mask_embed.layers.2.bias"]).transpose(0, 1)
         outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
         am = native_attn_mask(outputs_mask.detach(), attn_mask_target_size, mp_rows)
         return outputs_class, outputs_mask, am
@@ -385,25 +397,32 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             return mp["rows"][level]
 
         H = self.num_heads
+        output = output.float().contiguous()            # fp32 residual stream [Qtot, N, C]
+        xb = output.to(adt) if amp else output           # operand copy for the GEMMs (bf16 under AMP)
         outputs_class, outputs_mask, attn_mask = self._heads(W, output, mask_features, size_list[0], rows(0))
         predictions_class, predictions_mask = [outputs_class], [outputs_mask]
+
+        def post_norm(norm, x32, t2):
+            y32, y16 = res_ln(norm, x32, t2, want32=True, want16=amp)
+            return y32, (y16 if amp else y32)
+
         for i in range(self.num_layers):
             level = i % self.num_feature_levels
             # cross-attention first (:1784-1789), post-norm
             pre = f"transformer_cross_attention_layers.{i}.multihead_attn."
-            t2 = masked_mha_w(output, kin[level], src[level], W[pre + "in_proj_weight"], W[pre + "in_proj_bias"],
+            t2 = masked_mha_w(xb, kin[level], src[level], W[pre + "in_proj_weight"], W[pre + "in_proj_bias"],
                               W[pre + "out_proj.weight"], W[pre + "out_proj.bias"], H, attn_mask)
-            output = self.transformer_cross_attention_layers[i].norm(output + t2)
+            output, xb = post_norm(self.transformer_cross_attention_layers[i].norm, output, t2)
             # self-attention (:1791-1795)
             pre = f"transformer_self_attention_layers.{i}.self_attn."
-            t2 = masked_mha_w(output, output, output, W[pre + "in_proj_weight"], W[pre + "in_proj_bias"],
+            t2 = masked_mha_w(xb, xb, xb, W[pre + "in_proj_weight"], W[pre + "in_proj_bias"],
                               W[pre + "out_proj.weight"], W[pre + "out_proj.bias"], H, tgt_mask)
-            output = self.transformer_self_attention_layers[i].norm(output + t2)
+            output, xb = post_norm(self.transformer_self_attention_layers[i].norm, output, t2)
             # FFN (:1798-1800)
             pre = f"transformer_ffn_layers.{i}."
-            t2 = F.linear(F.relu(F.linear(output, W[pre + "linear1.weight"], W[pre + "linear1.bias"])),
+            t2 = F.linear(F.relu(F.linear(xb, W[pre + "linear1.weight"], W[pre + "linear1.bias"])),
                           W[pre + "linear2.weight"], W[pre + "linear2.bias"])
-            output = self.transformer_ffn_layers[i].norm(output + t2)
+            output, xb = post_norm(self.transformer_ffn_layers[i].norm, output, t2)
             nxt = (i + 1) % self.num_feature_levels
             outputs_class, outputs_mask, attn_mask = self._heads(W, output, mask_features, size_list[nxt], rows(nxt, i))
             predictions_class.append(outputs_class)

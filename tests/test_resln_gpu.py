@@ -1,0 +1,40 @@
+"""Fused residual + LayerNorm (csrc/elementwise.hip mpf_res_ln256_*) against add + F.layer_norm (+ cast):
+forward and all gradients, fp32 branch and bf16 branch (the AMP decoder), and the no-branch form
+(decoder_norm)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows", [3, 240, 2051])
+@pytest.mark.parametrize("tdtype", [None, torch.float32, torch.bfloat16])
+def test_res_ln_matches_torch(rows, tdtype):
+    from mp_former_amd.resln import res_ln
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    norm = torch.nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5); norm.bias.normal_()
+    x = torch.randn(rows, 1, 256, device=dev, requires_grad=True)
+    t = None if tdtype is None else torch.randn(rows, 1, 256, device=dev).to(tdtype).requires_grad_(True)
+    amp = tdtype == torch.bfloat16
+    y32, y16 = res_ln(norm, x, t, want32=True, want16=amp)
+    xr = x.detach().clone().requires_grad_(True)
+    tr = None if t is None else t.detach().clone().requires_grad_(True)
+    s = xr if tr is None else xr + tr.float()
+    r32 = F.layer_norm(s, (256,), norm.weight, norm.bias, norm.eps)
+    torch.testing.assert_close(y32, r32, rtol=1e-5, atol=1e-5)
+    g32 = torch.randn_like(y32)
+    loss, rloss = (y32 * g32).sum(), (r32 * g32).sum()
+    if amp:
+        assert torch.equal(y16, y32.to(torch.bfloat16))
+        g16 = torch.randn_like(y32).to(torch.bfloat16)
+        loss = loss + (y16.float() * g16.float()).sum()
+        rloss = rloss + (r32.to(torch.bfloat16).float() * g16.float()).sum()
+    gw = torch.autograd.grad(loss, [x] + ([t] if t is not None else []) + [norm.weight, norm.bias])
+    rw = torch.autograd.grad(rloss, [xr] + ([tr] if tr is not None else []) + [norm.weight, norm.bias])
+    for a, b in zip(gw, rw):
+        tol = 2e-2 if a.dtype == torch.bfloat16 else 2e-4
+        torch.testing.assert_close(a.float(), b.float(), rtol=tol, atol=tol * (1 + float(b.float().abs().max())))
