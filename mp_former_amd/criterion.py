@@ -25,6 +25,28 @@ from ._h2d import upload
 from .point_sample import MapSet, MaskLossSums, point_sample_offsets, select_uncertain
 
 
+def strided_stack(ts):
+    """torch.stack for tensors that are equally-spaced views of one parent (the per-layer class logits
+    of the batched prediction heads): returns (stacked [L, ...] VIEW of the parent, order) where
+    ``order[i]`` is the index in ``ts`` of row i, or (torch.stack(ts), identity) when they are not.
+    One as_strided node instead of L slice / transpose backward chains."""
+    ident = list(range(len(ts)))
+    base = ts[0]._base
+    if base is None or len(ts) < 2:
+        return torch.stack(ts), ident
+    shape, stride = ts[0].shape, ts[0].stride()
+    for t in ts:
+        if t._base is not base or t.shape != shape or t.stride() != stride:
+            return torch.stack(ts), ident
+    offs = [t.storage_offset() for t in ts]
+    order = sorted(ident, key=lambda i: offs[i])
+    so = [offs[i] for i in order]
+    delta = so[1] - so[0]
+    if delta <= 0 or any(so[i + 1] - so[i] != delta for i in range(len(so) - 1)):
+        return torch.stack(ts), ident
+    return base.as_strided((len(ts),) + tuple(shape), (delta,) + tuple(stride), so[0]), order
+
+
 class LossDict(dict):
     """The 60-entry loss dict of the reference interface; the entries are views of a few per-output
     vectors, which ``SetCriterion.weighted_total`` weights directly."""
@@ -167,18 +189,18 @@ class SetCriterion(nn.Module):
 
         # ---- stage 3: class losses ---------------------------------------------------------------------
         if "labels" in self.losses:
-            ce = self._class_losses(torch.stack([o["pred_logits"] for o in outs]),
-                                    upload(tc_main, dev))
-            losses.add_group(["loss_ce" + s_ for s_ in suffixes], ce)
+            logits, order = strided_stack([o["pred_logits"] for o in outs])
+            ce = self._class_losses(logits, upload(tc_main[order], dev))
+            losses.add_group(["loss_ce" + suffixes[i] for i in order], ce)
             if use_dn:
                 tc_dn = np.full((N, pad), K, dtype=np.int64)     # criterion.py:249-258: slot j of every group <-> GT j
                 for b in range(N):
                     T = gt.counts[b]
                     for s in range(scalar):
                         tc_dn[b, s * max_num:s * max_num + T] = labels_host[b]
-                ce_dn = self._class_losses(torch.stack([o["pred_logits"] for o in dn_outs]),
-                                           upload(tc_dn, dev))
-                losses.add_group(["loss_ce_dn" + s_ for s_ in suffixes], ce_dn)
+                logits_dn, order = strided_stack([o["pred_logits"] for o in dn_outs])
+                ce_dn = self._class_losses(logits_dn, upload(tc_dn, dev))
+                losses.add_group(["loss_ce_dn" + suffixes[i] for i in order], ce_dn)
         if not use_dn:
             z = torch.as_tensor(0.0, device=dev)
             for s in suffixes:

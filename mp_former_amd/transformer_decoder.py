@@ -357,6 +357,42 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         W = self._weights()
         return self._heads(W, output, mask_features.to(W["class_embed.weight"].dtype), attn_mask_target_size, mp_rows)
 
+    def _next_attn_mask(self, W, output, mask_features, attn_mask_target_size, mp_rows=None):
+        """The attention mask the NEXT layer needs (:1869-1875), from this layer's mask prediction,
+        outside autograd (the reference detaches it, :1875).  The differentiable predictions of all
+        layers are produced together by ``_heads_batched`` after the last layer."""
+        with torch.no_grad():
+            amp = W["class_embed.weight"].dtype == torch.bfloat16
+            d32, d16 = res_ln(self.decoder_norm, output.detach(), None, want32=not amp, want16=amp)
+            x = d16 if amp else d32
+            e = F.relu(F.linear(x, W["mask_embed.layers.0.weight"].detach(), W["mask_embed.layers.0.bias"].detach()))
+            e = F.relu(F.linear(e, W["mask_embed.layers.1.weight"].detach(), W["mask_embed.layers.1.bias"].detach()))
+            me = F.linear(e, W["mask_embed.layers.2.weight"].detach(), W["mask_embed.layers.2.bias"].detach()).transpose(0, 1)
+            m = torch.einsum("bqc,bchw->bqhw", me, mask_features.detach())
+            return native_attn_mask(m, attn_mask_target_size, mp_rows)
+
+    def _heads_batched(self, W, outputs, mask_features):
+        """forward_prediction_heads (:1859-1870) for the residual streams of ALL layers in one go: the
+        heads share their weights, so one LayerNorm / four GEMMs / one batched mask product over the
+        concatenated queries replace ten of each — and in the backward ten weight-gradient
+        accumulations per parameter and nine adds of a mask_features-sized gradient.  The mask
+        predictions of layer l are rows [l*Qtot, (l+1)*Qtot) of one [N, L*Qtot, H, W] tensor (the
+        criterion addresses them through that parent, point_sample.MapSet).
+        Returns (list of outputs_class [N,Qtot,K+1], list of outputs_mask [N,Qtot,H,W])."""
+        L = len(outputs)
+        Qt, N, C = outputs[0].shape
+        amp = W["class_embed.weight"].dtype == torch.bfloat16
+        X = torch.stack(outputs, 0).view(L * Qt, N, C)
+        d32, d16 = res_ln(self.decoder_norm, X, None, want32=not amp, want16=amp)
+        x = d16 if amp else d32
+        cls = F.linear(x, W["class_embed.weight"], W["class_embed.bias"])                    # [L*Qt, N, K+1]
+        e = F.relu(F.linear(x, W["mask_embed.layers.0.weight"], W["mask_embed.layers.0.bias"]))
+        e = F.relu(F.linear(e, W["mask_embed.layers.1.weight"], W["mask_embed.layers.1.bias"]))
+        me = F.linear(e, W["mask_embed.layers.2.weight"], W["mask_embed.layers.2.bias"]).transpose(0, 1)   # [N, L*Qt, C]
+        pm = torch.einsum("bqc,bchw->bqhw", me, mask_features)                               # [N, L*Qt, H, W]
+        cls = cls.view(L, Qt, N, -1)
+        return [cls[l].transpose(0, 1) for l in range(L)], [pm[:, l * Qt:(l + 1) * Qt] for l in range(L)]
+
     def forward(self, x, mask_features, mask=None, dn_args=None):
         assert len(x) == self.num_feature_levels
         del mask
@@ -399,8 +435,8 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         H = self.num_heads
         output = output.float().contiguous()            # fp32 residual stream [Qtot, N, C]
         xb = output.to(adt) if amp else output           # operand copy for the GEMMs (bf16 under AMP)
-        outputs_class, outputs_mask, attn_mask = self._heads(W, output, mask_features, size_list[0], rows(0))
-        predictions_class, predictions_mask = [outputs_class], [outputs_mask]
+        attn_mask = self._next_attn_mask(W, output, mask_features, size_list[0], rows(0))
+        streams = [output]
 
         def post_norm(norm, x32, t2):
             y32, y16 = res_ln(norm, x32, t2, want32=True, want16=amp)
@@ -424,9 +460,10 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
                           W[pre + "linear2.weight"], W[pre + "linear2.bias"])
             output, xb = post_norm(self.transformer_ffn_layers[i].norm, output, t2)
             nxt = (i + 1) % self.num_feature_levels
-            outputs_class, outputs_mask, attn_mask = self._heads(W, output, mask_features, size_list[nxt], rows(nxt, i))
-            predictions_class.append(outputs_class)
-            predictions_mask.append(outputs_mask)
+            streams.append(output)
+            if i + 1 < self.num_layers:
+                attn_mask = self._next_attn_mask(W, output, mask_features, size_list[nxt], rows(nxt, i))
+        predictions_class, predictions_mask = self._heads_batched(W, streams, mask_features)
 
         nq = self.num_queries
         if tgt_mask is not None:
