@@ -283,14 +283,17 @@ int mpf_planes_scatter(const float* src, const int64_t* dst_offs, void* dst, int
  * :165-169: tgt = LayerNorm(tgt + tgt2)) for 256 channels, one pass:
  *   s = x + t;  y = (s - mean) * rstd * gamma + beta      x fp32 [rows,256]; t fp32/bf16 or NULL
  * y is written as fp32 (y32, the next residual) and/or bf16 (y16, the next GEMM operand); s_out
- * (optional), mean, rstd [rows] are what the backward needs.
- * Backward: g = gy32 + gy16 (either may be NULL) -> ds32 / ds16 (same values, fp32 / bf16; either may
- * be NULL) and dgamma / dbeta ACCUMULATED with float atomics (zero them before the first call).
+ * (optional), mean, rstd [rows] are what the backward needs.  y_plus (optional) = y + padd[row %
+ * padd_rows]: the "src + pos" query input of the next encoder layer (msdeformattn.py:124).
+ * Backward: g = gy32 + gy16 + gy_plus (any may be NULL) -> ds32 / ds16 (same values, fp32 / bf16;
+ * either may be NULL) and dgamma / dbeta ACCUMULATED with float atomics (zero them before the first call).
  */
 int mpf_res_ln256_forward(const float* x, const void* t, int t_dtype, const float* gamma, const float* beta,
-                          float* s_out, float* y32, void* y16, float* mean, float* rstd, int rows, float eps, void* stream);
+                          float* s_out, float* y32, void* y16, float* mean, float* rstd, int rows, float eps,
+                          const float* padd, int padd_rows, float* y_plus, void* stream);
 int mpf_res_ln256_backward(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
-                           const void* gy16, float* ds32, void* ds16, float* dgamma, float* dbeta, int rows, void* stream);
+                           const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta,
+                           int rows, void* stream);
 
 /*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP

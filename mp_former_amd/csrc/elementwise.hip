@@ -160,7 +160,8 @@ template <typename TT>
 __global__ __launch_bounds__(256) void res_ln256_fwd_kernel(const float* __restrict__ x, const TT* __restrict__ t,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ s_out, float* __restrict__ y32, __bf16* __restrict__ y16,
-                                                            float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps)
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps,
+                                                            const float* __restrict__ padd, int padd_rows, float* __restrict__ y_plus)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -179,12 +180,17 @@ __global__ __launch_bounds__(256) void res_ln256_fwd_kernel(const float* __restr
     const float4 o = make_float4(d.x * rs * g.x + b.x, d.y * rs * g.y + b.y, d.z * rs * g.z + b.z, d.w * rs * g.w + b.w);
     if (y32) *reinterpret_cast<float4*>(y32 + (int64_t)row * 256 + c) = o;
     if (y16) *reinterpret_cast<bf16x4v*>(y16 + (int64_t)row * 256 + c) = bf16x4v{(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+    if (y_plus) {       // y + positional term (row-periodic): the query input of the next deformable-attention layer
+        const float4 pp = *reinterpret_cast<const float4*>(padd + (int64_t)(row % padd_rows) * 256 + c);
+        *reinterpret_cast<float4*>(y_plus + (int64_t)row * 256 + c) = make_float4(o.x + pp.x, o.y + pp.y, o.z + pp.z, o.w + pp.w);
+    }
     if ((threadIdx.x & 63) == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
 __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restrict__ s, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ gy32, const __bf16* __restrict__ gy16,
+                                                            const float* __restrict__ gy_plus,
                                                             float* __restrict__ ds32, __bf16* __restrict__ ds16,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int rows_per_block)
 {
@@ -198,6 +204,10 @@ __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restr
         if (gy32) dy = *reinterpret_cast<const float4*>(gy32 + (int64_t)row * 256 + c);
         if (gy16) {
             const float4 u = load4(gy16 + (int64_t)row * 256 + c);
+            dy = make_float4(dy.x + u.x, dy.y + u.y, dy.z + u.z, dy.w + u.w);
+        }
+        if (gy_plus) {
+            const float4 u = *reinterpret_cast<const float4*>(gy_plus + (int64_t)row * 256 + c);
             dy = make_float4(dy.x + u.x, dy.y + u.y, dy.z + u.z, dy.w + u.w);
         }
         const float4 sv = *reinterpret_cast<const float4*>(s + (int64_t)row * 256 + c);
@@ -225,29 +235,30 @@ __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restr
 
 extern "C" int mpf_res_ln256_forward(const float* x, const void* t, int t_dtype, const float* gamma, const float* beta,
                                      float* s_out, float* y32, void* y16, float* mean, float* rstd, int rows, float eps,
-                                     void* stream)
+                                     const float* padd, int padd_rows, float* y_plus, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) return 0;
     if (!x || !gamma || !beta || !mean || !rstd || (!y32 && !y16)) return mpf::fail(MPF_E_NULL, "res_ln256_forward: NULL buffer");
-    if (rows < 0) return mpf::fail(MPF_E_SHAPE, "res_ln256_forward: bad rows");
+    if (rows < 0 || (y_plus && (!padd || padd_rows <= 0))) return mpf::fail(MPF_E_SHAPE, "res_ln256_forward: bad rows / missing addend");
     const dim3 grid((rows + 3) / 4);
     mpf::set_kernel("res_ln256_fwd_kernel");
     if (t && t_dtype == MPF_BF16)
-        hipLaunchKernelGGL(res_ln256_fwd_kernel<__bf16>, grid, dim3(256), 0, st, x, (const __bf16*)t, gamma, beta, s_out, y32, (__bf16*)y16, mean, rstd, rows, eps);
+        hipLaunchKernelGGL(res_ln256_fwd_kernel<__bf16>, grid, dim3(256), 0, st, x, (const __bf16*)t, gamma, beta, s_out, y32, (__bf16*)y16, mean, rstd, rows, eps, padd, padd_rows, y_plus);
     else if (!t || t_dtype == MPF_F32)
-        hipLaunchKernelGGL(res_ln256_fwd_kernel<float>, grid, dim3(256), 0, st, x, (const float*)t, gamma, beta, s_out, y32, (__bf16*)y16, mean, rstd, rows, eps);
+        hipLaunchKernelGGL(res_ln256_fwd_kernel<float>, grid, dim3(256), 0, st, x, (const float*)t, gamma, beta, s_out, y32, (__bf16*)y16, mean, rstd, rows, eps, padd, padd_rows, y_plus);
     else
         return mpf::fail(MPF_E_DTYPE, "res_ln256_forward: t dtype must be MPF_F32 or MPF_BF16");
     return mpf::check(hipGetLastError(), "mpf_res_ln256_forward");
 }
 
 extern "C" int mpf_res_ln256_backward(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
-                                      const void* gy16, float* ds32, void* ds16, float* dgamma, float* dbeta, int rows, void* stream)
+                                      const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta,
+                                      int rows, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) return 0;
-    if (!s || !mean || !rstd || !gamma || (!gy32 && !gy16) || (!ds32 && !ds16) || !dgamma || !dbeta)
+    if (!s || !mean || !rstd || !gamma || (!gy32 && !gy16 && !gy_plus) || (!ds32 && !ds16) || !dgamma || !dbeta)
         return mpf::fail(MPF_E_NULL, "res_ln256_backward: NULL buffer");
     if (rows < 0) return mpf::fail(MPF_E_SHAPE, "res_ln256_backward: bad rows");
     // ~1024 blocks at most; each block reduces its rows' dgamma / dbeta before the atomics
@@ -255,7 +266,7 @@ extern "C" int mpf_res_ln256_backward(const float* s, const float* mean, const f
     rpb = ((rpb + 3) / 4) * 4;
     const dim3 grid((rows + rpb - 1) / rpb);
     mpf::set_kernel("res_ln256_bwd_kernel");
-    hipLaunchKernelGGL(res_ln256_bwd_kernel, grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16, ds32,
+    hipLaunchKernelGGL(res_ln256_bwd_kernel, grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16, gy_plus, ds32,
                        (__bf16*)ds16, dgamma, dbeta, rows, rpb);
     return mpf::check(hipGetLastError(), "mpf_res_ln256_backward");
 }

@@ -24,6 +24,7 @@ from torch.autograd import Function
 
 from .gemm3 import gemm3, gemm3_nt, split_weight
 from .msda import ms_deform_attn_backward, ms_deform_attn_forward
+from .resln import ln256_backward, ln256_forward
 
 PARAMS_PER_LAYER = 16
 _EPS = 1e-5
@@ -69,24 +70,26 @@ class EncoderFn(Function):
         x = src.reshape(R, C)
         saved = []
         no = M * L * P * 2
+        q = None
         for i in range(nl):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             w288 = torch.cat((wso, waw), 0)
             b288 = torch.cat((bso, baw), 0)
             value = gemm3(x, split_weight(wv), bv)
-            q = (x.view(N, S, C) + pos_full).view(R, C)
+            if q is None:       # layer 0; later layers get src + pos from the previous layer's norm2 pass
+                q = (x.view(N, S, C) + pos_full).view(R, C)
             raw = gemm3(q, split_weight(w288), b288)
             off = raw[:, :no].view(N, S, M, L, P, 2)
             attn = torch.softmax(raw[:, no:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
             loc = ref[None, :, None, None, None, :] + off / normalizer[None, None, None, :, None, :]
             ao = ms_deform_attn_forward(value.view(N, S, M, C // M), shapes, lsi, loc, attn, 128).view(R, C)
             s1 = gemm3(ao, split_weight(wo), bo, cin=x)
-            x1, mean1, rstd1 = torch.native_layer_norm(s1, [C], g1, b1, _EPS)
+            x1, mean1, rstd1, _ = ln256_forward(s1, g1, b1, _EPS)
             h = gemm3(x1, split_weight(w1), bb1, relu=True)
             s2 = gemm3(h, split_weight(w2), bb2, cin=x1)
-            x2, mean2, rstd2 = torch.native_layer_norm(s2, [C], g2, b2, _EPS)
+            x2, mean2, rstd2, qn = ln256_forward(s2, g2, b2, _EPS, padd=pos_full if i + 1 < nl else None)
             saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2]
-            x = x2
+            x, q = x2, qn
         ctx.save_for_backward(pos_full, level_embed, *params, *saved)
         ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
         return x.view(N, S, C)
@@ -115,18 +118,19 @@ class EncoderFn(Function):
                 split_level = meta["level_idx"][::rps].repeat(N)          # level of every split's rows
                 meta[key] = split_level
         dparams = [None] * (nl * PARAMS_PER_LAYER)
+        gq = None
         for i in reversed(range(nl)):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2) = saved[i * 14:(i + 1) * 14]
             dp = [None] * PARAMS_PER_LAYER
             # norm2 <- ffn
-            ds2, dp[14], dp[15] = torch.ops.aten.native_layer_norm_backward(g, s2, [C], mean2, rstd2, g2, b2, [True, True, True])
+            ds2, dp[14], dp[15] = ln256_backward(s2, mean2, rstd2, g2, g, gq)
             dh = gemm3(ds2, split_weight(w2, transpose=True), gate=h)
             dp[12], dp[13] = _wgrad(ds2, h, rps)
             dx1 = gemm3(dh, split_weight(w1, transpose=True), cin=ds2)
             dp[10], dp[11] = _wgrad(dh, x1, rps)
             # norm1 <- attention
-            ds1, dp[8], dp[9] = torch.ops.aten.native_layer_norm_backward(dx1, s1, [C], mean1, rstd1, g1, b1, [True, True, True])
+            ds1, dp[8], dp[9] = ln256_backward(s1, mean1, rstd1, g1, dx1)
             dao = gemm3(ds1, split_weight(wo, transpose=True))
             dp[6], dp[7] = _wgrad(ds1, ao, rps)
             gv, gl, ga = ms_deform_attn_backward(value.view(N, S, M, C // M), shapes, lsi, loc, attn,
@@ -149,7 +153,10 @@ class EncoderFn(Function):
             d_level += lvl @ w288
             dp[0], dp[1], dp[2], dp[3] = dw288[:no], db288[:no], dw288[no:], db288[no:]
             gv2 = gv.view(R, C)
-            g = gemm3(gv2, split_weight(wv, transpose=True), cin=ds1, cin2=dq)
+            # grad wrt this layer's input: through value_proj + the residual; the (src + pos) path (dq)
+            # joins inside the previous layer's norm2 backward (layer 0: added here)
+            g = gemm3(gv2, split_weight(wv, transpose=True), cin=ds1, cin2=dq if i == 0 else None)
+            gq = dq
             dp[4], dp[5] = _wgrad(gv2, x, rps)
             dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp
         return (g.view(N, S, C), None, d_level, None, *dparams)

@@ -141,7 +141,7 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         lay = self.encoder.layers[0]
         if self.training and (lay.dropout1.p > 0 or lay.dropout2.p > 0 or lay.dropout3.p > 0):
             return False
-        if self.d_model // self.nhead != 32 or self.d_model % 32 != 0:
+        if self.d_model != 256 or self.nhead != 8:       # the native LayerNorm / MSDA kernels of this path
             return False
         for s_, p_ in zip(srcs, pos_embeds):
             if not (s_.is_cuda and s_.dtype == torch.float32 and p_.dtype == torch.float32):

@@ -31,7 +31,7 @@ class _ResLN(Function):
                 x.data_ptr(), t.data_ptr() if t is not None else None, _DT[t.dtype] if t is not None else 0,
                 gamma.data_ptr(), beta.data_ptr(), s.data_ptr() if t is not None else None,
                 y32.data_ptr() if want32 else None, y16.data_ptr() if want16 else None, mean.data_ptr(), rstd.data_ptr(),
-                rows, float(eps), _stream(x))
+                rows, float(eps), None, 0, None, _stream(x))
         _lib.check(code, "mpf_res_ln256_forward")
         ctx.save_for_backward(s, mean, rstd, gamma)
         ctx.t_dtype = t.dtype if t is not None else None
@@ -54,7 +54,7 @@ class _ResLN(Function):
         with torch.cuda.device(s.device):
             code = _lib.lib().mpf_res_ln256_backward(
                 s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-                g32.data_ptr() if g32 is not None else None, g16.data_ptr() if g16 is not None else None,
+                g32.data_ptr() if g32 is not None else None, g16.data_ptr() if g16 is not None else None, None,
                 ds32.data_ptr() if ds32 is not None else None, ds16.data_ptr() if ds16 is not None else None,
                 dgb[0].data_ptr(), dgb[1].data_ptr(), ctx.rows, _stream(s))
         _lib.check(code, "mpf_res_ln256_backward")
@@ -76,3 +76,32 @@ def res_ln(norm, x, t=None, want32=True, want16=False):
     s = x if t is None else x + t
     y = F.layer_norm(s.float(), (C,), norm.weight, norm.bias, norm.eps)
     return (y if want32 else None), (y.to(torch.bfloat16) if want16 else None)
+
+
+def ln256_forward(x, gamma, beta, eps, padd=None):
+    """Raw forward for hand-scheduled callers (encoder_fused): x fp32 [rows, 256] -> (y, mean, rstd[, y + padd[row % len]])."""
+    rows = x.shape[0]
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    yp = torch.empty_like(x) if padd is not None else None
+    with torch.cuda.device(x.device):
+        code = _lib.lib().mpf_res_ln256_forward(
+            x.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), None, y.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(),
+            rows, float(eps), padd.data_ptr() if padd is not None else None, padd.shape[0] if padd is not None else 0,
+            yp.data_ptr() if yp is not None else None, _stream(x))
+    _lib.check(code, "mpf_res_ln256_forward")
+    return y, mean, rstd, yp
+
+
+def ln256_backward(s, mean, rstd, gamma, gy, gy_plus=None):
+    """Raw backward: -> (ds fp32, dgamma, dbeta) with g = gy (+ gy_plus)."""
+    ds = torch.empty_like(s)
+    dgb = torch.zeros((2, 256), dtype=torch.float32, device=s.device)
+    with torch.cuda.device(s.device):
+        code = _lib.lib().mpf_res_ln256_backward(
+            s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), gy.data_ptr(), None,
+            gy_plus.data_ptr() if gy_plus is not None else None, ds.data_ptr(), None, dgb[0].data_ptr(), dgb[1].data_ptr(),
+            s.shape[0], _stream(s))
+    _lib.check(code, "mpf_res_ln256_backward")
+    return ds, dgb[0], dgb[1]
