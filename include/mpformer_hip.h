@@ -271,14 +271,6 @@ int mpf_bias_act(const void* x, const float* bias, const void* res, void* y, int
                  int relu, void* stream);
 
 /*
- * dst[dst_offs[i] + p] = (dst dtype) src[i * plane + p], i < n, p < plane (plane % 4 == 0; dst_offs in
- * elements, 4-element aligned): moves the fp32 gradient planes accumulated by mpf_mask_loss_backward
- * (grad_offs[i] = i * plane) into the dense gradient of the prediction maps (criterion.py:172-191's
- * backward through point_sample), casting to the maps' dtype.
- */
-int mpf_planes_scatter(const float* src, const int64_t* dst_offs, void* dst, int dst_dtype, int n, int plane, void* stream);
-
-/*
  * Post-norm residual block of the decoder layers (mask2former_transformer_decoder.py:42-52, :100-112,
  * :165-169: tgt = LayerNorm(tgt + tgt2)) for 256 channels, one pass:
  *   s = x + t;  y = (s - mean) * rstd * gamma + beta      x fp32 [rows,256]; t fp32/bf16 or NULL
@@ -294,6 +286,18 @@ int mpf_res_ln256_forward(const float* x, const void* t, int t_dtype, const floa
 int mpf_res_ln256_backward(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
                            const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta,
                            int rows, void* stream);
+
+/*
+ * Same gradient as mpf_mask_loss_backward, written WITHOUT global atomics and without an fp32 image:
+ * grad[grad_offs[i] + p] (element offsets into a gradient of the maps' own dtype) receives the whole
+ * [h, w] plane of pair i (zeros where no point fell).  Every pair must name a distinct plane; planes
+ * of maps that have no pair are left untouched (zero them beforehand).  Accumulation is fixed-point in
+ * LDS (order-independent, deterministic; resolution 2^-23 of the per-pair gradient bound).
+ */
+int mpf_mask_loss_backward_dense(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows,
+                                 const uint8_t* gt, int H, int W, const int32_t* gt_rows, const float* coords,
+                                 const float* grad_sums, void* grad, int grad_dtype, const int64_t* grad_offs,
+                                 int n, int P, void* stream);
 
 /*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP

@@ -48,10 +48,11 @@ SIGNATURES = {
     "mpf_gemm3_nt": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp, _c_vp,
                            _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_bias_act": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
-    "mpf_planes_scatter": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_res_ln256_forward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
                                        _c_vp, _c_int, _c_vp, _c_vp]),
     "mpf_res_ln256_backward": (_c_int, [_c_vp] * 11 + [_c_int, _c_vp]),
+    "mpf_mask_loss_backward_dense": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
+                                              _c_vp, _c_int, _c_vp, _c_int, _c_int, _c_vp]),
     "mpf_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward_workspace_bytes": (ctypes.c_size_t, [_c_int] * 5 + [_c_vp]),

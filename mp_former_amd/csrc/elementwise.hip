@@ -79,54 +79,6 @@ extern "C" int mpf_bias_act(const void* x, const float* bias, const void* res, v
 }
 
 // ------------------------------------------------------------------------------------------------
-// dst[dst_offs[i] + p] = (T) src[i * plane + p]: the fp32 gradient planes that the point-sampled mask
-// loss accumulated (one scratch plane per (map, image, query) pair) -> their places in the dense
-// gradient of the prediction maps, cast to the maps' dtype.  Planes not named stay as the caller
-// initialised them (zero).
-// ------------------------------------------------------------------------------------------------
-namespace {
-
-template <typename T>
-__global__ __launch_bounds__(256) void planes_scatter_kernel(const float4* __restrict__ src, const int64_t* __restrict__ dst_offs,
-                                                             T* __restrict__ dst, int plane4)
-{
-    const int i = blockIdx.y;
-    const float4* s = src + (int64_t)i * plane4;
-    T* d = dst + dst_offs[i];
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < plane4; p += gridDim.x * 256) {
-        const float4 v = s[p];
-        if constexpr (sizeof(T) == 4) {
-            reinterpret_cast<float4*>(d)[p] = v;
-        } else {
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-            reinterpret_cast<bf16x4*>(d)[p] = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        }
-    }
-}
-
-}  // namespace
-
-extern "C" int mpf_planes_scatter(const float* src, const int64_t* dst_offs, void* dst, int dst_dtype, int n, int plane,
-                                  void* stream)
-{
-    hipStream_t st = (hipStream_t)stream;
-    if (n == 0) return 0;
-    if (!src || !dst_offs || !dst) return mpf::fail(MPF_E_NULL, "planes_scatter: NULL buffer");
-    if (n < 0 || plane <= 0 || plane % 4 != 0) return mpf::fail(MPF_E_SHAPE, "planes_scatter: plane must be a positive multiple of 4");
-    const int bx = (plane / 4 + 255) / 256 < 64 ? (plane / 4 + 255) / 256 : 64;
-    if (dst_dtype == MPF_BF16) {
-        mpf::set_kernel("planes_scatter_kernel<bf16>");
-        hipLaunchKernelGGL(planes_scatter_kernel<__bf16>, dim3(bx, n), dim3(256), 0, st, (const float4*)src, dst_offs, (__bf16*)dst, plane / 4);
-    } else if (dst_dtype == MPF_F32) {
-        mpf::set_kernel("planes_scatter_kernel<float>");
-        hipLaunchKernelGGL(planes_scatter_kernel<float>, dim3(bx, n), dim3(256), 0, st, (const float4*)src, dst_offs, (float*)dst, plane / 4);
-    } else {
-        return mpf::fail(MPF_E_DTYPE, "planes_scatter: dst dtype must be MPF_F32 or MPF_BF16");
-    }
-    return mpf::check(hipGetLastError(), "mpf_planes_scatter");
-}
-
-// ------------------------------------------------------------------------------------------------
 // Post-norm residual block of the decoder (mask2former_transformer_decoder.py:42-52, :100-112,
 // :165-169: tgt = LayerNorm(tgt + tgt2)), C = 256:  s = x + t (x fp32 residual stream, t bf16 or fp32
 // branch output, may be NULL), y = LN(s) * gamma + beta, written as fp32 (next residual) and/or bf16

@@ -151,6 +151,60 @@ __global__ __launch_bounds__(kThreads) void mask_loss_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward without global atomics: one workgroup per (pair, horizontal band of the prediction plane).
+// The band lives in LDS as 32-bit FIXED-POINT accumulators (per-lane LDS integer atomics run >10x
+// faster than fp32 LDS or global atomics on this chip, tools/ubench/lds_atomics.hip, and make the sum
+// order-independent = deterministic); every point of the pair whose bilinear footprint touches the
+// band is re-evaluated and scattered into it; the band is then written ONCE, converted to the
+// gradient dtype, to its place in the dense gradient of the prediction maps.  Scale: |d loss/d x| <=
+// B = |g_bce| + (|g_pt| + |g_p|)/4 per point, so 2^31 / (256 B) leaves room for 256 full-magnitude
+// hits on one pixel at a resolution of B * 2^-23 (fp32-grade).
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename TG>
+__global__ __launch_bounds__(1024) void mask_loss_bwd_band_kernel(
+    const T* __restrict__ pred, int h, int w, const int64_t* __restrict__ pred_offs,
+    const uint8_t* __restrict__ gt, int H, int W, const int32_t* __restrict__ gt_rows,
+    const float* __restrict__ coords, const float* __restrict__ gsum, TG* __restrict__ grad,
+    const int64_t* __restrict__ grad_offs, int n, int P, int band_rows)
+{
+    extern __shared__ int band[];
+    const int i = blockIdx.y;
+    const int y_lo = blockIdx.x * band_rows, y_hi = min(h, y_lo + band_rows);
+    const int cells = (y_hi - y_lo) * w;
+    for (int k = threadIdx.x; k < cells; k += 1024) band[k] = 0;
+    const T* pm = pred + pred_offs[i];
+    const uint8_t* gm = gt + (int64_t)gt_rows[i] * H * W;
+    const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)i * P;
+    const float g_bce = gsum[4 * i], g_pt = gsum[4 * i + 1], g_p = gsum[4 * i + 2];
+    const float B = fabsf(g_bce) + 0.25f * (fabsf(g_pt) + fabsf(g_p));
+    const float scale = B > 0.f ? 8388608.f / B : 0.f;             // 2^23 / B
+    const float inv = B > 0.f ? B * (1.f / 8388608.f) : 0.f;
+    __syncthreads();
+    if (B > 0.f) {
+        for (int p = threadIdx.x; p < P; p += 1024) {
+            const float2 xy = c[p];
+            const Bilin b = bilin(xy.x, xy.y, h, w);
+            if (b.y0 + 1 < y_lo || b.y0 >= y_hi) continue;       // footprint rows y0, y0+1 miss the band
+            const float x = sample(pm, h, w, b);
+            const float t = sample(gm, H, W, bilin(xy.x, xy.y, H, W));
+            const float sg = 1.f / (1.f + __expf(-x));
+            const float dx = (g_bce * (sg - t) + (g_pt * t + g_p) * sg * (1.f - sg)) * scale;
+            const bool x0v = b.x0 >= 0 && b.x0 < w, x1v = b.x0 + 1 >= 0 && b.x0 + 1 < w;
+            const bool y0v = b.y0 >= y_lo && b.y0 < y_hi, y1v = b.y0 + 1 >= y_lo && b.y0 + 1 < y_hi;
+            const int o = (b.y0 - y_lo) * w + b.x0;
+            const float hx = 1.f - b.lx, hy = 1.f - b.ly;
+            if (y0v && x0v) atomicAdd(&band[o], __float2int_rn(dx * hy * hx));
+            if (y0v && x1v) atomicAdd(&band[o + 1], __float2int_rn(dx * hy * b.lx));
+            if (y1v && x0v) atomicAdd(&band[o + w], __float2int_rn(dx * b.ly * hx));
+            if (y1v && x1v) atomicAdd(&band[o + w + 1], __float2int_rn(dx * b.ly * b.lx));
+        }
+    }
+    __syncthreads();
+    TG* dst = grad + grad_offs[i] + (int64_t)y_lo * w;
+    for (int k = threadIdx.x; k < cells; k += 1024) dst[k] = (TG)((float)band[k] * inv);
+}
+
 int check_common(const void* a, const void* b, const void* c, const void* d, int n, int P, int h, int w)
 {
     if (!a || !b || !c || !d) return mpf::fail(MPF_E_NULL, "point-sample: NULL buffer");
@@ -241,6 +295,44 @@ extern "C" int mpf_mask_loss_backward(const void* pred, int pred_dtype, int h, i
     }
     mpf::prof_end(mpf_last_kernel(), st, (double)n * P * (8.0 + 16.0 + 4.0 + 32.0));
     return mpf::check(hipGetLastError(), "mpf_mask_loss_backward");
+}
+
+extern "C" int mpf_mask_loss_backward_dense(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows,
+                                            const uint8_t* gt, int H, int W, const int32_t* gt_rows, const float* coords,
+                                            const float* grad_sums, void* grad, int grad_dtype, const int64_t* grad_offs,
+                                            int n, int P, void* stream)
+{
+    if (int e = check_common(pred, pred_rows, coords, grad, n, P, h, w)) return e;
+    if (!gt || !gt_rows || !grad_sums || !grad_offs) return mpf::fail(MPF_E_NULL, "mask_loss_backward_dense: NULL buffer");
+    if (n == 0) return 0;
+    if (grad_dtype != pred_dtype) return mpf::fail(MPF_E_DTYPE, "mask_loss_backward_dense: gradient dtype must equal the map dtype");
+    hipStream_t st = (hipStream_t)stream;
+    // horizontal bands of at most 128 KiB of 32-bit accumulators
+    const int max_rows = (128 * 1024) / (4 * w);
+    if (max_rows < 2) return mpf::fail(MPF_E_TOO_LARGE, "mask_loss_backward_dense: plane rows wider than 16384");
+    const int nb = (h + max_rows - 1) / max_rows;
+    const int band_rows = (h + nb - 1) / nb;
+    const size_t lds = (size_t)band_rows * w * 4;
+    const dim3 grid(nb, n);
+    mpf::prof_begin(st);
+    if (pred_dtype == MPF_F32) {
+        mpf::set_kernel("mask_loss_bwd_band_kernel<float>");
+        if (int e = mpf::check(hipFuncSetAttribute((const void*)mask_loss_bwd_band_kernel<float, float>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
+        hipLaunchKernelGGL((mask_loss_bwd_band_kernel<float, float>), grid, dim3(1024), lds, st, (const float*)pred, h, w, pred_rows, gt,
+                           H, W, gt_rows, coords, grad_sums, (float*)grad, grad_offs, n, P, band_rows);
+    } else if (pred_dtype == MPF_BF16) {
+        mpf::set_kernel("mask_loss_bwd_band_kernel<bf16>");
+        if (int e = mpf::check(hipFuncSetAttribute((const void*)mask_loss_bwd_band_kernel<__hip_bfloat16, __hip_bfloat16>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
+        hipLaunchKernelGGL((mask_loss_bwd_band_kernel<__hip_bfloat16, __hip_bfloat16>), grid, dim3(1024), lds, st,
+                           (const __hip_bfloat16*)pred, h, w, pred_rows, gt, H, W, gt_rows, coords, grad_sums,
+                           (__hip_bfloat16*)grad, grad_offs, n, P, band_rows);
+    } else {
+        return mpf::fail(MPF_E_DTYPE, "mpf_mask_loss_backward_dense: pred dtype must be MPF_F32 or MPF_BF16");
+    }
+    mpf::prof_end(mpf_last_kernel(), st, (double)n * P * (8.0 + 16.0 + 4.0) + (double)n * h * w * 2.0);
+    return mpf::check(hipGetLastError(), "mpf_mask_loss_backward_dense");
 }
 
 // ================================================================================================

@@ -139,9 +139,10 @@ class MaskLossSums(Function):
     pair i; x sampled from the plane at ms.base + pred_offs[i], t from gt_u8[gt_rows[i]]
     (criterion.py:172-191).  Differentiable wrt every base tensor of the MapSet (pass ``*ms.bases``).
 
-    Backward: the bilinear scatter accumulates in fp32 into one scratch plane per pair (the planes of a
-    step's pairs are distinct: a query is matched once per output), which are then cast into a dense
-    zero-initialised gradient of the maps' dtype — instead of an fp32 image of every map plus a cast."""
+    Backward: one workgroup per (pair, band of its plane) accumulates the bilinear scatter in LDS and
+    writes the band once into a dense zero-initialised gradient of the maps' dtype (the planes of a
+    step's pairs are distinct: a query is matched once per output) — no global atomics, no fp32 image
+    of every map."""
 
     @staticmethod
     def forward(ctx, ms, pred_offs, grad_offs, gt_u8, gt_rows, coords, *tensors):
@@ -165,35 +166,15 @@ class MaskLossSums(Function):
         pred_offs, grad_offs, gt_u8, gt_rows, coords = ctx.saved_tensors[:5]
         n, P = coords.shape[0], coords.shape[1]
         H, W = gt_u8.shape[-2:]
-        plane = ms.h * ms.w
-        if plane % 4 != 0:      # odd plane sizes: fp32 image of every map, then a cast (the simple route)
-            gbuf = torch.zeros(ms.g_total, dtype=torch.float32, device=ms.device)
-            if n:
-                g = grad_sums.contiguous().float()
-                with torch.cuda.device(ms.device):
-                    code = _lib.lib().mpf_mask_loss_backward(
-                        ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), H, W,
-                        gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), gbuf.data_ptr(), grad_offs.data_ptr(), n, P,
-                        _stream(ms.device))
-                _lib.check(code, "mpf_mask_loss_backward")
-            gbuf = gbuf.to(ms.dtype)
-            return (None, None, None, None, None, None,
-                    *[gbuf[int(ms.g_start[i]):int(ms.g_start[i]) + t.numel()].view(t.shape) for i, t in enumerate(ms.bases)])
         gbuf = torch.zeros(ms.g_total, dtype=ms.dtype, device=ms.device)
         if n:
             g = grad_sums.contiguous().float()
-            scratch = torch.zeros((n, plane), dtype=torch.float32, device=ms.device)
-            plane_offs = torch.arange(n, dtype=torch.int64, device=ms.device) * plane
-            lib = _lib.lib()
             with torch.cuda.device(ms.device):
-                code = lib.mpf_mask_loss_backward(
+                code = _lib.lib().mpf_mask_loss_backward_dense(
                     ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), H, W,
-                    gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), scratch.data_ptr(), plane_offs.data_ptr(), n, P,
-                    _stream(ms.device))
-                _lib.check(code, "mpf_mask_loss_backward")
-                code = lib.mpf_planes_scatter(scratch.data_ptr(), grad_offs.data_ptr(), gbuf.data_ptr(), _DT[ms.dtype], n, plane,
-                                              _stream(ms.device))
-            _lib.check(code, "mpf_planes_scatter")
+                    gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), gbuf.data_ptr(), _DT[ms.dtype], grad_offs.data_ptr(),
+                    n, P, _stream(ms.device))
+            _lib.check(code, "mpf_mask_loss_backward_dense")
         grads = []
         for i, t in enumerate(ms.bases):
             s = int(ms.g_start[i])

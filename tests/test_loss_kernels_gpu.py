@@ -90,13 +90,14 @@ def test_match_cost_matches_oracle():
         torch.testing.assert_close(C[i, :, :T[i]], ref, rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("hw", [(32, 32), (200, 176)])        # one LDS band / two bands in the backward
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_mask_loss_forward_backward_matches_autograd(dtype):
+def test_mask_loss_forward_backward_matches_autograd(dtype, hw):
     """fused BCE + dice sums and their gradient vs autograd through grid_sample + the reference losses
     (criterion.py:21-65,172-191).  bf16 maps are compared on the bf16-rounded values."""
     from mp_former_amd.point_sample import MapSet, MaskLossSums
     g = torch.Generator().manual_seed(3)
-    N, Q, h, w, H, W, P = 2, 6, 32, 32, 128, 128, 784
+    N, Q, (h, w), H, W, P = 2, 6, hw, 128, 128, 784
     a = (torch.randn(N, Q, h, w, generator=g) * 2).to(dtype).to(DEV).requires_grad_(True)
     bten = (torch.randn(N, 3, h, w, generator=g) * 2).to(dtype).to(DEV).requires_grad_(True)
     gt = (torch.rand(5, H, W, generator=g) < 0.4).to(DEV)
