@@ -171,11 +171,15 @@ int mpf_select_uncertain(const float* vals, const float* coords_in, float* coord
  * x = prediction sampled at coords[coord_rows[row]] on the fly, t = tsamp[t_first[row] + t, :]
  * (ground-truth masks pre-sampled at the same points with mpf_point_sample), t < t_count[row].
  *   cost [n_rows, Tmax] f32; entries t >= t_count[row] are left untouched.
+ * rows_per_group: the caller guarantees that every run of that many consecutive rows (starting at a
+ * multiple of it) shares coord_rows / t_first / t_count — the queries of one (output, image) — which
+ * lets one workgroup stage the planes in LDS and stream the target samples once per 4 rows; pass 1
+ * for no guarantee.
  */
 int mpf_match_cost(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_offs,
                    const float* coords, const int32_t* coord_rows, const float* tsamp,
                    const int32_t* t_first, const int32_t* t_count, float* cost,
-                   int n_rows, int Tmax, int P, float w_mask, float w_dice, void* stream);
+                   int n_rows, int Tmax, int P, float w_mask, float w_dice, int rows_per_group, void* stream);
 
 /*
  * Attention mask of the next decoder layer, fused (mask2former_transformer_decoder.py:1869-1875 +

@@ -33,7 +33,7 @@ SIGNATURES = {
                                         _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
     "mpf_select_uncertain": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_match_cost": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
-                                _c_int, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_vp]),
+                                _c_int, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int, _c_vp]),
     "mpf_attn_mask": (_c_int, [_c_vp, _c_int, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int, _c_vp, _c_int, _c_vp,
                                _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_attn_workspace_bytes": (ctypes.c_size_t, [_c_int] * 4),

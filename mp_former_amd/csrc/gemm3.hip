@@ -52,6 +52,20 @@ struct G3 {
 
 int g_ablate = 0;      // mpf_set_option("gemm3_ablate"): reserved for timing experiments
 
+#ifdef G3_TIMING
+// phase timing (build with -DG3_TIMING; tools/bench_gemm3.py --phases): s_memtime deltas of wave 0 of every
+// block, summed: [0] barrier-1 wait, [1] split + LDS write, [2] barrier-2 wait, [3] load issue, [4] MFMA step, [5] steps
+__device__ unsigned long long g3_dbg[8];
+#define G3_T(i)                                                       \
+    {                                                                 \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        tacc[i] += now_ - tlast;                                      \
+        tlast = now_;                                                 \
+    }
+#else
+#define G3_T(i)
+#endif
+
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b)       // {b.hi16, a.hi16}
 {
     return __builtin_amdgcn_perm(b, a, 0x07060302u);
@@ -86,35 +100,150 @@ __device__ __forceinline__ bf16x8 as_frag(const uint4 v)
     return c.f;
 }
 
-// one K step (32) of the wave's 64 x (16*NJ) tile from the LDS images; D^T = B . A^T, smallest terms first
-template <int NJ, int AKC, int BKC>
-__device__ __forceinline__ void mma_step(const unsigned char* lds, int a_frag, int b_frag, f32x4 (&acc)[4][NJ])
-{
-    bf16x8 fa[3][4];
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+// Accumulators of a wave's 64 x (16 NJ) output tile, one K step (32) of MFMAs from the LDS images, and
+// the walk over the lane's results.  D^T = B . A^T (a lane owns 4 consecutive output columns of one
+// row), smallest of the six products first.
+//   generic: 4 x NJ tiles of v_mfma_f32_16x16x32_bf16 (the TN kernels; NJ = 3 for 96-column tiles);
+//   Acc<4, true>: 2 x 2 tiles of v_mfma_f32_32x32x16_bf16 — half the MFMA issues; measured ~4 % faster in
+//     the NT kernel and ~8 % slower in the TN kernel, so only the NT kernel uses it.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int NJ, bool W32 = false>
+struct Acc {
+    f32x4 v[4][NJ];
+
+    __device__ __forceinline__ void zero()
+    {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            fa[pl][i] = as_frag(*reinterpret_cast<const uint4*>(lds + a_frag + pl * 4 * AKC + i * 256));
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        bf16x8 fb[3];
+            for (int j = 0; j < NJ; ++j) v[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // a_base / b_base: byte offset of the wave's first row in the A / B image
+    template <int AKC, int BKC>
+    __device__ __forceinline__ void step(const unsigned char* lds, int a_base, int b_base, int lane)
+    {
+        const int r16 = lane & 15, g = lane >> 4;
+        const int a_frag = a_base + g * AKC + (r16 ^ (2 * g)) * 16, b_frag = b_base + g * BKC + (r16 ^ (2 * g)) * 16;
+        bf16x8 fa[3][4];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            fb[pl] = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + pl * 4 * BKC + j * 256));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[2][i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+                fa[pl][i] = as_frag(*reinterpret_cast<const uint4*>(lds + a_frag + pl * 4 * AKC + i * 256));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2], fa[0][i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) {
+            bf16x8 fb[3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[1][i], acc[i][j], 0, 0, 0);
+            for (int pl = 0; pl < 3; ++pl)
+                fb[pl] = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + pl * 4 * BKC + j * 256));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[1][i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[2][i], v[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[0][i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2], fa[0][i], v[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[0][i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[1][i], v[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[1][i], v[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[0][i], v[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[0][i], v[i][j], 0, 0, 0);
+        }
     }
+
+    // f(row offset in the wave tile, column offset in the wave tile, the 4 values of that row at columns +0..3)
+    template <typename F>
+    __device__ __forceinline__ void quads(int lane, F f) const
+    {
+        const int r16 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f(i * 16 + r16, j * 16 + g * 4, make_float4(v[i][j][0], v[i][j][1], v[i][j][2], v[i][j][3]));
+    }
+};
+
+template <>
+struct Acc<4, true> {
+    f32x16 v[2][2];
+
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[i][j][e] = 0.f;
+    }
+
+    template <int AKC, int BKC>
+    __device__ __forceinline__ void step(const unsigned char* lds, int a_base, int b_base, int lane)
+    {
+        const int r32 = lane & 31, gh = lane >> 5;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const int kc = 2 * kh + gh;                       // this lane's k-chunk (8 values) of the 16-deep MFMA
+            const int sw = (r32 ^ (2 * kc)) * 16;
+            bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[pl][t] = as_frag(*reinterpret_cast<const uint4*>(lds + a_base + (pl * 4 + kc) * AKC + t * 512 + sw));
+                    fb[pl][t] = as_frag(*reinterpret_cast<const uint4*>(lds + b_base + (pl * 4 + kc) * BKC + t * 512 + sw));
+                }
+#define G3_MMA32(PB, PA)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int i = 0; i < 2; ++i)                   \
+        v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][j], fa[PA][i], v[i][j], 0, 0, 0);
+            G3_MMA32(0, 2) G3_MMA32(2, 0) G3_MMA32(1, 1) G3_MMA32(0, 1) G3_MMA32(1, 0) G3_MMA32(0, 0)
+#undef G3_MMA32
+        }
+    }
+
+    template <typename F>
+    __device__ __forceinline__ void quads(int lane, F f) const
+    {
+        const int r32 = lane & 31, gh = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    f(i * 32 + r32, j * 32 + 8 * q + 4 * gh,
+                      make_float4(v[i][j][4 * q], v[i][j][4 * q + 1], v[i][j][4 * q + 2], v[i][j][4 * q + 3]));
+    }
+};
+
+// epilogue of the TN kernels: bias / addends / ReLU / gate, 16-byte stores (m_wave, n_wave: first row / column of the wave tile)
+template <int NJ>
+__device__ __forceinline__ void g3_epilogue(const G3& p, const Acc<NJ, false>& acc, int lane, int m_wave, int n_wave)
+{
+    acc.quads(lane, [&](int mo, int no, float4 o) {
+        const int m = m_wave + mo, n = n_wave + no;
+        if (m >= p.M || n >= p.N) return;
+        if (p.bias) {
+            const float4 bz = *reinterpret_cast<const float4*>(p.bias + n);
+            o = make_float4(o.x + bz.x, o.y + bz.y, o.z + bz.z, o.w + bz.w);
+        }
+        if (p.cin) {
+            const float4 ci = *reinterpret_cast<const float4*>(p.cin + (int64_t)m * p.ldcin + n);
+            o = make_float4(o.x + ci.x, o.y + ci.y, o.z + ci.z, o.w + ci.w);
+        }
+        if (p.cin2) {
+            const float4 ci = *reinterpret_cast<const float4*>(p.cin2 + (int64_t)m * p.ldcin2 + n);
+            o = make_float4(o.x + ci.x, o.y + ci.y, o.z + ci.z, o.w + ci.w);
+        }
+        if (p.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        if (p.gate) {               // ReLU backward: pass the gradient where the saved activation is > 0
+            const float4 gt = *reinterpret_cast<const float4*>(p.gate + (int64_t)m * p.ldgate + n);
+            o = make_float4(gt.x > 0.f ? o.x : 0.f, gt.y > 0.f ? o.y : 0.f, gt.z > 0.f ? o.z : 0.f, gt.w > 0.f ? o.w : 0.f);
+        }
+        *reinterpret_cast<float4*>(p.c + (int64_t)m * p.ldc + n) = o;
+    });
 }
 
 template <int BN, bool A2>
@@ -137,7 +266,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int r16 = lane & 15, g = lane >> 4;
+
 
     // ---- staging maps ---------------------------------------------------------------------------
     const int akc = tid & 3;
@@ -215,73 +344,62 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    f32x4 acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Acc<NJ> acc;
+    acc.zero();
 
-    const int a_frag = g * kAKc + (wr * 64 + (r16 ^ (2 * g))) * 16;                       // + pl*4*kAKc + i*256
-    const int b_frag = kAbytes + g * kBKc + (wc * (BN / 2) + (r16 ^ (2 * g))) * 16;       // + pl*4*kBKc + j*256
+    const int a_frag = wr * 64 * 16;                        // byte offset of the wave's first row in the A image
+    const int b_frag = kAbytes + wc * (BN / 2) * 16;        // ... and in the B image
 
     const int nk = p.K / kBK;
     // All loads are unconditional (the K index is clamped; a surplus load is never stored): with
     // loads inside branches hipcc cannot count them and falls back to vmcnt(0) before the LDS writes,
     // which would drain the two-steps-ahead A loads every step.
     const int klast = (nk - 1) * kBK;
+#ifdef G3_TIMING
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     G3_LOAD_A(raE, 0);
     G3_LOAD_B(0);
     G3_LOAD_A(raO, min(kBK, klast));
     for (int kt = 0; kt < nk; kt += 2) {
         __syncthreads();
+        G3_T(0);
         G3_WRITE(raE);
+        G3_T(1);
         __syncthreads();
+        G3_T(2);
         G3_LOAD_B(min((kt + 1) * kBK, klast));      // B first: the next write waits for it with the A loads still in flight
         __builtin_amdgcn_sched_barrier(0);
         G3_LOAD_A(raE, min((kt + 2) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
-        mma_step<NJ, kAKc, kBKc>(lds, a_frag, b_frag, acc);
+        G3_T(3);
+        acc.template step<kAKc, kBKc>(lds, a_frag, b_frag, lane);
+        G3_T(4);
         if (kt + 1 >= nk) break;
         __syncthreads();
+        G3_T(0);
         G3_WRITE(raO);
+        G3_T(1);
         __syncthreads();
+        G3_T(2);
         G3_LOAD_B(min((kt + 2) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
         G3_LOAD_A(raO, min((kt + 3) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
-        mma_step<NJ, kAKc, kBKc>(lds, a_frag, b_frag, acc);
+        G3_T(3);
+        acc.template step<kAKc, kBKc>(lds, a_frag, b_frag, lane);
+        G3_T(4);
     }
+#ifdef G3_TIMING
+    if (tid == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&g3_dbg[i], tacc[i]);
+        atomicAdd(&g3_dbg[5], (unsigned long long)nk);
+    }
+#endif
 
-    // ---- epilogue: lane owns row m, columns n..n+3 of each tile -----------------------------------
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wc * (BN / 2) + j * 16 + g * 4;
-        if (n >= p.N) continue;
-        float4 bz = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bz = *reinterpret_cast<const float4*>(p.bias + n);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wr * 64 + i * 16 + r16;
-            if (m >= p.M) continue;
-            float4 o = make_float4(acc[i][j][0] + bz.x, acc[i][j][1] + bz.y, acc[i][j][2] + bz.z, acc[i][j][3] + bz.w);
-            if (p.cin) {
-                const float4 ci = *reinterpret_cast<const float4*>(p.cin + (int64_t)m * p.ldcin + n);
-                o = make_float4(o.x + ci.x, o.y + ci.y, o.z + ci.z, o.w + ci.w);
-            }
-            if (p.cin2) {
-                const float4 ci = *reinterpret_cast<const float4*>(p.cin2 + (int64_t)m * p.ldcin2 + n);
-                o = make_float4(o.x + ci.x, o.y + ci.y, o.z + ci.z, o.w + ci.w);
-            }
-            if (p.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-            if (p.gate) {               // ReLU backward: pass the gradient where the saved activation is > 0
-                const float4 gt = *reinterpret_cast<const float4*>(p.gate + (int64_t)m * p.ldgate + n);
-                o = make_float4(gt.x > 0.f ? o.x : 0.f, gt.y > 0.f ? o.y : 0.f, gt.z > 0.f ? o.z : 0.f, gt.w > 0.f ? o.w : 0.f);
-            }
-            *reinterpret_cast<float4*>(p.c + (int64_t)m * p.ldc + n) = o;
-        }
-    }
+    g3_epilogue<NJ>(p, acc, lane, m0 + wr * 64, n0 + wc * (BN / 2));
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // NT form (weight gradients): contraction over the ROWS of two row-major activations,
@@ -321,7 +439,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int r16 = lane & 15, g = lane >> 4;
+
 
     // staging maps: A units (kc, m) = (tid / 128 + {0, 2}, tid % 128); B units u = tid + {0, 256}
     const int am = tid & 127, akc = tid >> 7;
@@ -373,14 +491,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
         }                                                                                              \
     }
 
-    f32x4 acc[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Acc<NJ, NJ == 4> acc;
+    acc.zero();
 
-    const int a_frag = g * kAKc + (wr * 64 + (r16 ^ (2 * g))) * 16;
-    const int b_frag = kAbytes + g * kBKc + (wc * (BN / 2) + (r16 ^ (2 * g))) * 16;
+    const int a_frag = wr * 64 * 16;
+    const int b_frag = kAbytes + wc * (BN / 2) * 16;
 
     G3N_LOAD(r_begin);
     for (int r0 = r_begin; r0 < r_end; r0 += kBK) {
@@ -416,33 +531,29 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
         }
         __syncthreads();
         if (r0 + kBK < r_end) G3N_LOAD(r0 + kBK);
-        mma_step<NJ, kAKc, kBKc>(lds, a_frag, b_frag, acc);
+        acc.template step<kAKc, kBKc>(lds, a_frag, b_frag, lane);
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
     float* cp = p.c + (int64_t)sp * p.Mdim * p.Ndim;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + wc * (BN / 2) + j * 16 + g * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wr * 64 + i * 16 + r16;
-            if (m >= p.Mdim) continue;
-            if (!p.transpose_out) {
-                if (n + 3 < p.Ndim) {
-                    *reinterpret_cast<float4*>(cp + (int64_t)m * p.Ndim + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < p.Ndim) cp[(int64_t)m * p.Ndim + n + e] = acc[i][j][e];
-                }
+    acc.quads(lane, [&](int mo, int no, float4 o) {
+        const int m = m0 + wr * 64 + mo, n = n0 + wc * (BN / 2) + no;
+        if (m >= p.Mdim) return;
+        const float e4[4] = {o.x, o.y, o.z, o.w};
+        if (!p.transpose_out) {
+            if (n + 3 < p.Ndim) {
+                *reinterpret_cast<float4*>(cp + (int64_t)m * p.Ndim + n) = o;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (n + e < p.Ndim) cp[(int64_t)(n + e) * p.Mdim + m] = acc[i][j][e];
+                    if (n + e < p.Ndim) cp[(int64_t)m * p.Ndim + n + e] = e4[e];
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.Ndim) cp[(int64_t)(n + e) * p.Mdim + m] = e4[e];
         }
-    }
+    });
     // column sums: per-thread running sums -> LDS float atomics (once per block) -> per-split rows
     if (want_csa || want_csb) {
         __syncthreads();
@@ -574,3 +685,15 @@ extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t
     mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)R * Mdim + (double)R * Ndim + (double)p.nsplit * Mdim * Ndim));
     return mpf::check(hipGetLastError(), "mpf_gemm3_nt");
 }
+
+#ifdef G3_TIMING
+extern "C" int mpf_gemm3_debug_read(unsigned long long* out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g3_dbg), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g3_dbg), z, sizeof(z));
+    }
+    return mpf::check(e, "mpf_gemm3_debug_read");
+}
+#endif

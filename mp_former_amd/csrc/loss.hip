@@ -514,10 +514,178 @@ extern "C" int mpf_select_uncertain(const float* vals, const float* coords_in, f
     return mpf::check(hipGetLastError(), "mpf_select_uncertain");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Matching cost with the prediction plane staged in LDS.  The samples of a row are 4 x P random 2-byte
+// gathers from a 128 KB plane — from L2 that is the whole cost of the kernel above; from LDS it is
+// noise.  One workgroup takes G consecutive rows that share their point set and targets (the queries of
+// one (output, image)): for each row the plane is copied into LDS with 16-byte loads and sampled (the
+// samples and their sigmoids stay in registers, PT points per thread), then the target samples are
+// streamed ONCE for the G rows.  fp32 throughout; block reductions by wave shuffles + one LDS pass.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMcThreads = 1024;
+
+template <typename T>
+__device__ __forceinline__ float sample_lds(const T* plane, int h, int w, const Bilin& b)
+{
+    const bool x0v = b.x0 >= 0 && b.x0 < w, x1v = b.x0 + 1 >= 0 && b.x0 + 1 < w;
+    const bool y0v = b.y0 >= 0 && b.y0 < h, y1v = b.y0 + 1 >= 0 && b.y0 + 1 < h;
+    const int o = b.y0 * w + b.x0;
+    const float v00 = (y0v && x0v) ? ld(plane, o) : 0.f;
+    const float v01 = (y0v && x1v) ? ld(plane, o + 1) : 0.f;
+    const float v10 = (y1v && x0v) ? ld(plane, o + w) : 0.f;
+    const float v11 = (y1v && x1v) ? ld(plane, o + w + 1) : 0.f;
+    const float hx = 1.f - b.lx, hy = 1.f - b.ly;
+    return hy * (hx * v00 + b.lx * v01) + b.ly * (hx * v10 + b.lx * v11);
+}
+
+__device__ __forceinline__ float wave_sum64(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <typename T, int G, int PT>
+__global__ __launch_bounds__(kMcThreads) void match_cost_lds_kernel(
+    const T* __restrict__ pred, int h, int w, const int64_t* __restrict__ pred_offs,
+    const float* __restrict__ coords, const int32_t* __restrict__ coord_rows,
+    const float* __restrict__ tsamp, const int32_t* __restrict__ t_first, const int32_t* __restrict__ t_count,
+    float* __restrict__ cost, int n_rows, int Tmax, int P, float w_mask, float w_dice, int plane_bytes)
+{
+    constexpr int TT = 4;                       // targets per pass
+    constexpr int NV = 2 * G * TT + TT;         // values reduced per pass
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* plane = reinterpret_cast<T*>(smem);
+    float* red = reinterpret_cast<float*>(smem + plane_bytes);       // [16 waves][NV]
+    const int row0 = blockIdx.x * G;
+    const int Tn = t_count[row0];
+    if (Tn == 0) return;
+    const int T0 = t_first[row0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)coord_rows[row0] * P;
+    const int ng = min(G, n_rows - row0);
+
+    float2 xy[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int p = tid + j * kMcThreads;
+        xy[j] = p < P ? c[p] : make_float2(-4.f, -4.f);          // far outside: samples 0
+    }
+    float xs[G][PT], sg[G][PT];
+    float sp[G], sgs[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        sp[g] = 0.f; sgs[g] = 0.f;
+        __syncthreads();
+        if (g < ng) {
+            const uint4* src = reinterpret_cast<const uint4*>(pred + pred_offs[row0 + g]);
+            uint4* dst = reinterpret_cast<uint4*>(plane);
+            for (int k = tid; k < plane_bytes / 16; k += kMcThreads) dst[k] = src[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const bool valid = (tid + j * kMcThreads < P) && g < ng;
+            const float x = valid ? sample_lds(plane, h, w, bilin(xy[j].x, xy[j].y, h, w)) : 0.f;
+            const float s_ = 1.f / (1.f + __expf(-x));
+            xs[g][j] = x;
+            sg[g][j] = valid ? s_ : 0.f;
+            if (valid) {
+                sp[g] += fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));
+                sgs[g] += s_;
+            }
+        }
+    }
+    // softplus / sigmoid sums of each row
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float a = wave_sum64(sp[g]), b = wave_sum64(sgs[g]);
+        if (lane == 0) { red[wave * NV + 2 * g] = a; red[wave * NV + 2 * g + 1] = b; }
+    }
+    __syncthreads();
+    float sp_tot = 0.f, sg_tot = 0.f;          // needed by the threads that finalise (tid < G*TT): row g = tid / TT
+    {
+        const int g = min(tid / TT, G - 1);
+#pragma unroll
+        for (int k = 0; k < kMcThreads / 64; ++k) { sp_tot += red[k * NV + 2 * g]; sg_tot += red[k * NV + 2 * g + 1]; }
+    }
+    for (int tb = 0; tb < Tn; tb += TT) {
+        float ax[G][TT], as_[G][TT], at[TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            at[tt] = 0.f;
+#pragma unroll
+            for (int g = 0; g < G; ++g) { ax[g][tt] = 0.f; as_[g][tt] = 0.f; }
+        }
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const int p = tid + j * kMcThreads;
+            if (p < P) {
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    if (tb + tt < Tn) {
+                        const float tv = tsamp[(int64_t)(T0 + tb + tt) * P + p];
+                        at[tt] += tv;
+#pragma unroll
+                        for (int g = 0; g < G; ++g) { ax[g][tt] += xs[g][j] * tv; as_[g][tt] += sg[g][j] * tv; }
+                    }
+                }
+            }
+        }
+        __syncthreads();                        // previous pass's red[] fully consumed
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const float v = wave_sum64(at[tt]);
+            if (lane == 0) red[wave * NV + 2 * G * TT + tt] = v;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float a = wave_sum64(ax[g][tt]), b = wave_sum64(as_[g][tt]);
+                if (lane == 0) { red[wave * NV + (g * TT + tt) * 2] = a; red[wave * NV + (g * TT + tt) * 2 + 1] = b; }
+            }
+        }
+        __syncthreads();
+        if (tid < G * TT) {
+            const int g = tid / TT, tt = tid - g * TT;
+            if (g < ng && tb + tt < Tn) {
+                float sx = 0.f, ss = 0.f, st = 0.f;
+#pragma unroll
+                for (int k = 0; k < kMcThreads / 64; ++k) {
+                    sx += red[k * NV + (g * TT + tt) * 2];
+                    ss += red[k * NV + (g * TT + tt) * 2 + 1];
+                    st += red[k * NV + 2 * G * TT + tt];
+                }
+                const float cm = (sp_tot - sx) / (float)P;
+                const float cd = 1.f - (2.f * ss + 1.f) / (sg_tot + st + 1.f);
+                cost[(int64_t)(row0 + g) * Tmax + tb + tt] = w_mask * cm + w_dice * cd;
+            }
+        }
+    }
+}
+
+template <typename T>
+static bool launch_match_cost_lds(const T* pred, int h, int w, const int64_t* pred_offs, const float* coords,
+                                  const int32_t* coord_rows, const float* tsamp, const int32_t* t_first, const int32_t* t_count,
+                                  float* cost, int n_rows, int Tmax, int P, float w_mask, float w_dice, int G, hipStream_t st,
+                                  int* err)
+{
+    const int plane_bytes = h * w * (int)sizeof(T);
+    if (G != 4 || plane_bytes % 16 != 0 || plane_bytes > 136 * 1024 || P > 13 * kMcThreads || n_rows % 4 != 0) return false;
+    constexpr int PT = 13;
+    constexpr int NV = 2 * 4 * 4 + 4;
+    const size_t lds = (size_t)plane_bytes + (kMcThreads / 64) * NV * sizeof(float);
+    auto kfn = match_cost_lds_kernel<T, 4, PT>;
+    *err = mpf::check(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+    if (*err) return true;
+    hipLaunchKernelGGL(kfn, dim3(n_rows / 4), dim3(kMcThreads), lds, st, pred, h, w, pred_offs, coords, coord_rows, tsamp, t_first,
+                       t_count, cost, n_rows, Tmax, P, w_mask, w_dice, plane_bytes);
+    return true;
+}
+
 extern "C" int mpf_match_cost(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_offs,
                               const float* coords, const int32_t* coord_rows, const float* tsamp,
                               const int32_t* t_first, const int32_t* t_count, float* cost,
-                              int n_rows, int Tmax, int P, float w_mask, float w_dice, void* stream)
+                              int n_rows, int Tmax, int P, float w_mask, float w_dice, int rows_per_group, void* stream)
 {
     if (!pred || !pred_offs || !coords || !coord_rows || !tsamp || !t_first || !t_count || !cost)
         return mpf::fail(MPF_E_NULL, "match_cost: NULL buffer");
@@ -526,6 +694,16 @@ extern "C" int mpf_match_cost(const void* pred, int pred_dtype, int h, int w, co
     if (n_rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     mpf::prof_begin(st);
+    if (pred_dtype == MPF_BF16 && rows_per_group >= 4 && rows_per_group % 4 == 0) {
+        int err = 0;
+        mpf::set_kernel("match_cost_lds_kernel<bf16>");
+        if (launch_match_cost_lds((const __hip_bfloat16*)pred, h, w, pred_offs, coords, coord_rows, tsamp, t_first, t_count, cost,
+                                  n_rows, Tmax, P, w_mask, w_dice, 4, st, &err)) {
+            if (err) return err;
+            mpf::prof_end(mpf_last_kernel(), st, (double)n_rows * ((double)h * w * 2.0 + P * 8.0 / 4 + P * 4.0 * Tmax / 4));
+            return mpf::check(hipGetLastError(), "mpf_match_cost");
+        }
+    }
     if (pred_dtype == MPF_F32) {
         mpf::set_kernel("match_cost_kernel<float>");
         hipLaunchKernelGGL(match_cost_kernel<float>, dim3(n_rows), dim3(kThreads), (size_t)P * 4, st, (const float*)pred, h, w,

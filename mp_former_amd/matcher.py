@@ -95,7 +95,7 @@ class HungarianMatcher(nn.Module):
         # ---- ground-truth samples [L*Tt, P], then mask + dice cost [L*N*Q, Tmax] ------------------
         tsamp = point_sample_offsets(gt.u8.data_ptr(), torch.uint8, gt.H, gt.W, gt_offs_d, coords, gcrow_d, dev)
         C = match_cost(mapset, pred_offs_d, coords, crow_d, tsamp, tfirst_d, tcount_d, Tmax,
-                       self.cost_mask, self.cost_dice).view(L, N, Q, Tmax)
+                       self.cost_mask, self.cost_dice, rows_per_group=Q).view(L, N, Q, Tmax)   # rows are (l, b, q), q fastest
         # ---- class cost: -softmax(logits)[:, labels]  (matcher.py:105-111) ------------------------
         logits = torch.stack([o["pred_logits"] for o in outs]).float()                  # [L,N,Q,K+1]
         labels = torch.zeros((N, Tmax), dtype=torch.int64, device=dev)

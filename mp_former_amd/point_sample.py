@@ -120,7 +120,7 @@ def select_uncertain(vals, coords_in, k, P_out):
     return out
 
 
-def match_cost(ms, offs, coords, coord_rows, tsamp, t_first, t_count, Tmax, w_mask, w_dice):
+def match_cost(ms, offs, coords, coord_rows, tsamp, t_first, t_count, Tmax, w_mask, w_dice, rows_per_group=1):
     n = offs.numel()
     P = coords.shape[-2]
     cost = torch.zeros((n, Tmax), dtype=torch.float32, device=ms.device)
@@ -129,7 +129,7 @@ def match_cost(ms, offs, coords, coord_rows, tsamp, t_first, t_count, Tmax, w_ma
             code = _lib.lib().mpf_match_cost(ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, offs.data_ptr(), coords.data_ptr(),
                                              coord_rows.data_ptr(), tsamp.data_ptr(), t_first.data_ptr(),
                                              t_count.data_ptr(), cost.data_ptr(), n, Tmax, P, float(w_mask),
-                                             float(w_dice), _stream(ms.device))
+                                             float(w_dice), int(rows_per_group), _stream(ms.device))
         _lib.check(code, "mpf_match_cost")
     return cost
 

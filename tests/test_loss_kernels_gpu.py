@@ -61,14 +61,17 @@ def test_select_uncertain_equals_topk_set(n, M, k):
         torch.testing.assert_close(out[r, :k, 1], coords[r, idx[r], 1])
 
 
-def test_match_cost_matches_oracle():
-    """mask + dice part of the matching cost (matcher.py:15-62,122-148) vs oracle.matcher_cost."""
+@pytest.mark.parametrize("Q,dtype,group", [(9, torch.float32, 1), (12, torch.bfloat16, 12), (12, torch.bfloat16, 1)])
+def test_match_cost_matches_oracle(Q, dtype, group):
+    """mask + dice part of the matching cost (matcher.py:15-62,122-148) vs oracle.matcher_cost; bf16 maps
+    with a row-group guarantee take the LDS-staged kernel (4 rows per workgroup)."""
     from oracle import head_ref as O
+    from mp_former_amd import _lib
     from mp_former_amd.point_sample import MapSet, match_cost, point_sample_offsets
     g = torch.Generator().manual_seed(2)
-    N, Q, h, w, H, W, P = 2, 9, 16, 16, 64, 64, 500
+    N, h, w, H, W, P = 2, 16, 16, 64, 64, 500
     T = [3, 11]
-    masks = torch.randn(N, Q, h, w, generator=g) * 3
+    masks = (torch.randn(N, Q, h, w, generator=g) * 3).to(dtype)
     gts = [(torch.rand(t, H, W, generator=g) < 0.3) for t in T]
     coords = torch.rand(N, P, 2, generator=g)
     ms = MapSet([masks.to(DEV)])
@@ -81,11 +84,13 @@ def test_match_cost_matches_oracle():
     tsamp = point_sample_offsets(gt_u8.data_ptr(), torch.uint8, H, W, gt_offs, coords.to(DEV), img_of, torch.device(DEV))
     first = torch.tensor([0] * Q + [T[0]] * Q, dtype=torch.int32, device=DEV)
     cnt = torch.tensor([T[0]] * Q + [T[1]] * Q, dtype=torch.int32, device=DEV)
-    C = match_cost(ms, offs, coords.to(DEV), torch.from_numpy(b.astype(np.int32)).to(DEV), tsamp, first, cnt, Tmax, 5.0, 5.0)
+    C = match_cost(ms, offs, coords.to(DEV), torch.from_numpy(b.astype(np.int32)).to(DEV), tsamp, first, cnt, Tmax, 5.0, 5.0,
+                   rows_per_group=group)
+    assert ("match_cost_lds" in _lib.last_kernel()) == (group > 1 and dtype == torch.bfloat16), _lib.last_kernel()
     C = C.view(N, Q, Tmax).cpu()
     for i in range(N):
         logits = torch.zeros(Q, 4)          # class cost cancels: use zero weight
-        ref = O.matcher_cost(logits, masks[i], torch.zeros(T[i], dtype=torch.long), gts[i], coords[i:i + 1],
+        ref = O.matcher_cost(logits, masks[i].float(), torch.zeros(T[i], dtype=torch.long), gts[i], coords[i:i + 1],
                              w_class=0.0, w_mask=5.0, w_dice=5.0)
         torch.testing.assert_close(C[i, :, :T[i]], ref, rtol=2e-4, atol=2e-4)
 

@@ -152,6 +152,45 @@ def main_rps():
         print(f"{name:22s} {m}x{n}: " + "  ".join(out) + " us", flush=True)
 
 
+def main_l2():
+    """A operand with row stride 0 (every row the same 1-4 KB: L1/L2 resident) vs the real matrix."""
+    dev = torch.device("cuda:0")
+    M = 43008
+    for (n, k) in ((256, 256), (256, 1024), (1024, 256)):
+        a = torch.randn(M, k, device=dev)
+        a0 = torch.randn(1, k, device=dev).expand(M, k)
+        planes = split(torch.randn(n, k, device=dev))
+        c = torch.empty(M, n, device=dev)
+        t_real = timeit(lambda: gemm3(a, planes, out=c))
+        t_l2 = timeit(lambda: gemm3(a0, planes, out=c))
+        print(f"N={n} K={k}: real A {t_real:.1f} us, cache-resident A {t_l2:.1f} us", flush=True)
+
+
+def main_phases():
+    """needs a library built with -DG3_TIMING (make -C mp_former_amd/csrc clean all CXXFLAGS='... -DG3_TIMING')"""
+    import ctypes
+    dev = torch.device("cuda:0")
+    lib = _lib.lib()
+    fn = lib.mpf_gemm3_debug_read
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    M = 43008
+    for (n, k) in ((256, 256), (256, 1024), (1024, 256)):
+        a = torch.randn(M, k, device=dev)
+        planes = split(torch.randn(n, k, device=dev))
+        gemm3(a, planes); torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 8)()
+        fn(buf, 1)
+        t = timeit(lambda: gemm3(a, planes), iters=10)
+        torch.cuda.synchronize()
+        fn(buf, 1)
+        steps = buf[5]
+        names = ["barrier1", "split+write", "barrier2", "load issue", "mma step"]
+        per = [buf[i] / steps for i in range(5)]
+        print(f"N={n} K={k}: {t:.1f} us; per K-step of wave 0 (s_memtime ticks @100MHz?): " +
+              ", ".join(f"{nm} {v:.1f}" for nm, v in zip(names, per)) + f"  total {sum(per):.1f}", flush=True)
+
+
 def main_one():
     from mp_former_amd.gemm3 import gemm3_nt
     dev = torch.device("cuda:0")
@@ -167,6 +206,12 @@ def main_one():
 
 
 if __name__ == "__main__":
+    if "--l2" in sys.argv:
+        main_l2()
+        sys.exit(0)
+    if "--phases" in sys.argv:
+        main_phases()
+        sys.exit(0)
     if "--rps" in sys.argv:
         main_rps()
         sys.exit(0)
