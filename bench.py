@@ -141,8 +141,8 @@ def cpu_baseline(size, seconds_budget=30.0, threads=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=2, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
