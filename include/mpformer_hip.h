@@ -232,6 +232,27 @@ int mpf_attn_transpose2(const void* a, const void* b, void* aT, void* bT, int L,
 int mpf_attn_delta(const void* dout, const void* out, float* delta, int Lq, int N, int H, void* stream);
 
 /*
+ * Module-level forms of the two ops above (ops/modules/ms_deform_attn.py:103-117 folded in): the
+ * sampling locations and attention weights are derived inside the kernels from
+ *   raw[N*Lq, M*L*P*3]  = [sampling_offsets output (M,L,P,2) | attention_weights output (M,L*P)] of a row
+ *   ref_points[Lq, 2]    = the query's reference point, the same for every level (valid_ratios == 1)
+ *   attn = softmax over the L*P logits of (query, head);  loc = ref + offset / (W_l, H_l).
+ * Forward: loc_out / attn_out receive them (one preparation launch, then the gather kernel).  Backward (atomics-free
+ * formulation, as mpf_msda_backward_ws): grad_raw[N*Lq, M*L*P*3] replaces (grad_loc, grad_attn).
+ * fp32, 32 channels per head.
+ */
+int mpf_msda_forward_raw(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                         const void* raw, const void* ref_points, void* loc_out, void* attn_out, void* output,
+                         int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                         int num_point, int dtype, void* stream);
+int mpf_msda_backward_ws_raw(const void* value, const int64_t* host_spatial_shapes,
+                             const void* sampling_loc, const void* attn_weight, const void* grad_output,
+                             void* grad_value, void* grad_raw,
+                             int batch, int spatial_size, int num_heads, int channels,
+                             int num_levels, int num_query, int num_point, int dtype,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * fp32 GEMM of the pixel-decoder encoder's Linear layers (reference: nn.Linear inside
  * ops/modules/ms_deform_attn.py:58-62,98-106 and msdeformattn.py:103-131, fp32 because
  * msdeformattn.py:314 disables autocast) on the bf16 matrix cores: every fp32 operand is split

@@ -134,9 +134,9 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_tiled_f32(
         const int b = qm / LqM;
         const int m = qm % M;
         const int64_t gi = (int64_t)qm0 * LP + it;
+        const int H = lv.H[l], W = lv.W[l];
         const float2 xy = reinterpret_cast<const float2*>(loc)[gi];
         const float a = attn[gi];
-        const int H = lv.H[l], W = lv.W[l];
         const float x = xy.x * (float)W - 0.5f;
         const float y = xy.y * (float)H - 0.5f;
         int4 off = make_int4(-1, -1, -1, -1);
@@ -655,3 +655,65 @@ int set_msda_option(const char* key, int v)
     return 0;
 }
 }  // namespace mpf
+
+// Module-level op, front part (ops/modules/ms_deform_attn.py:103-117): from the raw projection outputs
+// raw[row, M*L*P*2 offsets | M*L*P logits] and the reference points ref[q, 2] (valid_ratios == 1: the same
+// point for every level) produce attn = softmax over the L*P logits of (q, m) and loc = ref + offset /
+// (W_l, H_l) in one pass — one launch instead of softmax + div + add.
+// (Deriving them inside the gather kernel's decode phase was slower: +47 us on the gather kernel for
+// 59 us of element-wise kernels removed; this kernel costs ~25 us.)
+namespace {
+// one thread per sampling point (coalesced reads of the offsets / writes of loc, attn); the L*P logits of
+// a (row, head) group go through LDS for the softmax; a workgroup takes kThreads / LP whole groups
+__global__ __launch_bounds__(kThreads) void msda_prep_kernel(const float* __restrict__ raw, const float* __restrict__ ref,
+                                                             const int64_t* __restrict__ shapes, float* __restrict__ loc,
+                                                             float* __restrict__ attn, int groups, int M, int L, int Lq, int P)
+{
+    __shared__ float s_lg[kThreads];
+    const int LP = L * P;
+    const int gpb = kThreads / LP;                              // groups per workgroup
+    const int gl = threadIdx.x / LP, lp = threadIdx.x - gl * LP;
+    const int grp = blockIdx.x * gpb + gl;                      // (row, head)
+    const bool ok = gl < gpb && grp < groups;
+    const int row = ok ? grp / M : 0, m = ok ? grp - row * M : 0;
+    const float* r = raw + (int64_t)row * (M * LP * 3);
+    if (ok) s_lg[threadIdx.x] = r[M * LP * 2 + m * LP + lp];
+    __syncthreads();
+    if (!ok) return;
+    float mx = -3.0e38f;
+    for (int j = 0; j < LP; ++j) mx = fmaxf(mx, s_lg[gl * LP + j]);
+    float sum = 0.f;
+    for (int j = 0; j < LP; ++j) sum += expf(s_lg[gl * LP + j] - mx);
+    const int l = lp / P;
+    const float W = (float)shapes[2 * l + 1], H = (float)shapes[2 * l];
+    const float2 o = reinterpret_cast<const float2*>(r + m * LP * 2)[lp];
+    const float2 rp = reinterpret_cast<const float2*>(ref)[row % Lq];
+    const int64_t gi = (int64_t)grp * LP + lp;
+    attn[gi] = expf(s_lg[threadIdx.x] - mx) / sum;
+    reinterpret_cast<float2*>(loc)[gi] = make_float2(rp.x + o.x / W, rp.y + o.y / H);
+}
+}  // namespace
+
+extern "C" int mpf_msda_forward_raw(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                    const void* raw, const void* ref_points, void* loc_out, void* attn_out, void* output,
+                                    int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                    int num_point, int dtype, void* stream)
+{
+    const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query, P = num_point;
+    if (int e = check_args(N, S, M, D, L, Lq, P, dtype)) return e;
+    if (!value || !spatial_shapes || !level_start_index || !raw || !ref_points || !output || !loc_out || !attn_out)
+        return mpf::fail(MPF_E_NULL, "msda_forward_raw: NULL buffer");
+    if (!tiled_ok(N, S, M, D, L, Lq, P, dtype, 1) || L * P > 32)
+        return mpf::fail(MPF_E_DTYPE, "msda_forward_raw: fp32 with 32 channels per head and L*P <= 32 only");
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = N * Lq * M, gpb = kThreads / (L * P);
+    mpf::set_kernel("msda_prep_kernel");
+    hipLaunchKernelGGL(msda_prep_kernel, dim3((groups + gpb - 1) / gpb), dim3(kThreads), 0, st, (const float*)raw,
+                       (const float*)ref_points, spatial_shapes, (float*)loc_out, (float*)attn_out, groups, M, L, Lq, P);
+    mpf::prof_begin(st);
+    mpf::set_kernel("msda_fwd_tiled_f32<32,1>");
+    hipError_t err = launch_fwd_tiled<32, 1>((const float*)value, spatial_shapes, level_start_index, (const float*)loc_out,
+                                             (const float*)attn_out, (float*)output, N, S, M, L, Lq, P, st);
+    mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)N * S * M * D + (double)N * Lq * M * L * P * 3 + (double)N * Lq * M * D));
+    return mpf::check(err, "mpf_msda_forward_raw");
+}

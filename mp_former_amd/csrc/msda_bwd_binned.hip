@@ -162,7 +162,8 @@ __device__ __forceinline__ float half_sum32(float v)
 __global__ __launch_bounds__(kThreads) void msda_bwd_push_kernel(
     const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
     const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
-    int* __restrict__ tile_count, Geom g, int nchunks, int nblocks, int ablate, unsigned value_bytes)
+    int* __restrict__ tile_count, Geom g, int nchunks, int nblocks, int ablate, unsigned value_bytes,
+    float* __restrict__ grad_raw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int LP = g.L * g.P;
@@ -280,6 +281,23 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_push_kernel(
         }
     }
     __syncthreads();
+    if (grad_raw) {
+        // fused epilogue (module-level op): gradients wrt the RAW projection outputs instead of wrt
+        // (loc, attn):  loc = ref + off / (W_l, H_l)  =>  d off = d loc / (W_l, H_l);
+        // attn = softmax over the L*P logits of (q, m)  =>  d logit = a (dA - sum_j a_j dA_j).
+        // Row layout of raw: [M*L*P*2 offsets | M*L*P logits].
+        const int no = g.M * LP * 2, nr = g.M * LP * 3;
+        for (int s = tid; s < nq * LP; s += kThreads) {
+            const int ql = s / LP, lp = s - ql * LP, l = lp / g.P;
+            float dot = 0.f;
+            for (int j = 0; j < LP; ++j) dot += s_f[ql * LP + j].z * s_ga[ql * LP + j];
+            float* row = grad_raw + (int64_t)(b * g.Lq + q0 + ql) * nr;
+            const float2 gl = s_gl[s];
+            reinterpret_cast<float2*>(row + m * LP * 2)[lp] = make_float2(gl.x / (float)g.W[l], gl.y / (float)g.H[l]);
+            row[no + m * LP + lp] = s_f[s].z * (s_ga[s] - dot);
+        }
+        return;
+    }
     for (int s = tid; s < nq * LP; s += kThreads) {
         const int ql = s / LP, lp = s - ql * LP;
         const int64_t gi = ((int64_t)(b * g.Lq + q0 + ql) * g.M + m) * LP + lp;
@@ -556,16 +574,16 @@ extern "C" size_t mpf_msda_backward_workspace_bytes(int batch, int num_heads, in
     return align256((3 * T + 1) * sizeof(int)) + max_entries * sizeof(Entry);
 }
 
-extern "C" int mpf_msda_backward_ws(const void* value, const int64_t* host_spatial_shapes,
-                                    const void* sampling_loc, const void* attn_weight, const void* grad_output,
-                                    void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
-                                    int batch, int spatial_size, int num_heads, int channels,
-                                    int num_levels, int num_query, int num_point, int dtype,
-                                    void* workspace, size_t workspace_bytes, void* stream)
+static int backward_ws_impl(const void* value, const int64_t* host_spatial_shapes,
+                            const void* sampling_loc, const void* attn_weight, const void* grad_output,
+                            void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, void* grad_raw,
+                            int batch, int spatial_size, int num_heads, int channels,
+                            int num_levels, int num_query, int num_point, int dtype,
+                            void* workspace, size_t workspace_bytes, void* stream)
 {
     const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query, P = num_point;
     if (!value || !host_spatial_shapes || !sampling_loc || !attn_weight || !grad_output || !grad_value ||
-        !grad_sampling_loc || !grad_attn_weight || !workspace)
+        (!grad_raw && (!grad_sampling_loc || !grad_attn_weight)) || !workspace)
         return mpf::fail(MPF_E_NULL, "msda_backward_ws: NULL buffer");
     if (dtype != MPF_F32 || D != kD) return mpf::fail(MPF_E_DTYPE, "msda_backward_ws: fp32 with 32 channels per head only");
     if (N <= 0 || S <= 0 || M <= 0 || L <= 0 || Lq <= 0 || P <= 0) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: bad sizes");
@@ -599,7 +617,7 @@ extern "C" int mpf_msda_backward_ws(const void* value, const int64_t* host_spati
     hipLaunchKernelGGL(msda_bwd_push_kernel, dim3(grid), dim3(kThreads), lds_push, st,
                        (const float*)value, (const float*)sampling_loc, (const float*)attn_weight,
                        (const float*)grad_output, (float*)grad_sampling_loc, (float*)grad_attn_weight,
-                       tile_count, g, nchunks, nblocks, g_push_ablate, (unsigned)((size_t)N * S * M * D * 4));
+                       tile_count, g, nchunks, nblocks, g_push_ablate, (unsigned)((size_t)N * S * M * D * 4), (float*)grad_raw);
     mpf::prof_end("msda_bwd_push_kernel", st, bytes_push);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, tile_start, total, T);
     mpf::prof_begin(st);
@@ -617,6 +635,31 @@ extern "C" int mpf_msda_backward_ws(const void* value, const int64_t* host_spati
     mpf::prof_end("msda_bwd_pull_kernel", st, esz * ((double)N * Lq * M * D + (double)N * S * M * D));
     mpf::set_kernel("msda_bwd_binned(push+fill+pull)");
     return mpf::check(hipGetLastError(), "mpf_msda_backward_ws");
+}
+
+extern "C" int mpf_msda_backward_ws(const void* value, const int64_t* host_spatial_shapes,
+                                    const void* sampling_loc, const void* attn_weight, const void* grad_output,
+                                    void* grad_value, void* grad_sampling_loc, void* grad_attn_weight,
+                                    int batch, int spatial_size, int num_heads, int channels,
+                                    int num_levels, int num_query, int num_point, int dtype,
+                                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    return backward_ws_impl(value, host_spatial_shapes, sampling_loc, attn_weight, grad_output, grad_value, grad_sampling_loc,
+                            grad_attn_weight, nullptr, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point,
+                            dtype, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mpf_msda_backward_ws_raw(const void* value, const int64_t* host_spatial_shapes,
+                                        const void* sampling_loc, const void* attn_weight, const void* grad_output,
+                                        void* grad_value, void* grad_raw,
+                                        int batch, int spatial_size, int num_heads, int channels,
+                                        int num_levels, int num_query, int num_point, int dtype,
+                                        void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!grad_raw) return mpf::fail(MPF_E_NULL, "msda_backward_ws_raw: NULL grad_raw");
+    return backward_ws_impl(value, host_spatial_shapes, sampling_loc, attn_weight, grad_output, grad_value, nullptr, nullptr,
+                            grad_raw, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, dtype,
+                            workspace, workspace_bytes, stream);
 }
 
 namespace mpf {

@@ -23,7 +23,7 @@ import torch
 from torch.autograd import Function
 
 from .gemm3 import gemm3, gemm3_nt, split_weight
-from .msda import ms_deform_attn_backward, ms_deform_attn_forward
+from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
 from .resln import ln256_backward, ln256_forward
 
 PARAMS_PER_LAYER = 16
@@ -79,10 +79,9 @@ class EncoderFn(Function):
             if q is None:       # layer 0; later layers get src + pos from the previous layer's norm2 pass
                 q = (x.view(N, S, C) + pos_full).view(R, C)
             raw = gemm3(q, split_weight(w288), b288)
-            off = raw[:, :no].view(N, S, M, L, P, 2)
-            attn = torch.softmax(raw[:, no:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
-            loc = ref[None, :, None, None, None, :] + off / normalizer[None, None, None, :, None, :]
-            ao = ms_deform_attn_forward(value.view(N, S, M, C // M), shapes, lsi, loc, attn, 128).view(R, C)
+            # softmax over the 12 logits, loc = ref + offset / (W_l, H_l) happen inside the MSDA kernel
+            ao, loc, attn = ms_deform_attn_forward_raw(value.view(N, S, M, C // M), shapes, lsi, raw, ref)
+            ao = ao.view(R, C)
             s1 = gemm3(ao, split_weight(wo), bo, cin=x)
             x1, mean1, rstd1, _ = ln256_forward(s1, g1, b1, _EPS)
             h = gemm3(x1, split_weight(w1), bb1, relu=True)
@@ -133,12 +132,8 @@ class EncoderFn(Function):
             ds1, dp[8], dp[9] = ln256_backward(s1, mean1, rstd1, g1, dx1)
             dao = gemm3(ds1, split_weight(wo, transpose=True))
             dp[6], dp[7] = _wgrad(ds1, ao, rps)
-            gv, gl, ga = ms_deform_attn_backward(value.view(N, S, M, C // M), shapes, lsi, loc, attn,
-                                                 dao.view(N, S, C), 128, host_shapes)
-            draw = torch.empty((R, no + M * L * P), dtype=torch.float32, device=g.device)
-            torch.div(gl, normalizer[None, None, None, :, None, :], out=draw[:, :no].view(N, S, M, L, P, 2))
-            draw[:, no:] = torch._softmax_backward_data(ga.view(N, S, M, L * P), attn.view(N, S, M, L * P), -1,
-                                                        torch.float32).view(R, M * L * P)
+            # d(raw): the softmax / offset-normaliser backward is the epilogue of the push kernel
+            gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C))
             w288 = torch.cat((wso, waw), 0)
             dq = gemm3(draw, split_weight(w288, transpose=True))
             # dW288^T = q^T . draw (288 on the 96-wide tile side) + per-split column sums of draw: the

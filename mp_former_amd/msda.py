@@ -157,6 +157,47 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [gv, gl, ga]
 
 
+def ms_deform_attn_forward_raw(value, spatial_shapes, level_start_index, raw, ref_points):
+    """Module-level forward (mpf_msda_forward_raw): value [N,S,M,32] fp32, raw [N*Lq, M*L*P*3] (sampling
+    offsets | attention logits of ops/modules/ms_deform_attn.py:103-106), ref_points [Lq,2] (the same
+    point for every level) -> (out [N,Lq,M*32], loc [N,Lq,M,L,P,2], attn [N,Lq,M,L,P])."""
+    N, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq = ref_points.shape[0]
+    P = raw.shape[1] // (M * L * 3)
+    assert raw.shape == (N * Lq, M * L * P * 3) and raw.is_contiguous() and ref_points.is_contiguous() and value.is_contiguous()
+    out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    loc = torch.empty((N, Lq, M, L, P, 2), dtype=value.dtype, device=value.device)
+    attn = torch.empty((N, Lq, M, L, P), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        code = _lib.lib().mpf_msda_forward_raw(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), raw.data_ptr(), ref_points.data_ptr(),
+            loc.data_ptr(), attn.data_ptr(), out.data_ptr(),
+            N, S, M, D, L, Lq, P, _DTYPES[value.dtype], _stream(value))
+    _lib.check(code, "mpf_msda_forward_raw")
+    return out, loc, attn
+
+
+def ms_deform_attn_backward_raw(value, host_shapes, sampling_loc, attn_weight, grad_output):
+    """-> (grad_value, grad_raw [N*Lq, M*L*P*3]) with the atomics-free kernels (mpf_msda_backward_ws_raw)."""
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_loc.shape
+    gv = torch.empty_like(value)
+    graw = torch.empty((N * Lq, M * L * P * 3), dtype=value.dtype, device=value.device)
+    lib = _lib.lib()
+    need = lib.mpf_msda_backward_workspace_bytes(N, M, L, Lq, P, host_shapes.data_ptr())
+    if need == 0:
+        raise RuntimeError("mpf_msda_backward_workspace_bytes rejected the level geometry")
+    ws = _workspace(value.device, need)
+    with torch.cuda.device(value.device):
+        code = lib.mpf_msda_backward_ws_raw(
+            value.data_ptr(), host_shapes.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            grad_output.data_ptr(), gv.data_ptr(), graw.data_ptr(),
+            N, S, M, D, L, Lq, P, _DTYPES[value.dtype], ws.data_ptr(), ws.numel(), _stream(value))
+    _lib.check(code, "mpf_msda_backward_ws_raw")
+    return gv, graw
+
+
 class MSDeformAttnFunction(Function):
     """ops/functions/ms_deform_attn_func.py:32-49."""
 

@@ -271,3 +271,46 @@ def test_module_matches_oracle_module_math(dev, oracle_msda):
     md = m.to(dev)
     got = md(q.to(dev), ref_pts.to(dev), src.to(dev), shapes.to(dev), lsi.to(dev))
     torch.testing.assert_close(got.cpu(), want, rtol=2e-3, atol=2e-3)  # GPU GEMMs (TF32-free fp32) vs CPU
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shapes,N", [(((6, 4), (3, 2), (12, 8)), 2), (((16, 16), (8, 8), (32, 32)), 1)])
+def test_raw_forms_match_softmax_plus_op(shapes, N):
+    """mpf_msda_forward_raw / mpf_msda_backward_ws_raw (softmax over the logits, loc = ref + offset /
+    (W_l, H_l) and their backward folded into the kernels; ops/modules/ms_deform_attn.py:103-117)
+    against torch softmax / division around the plain op."""
+    import torch
+    from mp_former_amd import msda
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    M, D, L, P = 8, 32, len(shapes), 4
+    S = sum(h * w for h, w in shapes)
+    ss = msda.attach_host_shapes(torch.as_tensor(shapes, dtype=torch.long, device=dev), list(shapes))
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(N, S, M, D, device=dev)
+    raw = torch.randn(N * S, M * L * P * 3, device=dev)
+    raw[:, :M * L * P * 2] *= 3.0                      # offsets of a few pixels, some out of range
+    ref = torch.rand(S, 2, device=dev)
+    go = torch.randn(N, S, M * D, device=dev)
+    out, loc, attn = msda.ms_deform_attn_forward_raw(value, ss, lsi, raw, ref)
+    # reference composition
+    r = raw.detach().clone().requires_grad_(True)
+    v = value.detach().clone().requires_grad_(True)
+    no = M * L * P * 2
+    off = r[:, :no].view(N, S, M, L, P, 2)
+    normalizer = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32, device=dev)
+    a_ref = torch.softmax(r[:, no:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
+    l_ref = ref[None, :, None, None, None, :] + off / normalizer[None, None, None, :, None, :]
+    o_ref = msda.MSDeformAttnFunction.apply(v, ss, lsi, l_ref.contiguous(), a_ref, 128)
+    torch.testing.assert_close(attn, a_ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loc, l_ref.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out, o_ref.detach(), rtol=1e-4, atol=1e-4)
+    o_ref.backward(go)
+    gv, graw = msda.ms_deform_attn_backward_raw(value, ss._mpf_host, loc, attn, go)
+    torch.testing.assert_close(gv, v.grad, rtol=1e-4, atol=1e-4)
+    pts = ((loc.detach() * normalizer[None, None, None, :, None, :] - 0.5) % 1.0)
+    smooth = ((pts > 1e-3) & (pts < 1 - 1e-3)).all(-1)                           # away from bilinear cell edges
+    g_off = graw[:, :no].view(N, S, M, L, P, 2)
+    r_off = r.grad[:, :no].view(N, S, M, L, P, 2)
+    torch.testing.assert_close(g_off[smooth], r_off[smooth], rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(graw[:, no:], r.grad[:, no:], rtol=2e-3, atol=2e-3)
