@@ -165,6 +165,16 @@ int mpf_select_uncertain(const float* vals, const float* coords_in, float* coord
                          int n, int M, int k, int P_out, void* stream);
 
 /*
+ * mpf_point_sample + mpf_select_uncertain in one launch for bf16 maps whose [h, w] plane fits 128 KiB:
+ * coords_out[i, :k] = the k candidate points (of the M in coords_in[i]) with the smallest |logit| of
+ * the plane at pred + pred_offs[i], in candidate order (ties at the threshold by index).  The plane is
+ * staged in LDS and the logits never reach memory.  M <= 40960.
+ */
+int mpf_sample_select_uncertain(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_offs,
+                                const float* coords_in, float* coords_out, int n, int M, int k, int P_out,
+                                void* stream);
+
+/*
  * Matching cost, mask + dice part (mask2former/modeling/matcher.py:15-62,122-148), for n_rows
  * (layer, image, query) prediction maps against the ground-truth masks of their image:
  *   cost[row, t] = w_mask*(sum softplus(x) - sum x*t)/P + w_dice*(1 - (2 sum s*t + 1)/(sum s + sum t + 1))

@@ -32,6 +32,7 @@ SIGNATURES = {
     "mpf_mask_loss_backward": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp,
                                         _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
     "mpf_select_uncertain": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
+    "mpf_sample_select_uncertain": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_match_cost": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp,
                                 _c_int, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_int, _c_vp]),
     "mpf_attn_mask": (_c_int, [_c_vp, _c_int, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int, _c_vp, _c_int, _c_vp,

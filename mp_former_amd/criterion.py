@@ -22,7 +22,7 @@ from . import _rng
 from .dist import global_num_masks
 from .matcher import GTMasks
 from ._h2d import upload
-from .point_sample import MapSet, MaskLossSums, point_sample_offsets, select_uncertain
+from .point_sample import MapSet, MaskLossSums, sample_select_uncertain
 
 
 def strided_stack(ts):
@@ -163,8 +163,7 @@ class SetCriterion(nn.Module):
                 gt_rows = upload(gr.astype(np.int32), dev)
                 with torch.no_grad():   # criterion.py:162-176: point selection carries no gradient
                     coords_over = _rng.rand_cat(over_parts, dev)
-                    logits_over = point_sample_offsets(ms.base_ptr, ms.dtype, ms.h, ms.w, pred_offs, coords_over, None, dev)
-                    coords = select_uncertain(logits_over, coords_over, num_uncertain, P)
+                    coords = sample_select_uncertain(ms, pred_offs, coords_over, num_uncertain, P)
                     if P - num_uncertain > 0:
                         coords[:, num_uncertain:] = _rng.rand_cat(rand_parts, dev)
                 sums = MaskLossSums.apply(ms, pred_offs, grad_offs, gt.u8, gt_rows, coords, *ms.bases)

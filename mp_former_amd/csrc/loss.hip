@@ -663,6 +663,123 @@ __global__ __launch_bounds__(kMcThreads) void match_cost_lds_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Importance sampling in one kernel (criterion.py:164-170 + detectron2
+// get_uncertain_point_coords_with_randomness): sample the M = 3P candidate points of a prediction
+// plane and keep the k with the smallest |logit|.  One workgroup per (prediction, target) pair: the
+// 128 KB bf16 plane is copied into LDS and sampled from there, the |logit| keys never leave the
+// registers (PT per thread, point p = tid + 1024 j), the k-th smallest key is found by an MSB-first
+// 8-bit radix select on an LDS histogram, and the selected coordinates are emitted in index order
+// (ties at the threshold broken by index) from wave ballots + one scan of the per-(j, wave) counts.
+// Replaces point_sample (60 MB of logits written and read back) + select_uncertain.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int PT>
+__global__ __launch_bounds__(kMcThreads) void sample_select_kernel(
+    const T* __restrict__ pred, int h, int w, const int64_t* __restrict__ pred_offs,
+    const float* __restrict__ coords_in, float* __restrict__ coords_out, int M, int k, int P_out, int plane_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* plane = reinterpret_cast<T*>(smem);
+    int* hist = reinterpret_cast<int*>(smem + plane_bytes);           // [256]
+    int* cnt = hist + 256;                                             // [2][PT][16] less / equal counts per (j, wave)
+    int* misc = cnt + 2 * PT * 16;                                     // [0] prefix, [1] krem, [2] total less
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float2* cin = reinterpret_cast<const float2*>(coords_in) + (int64_t)row * M;
+    float2* cout = reinterpret_cast<float2*>(coords_out) + (int64_t)row * P_out;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(pred + pred_offs[row]);
+        uint4* dst = reinterpret_cast<uint4*>(plane);
+        for (int i = tid; i < plane_bytes / 16; i += kMcThreads) dst[i] = src[i];
+    }
+    if (tid == 0) { misc[0] = 0; misc[1] = k; }
+    __syncthreads();
+    unsigned key[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int p = tid + j * kMcThreads;
+        key[j] = 0xFFFFFFFFu;                                          // past the end: never selected (k <= M)
+        if (p < M) {
+            const float2 xy = cin[p];
+            key[j] = __float_as_uint(fabsf(sample_lds(plane, h, w, bilin(xy.x, xy.y, h, w))));
+        }
+    }
+    unsigned prefix = 0u, mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        prefix = (unsigned)misc[0];
+#pragma unroll
+        for (int j = 0; j < PT; ++j)
+            if (tid + j * kMcThreads < M && (key[j] & mask) == prefix) atomicAdd(&hist[(key[j] >> shift) & 255u], 1);
+        __syncthreads();
+        const int krem = misc[1];
+        int below = 0, mine = 0;
+        if (tid < 256) {
+            for (int d = 0; d < tid; ++d) below += hist[d];
+            mine = hist[tid];
+        }
+        __syncthreads();                                               // everyone has read misc[1] / hist
+        if (tid < 256 && below < krem && krem <= below + mine) {       // exactly one digit holds the k-th key
+            misc[1] = krem - below;
+            misc[0] = (int)(prefix | ((unsigned)tid << shift));
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const unsigned thr = (unsigned)misc[0];
+    const int need_eq = misc[1];
+    // per-(j, wave) counts -> exclusive offsets in index order p = tid + 1024 j  (j major, then wave, then lane)
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const bool in = tid + j * kMcThreads < M;
+        const unsigned long long bl = __ballot(in && key[j] < thr), be = __ballot(in && key[j] == thr);
+        if (lane == 0) { cnt[j * 16 + wave] = __popcll(bl); cnt[PT * 16 + j * 16 + wave] = __popcll(be); }
+    }
+    __syncthreads();
+    if (wave < 2) {                                                    // wave 0 scans the "less" counts, wave 1 the "equal" counts
+        int* c = cnt + wave * PT * 16;
+        constexpr int N = PT * 16, PER = (N + 63) / 64;
+        int loc[PER], tot = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = lane * PER + i;
+            loc[i] = idx < N ? c[idx] : 0;
+            tot += loc[i];
+        }
+        int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        int run = incl - tot;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = lane * PER + i;
+            if (idx < N) c[idx] = run;
+            run += loc[i];
+        }
+        if (wave == 0 && lane == 63) misc[2] = incl;                   // total number of keys below the threshold
+    }
+    __syncthreads();
+    const int tot_less = misc[2];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const int p = tid + j * kMcThreads;
+        const bool less = p < M && key[j] < thr, eq = p < M && key[j] == thr;
+        const unsigned long long bl = __ballot(less), be = __ballot(eq);
+        if (less) {
+            cout[cnt[j * 16 + wave] + __popcll(bl & lt)] = cin[p];
+        } else if (eq) {
+            const int rank = cnt[PT * 16 + j * 16 + wave] + __popcll(be & lt);
+            if (rank < need_eq) cout[tot_less + rank] = cin[p];
+        }
+    }
+}
+
 template <typename T>
 static bool launch_match_cost_lds(const T* pred, int h, int w, const int64_t* pred_offs, const float* coords,
                                   const int32_t* coord_rows, const float* tsamp, const int32_t* t_first, const int32_t* t_count,
@@ -718,4 +835,28 @@ extern "C" int mpf_match_cost(const void* pred, int pred_dtype, int h, int w, co
     }
     mpf::prof_end(mpf_last_kernel(), st, (double)n_rows * P * (8.0 + 16.0 + 4.0 * Tmax));
     return mpf::check(hipGetLastError(), "mpf_match_cost");
+}
+
+extern "C" int mpf_sample_select_uncertain(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_offs,
+                                           const float* coords_in, float* coords_out, int n, int M, int k, int P_out,
+                                           void* stream)
+{
+    if (!pred || !pred_offs || !coords_in || !coords_out) return mpf::fail(MPF_E_NULL, "sample_select_uncertain: NULL buffer");
+    if (n < 0 || M <= 0 || k < 0 || k > M || k > P_out || h <= 0 || w <= 0) return mpf::fail(MPF_E_SHAPE, "sample_select_uncertain: bad sizes");
+    if (n == 0 || k == 0) return 0;
+    constexpr int PT = 40;
+    const int plane_bytes = h * w * 2;
+    if (pred_dtype != MPF_BF16) return mpf::fail(MPF_E_DTYPE, "sample_select_uncertain: bf16 maps only (use mpf_point_sample + mpf_select_uncertain)");
+    if (plane_bytes % 16 != 0 || plane_bytes > 128 * 1024 || M > PT * kMcThreads)
+        return mpf::fail(MPF_E_TOO_LARGE, "sample_select_uncertain: plane larger than 128 KiB or more than 40960 candidates");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)plane_bytes + (256 + 2 * PT * 16 + 8) * sizeof(int);
+    auto kfn = sample_select_kernel<__hip_bfloat16, PT>;
+    if (int e = mpf::check(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
+    mpf::prof_begin(st);
+    mpf::set_kernel("sample_select_kernel<bf16>");
+    hipLaunchKernelGGL(kfn, dim3(n), dim3(kMcThreads), lds, st, (const __hip_bfloat16*)pred, h, w, pred_offs, coords_in, coords_out,
+                       M, k, P_out, plane_bytes);
+    mpf::prof_end(mpf_last_kernel(), st, (double)n * ((double)plane_bytes + M * 8.0 + k * 16.0));
+    return mpf::check(hipGetLastError(), "mpf_sample_select_uncertain");
 }

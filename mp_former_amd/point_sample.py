@@ -120,6 +120,22 @@ def select_uncertain(vals, coords_in, k, P_out):
     return out
 
 
+def sample_select_uncertain(ms, offs, coords_in, k, P_out):
+    """coords_out[:, :k] = the k most uncertain (smallest |logit|) of the candidate points of every row's
+    plane.  bf16 planes of at most 128 KiB take the fused LDS kernel; everything else point_sample +
+    select_uncertain."""
+    n, M = coords_in.shape[0], coords_in.shape[1]
+    if ms.dtype == torch.bfloat16 and ms.h * ms.w * 2 <= 128 * 1024 and (ms.h * ms.w * 2) % 16 == 0 and M <= 40960 and n and k:
+        out = torch.empty((n, P_out, 2), dtype=torch.float32, device=coords_in.device)
+        with torch.cuda.device(ms.device):
+            code = _lib.lib().mpf_sample_select_uncertain(ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, offs.data_ptr(), coords_in.data_ptr(),
+                                                          out.data_ptr(), n, M, k, P_out, _stream(ms.device))
+        _lib.check(code, "mpf_sample_select_uncertain")
+        return out
+    logits = point_sample_offsets(ms.base_ptr, ms.dtype, ms.h, ms.w, offs, coords_in, None, ms.device)
+    return select_uncertain(logits, coords_in, k, P_out)
+
+
 def match_cost(ms, offs, coords, coord_rows, tsamp, t_first, t_count, Tmax, w_mask, w_dice, rows_per_group=1):
     n = offs.numel()
     P = coords.shape[-2]

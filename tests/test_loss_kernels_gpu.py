@@ -61,6 +61,28 @@ def test_select_uncertain_equals_topk_set(n, M, k):
         torch.testing.assert_close(out[r, :k, 1], coords[r, idx[r], 1])
 
 
+@pytest.mark.parametrize("hw,M,k", [((64, 64), 3000, 750), ((256, 256), 37632, 9408), ((32, 48), 1024, 1024), ((16, 16), 700, 1)])
+def test_sample_select_uncertain_equals_two_step(hw, M, k):
+    """fused LDS kernel (sample the plane + radix select in registers) == point_sample followed by
+    select_uncertain: same coordinates in the same order."""
+    from mp_former_amd import _lib
+    from mp_former_amd.point_sample import MapSet, point_sample_offsets, sample_select_uncertain, select_uncertain
+    g = torch.Generator().manual_seed(7)
+    h, w = hw
+    maps = (torch.randn(2, 5, h, w, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    maps[0, 1].round_()                       # plenty of ties in one plane
+    ms = MapSet([maps])
+    ti = np.zeros(4, np.int64); bi = np.array([0, 0, 1, 1]); qi = np.array([1, 4, 0, 2])
+    offs = torch.from_numpy(ms.offsets(ti, bi, qi)).to(DEV)
+    coords = torch.rand(4, M, 2, generator=g).to(DEV)
+    P_out = k + 5
+    got = sample_select_uncertain(ms, offs, coords, k, P_out)
+    assert "sample_select_kernel" in _lib.last_kernel(), _lib.last_kernel()
+    logits = point_sample_offsets(ms.base_ptr, ms.dtype, h, w, offs, coords, None, torch.device(DEV))
+    ref = select_uncertain(logits, coords, k, P_out)
+    assert torch.equal(got[:, :k], ref[:, :k])
+
+
 @pytest.mark.parametrize("Q,dtype,group", [(9, torch.float32, 1), (12, torch.bfloat16, 12), (12, torch.bfloat16, 1)])
 def test_match_cost_matches_oracle(Q, dtype, group):
     """mask + dice part of the matching cost (matcher.py:15-62,122-148) vs oracle.matcher_cost; bf16 maps
