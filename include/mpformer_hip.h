@@ -22,7 +22,7 @@ extern "C" {
 #endif
 
 /* element types of the floating-point buffers */
-enum { MPF_F32 = 0, MPF_F64 = 1, MPF_BF16 = 2, MPF_U8 = 3 };
+enum { MPF_F32 = 0, MPF_F64 = 1, MPF_BF16 = 2, MPF_U8 = 3, MPF_BITS = 4 /* byte masks packed 32 pixels per word */ };
 
 /* argument errors */
 enum {
@@ -118,8 +118,9 @@ const char* mpf_last_kernel(void);
  * its masks -> coord_rows[i] = image of row i) and mask2former/modeling/criterion.py:164-170
  * (importance sampling of the loss points: coord_rows = NULL, i.e. one point set per row).
  *   src   base pointer of dense [h, w] maps of dtype MPF_F32 / MPF_BF16 / MPF_U8 (bool ground-truth
- *         masks, 0/1 bytes); rows [n] int64 = ELEMENT offset of each row's map from `src` (maps of
- *         several tensors can be addressed in one launch from a common base)
+ *         masks, 0/1 bytes) / MPF_BITS (the same masks packed by mpf_pack_mask_bits); rows [n] int64 =
+ *         ELEMENT (pixel, for MPF_BITS) offset of each row's map from `src` (maps of several tensors
+ *         can be addressed in one launch from a common base)
  *   coords [C, P, 2] f32 (x, y) in [0,1]            coord_rows [n] int32 or NULL (= identity)
  *   out   [n, P] f32, fully overwritten
  */
@@ -136,12 +137,16 @@ int mpf_point_sample(const void* src, int src_dtype, int h, int w, const int64_t
  * gather of src_masks, the float copy of the GT masks, two point_sample calls and the element-wise
  * loss tensors of the reference.
  *   pred  base pointer, MPF_F32 / MPF_BF16; pred_rows [n] int64 element offsets of the [h,w] maps
- *   gt [Rt, H, W] bytes (0/1), gt_rows [n] int32    coords [n, P, 2] f32
- *   partial [n, chunks, 4] f32, fully overwritten
+ *   gt [Rt, H, W] bytes (0/1) (gt_dtype MPF_U8) or their bit-packed form [Rt, H*W/32] words (MPF_BITS,
+ *   H*W % 32 == 0: 8x smaller, L2-resident under the random gathers), gt_rows [n] int32
+ *   coords [n, P, 2] f32      partial [n, chunks, 4] f32, fully overwritten
  */
 int mpf_mask_loss_forward(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows,
-                          const uint8_t* gt, int H, int W, const int32_t* gt_rows,
+                          const void* gt, int gt_dtype, int H, int W, const int32_t* gt_rows,
                           const float* coords, float* partial, int n, int P, int chunks, void* stream);
+
+/* bits[i] bit j = masks[32 i + j] != 0 (n_pixels % 32 == 0): the MPF_BITS form of byte masks */
+int mpf_pack_mask_bits(const uint8_t* masks, void* bits, int64_t n_pixels, void* stream);
 
 /*
  * Backward of the above wrt pred: the f32 map at grad_pred + grad_offs[i] (caller zero-fills;
@@ -330,7 +335,7 @@ int mpf_res_ln256_backward(const float* s, const float* mean, const float* rstd,
  * LDS (order-independent, deterministic; resolution 2^-23 of the per-pair gradient bound).
  */
 int mpf_mask_loss_backward_dense(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows,
-                                 const uint8_t* gt, int H, int W, const int32_t* gt_rows, const float* coords,
+                                 const void* gt, int gt_dtype, int H, int W, const int32_t* gt_rows, const float* coords,
                                  const float* grad_sums, void* grad, int grad_dtype, const int64_t* grad_offs,
                                  int n, int P, void* stream);
 

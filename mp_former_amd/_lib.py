@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpformer_hip.so")
 ABI_VERSION = 1
 
-MPF_F32, MPF_F64, MPF_BF16, MPF_U8 = 0, 1, 2, 3
+MPF_F32, MPF_F64, MPF_BF16, MPF_U8, MPF_BITS = 0, 1, 2, 3, 4
 
 _lib = None
 
@@ -27,8 +27,9 @@ SIGNATURES = {
     "mpf_profile_get": (_c_int, [ctypes.c_char_p, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(ctypes.c_double)]),
     "mpf_point_sample": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
-    "mpf_mask_loss_forward": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp,
+    "mpf_mask_loss_forward": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp,
                                        _c_vp, _c_int, _c_int, _c_int, _c_vp]),
+    "mpf_pack_mask_bits": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_vp]),
     "mpf_mask_loss_backward": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp,
                                         _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
     "mpf_select_uncertain": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
@@ -52,7 +53,7 @@ SIGNATURES = {
     "mpf_res_ln256_forward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
                                        _c_vp, _c_int, _c_vp, _c_vp]),
     "mpf_res_ln256_backward": (_c_int, [_c_vp] * 11 + [_c_int, _c_vp]),
-    "mpf_mask_loss_backward_dense": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
+    "mpf_mask_loss_backward_dense": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
                                               _c_vp, _c_int, _c_vp, _c_int, _c_int, _c_vp]),
     "mpf_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),

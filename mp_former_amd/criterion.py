@@ -166,7 +166,7 @@ class SetCriterion(nn.Module):
                     coords = sample_select_uncertain(ms, pred_offs, coords_over, num_uncertain, P)
                     if P - num_uncertain > 0:
                         coords[:, num_uncertain:] = _rng.rand_cat(rand_parts, dev)
-                sums = MaskLossSums.apply(ms, pred_offs, grad_offs, gt.u8, gt_rows, coords, *ms.bases)
+                sums = MaskLossSums.apply(ms, pred_offs, grad_offs, gt, gt_rows, coords, *ms.bases)
                 per_mask = sums[:, 0] / P                                                  # mean_p BCE (criterion.py:48-65)
                 per_dice = 1 - (2 * sums[:, 1] + 1) / (sums[:, 2] + sums[:, 3] + 1)        # criterion.py:21-40
                 z = torch.zeros(G, dtype=torch.float32, device=dev)

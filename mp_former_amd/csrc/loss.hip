@@ -26,6 +26,18 @@ __device__ __forceinline__ float ld(const float* p, int64_t i) { return p[i]; }
 __device__ __forceinline__ float ld(const __hip_bfloat16* p, int64_t i) { return __bfloat162float(p[i]); }
 __device__ __forceinline__ float ld(const uint8_t* p, int64_t i) { return p[i] ? 1.f : 0.f; }
 
+// ground-truth masks packed 32 pixels per word (mpf_pack_mask_bits): 1 MiB -> 128 KiB per 1024^2 mask,
+// so a step's masks stay L2-resident under the random bilinear gathers of the loss kernels
+struct BitPlane {
+    const uint32_t* words;      // base of ALL planes
+    int64_t first;              // pixel index of this plane's (0, 0)
+};
+__device__ __forceinline__ float ld(const BitPlane& m, int64_t i)
+{
+    const int64_t j = m.first + i;
+    return ((m.words[j >> 5] >> (unsigned)(j & 31)) & 1u) ? 1.f : 0.f;
+}
+
 struct Bilin {
     int x0, y0;
     float lx, ly;
@@ -41,8 +53,8 @@ __device__ __forceinline__ Bilin bilin(float cx, float cy, int h, int w)
     return b;
 }
 
-template <typename T>
-__device__ __forceinline__ float sample(const T* map, int h, int w, const Bilin& b)
+template <typename MAP>
+__device__ __forceinline__ float sample(const MAP map, int h, int w, const Bilin& b)
 {
     const bool x0v = b.x0 >= 0 && b.x0 < w, x1v = b.x0 + 1 >= 0 && b.x0 + 1 < w;
     const bool y0v = b.y0 >= 0 && b.y0 < h, y1v = b.y0 + 1 >= 0 && b.y0 + 1 < h;
@@ -53,6 +65,51 @@ __device__ __forceinline__ float sample(const T* map, int h, int w, const Bilin&
     const float v11 = (y1v && x1v) ? ld(map, o + w + 1) : 0.f;
     const float hx = 1.f - b.lx, hy = 1.f - b.ly;
     return hy * (hx * v00 + b.lx * v01) + b.ly * (hx * v10 + b.lx * v11);
+}
+
+// the ground-truth plane of row r as a sampling source: byte mask or bit-packed
+template <bool BITS>
+struct GtPlane;
+template <>
+struct GtPlane<false> {
+    const uint8_t* p;
+    __device__ __forceinline__ GtPlane(const void* gt, int64_t row, int H, int W) : p((const uint8_t*)gt + row * H * W) {}
+    __device__ __forceinline__ float at(int H, int W, const Bilin& b) const { return sample(p, H, W, b); }
+};
+template <>
+struct GtPlane<true> {
+    BitPlane p;
+    __device__ __forceinline__ GtPlane(const void* gt, int64_t row, int H, int W) : p{(const uint32_t*)gt, row * H * W} {}
+    __device__ __forceinline__ float at(int H, int W, const Bilin& b) const { return sample(p, H, W, b); }
+};
+
+// bits[i] = 32 consecutive pixels of the byte masks (pixel count a multiple of 32)
+__global__ __launch_bounds__(kThreads) void pack_mask_bits_kernel(const uint8_t* __restrict__ m, uint32_t* __restrict__ bits, int64_t nwords)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * kThreads) {
+        const uint4 a = reinterpret_cast<const uint4*>(m)[2 * i], b = reinterpret_cast<const uint4*>(m)[2 * i + 1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o |= (((w[k] >> (8 * j)) & 0xFFu) ? 1u : 0u) << (4 * k + j);
+        bits[i] = o;
+    }
+}
+
+// out[i, p] = bilinear(bit plane offs[i] (pixel index), coords[coord_rows ? coord_rows[i] : i, p])
+__global__ __launch_bounds__(kThreads) void point_sample_bits_kernel(
+    const uint32_t* __restrict__ src, int h, int w, const int64_t* __restrict__ offs,
+    const float* __restrict__ coords, const int32_t* __restrict__ coord_rows, float* __restrict__ out, int n, int P)
+{
+    const int i = blockIdx.y;
+    const BitPlane map{src, offs[i]};
+    const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)(coord_rows ? coord_rows[i] : i) * P;
+    for (int p = blockIdx.x * kThreads + threadIdx.x; p < P; p += gridDim.x * kThreads) {
+        const float2 xy = c[p];
+        out[(int64_t)i * P + p] = sample(map, h, w, bilin(xy.x, xy.y, h, w));
+    }
 }
 
 // out[i, p] = bilinear(map at src + offs[i], coords[coord_rows ? coord_rows[i] : i, p])
@@ -85,16 +142,16 @@ __device__ __forceinline__ float block_sum(float v, float* red)
 }
 
 // partial[i, chunk, 0..3] = sum over the chunk's points of {bce(x,t), sigmoid(x)*t, sigmoid(x), t}
-template <typename T>
+template <typename T, bool BITS>
 __global__ __launch_bounds__(kThreads) void mask_loss_fwd_kernel(
     const T* __restrict__ pred, int h, int w, const int64_t* __restrict__ pred_offs,
-    const uint8_t* __restrict__ gt, int H, int W, const int32_t* __restrict__ gt_rows,
+    const void* __restrict__ gt, int H, int W, const int32_t* __restrict__ gt_rows,
     const float* __restrict__ coords, float* __restrict__ partial, int n, int P, int chunks)
 {
     __shared__ float red[kThreads / 64];
     const int i = blockIdx.y, ch = blockIdx.x;
     const T* pm = pred + pred_offs[i];
-    const uint8_t* gm = gt + (int64_t)gt_rows[i] * H * W;
+    const GtPlane<BITS> gm(gt, gt_rows[i], H, W);
     const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)i * P;
     const int per = (P + chunks - 1) / chunks;
     const int p0 = ch * per, p1 = min(P, p0 + per);
@@ -102,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void mask_loss_fwd_kernel(
     for (int p = p0 + threadIdx.x; p < p1; p += kThreads) {
         const float2 xy = c[p];
         const float x = sample(pm, h, w, bilin(xy.x, xy.y, h, w));
-        const float t = sample(gm, H, W, bilin(xy.x, xy.y, H, W));
+        const float t = gm.at(H, W, bilin(xy.x, xy.y, H, W));
         const float sg = 1.f / (1.f + __expf(-x));
         s_bce += fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));   // BCE-with-logits, stable form
         s_pt += sg * t;
@@ -161,10 +218,10 @@ __global__ __launch_bounds__(kThreads) void mask_loss_bwd_kernel(
 // B = |g_bce| + (|g_pt| + |g_p|)/4 per point, so 2^31 / (256 B) leaves room for 256 full-magnitude
 // hits on one pixel at a resolution of B * 2^-23 (fp32-grade).
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename TG>
+template <typename T, typename TG, bool BITS>
 __global__ __launch_bounds__(1024) void mask_loss_bwd_band_kernel(
     const T* __restrict__ pred, int h, int w, const int64_t* __restrict__ pred_offs,
-    const uint8_t* __restrict__ gt, int H, int W, const int32_t* __restrict__ gt_rows,
+    const void* __restrict__ gt, int H, int W, const int32_t* __restrict__ gt_rows,
     const float* __restrict__ coords, const float* __restrict__ gsum, TG* __restrict__ grad,
     const int64_t* __restrict__ grad_offs, int n, int P, int band_rows)
 {
@@ -174,7 +231,7 @@ __global__ __launch_bounds__(1024) void mask_loss_bwd_band_kernel(
     const int cells = (y_hi - y_lo) * w;
     for (int k = threadIdx.x; k < cells; k += 1024) band[k] = 0;
     const T* pm = pred + pred_offs[i];
-    const uint8_t* gm = gt + (int64_t)gt_rows[i] * H * W;
+    const GtPlane<BITS> gm(gt, gt_rows[i], H, W);
     const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)i * P;
     const float g_bce = gsum[4 * i], g_pt = gsum[4 * i + 1], g_p = gsum[4 * i + 2];
     const float B = fabsf(g_bce) + 0.25f * (fabsf(g_pt) + fabsf(g_p));
@@ -187,7 +244,7 @@ __global__ __launch_bounds__(1024) void mask_loss_bwd_band_kernel(
             const Bilin b = bilin(xy.x, xy.y, h, w);
             if (b.y0 + 1 < y_lo || b.y0 >= y_hi) continue;       // footprint rows y0, y0+1 miss the band
             const float x = sample(pm, h, w, b);
-            const float t = sample(gm, H, W, bilin(xy.x, xy.y, H, W));
+            const float t = gm.at(H, W, bilin(xy.x, xy.y, H, W));
             const float sg = 1.f / (1.f + __expf(-x));
             const float dx = (g_bce * (sg - t) + (g_pt * t + g_p) * sg * (1.f - sg)) * scale;
             const bool x0v = b.x0 >= 0 && b.x0 < w, x1v = b.x0 + 1 >= 0 && b.x0 + 1 < w;
@@ -235,33 +292,69 @@ extern "C" int mpf_point_sample(const void* src, int src_dtype, int h, int w, co
         mpf::set_kernel("point_sample_kernel<u8>");
         hipLaunchKernelGGL(point_sample_kernel<uint8_t>, grid, dim3(kThreads), 0, st, (const uint8_t*)src, h, w,
                            rows, coords, coord_rows, out, n, P);
+    } else if (src_dtype == MPF_BITS) {        // rows[] are PIXEL indices of the planes' first pixel
+        mpf::set_kernel("point_sample_bits_kernel");
+        hipLaunchKernelGGL(point_sample_bits_kernel, grid, dim3(kThreads), 0, st, (const uint32_t*)src, h, w,
+                           rows, coords, coord_rows, out, n, P);
     } else {
-        return mpf::fail(MPF_E_DTYPE, "mpf_point_sample: dtype must be MPF_F32, MPF_BF16 or MPF_U8");
+        return mpf::fail(MPF_E_DTYPE, "mpf_point_sample: dtype must be MPF_F32, MPF_BF16, MPF_U8 or MPF_BITS");
     }
     mpf::prof_end(mpf_last_kernel(), st, (double)n * P * (8.0 + 4.0 + 16.0));
     return mpf::check(hipGetLastError(), "mpf_point_sample");
 }
 
+// defined further down (needs the LDS sampling helpers): returns false if the LDS variant does not apply
+static bool launch_mask_loss_fwd_lds(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows, const void* gt, bool bits,
+                                     int H, int W, const int32_t* gt_rows, const float* coords, float* partial, int n, int P, int chunks,
+                                     hipStream_t st, int* err);
+
+extern "C" int mpf_pack_mask_bits(const uint8_t* masks, void* bits, int64_t n_pixels, void* stream)
+{
+    if (!masks || !bits) return mpf::fail(MPF_E_NULL, "pack_mask_bits: NULL buffer");
+    if (n_pixels < 0 || n_pixels % 32 != 0) return mpf::fail(MPF_E_SHAPE, "pack_mask_bits: pixel count must be a multiple of 32");
+    if (n_pixels == 0) return 0;
+    const int64_t nwords = n_pixels / 32;
+    const int blocks = (int)((nwords + kThreads - 1) / kThreads < 4096 ? (nwords + kThreads - 1) / kThreads : 4096);
+    mpf::set_kernel("pack_mask_bits_kernel");
+    hipLaunchKernelGGL(pack_mask_bits_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, masks, (uint32_t*)bits, nwords);
+    return mpf::check(hipGetLastError(), "mpf_pack_mask_bits");
+}
+
 extern "C" int mpf_mask_loss_forward(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows,
-                                     const uint8_t* gt, int H, int W, const int32_t* gt_rows,
+                                     const void* gt, int gt_dtype, int H, int W, const int32_t* gt_rows,
                                      const float* coords, float* partial, int n, int P, int chunks,
                                      void* stream)
 {
     if (int e = check_common(pred, pred_rows, coords, partial, n, P, h, w)) return e;
     if (!gt || !gt_rows) return mpf::fail(MPF_E_NULL, "mask_loss_forward: NULL buffer");
     if (H <= 0 || W <= 0 || chunks <= 0) return mpf::fail(MPF_E_SHAPE, "mask_loss_forward: bad sizes");
+    if (gt_dtype != MPF_U8 && gt_dtype != MPF_BITS) return mpf::fail(MPF_E_DTYPE, "mask_loss_forward: gt dtype must be MPF_U8 or MPF_BITS");
+    if (gt_dtype == MPF_BITS && ((int64_t)H * W) % 32 != 0) return mpf::fail(MPF_E_SHAPE, "mask_loss_forward: bit-packed masks need H*W % 32 == 0");
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(chunks, n);
+    const bool bits = gt_dtype == MPF_BITS;
     mpf::prof_begin(st);
+    {
+        int err = 0;
+        if (launch_mask_loss_fwd_lds(pred, pred_dtype, h, w, pred_rows, gt, bits, H, W, gt_rows, coords, partial, n, P, chunks, st, &err)) {
+            if (err) return err;
+            mpf::prof_end(mpf_last_kernel(), st, (double)n * ((double)h * w * 2.0 + P * (8.0 + 4.0)));
+            return mpf::check(hipGetLastError(), "mpf_mask_loss_forward");
+        }
+    }
     if (pred_dtype == MPF_F32) {
         mpf::set_kernel("mask_loss_fwd_kernel<float>");
-        hipLaunchKernelGGL(mask_loss_fwd_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)pred, h, w,
-                           pred_rows, gt, H, W, gt_rows, coords, partial, n, P, chunks);
+        if (bits) hipLaunchKernelGGL((mask_loss_fwd_kernel<float, true>), grid, dim3(kThreads), 0, st, (const float*)pred, h, w,
+                                     pred_rows, gt, H, W, gt_rows, coords, partial, n, P, chunks);
+        else hipLaunchKernelGGL((mask_loss_fwd_kernel<float, false>), grid, dim3(kThreads), 0, st, (const float*)pred, h, w,
+                                pred_rows, gt, H, W, gt_rows, coords, partial, n, P, chunks);
     } else if (pred_dtype == MPF_BF16) {
         mpf::set_kernel("mask_loss_fwd_kernel<bf16>");
-        hipLaunchKernelGGL(mask_loss_fwd_kernel<__hip_bfloat16>, grid, dim3(kThreads), 0, st,
-                           (const __hip_bfloat16*)pred, h, w, pred_rows, gt, H, W, gt_rows, coords, partial, n, P, chunks);
+        if (bits) hipLaunchKernelGGL((mask_loss_fwd_kernel<__hip_bfloat16, true>), grid, dim3(kThreads), 0, st,
+                                     (const __hip_bfloat16*)pred, h, w, pred_rows, gt, H, W, gt_rows, coords, partial, n, P, chunks);
+        else hipLaunchKernelGGL((mask_loss_fwd_kernel<__hip_bfloat16, false>), grid, dim3(kThreads), 0, st,
+                                (const __hip_bfloat16*)pred, h, w, pred_rows, gt, H, W, gt_rows, coords, partial, n, P, chunks);
     } else {
         return mpf::fail(MPF_E_DTYPE, "mpf_mask_loss_forward: pred dtype must be MPF_F32 or MPF_BF16");
     }
@@ -298,7 +391,7 @@ extern "C" int mpf_mask_loss_backward(const void* pred, int pred_dtype, int h, i
 }
 
 extern "C" int mpf_mask_loss_backward_dense(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows,
-                                            const uint8_t* gt, int H, int W, const int32_t* gt_rows, const float* coords,
+                                            const void* gt, int gt_dtype, int H, int W, const int32_t* gt_rows, const float* coords,
                                             const float* grad_sums, void* grad, int grad_dtype, const int64_t* grad_offs,
                                             int n, int P, void* stream)
 {
@@ -306,6 +399,9 @@ extern "C" int mpf_mask_loss_backward_dense(const void* pred, int pred_dtype, in
     if (!gt || !gt_rows || !grad_sums || !grad_offs) return mpf::fail(MPF_E_NULL, "mask_loss_backward_dense: NULL buffer");
     if (n == 0) return 0;
     if (grad_dtype != pred_dtype) return mpf::fail(MPF_E_DTYPE, "mask_loss_backward_dense: gradient dtype must equal the map dtype");
+    if (gt_dtype != MPF_U8 && gt_dtype != MPF_BITS) return mpf::fail(MPF_E_DTYPE, "mask_loss_backward_dense: gt dtype must be MPF_U8 or MPF_BITS");
+    if (gt_dtype == MPF_BITS && ((int64_t)H * W) % 32 != 0) return mpf::fail(MPF_E_SHAPE, "mask_loss_backward_dense: bit-packed masks need H*W % 32 == 0");
+    const bool bits = gt_dtype == MPF_BITS;
     hipStream_t st = (hipStream_t)stream;
     // horizontal bands of at most 128 KiB of 32-bit accumulators
     const int max_rows = (128 * 1024) / (4 * w);
@@ -317,17 +413,23 @@ extern "C" int mpf_mask_loss_backward_dense(const void* pred, int pred_dtype, in
     mpf::prof_begin(st);
     if (pred_dtype == MPF_F32) {
         mpf::set_kernel("mask_loss_bwd_band_kernel<float>");
-        if (int e = mpf::check(hipFuncSetAttribute((const void*)mask_loss_bwd_band_kernel<float, float>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
-        hipLaunchKernelGGL((mask_loss_bwd_band_kernel<float, float>), grid, dim3(1024), lds, st, (const float*)pred, h, w, pred_rows, gt,
-                           H, W, gt_rows, coords, grad_sums, (float*)grad, grad_offs, n, P, band_rows);
+        const void* fn = bits ? (const void*)mask_loss_bwd_band_kernel<float, float, true> : (const void*)mask_loss_bwd_band_kernel<float, float, false>;
+        if (int e = mpf::check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
+        if (bits) hipLaunchKernelGGL((mask_loss_bwd_band_kernel<float, float, true>), grid, dim3(1024), lds, st, (const float*)pred, h, w,
+                                     pred_rows, gt, H, W, gt_rows, coords, grad_sums, (float*)grad, grad_offs, n, P, band_rows);
+        else hipLaunchKernelGGL((mask_loss_bwd_band_kernel<float, float, false>), grid, dim3(1024), lds, st, (const float*)pred, h, w,
+                                pred_rows, gt, H, W, gt_rows, coords, grad_sums, (float*)grad, grad_offs, n, P, band_rows);
     } else if (pred_dtype == MPF_BF16) {
         mpf::set_kernel("mask_loss_bwd_band_kernel<bf16>");
-        if (int e = mpf::check(hipFuncSetAttribute((const void*)mask_loss_bwd_band_kernel<__hip_bfloat16, __hip_bfloat16>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
-        hipLaunchKernelGGL((mask_loss_bwd_band_kernel<__hip_bfloat16, __hip_bfloat16>), grid, dim3(1024), lds, st,
-                           (const __hip_bfloat16*)pred, h, w, pred_rows, gt, H, W, gt_rows, coords, grad_sums,
-                           (__hip_bfloat16*)grad, grad_offs, n, P, band_rows);
+        const void* fn = bits ? (const void*)mask_loss_bwd_band_kernel<__hip_bfloat16, __hip_bfloat16, true>
+                              : (const void*)mask_loss_bwd_band_kernel<__hip_bfloat16, __hip_bfloat16, false>;
+        if (int e = mpf::check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
+        if (bits) hipLaunchKernelGGL((mask_loss_bwd_band_kernel<__hip_bfloat16, __hip_bfloat16, true>), grid, dim3(1024), lds, st,
+                                     (const __hip_bfloat16*)pred, h, w, pred_rows, gt, H, W, gt_rows, coords, grad_sums,
+                                     (__hip_bfloat16*)grad, grad_offs, n, P, band_rows);
+        else hipLaunchKernelGGL((mask_loss_bwd_band_kernel<__hip_bfloat16, __hip_bfloat16, false>), grid, dim3(1024), lds, st,
+                                (const __hip_bfloat16*)pred, h, w, pred_rows, gt, H, W, gt_rows, coords, grad_sums,
+                                (__hip_bfloat16*)grad, grad_offs, n, P, band_rows);
     } else {
         return mpf::fail(MPF_E_DTYPE, "mpf_mask_loss_backward_dense: pred dtype must be MPF_F32 or MPF_BF16");
     }
@@ -524,6 +626,29 @@ extern "C" int mpf_select_uncertain(const float* vals, const float* coords_in, f
 // ------------------------------------------------------------------------------------------------
 constexpr int kMcThreads = 1024;
 
+// global -> LDS copy of a plane by a 1024-thread workgroup: all loads of a thread are issued before its
+// first LDS store (a load-store-load-store loop exposes one memory latency per 16 KiB)
+template <int THREADS = 1024>
+__device__ __forceinline__ void copy_plane_to_lds(void* lds_plane, const void* src_plane, int plane_bytes, int tid)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(src_plane);
+    uint4* dst = reinterpret_cast<uint4*>(lds_plane);
+    const int n16 = plane_bytes / 16;
+    for (int base = 0; base < n16; base += 8 * THREADS) {
+        uint4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = base + tid + k * THREADS;
+            t[k] = idx < n16 ? src[idx] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = base + tid + k * THREADS;
+            if (idx < n16) dst[idx] = t[k];
+        }
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ float sample_lds(const T* plane, int h, int w, const Bilin& b)
 {
@@ -538,15 +663,26 @@ __device__ __forceinline__ float sample_lds(const T* plane, int h, int w, const 
     return hy * (hx * v00 + b.lx * v01) + b.ly * (hx * v10 + b.lx * v11);
 }
 
+// sum over the 64 lanes with DPP row operations (VALU cross-lane moves; __shfl_xor lowers to ds_bpermute
+// = an LDS instruction + a wait per step) and two v_readlane
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add_(float v)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(t);
+}
 __device__ __forceinline__ float wave_sum64(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add_<0xB1>(v);          // quad_perm [1,0,3,2]
+    v = dpp_add_<0x4E>(v);          // quad_perm [2,3,0,1]
+    v = dpp_add_<0x141>(v);         // row_half_mirror
+    v = dpp_add_<0x140>(v);         // row_mirror: every lane = sum of its row of 16
+    v = dpp_add_<0x142, 0xa>(v);    // row_bcast15 into rows 1 and 3: lanes 16..31 / 48..63 = sums of the 32-lane halves
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-template <typename T, int G, int PT>
-__global__ __launch_bounds__(kMcThreads) void match_cost_lds_kernel(
+template <typename T, int G, int PT, int THREADS>
+__global__ __launch_bounds__(THREADS) void match_cost_lds_kernel(
     const T* __restrict__ pred, int h, int w, const int64_t* __restrict__ pred_offs,
     const float* __restrict__ coords, const int32_t* __restrict__ coord_rows,
     const float* __restrict__ tsamp, const int32_t* __restrict__ t_first, const int32_t* __restrict__ t_count,
@@ -568,30 +704,25 @@ __global__ __launch_bounds__(kMcThreads) void match_cost_lds_kernel(
     float2 xy[PT];
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
-        const int p = tid + j * kMcThreads;
+        const int p = tid + j * THREADS;
         xy[j] = p < P ? c[p] : make_float2(-4.f, -4.f);          // far outside: samples 0
     }
-    float xs[G][PT], sg[G][PT];
+    float xs[G][PT];            // (the sigmoids are recomputed per target pass: 1024 threads leave 128 VGPRs per lane)
     float sp[G], sgs[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         sp[g] = 0.f; sgs[g] = 0.f;
         __syncthreads();
-        if (g < ng) {
-            const uint4* src = reinterpret_cast<const uint4*>(pred + pred_offs[row0 + g]);
-            uint4* dst = reinterpret_cast<uint4*>(plane);
-            for (int k = tid; k < plane_bytes / 16; k += kMcThreads) dst[k] = src[k];
-        }
+        if (g < ng) copy_plane_to_lds<THREADS>(plane, pred + pred_offs[row0 + g], plane_bytes, tid);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-            const bool valid = (tid + j * kMcThreads < P) && g < ng;
+            const bool valid = (tid + j * THREADS < P) && g < ng;
             const float x = valid ? sample_lds(plane, h, w, bilin(xy[j].x, xy[j].y, h, w)) : 0.f;
             const float s_ = 1.f / (1.f + __expf(-x));
-            xs[g][j] = x;
-            sg[g][j] = valid ? s_ : 0.f;
+            xs[g][j] = x;                                        // (0 for padding points)
             if (valid) {
-                sp[g] += fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));
+                sp[g] += fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x)));       // softplus; |error| <= 6e-8 per point
                 sgs[g] += s_;
             }
         }
@@ -608,7 +739,7 @@ __global__ __launch_bounds__(kMcThreads) void match_cost_lds_kernel(
     {
         const int g = min(tid / TT, G - 1);
 #pragma unroll
-        for (int k = 0; k < kMcThreads / 64; ++k) { sp_tot += red[k * NV + 2 * g]; sg_tot += red[k * NV + 2 * g + 1]; }
+        for (int k = 0; k < THREADS / 64; ++k) { sp_tot += red[k * NV + 2 * g]; sg_tot += red[k * NV + 2 * g + 1]; }
     }
     for (int tb = 0; tb < Tn; tb += TT) {
         float ax[G][TT], as_[G][TT], at[TT];
@@ -618,20 +749,41 @@ __global__ __launch_bounds__(kMcThreads) void match_cost_lds_kernel(
 #pragma unroll
             for (int g = 0; g < G; ++g) { ax[g][tt] = 0.f; as_[g][tt] = 0.f; }
         }
+        // 5 points x TT targets of loads in flight at a time (all PT x TT at once would spill ~200 registers)
+        constexpr int JC = 5;
 #pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            const int p = tid + j * kMcThreads;
-            if (p < P) {
+        for (int jc = 0; jc < PT; jc += JC) {
+            float tv[JC][TT];
 #pragma unroll
-                for (int tt = 0; tt < TT; ++tt) {
-                    if (tb + tt < Tn) {
-                        const float tv = tsamp[(int64_t)(T0 + tb + tt) * P + p];
-                        at[tt] += tv;
+            for (int jj = 0; jj < JC; ++jj) {
+                const int j = jc + jj;
+                const int p = min(tid + j * THREADS, P - 1);
+                // unconditional loads (indices clamped, values masked below): a load behind a run-time condition
+                // makes hipcc wait for each one separately — 100 dependent L2 round trips per pass
 #pragma unroll
-                        for (int g = 0; g < G; ++g) { ax[g][tt] += xs[g][j] * tv; as_[g][tt] += sg[g][j] * tv; }
+                for (int tt = 0; tt < TT; ++tt) tv[jj][tt] = tsamp[(int64_t)(T0 + min(tb + tt, Tn - 1)) * P + p];
+            }
+#pragma unroll
+            for (int jj = 0; jj < JC; ++jj) {
+                const int j = jc + jj;
+                if (j < PT) {
+                    const bool pv = tid + j * THREADS < P;         // padding point: its target value counts as 0
+                    float sgv[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) sgv[g] = __frcp_rn(1.f + __expf(-xs[g][j]));
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) {
+                        const float t_ = pv ? tv[jj][tt] : 0.f;
+                        at[tt] += t_;
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            ax[g][tt] += xs[g][j] * t_;
+                            as_[g][tt] += sgv[g] * t_;
+                        }
                     }
                 }
             }
+            asm volatile("" ::: "memory");       // keep the next chunk's loads behind this chunk's arithmetic
         }
         __syncthreads();                        // previous pass's red[] fully consumed
 #pragma unroll
@@ -650,7 +802,7 @@ __global__ __launch_bounds__(kMcThreads) void match_cost_lds_kernel(
             if (g < ng && tb + tt < Tn) {
                 float sx = 0.f, ss = 0.f, st = 0.f;
 #pragma unroll
-                for (int k = 0; k < kMcThreads / 64; ++k) {
+                for (int k = 0; k < THREADS / 64; ++k) {
                     sx += red[k * NV + (g * TT + tt) * 2];
                     ss += red[k * NV + (g * TT + tt) * 2 + 1];
                     st += red[k * NV + 2 * G * TT + tt];
@@ -687,11 +839,7 @@ __global__ __launch_bounds__(kMcThreads) void sample_select_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float2* cin = reinterpret_cast<const float2*>(coords_in) + (int64_t)row * M;
     float2* cout = reinterpret_cast<float2*>(coords_out) + (int64_t)row * P_out;
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(pred + pred_offs[row]);
-        uint4* dst = reinterpret_cast<uint4*>(plane);
-        for (int i = tid; i < plane_bytes / 16; i += kMcThreads) dst[i] = src[i];
-    }
+    copy_plane_to_lds(plane, pred + pred_offs[row], plane_bytes, tid);
     if (tid == 0) { misc[0] = 0; misc[1] = k; }
     __syncthreads();
     unsigned key[PT];
@@ -780,21 +928,80 @@ __global__ __launch_bounds__(kMcThreads) void sample_select_kernel(
     }
 }
 
+// mask_loss_fwd with the prediction plane staged in LDS (bf16 planes of at most 128 KiB): one workgroup per
+// pair, all P points; partial[i, 0, :] receives the sums, the other chunks zeros
+template <bool BITS>
+__global__ __launch_bounds__(kMcThreads) void mask_loss_fwd_lds_kernel(
+    const __hip_bfloat16* __restrict__ pred, int h, int w, const int64_t* __restrict__ pred_offs,
+    const void* __restrict__ gt, int H, int W, const int32_t* __restrict__ gt_rows,
+    const float* __restrict__ coords, float* __restrict__ partial, int P, int chunks, int plane_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __hip_bfloat16* plane = reinterpret_cast<__hip_bfloat16*>(smem);
+    float* red = reinterpret_cast<float*>(smem + plane_bytes);          // [16 waves][4]
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    copy_plane_to_lds(plane, pred + pred_offs[i], plane_bytes, tid);
+    const GtPlane<BITS> gm(gt, gt_rows[i], H, W);
+    const float2* c = reinterpret_cast<const float2*>(coords) + (int64_t)i * P;
+    __syncthreads();
+    float s_bce = 0.f, s_pt = 0.f, s_p = 0.f, s_t = 0.f;
+    for (int p = tid; p < P; p += kMcThreads) {
+        const float2 xy = c[p];
+        const float x = sample_lds(plane, h, w, bilin(xy.x, xy.y, h, w));
+        const float t = gm.at(H, W, bilin(xy.x, xy.y, H, W));
+        const float sg = 1.f / (1.f + __expf(-x));
+        s_bce += fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
+        s_pt += sg * t;
+        s_p += sg;
+        s_t += t;
+    }
+    s_bce = wave_sum64(s_bce); s_pt = wave_sum64(s_pt); s_p = wave_sum64(s_p); s_t = wave_sum64(s_t);
+    if (lane == 0) { red[wave * 4] = s_bce; red[wave * 4 + 1] = s_pt; red[wave * 4 + 2] = s_p; red[wave * 4 + 3] = s_t; }
+    __syncthreads();
+    if (tid < 4 * chunks) {
+        float v = 0.f;
+        if (tid < 4)
+            for (int k = 0; k < kMcThreads / 64; ++k) v += red[k * 4 + tid];
+        partial[(int64_t)i * chunks * 4 + tid] = v;
+    }
+}
+
+static bool launch_mask_loss_fwd_lds(const void* pred, int pred_dtype, int h, int w, const int64_t* pred_rows, const void* gt, bool bits,
+                                     int H, int W, const int32_t* gt_rows, const float* coords, float* partial, int n, int P, int chunks,
+                                     hipStream_t st, int* err)
+{
+    const int plane_bytes = h * w * 2;
+    if (pred_dtype != MPF_BF16 || plane_bytes % 16 != 0 || plane_bytes > 128 * 1024 || chunks > 256) return false;
+    const size_t lds = (size_t)plane_bytes + (kMcThreads / 64) * 4 * sizeof(float);
+    const void* fn = bits ? (const void*)mask_loss_fwd_lds_kernel<true> : (const void*)mask_loss_fwd_lds_kernel<false>;
+    *err = mpf::check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+    if (*err) return true;
+    mpf::set_kernel("mask_loss_fwd_lds_kernel");
+    if (bits) hipLaunchKernelGGL(mask_loss_fwd_lds_kernel<true>, dim3(n), dim3(kMcThreads), lds, st, (const __hip_bfloat16*)pred, h, w,
+                                 pred_rows, gt, H, W, gt_rows, coords, partial, P, chunks, plane_bytes);
+    else hipLaunchKernelGGL(mask_loss_fwd_lds_kernel<false>, dim3(n), dim3(kMcThreads), lds, st, (const __hip_bfloat16*)pred, h, w,
+                            pred_rows, gt, H, W, gt_rows, coords, partial, P, chunks, plane_bytes);
+    return true;
+}
+
+// 512 threads x 25 points: the samples of 4 rows stay in registers without spilling (1024 threads leave
+// 128 VGPRs per lane: 180 spilled registers and 2.6x the time)
 template <typename T>
 static bool launch_match_cost_lds(const T* pred, int h, int w, const int64_t* pred_offs, const float* coords,
                                   const int32_t* coord_rows, const float* tsamp, const int32_t* t_first, const int32_t* t_count,
                                   float* cost, int n_rows, int Tmax, int P, float w_mask, float w_dice, int G, hipStream_t st,
                                   int* err)
 {
+    constexpr int THREADS = 512, PT = 25;
     const int plane_bytes = h * w * (int)sizeof(T);
-    if (G != 4 || plane_bytes % 16 != 0 || plane_bytes > 136 * 1024 || P > 13 * kMcThreads || n_rows % 4 != 0) return false;
-    constexpr int PT = 13;
-    constexpr int NV = 2 * 4 * 4 + 4;
-    const size_t lds = (size_t)plane_bytes + (kMcThreads / 64) * NV * sizeof(float);
-    auto kfn = match_cost_lds_kernel<T, 4, PT>;
+    constexpr int GQ = 2;                      // rows per workgroup (4 would need ~300 registers per lane)
+    if (G % GQ != 0 || plane_bytes % 16 != 0 || plane_bytes > 136 * 1024 || P > PT * THREADS || n_rows % GQ != 0) return false;
+    constexpr int NV = 2 * GQ * 4 + 4;
+    const size_t lds = (size_t)plane_bytes + (THREADS / 64) * NV * sizeof(float);
+    auto kfn = match_cost_lds_kernel<T, GQ, PT, THREADS>;
     *err = mpf::check(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
     if (*err) return true;
-    hipLaunchKernelGGL(kfn, dim3(n_rows / 4), dim3(kMcThreads), lds, st, pred, h, w, pred_offs, coords, coord_rows, tsamp, t_first,
+    hipLaunchKernelGGL(kfn, dim3(n_rows / GQ), dim3(THREADS), lds, st, pred, h, w, pred_offs, coords, coord_rows, tsamp, t_first,
                        t_count, cost, n_rows, Tmax, P, w_mask, w_dice, plane_bytes);
     return true;
 }
@@ -811,11 +1018,11 @@ extern "C" int mpf_match_cost(const void* pred, int pred_dtype, int h, int w, co
     if (n_rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     mpf::prof_begin(st);
-    if (pred_dtype == MPF_BF16 && rows_per_group >= 4 && rows_per_group % 4 == 0) {
+    if (pred_dtype == MPF_BF16 && rows_per_group >= 2 && rows_per_group % 2 == 0) {
         int err = 0;
         mpf::set_kernel("match_cost_lds_kernel<bf16>");
         if (launch_match_cost_lds((const __hip_bfloat16*)pred, h, w, pred_offs, coords, coord_rows, tsamp, t_first, t_count, cost,
-                                  n_rows, Tmax, P, w_mask, w_dice, 4, st, &err)) {
+                                  n_rows, Tmax, P, w_mask, w_dice, rows_per_group, st, &err)) {
             if (err) return err;
             mpf::prof_end(mpf_last_kernel(), st, (double)n_rows * ((double)h * w * 2.0 + P * 8.0 / 4 + P * 4.0 * Tmax / 4));
             return mpf::check(hipGetLastError(), "mpf_match_cost");
@@ -844,19 +1051,24 @@ extern "C" int mpf_sample_select_uncertain(const void* pred, int pred_dtype, int
     if (!pred || !pred_offs || !coords_in || !coords_out) return mpf::fail(MPF_E_NULL, "sample_select_uncertain: NULL buffer");
     if (n < 0 || M <= 0 || k < 0 || k > M || k > P_out || h <= 0 || w <= 0) return mpf::fail(MPF_E_SHAPE, "sample_select_uncertain: bad sizes");
     if (n == 0 || k == 0) return 0;
-    constexpr int PT = 40;
     const int plane_bytes = h * w * 2;
     if (pred_dtype != MPF_BF16) return mpf::fail(MPF_E_DTYPE, "sample_select_uncertain: bf16 maps only (use mpf_point_sample + mpf_select_uncertain)");
-    if (plane_bytes % 16 != 0 || plane_bytes > 128 * 1024 || M > PT * kMcThreads)
+    if (plane_bytes % 16 != 0 || plane_bytes > 128 * 1024 || M > 40 * kMcThreads)
         return mpf::fail(MPF_E_TOO_LARGE, "sample_select_uncertain: plane larger than 128 KiB or more than 40960 candidates");
     hipStream_t st = (hipStream_t)stream;
+    // keys per thread: 37 covers the shipped 3 x 12544 candidates without register spills; 40 is the general cap
+    const int PT = M <= 16 * kMcThreads ? 16 : (M <= 37 * kMcThreads ? 37 : 40);
     const size_t lds = (size_t)plane_bytes + (256 + 2 * PT * 16 + 8) * sizeof(int);
-    auto kfn = sample_select_kernel<__hip_bfloat16, PT>;
-    if (int e = mpf::check(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
+    const void* fn = PT == 16 ? (const void*)sample_select_kernel<__hip_bfloat16, 16>
+                              : (PT == 37 ? (const void*)sample_select_kernel<__hip_bfloat16, 37> : (const void*)sample_select_kernel<__hip_bfloat16, 40>);
+    if (int e = mpf::check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
     mpf::prof_begin(st);
     mpf::set_kernel("sample_select_kernel<bf16>");
-    hipLaunchKernelGGL(kfn, dim3(n), dim3(kMcThreads), lds, st, (const __hip_bfloat16*)pred, h, w, pred_offs, coords_in, coords_out,
-                       M, k, P_out, plane_bytes);
+#define MPF_SS_LAUNCH(PTV)                                                                                                        \
+    hipLaunchKernelGGL((sample_select_kernel<__hip_bfloat16, PTV>), dim3(n), dim3(kMcThreads), lds, st, (const __hip_bfloat16*)pred, h, w, \
+                       pred_offs, coords_in, coords_out, M, k, P_out, plane_bytes)
+    if (PT == 16) MPF_SS_LAUNCH(16); else if (PT == 37) MPF_SS_LAUNCH(37); else MPF_SS_LAUNCH(40);
+#undef MPF_SS_LAUNCH
     mpf::prof_end(mpf_last_kernel(), st, (double)n * ((double)plane_bytes + M * 8.0 + k * 16.0));
     return mpf::check(hipGetLastError(), "mpf_sample_select_uncertain");
 }

@@ -16,6 +16,7 @@ from scipy.optimize import linear_sum_assignment
 from torch import nn
 
 from . import _rng
+from . import _lib
 from ._h2d import upload
 from .point_sample import MapSet, match_cost, point_sample_offsets
 
@@ -42,6 +43,13 @@ class GTMasks:
             H, W = targets[0]["masks"].shape[-2:]
             self.u8 = torch.zeros((0, H, W), dtype=torch.uint8, device=dev)
         self.H, self.W = self.u8.shape[-2:]
+        # bit-packed copy (32 pixels per word) for the loss / matcher gathers: 8x smaller, stays in L2
+        self.bits = None
+        if self.total and (self.H * self.W) % 32 == 0:
+            self.bits = torch.empty((self.total, self.H * self.W // 32), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().mpf_pack_mask_bits(self.u8.data_ptr(), self.bits.data_ptr(), self.u8.numel(),
+                                                         torch.cuda.current_stream(dev).cuda_stream), "mpf_pack_mask_bits")
         self.image_of_row = np.concatenate([np.full(c, b, dtype=np.int64) for b, c in enumerate(self.counts)]) \
             if self.total else np.zeros(0, dtype=np.int64)
         self.device = dev
@@ -93,7 +101,10 @@ class HungarianMatcher(nn.Module):
         pred_offs_d, gt_offs_d = i64[:n_rows], i64[n_rows:]
         crow_d, tfirst_d, tcount_d, gcrow_d = i32[:n_rows], i32[n_rows:2 * n_rows], i32[2 * n_rows:3 * n_rows], i32[3 * n_rows:]
         # ---- ground-truth samples [L*Tt, P], then mask + dice cost [L*N*Q, Tmax] ------------------
-        tsamp = point_sample_offsets(gt.u8.data_ptr(), torch.uint8, gt.H, gt.W, gt_offs_d, coords, gcrow_d, dev)
+        if gt.bits is not None:      # gt_offs are pixel offsets either way
+            tsamp = point_sample_offsets(gt.bits.data_ptr(), "bits", gt.H, gt.W, gt_offs_d, coords, gcrow_d, dev)
+        else:
+            tsamp = point_sample_offsets(gt.u8.data_ptr(), torch.uint8, gt.H, gt.W, gt_offs_d, coords, gcrow_d, dev)
         C = match_cost(mapset, pred_offs_d, coords, crow_d, tsamp, tfirst_d, tcount_d, Tmax,
                        self.cost_mask, self.cost_dice, rows_per_group=Q).view(L, N, Q, Tmax)   # rows are (l, b, q), q fastest
         # ---- class cost: -softmax(logits)[:, labels]  (matcher.py:105-111) ------------------------

@@ -17,7 +17,8 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib
 
-_DT = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16, torch.uint8: _lib.MPF_U8, torch.bool: _lib.MPF_U8}
+_DT = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16, torch.uint8: _lib.MPF_U8, torch.bool: _lib.MPF_U8,
+       "bits": _lib.MPF_BITS}
 _CHUNKS = 8
 
 
@@ -161,14 +162,18 @@ class MaskLossSums(Function):
     of every map."""
 
     @staticmethod
-    def forward(ctx, ms, pred_offs, grad_offs, gt_u8, gt_rows, coords, *tensors):
+    def forward(ctx, ms, pred_offs, grad_offs, gt, gt_rows, coords, *tensors):
+        # gt: GTMasks (its bit-packed copy is used when present) or a [R, H, W] byte tensor
+        gt_u8 = gt if torch.is_tensor(gt) else (gt.bits if gt.bits is not None else gt.u8)
+        gdt = _lib.MPF_U8 if (torch.is_tensor(gt) or gt.bits is None) else _lib.MPF_BITS
         n, P = coords.shape[0], coords.shape[1]
-        H, W = gt_u8.shape[-2:]
+        H, W = (gt.shape[-2:] if torch.is_tensor(gt) else (gt.H, gt.W))
+        ctx.gt_hw, ctx.gdt = (H, W), gdt
         partial = torch.empty((n, _CHUNKS, 4), dtype=torch.float32, device=ms.device)
         if n:
             with torch.cuda.device(ms.device):
                 code = _lib.lib().mpf_mask_loss_forward(
-                    ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), H, W,
+                    ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), gdt, H, W,
                     gt_rows.data_ptr(), coords.data_ptr(), partial.data_ptr(), n, P, _CHUNKS, _stream(ms.device))
             _lib.check(code, "mpf_mask_loss_forward")
         ctx.ms = ms
@@ -181,13 +186,13 @@ class MaskLossSums(Function):
         ms = ctx.ms
         pred_offs, grad_offs, gt_u8, gt_rows, coords = ctx.saved_tensors[:5]
         n, P = coords.shape[0], coords.shape[1]
-        H, W = gt_u8.shape[-2:]
+        H, W = ctx.gt_hw
         gbuf = torch.zeros(ms.g_total, dtype=ms.dtype, device=ms.device)
         if n:
             g = grad_sums.contiguous().float()
             with torch.cuda.device(ms.device):
                 code = _lib.lib().mpf_mask_loss_backward_dense(
-                    ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), H, W,
+                    ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), ctx.gdt, H, W,
                     gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), gbuf.data_ptr(), _DT[ms.dtype], grad_offs.data_ptr(),
                     n, P, _stream(ms.device))
             _lib.check(code, "mpf_mask_loss_backward_dense")

@@ -117,9 +117,27 @@ def test_match_cost_matches_oracle(Q, dtype, group):
         torch.testing.assert_close(C[i, :, :T[i]], ref, rtol=2e-4, atol=2e-4)
 
 
+def test_bit_packed_masks_sample_like_byte_masks():
+    """mpf_pack_mask_bits + the MPF_BITS source of mpf_point_sample == sampling the byte masks."""
+    from mp_former_amd.matcher import GTMasks
+    from mp_former_amd.point_sample import point_sample_offsets
+    g = torch.Generator().manual_seed(11)
+    H, W, P = 96, 64, 3000
+    masks = (torch.rand(7, H, W, generator=g) < 0.35).to(DEV)
+    gtm = GTMasks([{"masks": masks[:3]}, {"masks": masks[3:]}])
+    assert gtm.bits is not None
+    coords = torch.rand(2, P, 2, generator=g).to(DEV) * 1.1 - 0.05          # some points outside
+    offs = (torch.arange(7, device=DEV) * H * W).long()
+    rows = torch.tensor([0, 0, 0, 1, 1, 1, 1], dtype=torch.int32, device=DEV)
+    a = point_sample_offsets(gtm.u8.data_ptr(), torch.uint8, H, W, offs, coords, rows, torch.device(DEV))
+    b = point_sample_offsets(gtm.bits.data_ptr(), "bits", H, W, offs, coords, rows, torch.device(DEV))
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("hw", [(32, 32), (200, 176)])        # one LDS band / two bands in the backward
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_mask_loss_forward_backward_matches_autograd(dtype, hw):
+def test_mask_loss_forward_backward_matches_autograd(dtype, hw, packed):
     """fused BCE + dice sums and their gradient vs autograd through grid_sample + the reference losses
     (criterion.py:21-65,172-191).  bf16 maps are compared on the bf16-rounded values."""
     from mp_former_amd.point_sample import MapSet, MaskLossSums
@@ -135,7 +153,13 @@ def test_mask_loss_forward_backward_matches_autograd(dtype, hw):
     po = torch.from_numpy(ms.offsets(ti, bi, qi)).to(DEV)
     go = torch.from_numpy(ms.grad_offsets(ti, bi, qi)).to(DEV)
     gt_rows = torch.from_numpy(gr.astype(np.int32)).to(DEV)
-    sums = MaskLossSums.apply(ms, po, go, gt.view(torch.uint8), gt_rows, coords, a, bten)
+    if packed:
+        from mp_former_amd.matcher import GTMasks
+        gsrc = GTMasks([{"masks": gt}])
+        assert gsrc.bits is not None
+    else:
+        gsrc = gt.view(torch.uint8)
+    sums = MaskLossSums.apply(ms, po, go, gsrc, gt_rows, coords, a, bten)
     wts = torch.tensor([[1.0, -2.0, 0.5, 0.0]], device=DEV) * torch.arange(1, n + 1, device=DEV)[:, None]
     (sums * wts).sum().backward()
     ga, gb = a.grad.float().clone(), bten.grad.float().clone()

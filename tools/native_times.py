@@ -33,7 +33,7 @@ for i in range(steps):
     step(3 + i)
 torch.cuda.synchronize()
 names = ["msda_fwd", "msda_bwd_push", "tile_scan", "msda_bwd_fill", "msda_bwd_pull", "gemm3_tn_kernel<128>", "gemm3_tn_kernel<96>",
-         "gemm3_nt_kernel<128>", "gemm3_nt_kernel<96>", "point_sample_kernel", "select_uncertain", "sample_select", "match_cost", "mask_loss_fwd",
+         "gemm3_nt_kernel<128>", "gemm3_nt_kernel<96>", "point_sample_kernel", "select_uncertain", "sample_select", "match_cost", "mask_loss_fwd", "point_sample_bits",
          "mask_loss_bwd", "attn_fwd", "attn_bwd", "attn_mask"]
 tot = 0.0
 for n in names:
