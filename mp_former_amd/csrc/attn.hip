@@ -34,6 +34,32 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// Loads are issued UNCONDITIONALLY on clamped indices and zeroed afterwards where out of range: a load
+// behind a run-time condition makes hipcc branch around it and wait for it on its own, which turned every
+// 32-key step of these kernels into ~8 dependent L2 round trips.
+__device__ __forceinline__ bf16x8 ld8_rows(const __hip_bfloat16* base, int row, int limit, int64_t row_stride, int col)
+{
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(base + (int64_t)min(row, limit - 1) * row_stride + col);
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return row < limit ? v : z;
+}
+// 4 consecutive elements of a row starting at i (zero past `limit`); aligned: i and limit multiples of 4
+__device__ __forceinline__ bf16x4 ld4_clamped(const __hip_bfloat16* row, int i, int limit, bool aligned)
+{
+    const bf16x4 z = {0, 0, 0, 0};
+    if (aligned) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(row + max(min(i, limit - 4), 0));
+        return i < limit ? v : z;
+    }
+    bf16x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __bf16 e = *reinterpret_cast<const __bf16*>(row + min(i + j, limit - 1));
+        r[j] = i + j < limit ? e : (__bf16)0.f;
+    }
+    return r;
+}
+
 constexpr int kHD = 32;          // head dim
 constexpr float kNegInf = -INFINITY;
 
@@ -82,9 +108,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p)
     bf16x8 bq[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
-        const int qi = q0 + 16 * s + c16;
-        bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        bq[s] = qi < p.Lq ? *reinterpret_cast<const bf16x8*>(qb + (int64_t)qi * rowE + 8 * g) : z;
+        bq[s] = ld8_rows(qb, q0 + 16 * s + c16, p.Lq, rowE, 8 * g);
     }
     f32x4 o[QS][2];
     float m[QS], l[QS];
@@ -99,27 +123,15 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p)
         bf16x8 ak[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int key = kk + 16 * t + c16;
-            bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            ak[t] = key < kb1 ? *reinterpret_cast<const bf16x8*>(kb + (int64_t)key * rowE + 8 * g) : z;
+            ak[t] = ld8_rows(kb, kk + 16 * t + c16, kb1, rowE, 8 * g);
         }
         // V^T fragments: rows d = 16*dt + c16, keys {kk+4g..+3} and {kk+16+4g..+3}
         bf16x8 av[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             const __hip_bfloat16* vr = vb + (int64_t)(16 * dt + c16) * p.Lk;
-            bf16x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
-            const int k0 = kk + 4 * g, k1 = kk + 16 + 4 * g;
-            if (mask_aligned) {          // Lk % 4 == 0: 8-byte aligned, whole quads in range or not
-                if (k0 < kb1) lo = *reinterpret_cast<const bf16x4*>(vr + k0);
-                if (k1 < kb1) hi = *reinterpret_cast<const bf16x4*>(vr + k1);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (k0 + j < kb1) lo[j] = *reinterpret_cast<const __bf16*>(vr + k0 + j);
-                    if (k1 + j < kb1) hi[j] = *reinterpret_cast<const __bf16*>(vr + k1 + j);
-                }
-            }
+            // (Lk % 4 == 0: 8-byte aligned, whole quads in range or not)
+            const bf16x4 lo = ld4_clamped(vr, kk + 4 * g, kb1, mask_aligned), hi = ld4_clamped(vr, kk + 16 + 4 * g, kb1, mask_aligned);
             av[dt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
@@ -133,12 +145,13 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p)
                 // lane (query c16, group g) holds keys kk + 16t + 4g + r
                 const int key0 = kk + 16 * t + 4 * g;
                 uint32_t mw = 0;
-                if (p.mask && qi < p.Lq) {
-                    const uint8_t* mr = p.mask + (int64_t)n * p.mask_stride_n + (int64_t)qi * p.Lk + key0;
-                    if (mask_aligned) { if (key0 < kb1) mw = *reinterpret_cast<const uint32_t*>(mr); }
-                    else {
+                if (p.mask) {            // (uniform) mask bytes of keys key0..key0+3 for query qi, clamped reads
+                    const uint8_t* mrow = p.mask + (int64_t)n * p.mask_stride_n + (int64_t)min(qi, p.Lq - 1) * p.Lk;
+                    if (mask_aligned) {
+                        mw = *reinterpret_cast<const uint32_t*>(mrow + max(min(key0, kb1 - 4), 0));
+                    } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (key0 + r < kb1 && mr[r]) mw |= 0xFFu << (8 * r);
+                        for (int r = 0; r < 4; ++r) mw |= (mrow[min(key0 + r, kb1 - 1)] ? 0xFFu : 0u) << (8 * r);
                     }
                 }
 #pragma unroll
@@ -242,17 +255,7 @@ __device__ __forceinline__ bf16x8 zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0
 // two 8-byte pieces (4 + 4 consecutive elements) of a row -> one MFMA fragment
 __device__ __forceinline__ bf16x8 load4x2(const __hip_bfloat16* row, int i0, int i1, int limit, bool aligned)
 {
-    bf16x4 lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
-    if (aligned) {
-        if (i0 < limit) lo = *reinterpret_cast<const bf16x4*>(row + i0);
-        if (i1 < limit) hi = *reinterpret_cast<const bf16x4*>(row + i1);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (i0 + j < limit) lo[j] = *reinterpret_cast<const __bf16*>(row + i0 + j);
-            if (i1 + j < limit) hi[j] = *reinterpret_cast<const __bf16*>(row + i1 + j);
-        }
-    }
+    const bf16x4 lo = ld4_clamped(row, i0, limit, aligned), hi = ld4_clamped(row, i1, limit, aligned);
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
@@ -266,8 +269,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         const int key = kb + 16 * kt + c16;
-        bk[kt] = key < p.Lk ? load8(p.k + hoff + (int64_t)key * rowE + 8 * g) : zero8();
-        bv[kt] = key < p.Lk ? load8(p.v + hoff + (int64_t)key * rowE + 8 * g) : zero8();
+        bk[kt] = ld8_rows(p.k + hoff, key, p.Lk, rowE, 8 * g);
+        bv[kt] = ld8_rows(p.v + hoff, key, p.Lk, rowE, 8 * g);
     }
     f32x4 dkt[2][2], dvt[2][2];
 #pragma unroll
@@ -284,8 +287,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             const int qi = qq + 16 * qt + c16;
-            aq[qt] = qi < p.Lq ? load8(p.q + hoff + (int64_t)qi * rowE + 8 * g) : zero8();
-            ado[qt] = qi < p.Lq ? load8(p.dout + hoff + (int64_t)qi * rowE + 8 * g) : zero8();
+            aq[qt] = ld8_rows(p.q + hoff, qi, p.Lq, rowE, 8 * g);
+            ado[qt] = ld8_rows(p.dout + hoff, qi, p.Lq, rowE, 8 * g);
         }
         float ls[2][4], de[2][4];
 #pragma unroll
@@ -293,8 +296,9 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int qi = qq + 16 * qt + 4 * g + r;
-                ls[qt][r] = qi < p.Lq ? lse[qi] : 0.f;
-                de[qt][r] = qi < p.Lq ? dl[qi] : 0.f;
+                const float lv = lse[min(qi, p.Lq - 1)], dv_ = dl[min(qi, p.Lq - 1)];
+                ls[qt][r] = qi < p.Lq ? lv : 0.f;
+                de[qt][r] = qi < p.Lq ? dv_ : 0.f;
             }
         bf16x8 bp[2], bds[2];
 #pragma unroll
@@ -309,7 +313,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
                 for (int r = 0; r < 4; ++r) {
                     const int qi = qq + 16 * qt + 4 * g + r;
                     bool dead = (qi >= p.Lq) || (key >= p.Lk) || (ls[qt][r] == kNegInf);
-                    if (!dead && p.mask) dead = p.mask[(int64_t)n * p.mask_stride_n + (int64_t)qi * p.Lk + key] != 0;
+                    if (p.mask)          // (uniform branch; the byte is read on clamped indices, unconditionally)
+                        dead = dead || p.mask[(int64_t)n * p.mask_stride_n + (int64_t)min(qi, p.Lq - 1) * p.Lk + min(key, p.Lk - 1)] != 0;
                     const float pr = dead ? 0.f : __expf(sacc[r] * p.scale - ls[qt][r]);
                     const float ds = pr * (dpacc[r] - de[qt][r]) * p.scale;
                     bp[kt][4 * qt + r] = (__bf16)pr;
@@ -365,8 +370,8 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(AttnBwdParams p)
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
         const int qi = q0 + 16 * s + c16;
-        bq[s] = qi < p.Lq ? load8(p.q + hoff + (int64_t)qi * rowE + 8 * g) : zero8();
-        bdo[s] = qi < p.Lq ? load8(p.dout + hoff + (int64_t)qi * rowE + 8 * g) : zero8();
+        bq[s] = ld8_rows(p.q + hoff, qi, p.Lq, rowE, 8 * g);
+        bdo[s] = ld8_rows(p.dout + hoff, qi, p.Lq, rowE, 8 * g);
         ls[s] = qi < p.Lq ? p.lse[((int64_t)n * p.H + h) * p.Lq + qi] : kNegInf;
         de[s] = qi < p.Lq ? p.delta[((int64_t)n * p.H + h) * p.Lq + qi] : 0.f;
         dq[s][0] = f32x4{0, 0, 0, 0}; dq[s][1] = f32x4{0, 0, 0, 0};
@@ -376,8 +381,8 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(AttnBwdParams p)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = kk + 16 * t + c16;
-            ak[t] = key < kb1 ? load8(p.k + hoff + (int64_t)key * rowE + 8 * g) : zero8();
-            av[t] = key < kb1 ? load8(p.v + hoff + (int64_t)key * rowE + 8 * g) : zero8();
+            ak[t] = ld8_rows(p.k + hoff, key, kb1, rowE, 8 * g);
+            av[t] = ld8_rows(p.v + hoff, key, kb1, rowE, 8 * g);
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -393,12 +398,13 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(AttnBwdParams p)
                 const f32x4 dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[t], bdo[s], z, 0, 0, 0);
                 const int key0 = kk + 16 * t + 4 * g;
                 uint32_t mw = 0;
-                if (p.mask && qi < p.Lq) {
-                    const uint8_t* mr = p.mask + (int64_t)n * p.mask_stride_n + (int64_t)qi * p.Lk + key0;
-                    if (aligned) { if (key0 < kb1) mw = *reinterpret_cast<const uint32_t*>(mr); }
-                    else {
+                if (p.mask) {
+                    const uint8_t* mrow = p.mask + (int64_t)n * p.mask_stride_n + (int64_t)min(qi, p.Lq - 1) * p.Lk;
+                    if (aligned) {
+                        mw = *reinterpret_cast<const uint32_t*>(mrow + max(min(key0, kb1 - 4), 0));
+                    } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (key0 + r < kb1 && mr[r]) mw |= 0xFFu << (8 * r);
+                        for (int r = 0; r < 4; ++r) mw |= (mrow[min(key0 + r, kb1 - 1)] ? 0xFFu : 0u) << (8 * r);
                     }
                 }
 #pragma unroll
@@ -488,10 +494,23 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const __hip_bfloat16* _
 
 }  // namespace
 
+// Key splits of the forward / dQ kernels: one WAVE per (32 queries, head, image, split) and each wave
+// walks its keys in dependent 32-key steps, so the chip needs several thousand waves to hide the load
+// latency of a step: aim at ~4096 waves, at least 64 keys and at most 1024 keys per split.
+static int attn_splits(int Lq, int Lk, int N, int H)
+{
+    const int qtiles = (Lq + 31) / 32;
+    int splits = (4096 + qtiles * H * N - 1) / (qtiles * H * N);
+    const int max_splits = (Lk + 63) / 64, min_splits = (Lk + 1023) / 1024;
+    splits = splits > max_splits ? max_splits : splits;
+    splits = splits < min_splits ? min_splits : splits;
+    return splits < 1 ? 1 : splits;
+}
+
 extern "C" size_t mpf_attn_workspace_bytes(int Lq, int Lk, int N, int H)
 {
     if (Lq <= 0 || Lk <= 0 || N <= 0 || H <= 0) return 0;
-    const int splits = (Lk + 1023) / 1024;
+    const int splits = attn_splits(Lq, Lk, N, H);
     return (size_t)splits * N * H * Lq * (kHD + 2) * sizeof(float);
 }
 
@@ -508,8 +527,9 @@ extern "C" int mpf_attn_forward(const void* q, const void* k, const void* vt, co
     p.q = (const __hip_bfloat16*)q; p.k = (const __hip_bfloat16*)k; p.vt = (const __hip_bfloat16*)vt;
     p.mask = mask; p.mask_stride_n = mask_per_image ? (int64_t)Lq * Lk : 0;
     p.Lq = Lq; p.Lk = Lk; p.N = N; p.H = H; p.E = H * kHD; p.scale = scale;
-    p.splits = (Lk + 1023) / 1024;
+    p.splits = attn_splits(Lq, Lk, N, H);
     p.keys_per_split = (((Lk + p.splits - 1) / p.splits) + 31) & ~31;
+    p.splits = (Lk + p.keys_per_split - 1) / p.keys_per_split;          // (rounding up to 32 keys may need fewer)
     p.part_o = (float*)workspace;
     p.part_ml = p.part_o + (size_t)p.splits * N * H * Lq * kHD;
     constexpr int QS = 2;
@@ -544,8 +564,9 @@ extern "C" int mpf_attn_backward(const void* q, const void* k, const void* v, co
     p.lse = lse; p.delta = delta;
     p.dk = (__hip_bfloat16*)dk; p.dv = (__hip_bfloat16*)dv; p.part_dq = (float*)workspace;
     p.Lq = Lq; p.LqP = LqP; p.Lk = Lk; p.N = N; p.H = H; p.E = H * kHD; p.scale = scale;
-    p.splits = (Lk + 1023) / 1024;
+    p.splits = attn_splits(Lq, Lk, N, H);
     p.keys_per_split = (((Lk + p.splits - 1) / p.splits) + 31) & ~31;
+    p.splits = (Lk + p.keys_per_split - 1) / p.keys_per_split;          // (rounding up to 32 keys may need fewer)
     const double bytes = 2.0 * (4.0 * Lk * N * p.E + 4.0 * Lq * N * p.E) + (mask ? 2.0 * N * Lq * Lk : 0.0);
     mpf::prof_begin(st);
     mpf::set_kernel("attn_bwd_kv_kernel");

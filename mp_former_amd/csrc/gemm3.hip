@@ -466,22 +466,28 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
     float csa = 0.f, csb0 = 0.f, csb1 = 0.f;
     const bool want_csa = p.csum_a && tn == 0, want_csb = p.csum_b && tm == 0;
 
+// loads are UNCONDITIONAL (row index clamped, value masked): a load behind a run-time condition makes
+// hipcc branch around it and wait for it separately
 #define G3N_LOAD(r0)                                                                                   \
     {                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
             const int ra0 = (r0) + akc * 8 + j, ra1 = ra0 + 16;                                        \
-            xa0[j] = ra0 < r_end ? acol[(int64_t)ra0 * p.lda] : 0.f;                                   \
-            xa1[j] = ra1 < r_end ? acol[(int64_t)ra1 * p.lda] : 0.f;                                   \
+            const float va0 = acol[(int64_t)min(ra0, r_end - 1) * p.lda];                              \
+            const float va1 = acol[(int64_t)min(ra1, r_end - 1) * p.lda];                              \
             const int rb0 = (r0) + bkc_[0] * 8 + j, rb1 = (r0) + bkc_[1] * 8 + j;                      \
-            xb0[j] = rb0 < r_end ? bcol[0][(int64_t)rb0 * p.ldb] : 0.f;                                \
-            xb1[j] = (b_ok[1] && rb1 < r_end) ? bcol[1][(int64_t)rb1 * p.ldb] : 0.f;                   \
+            float vb0 = bcol[0][(int64_t)min(rb0, r_end - 1) * p.ldb];                                 \
+            float vb1 = bcol[1][(int64_t)min(rb1, r_end - 1) * p.ldb];                                 \
             if (p.b2) {                                                                                \
                 int q0 = b2row[0] + j, q1 = b2row[1] + j;                                              \
                 q0 = q0 >= p.b2_rows ? q0 - p.b2_rows : q0;                                            \
                 q1 = q1 >= p.b2_rows ? q1 - p.b2_rows : q1;                                            \
-                if (rb0 < r_end) xb0[j] += b2col[0][(int64_t)q0 * p.ldb2];                             \
-                if (b_ok[1] && rb1 < r_end) xb1[j] += b2col[1][(int64_t)q1 * p.ldb2];                  \
+                vb0 += b2col[0][(int64_t)q0 * p.ldb2];                                                 \
+                vb1 += b2col[1][(int64_t)q1 * p.ldb2];                                                 \
             }                                                                                          \
+            xa0[j] = ra0 < r_end ? va0 : 0.f;                                                          \
+            xa1[j] = ra1 < r_end ? va1 : 0.f;                                                          \
+            xb0[j] = rb0 < r_end ? vb0 : 0.f;                                                          \
+            xb1[j] = (b_ok[1] && rb1 < r_end) ? vb1 : 0.f;                                             \
         }                                                                                              \
         if (p.b2) {                                                                                    \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \

@@ -53,16 +53,19 @@ __device__ __forceinline__ Bilin bilin(float cx, float cy, int h, int w)
     return b;
 }
 
+// the four corner loads are UNCONDITIONAL (indices clamped into the plane, out-of-range corners zeroed
+// afterwards): a load behind a run-time condition makes hipcc branch around it and wait for it separately,
+// i.e. four dependent round trips per sample instead of four loads in flight
 template <typename MAP>
 __device__ __forceinline__ float sample(const MAP map, int h, int w, const Bilin& b)
 {
     const bool x0v = b.x0 >= 0 && b.x0 < w, x1v = b.x0 + 1 >= 0 && b.x0 + 1 < w;
     const bool y0v = b.y0 >= 0 && b.y0 < h, y1v = b.y0 + 1 >= 0 && b.y0 + 1 < h;
-    const int64_t o = (int64_t)b.y0 * w + b.x0;
-    const float v00 = (y0v && x0v) ? ld(map, o) : 0.f;
-    const float v01 = (y0v && x1v) ? ld(map, o + 1) : 0.f;
-    const float v10 = (y1v && x0v) ? ld(map, o + w) : 0.f;
-    const float v11 = (y1v && x1v) ? ld(map, o + w + 1) : 0.f;
+    const int xa = min(max(b.x0, 0), w - 1), xb = min(max(b.x0 + 1, 0), w - 1);
+    const int64_t ra = (int64_t)min(max(b.y0, 0), h - 1) * w, rb = (int64_t)min(max(b.y0 + 1, 0), h - 1) * w;
+    const float l00 = ld(map, ra + xa), l01 = ld(map, ra + xb), l10 = ld(map, rb + xa), l11 = ld(map, rb + xb);
+    const float v00 = (y0v && x0v) ? l00 : 0.f, v01 = (y0v && x1v) ? l01 : 0.f;
+    const float v10 = (y1v && x0v) ? l10 : 0.f, v11 = (y1v && x1v) ? l11 : 0.f;
     const float hx = 1.f - b.lx, hy = 1.f - b.ly;
     return hy * (hx * v00 + b.lx * v01) + b.ly * (hx * v10 + b.lx * v11);
 }
