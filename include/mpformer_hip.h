@@ -340,6 +340,16 @@ int mpf_mask_loss_backward_dense(const void* pred, int pred_dtype, int h, int w,
                                  int n, int P, void* stream);
 
 /*
+ * GroupNorm statistics of the pixel decoder (nn.GroupNorm(32, conv_dim), msdeformattn.py:245-281):
+ * mean[r], rstd[r] = 1/sqrt(var + eps) (biased variance) of `rows` = N*G contiguous runs of row_len =
+ * (C/G)*H*W floats (NCHW).  Rows are cut into 8192-element chunks (count, mean, M2 per chunk, merged
+ * with Chan's formula) so that 64 rows still fill the chip.  row_len % 4 == 0.
+ */
+size_t mpf_group_stats_workspace_bytes(int rows, int64_t row_len);
+int mpf_group_stats(const float* x, int rows, int64_t row_len, float eps, float* mean, float* rstd,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
  * events recorded on the launch stream (kernel only: memsets and host work are outside the
  * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events

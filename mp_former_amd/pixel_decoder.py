@@ -18,6 +18,7 @@ from torch import nn
 from torch.nn.init import normal_
 
 from . import encoder_fused
+from .groupnorm import GroupNorm
 from .linear import linear_tall
 from .msda import MSDeformAttn, attach_host_shapes
 
@@ -212,7 +213,7 @@ def _get_norm(norm, channels):
         return None
     if norm != "GN":
         raise ValueError(f"only GN / no norm are supported by this mirror, got {norm!r}")
-    return nn.GroupNorm(32, channels)
+    return GroupNorm(32, channels)
 
 
 def _c2_xavier_fill(m):
@@ -241,7 +242,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         self.transformer_num_feature_levels = len(self.transformer_in_features)
         chans = tr_channels[::-1] if self.transformer_num_feature_levels > 1 else [tr_channels[-1]]
         self.input_proj = nn.ModuleList([
-            nn.Sequential(nn.Conv2d(c, conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for c in chans])
+            nn.Sequential(nn.Conv2d(c, conv_dim, kernel_size=1), GroupNorm(32, conv_dim)) for c in chans])
         for proj in self.input_proj:
             nn.init.xavier_uniform_(proj[0].weight, gain=1)
             nn.init.constant_(proj[0].bias, 0)

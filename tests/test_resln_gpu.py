@@ -38,3 +38,25 @@ def test_res_ln_matches_torch(rows, tdtype):
     for a, b in zip(gw, rw):
         tol = 2e-2 if a.dtype == torch.bfloat16 else 2e-4
         torch.testing.assert_close(a.float(), b.float(), rtol=tol, atol=tol * (1 + float(b.float().abs().max())))
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 64, 64), (1, 256, 20, 28), (3, 64, 9, 4)])
+def test_group_norm_matches_torch(shape):
+    """chunked GroupNorm statistics (mpf_group_stats) + one-pass apply against nn.GroupNorm, forward and gradients."""
+    from mp_former_amd.groupnorm import GroupNorm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    gn = GroupNorm(32, shape[1]).to(dev)
+    ref = torch.nn.GroupNorm(32, shape[1]).to(dev)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5); gn.bias.normal_()
+        ref.weight.copy_(gn.weight); ref.bias.copy_(gn.bias)
+    x = (torch.randn(shape, device=dev) * 2 + 0.5).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    g = torch.randn(shape, device=dev)
+    y, yr = gn(x), ref(xr)
+    torch.testing.assert_close(y, yr, rtol=2e-5, atol=2e-5)
+    y.backward(g); yr.backward(g)
+    torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gn.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(gn.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)

@@ -34,7 +34,7 @@ for i in range(steps):
 torch.cuda.synchronize()
 names = ["msda_fwd", "msda_bwd_push", "tile_scan", "msda_bwd_fill", "msda_bwd_pull", "gemm3_tn_kernel<128>", "gemm3_tn_kernel<96>",
          "gemm3_nt_kernel<128>", "gemm3_nt_kernel<96>", "point_sample_kernel", "select_uncertain", "sample_select", "match_cost", "mask_loss_fwd", "point_sample_bits",
-         "mask_loss_bwd", "attn_fwd", "attn_bwd", "attn_mask"]
+         "mask_loss_bwd", "attn_fwd", "attn_bwd_kv", "attn_bwd_q", "attn_mask", "res_ln256_fwd", "res_ln256_bwd", "bias_act"]
 tot = 0.0
 for n in names:
     c, ms, by = _lib.profile_get(n)
