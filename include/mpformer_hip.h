@@ -344,12 +344,8 @@ int mpf_mask_loss_backward_dense(const void* pred, int pred_dtype, int h, int w,
  * mean[r], rstd[r] = 1/sqrt(var + eps) (biased variance) of `rows` = N*G contiguous runs of row_len =
  * (C/G)*H*W floats (NCHW).  Rows are cut into 8192-element chunks (count, mean, M2 per chunk, merged
  * with Chan's formula) so that 64 rows still fill the chip.  row_len % 4 == 0.
- * mpf_group_stats_nhwc: the same statistics for a channel-last activation x[N, HW, C] with C = 8 G
- * (rows = N*G, row_len = 8*HW for the workspace size).
  */
 size_t mpf_group_stats_workspace_bytes(int rows, int64_t row_len);
-int mpf_group_stats_nhwc(const float* x, int N, int HW, int C, int G, float eps, float* mean, float* rstd,
-                         void* workspace, size_t workspace_bytes, void* stream);
 int mpf_group_stats(const float* x, int rows, int64_t row_len, float eps, float* mean, float* rstd,
                     void* workspace, size_t workspace_bytes, void* stream);
 

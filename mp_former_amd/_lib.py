@@ -56,7 +56,6 @@ SIGNATURES = {
     "mpf_mask_loss_backward_dense": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
                                               _c_vp, _c_int, _c_vp, _c_int, _c_int, _c_vp]),
     "mpf_group_stats_workspace_bytes": (ctypes.c_size_t, [_c_int, ctypes.c_int64]),
-    "mpf_group_stats_nhwc": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, _c_vp, _c_vp, ctypes.c_size_t, _c_vp]),
     "mpf_group_stats": (_c_int, [_c_vp, _c_int, ctypes.c_int64, ctypes.c_float, _c_vp, _c_vp, _c_vp, ctypes.c_size_t, _c_vp]),
     "mpf_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),

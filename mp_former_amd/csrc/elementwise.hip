@@ -282,50 +282,6 @@ __global__ __launch_bounds__(kGnThreads) void gn_chunk_stats_kernel(const float*
     (void)cnt;
 }
 
-// channel-last variant (the conv outputs of a channel-last backbone feature): x [N, HW, C] with C = 8 G;
-// thread = (pixel, group) reads its 8 channels of one pixel as two float4 (a wave covers two whole pixels),
-// runs Welford over its pixels, and the 8 threads of a group in the workgroup merge through LDS.
-constexpr int kGnPix = 512;                            // pixels per chunk (x 256 channels = 512 KB)
-__global__ __launch_bounds__(kGnThreads) void gn_chunk_stats_nhwc_kernel(const float* __restrict__ x, float* __restrict__ part,
-                                                                         int HW, int C, int G, int chunks)
-{
-    __shared__ float sm[3][kGnThreads];
-    const int n = blockIdx.y, ch = blockIdx.x;
-    const int g = threadIdx.x % G, pl = threadIdx.x / G, ppb = kGnThreads / G;       // pixel lanes per workgroup
-    const int p0 = ch * kGnPix, p1 = min(HW, p0 + kGnPix);
-    const float* base = x + ((int64_t)n * HW) * C + g * 8;
-    float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    for (int px = p0 + pl; px < p1; px += ppb) {
-        const float4 a = *reinterpret_cast<const float4*>(base + (int64_t)px * C);
-        const float4 b = *reinterpret_cast<const float4*>(base + (int64_t)px * C + 4);
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        const float s8 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-        const float m8 = s8 * 0.125f;
-        float q8 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) q8 += (v[k] - m8) * (v[k] - m8);
-        const float d = m8 - mean, nn = cnt + 8.f;                                  // Chan merge of (8, m8, q8)
-        mean += d * 8.f / nn;
-        m2 += q8 + d * d * cnt * 8.f / nn;
-        cnt = nn;
-    }
-    sm[0][threadIdx.x] = cnt; sm[1][threadIdx.x] = mean; sm[2][threadIdx.x] = m2;
-    __syncthreads();
-    if (pl == 0) {
-        for (int k = 1; k < ppb; ++k) {
-            const float nb = sm[0][k * G + g], mb = sm[1][k * G + g], qb = sm[2][k * G + g];
-            if (nb > 0.f) {
-                const float d = mb - mean, nn = cnt + nb;
-                mean += d * nb / nn;
-                m2 += qb + d * d * cnt * nb / nn;
-                cnt = nn;
-            }
-        }
-        float* o = part + ((int64_t)(n * G + g) * chunks + ch) * 3;
-        o[0] = cnt; o[1] = mean; o[2] = m2;
-    }
-}
-
 __global__ __launch_bounds__(64) void gn_merge_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
                                                       int rows, int chunks, float eps)
 {
@@ -349,26 +305,8 @@ __global__ __launch_bounds__(64) void gn_merge_kernel(const float* __restrict__ 
 extern "C" size_t mpf_group_stats_workspace_bytes(int rows, int64_t row_len)
 {
     if (rows <= 0 || row_len <= 0) return 0;
-    // covers both layouts: 8192-element chunks (NCHW) and 512-pixel x 8-channel chunks (NHWC, 4096 elements)
-    const int64_t chunks = (row_len + 4096 - 1) / 4096;
+    const int64_t chunks = (row_len + kGnThreads * kGnPer - 1) / (kGnThreads * kGnPer);
     return (size_t)rows * chunks * 3 * sizeof(float);
-}
-
-extern "C" int mpf_group_stats_nhwc(const float* x, int N, int HW, int C, int G, float eps, float* mean, float* rstd,
-                                    void* workspace, size_t workspace_bytes, void* stream)
-{
-    hipStream_t st = (hipStream_t)stream;
-    if (!x || !mean || !rstd || !workspace) return mpf::fail(MPF_E_NULL, "group_stats_nhwc: NULL buffer");
-    if (N <= 0 || HW <= 0 || G <= 0 || C != 8 * G || kGnThreads % G != 0)
-        return mpf::fail(MPF_E_SHAPE, "group_stats_nhwc: needs 8 channels per group and a group count dividing 256");
-    if (workspace_bytes < mpf_group_stats_workspace_bytes(N * G, (int64_t)8 * HW)) return mpf::fail(MPF_E_SHAPE, "group_stats_nhwc: workspace too small");
-    const int chunks = (HW + kGnPix - 1) / kGnPix;
-    mpf::prof_begin(st);
-    mpf::set_kernel("gn_chunk_stats_nhwc_kernel");
-    hipLaunchKernelGGL(gn_chunk_stats_nhwc_kernel, dim3(chunks, N), dim3(kGnThreads), 0, st, x, (float*)workspace, HW, C, G, chunks);
-    mpf::prof_end(mpf_last_kernel(), st, 4.0 * (double)N * HW * C);
-    hipLaunchKernelGGL(gn_merge_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, (const float*)workspace, mean, rstd, N * G, chunks, eps);
-    return mpf::check(hipGetLastError(), "mpf_group_stats_nhwc");
 }
 
 extern "C" int mpf_group_stats(const float* x, int rows, int64_t row_len, float eps, float* mean, float* rstd,

@@ -33,12 +33,8 @@ class _GroupNormFn(Function):
         lib = _lib.lib()
         ws = _workspace(x.device, lib.mpf_group_stats_workspace_bytes(rows, row_len))
         with torch.cuda.device(x.device):
-            if x.is_contiguous():
-                code = lib.mpf_group_stats(x.data_ptr(), rows, row_len, float(eps), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(),
-                                           ws.numel(), torch.cuda.current_stream(x.device).cuda_stream)
-            else:               # channels_last: [N, HW, C] in memory
-                code = lib.mpf_group_stats_nhwc(x.data_ptr(), N, hw, C, groups, float(eps), mean.data_ptr(), rstd.data_ptr(),
-                                                ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream)
+            code = lib.mpf_group_stats(x.data_ptr(), rows, row_len, float(eps), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), torch.cuda.current_stream(x.device).cuda_stream)
         _lib.check(code, "mpf_group_stats")
         # y = x * a + b with a[n, c] = rstd[n, g] * gamma[c], b[n, c] = beta[c] - mean[n, g] * a[n, c]
         a = (rstd.view(N, groups, 1) * weight.view(1, groups, C // groups)).view(N, C)
@@ -53,10 +49,8 @@ class _GroupNormFn(Function):
     def backward(ctx, gy):
         x, weight, mean, rstd = ctx.saved_tensors
         N, C = x.shape[:2]
-        # (aten's backward wants NCHW-contiguous operands; a channel-last activation is copied here, as the
-        # stock module does in its forward)
         gx, gw, gb = torch.ops.aten.native_group_norm_backward(
-            gy.contiguous(), x.contiguous(), mean.view(N, ctx.groups), rstd.view(N, ctx.groups), weight, N, C, ctx.hw, ctx.groups,
+            gy.contiguous(), x, mean.view(N, ctx.groups), rstd.view(N, ctx.groups), weight, N, C, ctx.hw, ctx.groups,
             [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]])
         return gx, gw, gb, None, None
 
@@ -64,10 +58,7 @@ class _GroupNormFn(Function):
 class GroupNorm(nn.GroupNorm):
     def forward(self, x):
         C = x.shape[1]
-        if x.is_cuda and x.dtype == torch.float32 and self.affine and x.dim() >= 3:
-            nchw = x.is_contiguous() and ((C // self.num_groups) * (x.numel() // (x.shape[0] * C))) % 4 == 0
-            nhwc = (x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
-                    and C == 8 * self.num_groups and 256 % self.num_groups == 0)
-            if nchw or nhwc:
-                return _GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps)
+        if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and self.affine and x.dim() >= 3
+                and ((C // self.num_groups) * (x.numel() // (x.shape[0] * C))) % 4 == 0):
+            return _GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps)
         return super().forward(x)
