@@ -26,7 +26,7 @@ for si in range(warmup, len(ends) - 1):
             if pred(seg[i][2]):
                 return i
         return len(seg)
-    i_pix = first(lambda n: "RowwiseMoments" in n)
+    i_pix = first(lambda n: "RowwiseMoments" in n or "gn_chunk_stats" in n)
     i_dec = first(lambda n: "attn_mask_kernel" in n, i_pix)
     i_crit = first(lambda n: "point_sample_kernel" in n or "match_cost" in n, i_dec)
     i_bwd = first(lambda n: "mask_loss_bwd" in n, i_crit)
