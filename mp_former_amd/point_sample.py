@@ -27,15 +27,24 @@ def _stream(dev):
 
 
 def _row_slice_of(t):
-    """(base, first row) if ``t`` is a dim-1 slice view of a 4-D tensor (e.g. the MP / matching halves
-    of a layer's mask predictions), else (t, 0)."""
-    b = t._base
-    if (b is not None and b.dim() == 4 and t.dim() == 4 and b.shape[0] == t.shape[0] and b.shape[2:] == t.shape[2:]
-            and b.stride() == t.stride() and b.stride(1) > 0):
-        d = t.storage_offset() - b.storage_offset()
-        if d >= 0 and d % b.stride(1) == 0 and d // b.stride(1) + t.shape[1] <= b.shape[1]:
-            return b, d // b.stride(1)
-    return t, 0
+    """If ``t`` [N, Q, h, w] is a row-range view (possibly through several views) of a dense parent that
+    can be seen as [N, Qb, h, w] — e.g. the MP / matching halves of one layer's mask predictions inside
+    the batched-heads tensor — return (root, Qb, first row); else None."""
+    root = t._base
+    if root is None or t.dim() != 4 or not root.is_contiguous():
+        return None
+    N, Q, h, w = t.shape
+    s0, s1, s2, s3 = t.stride()
+    if s3 != 1 or s2 != w or s1 != h * w or s0 % (h * w) != 0:
+        return None
+    Qb = s0 // (h * w)
+    d = t.storage_offset() - root.storage_offset()
+    if d < 0 or root.numel() != N * Qb * h * w or d % (h * w) != 0:
+        return None
+    q0 = d // (h * w)
+    if q0 + Q > Qb:
+        return None
+    return root, Qb, q0
 
 
 class MapSet:
@@ -63,11 +72,18 @@ class MapSet:
                 raise RuntimeError("all maps of a MapSet must share dtype, device and [h, w]")
             if t.stride(3) != 1 or t.stride(2) != self.w:
                 raise RuntimeError("maps must be dense [h, w] planes")
-            b, q0 = _row_slice_of(t)
-            k = id(b)
-            if k not in seen:
-                seen[k] = len(self.bases)
-                self.bases.append(b)
+            rs = _row_slice_of(t)
+            if rs is None:
+                k, q0 = id(t), 0
+                if k not in seen:
+                    seen[k] = len(self.bases)
+                    self.bases.append(t)
+            else:
+                root, Qb, q0 = rs
+                k = (id(root), Qb)
+                if k not in seen:
+                    seen[k] = len(self.bases)
+                    self.bases.append(root.view(t.shape[0], Qb, self.h, self.w))     # one parent view per root
             self.base_of.append(seen[k])
             self.q0.append(q0)
         self.base_of = np.array(self.base_of, dtype=np.int64)
