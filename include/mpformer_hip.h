@@ -301,6 +301,22 @@ int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t ldb, const
                  int transpose_out, void* stream);
 
 /*
+ * Small-row bf16 GEMM of the transformer decoder's query-side Linear layers (the nn.Linear /
+ * nn.MultiheadAttention projections of mask2former_transformer_decoder.py:19-206 under autocast;
+ * Qtot * N ~ 200-300 rows), fp32 accumulation:
+ *   C[i][j] = sum_k A(i,k) * B(j,k) (+ bias[j]) (ReLU),  i < I, j < J, k < Kc,  C row-major, row stride ldc
+ * A(i,k) = a[i*a_rs + k*a_ks], B(j,k) = b[j*b_rs + k*b_ks] (element strides); for each operand one of
+ * the two strides must be 1, so forward (x, W), input gradient (dY, W read along its rows) and weight
+ * gradient (dY and x read along their rows) need no transposed copies.  gate (NULL or addressed like
+ * a) keeps A(i,k) only where gate(i,k) > 0 (ReLU backward); rowsum_a (NULL or [I] bf16) receives
+ * sum_k A(i,k) after the gate (the bias gradient in the weight-gradient form).  All buffers bf16.
+ * Contraction-contiguous operands need 16-B aligned rows and Kc % 8 == 0; J % 4 == 0, ldc % 4 == 0.
+ */
+int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, const void* gate, const void* b, int64_t b_rs,
+                        int64_t b_ks, const void* bias, void* c, int64_t ldc, void* rowsum_a, int I, int J, int Kc,
+                        int relu, void* stream);
+
+/*
  * y = relu?(x + bias[c] + res) over a dense channel-last activation (channel = fastest dimension,
  * C % 8 == 0): the folded FrozenBatchNorm shift, the residual add and the ReLU of a ResNet
  * bottleneck (detectron2 BottleneckBlock, used by configs/coco/instance-segmentation/Base-COCO-

@@ -49,6 +49,8 @@ SIGNATURES = {
                            _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_gemm3_nt": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp, _c_vp,
                            _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),
+    "mpf_small_gemm_bf16": (_c_int, [_c_vp, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_vp,
+                                     ctypes.c_int64, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_bias_act": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_res_ln256_forward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
                                        _c_vp, _c_int, _c_vp, _c_vp]),

@@ -1,0 +1,257 @@
+// bf16 GEMMs of the transformer decoder's query-side Linear layers (Qtot * N ~ 200-300 rows):
+// forward, input gradient and weight gradient (+ bias gradient) of y = x W^T + b, optional ReLU.
+//
+// Reference: the nn.Linear / nn.MultiheadAttention projections of SelfAttentionLayer /
+// CrossAttentionLayer / FFNLayer / MLP (mask2former_transformer_decoder.py:19-206) under autocast.
+// These problems are 30-240 MFLOP: the library picks one or two 256x256 macro-tiles for them (13 us
+// on one CU); here a block of 4 waves owns one 16 x (16*NJ) output tile, splits the contraction between its
+// waves and feeds v_mfma_f32_16x16x32_bf16 straight from global memory (the operands are L2 resident),
+// so a 228x256x256 problem is 240 blocks of 4 waves x 2 MFMA steps.
+//
+//   C[i][j] = sum_k A(i,k) * B(j,k) (+ bias[j]) (ReLU),   i < I, j < J, k < Kc,   fp32 accumulation
+//
+// Each operand is addressed through (row stride, contraction stride), one of which must be 1:
+//   contraction-contiguous: a lane's 8 consecutive k are one 16-B load         (x, W in the forward)
+//   row-contiguous:         8 two-byte loads, 16 lanes cover 32 contiguous B   (W in dX; dY and x in dW)
+// so the three GEMMs of a Linear need no transposed copies.  `gate` (same addressing as A) applies
+// the ReLU backward to A on the fly: A(i,k) is used only where gate(i,k) > 0.  `rowsum_a` returns
+// sum_k A(i,k) after the gate — the bias gradient in the dW form (A(n,m) = dY[m,n]).
+// MFMA is issued as D^T = B . A^T so a lane owns 4 consecutive output columns (8-B bf16 stores).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mpf_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short u16;
+
+struct SG {
+    const u16* a;
+    const u16* gate;
+    const u16* b;
+    const u16* bias;
+    u16* c;
+    u16* rowsum;
+    int64_t a_rs, a_ks, b_rs, b_ks, ldc;
+    int I, J, Kc, relu, n_it, n_waves;
+};
+
+union Frag {
+    uint4 q;
+    unsigned w[4];
+    bf16x8 v;
+};
+
+__device__ __forceinline__ unsigned f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+// 8 consecutive-k elements of one operand row for this lane.  CONTIG: one 16-B load; else 8 u16 loads
+// at stride ks.  MASK: elements with k >= Kc read as zero (loads stay unconditional: clamped address).
+template <bool CONTIG, bool MASK>
+__device__ __forceinline__ Frag load_frag(const u16* __restrict__ row, int64_t ks, int k, int Kc)
+{
+    Frag f;
+    if (CONTIG) {
+        const int kc = MASK ? min(k, Kc - 8) : k;
+        f.q = *reinterpret_cast<const uint4*>(row + kc);
+        if (MASK && k >= Kc) f.q = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+        unsigned e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = MASK ? min(k + j, Kc - 1) : k + j;
+            e[j] = row[(int64_t)kk * ks];
+            if (MASK && k + j >= Kc) e[j] = 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.w[j] = e[2 * j] | (e[2 * j + 1] << 16);
+    }
+    return f;
+}
+
+__device__ __forceinline__ unsigned gate_word(unsigned v, unsigned g)
+{
+    const unsigned lo = ((int)(g << 16) > 0) ? 0x0000ffffu : 0u;
+    const unsigned hi = ((int)(g & 0xffff0000u) > 0) ? 0xffff0000u : 0u;
+    return v & (lo | hi);
+}
+
+__device__ __forceinline__ float sum_words(const Frag& f)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += __uint_as_float(f.w[j] << 16) + __uint_as_float(f.w[j] & 0xffff0000u);
+    return s;
+}
+
+// One block = one 16 x (16*NJ) output tile; its 4 waves take the 32-wide contraction steps round-robin
+// (step s belongs to wave s % 4, so at any time the block reads 4 adjacent 64-B pieces of a row) and
+// U = 4 / NJ of a wave's steps are loaded together before their MFMAs: a 256-deep contraction is ONE
+// memory latency per wave, a 2048-deep one four.  The partial tiles are summed through LDS by wave 0.
+template <int NJ, bool AC, bool BC, bool GATE, bool MASK>
+__global__ __launch_bounds__(256) void small_gemm_kernel(const SG p)
+{
+    constexpr int U = 4 / NJ;
+    __shared__ float4 red[3][NJ][64];
+    __shared__ float red_rs[3][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int it = blockIdx.x % p.n_it, jt = blockIdx.x / p.n_it;
+    const int li = lane & 15, g = lane >> 4;
+    const int i = it * 16 + li;
+    const int ic = min(i, p.I - 1);
+    const u16* __restrict__ arow = p.a + (int64_t)ic * p.a_rs;
+    const u16* __restrict__ grow = GATE ? p.gate + (int64_t)ic * p.a_rs : nullptr;
+    const u16* __restrict__ brow[NJ];
+    const int j0 = jt * 16 * NJ;
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) brow[n] = p.b + (int64_t)min(j0 + 16 * n + li, p.J - 1) * p.b_rs;
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rs = 0.f;
+    const int nsteps = (p.Kc + 31) >> 5;
+    for (int s0 = wv; s0 < nsteps; s0 += 4 * U) {
+        Frag fa[U], fg[U], fb[U][NJ];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {       // steps past the end re-read the last one (discarded below)
+            const int k = min(s0 + 4 * u, nsteps - 1) * 32 + 8 * g;
+#pragma unroll
+            for (int n = 0; n < NJ; ++n) fb[u][n] = load_frag<BC, MASK>(brow[n], p.b_ks, k, p.Kc);
+            fa[u] = load_frag<AC, MASK>(arow, p.a_ks, k, p.Kc);
+            if (GATE) fg[u] = load_frag<AC, MASK>(grow, p.a_ks, k, p.Kc);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (GATE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fa[u].w[j] = gate_word(fa[u].w[j], fg[u].w[j]);
+            }
+            if (u > 0 && s0 + 4 * u >= nsteps) fa[u].q = make_uint4(0u, 0u, 0u, 0u);
+            rs += sum_words(fa[u]);
+#pragma unroll
+            for (int n = 0; n < NJ; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u][n].v, fa[u].v, acc[n], 0, 0, 0);
+        }
+    }
+    if (wv > 0) {
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) red[wv - 1][n][lane] = make_float4(acc[n][0], acc[n][1], acc[n][2], acc[n][3]);
+        red_rs[wv - 1][lane] = rs;
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+#pragma unroll
+        for (int n = 0; n < NJ; ++n) {
+            const float4 t = red[o][n][lane];
+            acc[n][0] += t.x; acc[n][1] += t.y; acc[n][2] += t.z; acc[n][3] += t.w;
+        }
+        rs += red_rs[o][lane];
+    }
+    if (p.rowsum && jt == 0) {
+        rs += __shfl_xor(rs, 16);
+        rs += __shfl_xor(rs, 32);
+        if (g == 0 && i < p.I) p.rowsum[i] = (u16)f2bf(rs);
+    }
+    if (i >= p.I) return;
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) {
+        const int j = j0 + 16 * n + 4 * g;
+        if (j >= p.J) continue;
+        float v[4] = {acc[n][0], acc[n][1], acc[n][2], acc[n][3]};
+        if (p.bias) {
+            const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + j);
+            v[0] += __uint_as_float(bb.x << 16);
+            v[1] += __uint_as_float(bb.x & 0xffff0000u);
+            v[2] += __uint_as_float(bb.y << 16);
+            v[3] += __uint_as_float(bb.y & 0xffff0000u);
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        uint2 o;
+        o.x = f2bf(v[0]) | (f2bf(v[1]) << 16);
+        o.y = f2bf(v[2]) | (f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(p.c + (int64_t)i * p.ldc + j) = o;
+    }
+}
+
+template <int NJ, bool AC, bool BC>
+void launch2(const SG& p, bool gate, bool mask, int blocks, hipStream_t st)
+{
+    if (gate && mask)
+        small_gemm_kernel<NJ, AC, BC, true, true><<<blocks, 256, 0, st>>>(p);
+    else if (gate)
+        small_gemm_kernel<NJ, AC, BC, true, false><<<blocks, 256, 0, st>>>(p);
+    else if (mask)
+        small_gemm_kernel<NJ, AC, BC, false, true><<<blocks, 256, 0, st>>>(p);
+    else
+        small_gemm_kernel<NJ, AC, BC, false, false><<<blocks, 256, 0, st>>>(p);
+}
+
+template <int NJ>
+void launch(const SG& p, bool ac, bool bc, int blocks, hipStream_t st)
+{
+    const bool gate = p.gate != nullptr, mask = (p.Kc & 31) != 0;
+    if (ac && bc)
+        launch2<NJ, true, true>(p, gate, mask, blocks, st);
+    else if (ac)
+        launch2<NJ, true, false>(p, gate, mask, blocks, st);
+    else if (bc)
+        launch2<NJ, false, true>(p, gate, mask, blocks, st);
+    else
+        launch2<NJ, false, false>(p, gate, mask, blocks, st);
+}
+
+}  // namespace
+
+extern "C" int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, const void* gate, const void* b,
+                                   int64_t b_rs, int64_t b_ks, const void* bias, void* c, int64_t ldc, void* rowsum_a,
+                                   int I, int J, int Kc, int relu, void* stream)
+{
+    if (I < 0 || J < 0 || Kc < 0) return mpf::fail(MPF_E_SHAPE, "small_gemm: negative size");
+    if (I == 0 || J == 0) return 0;
+    if (!a || !b || !c) return mpf::fail(MPF_E_NULL, "small_gemm: a, b, c must not be null");
+    if (Kc == 0) return mpf::fail(MPF_E_SHAPE, "small_gemm: empty contraction");
+    const bool ac = a_ks == 1, bc = b_ks == 1;
+    if ((!ac && a_rs != 1) || (!bc && b_rs != 1))
+        return mpf::fail(MPF_E_SHAPE, "small_gemm: each operand needs a unit row or contraction stride");
+    if ((ac && (Kc % 8 || a_rs % 8 || ((uintptr_t)a & 15) || (gate && ((uintptr_t)gate & 15)))) ||
+        (bc && (Kc % 8 || b_rs % 8 || ((uintptr_t)b & 15))))
+        return mpf::fail(MPF_E_SHAPE, "small_gemm: contraction-contiguous operands need 16-B aligned rows, Kc % 8 == 0");
+    if (J % 4 || ldc % 4 || ((uintptr_t)c & 7) || (bias && ((uintptr_t)bias & 7)))
+        return mpf::fail(MPF_E_SHAPE, "small_gemm: J and ldc must be multiples of 4 (8-B stores)");
+    SG p;
+    p.a = static_cast<const u16*>(a);
+    p.gate = static_cast<const u16*>(gate);
+    p.b = static_cast<const u16*>(b);
+    p.bias = static_cast<const u16*>(bias);
+    p.c = static_cast<u16*>(c);
+    p.rowsum = static_cast<u16*>(rowsum_a);
+    p.a_rs = a_rs; p.a_ks = a_ks; p.b_rs = b_rs; p.b_ks = b_ks; p.ldc = ldc;
+    p.I = I; p.J = J; p.Kc = Kc; p.relu = relu;
+    p.n_it = (I + 15) / 16;
+    // widest tile that still gives the chip >= 256 blocks
+    int nj = 4;
+    while (nj > 1 && (int64_t)p.n_it * ((J + 16 * nj - 1) / (16 * nj)) < 256) nj >>= 1;
+    p.n_waves = p.n_it * ((J + 16 * nj - 1) / (16 * nj));
+    const int blocks = p.n_waves;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mpf::prof_begin(st);
+    if (nj == 4) launch<4>(p, ac, bc, blocks, st);
+    else if (nj == 2) launch<2>(p, ac, bc, blocks, st);
+    else launch<1>(p, ac, bc, blocks, st);
+    mpf::set_kernel("small_gemm_kernel");
+    const double bytes = 2.0 * ((double)I * Kc * (gate ? 2 : 1) + (double)J * Kc + (double)I * J);
+    mpf::prof_end("small_gemm_kernel", st, bytes);
+    return mpf::check(hipGetLastError(), "small_gemm launch");
+}

@@ -1,0 +1,80 @@
+"""bf16 Linear for the decoder's query-side activations (a few hundred rows) on the small-row MFMA GEMM
+(csrc/small_gemm.hip; include/mpformer_hip.h mpf_small_gemm_bf16).
+
+``small_linear(x, w, b, relu)`` == ``relu?(F.linear(x, w, b))`` for bf16 CUDA tensors (what autocast
+makes of the nn.Linear / nn.MultiheadAttention projections of mask2former_transformer_decoder.py:19-206),
+with the ReLU, its backward gate and the bias gradient folded into the three GEMMs of the layer.
+Same rounding points as the library path: fp32 accumulation, bf16 results.  GPU only.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+MAX_ROWS = 1024     # above this the library GEMMs have enough tiles to fill the chip
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def small_gemm(a, a_rs, a_ks, b, b_rs, b_ks, I, J, Kc, bias=None, gate=None, relu=False, rowsum=False):
+    """C[I, J] = sum_k A(i,k) B(j,k) (+bias) (ReLU) with explicit element strides; returns (C, rowsum_a or None)."""
+    c = torch.empty((I, J), dtype=torch.bfloat16, device=a.device)
+    rs = torch.empty((I,), dtype=torch.bfloat16, device=a.device) if rowsum else None
+    with torch.cuda.device(a.device):
+        code = _lib.lib().mpf_small_gemm_bf16(
+            a.data_ptr(), a_rs, a_ks, gate.data_ptr() if gate is not None else None, b.data_ptr(), b_rs, b_ks,
+            bias.data_ptr() if bias is not None else None, c.data_ptr(), J, rs.data_ptr() if rowsum else None,
+            I, J, Kc, 1 if relu else 0, _stream(a))
+    _lib.check(code, "mpf_small_gemm_bf16")
+    return c, rs
+
+
+def usable(x, w, b=None):
+    """Shapes / dtypes the kernel takes (callers use F.linear otherwise)."""
+    K = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and (b is None or b.dtype == torch.bfloat16)
+            and x.numel() // max(K, 1) <= MAX_ROWS and K % 8 == 0 and w.shape[0] % 8 == 0 and x.numel() > 0)
+
+
+class _SmallLinear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        w = w.contiguous()
+        M, N = x2.shape[0], w.shape[0]
+        y, _ = small_gemm(x2, x2.stride(0), 1, w, K, 1, M, N, K, bias=b, relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x2, w, y if relu else None)
+        ctx.has_bias = b is not None
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, y = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        g2 = gy.reshape(M, N)
+        if g2.stride(1) != 1 or g2.stride(0) % 8 or g2.data_ptr() % 16 or g2.dtype != torch.bfloat16:
+            g2 = g2.to(torch.bfloat16).contiguous()
+        if y is not None and g2.stride(0) != N:
+            g2 = g2.contiguous()        # the gate is addressed like the gradient
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dX[m, k] = sum_n dY[m, n] W[n, k]: A = dY (contraction-contiguous), B(k, n) = W[n, k] (row-contiguous)
+            dx, _ = small_gemm(g2, g2.stride(0), 1, w, 1, K, M, K, N, gate=y)
+            dx = dx.view(*gy.shape[:-1], K)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            # dW[n, k] = sum_m dY[m, n] x[m, k]; db[n] = sum_m dY[m, n] (row sums of the A operand)
+            dw, db = small_gemm(g2, 1, g2.stride(0), x2, 1, x2.stride(0), N, K, M, gate=y, rowsum=ctx.has_bias)
+        return dx, dw, db, None
+
+
+def small_linear(x, w, b=None, relu=False):
+    if not x.is_cuda:
+        raise RuntimeError("mp_former_amd small_linear runs on the GPU only (no CPU fallback)")
+    return _SmallLinear.apply(x, w, b, relu)

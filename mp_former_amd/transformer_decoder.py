@@ -29,6 +29,7 @@ from . import _lib, _rng
 from ._h2d import upload
 from .attention import attention_core
 from .resln import res_ln
+from .small_linear import small_linear, usable as _small_ok
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
 
 
@@ -106,6 +107,16 @@ def native_attn_mask(masks, size, mp_rows=None):
     return out
 
 
+def linear(x, w, b=None, relu=False):
+    """relu?(F.linear(x, w, b)).  bf16 activations with a few hundred rows (the query side of the decoder
+    under autocast) run on the small-row MFMA GEMM with the ReLU / its backward gate / the bias gradient
+    fused (small_linear.py); everything else is the library GEMM."""
+    if _small_ok(x, w, b) and os.environ.get("MPF_SMALL_LINEAR", "1") == "1":
+        return small_linear(x, w, b, relu)
+    y = F.linear(x, w, b)
+    return F.relu(y) if relu else y
+
+
 def masked_mha_w(q_in, k_in, v_in, w, b, wo, bo, nheads, mask: Optional[Tensor]):
     """Multi-head attention with in-projection (w, b) and out-projection (wo, bo), seq-first.
     q_in [Lq,N,E]; k_in, v_in [Lk,N,E]; mask bool, True = masked: [N,Lq,Lk] (shared by heads) or
@@ -119,11 +130,11 @@ def masked_mha_w(q_in, k_in, v_in, w, b, wo, bo, nheads, mask: Optional[Tensor])
     else:
         if not isinstance(w, (tuple, list)):
             w, b = (w[:E], w[E:2 * E], w[2 * E:]), (b[:E], b[E:2 * E], b[2 * E:])
-        q = F.linear(q_in, w[0], b[0])
-        k = F.linear(k_in, w[1], b[1])
-        v = F.linear(v_in, w[2], b[2])
+        q = linear(q_in, w[0], b[0])
+        k = linear(k_in, w[1], b[1])
+        v = linear(v_in, w[2], b[2])
     o = attention_core(q, k, v, mask, nheads)
-    return F.linear(o, wo, bo)
+    return linear(o, wo, bo)
 
 
 def masked_mha(q_in, k_in, v_in, mha: nn.MultiheadAttention, mask: Optional[Tensor]):
@@ -365,9 +376,9 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             amp = W["class_embed.weight"].dtype == torch.bfloat16
             d32, d16 = res_ln(self.decoder_norm, output.detach(), None, want32=not amp, want16=amp)
             x = d16 if amp else d32
-            e = F.relu(F.linear(x, W["mask_embed.layers.0.weight"].detach(), W["mask_embed.layers.0.bias"].detach()))
-            e = F.relu(F.linear(e, W["mask_embed.layers.1.weight"].detach(), W["mask_embed.layers.1.bias"].detach()))
-            me = F.linear(e, W["mask_embed.layers.2.weight"].detach(), W["mask_embed.layers.2.bias"].detach()).transpose(0, 1)
+            e = linear(x, W["mask_embed.layers.0.weight"].detach(), W["mask_embed.layers.0.bias"].detach(), relu=True)
+            e = linear(e, W["mask_embed.layers.1.weight"].detach(), W["mask_embed.layers.1.bias"].detach(), relu=True)
+            me = linear(e, W["mask_embed.layers.2.weight"].detach(), W["mask_embed.layers.2.bias"].detach()).transpose(0, 1)
             m = torch.einsum("bqc,bchw->bqhw", me, mask_features.detach())
             return native_attn_mask(m, attn_mask_target_size, mp_rows)
 
@@ -456,8 +467,8 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             output, xb = post_norm(self.transformer_self_attention_layers[i].norm, output, t2)
             # FFN (:1798-1800)
             pre = f"transformer_ffn_layers.{i}."
-            t2 = F.linear(F.relu(F.linear(xb, W[pre + "linear1.weight"], W[pre + "linear1.bias"])),
-                          W[pre + "linear2.weight"], W[pre + "linear2.bias"])
+            t2 = linear(linear(xb, W[pre + "linear1.weight"], W[pre + "linear1.bias"], relu=True),
+                        W[pre + "linear2.weight"], W[pre + "linear2.bias"])
             output, xb = post_norm(self.transformer_ffn_layers[i].norm, output, t2)
             nxt = (i + 1) % self.num_feature_levels
             streams.append(output)
