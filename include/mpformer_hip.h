@@ -304,7 +304,8 @@ int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t ldb, const
  * Small-row bf16 GEMM of the transformer decoder's query-side Linear layers (the nn.Linear /
  * nn.MultiheadAttention projections of mask2former_transformer_decoder.py:19-206 under autocast;
  * Qtot * N ~ 200-300 rows), fp32 accumulation:
- *   C[i][j] = sum_k A(i,k) * B(j,k) (+ bias[j]) (ReLU),  i < I, j < J, k < Kc,  C row-major, row stride ldc
+ *   C[i][j] = sum_k A(i,k) * B(j,k) (+ bias[j]) (+ c_in[i][j]) (ReLU),  i < I, j < J, k < Kc
+ * C and c_in (NULL or bf16, may alias c) row-major with row strides ldc / ldcin.
  * A(i,k) = a[i*a_rs + k*a_ks], B(j,k) = b[j*b_rs + k*b_ks] (element strides); for each operand one of
  * the two strides must be 1, so forward (x, W), input gradient (dY, W read along its rows) and weight
  * gradient (dY and x read along their rows) need no transposed copies.  gate (NULL or addressed like
@@ -313,8 +314,78 @@ int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t ldb, const
  * Contraction-contiguous operands need 16-B aligned rows and Kc % 8 == 0; J % 4 == 0, ldc % 4 == 0.
  */
 int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, const void* gate, const void* b, int64_t b_rs,
-                        int64_t b_ks, const void* bias, void* c, int64_t ldc, void* rowsum_a, int I, int J, int Kc,
-                        int relu, void* stream);
+                        int64_t b_ks, const void* bias, const void* c_in, int64_t ldcin, void* c, int64_t ldc,
+                        void* rowsum_a, int I, int J, int Kc, int relu, void* stream);
+
+/*
+ * One decoder layer of the masked-attention transformer decoder — cross-attention, self-attention, FFN,
+ * each followed by its post-norm residual (mask2former_transformer_decoder.py:1784-1800 with
+ * CrossAttentionLayer.forward_post :100-112, SelfAttentionLayer.forward_post :42-52, FFNLayer.forward_post
+ * :165-169), under autocast — issued as ONE host call: the ~20 (forward) / ~45 (backward) kernels of the
+ * layer are the entry points above (mpf_small_gemm_bf16, mpf_attn_*, mpf_res_ln256_*), launched back to
+ * back on `stream` from native code instead of one Python-level autograd node each.  The key / value
+ * projections of the cross-attention (k_c, v_c: [S, N, E] rows, library-sized GEMMs) stay outside.
+ *
+ * Shapes: R = Qt * N query rows, E = H * 32 = 256 channels, F = ffn_dim.  Activations marked bf16 are
+ * the autocast operand copies; the residual stream (x0 .. x3, s1 .. s3) is fp32.  Masks: bytes, 1 =
+ * masked; mask_c [N, Qt, S] per image, mask_s [Qt, Qt] shared or NULL.  All buffers are caller-owned
+ * device memory; `scratch` must hold mpf_decoder_layer_scratch_bytes(...) bytes (contents undefined
+ * afterwards), `attn_ws` max(mpf_attn_workspace_bytes(Qt, S, N, H), mpf_attn_workspace_bytes(Qt, Qt, N, H)).
+ */
+typedef struct MpfDecoderLayer {
+    /* parameters: bf16 GEMM weights [out, in] and biases; fp32 LayerNorm affine */
+    const void *ca_wq, *ca_bq, *ca_wo, *ca_bo;
+    const float *ca_gamma, *ca_beta;
+    const void *sa_wq, *sa_bq, *sa_wk, *sa_bk, *sa_wv, *sa_bv, *sa_wo, *sa_bo;
+    const float *sa_gamma, *sa_beta;
+    const void *ff_w1, *ff_b1, *ff_w2, *ff_b2;
+    const float *ff_gamma, *ff_beta;
+    /* forward inputs */
+    const float* x0;       /* [R, E] fp32 residual stream */
+    const void* xb0;       /* [R, E] bf16 copy of x0 */
+    const void *k_c, *v_c; /* [S, N, E] bf16 projected keys / values of the level */
+    const uint8_t *mask_c, *mask_s;
+    /* written by forward, read by backward */
+    void *q_c, *kT_c, *o_c; /* [R, E], [N, E, S], [R, E] bf16 */
+    float* lse_c;           /* [N, H, Qt] */
+    float *s1, *mean1, *rstd1;
+    void* xb1;
+    void *q_s, *k_s, *v_s, *kT_s, *o_s; /* [R, E] x3, [N, E, Qt], [R, E] bf16 */
+    float* lse_s;
+    float *s2, *mean2, *rstd2;
+    void* xb2;
+    void* h;                /* [R, F] bf16, after the ReLU */
+    float *s3, *mean3, *rstd3;
+    /* forward outputs */
+    float* x3;              /* [R, E] fp32 */
+    void* xb3;              /* [R, E] bf16 */
+    /* workspaces */
+    void *scratch, *attn_ws;
+    uint64_t scratch_bytes, attn_ws_bytes;
+    int32_t Qt, N, H, S, ffn_dim;
+    float eps;
+} MpfDecoderLayer;
+
+typedef struct MpfDecoderLayerGrad {
+    /* upstream gradients of the outputs (either may be NULL, not both) */
+    const float* g_x3;
+    const void* g_xb3;
+    /* gradients of the inputs */
+    float* d_x0;            /* [R, E] fp32 */
+    void* d_xb0;            /* [R, E] bf16 */
+    void *d_k_c, *d_v_c;    /* [S, N, E] bf16 */
+    /* gradients of the parameters: bf16 like the working copies; LayerNorm fp32 as one [6, 256] block
+       (ca_gamma, ca_beta, sa_gamma, sa_beta, ff_gamma, ff_beta), zeroed by the call */
+    void *d_ca_wq, *d_ca_bq, *d_ca_wo, *d_ca_bo;
+    void *d_sa_wq, *d_sa_bq, *d_sa_wk, *d_sa_bk, *d_sa_wv, *d_sa_bv, *d_sa_wo, *d_sa_bo;
+    void *d_ff_w1, *d_ff_b1, *d_ff_w2, *d_ff_b2;
+    float* d_ln;
+} MpfDecoderLayerGrad;
+
+uint64_t mpf_decoder_layer_struct_bytes(int which); /* 0: sizeof(MpfDecoderLayer), 1: sizeof(MpfDecoderLayerGrad) */
+uint64_t mpf_decoder_layer_scratch_bytes(int Qt, int N, int H, int S, int ffn_dim, int backward);
+int mpf_decoder_layer_forward(const MpfDecoderLayer* layer, void* stream);
+int mpf_decoder_layer_backward(const MpfDecoderLayer* layer, const MpfDecoderLayerGrad* grad, void* stream);
 
 /*
  * y = relu?(x + bias[c] + res) over a dense channel-last activation (channel = fastest dimension,

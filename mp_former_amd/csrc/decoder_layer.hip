@@ -1,0 +1,215 @@
+// One transformer-decoder layer (cross-attention, self-attention, FFN, post-norm residuals) issued
+// from native code: the host side of include/mpformer_hip.h MpfDecoderLayer.  No kernels here — the
+// layer is a fixed sequence of the library's own entry points (small_gemm.hip, attn.hip,
+// elementwise.hip); what this file removes is the per-kernel cost of a Python autograd node (~20 us of
+// host time against 3-6 us of GPU time per launch), which made the decoder launch-bound.
+// Reference: mask2former_transformer_decoder.py:1784-1800 (the layer loop), :42-52, :100-112, :165-169.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mpf_common.h"
+
+namespace {
+
+constexpr int kE = 256;
+
+struct Carve {
+    char* p;
+    size_t used = 0;
+    explicit Carve(void* base) : p(static_cast<char*>(base)) {}
+    template <typename T>
+    T* take(size_t count)
+    {
+        T* r = reinterpret_cast<T*>(p + used);
+        used += (count * sizeof(T) + 255) & ~size_t(255);
+        return r;
+    }
+};
+
+struct FwdScratch {
+    void *vT_c, *vT_s, *t;
+    float *x1, *x2;
+    size_t bytes;
+};
+
+FwdScratch fwd_scratch(void* base, int Qt, int N, int S)
+{
+    Carve c(base);
+    FwdScratch f;
+    const size_t R = (size_t)Qt * N;
+    f.vT_c = c.take<uint16_t>((size_t)N * kE * S);
+    f.vT_s = c.take<uint16_t>((size_t)N * kE * Qt);
+    f.t = c.take<uint16_t>(R * kE);
+    f.x1 = c.take<float>(R * kE);
+    f.x2 = c.take<float>(R * kE);
+    f.bytes = c.used;
+    return f;
+}
+
+struct BwdScratch {
+    void *dt, *dxb, *dh, *dout, *dq, *dk_s, *dv_s, *qT, *doT;
+    float *ds_a, *ds_b, *delta;
+    size_t bytes;
+};
+
+BwdScratch bwd_scratch(void* base, int Qt, int N, int H, int F)
+{
+    Carve c(base);
+    BwdScratch b;
+    const size_t R = (size_t)Qt * N;
+    const size_t LqP = (size_t)((Qt + 31) / 32 * 32);
+    b.dt = c.take<uint16_t>(R * kE);
+    b.dxb = c.take<uint16_t>(R * kE);
+    b.dh = c.take<uint16_t>(R * F);
+    b.dout = c.take<uint16_t>(R * kE);
+    b.dq = c.take<uint16_t>(R * kE);
+    b.dk_s = c.take<uint16_t>(R * kE);
+    b.dv_s = c.take<uint16_t>(R * kE);
+    b.qT = c.take<uint16_t>((size_t)N * kE * LqP);
+    b.doT = c.take<uint16_t>((size_t)N * kE * LqP);
+    b.ds_a = c.take<float>(R * kE);
+    b.ds_b = c.take<float>(R * kE);
+    b.delta = c.take<float>((size_t)N * H * Qt);
+    b.bytes = c.used;
+    return b;
+}
+
+int check_layer(const MpfDecoderLayer* L, const char* who)
+{
+    if (!L) return mpf::fail(MPF_E_NULL, who);
+    if (L->Qt <= 0 || L->N <= 0 || L->S <= 0 || L->ffn_dim <= 0 || L->H * 32 != kE || L->ffn_dim % 32)
+        return mpf::fail(MPF_E_SHAPE, "decoder_layer: needs H * 32 == 256 channels, positive sizes, ffn_dim % 32 == 0");
+    const void* need[] = {L->ca_wq, L->ca_bq, L->ca_wo, L->ca_bo, L->ca_gamma, L->ca_beta, L->sa_wq, L->sa_bq, L->sa_wk, L->sa_bk,
+                          L->sa_wv, L->sa_bv, L->sa_wo, L->sa_bo, L->sa_gamma, L->sa_beta, L->ff_w1, L->ff_b1, L->ff_w2, L->ff_b2,
+                          L->ff_gamma, L->ff_beta, L->x0, L->xb0, L->k_c, L->v_c, L->mask_c, L->q_c, L->kT_c, L->o_c, L->lse_c,
+                          L->s1, L->mean1, L->rstd1, L->xb1, L->q_s, L->k_s, L->v_s, L->kT_s, L->o_s, L->lse_s, L->s2, L->mean2,
+                          L->rstd2, L->xb2, L->h, L->s3, L->mean3, L->rstd3, L->scratch, L->attn_ws};
+    for (const void* q : need)
+        if (!q) return mpf::fail(MPF_E_NULL, "decoder_layer: NULL buffer in MpfDecoderLayer");
+    return 0;
+}
+
+// y[R, J] = x[R, Kc] . w[J, Kc]^T + b (ReLU)
+int lin_fwd(const void* x, const void* w, const void* b, void* y, int R, int J, int Kc, int relu, void* st)
+{
+    return mpf_small_gemm_bf16(x, Kc, 1, nullptr, w, Kc, 1, b, nullptr, 0, y, J, nullptr, R, J, Kc, relu, st);
+}
+
+// dx[R, Kin] = (dy[R, J] gated) . w[J, Kin] (+ acc)
+int lin_dx(const void* dy, const void* gate, const void* w, const void* acc, void* dx, int R, int J, int Kin, void* st)
+{
+    return mpf_small_gemm_bf16(dy, J, 1, gate, w, 1, Kin, nullptr, acc, Kin, dx, Kin, nullptr, R, Kin, J, 0, st);
+}
+
+// dw[J, Kin] = (dy gated)^T . x[R, Kin];  db[J] = column sums of (dy gated)
+int lin_dw(const void* dy, const void* gate, const void* x, void* dw, void* db, int R, int J, int Kin, void* st)
+{
+    return mpf_small_gemm_bf16(dy, 1, J, gate, x, 1, Kin, nullptr, nullptr, 0, dw, Kin, db, J, Kin, R, 0, st);
+}
+
+}  // namespace
+
+#define MPF_TRY(expr)                \
+    do {                             \
+        const int rc_ = (expr);      \
+        if (rc_ != 0) return rc_;    \
+    } while (0)
+
+extern "C" uint64_t mpf_decoder_layer_struct_bytes(int which)
+{
+    return which == 0 ? sizeof(MpfDecoderLayer) : sizeof(MpfDecoderLayerGrad);
+}
+
+extern "C" uint64_t mpf_decoder_layer_scratch_bytes(int Qt, int N, int H, int S, int ffn_dim, int backward)
+{
+    if (Qt <= 0 || N <= 0 || H <= 0 || S <= 0 || ffn_dim <= 0) return 0;
+    return backward ? bwd_scratch(nullptr, Qt, N, H, ffn_dim).bytes : fwd_scratch(nullptr, Qt, N, S).bytes;
+}
+
+extern "C" int mpf_decoder_layer_forward(const MpfDecoderLayer* L, void* st)
+{
+    MPF_TRY(check_layer(L, "decoder_layer_forward: NULL layer"));
+    if (!L->x3 && !L->xb3) return mpf::fail(MPF_E_NULL, "decoder_layer_forward: no output buffer");
+    const int Qt = L->Qt, N = L->N, H = L->H, S = L->S, F = L->ffn_dim, R = Qt * N;
+    if (L->scratch_bytes < fwd_scratch(nullptr, Qt, N, S).bytes)
+        return mpf::fail(MPF_E_SHAPE, "decoder_layer_forward: scratch too small");
+    const FwdScratch f = fwd_scratch(L->scratch, Qt, N, S);
+    const float scale = 0.17677669529663687f;       // 1 / sqrt(32)
+    // cross-attention (:1784-1789) + post-norm
+    MPF_TRY(lin_fwd(L->xb0, L->ca_wq, L->ca_bq, L->q_c, R, kE, kE, 0, st));
+    MPF_TRY(mpf_attn_transpose2(L->k_c, L->v_c, L->kT_c, f.vT_c, S, S, N, kE, st));
+    MPF_TRY(mpf_attn_forward(L->q_c, L->k_c, f.vT_c, L->mask_c, 1, L->o_c, L->lse_c, Qt, S, N, H, 32, scale, L->attn_ws,
+                             L->attn_ws_bytes, st));
+    MPF_TRY(lin_fwd(L->o_c, L->ca_wo, L->ca_bo, f.t, R, kE, kE, 0, st));
+    MPF_TRY(mpf_res_ln256_forward(L->x0, f.t, MPF_BF16, L->ca_gamma, L->ca_beta, L->s1, f.x1, L->xb1, L->mean1, L->rstd1, R,
+                                  L->eps, nullptr, 0, nullptr, st));
+    // self-attention (:1791-1795) + post-norm
+    MPF_TRY(lin_fwd(L->xb1, L->sa_wq, L->sa_bq, L->q_s, R, kE, kE, 0, st));
+    MPF_TRY(lin_fwd(L->xb1, L->sa_wk, L->sa_bk, L->k_s, R, kE, kE, 0, st));
+    MPF_TRY(lin_fwd(L->xb1, L->sa_wv, L->sa_bv, L->v_s, R, kE, kE, 0, st));
+    MPF_TRY(mpf_attn_transpose2(L->k_s, L->v_s, L->kT_s, f.vT_s, Qt, Qt, N, kE, st));
+    MPF_TRY(mpf_attn_forward(L->q_s, L->k_s, f.vT_s, L->mask_s, 0, L->o_s, L->lse_s, Qt, Qt, N, H, 32, scale, L->attn_ws,
+                             L->attn_ws_bytes, st));
+    MPF_TRY(lin_fwd(L->o_s, L->sa_wo, L->sa_bo, f.t, R, kE, kE, 0, st));
+    MPF_TRY(mpf_res_ln256_forward(f.x1, f.t, MPF_BF16, L->sa_gamma, L->sa_beta, L->s2, f.x2, L->xb2, L->mean2, L->rstd2, R,
+                                  L->eps, nullptr, 0, nullptr, st));
+    // FFN (:1798-1800) + post-norm
+    MPF_TRY(lin_fwd(L->xb2, L->ff_w1, L->ff_b1, L->h, R, F, kE, 1, st));
+    MPF_TRY(lin_fwd(L->h, L->ff_w2, L->ff_b2, f.t, R, kE, F, 0, st));
+    MPF_TRY(mpf_res_ln256_forward(f.x2, f.t, MPF_BF16, L->ff_gamma, L->ff_beta, L->s3, L->x3, L->xb3, L->mean3, L->rstd3, R,
+                                  L->eps, nullptr, 0, nullptr, st));
+    return 0;
+}
+
+extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDecoderLayerGrad* G, void* st)
+{
+    MPF_TRY(check_layer(L, "decoder_layer_backward: NULL layer"));
+    if (!G) return mpf::fail(MPF_E_NULL, "decoder_layer_backward: NULL grad");
+    if (!G->g_x3 && !G->g_xb3) return mpf::fail(MPF_E_NULL, "decoder_layer_backward: no upstream gradient");
+    const void* need[] = {G->d_x0, G->d_xb0, G->d_k_c, G->d_v_c, G->d_ca_wq, G->d_ca_bq, G->d_ca_wo, G->d_ca_bo, G->d_sa_wq, G->d_sa_bq,
+                          G->d_sa_wk, G->d_sa_bk, G->d_sa_wv, G->d_sa_bv, G->d_sa_wo, G->d_sa_bo, G->d_ff_w1, G->d_ff_b1, G->d_ff_w2,
+                          G->d_ff_b2, G->d_ln};
+    for (const void* q : need)
+        if (!q) return mpf::fail(MPF_E_NULL, "decoder_layer_backward: NULL buffer in MpfDecoderLayerGrad");
+    const int Qt = L->Qt, N = L->N, H = L->H, S = L->S, F = L->ffn_dim, R = Qt * N;
+    const int LqP = (Qt + 31) / 32 * 32;
+    if (L->scratch_bytes < bwd_scratch(nullptr, Qt, N, H, F).bytes)
+        return mpf::fail(MPF_E_SHAPE, "decoder_layer_backward: scratch too small");
+    const BwdScratch b = bwd_scratch(L->scratch, Qt, N, H, F);
+    const float scale = 0.17677669529663687f;
+    float* dln = G->d_ln;
+    MPF_TRY(mpf::check(hipMemsetAsync(dln, 0, 6 * kE * sizeof(float), (hipStream_t)st), "decoder_layer_backward memset"));
+    // FFN block: x3 = LN(x2 + W2 relu(W1 xb2))
+    MPF_TRY(mpf_res_ln256_backward(L->s3, L->mean3, L->rstd3, L->ff_gamma, G->g_x3, G->g_xb3, nullptr, b.ds_a, b.dt, dln + 4 * kE,
+                                   dln + 5 * kE, R, st));
+    MPF_TRY(lin_dx(b.dt, nullptr, L->ff_w2, nullptr, b.dh, R, kE, F, st));
+    MPF_TRY(lin_dw(b.dt, nullptr, L->h, G->d_ff_w2, G->d_ff_b2, R, kE, F, st));
+    MPF_TRY(lin_dx(b.dh, L->h, L->ff_w1, nullptr, b.dxb, R, F, kE, st));
+    MPF_TRY(lin_dw(b.dh, L->h, L->xb2, G->d_ff_w1, G->d_ff_b1, R, F, kE, st));
+    // self-attention block: x2 = LN(x1 + Wo attn(Wq xb1, Wk xb1, Wv xb1))
+    MPF_TRY(mpf_res_ln256_backward(L->s2, L->mean2, L->rstd2, L->sa_gamma, b.ds_a, b.dxb, nullptr, b.ds_b, b.dt, dln + 2 * kE,
+                                   dln + 3 * kE, R, st));
+    MPF_TRY(lin_dx(b.dt, nullptr, L->sa_wo, nullptr, b.dout, R, kE, kE, st));
+    MPF_TRY(lin_dw(b.dt, nullptr, L->o_s, G->d_sa_wo, G->d_sa_bo, R, kE, kE, st));
+    MPF_TRY(mpf_attn_delta(b.dout, L->o_s, b.delta, Qt, N, H, st));
+    MPF_TRY(mpf_attn_transpose2(L->q_s, b.dout, b.qT, b.doT, Qt, LqP, N, kE, st));
+    MPF_TRY(mpf_attn_backward(L->q_s, L->k_s, L->v_s, L->kT_s, b.qT, b.dout, b.doT, L->mask_s, 0, L->lse_s, b.delta, b.dq, b.dk_s,
+                              b.dv_s, Qt, LqP, Qt, N, H, 32, scale, L->attn_ws, L->attn_ws_bytes, st));
+    MPF_TRY(lin_dx(b.dq, nullptr, L->sa_wq, nullptr, b.dxb, R, kE, kE, st));
+    MPF_TRY(lin_dx(b.dk_s, nullptr, L->sa_wk, b.dxb, b.dxb, R, kE, kE, st));
+    MPF_TRY(lin_dx(b.dv_s, nullptr, L->sa_wv, b.dxb, b.dxb, R, kE, kE, st));
+    MPF_TRY(lin_dw(b.dq, nullptr, L->xb1, G->d_sa_wq, G->d_sa_bq, R, kE, kE, st));
+    MPF_TRY(lin_dw(b.dk_s, nullptr, L->xb1, G->d_sa_wk, G->d_sa_bk, R, kE, kE, st));
+    MPF_TRY(lin_dw(b.dv_s, nullptr, L->xb1, G->d_sa_wv, G->d_sa_bv, R, kE, kE, st));
+    // cross-attention block: x1 = LN(x0 + Wo attn(Wq xb0, k_c, v_c))
+    MPF_TRY(mpf_res_ln256_backward(L->s1, L->mean1, L->rstd1, L->ca_gamma, b.ds_b, b.dxb, nullptr, G->d_x0, b.dt, dln, dln + kE, R, st));
+    MPF_TRY(lin_dx(b.dt, nullptr, L->ca_wo, nullptr, b.dout, R, kE, kE, st));
+    MPF_TRY(lin_dw(b.dt, nullptr, L->o_c, G->d_ca_wo, G->d_ca_bo, R, kE, kE, st));
+    MPF_TRY(mpf_attn_delta(b.dout, L->o_c, b.delta, Qt, N, H, st));
+    MPF_TRY(mpf_attn_transpose2(L->q_c, b.dout, b.qT, b.doT, Qt, LqP, N, kE, st));
+    MPF_TRY(mpf_attn_backward(L->q_c, L->k_c, L->v_c, L->kT_c, b.qT, b.dout, b.doT, L->mask_c, 1, L->lse_c, b.delta, b.dq, G->d_k_c,
+                              G->d_v_c, Qt, LqP, S, N, H, 32, scale, L->attn_ws, L->attn_ws_bytes, st));
+    MPF_TRY(lin_dx(b.dq, nullptr, L->ca_wq, nullptr, G->d_xb0, R, kE, kE, st));
+    MPF_TRY(lin_dw(b.dq, nullptr, L->xb0, G->d_ca_wq, G->d_ca_bq, R, kE, kE, st));
+    return 0;
+}

@@ -8,7 +8,7 @@
 // waves and feeds v_mfma_f32_16x16x32_bf16 straight from global memory (the operands are L2 resident),
 // so a 228x256x256 problem is 240 blocks of 4 waves x 2 MFMA steps.
 //
-//   C[i][j] = sum_k A(i,k) * B(j,k) (+ bias[j]) (ReLU),   i < I, j < J, k < Kc,   fp32 accumulation
+//   C[i][j] = sum_k A(i,k) * B(j,k) (+ bias[j]) (+ Cin[i][j]) (ReLU),   i < I, j < J, k < Kc,   fp32 accumulation
 //
 // Each operand is addressed through (row stride, contraction stride), one of which must be 1:
 //   contraction-contiguous: a lane's 8 consecutive k are one 16-B load         (x, W in the forward)
@@ -33,9 +33,10 @@ struct SG {
     const u16* gate;
     const u16* b;
     const u16* bias;
+    const u16* cin;
     u16* c;
     u16* rowsum;
-    int64_t a_rs, a_ks, b_rs, b_ks, ldc;
+    int64_t a_rs, a_ks, b_rs, b_ks, ldc, ldcin;
     int I, J, Kc, relu, n_it, n_waves;
 };
 
@@ -174,6 +175,13 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SG p)
             v[2] += __uint_as_float(bb.y << 16);
             v[3] += __uint_as_float(bb.y & 0xffff0000u);
         }
+        if (p.cin) {
+            const uint2 cc = *reinterpret_cast<const uint2*>(p.cin + (int64_t)i * p.ldcin + j);
+            v[0] += __uint_as_float(cc.x << 16);
+            v[1] += __uint_as_float(cc.x & 0xffff0000u);
+            v[2] += __uint_as_float(cc.y << 16);
+            v[3] += __uint_as_float(cc.y & 0xffff0000u);
+        }
         if (p.relu) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -215,8 +223,8 @@ void launch(const SG& p, bool ac, bool bc, int blocks, hipStream_t st)
 }  // namespace
 
 extern "C" int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, const void* gate, const void* b,
-                                   int64_t b_rs, int64_t b_ks, const void* bias, void* c, int64_t ldc, void* rowsum_a,
-                                   int I, int J, int Kc, int relu, void* stream)
+                                   int64_t b_rs, int64_t b_ks, const void* bias, const void* c_in, int64_t ldcin, void* c,
+                                   int64_t ldc, void* rowsum_a, int I, int J, int Kc, int relu, void* stream)
 {
     if (I < 0 || J < 0 || Kc < 0) return mpf::fail(MPF_E_SHAPE, "small_gemm: negative size");
     if (I == 0 || J == 0) return 0;
@@ -228,13 +236,16 @@ extern "C" int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, co
     if ((ac && (Kc % 8 || a_rs % 8 || ((uintptr_t)a & 15) || (gate && ((uintptr_t)gate & 15)))) ||
         (bc && (Kc % 8 || b_rs % 8 || ((uintptr_t)b & 15))))
         return mpf::fail(MPF_E_SHAPE, "small_gemm: contraction-contiguous operands need 16-B aligned rows, Kc % 8 == 0");
-    if (J % 4 || ldc % 4 || ((uintptr_t)c & 7) || (bias && ((uintptr_t)bias & 7)))
+    if (J % 4 || ldc % 4 || ((uintptr_t)c & 7) || (bias && ((uintptr_t)bias & 7)) ||
+        (c_in && (ldcin % 4 || ((uintptr_t)c_in & 7))))
         return mpf::fail(MPF_E_SHAPE, "small_gemm: J and ldc must be multiples of 4 (8-B stores)");
     SG p;
     p.a = static_cast<const u16*>(a);
     p.gate = static_cast<const u16*>(gate);
     p.b = static_cast<const u16*>(b);
     p.bias = static_cast<const u16*>(bias);
+    p.cin = static_cast<const u16*>(c_in);
+    p.ldcin = ldcin;
     p.c = static_cast<u16*>(c);
     p.rowsum = static_cast<u16*>(rowsum_a);
     p.a_rs = a_rs; p.a_ks = a_ks; p.b_rs = b_rs; p.b_ks = b_ks; p.ldc = ldc;

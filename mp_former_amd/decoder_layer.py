@@ -1,0 +1,178 @@
+"""One masked-attention decoder layer (cross-attention, self-attention, FFN, post-norm residuals) as ONE
+autograd node whose forward / backward are single native calls (csrc/decoder_layer.hip;
+include/mpformer_hip.h MpfDecoderLayer).  Reference: mask2former_transformer_decoder.py:1784-1800.
+
+Same kernels and rounding points as the op-by-op path of transformer_decoder.py (small_linear, attention
+core, res_ln) — what changes is who issues them: ~20 / ~45 launches per layer from C++ instead of one
+Python autograd node per launch, which left the GPU idle for most of the decoder.  bf16 autocast, 256
+channels, 8 heads, GPU only; the caller projects the cross-attention keys / values (library GEMMs).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .attention import _workspace as _attn_workspace
+
+_vp, _u64, _i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32
+
+PARAM_NAMES = ("ca_wq", "ca_bq", "ca_wo", "ca_bo", "ca_gamma", "ca_beta",
+               "sa_wq", "sa_bq", "sa_wk", "sa_bk", "sa_wv", "sa_bv", "sa_wo", "sa_bo", "sa_gamma", "sa_beta",
+               "ff_w1", "ff_b1", "ff_w2", "ff_b2", "ff_gamma", "ff_beta")
+_LN = ("ca_gamma", "ca_beta", "sa_gamma", "sa_beta", "ff_gamma", "ff_beta")
+_SAVED = ("q_c", "kT_c", "o_c", "lse_c", "s1", "mean1", "rstd1", "xb1", "q_s", "k_s", "v_s", "kT_s", "o_s", "lse_s",
+          "s2", "mean2", "rstd2", "xb2", "h", "s3", "mean3", "rstd3")
+
+
+class MpfDecoderLayer(ctypes.Structure):
+    _fields_ = ([(n, _vp) for n in PARAM_NAMES] + [(n, _vp) for n in ("x0", "xb0", "k_c", "v_c", "mask_c", "mask_s")]
+                + [(n, _vp) for n in _SAVED] + [("x3", _vp), ("xb3", _vp), ("scratch", _vp), ("attn_ws", _vp),
+                                                ("scratch_bytes", _u64), ("attn_ws_bytes", _u64)]
+                + [(n, _i32) for n in ("Qt", "N", "H", "S", "ffn_dim")] + [("eps", ctypes.c_float)])
+
+
+_WGRADS = tuple("d_" + n for n in PARAM_NAMES if n not in _LN)
+
+
+class MpfDecoderLayerGrad(ctypes.Structure):
+    _fields_ = ([(n, _vp) for n in ("g_x3", "g_xb3", "d_x0", "d_xb0", "d_k_c", "d_v_c")] + [(n, _vp) for n in _WGRADS]
+                + [("d_ln", _vp)])
+
+
+_checked = False
+_scratch = {}
+
+
+def _lib_checked():
+    global _checked
+    lib = _lib.lib()
+    if not _checked:
+        if (lib.mpf_decoder_layer_struct_bytes(0) != ctypes.sizeof(MpfDecoderLayer)
+                or lib.mpf_decoder_layer_struct_bytes(1) != ctypes.sizeof(MpfDecoderLayerGrad)):
+            raise RuntimeError("MpfDecoderLayer layout differs between decoder_layer.py and libmpformer_hip.so")
+        _checked = True
+    return lib
+
+
+def _scratch_buf(device, nbytes):
+    w = _scratch.get(device)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _scratch[device] = w
+    return w
+
+
+def _al(n):
+    return (n + 255) & ~255
+
+
+class DecoderLayerFn(Function):
+    @staticmethod
+    def forward(ctx, x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, *params):
+        lib = _lib_checked()
+        Qt, N, E = x0.shape
+        S = k_c.shape[0]
+        F_ = params[16].shape[0]
+        R = Qt * N
+        dev = x0.device
+        assert E == 256 and nheads * 32 == E and len(params) == len(PARAM_NAMES)
+        assert x0.dtype == torch.float32 and x0.is_contiguous() and xb0.dtype == torch.bfloat16 and xb0.is_contiguous()
+        assert k_c.dtype == torch.bfloat16 and k_c.is_contiguous() and v_c.is_contiguous() and k_c.shape == v_c.shape == (S, N, E)
+        assert mask_c.dtype == torch.bool and mask_c.is_contiguous() and mask_c.shape == (N, Qt, S)
+        if mask_s is not None:
+            assert mask_s.dtype == torch.bool and mask_s.shape == (Qt, Qt)
+            mask_s = mask_s.contiguous()
+        params = tuple(p if p.is_contiguous() else p.contiguous() for p in params)
+        for n, p in zip(PARAM_NAMES, params):
+            assert p.dtype == (torch.float32 if n in _LN else torch.bfloat16), n
+        # one arena for everything the backward reads
+        sizes = {"q_c": R * E * 2, "kT_c": N * E * S * 2, "o_c": R * E * 2, "lse_c": N * nheads * Qt * 4,
+                 "s1": R * E * 4, "mean1": R * 4, "rstd1": R * 4, "xb1": R * E * 2,
+                 "q_s": R * E * 2, "k_s": R * E * 2, "v_s": R * E * 2, "kT_s": N * E * Qt * 2, "o_s": R * E * 2,
+                 "lse_s": N * nheads * Qt * 4, "s2": R * E * 4, "mean2": R * 4, "rstd2": R * 4, "xb2": R * E * 2,
+                 "h": R * F_ * 2, "s3": R * E * 4, "mean3": R * 4, "rstd3": R * 4}
+        total = sum(_al(v) for v in sizes.values())
+        arena = torch.empty(total, dtype=torch.uint8, device=dev)
+        x3 = torch.empty_like(x0)
+        xb3 = torch.empty_like(xb0)
+        L = MpfDecoderLayer()
+        base = arena.data_ptr()
+        for n in _SAVED:
+            setattr(L, n, base)
+            base += _al(sizes[n])
+        for n, p in zip(PARAM_NAMES, params):
+            setattr(L, n, p.data_ptr())
+        L.x0, L.xb0, L.k_c, L.v_c = x0.data_ptr(), xb0.data_ptr(), k_c.data_ptr(), v_c.data_ptr()
+        L.mask_c = mask_c.data_ptr()
+        L.mask_s = mask_s.data_ptr() if mask_s is not None else None
+        L.x3, L.xb3 = x3.data_ptr(), xb3.data_ptr()
+        L.Qt, L.N, L.H, L.S, L.ffn_dim, L.eps = Qt, N, nheads, S, F_, float(eps)
+        sc = _scratch_buf(dev, max(lib.mpf_decoder_layer_scratch_bytes(Qt, N, nheads, S, F_, 0),
+                                   lib.mpf_decoder_layer_scratch_bytes(Qt, N, nheads, S, F_, 1)))
+        ws = _attn_workspace(dev, max(lib.mpf_attn_workspace_bytes(Qt, S, N, nheads), lib.mpf_attn_workspace_bytes(Qt, Qt, N, nheads)))
+        L.scratch, L.scratch_bytes, L.attn_ws, L.attn_ws_bytes = sc.data_ptr(), sc.numel(), ws.data_ptr(), ws.numel()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            code = lib.mpf_decoder_layer_forward(ctypes.byref(L), stream)
+        _lib.check(code, "mpf_decoder_layer_forward")
+        ctx.save_for_backward(xb0, k_c, v_c, mask_c, mask_s, arena, *params)
+        ctx.layer = L
+        ctx.dims = (Qt, N, E, S, F_, nheads)
+        return x3, xb3
+
+    @staticmethod
+    def backward(ctx, g_x3, g_xb3):
+        lib = _lib_checked()
+        saved = ctx.saved_tensors
+        xb0, k_c = saved[0], saved[1]
+        params = saved[6:]
+        Qt, N, E, S, F_, H = ctx.dims
+        dev = xb0.device
+        L = ctx.layer
+        if g_x3 is not None:
+            g_x3 = g_x3.to(torch.float32).contiguous()
+        if g_xb3 is not None:
+            g_xb3 = g_xb3.to(torch.bfloat16).contiguous()
+        d_x0 = torch.empty((Qt, N, E), dtype=torch.float32, device=dev)
+        d_xb0 = torch.empty((Qt, N, E), dtype=torch.bfloat16, device=dev)
+        d_kv = torch.empty((2,) + tuple(k_c.shape), dtype=torch.bfloat16, device=dev)
+        wshapes = [p.shape for n, p in zip(PARAM_NAMES, params) if n not in _LN]
+        offs, tot = [], 0
+        for s_ in wshapes:
+            offs.append(tot)
+            tot += (s_.numel() + 127) & ~127
+        wg = torch.empty(tot, dtype=torch.bfloat16, device=dev)
+        d_ln = torch.empty((6, 256), dtype=torch.float32, device=dev)
+        G = MpfDecoderLayerGrad()
+        G.g_x3 = g_x3.data_ptr() if g_x3 is not None else None
+        G.g_xb3 = g_xb3.data_ptr() if g_xb3 is not None else None
+        G.d_x0, G.d_xb0, G.d_k_c, G.d_v_c = d_x0.data_ptr(), d_xb0.data_ptr(), d_kv[0].data_ptr(), d_kv[1].data_ptr()
+        wbase = wg.data_ptr()
+        for n, o in zip(_WGRADS, offs):
+            setattr(G, n, wbase + 2 * o)
+        G.d_ln = d_ln.data_ptr()
+        sc = _scratch_buf(dev, lib.mpf_decoder_layer_scratch_bytes(Qt, N, H, S, F_, 1))
+        ws = _attn_workspace(dev, max(lib.mpf_attn_workspace_bytes(Qt, S, N, H), lib.mpf_attn_workspace_bytes(Qt, Qt, N, H)))
+        L.scratch, L.scratch_bytes, L.attn_ws, L.attn_ws_bytes = sc.data_ptr(), sc.numel(), ws.data_ptr(), ws.numel()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            code = lib.mpf_decoder_layer_backward(ctypes.byref(L), ctypes.byref(G), stream)
+        _lib.check(code, "mpf_decoder_layer_backward")
+        grads, wi, li = [], 0, 0
+        for n in PARAM_NAMES:
+            if n in _LN:
+                grads.append(d_ln[li])
+                li += 1
+            else:
+                s_ = wshapes[wi]
+                grads.append(wg[offs[wi]:offs[wi] + s_.numel()].view(s_))
+                wi += 1
+        return (d_x0, d_xb0, d_kv[0], d_kv[1], None, None, None, None, *grads)
+
+
+def decoder_layer(x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, params):
+    """(x3 fp32, xb3 bf16) = one decoder layer; ``params``: the 22 tensors of PARAM_NAMES."""
+    if not x0.is_cuda:
+        raise RuntimeError("mp_former_amd decoder layer runs on the GPU only (no CPU fallback)")
+    return DecoderLayerFn.apply(x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, *params)

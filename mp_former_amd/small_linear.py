@@ -18,14 +18,15 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def small_gemm(a, a_rs, a_ks, b, b_rs, b_ks, I, J, Kc, bias=None, gate=None, relu=False, rowsum=False):
+def small_gemm(a, a_rs, a_ks, b, b_rs, b_ks, I, J, Kc, bias=None, gate=None, relu=False, rowsum=False, cin=None):
     """C[I, J] = sum_k A(i,k) B(j,k) (+bias) (ReLU) with explicit element strides; returns (C, rowsum_a or None)."""
     c = torch.empty((I, J), dtype=torch.bfloat16, device=a.device)
     rs = torch.empty((I,), dtype=torch.bfloat16, device=a.device) if rowsum else None
     with torch.cuda.device(a.device):
         code = _lib.lib().mpf_small_gemm_bf16(
             a.data_ptr(), a_rs, a_ks, gate.data_ptr() if gate is not None else None, b.data_ptr(), b_rs, b_ks,
-            bias.data_ptr() if bias is not None else None, c.data_ptr(), J, rs.data_ptr() if rowsum else None,
+            bias.data_ptr() if bias is not None else None, cin.data_ptr() if cin is not None else None,
+            cin.stride(0) if cin is not None else 0, c.data_ptr(), J, rs.data_ptr() if rowsum else None,
             I, J, Kc, 1 if relu else 0, _stream(a))
     _lib.check(code, "mpf_small_gemm_bf16")
     return c, rs

@@ -30,6 +30,7 @@ from ._h2d import upload
 from .attention import attention_core
 from .resln import res_ln
 from .small_linear import small_linear, usable as _small_ok
+from .decoder_layer import decoder_layer
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
 
 
@@ -404,6 +405,26 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         cls = cls.view(L, Qt, N, -1)
         return [cls[l].transpose(0, 1) for l in range(L)], [pm[:, l * Qt:(l + 1) * Qt] for l in range(L)]
 
+    def _layer_by_ops(self, W, i, level, output, xb, kin, src, attn_mask, tgt_mask, post_norm):
+        """One decoder layer, one autograd node per op (fp32 / non-AMP runs, and the reference the fused
+        layer is tested against)."""
+        H = self.num_heads
+        # cross-attention first (:1784-1789), post-norm
+        pre = f"transformer_cross_attention_layers.{i}.multihead_attn."
+        t2 = masked_mha_w(xb, kin[level], src[level], W[pre + "in_proj_weight"], W[pre + "in_proj_bias"],
+                          W[pre + "out_proj.weight"], W[pre + "out_proj.bias"], H, attn_mask)
+        output, xb = post_norm(self.transformer_cross_attention_layers[i].norm, output, t2)
+        # self-attention (:1791-1795)
+        pre = f"transformer_self_attention_layers.{i}.self_attn."
+        t2 = masked_mha_w(xb, xb, xb, W[pre + "in_proj_weight"], W[pre + "in_proj_bias"],
+                          W[pre + "out_proj.weight"], W[pre + "out_proj.bias"], H, tgt_mask)
+        output, xb = post_norm(self.transformer_self_attention_layers[i].norm, output, t2)
+        # FFN (:1798-1800)
+        pre = f"transformer_ffn_layers.{i}."
+        t2 = linear(linear(xb, W[pre + "linear1.weight"], W[pre + "linear1.bias"], relu=True),
+                    W[pre + "linear2.weight"], W[pre + "linear2.bias"])
+        return post_norm(self.transformer_ffn_layers[i].norm, output, t2)
+
     def forward(self, x, mask_features, mask=None, dn_args=None):
         assert len(x) == self.num_feature_levels
         del mask
@@ -453,23 +474,30 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             y32, y16 = res_ln(norm, x32, t2, want32=True, want16=amp)
             return y32, (y16 if amp else y32)
 
+        # bf16 autocast, 256 channels x 8 heads: the whole layer is one native call (decoder_layer.py)
+        fused = (amp and adt == torch.bfloat16 and output.shape[-1] == 256 and H == 8
+                 and isinstance(W["transformer_cross_attention_layers.0.multihead_attn.in_proj_weight"], tuple)
+                 and os.environ.get("MPF_FUSED_DECODER", "1") == "1")
         for i in range(self.num_layers):
             level = i % self.num_feature_levels
-            # cross-attention first (:1784-1789), post-norm
-            pre = f"transformer_cross_attention_layers.{i}.multihead_attn."
-            t2 = masked_mha_w(xb, kin[level], src[level], W[pre + "in_proj_weight"], W[pre + "in_proj_bias"],
-                              W[pre + "out_proj.weight"], W[pre + "out_proj.bias"], H, attn_mask)
-            output, xb = post_norm(self.transformer_cross_attention_layers[i].norm, output, t2)
-            # self-attention (:1791-1795)
-            pre = f"transformer_self_attention_layers.{i}.self_attn."
-            t2 = masked_mha_w(xb, xb, xb, W[pre + "in_proj_weight"], W[pre + "in_proj_bias"],
-                              W[pre + "out_proj.weight"], W[pre + "out_proj.bias"], H, tgt_mask)
-            output, xb = post_norm(self.transformer_self_attention_layers[i].norm, output, t2)
-            # FFN (:1798-1800)
-            pre = f"transformer_ffn_layers.{i}."
-            t2 = linear(linear(xb, W[pre + "linear1.weight"], W[pre + "linear1.bias"], relu=True),
-                        W[pre + "linear2.weight"], W[pre + "linear2.bias"])
-            output, xb = post_norm(self.transformer_ffn_layers[i].norm, output, t2)
+            if fused:
+                ca = f"transformer_cross_attention_layers.{i}.multihead_attn."
+                sa = f"transformer_self_attention_layers.{i}.self_attn."
+                ff = f"transformer_ffn_layers.{i}."
+                cw, cb = W[ca + "in_proj_weight"], W[ca + "in_proj_bias"]
+                sw, sb = W[sa + "in_proj_weight"], W[sa + "in_proj_bias"]
+                k_c = linear(kin[level], cw[1], cb[1])
+                v_c = linear(src[level], cw[2], cb[2])
+                n1, n2, n3 = (self.transformer_cross_attention_layers[i].norm, self.transformer_self_attention_layers[i].norm,
+                              self.transformer_ffn_layers[i].norm)
+                output, xb = decoder_layer(
+                    output, xb, k_c, v_c, attn_mask, tgt_mask, H, n1.eps,
+                    (cw[0], cb[0], W[ca + "out_proj.weight"], W[ca + "out_proj.bias"], n1.weight, n1.bias,
+                     sw[0], sb[0], sw[1], sb[1], sw[2], sb[2], W[sa + "out_proj.weight"], W[sa + "out_proj.bias"], n2.weight, n2.bias,
+                     W[ff + "linear1.weight"], W[ff + "linear1.bias"], W[ff + "linear2.weight"], W[ff + "linear2.bias"],
+                     n3.weight, n3.bias))
+            else:
+                output, xb = self._layer_by_ops(W, i, level, output, xb, kin, src, attn_mask, tgt_mask, post_norm)
             nxt = (i + 1) % self.num_feature_levels
             streams.append(output)
             if i + 1 < self.num_layers:

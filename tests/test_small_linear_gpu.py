@@ -92,7 +92,7 @@ def test_small_gemm_rejects_bad_strides():
     a = torch.zeros(16, 32, device=dev, dtype=torch.bfloat16)
     c = torch.zeros(16, 16, device=dev, dtype=torch.bfloat16)
     s = torch.cuda.current_stream().cuda_stream
-    code = _lib.lib().mpf_small_gemm_bf16(a.data_ptr(), 32, 2, None, a.data_ptr(), 32, 1, None, c.data_ptr(), 16, None, 16, 16, 32, 0, s)
-    assert code == _lib.MPF_E_SHAPE if hasattr(_lib, "MPF_E_SHAPE") else code < 0
-    code = _lib.lib().mpf_small_gemm_bf16(a.data_ptr(), 32, 1, None, a.data_ptr(), 32, 1, None, c.data_ptr(), 16, None, 16, 14, 32, 0, s)
+    code = _lib.lib().mpf_small_gemm_bf16(a.data_ptr(), 32, 2, None, a.data_ptr(), 32, 1, None, None, 0, c.data_ptr(), 16, None, 16, 16, 32, 0, s)
+    assert code == -2      # MPF_E_SHAPE
+    code = _lib.lib().mpf_small_gemm_bf16(a.data_ptr(), 32, 1, None, a.data_ptr(), 32, 1, None, None, 0, c.data_ptr(), 16, None, 16, 14, 32, 0, s)
     assert code < 0
