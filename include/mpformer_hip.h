@@ -318,6 +318,32 @@ int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, const void* g
                         void* rowsum_a, int I, int J, int Kc, int relu, void* stream);
 
 /*
+ * Linear sum assignment (the Hungarian step of HungarianMatcher.memory_efficient_forward, matcher.py:
+ * 149-151, where the reference calls scipy.optimize.linear_sum_assignment on a host copy of the cost
+ * matrix) solved on the device, one wavefront per problem, with SciPy's algorithm and tie-breaking
+ * (csrc/lsa.hip) — the matcher needs no device->host copy.  Problem p is the n_rows x n_cols fp32
+ * matrix at cost + cost_off (row stride row_stride); its min(n_rows, n_cols) assigned pairs (row, col)
+ * are reported in SciPy's order (ascending row) at slots out_pos, out_pos + 1, ...:
+ *   row_out[slot] = row           col_out[slot] = col_base + col
+ *   aff_a[slot]   = a_base + row * a_stride        aff_b[slot] = b_base + row * b_stride
+ *   scatter_dst[scatter_base + row] = scatter_src[col_base + col]
+ * (any output pointer may be NULL).  The affine / scatter outputs are the index arrays of the loss
+ * kernels: element offsets of the matched prediction planes, and the class target of a matched query.
+ * max_dim = max over problems of max(n_rows, n_cols) (<= 512); max_entries = max n_rows * n_cols.
+ * An infeasible problem (no finite assignment; SciPy raises) leaves its slots untouched.
+ */
+typedef struct MpfLsaProblem {
+    int64_t cost_off, n_rows, n_cols, row_stride;
+    int64_t out_pos, col_base;
+    int64_t a_base, a_stride, b_base, b_stride;
+    int64_t scatter_base;
+} MpfLsaProblem;
+
+int mpf_lsa_assign(const float* cost, const MpfLsaProblem* problems, int n_problems, int max_dim, int64_t max_entries,
+                   int32_t* row_out, int32_t* col_out, int64_t* aff_a, int64_t* aff_b, int64_t* scatter_dst,
+                   const int64_t* scatter_src, void* stream);
+
+/*
  * One decoder layer of the masked-attention transformer decoder — cross-attention, self-attention, FFN,
  * each followed by its post-norm residual (mask2former_transformer_decoder.py:1784-1800 with
  * CrossAttentionLayer.forward_post :100-112, SelfAttentionLayer.forward_post :42-52, FFNLayer.forward_post

@@ -7,12 +7,16 @@ Scheduling (results identical for identical random draws): the reference walks t
 by one — matcher, CE, point-sampled BCE/dice, then the same for the MP (`_dn`) queries — with a
 blocking `.cpu()` per image per output (matcher.py:149) and ~100 small kernels per output.  Here a
 step is three batched stages over ALL outputs at once:
-  1. matching: native GT sampling + native mask/dice cost + one D2H copy + SciPy (matcher.py);
+  1. matching: native GT sampling + native mask/dice cost + the native device solver (lsa.py: SciPy's
+     algorithm, one wavefront per problem) — the step has NO device->host copy; MPF_DEVICE_LSA=0 takes
+     the reference's route instead (one D2H copy + SciPy, matcher.py);
   2. mask losses: one importance-sampling pass (native sampling + native radix selection) and one
      fused native BCE/dice kernel over every matched / MP (prediction, target) pair of every output;
      its backward is one scatter kernel;
   3. class losses: one batched log-softmax over all outputs.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -22,6 +26,7 @@ from . import _rng
 from .dist import global_num_masks
 from .matcher import GTMasks
 from ._h2d import upload
+from .lsa import MAX_DIM as LSA_MAX_DIM, lsa_assign
 from .point_sample import MapSet, MaskLossSums, sample_select_uncertain
 
 
@@ -112,28 +117,53 @@ class SetCriterion(nn.Module):
         ms = MapSet(map_tensors)
 
         # ---- stage 1: all matchings -----------------------------------------------------------------
-        indices = self.matcher.match_many(outs, targets, gt=gt, tags=["match" + s for s in suffixes],
-                                          mapset=ms, map_index=list(range(L)))
+        # device solver (csrc/lsa.hip): the matched query / target of every pair stays on the GPU and the
+        # step has no device->host copy; MPF_DEVICE_LSA=0 (or a problem larger than the kernel takes)
+        # selects the reference's route: cost matrices to the host, SciPy, indices back up.
+        tags = ["match" + s for s in suffixes]
+        dev_lsa = (os.environ.get("MPF_DEVICE_LSA", "1") == "1" and max(Q, gt.tmax) <= LSA_MAX_DIM)
+        firsts = gt.offsets
+        if dev_lsa:
+            C = self.matcher.cost_matrices(outs, targets, gt=gt, tags=tags, mapset=ms, map_index=list(range(L)))
+            indices = None
+        else:
+            indices = self.matcher.match_many(outs, targets, gt=gt, tags=tags, mapset=ms, map_index=list(range(L)))
 
         # ---- pair lists (host): order = for each output: matched pairs, then MP pairs ----------------
-        firsts = gt.offsets
         ti, bi, qi, gr, gid, over_parts, rand_parts = [], [], [], [], [], [], []
         num_uncertain = int(self.importance_sample_ratio * P)
         num_sampled = int(P * self.oversample_ratio)
-        tc_main = np.full((L, N, Q), K, dtype=np.int64)
-        if gt.total:   # one D2H copy for all labels (the stream was just drained by the matcher's copy)
-            lab = torch.cat([t["labels"] for t in targets]).cpu().numpy()
-            labels_host = [lab[firsts[b]:firsts[b + 1]] for b in range(N)]
+        logits_main, order_main = strided_stack([o["pred_logits"] for o in outs])
+        slot_of_output = {l: i for i, l in enumerate(order_main)}       # row of output l in logits_main
+        problems = []                                                    # device solver: one row per (output, image)
+        n_pos = 0
+        if dev_lsa:
+            labels_dev = torch.cat([t["labels"] for t in targets]) if gt.total else None
+            Tmax = gt.tmax
         else:
-            labels_host = [np.zeros(0, np.int64)] * N
+            tc_main = np.full((L, N, Q), K, dtype=np.int64)
+            if gt.total:   # one D2H copy for all labels (the stream was just drained by the matcher's copy)
+                lab = torch.cat([t["labels"] for t in targets]).cpu().numpy()
+                labels_host = [lab[firsts[b]:firsts[b + 1]] for b in range(N)]
+            else:
+                labels_host = [np.zeros(0, np.int64)] * N
         for l in range(L):
             n_l = 0
-            for b, (src, tgt) in enumerate(indices[l]):
-                src, tgt = src.numpy(), tgt.numpy()
+            for b in range(N):
+                if dev_lsa:
+                    k = min(Q, gt.counts[b])
+                    if k:
+                        problems.append([(l * N + b) * Q * Tmax, Q, gt.counts[b], Tmax, n_pos, firsts[b],
+                                         0, 0, 0, 0, (slot_of_output[l] * N + b) * Q])
+                    src = np.zeros(k, np.int64)      # filled in on the device
+                    tgt = np.zeros(k, np.int64)
+                else:
+                    src, tgt = (x.numpy() for x in indices[l][b])
+                    tc_main[l, b, src] = labels_host[b][tgt]
                 ti.append(np.full(len(src), l)); bi.append(np.full(len(src), b)); qi.append(src)
                 gr.append(firsts[b] + tgt); gid.append(np.full(len(src), l))
-                tc_main[l, b, src] = labels_host[b][tgt]
                 n_l += len(src)
+                n_pos += len(src)
             over_parts.append(("loss" + suffixes[l] + "_over", (n_l, num_sampled, 2)))
             rand_parts.append(("loss" + suffixes[l] + "_rand", (n_l, P - num_uncertain, 2)))
             if use_dn:
@@ -145,6 +175,7 @@ class SetCriterion(nn.Module):
                     ti.append(np.full(len(j), L + l)); bi.append(np.full(len(j), b)); qi.append(slot)
                     gr.append(firsts[b] + j); gid.append(np.full(len(j), L + l))
                     n_d += len(j)
+                n_pos += n_d
                 over_parts.append(("loss_dn" + suffixes[l] + "_over", (n_d, num_sampled, 2)))
                 rand_parts.append(("loss_dn" + suffixes[l] + "_rand", (n_d, P - num_uncertain, 2)))
         cat = lambda xs: np.concatenate(xs).astype(np.int64) if xs else np.zeros(0, np.int64)  # noqa: E731
@@ -153,14 +184,29 @@ class SetCriterion(nn.Module):
         G = 2 * L if use_dn else L
         losses = LossDict()
 
+        # ---- index arrays of the pairs -> device (one upload each); the solver fills the matched slots ----
+        tc_main_d = torch.full((L, N, Q), K, dtype=torch.int64, device=dev) if dev_lsa else None
+        if n_pairs:
+            g_offs = ms.grad_offsets(ti, bi, qi)
+            p_offs = ms.offsets(ti, bi, qi)
+            if not dev_lsa:
+                assert len(np.unique(g_offs)) == n_pairs, "a prediction plane is paired twice in one step"
+            up = upload(np.concatenate([p_offs, g_offs, gid]), dev)
+            pred_offs, grad_offs, gid_d = up[:n_pairs], up[n_pairs:2 * n_pairs], up[2 * n_pairs:]
+            gt_rows = upload(gr.astype(np.int32), dev)
+            if dev_lsa and problems:
+                # matched slots: the offsets of query 0 were uploaded; the solver writes base + q * stride,
+                # the ground-truth row, and the class target of the matched query
+                pr = np.asarray(problems, dtype=np.int64)
+                pos = pr[:, 4]
+                pr[:, 6], pr[:, 7] = p_offs[pos], ms.s1[ms.base_of[ti[pos]]]
+                pr[:, 8], pr[:, 9] = g_offs[pos], ms.h * ms.w
+                lsa_assign(C, pr, n_pairs, want_rows=False, scatter_dst=tc_main_d, scatter_src=labels_dev,
+                           into={"cols": gt_rows, "a": pred_offs, "b": grad_offs})
+
         # ---- stage 2: mask losses ----------------------------------------------------------------------
         if "masks" in self.losses:
             if n_pairs:
-                g_offs = ms.grad_offsets(ti, bi, qi)
-                assert len(np.unique(g_offs)) == n_pairs, "a prediction plane is paired twice in one step"
-                up = upload(np.concatenate([ms.offsets(ti, bi, qi), g_offs, gid]), dev)
-                pred_offs, grad_offs, gid_d = up[:n_pairs], up[n_pairs:2 * n_pairs], up[2 * n_pairs:]
-                gt_rows = upload(gr.astype(np.int32), dev)
                 with torch.no_grad():   # criterion.py:162-176: point selection carries no gradient
                     coords_over = _rng.rand_cat(over_parts, dev)
                     coords = sample_select_uncertain(ms, pred_offs, coords_over, num_uncertain, P)
@@ -188,17 +234,31 @@ class SetCriterion(nn.Module):
 
         # ---- stage 3: class losses ---------------------------------------------------------------------
         if "labels" in self.losses:
-            logits, order = strided_stack([o["pred_logits"] for o in outs])
-            ce = self._class_losses(logits, upload(tc_main[order], dev))
-            losses.add_group(["loss_ce" + suffixes[i] for i in order], ce)
+            if dev_lsa:
+                tc_d = tc_main_d                                     # already in the row order of logits_main
+            else:
+                tc_d = upload(tc_main[order_main], dev)
+            ce = self._class_losses(logits_main, tc_d)
+            losses.add_group(["loss_ce" + suffixes[i] for i in order_main], ce)
             if use_dn:
-                tc_dn = np.full((N, pad), K, dtype=np.int64)     # criterion.py:249-258: slot j of every group <-> GT j
-                for b in range(N):
-                    T = gt.counts[b]
-                    for s in range(scalar):
-                        tc_dn[b, s * max_num:s * max_num + T] = labels_host[b]
+                # criterion.py:249-258: slot j of every group <-> GT j
+                if dev_lsa:
+                    tc_dn_d = torch.full((N * pad,), K, dtype=torch.int64, device=dev)
+                    if gt.total:
+                        dst = np.concatenate([b * pad + s * max_num + np.arange(gt.counts[b]) for b in range(N) for s in range(scalar)])
+                        srcp = np.concatenate([firsts[b] + np.arange(gt.counts[b]) for b in range(N) for s in range(scalar)])
+                        ix = upload(np.concatenate([dst, srcp]).astype(np.int64), dev)
+                        tc_dn_d[ix[:len(dst)]] = labels_dev[ix[len(dst):]]
+                    tc_dn_d = tc_dn_d.view(N, pad)
+                else:
+                    tc_dn = np.full((N, pad), K, dtype=np.int64)
+                    for b in range(N):
+                        T = gt.counts[b]
+                        for s in range(scalar):
+                            tc_dn[b, s * max_num:s * max_num + T] = labels_host[b]
+                    tc_dn_d = upload(tc_dn, dev)
                 logits_dn, order = strided_stack([o["pred_logits"] for o in dn_outs])
-                ce_dn = self._class_losses(logits_dn, upload(tc_dn, dev))
+                ce_dn = self._class_losses(logits_dn, tc_dn_d)
                 losses.add_group(["loss_ce_dn" + suffixes[i] for i in order], ce_dn)
         if not use_dn:
             z = torch.as_tensor(0.0, device=dev)

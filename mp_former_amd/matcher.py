@@ -6,9 +6,11 @@ The matchings of ALL decoder outputs of a step (final + auxiliary) are computed 
   * one native launch (mpf_match_cost) produces the mask + dice cost of every (output, image, query,
     target) from the prediction maps in place — no gathered / float copies, no [Q,P] temporaries,
   * the class cost is one batched softmax + gather,
-  * ONE device->host copy carries all cost matrices to SciPy's linear_sum_assignment, which runs on
-    the host exactly as in the reference (:149-151) — assignments are unchanged, the 10*N blocking
-    `.cpu()` calls per step are gone.
+  * the assignment itself: the training criterion solves all problems on the device (csrc/lsa.hip,
+    SciPy's algorithm and tie-breaking, no device->host copy at all); `match_many` / `forward` (the
+    reference interface, CPU index tensors) make ONE device->host copy for all outputs and call SciPy's
+    linear_sum_assignment as the reference does (:149-151) — either way the 10*N blocking `.cpu()`
+    calls per step are gone.
 """
 import numpy as np
 import torch
@@ -63,21 +65,20 @@ class HungarianMatcher(nn.Module):
         self.num_points = num_points
 
     @torch.no_grad()
-    def match_many(self, outs, targets, gt=None, tags=None, mapset=None, map_index=None):
-        """outs: list of {"pred_logits" [N,Q,K+1], "pred_masks" [N,Q,h,w]}  ->  list (per output) of
-        list (per image) of (index_i, index_j) int64 CPU tensors (matcher.py:95-156).
-        `mapset` / `map_index` optionally give a MapSet that already contains the mask tensors."""
+    def cost_matrices(self, outs, targets, gt=None, tags=None, mapset=None, map_index=None):
+        """The matching cost of every (output, image, query, target) (matcher.py:95-147), on the device:
+        fp32 [L, N, Q, Tmax] (columns >= the image's target count are padding), or None when no image
+        has a target.  Draws the matcher's point sets either way (RNG parity)."""
         L = len(outs)
         N, Q = outs[0]["pred_logits"].shape[:2]
         gt = gt or GTMasks(targets)
         dev = gt.device
         P = self.num_points
         tags = tags or ["match"] + [f"match_{i}" for i in range(L - 1)]
-        empty = (torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64))
         # one point set per (output, image), shared by all of that image's masks (matcher.py:120)
         coords = _rng.rand_cat([(tags[l], (1, P, 2)) for l in range(L) for _ in range(N)], dev)   # [L*N,P,2]
         if gt.tmax == 0:
-            return [[empty for _ in range(N)] for _ in range(L)]
+            return None
         if mapset is None:
             mapset = MapSet([o["pred_masks"] for o in outs])
             map_index = list(range(L))
@@ -114,7 +115,22 @@ class HungarianMatcher(nn.Module):
             if gt.counts[b]:
                 labels[b, :gt.counts[b]] = t["labels"]
         prob = logits.softmax(-1)
-        C = C - self.cost_class * torch.gather(prob, 3, labels[None, :, None, :].expand(L, N, Q, Tmax))
+        return (C - self.cost_class * torch.gather(prob, 3, labels[None, :, None, :].expand(L, N, Q, Tmax))).contiguous()
+
+    @torch.no_grad()
+    def match_many(self, outs, targets, gt=None, tags=None, mapset=None, map_index=None):
+        """outs: list of {"pred_logits" [N,Q,K+1], "pred_masks" [N,Q,h,w]}  ->  list (per output) of
+        list (per image) of (index_i, index_j) int64 CPU tensors (matcher.py:95-156), solved by SciPy on
+        the host as in the reference (one device->host copy for all outputs).  The training criterion
+        uses the device solver instead (criterion.py, lsa.py) and never synchronises.
+        `mapset` / `map_index` optionally give a MapSet that already contains the mask tensors."""
+        L = len(outs)
+        N = outs[0]["pred_logits"].shape[0]
+        gt = gt or GTMasks(targets)
+        empty = (torch.zeros(0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64))
+        C = self.cost_matrices(outs, targets, gt=gt, tags=tags, mapset=mapset, map_index=map_index)
+        if C is None:
+            return [[empty for _ in range(N)] for _ in range(L)]
         host = C.cpu().numpy()                                                           # the one D2H copy
         res = []
         for l in range(L):
