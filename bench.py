@@ -164,6 +164,8 @@ def main():
     _lib.lib()   # fail loudly if the native library is missing
 
     torch.manual_seed(rank)
+    if os.environ.get("MPF_CONV_FIND", "0") == "1":      # let MIOpen time its solvers per conv shape (slow warm-up)
+        torch.backends.cudnn.benchmark = True
     model = TrainModel().to(dev).train()
     model.backbone.to(memory_format=torch.channels_last)
     ddp = mdist.wrap_ddp(model, [local_rank])
