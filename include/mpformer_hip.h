@@ -318,6 +318,13 @@ int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, const void* g
                         void* rowsum_a, int I, int J, int Kc, int relu, void* stream);
 
 /*
+ * 'masked' rows of the mask-piloted queries (prepare_for_dn_v5, mask2former_transformer_decoder.py:
+ * 986-987: F.interpolate(masks, size, mode='area') <= 1e-8): out[t, y, x] = 1 iff the byte mask t
+ * [H, W] has no non-zero pixel inside block (y, x) of the h x w grid (H % h == 0, W % w == 0).
+ */
+int mpf_mask_block_empty(const uint8_t* masks, uint8_t* out, int T, int H, int W, int h, int w, void* stream);
+
+/*
  * Linear sum assignment (the Hungarian step of HungarianMatcher.memory_efficient_forward, matcher.py:
  * 149-151, where the reference calls scipy.optimize.linear_sum_assignment on a host copy of the cost
  * matrix) solved on the device, one wavefront per problem, with SciPy's algorithm and tie-breaking

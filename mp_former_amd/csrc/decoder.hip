@@ -92,3 +92,56 @@ extern "C" int mpf_attn_mask(const void* masks, int dtype, int64_t stride_n, int
     mpf::prof_end(mpf_last_kernel(), st, (double)N * Q * hl * wl * (1.0 + 4.0 * (dtype == MPF_F32 ? 4.0 : 2.0)));
     return mpf::check(hipGetLastError(), "mpf_attn_mask");
 }
+
+// ------------------------------------------------------------------------------------------------
+// 'masked' rows of the mask-piloted queries: out[t, y, x] = 1 iff ground-truth mask t has NO pixel in
+// the (H/h) x (W/w) block (y, x) — F.interpolate(mode='area') <= 1e-8 of prepare_for_dn_v5
+// (mask2former_transformer_decoder.py:986-987) for H % h == 0, W % w == 0.  One thread per block,
+// adjacent threads own adjacent blocks of a row, so a wave reads whole mask rows.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename WORD>
+__global__ __launch_bounds__(256) void block_empty_kernel(const uint8_t* __restrict__ masks, uint8_t* __restrict__ out, int T, int H,
+                                                          int W, int h, int w)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)T * h * w;
+    if (idx >= total) return;
+    const int x = (int)(idx % w);
+    const int y = (int)((idx / w) % h);
+    const int64_t t = idx / ((int64_t)w * h);
+    const int bh = H / h, bw = W / w;
+    const uint8_t* p = masks + (t * H + (int64_t)y * bh) * W + (int64_t)x * bw;
+    constexpr int WB = (int)sizeof(WORD);
+    WORD acc = 0;
+    for (int r = 0; r < bh; ++r) {
+        const WORD* row = reinterpret_cast<const WORD*>(p + (int64_t)r * W);
+        for (int c = 0; c < bw / WB; ++c) acc |= row[c];
+    }
+    out[idx] = acc == 0 ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int mpf_mask_block_empty(const uint8_t* masks, uint8_t* out, int T, int H, int W, int h, int w, void* stream)
+{
+    if (T == 0) return 0;
+    if (!masks || !out) return mpf::fail(MPF_E_NULL, "mask_block_empty: NULL buffer");
+    if (T < 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || H % h || W % w)
+        return mpf::fail(MPF_E_SHAPE, "mask_block_empty: the level size must divide the mask size");
+    hipStream_t st = (hipStream_t)stream;
+    const int bw = W / w;
+    const int64_t total = (int64_t)T * h * w;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    mpf::prof_begin(st);
+    mpf::set_kernel("block_empty_kernel");
+    if (bw % 8 == 0 && W % 8 == 0 && ((uintptr_t)masks & 7) == 0)
+        hipLaunchKernelGGL(block_empty_kernel<uint64_t>, grid, dim3(256), 0, st, masks, out, T, H, W, h, w);
+    else if (bw % 4 == 0 && W % 4 == 0 && ((uintptr_t)masks & 3) == 0)
+        hipLaunchKernelGGL(block_empty_kernel<uint32_t>, grid, dim3(256), 0, st, masks, out, T, H, W, h, w);
+    else
+        hipLaunchKernelGGL(block_empty_kernel<uint8_t>, grid, dim3(256), 0, st, masks, out, T, H, W, h, w);
+    mpf::prof_end("block_empty_kernel", st, (double)T * H * W + (double)total);
+    return mpf::check(hipGetLastError(), "mpf_mask_block_empty");
+}

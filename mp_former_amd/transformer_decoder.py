@@ -212,8 +212,15 @@ def gt_block_or(masks: Tensor, size):
     if H % h or W % w:
         return F.interpolate(masks.float().unsqueeze(1), size=size, mode="area").flatten(1) <= 1e-8
     m = masks if masks.dtype == torch.bool else masks > 0
-    any_ = m.view(T, h, H // h, w, W // w).any(dim=4).any(dim=2)
-    return ~any_.flatten(1)
+    if not m.is_cuda:
+        raise RuntimeError("mp_former_amd decoder runs on the GPU only (no CPU fallback)")
+    m = m.contiguous()
+    out = torch.empty((T, h * w), dtype=torch.bool, device=m.device)
+    with torch.cuda.device(m.device):
+        code = _lib.lib().mpf_mask_block_empty(m.data_ptr(), out.data_ptr(), T, H, W, h, w,
+                                               torch.cuda.current_stream(m.device).cuda_stream)
+    _lib.check(code, "mpf_mask_block_empty")
+    return out
 
 
 class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
@@ -318,10 +325,13 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         padding[(bid, slot)] = feats
         # GT rows per level, computed once per forward (the reference re-derives them every layer)
         rows = []
+        gts = [t["masks"] for t in targets if len(t["masks"]) > 0]
+        same = all(g.shape[1:] == gts[0].shape[1:] and g.dtype == gts[0].dtype for g in gts)
+        all_masks = torch.cat(gts) if same else None
         for size in size_list:
             pm = torch.ones(bs, pad, size[0] * size[1], dtype=torch.bool, device=device)
-            gt = [gt_block_or(t["masks"], size) for t in targets if len(t["masks"]) > 0]
-            pm[(bid, slot)] = torch.cat(gt).repeat(scalar, 1)
+            gt = gt_block_or(all_masks, size) if same else torch.cat([gt_block_or(g, size) for g in gts])
+            pm[(bid, slot)] = gt.repeat(scalar, 1)
             rows.append(pm)
         tgt_size = pad + self.num_queries
         tgt_mask = torch.zeros(tgt_size, tgt_size, dtype=torch.bool, device=device)

@@ -64,3 +64,23 @@ def test_decoder_layer_rejects_bad_struct():
     assert _lib.lib().mpf_decoder_layer_forward(ctypes.byref(L), None) == -3      # MPF_E_NULL
     L.H = 4
     assert _lib.lib().mpf_decoder_layer_forward(ctypes.byref(L), None) == -2      # MPF_E_SHAPE
+
+
+@pytest.mark.parametrize("T,H,W,size", [(5, 64, 64, (8, 8)), (3, 96, 160, (12, 20)), (7, 1024, 1024, (128, 128)),
+                                        (2, 1024, 1024, (32, 32)), (4, 60, 60, (20, 12)), (1, 48, 36, (16, 12))])
+def test_mp_rows_block_empty_matches_area_interpolation(T, H, W, size):
+    """gt_block_or == (F.interpolate(masks, size, mode='area') <= 1e-8), mask2former_transformer_decoder.py:986-987"""
+    import torch.nn.functional as F
+    from mp_former_amd.transformer_decoder import gt_block_or
+    g = torch.Generator(device="cpu").manual_seed(T * H + W)
+    masks = torch.zeros(T, H, W, dtype=torch.bool)
+    for t in range(T):      # sparse blobs + isolated pixels, some maps empty
+        if t % 4 == 3:
+            continue
+        y0, x0 = int(torch.randint(0, H // 2, (1,), generator=g)), int(torch.randint(0, W // 2, (1,), generator=g))
+        masks[t, y0:y0 + H // 3, x0:x0 + W // 4] = True
+        masks[t, int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))] = True
+    masks = masks.cuda()
+    ref = F.interpolate(masks.float().unsqueeze(1), size=size, mode="area").flatten(1) <= 1e-8
+    got = gt_block_or(masks, size)
+    assert got.dtype == torch.bool and torch.equal(got, ref)

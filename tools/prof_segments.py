@@ -13,6 +13,7 @@ adam = [i for i, (s, e, n) in enumerate(rows) if "FusedAdam" in n]
 ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or rows[adam[i + 1]][0] - rows[adam[i]][1] > 5e6]
 acc = collections.OrderedDict()
 kinds = {}
+ktime = {}
 def short(n):
     n = n.replace("void ", "").replace("at::native::", "").replace("(anonymous namespace)::", "")
     return n[:90]
@@ -47,8 +48,10 @@ for si in range(warmup, len(ends) - 1):
         d = acc.setdefault(name, [0, 0.0, 0.0])
         d[0] += len(part); d[1] += busy; d[2] += span
         kc = kinds.setdefault(name, collections.Counter())
+        kt = ktime.setdefault(name, collections.Counter())
         for s_, e_, n_ in part:
             kc[short(n_)] += 1
+            kt[short(n_)] += (e_ - s_) / 1e6
 print(f"{'phase':28s} {'launches':>9s} {'busy ms':>9s} {'span ms':>9s} {'idle ms':>9s} {'us/launch':>10s}")
 tl = tb = ts = 0
 for k, (c, b, s) in acc.items():
@@ -59,6 +62,6 @@ print(f"{'total':28s} {tl:9.0f} {tb:9.2f} {ts:9.2f} {ts - tb:9.2f}")
 
 if len(sys.argv) > 3:
     for k, kc in kinds.items():
-        print(f"--- {k}: kernels by launch count (per step)")
-        for n, c in kc.most_common(int(sys.argv[3])):
-            print(f"   {c / nsteps:7.1f}  {n}")
+        print(f"--- {k}: kernels by time (ms per step, launches per step)")
+        for n, t in ktime[k].most_common(int(sys.argv[3])):
+            print(f"   {t / nsteps:7.3f} ms  x{kc[n] / nsteps:6.1f}  {n}")
