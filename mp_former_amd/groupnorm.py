@@ -58,6 +58,8 @@ class _GroupNormFn(Function):
 class GroupNorm(nn.GroupNorm):
     def forward(self, x):
         C = x.shape[1]
+        if x.is_cuda and x.dtype == torch.float32 and not x.is_contiguous():
+            x = x.contiguous()      # channels_last conv outputs: aten's GroupNorm makes the same NCHW copy first
         if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and self.affine and x.dim() >= 3
                 and ((C // self.num_groups) * (x.numel() // (x.shape[0] * C))) % 4 == 0):
             return _GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps)
