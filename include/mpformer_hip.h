@@ -421,6 +421,18 @@ int mpf_decoder_layer_forward(const MpfDecoderLayer* layer, void* stream);
 int mpf_decoder_layer_backward(const MpfDecoderLayer* layer, const MpfDecoderLayerGrad* grad, void* stream);
 
 /*
+ * Weight gradient of a bf16 Linear with MANY rows (the key / value projections of the cross-attention,
+ * nn.MultiheadAttention in_proj of mask2former_transformer_decoder.py:100-112 under autocast; rows =
+ * S * N = 2 048 .. 65 536):  c_out[Mdim, Ndim] = a^T . b,  csum_out[Mdim] = column sums of a  (the bias
+ * gradient; may be NULL),  a [R, Mdim] = dY, b [R, Ndim] = x, all bf16, fp32 accumulation.  Split over
+ * rows like mpf_gemm3_nt (same kernel, one bf16 product instead of six), partials summed in a fixed
+ * order by a second launch.  workspace: mpf_gemm_nt_bf16_workspace_bytes(...) bytes.
+ */
+size_t mpf_gemm_nt_bf16_workspace_bytes(int R, int Mdim, int Ndim, int rows_per_split);
+int mpf_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* c_out, void* csum_out, int R, int Mdim,
+                     int Ndim, int rows_per_split, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * y = relu?(x + bias[c] + res) over a dense channel-last activation (channel = fastest dimension,
  * C % 8 == 0): the folded FrozenBatchNorm shift, the residual add and the ReLU of a ResNet
  * bottleneck (detectron2 BottleneckBlock, used by configs/coco/instance-segmentation/Base-COCO-

@@ -121,11 +121,23 @@ struct Acc {
     }
 
     // a_base / b_base: byte offset of the wave's first row in the A / B image
-    template <int AKC, int BKC>
+    template <int AKC, int BKC, bool ONE = false>
     __device__ __forceinline__ void step(const unsigned char* lds, int a_base, int b_base, int lane)
     {
         const int r16 = lane & 15, g = lane >> 4;
         const int a_frag = a_base + g * AKC + (r16 ^ (2 * g)) * 16, b_frag = b_base + g * BKC + (r16 ^ (2 * g)) * 16;
+        if (ONE) {      // bf16 operands: plane 0 is the whole value
+            bf16x8 fa0[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa0[i] = as_frag(*reinterpret_cast<const uint4*>(lds + a_frag + i * 256));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bf16x8 fb0 = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + j * 256));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0, fa0[i], v[i][j], 0, 0, 0);
+            }
+            return;
+        }
         bf16x8 fa[3][4];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
@@ -179,7 +191,7 @@ struct Acc<4, true> {
                 for (int e = 0; e < 16; ++e) v[i][j][e] = 0.f;
     }
 
-    template <int AKC, int BKC>
+    template <int AKC, int BKC, bool ONE = false>
     __device__ __forceinline__ void step(const unsigned char* lds, int a_base, int b_base, int lane)
     {
         const int r32 = lane & 31, gh = lane >> 5;
@@ -187,6 +199,19 @@ struct Acc<4, true> {
         for (int kh = 0; kh < 2; ++kh) {
             const int kc = 2 * kh + gh;                       // this lane's k-chunk (8 values) of the 16-deep MFMA
             const int sw = (r32 ^ (2 * kc)) * 16;
+            if (ONE) {      // bf16 operands: plane 0 is the whole value
+                bf16x8 fa0[2], fb0[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa0[t] = as_frag(*reinterpret_cast<const uint4*>(lds + a_base + kc * AKC + t * 512 + sw));
+                    fb0[t] = as_frag(*reinterpret_cast<const uint4*>(lds + b_base + kc * BKC + t * 512 + sw));
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0[j], fa0[i], v[i][j], 0, 0, 0);
+                continue;
+            }
             bf16x8 fa[3][2], fb[3][2];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
@@ -420,7 +445,9 @@ struct G3N {
     int R, Mdim, Ndim, b2_rows, rows_per_split, nsplit, tiles_m, tiles_n, ntiles, transpose_out;
 };
 
-template <int BN>
+// BF: the operands are bf16 matrices (p.a / p.b point to 2-byte elements): one plane, one product —
+// the weight gradient of a bf16 Linear with many rows (the K / V projections of the cross-attention).
+template <int BN, bool BF = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
 {
     constexpr int NJ = BN / 32;
@@ -445,6 +472,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
     const int am = tid & 127, akc = tid >> 7;
     const bool a_col_ok = m0 + am < p.Mdim;
     const float* acol = p.a + min(m0 + am, p.Mdim - 1);
+    const unsigned short* acol16 = reinterpret_cast<const unsigned short*>(p.a) + min(m0 + am, p.Mdim - 1);
+    const unsigned short* bcol16[2];
     int bn_[2], bkc_[2];
     bool b_ok[2], b_col_ok[2];
     const float* bcol[2];
@@ -458,6 +487,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
         bkc_[i] = min(u / BN, 3);
         b_col_ok[i] = b_ok[i] && n0 + bn_[i] < p.Ndim;
         bcol[i] = p.b + min(n0 + bn_[i], p.Ndim - 1);
+        bcol16[i] = reinterpret_cast<const unsigned short*>(p.b) + min(n0 + bn_[i], p.Ndim - 1);
         b2col[i] = p.b2 ? p.b2 + min(n0 + bn_[i], p.Ndim - 1) : nullptr;
         b2row[i] = p.b2 ? (r_begin + bkc_[i] * 8) % p.b2_rows : 0;
     }
@@ -472,12 +502,20 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
     {                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
             const int ra0 = (r0) + akc * 8 + j, ra1 = ra0 + 16;                                        \
-            const float va0 = acol[(int64_t)min(ra0, r_end - 1) * p.lda];                              \
-            const float va1 = acol[(int64_t)min(ra1, r_end - 1) * p.lda];                              \
             const int rb0 = (r0) + bkc_[0] * 8 + j, rb1 = (r0) + bkc_[1] * 8 + j;                      \
-            float vb0 = bcol[0][(int64_t)min(rb0, r_end - 1) * p.ldb];                                 \
-            float vb1 = bcol[1][(int64_t)min(rb1, r_end - 1) * p.ldb];                                 \
-            if (p.b2) {                                                                                \
+            float va0, va1, vb0, vb1;                                                                  \
+            if (BF) {                                                                                  \
+                va0 = __uint_as_float((unsigned)acol16[(int64_t)min(ra0, r_end - 1) * p.lda] << 16);   \
+                va1 = __uint_as_float((unsigned)acol16[(int64_t)min(ra1, r_end - 1) * p.lda] << 16);   \
+                vb0 = __uint_as_float((unsigned)bcol16[0][(int64_t)min(rb0, r_end - 1) * p.ldb] << 16); \
+                vb1 = __uint_as_float((unsigned)bcol16[1][(int64_t)min(rb1, r_end - 1) * p.ldb] << 16); \
+            } else {                                                                                   \
+                va0 = acol[(int64_t)min(ra0, r_end - 1) * p.lda];                                      \
+                va1 = acol[(int64_t)min(ra1, r_end - 1) * p.lda];                                      \
+                vb0 = bcol[0][(int64_t)min(rb0, r_end - 1) * p.ldb];                                   \
+                vb1 = bcol[1][(int64_t)min(rb1, r_end - 1) * p.ldb];                                   \
+            }                                                                                          \
+            if (!BF && p.b2) {                                                                         \
                 int q0 = b2row[0] + j, q1 = b2row[1] + j;                                              \
                 q0 = q0 >= p.b2_rows ? q0 - p.b2_rows : q0;                                            \
                 q1 = q1 >= p.b2_rows ? q1 - p.b2_rows : q1;                                            \
@@ -489,7 +527,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
             xb0[j] = rb0 < r_end ? vb0 : 0.f;                                                          \
             xb1[j] = (b_ok[1] && rb1 < r_end) ? vb1 : 0.f;                                             \
         }                                                                                              \
-        if (p.b2) {                                                                                    \
+        if (!BF && p.b2) {                                                                             \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
                 b2row[i] += kBK;                                                                       \
                 while (b2row[i] >= p.b2_rows) b2row[i] -= p.b2_rows;                                   \
@@ -510,21 +548,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
             uint4 h, m, l;
             split8(make_float4(xa0[0], xa0[1], xa0[2], xa0[3]), make_float4(xa0[4], xa0[5], xa0[6], xa0[7]), &h, &m, &l);
             *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = h;
-            *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = m;
-            *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = l;
+            if (!BF) *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = m;
+            if (!BF) *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = l;
             split8(make_float4(xa1[0], xa1[1], xa1[2], xa1[3]), make_float4(xa1[4], xa1[5], xa1[6], xa1[7]), &h, &m, &l);
             *reinterpret_cast<uint4*>(lds + (0 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = h;
-            *reinterpret_cast<uint4*>(lds + (1 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = m;
-            *reinterpret_cast<uint4*>(lds + (2 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = l;
+            if (!BF) *reinterpret_cast<uint4*>(lds + (1 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = m;
+            if (!BF) *reinterpret_cast<uint4*>(lds + (2 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = l;
             split8(make_float4(xb0[0], xb0[1], xb0[2], xb0[3]), make_float4(xb0[4], xb0[5], xb0[6], xb0[7]), &h, &m, &l);
             *reinterpret_cast<uint4*>(lds + kAbytes + (0 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = h;
-            *reinterpret_cast<uint4*>(lds + kAbytes + (1 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = m;
-            *reinterpret_cast<uint4*>(lds + kAbytes + (2 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = l;
+            if (!BF) *reinterpret_cast<uint4*>(lds + kAbytes + (1 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = m;
+            if (!BF) *reinterpret_cast<uint4*>(lds + kAbytes + (2 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = l;
             if (b_ok[1]) {
                 split8(make_float4(xb1[0], xb1[1], xb1[2], xb1[3]), make_float4(xb1[4], xb1[5], xb1[6], xb1[7]), &h, &m, &l);
                 *reinterpret_cast<uint4*>(lds + kAbytes + (0 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = h;
-                *reinterpret_cast<uint4*>(lds + kAbytes + (1 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = m;
-                *reinterpret_cast<uint4*>(lds + kAbytes + (2 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = l;
+                if (!BF) *reinterpret_cast<uint4*>(lds + kAbytes + (1 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = m;
+                if (!BF) *reinterpret_cast<uint4*>(lds + kAbytes + (2 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = l;
             }
             if (want_csa) {
 #pragma unroll
@@ -537,7 +575,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
         }
         __syncthreads();
         if (r0 + kBK < r_end) G3N_LOAD(r0 + kBK);
-        acc.template step<kAKc, kBKc>(lds, a_frag, b_frag, lane);
+        acc.template step<kAKc, kBKc, BF>(lds, a_frag, b_frag, lane);
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
@@ -690,6 +728,80 @@ extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t
     }
     mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)R * Mdim + (double)R * Ndim + (double)p.nsplit * Mdim * Ndim));
     return mpf::check(hipGetLastError(), "mpf_gemm3_nt");
+}
+
+namespace {
+
+// out[j] = bf16(sum_s part[s][j]): the split partials of the bf16 weight-gradient GEMM and of its column
+// sums, both in one launch (float4 per thread per split, coalesced; summation order fixed)
+__global__ __launch_bounds__(256) void nt_reduce_bf16_kernel(const float* __restrict__ c_part, int64_t cn,
+                                                             const float* __restrict__ s_part, int64_t sn, int nsplit,
+                                                             unsigned short* __restrict__ c_out, unsigned short* __restrict__ s_out)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t cq = cn >> 2, sq = sn >> 2;
+    if (q >= cq + sq) return;
+    const bool is_c = q < cq;
+    const float* src = is_c ? c_part + 4 * q : s_part + 4 * (q - cq);
+    const int64_t stride = is_c ? cn : sn;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float4 t = *reinterpret_cast<const float4*>(src + sp * stride);
+        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    auto rne = [](float f) -> unsigned {
+        unsigned u = __float_as_uint(f);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return u >> 16;
+    };
+    uint2 o;
+    o.x = rne(acc.x) | (rne(acc.y) << 16);
+    o.y = rne(acc.z) | (rne(acc.w) << 16);
+    unsigned short* dst = is_c ? c_out + 4 * q : s_out + 4 * (q - cq);
+    *reinterpret_cast<uint2*>(dst) = o;
+}
+
+}  // namespace
+
+extern "C" size_t mpf_gemm_nt_bf16_workspace_bytes(int R, int Mdim, int Ndim, int rows_per_split)
+{
+    if (R <= 0 || Mdim <= 0 || Ndim <= 0 || rows_per_split <= 0) return 0;
+    const size_t ns = (size_t)(R + rows_per_split - 1) / rows_per_split;
+    return ns * ((size_t)Mdim * Ndim + Mdim) * sizeof(float);
+}
+
+extern "C" int mpf_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* c_out, void* csum_out, int R,
+                                int Mdim, int Ndim, int rows_per_split, void* workspace, size_t workspace_bytes, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!a || !b || !c_out || !workspace) return mpf::fail(MPF_E_NULL, "gemm_nt_bf16: NULL buffer");
+    if (R <= 0 || Mdim <= 0 || Ndim <= 0 || rows_per_split <= 0 || rows_per_split % kBK != 0 || Mdim % 4 || Ndim % 4)
+        return mpf::fail(MPF_E_SHAPE, "gemm_nt_bf16: bad sizes (rows_per_split % 32, Mdim % 4, Ndim % 4 must be 0)");
+    if (workspace_bytes < mpf_gemm_nt_bf16_workspace_bytes(R, Mdim, Ndim, rows_per_split))
+        return mpf::fail(MPF_E_SHAPE, "gemm_nt_bf16: workspace too small");
+    G3N p;
+    p.a = static_cast<const float*>(a); p.b = static_cast<const float*>(b); p.b2 = nullptr;
+    p.nsplit = (R + rows_per_split - 1) / rows_per_split;
+    p.c = static_cast<float*>(workspace);
+    p.csum_a = p.c + (size_t)p.nsplit * Mdim * Ndim;
+    p.csum_b = nullptr;
+    p.lda = lda; p.ldb = ldb; p.ldb2 = 0;
+    p.R = R; p.Mdim = Mdim; p.Ndim = Ndim; p.b2_rows = 0; p.rows_per_split = rows_per_split;
+    p.transpose_out = 0;
+    p.tiles_m = (Mdim + kBM - 1) / kBM;
+    p.tiles_n = (Ndim + 127) / 128;
+    p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
+    const int grid = ((p.ntiles + 7) / 8) * 8;
+    mpf::prof_begin(st);
+    mpf::set_kernel("gemm3_nt_kernel<128, bf16>");
+    hipLaunchKernelGGL((gemm3_nt_kernel<128, true>), dim3(grid), dim3(kThreads), 0, st, p);
+    mpf::prof_end("gemm3_nt_kernel<128, bf16>", st, 2.0 * ((double)R * Mdim * p.tiles_n + (double)R * Ndim * p.tiles_m) +
+                                                       4.0 * (double)p.nsplit * Mdim * Ndim);
+    const int64_t cn = (int64_t)Mdim * Ndim, sn = csum_out ? Mdim : 0;
+    const int64_t quads = (cn + sn) / 4;
+    hipLaunchKernelGGL(nt_reduce_bf16_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, p.c, cn, p.csum_a, sn,
+                       p.nsplit, static_cast<unsigned short*>(c_out), static_cast<unsigned short*>(csum_out));
+    return mpf::check(hipGetLastError(), "mpf_gemm_nt_bf16");
 }
 
 #ifdef G3_TIMING

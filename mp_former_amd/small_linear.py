@@ -79,3 +79,71 @@ def small_linear(x, w, b=None, relu=False):
     if not x.is_cuda:
         raise RuntimeError("mp_former_amd small_linear runs on the GPU only (no CPU fallback)")
     return _SmallLinear.apply(x, w, b, relu)
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 Linear with MANY rows (the key / value projections of the cross-attention): forward and input
+# gradient stay library GEMMs; the weight gradient dW = dY^T x — a 256x256 output contracted over
+# thousands of rows, 57-66 us in the library plus a separate bias reduction — runs on the split-over-rows
+# MFMA kernel of gemm3.hip in its one-product bf16 form (mpf_gemm_nt_bf16), bias gradient included.
+_nt_ws = {}
+
+
+def _nt_workspace(device, nbytes):
+    w = _nt_ws.get(device)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _nt_ws[device] = w
+    return w
+
+
+def gemm_nt_bf16(a, b, want_csum=True):
+    """a [R, M], b [R, N] bf16 (unit column stride) -> (a^T b [M, N] bf16, column sums of a [M] bf16 or None)."""
+    from .gemm3 import pick_rows_per_split
+    R, M = a.shape
+    N = b.shape[1]
+    rps = pick_rows_per_split(R, ((M + 127) // 128) * ((N + 127) // 128))
+    lib = _lib.lib()
+    ws = _nt_workspace(a.device, lib.mpf_gemm_nt_bf16_workspace_bytes(R, M, N, rps))
+    c = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    cs = torch.empty((M,), dtype=torch.bfloat16, device=a.device) if want_csum else None
+    with torch.cuda.device(a.device):
+        code = lib.mpf_gemm_nt_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(),
+                                    cs.data_ptr() if want_csum else None, R, M, N, rps, ws.data_ptr(), ws.numel(), _stream(a))
+    _lib.check(code, "mpf_gemm_nt_bf16")
+    return c, cs
+
+
+def tall_usable(x, w, b=None):
+    K = x.shape[-1]
+    return (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and (b is None or b.dtype == torch.bfloat16)
+            and x.numel() // max(K, 1) > MAX_ROWS and K % 4 == 0 and w.shape[0] % 4 == 0)
+
+
+class _TallLinear(Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        K, N = x.shape[-1], w.shape[0]
+        g2 = gy.reshape(-1, N)
+        if g2.stride(1) != 1 or g2.dtype != torch.bfloat16:
+            g2 = g2.to(torch.bfloat16).contiguous()
+        x2 = x.reshape(-1, K)
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.matmul(g2, w).view(x.shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = gemm_nt_bf16(g2, x2, want_csum=ctx.has_bias)
+        return dx, dw, db
+
+
+def tall_linear(x, w, b=None):
+    return _TallLinear.apply(x, w, b)

@@ -29,7 +29,7 @@ from . import _lib, _rng
 from ._h2d import upload
 from .attention import attention_core
 from .resln import res_ln
-from .small_linear import small_linear, usable as _small_ok
+from .small_linear import small_linear, tall_linear, tall_usable as _tall_ok, usable as _small_ok
 from .decoder_layer import decoder_layer
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
 
@@ -114,6 +114,8 @@ def linear(x, w, b=None, relu=False):
     fused (small_linear.py); everything else is the library GEMM."""
     if _small_ok(x, w, b) and os.environ.get("MPF_SMALL_LINEAR", "1") == "1":
         return small_linear(x, w, b, relu)
+    if not relu and _tall_ok(x, w, b) and os.environ.get("MPF_TALL_LINEAR", "1") == "1":
+        return tall_linear(x, w, b)         # library forward / dX, native split-over-rows weight gradient
     y = F.linear(x, w, b)
     return F.relu(y) if relu else y
 

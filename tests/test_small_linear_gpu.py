@@ -96,3 +96,39 @@ def test_small_gemm_rejects_bad_strides():
     assert code == -2      # MPF_E_SHAPE
     code = _lib.lib().mpf_small_gemm_bf16(a.data_ptr(), 32, 1, None, a.data_ptr(), 32, 1, None, None, 0, c.data_ptr(), 16, None, 16, 14, 32, 0, s)
     assert code < 0
+
+
+@pytest.mark.parametrize("R,M,N", [(2048, 256, 256), (8192, 256, 256), (32768, 256, 256), (5000, 256, 128), (3001, 100, 36)])
+def test_gemm_nt_bf16_matches_reference(R, M, N):
+    from mp_former_amd.small_linear import gemm_nt_bf16
+    torch.manual_seed(R + M)
+    dev = torch.device("cuda:0")
+    a = torch.randn(R, M, device=dev).bfloat16()
+    b = torch.randn(R, N, device=dev).bfloat16()
+    c, cs = gemm_nt_bf16(a, b)
+    ref = a.double().t() @ b.double()
+    lib = (a.t() @ b)
+    e_got = (c.double() - ref).abs().max().item()
+    e_lib = (lib.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert e_got <= max(2 * e_lib, 2 ** -8 * scale), (e_got, e_lib, scale)
+    sref = a.double().sum(0)
+    assert (cs.double() - sref).abs().max().item() <= 2 ** -8 * sref.abs().max().item() + 1e-3
+
+
+def test_tall_linear_grads():
+    from mp_former_amd.small_linear import tall_linear
+    torch.manual_seed(1)
+    dev = torch.device("cuda:0")
+    x = torch.randn(4096, 2, 256, device=dev).bfloat16().requires_grad_(True)
+    w = (torch.randn(256, 256, device=dev) / 16).bfloat16().requires_grad_(True)
+    b = torch.randn(256, device=dev).bfloat16().requires_grad_(True)
+    g = torch.randn(4096, 2, 256, device=dev).bfloat16()
+    y = tall_linear(x, w, b)
+    y.backward(g)
+    xl, wl, bl = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    yl = F.linear(xl, wl, bl)
+    yl.backward(g)
+    assert torch.equal(y, yl)
+    for got, lib in ((x.grad, xl.grad), (w.grad, wl.grad), (b.grad, bl.grad)):
+        assert (got.float() - lib.float()).abs().max().item() <= 2 ** -6 * lib.float().abs().max().item()
