@@ -421,6 +421,13 @@ int mpf_decoder_layer_forward(const MpfDecoderLayer* layer, void* stream);
 int mpf_decoder_layer_backward(const MpfDecoderLayer* layer, const MpfDecoderLayerGrad* grad, void* stream);
 
 /*
+ * Sum of the split partials of mpf_gemm3_nt in one launch and a fixed order: c_out[j] = sum_s
+ * c_part[s][j] (j < c_numel) and s_out[j] = sum_s s_part[s][j] (j < s_numel; s_numel may be 0).
+ */
+int mpf_gemm3_nt_reduce(const float* c_part, int64_t c_numel, const float* s_part, int64_t s_numel, int nsplit,
+                        float* c_out, float* s_out, void* stream);
+
+/*
  * Weight gradient of a bf16 Linear with MANY rows (the key / value projections of the cross-attention,
  * nn.MultiheadAttention in_proj of mask2former_transformer_decoder.py:100-112 under autocast; rows =
  * S * N = 2 048 .. 65 536):  c_out[Mdim, Ndim] = a^T . b,  csum_out[Mdim] = column sums of a  (the bias

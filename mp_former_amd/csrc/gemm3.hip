@@ -734,31 +734,43 @@ namespace {
 
 // out[j] = bf16(sum_s part[s][j]): the split partials of the bf16 weight-gradient GEMM and of its column
 // sums, both in one launch (float4 per thread per split, coalesced; summation order fixed)
-__global__ __launch_bounds__(256) void nt_reduce_bf16_kernel(const float* __restrict__ c_part, int64_t cn,
-                                                             const float* __restrict__ s_part, int64_t sn, int nsplit,
-                                                             unsigned short* __restrict__ c_out, unsigned short* __restrict__ s_out)
+template <bool F32OUT>
+__global__ __launch_bounds__(256) void nt_reduce_kernel(const float* __restrict__ c_part, int64_t cn,
+                                                        const float* __restrict__ s_part, int64_t sn, int nsplit,
+                                                        void* __restrict__ c_out_, void* __restrict__ s_out_)
 {
+    // one float2 per thread (a wave reads 512 contiguous bytes per split), 8 splits in flight
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t cq = cn >> 2, sq = sn >> 2;
+    const int64_t cq = cn >> 1, sq = sn >> 1;
     if (q >= cq + sq) return;
     const bool is_c = q < cq;
-    const float* src = is_c ? c_part + 4 * q : s_part + 4 * (q - cq);
+    const float* src = is_c ? c_part + 2 * q : s_part + 2 * (q - cq);
     const int64_t stride = is_c ? cn : sn;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int sp = 0; sp < nsplit; ++sp) {
-        const float4 t = *reinterpret_cast<const float4*>(src + sp * stride);
-        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    float2 acc = make_float2(0.f, 0.f);
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8) {
+        float2 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const float2*>(src + (int64_t)(sp + k) * stride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc.x += t[k].x; acc.y += t[k].y; }
+    }
+    for (; sp < nsplit; ++sp) {
+        const float2 t = *reinterpret_cast<const float2*>(src + (int64_t)sp * stride);
+        acc.x += t.x; acc.y += t.y;
+    }
+    if (F32OUT) {
+        float* dst = is_c ? static_cast<float*>(c_out_) + 2 * q : static_cast<float*>(s_out_) + 2 * (q - cq);
+        *reinterpret_cast<float2*>(dst) = acc;
+        return;
     }
     auto rne = [](float f) -> unsigned {
         unsigned u = __float_as_uint(f);
         u += 0x7fffu + ((u >> 16) & 1u);
         return u >> 16;
     };
-    uint2 o;
-    o.x = rne(acc.x) | (rne(acc.y) << 16);
-    o.y = rne(acc.z) | (rne(acc.w) << 16);
-    unsigned short* dst = is_c ? c_out + 4 * q : s_out + 4 * (q - cq);
-    *reinterpret_cast<uint2*>(dst) = o;
+    unsigned short* dst = is_c ? static_cast<unsigned short*>(c_out_) + 2 * q : static_cast<unsigned short*>(s_out_) + 2 * (q - cq);
+    *reinterpret_cast<unsigned*>(dst) = rne(acc.x) | (rne(acc.y) << 16);
 }
 
 }  // namespace
@@ -798,10 +810,23 @@ extern "C" int mpf_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64
     mpf::prof_end("gemm3_nt_kernel<128, bf16>", st, 2.0 * ((double)R * Mdim * p.tiles_n + (double)R * Ndim * p.tiles_m) +
                                                        4.0 * (double)p.nsplit * Mdim * Ndim);
     const int64_t cn = (int64_t)Mdim * Ndim, sn = csum_out ? Mdim : 0;
-    const int64_t quads = (cn + sn) / 4;
-    hipLaunchKernelGGL(nt_reduce_bf16_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, p.c, cn, p.csum_a, sn,
-                       p.nsplit, static_cast<unsigned short*>(c_out), static_cast<unsigned short*>(csum_out));
+    const int64_t quads = (cn + sn) / 2;
+    hipLaunchKernelGGL(nt_reduce_kernel<false>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, p.c, cn, p.csum_a, sn,
+                       p.nsplit, c_out, csum_out);
     return mpf::check(hipGetLastError(), "mpf_gemm_nt_bf16");
+}
+
+extern "C" int mpf_gemm3_nt_reduce(const float* c_part, int64_t c_numel, const float* s_part, int64_t s_numel, int nsplit,
+                                   float* c_out, float* s_out, void* stream)
+{
+    if (!c_part || !c_out || (s_numel > 0 && (!s_part || !s_out))) return mpf::fail(MPF_E_NULL, "gemm3_nt_reduce: NULL buffer");
+    if (nsplit <= 0 || c_numel <= 0 || s_numel < 0 || c_numel % 4 || s_numel % 4)
+        return mpf::fail(MPF_E_SHAPE, "gemm3_nt_reduce: sizes must be positive multiples of 4");
+    const int64_t quads = (c_numel + s_numel) / 2;
+    mpf::set_kernel("nt_reduce_kernel");
+    hipLaunchKernelGGL(nt_reduce_kernel<true>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c_part,
+                       c_numel, s_part, s_numel, nsplit, c_out, s_out);
+    return mpf::check(hipGetLastError(), "mpf_gemm3_nt_reduce");
 }
 
 #ifdef G3_TIMING

@@ -22,7 +22,7 @@ import math
 import torch
 from torch.autograd import Function
 
-from .gemm3 import gemm3, gemm3_nt, split_weight
+from .gemm3 import gemm3, gemm3_nt, nt_reduce, split_weight
 from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
 from .resln import ln256_backward, ln256_forward
 
@@ -54,7 +54,7 @@ def rows_per_split(sizes):
 def _wgrad(g2, x2, rps):
     """dW[out, in] = g2^T . x2 and the bias gradient colsum(g2), both from the split-K NT GEMM."""
     c, ca, _ = gemm3_nt(g2, x2, rps, want_csum_a=True)
-    return c.sum(0), ca.sum(0)
+    return nt_reduce(c, ca)
 
 
 class EncoderFn(Function):

@@ -87,3 +87,17 @@ def gemm3_nt(a, b, rows_per_split, b2=None, want_csum_a=False, want_csum_b=False
             1 if transpose_out else 0, _stream(a))
     _lib.check(code, "mpf_gemm3_nt")
     return c, ca, cb
+
+
+def nt_reduce(c_part, s_part=None):
+    """(sum over splits of c_part [ns, ...], of s_part [ns, n] or None) in ONE launch, fixed order."""
+    ns = c_part.shape[0]
+    c = torch.empty(c_part.shape[1:], dtype=torch.float32, device=c_part.device)
+    s = torch.empty(s_part.shape[1:], dtype=torch.float32, device=c_part.device) if s_part is not None else None
+    if c.numel() % 4 or (s is not None and s.numel() % 4):
+        return c_part.sum(0), (s_part.sum(0) if s_part is not None else None)
+    with torch.cuda.device(c_part.device):
+        code = _lib.lib().mpf_gemm3_nt_reduce(c_part.data_ptr(), c.numel(), _p(s_part), s.numel() if s is not None else 0, ns,
+                                              c.data_ptr(), _p(s), _stream(c_part))
+    _lib.check(code, "mpf_gemm3_nt_reduce")
+    return c, s
