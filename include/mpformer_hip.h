@@ -421,6 +421,24 @@ int mpf_decoder_layer_forward(const MpfDecoderLayer* layer, void* stream);
 int mpf_decoder_layer_backward(const MpfDecoderLayer* layer, const MpfDecoderLayerGrad* grad, void* stream);
 
 /*
+ * dst_i[c, j] = cast(src_i[c, j] * scale_i[c]) for a list of tensors in ONE launch (the FrozenBatchNorm
+ * scale folded into every convolution weight of the bench backbone — detectron2 FrozenBatchNorm2d under
+ * configs/coco/instance-segmentation/Base-COCO-InstanceSegmentation.yaml:2-15 — and the matching
+ * gradient rescale).  items_device: device array; item i covers workgroups [first_block, first_block +
+ * ceil(numel / 2048)), first_block ascending from 0; total_blocks = their sum.  inner = elements per
+ * channel (numel / C).  (src, dst) dtypes: (MPF_F32, MPF_BF16), (MPF_BF16, MPF_F32), (MPF_F32, MPF_F32).
+ */
+typedef struct MpfScaleCastItem {
+    const void* src;
+    void* dst;
+    const float* scale;
+    int64_t numel, inner, first_block;
+} MpfScaleCastItem;
+
+int mpf_grouped_scale_cast(const MpfScaleCastItem* items_device, int n_items, int64_t total_blocks, int src_dtype, int dst_dtype,
+                           void* stream);
+
+/*
  * Sum of the split partials of mpf_gemm3_nt in one launch and a fixed order: c_out[j] = sum_s
  * c_part[s][j] (j < c_numel) and s_out[j] = sum_s s_part[s][j] (j < s_numel; s_numel may be 0).
  */

@@ -3,11 +3,13 @@ strides 4/8/16/32, channels 256/512/1024/2048; detectron2 `build_resnet_backbone
 STRIDE_IN_1X1 False and FrozenBN, configs/coco/instance-segmentation/Base-COCO-InstanceSegmentation.yaml:2-15).
 Stock PyTorch-ROCm ops (MIOpen convolutions) — the backbone is outside the native hot path
 ('backbone stays stock PyTorch-ROCm')."""
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
+from ._h2d import upload
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -90,14 +92,52 @@ def conv_bn(conv, bn, x, folded=None, res=None, relu=True):
     return bias_act(F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups), shift, res, relu)
 
 
+def _dense(t):
+    """memory is one dense block with dim 0 outermost (contiguous or channels_last)"""
+    return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+
+def _grouped_scale_cast(srcs, scales, out_dtype):
+    """[cast(src_i * scale_i[c])] for a list of [C, ...] tensors (dense, dim 0 outermost) in ONE native
+    launch (csrc/elementwise.hip); the results are views of one buffer with the sources' strides."""
+    dev = srcs[0].device
+    numels = [t.numel() for t in srcs]
+    offs, tot = [], 0
+    for n in numels:
+        offs.append(tot)
+        tot += (n + 63) & ~63
+    out = torch.empty(tot, dtype=out_dtype, device=dev)
+    esz = out.element_size()
+    table = np.empty((len(srcs), 6), dtype=np.int64)
+    blk = 0
+    base = out.data_ptr()
+    for i, (t, sc) in enumerate(zip(srcs, scales)):
+        assert _dense(t) and sc.dtype == torch.float32 and sc.is_contiguous() and sc.numel() == t.shape[0]
+        table[i] = (t.data_ptr(), base + offs[i] * esz, sc.data_ptr(), numels[i], numels[i] // t.shape[0], blk)
+        blk += (numels[i] + 2047) // 2048
+    items = upload(table.reshape(-1), dev)
+    dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}
+    with torch.cuda.device(dev):
+        code = _lib.lib().mpf_grouped_scale_cast(items.data_ptr(), len(srcs), blk, dt[srcs[0].dtype], dt[out_dtype],
+                                                 torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(code, "mpf_grouped_scale_cast")
+    return [out[o:o + n].as_strided(t.shape, t.stride()) for o, n, t in zip(offs, numels, srcs)]
+
+
 class _FoldCast(torch.autograd.Function):
-    """All folded conv weights of the network in a few multi-tensor launches: w'_i = w_i * scale_i, cast to
-    the autocast dtype; the backward casts the gradients back to fp32 and multiplies by scale_i."""
+    """All folded conv weights of a stage in ONE launch: w'_i = w_i * scale_i, cast to the autocast dtype;
+    the backward casts the gradients back to fp32 and multiplies by scale_i, also in one launch."""
 
     @staticmethod
     def forward(ctx, dtype, scales, *weights):
         ctx.scales = scales
-        w = torch._foreach_mul([p.detach() for p in weights], scales)
+        ws = [p.detach() for p in weights]
+        native = (ws[0].is_cuda and all(w.dtype == torch.float32 and _dense(w) for w in ws)
+                  and dtype in (None, torch.float32, torch.bfloat16))
+        ctx.native = native
+        if native:
+            return tuple(_grouped_scale_cast(ws, scales, dtype or torch.float32))
+        w = torch._foreach_mul(ws, [s_.view(-1, 1, 1, 1) for s_ in scales])
         if dtype is None:
             return tuple(w)
         outs = [torch.empty_like(t, dtype=dtype) for t in w]
@@ -106,9 +146,13 @@ class _FoldCast(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        if ctx.native and all(g is not None and g.dtype == grads[0].dtype for g in grads) \
+                and grads[0].dtype in (torch.float32, torch.bfloat16):
+            gs = [g if _dense(g) else g.contiguous() for g in grads]
+            return (None, None, *_grouped_scale_cast(gs, ctx.scales, torch.float32))
         g32 = [torch.empty_like(g, dtype=torch.float32) for g in grads]
         torch._foreach_copy_(g32, list(grads))
-        torch._foreach_mul_(g32, ctx.scales)
+        torch._foreach_mul_(g32, [s_.view(-1, 1, 1, 1) for s_ in ctx.scales])
         return (None, None, *g32)
 
 
@@ -164,7 +208,7 @@ class ResNet50(nn.Module):
         the whole network) so that, in backward, the stage's weight gradients become ready as soon as
         the stage has been back-propagated and DDP can start all-reducing them under the earlier stages."""
         sb = [bn.scale_bias() for _, bn in pairs]
-        scales = [s_.view(-1, 1, 1, 1) for s_, _ in sb]
+        scales = [s_ for s_, _ in sb]
         ws = _FoldCast.apply(dtype, scales, *[c.weight for c, _ in pairs])
         return [(w, b_) for w, (_, b_) in zip(ws, sb)]
 

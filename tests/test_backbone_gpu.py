@@ -62,3 +62,28 @@ def test_folded_bottleneck_matches_unfolded_fp32():
     torch.testing.assert_close(gx, x.grad, rtol=1e-3, atol=1e-3)
     for n, p in blk.named_parameters():
         torch.testing.assert_close(gw[n], p.grad, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("dtype", [None, torch.bfloat16])
+def test_grouped_fold_cast_matches_foreach(channels_last, dtype):
+    """_FoldCast (one native launch per direction) == w * scale[:, None, None, None] cast to the autocast dtype,
+    and its backward == grad.float() * scale"""
+    from mp_former_amd.backbone import _FoldCast
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    shapes = [(64, 3, 7, 7), (64, 64, 1, 1), (256, 64, 3, 3), (5, 7, 3, 3), (2048, 512, 1, 1)]
+    ws = [torch.randn(s, device=dev, requires_grad=True) for s in shapes]
+    if channels_last:
+        ws = [w.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True) for w in ws]
+    scales = [torch.rand(s[0], device=dev) + 0.5 for s in shapes]
+    outs = _FoldCast.apply(dtype, scales, *ws)
+    gs = [torch.randn_like(o) for o in outs]
+    torch.autograd.backward(outs, gs)
+    for w, sc, o, g in zip(ws, scales, outs, gs):
+        ref = w.detach() * sc.view(-1, 1, 1, 1)
+        if dtype is not None:
+            ref = ref.to(dtype)
+        assert o.dtype == (dtype or torch.float32) and o.shape == w.shape and o.stride() == w.stride()
+        assert torch.equal(o, ref)
+        assert torch.equal(w.grad, g.float() * sc.view(-1, 1, 1, 1))
