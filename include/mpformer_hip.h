@@ -439,6 +439,22 @@ int mpf_grouped_scale_cast(const MpfScaleCastItem* items_device, int n_items, in
                            void* stream);
 
 /*
+ * mpf_gemm3_split for a LIST of weight matrices in one launch (all Linear weights of the encoder, both
+ * orientations, once per step).  Item i: src fp32 [rows, cols] contiguous -> three bf16 planes at dst,
+ * dst + plane_stride, dst + 2 * plane_stride (elements), written as [rows][dst_ld] (transpose = 0) or
+ * [cols][dst_ld] (transpose = 1) — so several sources can fill row / column ranges of one operand (the
+ * 288-row sampling_offsets | attention_weights matrix).  Item i owns workgroups [first_block, first_block
+ * + ceil(rows * cols / 1024)), first_block ascending from 0; total_blocks = their sum.
+ */
+typedef struct MpfSplitItem {
+    const float* src;
+    void* dst;
+    int64_t rows, cols, transpose, dst_ld, plane_stride, first_block;
+} MpfSplitItem;
+
+int mpf_gemm3_split_grouped(const MpfSplitItem* items_device, int n_items, int64_t total_blocks, void* stream);
+
+/*
  * Sum of the split partials of mpf_gemm3_nt in one launch and a fixed order: c_out[j] = sum_s
  * c_part[s][j] (j < c_numel) and s_out[j] = sum_s s_part[s][j] (j < s_numel; s_numel may be 0).
  */

@@ -637,6 +637,42 @@ __global__ __launch_bounds__(256) void gemm3_split_kernel(const float* __restric
     }
 }
 
+// the same split for a LIST of weight matrices in one launch: item i owns workgroups [first_block,
+// first_block + ceil(rows * cols / 1024)); its three planes are `plane_stride` elements apart and are
+// written with leading dimension dst_ld (so two sources can fill row / column ranges of one operand)
+__global__ __launch_bounds__(256) void gemm3_split_grouped_kernel(const MpfSplitItem* __restrict__ items, int n_items)
+{
+    int lo = 0, hi = n_items - 1;
+    const int64_t blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const MpfSplitItem it = items[lo];
+    const float* __restrict__ w = it.src;
+    unsigned short* __restrict__ out = static_cast<unsigned short*>(it.dst);
+    const int R = (int)it.rows, C = (int)it.cols;
+    const int64_t total = (int64_t)R * C, base = (blk - it.first_block) * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;       // index in the (possibly transposed) output matrix
+        if (i >= total) continue;
+        int r, c;
+        int64_t o;
+        if (it.transpose) { c = (int)(i / R); r = (int)(i - (int64_t)c * R); o = (int64_t)c * it.dst_ld + r; }
+        else { r = (int)(i / C); c = (int)(i - (int64_t)r * C); o = (int64_t)r * it.dst_ld + c; }
+        const float x = w[(int64_t)r * C + c];
+        const unsigned xb = __float_as_uint(x);
+        const float r1 = x - __uint_as_float(xb & 0xFFFF0000u);
+        const unsigned rb = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(rb & 0xFFFF0000u);
+        const unsigned lb = __float_as_uint(r2) + 0x8000u;
+        out[o] = (unsigned short)(xb >> 16);
+        out[it.plane_stride + o] = (unsigned short)(rb >> 16);
+        out[2 * it.plane_stride + o] = (unsigned short)(lb >> 16);
+    }
+}
+
 }  // namespace
 
 int mpf::set_gemm3_option(const char* key, int v)
@@ -656,6 +692,17 @@ extern "C" int mpf_gemm3_split(const float* w, int rows, int cols, int transpose
     mpf::set_kernel("gemm3_split_kernel");
     hipLaunchKernelGGL(gemm3_split_kernel, dim3(blocks), dim3(256), 0, st, w, (unsigned short*)planes, rows, cols, transpose);
     return mpf::check(hipGetLastError(), "mpf_gemm3_split");
+}
+
+extern "C" int mpf_gemm3_split_grouped(const MpfSplitItem* items_device, int n_items, int64_t total_blocks, void* stream)
+{
+    if (n_items == 0 || total_blocks == 0) return 0;
+    if (!items_device) return mpf::fail(MPF_E_NULL, "gemm3_split_grouped: NULL table");
+    if (n_items < 0 || total_blocks < 0 || total_blocks > 0x7fffffffLL) return mpf::fail(MPF_E_SHAPE, "gemm3_split_grouped: bad sizes");
+    mpf::set_kernel("gemm3_split_grouped_kernel");
+    hipLaunchKernelGGL(gemm3_split_grouped_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_device,
+                       n_items);
+    return mpf::check(hipGetLastError(), "mpf_gemm3_split_grouped");
 }
 
 extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2_rows, const void* b_planes,

@@ -22,7 +22,7 @@ import math
 import torch
 from torch.autograd import Function
 
-from .gemm3 import gemm3, gemm3_nt, nt_reduce, split_weight
+from .gemm3 import gemm3, gemm3_nt, nt_reduce, split_weights_grouped
 from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
 from .resln import ln256_backward, ln256_forward
 
@@ -71,26 +71,35 @@ class EncoderFn(Function):
         saved = []
         no = M * L * P * 2
         q = None
+        # bf16 planes of every weight, both orientations (W for forward, W^T for the input gradients), in ONE
+        # launch; sampling_offsets | attention_weights are stacked into one 288-row operand on the way
+        groups = []
+        for i in range(nl):
+            (wso, _, waw, _, wv, _, wo, _, _, _, w1, _, w2, _, _, _) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
+            ws = ([wv], [wso, waw], [wo], [w1], [w2])
+            groups += [(w_, False) for w_ in ws] + [(w_, True) for w_ in ws]
+        planes = split_weights_grouped(groups)
         for i in range(nl):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            w288 = torch.cat((wso, waw), 0)
+            pv, p288, po, p1, p2 = planes[10 * i:10 * i + 5]
             b288 = torch.cat((bso, baw), 0)
-            value = gemm3(x, split_weight(wv), bv)
+            value = gemm3(x, pv, bv)
             if q is None:       # layer 0; later layers get src + pos from the previous layer's norm2 pass
                 q = (x.view(N, S, C) + pos_full).view(R, C)
-            raw = gemm3(q, split_weight(w288), b288)
+            raw = gemm3(q, p288, b288)
             # softmax over the 12 logits, loc = ref + offset / (W_l, H_l) happen inside the MSDA kernel
             ao, loc, attn = ms_deform_attn_forward_raw(value.view(N, S, M, C // M), shapes, lsi, raw, ref)
             ao = ao.view(R, C)
-            s1 = gemm3(ao, split_weight(wo), bo, cin=x)
+            s1 = gemm3(ao, po, bo, cin=x)
             x1, mean1, rstd1, _ = ln256_forward(s1, g1, b1, _EPS)
-            h = gemm3(x1, split_weight(w1), bb1, relu=True)
-            s2 = gemm3(h, split_weight(w2), bb2, cin=x1)
+            h = gemm3(x1, p1, bb1, relu=True)
+            s2 = gemm3(h, p2, bb2, cin=x1)
             x2, mean2, rstd2, qn = ln256_forward(s2, g2, b2, _EPS, padd=pos_full if i + 1 < nl else None)
             saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2]
             x, q = x2, qn
         ctx.save_for_backward(pos_full, level_embed, *params, *saved)
         ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
+        ctx.planes_t = [planes[10 * i + 5:10 * i + 10] for i in range(nl)]       # W^T planes for the backward
         return x.view(N, S, C)
 
     @staticmethod
@@ -122,20 +131,21 @@ class EncoderFn(Function):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2) = saved[i * 14:(i + 1) * 14]
             dp = [None] * PARAMS_PER_LAYER
+            tv, t288, to, t1, t2 = ctx.planes_t[i]
             # norm2 <- ffn
             ds2, dp[14], dp[15] = ln256_backward(s2, mean2, rstd2, g2, g, gq)
-            dh = gemm3(ds2, split_weight(w2, transpose=True), gate=h)
+            dh = gemm3(ds2, t2, gate=h)
             dp[12], dp[13] = _wgrad(ds2, h, rps)
-            dx1 = gemm3(dh, split_weight(w1, transpose=True), cin=ds2)
+            dx1 = gemm3(dh, t1, cin=ds2)
             dp[10], dp[11] = _wgrad(dh, x1, rps)
             # norm1 <- attention
             ds1, dp[8], dp[9] = ln256_backward(s1, mean1, rstd1, g1, dx1)
-            dao = gemm3(ds1, split_weight(wo, transpose=True))
+            dao = gemm3(ds1, to)
             dp[6], dp[7] = _wgrad(ds1, ao, rps)
             # d(raw): the softmax / offset-normaliser backward is the epilogue of the push kernel
             gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C))
             w288 = torch.cat((wso, waw), 0)
-            dq = gemm3(draw, split_weight(w288, transpose=True))
+            dq = gemm3(draw, t288)
             # dW288^T = q^T . draw (288 on the 96-wide tile side) + per-split column sums of draw: the
             # bias gradient and, summed per level, the level_embed gradient
             cpart, _, cs = gemm3_nt(q, draw, rps, want_csum_b=True, transpose_out=True)
@@ -150,7 +160,7 @@ class EncoderFn(Function):
             gv2 = gv.view(R, C)
             # grad wrt this layer's input: through value_proj + the residual; the (src + pos) path (dq)
             # joins inside the previous layer's norm2 backward (layer 0: added here)
-            g = gemm3(gv2, split_weight(wv, transpose=True), cin=ds1, cin2=dq if i == 0 else None)
+            g = gemm3(gv2, tv, cin=ds1, cin2=dq if i == 0 else None)
             gq = dq
             dp[4], dp[5] = _wgrad(gv2, x, rps)
             dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp

@@ -22,6 +22,40 @@ def split_weight(w, transpose=False):
     return out
 
 
+def split_weights_grouped(groups):
+    """Every operand of ``groups`` split in ONE launch.  groups: list of (sources, transpose) where sources
+    is a list of fp32 [rows_i, K] matrices stacked along dim 0 (one logical weight [sum rows_i, K]);
+    returns one planes tensor per group: [3, R, K] (transpose False) or [3, K, R] (the planes of W^T)."""
+    import numpy as np
+    from ._h2d import upload
+    dev = groups[0][0][0].device
+    sizes, tot = [], 0
+    for srcs, _ in groups:
+        n = sum(t.numel() for t in srcs)
+        sizes.append((tot, n))
+        tot += 3 * n
+    buf = torch.empty(tot, dtype=torch.bfloat16, device=dev)
+    base = buf.data_ptr()
+    rows_tab, blk, outs = [], 0, []
+    for (srcs, tr), (off, n) in zip(groups, sizes):
+        K = srcs[0].shape[1]
+        R = sum(t.shape[0] for t in srcs)
+        r0 = 0
+        for t in srcs:
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[1] == K
+            # rows r0.. of W (transpose False: rows of the output; True: columns of the output)
+            dst = base + 2 * (off + (r0 if tr else r0 * K))
+            rows_tab.append((t.data_ptr(), dst, t.shape[0], K, 1 if tr else 0, R if tr else K, n, blk))
+            blk += (t.numel() + 1023) // 1024
+            r0 += t.shape[0]
+        outs.append(buf[off:off + 3 * n].view((3, K, R) if tr else (3, R, K)))
+    items = upload(np.asarray(rows_tab, dtype=np.int64).reshape(-1), dev)
+    with torch.cuda.device(dev):
+        code = _lib.lib().mpf_gemm3_split_grouped(items.data_ptr(), len(rows_tab), blk, _stream(buf))
+    _lib.check(code, "mpf_gemm3_split_grouped")
+    return outs
+
+
 def _p(t):
     return t.data_ptr() if t is not None else None
 
