@@ -205,6 +205,7 @@ def main():
     n_pull, _, _ = _lib.profile_get("msda_bwd_pull")
     n_b = n_pull if n_pull else n_k          # calls (binned: 3 kernels per call; atomic path: 1)
     n_f, ms_f, by_f = _lib.profile_get("msda_fwd")
+    n_g, ms_g, _ = _lib.profile_get("gemm3_tn_kernel")
     _lib.profile_enable(False)
     S_tok = sum((a.size // s) ** 2 for s in (8, 16, 32))
     by_b = 1344.0 * 4 * S_tok * a.batch * n_b     # algorithmic bytes: SURVEY.md §8(d), fp32, per call
@@ -238,9 +239,17 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "launches": n_b, "avg_us": round(ms_b * 1e3 / max(n_b, 1), 1),
                          "algorithmic_bytes_per_launch": round(by_b / max(n_b, 1)),
-                         "also": {"kernel": "msda_fwd_tiled_f32", "launches": n_f,
-                                  "avg_us": round(ms_f * 1e3 / max(n_f, 1), 1),
-                                  "achieved": round(by_f / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0, 1)}},
+                         "also": [
+                             {"kernel": "msda_fwd_tiled_f32", "launches": n_f, "avg_us": round(ms_f * 1e3 / max(n_f, 1), 1),
+                              "bound": "hbm", "achieved": round(by_f / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0, 1), "unit": "GB/s"},
+                             # the largest native kernel by time: the encoder's fp32 Linear layers as 3xbf16 MFMA
+                             # products (csrc/gemm3.hip).  Algorithmic flops = 2*M*N*K of the fp32 GEMMs it
+                             # replaces (10 per encoder layer, forward + input gradients); peak = the dense fp32
+                             # MFMA rate (256 flops/clk/CU x 256 CUs x 2.4 GHz), which an fp32 GEMM is priced against
+                             {"kernel": "gemm3_tn_kernel", "launches": n_g, "avg_us": round(ms_g * 1e3 / max(n_g, 1), 1),
+                              "bound": "mfma", "unit": "TFLOP/s (fp32-equivalent)", "peak": 157.3,
+                              "achieved": round(4.0 * 729088 * 6 * S_tok * a.batch * a.steps / (ms_g * 1e-3) / 1e12, 1)
+                              if ms_g > 0 and n_g == 60 * a.steps else None}]},
             "cpu_baseline": None,
         }
         if world == 1 and not a.no_cpu_baseline:
