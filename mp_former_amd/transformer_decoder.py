@@ -452,8 +452,11 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
                 xi = F.conv2d(xi, W[f"input_proj.{i}.weight"], W[f"input_proj.{i}.bias"])
             s = (xi.flatten(2) + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1)
             k_in = s + p                 # key input, shared by the 3 layers that use this level
-            if amp:                      # one cast per level instead of one per use (9 uses each)
-                s, k_in = s.to(adt), k_in.to(adt)
+            if amp:                      # one cast per level instead of one per use (9 uses each); the cast also
+                # makes the [S, N, C] operands of the key / value projections row-contiguous (s and k_in are
+                # permuted views of [N, C, S] memory: left like that, every projection copies its input first)
+                s = s.to(adt, memory_format=torch.contiguous_format)
+                k_in = k_in.to(adt, memory_format=torch.contiguous_format)
             pos.append(p)
             src.append(s)
             kin.append(k_in)
