@@ -325,6 +325,19 @@ int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, const void* g
 int mpf_mask_block_empty(const uint8_t* masks, uint8_t* out, int T, int H, int W, int h, int w, void* stream);
 
 /*
+ * Decoder inputs of one feature level (mask2former_transformer_decoder.py:1756-1764: input_proj +
+ * level_embed, flatten, permute; the key input adds the sine position embedding, :100-112):
+ *   src[s, n, c] = x(n, c, s) + level_embed[c]        kin[s, n, c] = src[s, n, c] + pos[s, c]
+ * x(n, c, s) = x[n * sx_n + s * sx_s + c] fp32 (unit channel stride: a channel-last view of the encoder
+ * memory), pos [S, C] fp32; src / kin [S, N, C] row-contiguous, out_dtype MPF_BF16 (autocast) or MPF_F32.
+ * Backward: dx(n, c, s) = g_src[s, n, c] + g_kin[s, n, c] (either may be NULL), written with x's strides.
+ */
+int mpf_decoder_inputs_forward(const float* x, int64_t sx_n, int64_t sx_s, const float* level_embed, const float* pos,
+                               void* src, void* kin, int out_dtype, int S, int N, int C, void* stream);
+int mpf_decoder_inputs_backward(const void* g_src, const void* g_kin, int g_dtype, float* dx, int64_t sx_n, int64_t sx_s, int S,
+                                int N, int C, void* stream);
+
+/*
  * Linear sum assignment (the Hungarian step of HungarianMatcher.memory_efficient_forward, matcher.py:
  * 149-151, where the reference calls scipy.optimize.linear_sum_assignment on a host copy of the cost
  * matrix) solved on the device, one wavefront per problem, with SciPy's algorithm and tie-breaking

@@ -63,6 +63,9 @@ SIGNATURES = {
     "mpf_gemm3_nt_reduce": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, _c_vp, _c_vp, _c_vp]),
     "mpf_grouped_scale_cast": (_c_int, [_c_vp, _c_int, ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "mpf_gemm3_split_grouped": (_c_int, [_c_vp, _c_int, ctypes.c_int64, _c_vp]),
+    "mpf_decoder_inputs_forward": (_c_int, [_c_vp, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int,
+                                            _c_vp]),
+    "mpf_decoder_inputs_backward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_bias_act": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_res_ln256_forward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
                                        _c_vp, _c_int, _c_vp, _c_vp]),

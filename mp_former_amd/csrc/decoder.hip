@@ -145,3 +145,140 @@ extern "C" int mpf_mask_block_empty(const uint8_t* masks, uint8_t* out, int T, i
     mpf::prof_end("block_empty_kernel", st, (double)T * H * W + (double)total);
     return mpf::check(hipGetLastError(), "mpf_mask_block_empty");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Decoder inputs of one feature level (mask2former_transformer_decoder.py:1756-1764): from the level's
+// feature map x (n, c, s) — here a channel-last VIEW of the encoder memory —
+//   src[s, n, c]  = x[n, c, s] + level_embed[c]               (value input of the cross-attention)
+//   kin[s, n, c]  = src[s, n, c] + pos[s, c]                   (key input: + sine position embedding)
+// both written sequence-first, row-contiguous, in the autocast dtype (bf16) or fp32: one pass instead of
+// two strided adds and two strided casts.  Backward: dx(n, c, s) = g_src[s, n, c] + g_kin[s, n, c].
+// Thread = 8 consecutive channels of one (s, n); x needs unit channel stride.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename TO>
+__device__ __forceinline__ void store8(TO* dst, const float (&v)[8]);
+
+template <>
+__device__ __forceinline__ void store8<float>(float* dst, const float (&v)[8])
+{
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+template <>
+__device__ __forceinline__ void store8<__hip_bfloat16>(__hip_bfloat16* dst, const float (&v)[8])
+{
+    unsigned w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const __hip_bfloat16 lo = __float2bfloat16(v[2 * j]), hi = __float2bfloat16(v[2 * j + 1]);
+        w[j] = (unsigned)(*reinterpret_cast<const unsigned short*>(&lo)) | ((unsigned)(*reinterpret_cast<const unsigned short*>(&hi)) << 16);
+    }
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void decoder_inputs_fwd_kernel(const float* __restrict__ x, int64_t sx_n, int64_t sx_s,
+                                                                 const float* __restrict__ level_embed, const float* __restrict__ pos,
+                                                                 TO* __restrict__ src, TO* __restrict__ kin, int S, int N, int C)
+{
+    const int c8 = C >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)S * N * c8) return;
+    const int cg = (int)(idx % c8);
+    const int n = (int)((idx / c8) % N);
+    const int s = (int)(idx / ((int64_t)c8 * N));
+    const float* xp = x + (int64_t)n * sx_n + (int64_t)s * sx_s + 8 * cg;
+    const float4 a0 = *reinterpret_cast<const float4*>(xp), a1 = *reinterpret_cast<const float4*>(xp + 4);
+    const float4 e0 = *reinterpret_cast<const float4*>(level_embed + 8 * cg), e1 = *reinterpret_cast<const float4*>(level_embed + 8 * cg + 4);
+    const float4 p0 = *reinterpret_cast<const float4*>(pos + (int64_t)s * C + 8 * cg), p1 = *reinterpret_cast<const float4*>(pos + (int64_t)s * C + 8 * cg + 4);
+    const float v[8] = {a0.x + e0.x, a0.y + e0.y, a0.z + e0.z, a0.w + e0.w, a1.x + e1.x, a1.y + e1.y, a1.z + e1.z, a1.w + e1.w};
+    const float k[8] = {v[0] + p0.x, v[1] + p0.y, v[2] + p0.z, v[3] + p0.w, v[4] + p1.x, v[5] + p1.y, v[6] + p1.z, v[7] + p1.w};
+    const int64_t o = ((int64_t)s * N + n) * C + 8 * cg;
+    store8<TO>(src + o, v);
+    store8<TO>(kin + o, k);
+}
+
+__device__ __forceinline__ void load8(const float* p, float (&v)[8])
+{
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+__device__ __forceinline__ void load8(const __hip_bfloat16* p, float (&v)[8])
+{
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = __uint_as_float(w[j] << 16);
+        v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+    }
+}
+
+template <typename TG>
+__global__ __launch_bounds__(256) void decoder_inputs_bwd_kernel(const TG* __restrict__ g_src, const TG* __restrict__ g_kin,
+                                                                 float* __restrict__ dx, int64_t sx_n, int64_t sx_s, int S, int N, int C)
+{
+    const int c8 = C >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)S * N * c8) return;
+    const int cg = (int)(idx % c8);
+    const int n = (int)((idx / c8) % N);
+    const int s = (int)(idx / ((int64_t)c8 * N));
+    const int64_t o = ((int64_t)s * N + n) * C + 8 * cg;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g_src) load8(g_src + o, a);
+    if (g_kin) load8(g_kin + o, b);
+    float* d = dx + (int64_t)n * sx_n + (int64_t)s * sx_s + 8 * cg;
+    *reinterpret_cast<float4*>(d) = make_float4(a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]);
+    *reinterpret_cast<float4*>(d + 4) = make_float4(a[4] + b[4], a[5] + b[5], a[6] + b[6], a[7] + b[7]);
+}
+
+}  // namespace
+
+extern "C" int mpf_decoder_inputs_forward(const float* x, int64_t sx_n, int64_t sx_s, const float* level_embed, const float* pos,
+                                          void* src, void* kin, int out_dtype, int S, int N, int C, void* stream)
+{
+    if (S == 0 || N == 0) return 0;
+    if (!x || !level_embed || !pos || !src || !kin) return mpf::fail(MPF_E_NULL, "decoder_inputs_forward: NULL buffer");
+    if (S < 0 || N < 0 || C <= 0 || C % 8 || sx_n % 4 || sx_s % 4 || ((uintptr_t)x & 15))
+        return mpf::fail(MPF_E_SHAPE, "decoder_inputs_forward: C % 8 == 0 and 16-B aligned rows (unit channel stride) required");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)S * N * (C / 8);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    mpf::set_kernel("decoder_inputs_fwd_kernel");
+    if (out_dtype == MPF_BF16)
+        hipLaunchKernelGGL(decoder_inputs_fwd_kernel<__hip_bfloat16>, grid, dim3(256), 0, st, x, sx_n, sx_s, level_embed, pos,
+                           (__hip_bfloat16*)src, (__hip_bfloat16*)kin, S, N, C);
+    else if (out_dtype == MPF_F32)
+        hipLaunchKernelGGL(decoder_inputs_fwd_kernel<float>, grid, dim3(256), 0, st, x, sx_n, sx_s, level_embed, pos, (float*)src,
+                           (float*)kin, S, N, C);
+    else
+        return mpf::fail(MPF_E_DTYPE, "decoder_inputs_forward: out dtype must be MPF_F32 or MPF_BF16");
+    return mpf::check(hipGetLastError(), "mpf_decoder_inputs_forward");
+}
+
+extern "C" int mpf_decoder_inputs_backward(const void* g_src, const void* g_kin, int g_dtype, float* dx, int64_t sx_n, int64_t sx_s,
+                                           int S, int N, int C, void* stream)
+{
+    if (S == 0 || N == 0) return 0;
+    if (!dx || (!g_src && !g_kin)) return mpf::fail(MPF_E_NULL, "decoder_inputs_backward: NULL buffer");
+    if (S < 0 || N < 0 || C <= 0 || C % 8 || sx_n % 4 || sx_s % 4 || ((uintptr_t)dx & 15))
+        return mpf::fail(MPF_E_SHAPE, "decoder_inputs_backward: C % 8 == 0 and 16-B aligned rows required");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)S * N * (C / 8);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    mpf::set_kernel("decoder_inputs_bwd_kernel");
+    if (g_dtype == MPF_BF16)
+        hipLaunchKernelGGL(decoder_inputs_bwd_kernel<__hip_bfloat16>, grid, dim3(256), 0, st, (const __hip_bfloat16*)g_src,
+                           (const __hip_bfloat16*)g_kin, dx, sx_n, sx_s, S, N, C);
+    else if (g_dtype == MPF_F32)
+        hipLaunchKernelGGL(decoder_inputs_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)g_src, (const float*)g_kin, dx,
+                           sx_n, sx_s, S, N, C);
+    else
+        return mpf::fail(MPF_E_DTYPE, "decoder_inputs_backward: gradient dtype must be MPF_F32 or MPF_BF16");
+    return mpf::check(hipGetLastError(), "mpf_decoder_inputs_backward");
+}

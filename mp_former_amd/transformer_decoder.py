@@ -83,6 +83,52 @@ class _CastParams(torch.autograd.Function):
         return (None, None, *res)
 
 
+class _DecoderInputs(torch.autograd.Function):
+    """(src, kin) [S, N, C] of one feature level from its map x [N, C, H, W] (a channel-last view), the level
+    embedding row and the [S, C] sine position embedding — one native pass each way (csrc/decoder.hip;
+    mask2former_transformer_decoder.py:1756-1764)."""
+
+    @staticmethod
+    def forward(ctx, x, level_row, pos_t, out_dtype):
+        N, C, H, W = x.shape
+        S = H * W
+        src = torch.empty((S, N, C), dtype=out_dtype, device=x.device)
+        kin = torch.empty((S, N, C), dtype=out_dtype, device=x.device)
+        dt = _lib.MPF_BF16 if out_dtype == torch.bfloat16 else _lib.MPF_F32
+        with torch.cuda.device(x.device):
+            code = _lib.lib().mpf_decoder_inputs_forward(x.data_ptr(), x.stride(0), x.stride(3), level_row.data_ptr(), pos_t.data_ptr(),
+                                                         src.data_ptr(), kin.data_ptr(), dt, S, N, C,
+                                                         torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(code, "mpf_decoder_inputs_forward")
+        ctx.dims = (N, C, H, W)
+        return src, kin
+
+    @staticmethod
+    def backward(ctx, g_src, g_kin):
+        N, C, H, W = ctx.dims
+        S = H * W
+        g = g_src if g_src is not None else g_kin
+        if g_src is not None and g_kin is not None and g_src.dtype != g_kin.dtype:
+            g_src, g_kin = g_src.float(), g_kin.float()
+            g = g_src
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g_src = g_src.float() if g_src is not None else None
+            g_kin = g_kin.float() if g_kin is not None else None
+            g = g_src if g_src is not None else g_kin
+        g_src = g_src.contiguous() if g_src is not None else None
+        g_kin = g_kin.contiguous() if g_kin is not None else None
+        mem = torch.empty((N, S, C), dtype=torch.float32, device=g.device)       # channel-last, like the input view
+        dt = _lib.MPF_BF16 if g.dtype == torch.bfloat16 else _lib.MPF_F32
+        with torch.cuda.device(g.device):
+            code = _lib.lib().mpf_decoder_inputs_backward(g_src.data_ptr() if g_src is not None else None,
+                                                          g_kin.data_ptr() if g_kin is not None else None, dt, mem.data_ptr(),
+                                                          S * C, C, S, N, C, torch.cuda.current_stream(g.device).cuda_stream)
+        _lib.check(code, "mpf_decoder_inputs_backward")
+        dx = mem.permute(0, 2, 1).view(N, C, H, W)
+        d_level = mem.sum((0, 1)) if ctx.needs_input_grad[1] else None
+        return dx, d_level, None, None
+
+
 def native_attn_mask(masks, size, mp_rows=None):
     """[N,Qtot,h,w] mask logits (f32/bf16) -> bool [N,Qtot,hl*wl] attention mask of the next layer:
     bilinear resize + (< 0) + MP-row overwrite + all-masked-row rule in one native kernel
@@ -251,6 +297,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         self.mask_classification = mask_classification
         self.head_dn, self.dn_ratio = head_dn, dn_ratio
         self.pe_layer = PositionEmbeddingSine(hidden_dim // 2, normalize=True)
+        self._pos_t = {}            # [S, C] transposes of the cached position embeddings, per (H, W, device)
         self.dn_label_noise_ratio = dn_label_noise_ratio
         self.num_heads, self.num_classes, self.num_layers = nheads, num_classes, dec_layers
         self.dn_mode = dn_mode
@@ -443,21 +490,31 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         W = self._weights()
         amp = torch.is_autocast_enabled() and x[0].is_cuda
         adt = torch.get_autocast_dtype("cuda") if amp else None
-        src, pos, kin, size_list = [], [], [], []
+        src, kin, size_list = [], [], []
         for i in range(self.num_feature_levels):
             size_list.append(tuple(x[i].shape[-2:]))
-            p = self.pe_layer(x[i]).flatten(2).permute(2, 0, 1)
             xi = x[i]
             if len(self.input_proj[i]._modules) or isinstance(self.input_proj[i], nn.Conv2d):   # 1x1 conv when channels differ
                 xi = F.conv2d(xi, W[f"input_proj.{i}.weight"], W[f"input_proj.{i}.bias"])
-            s = (xi.flatten(2) + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1)
-            k_in = s + p                 # key input, shared by the 3 layers that use this level
-            if amp:                      # one cast per level instead of one per use (9 uses each); the cast also
-                # makes the [S, N, C] operands of the key / value projections row-contiguous (s and k_in are
-                # permuted views of [N, C, S] memory: left like that, every projection copies its input first)
-                s = s.to(adt, memory_format=torch.contiguous_format)
-                k_in = k_in.to(adt, memory_format=torch.contiguous_format)
-            pos.append(p)
+            Hi, Wi = size_list[-1]
+            if (xi.is_cuda and xi.dtype == torch.float32 and xi.shape[1] % 8 == 0 and xi.stride(1) == 1 and xi.stride(2) == Wi * xi.stride(3)
+                    and xi.stride(3) % 4 == 0 and xi.stride(0) % 4 == 0 and xi.data_ptr() % 16 == 0
+                    and (not amp or adt == torch.bfloat16) and os.environ.get("MPF_DEC_INPUTS", "1") == "1"):
+                # the pixel decoder hands over channel-last views of the encoder memory: one native pass
+                key = (Hi, Wi, xi.device)
+                pos_t = self._pos_t.get(key)
+                if pos_t is None:
+                    pos_t = self.pe_layer(xi)[0].flatten(1).t().contiguous()          # [S, C]
+                    self._pos_t[key] = pos_t
+                s, k_in = _DecoderInputs.apply(xi, self.level_embed.weight[i], pos_t, adt if amp else torch.float32)
+            else:
+                p = self.pe_layer(xi).flatten(2).permute(2, 0, 1)
+                s = (xi.flatten(2) + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1)
+                k_in = s + p                 # key input, shared by the 3 layers that use this level
+                if amp:                      # one cast per level instead of one per use (9 uses each); the cast also
+                    # makes the [S, N, C] operands of the key / value projections row-contiguous
+                    s = s.to(adt, memory_format=torch.contiguous_format)
+                    k_in = k_in.to(adt, memory_format=torch.contiguous_format)
             src.append(s)
             kin.append(k_in)
         if amp:                          # one cast for the 10 prediction heads

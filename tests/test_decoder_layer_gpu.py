@@ -84,3 +84,39 @@ def test_mp_rows_block_empty_matches_area_interpolation(T, H, W, size):
     ref = F.interpolate(masks.float().unsqueeze(1), size=size, mode="area").flatten(1) <= 1e-8
     got = gt_block_or(masks, size)
     assert got.dtype == torch.bool and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_decoder_inputs_kernel_matches_torch(out_dtype):
+    """src = x + level_embed, kin = src + pos, sequence-first (mask2former_transformer_decoder.py:1756-1764), from a
+    channel-last view of a larger memory tensor, forward and backward"""
+    from mp_former_amd.transformer_decoder import _DecoderInputs
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    N, C, H, W = 2, 256, 12, 20
+    S = H * W
+    mem = torch.randn(N, 500, C, device=dev)                   # this level = rows 100 .. 100 + S of the encoder memory
+    base = mem[:, 100:100 + S].detach().clone().requires_grad_(True)
+    le = torch.randn(C, device=dev, requires_grad=True)
+    pos = torch.randn(C, H, W, device=dev)
+    pos_t = pos.flatten(1).t().contiguous()
+
+    def view(t):
+        return t.transpose(1, 2).reshape(N, C, H, W)
+
+    x = view(base)
+    assert x.stride(1) == 1
+    src, kin = _DecoderInputs.apply(x, le, pos_t, out_dtype)
+    g1 = torch.randn(S, N, C, device=dev).to(out_dtype)
+    g2 = torch.randn(S, N, C, device=dev).to(out_dtype)
+    torch.autograd.backward([src, kin], [g1, g2])
+    gb, gl = base.grad.clone(), le.grad.clone()
+    base.grad = None; le.grad = None
+    xr = view(base)
+    s_ref = (xr.flatten(2) + le[None, :, None]).permute(2, 0, 1)
+    k_ref = s_ref + pos.flatten(1).t()[:, None, :]
+    s_c, k_c = s_ref.to(out_dtype), k_ref.to(out_dtype)
+    assert torch.equal(src, s_c) and torch.equal(kin, k_c) and src.is_contiguous() and kin.is_contiguous()
+    torch.autograd.backward([s_c, k_c], [g1, g2])
+    torch.testing.assert_close(gb, base.grad, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(gl, le.grad, rtol=1e-4, atol=1e-3)
