@@ -98,6 +98,10 @@ def build_optimizer(model):
                 wd = 0.0
             buckets.setdefault((lr, wd), []).append(p)   # 4 groups -> 4 fused multi-tensor launches
     groups = [{"params": ps, "lr": lr, "weight_decay": wd} for (lr, wd), ps in buckets.items()]
+    if os.environ.get("MPF_NATIVE_OPTIM", "1") == "1":
+        # full-model clip (CLIP_VALUE 0.01, train_net.py:316-320) + AdamW in three native launches
+        from mp_former_amd.optim import ClipAdamW
+        return ClipAdamW(groups, lr=1e-4, max_norm=0.01)
     return torch.optim.AdamW(groups, lr=1e-4, fused=True)
 
 
@@ -178,7 +182,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = ddp(images, targets)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 0.01, foreach=True)   # full-model clip (train_net.py:316-320)
+        if not hasattr(opt, "max_norm"):      # stock AdamW: separate full-model clip (train_net.py:316-320)
+            torch.nn.utils.clip_grad_norm_(params, 0.01, foreach=True)
         opt.step()
         return loss
 

@@ -468,6 +468,29 @@ typedef struct MpfSplitItem {
 int mpf_gemm3_split_grouped(const MpfSplitItem* items_device, int n_items, int64_t total_blocks, void* stream);
 
 /*
+ * Optimizer tail: full-model gradient-norm clipping + AdamW over ALL parameters in three launches — the
+ * reference's FullModelGradientClippingOptimizer around torch.optim.AdamW (train_net.py:259-337,
+ * :316-320: clip_grad_norm_(all params, CLIP_VALUE) then AdamW.step()).  Same arithmetic as
+ * torch.nn.utils.clip_grad_norm_ (clip = min(1, max_norm / (norm + 1e-6))) followed by torch's AdamW
+ * (decoupled weight decay; per-parameter bias corrections bc1 = 1 - beta1^step, bc2_sqrt = sqrt(1 -
+ * beta2^step) from the parameter's own step count); the clipped gradients are applied on the fly, not
+ * written back.  Item i = one parameter (fp32, dense): workgroups [first_block, first_block +
+ * ceil(numel / 2048)), first_block ascending from 0.  partial: >= total_blocks floats of scratch;
+ * norm_clip[2] receives {gradient norm, clip coefficient}.  max_norm <= 0 disables clipping.
+ */
+typedef struct MpfOptItem {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t numel, first_block;
+    float lr, weight_decay, bc1, bc2_sqrt;
+} MpfOptItem;
+
+int mpf_clip_adamw_step(const MpfOptItem* items_device, int n_items, int64_t total_blocks, float max_norm, double beta1,
+                        double beta2, double eps, float* partial, float* norm_clip, void* stream);
+
+/*
  * Sum of the split partials of mpf_gemm3_nt in one launch and a fixed order: c_out[j] = sum_s
  * c_part[s][j] (j < c_numel) and s_out[j] = sum_s s_part[s][j] (j < s_numel; s_numel may be 0).
  */

@@ -383,3 +383,106 @@ extern "C" int mpf_grouped_scale_cast(const MpfScaleCastItem* items_device, int 
         return mpf::fail(MPF_E_DTYPE, "grouped_scale_cast: (src, dst) must be (f32, bf16), (bf16, f32) or (f32, f32)");
     return mpf::check(hipGetLastError(), "mpf_grouped_scale_cast");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer tail: full-model gradient-norm clipping + AdamW of the reference's
+// FullModelGradientClippingOptimizer (train_net.py:316-320 around torch.optim.AdamW, :259-337) in three
+// launches over ALL parameters: squared-norm partials per 2048-element block, a one-workgroup
+// fixed-order reduction that also derives clip = min(1, max_norm / (norm + 1e-6)), and the AdamW update
+// reading `clip` from device memory (so nothing synchronises and the clipped gradients are never written).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kOptBlock = 2048;
+
+__device__ __forceinline__ const MpfOptItem& opt_item_of(const MpfOptItem* __restrict__ items, int n_items, int64_t blk)
+{
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    return items[lo];
+}
+
+__global__ __launch_bounds__(256) void opt_sqnorm_kernel(const MpfOptItem* __restrict__ items, int n_items, float* __restrict__ partial)
+{
+    __shared__ float red[4];
+    const MpfOptItem& it = opt_item_of(items, n_items, blockIdx.x);
+    const float* __restrict__ g = it.grad;
+    const int64_t base = ((int64_t)blockIdx.x - it.first_block) * kOptBlock;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kOptBlock / 256; ++k) {
+        const int64_t e = base + (int64_t)k * 256 + threadIdx.x;
+        const float v = e < it.numel ? g[e] : 0.f;
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[0] = total gradient norm, out[1] = clip coefficient
+__global__ __launch_bounds__(1024) void opt_clip_coef_kernel(const float* __restrict__ partial, int64_t n, float max_norm, float* __restrict__ out)
+{
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        const float norm = (float)sqrt(t);
+        out[0] = norm;
+        out[1] = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void opt_adamw_kernel(const MpfOptItem* __restrict__ items, int n_items, const float* __restrict__ clip,
+                                                        float one_minus_beta1, float beta2, float one_minus_beta2, float eps)
+{
+    const MpfOptItem& it = opt_item_of(items, n_items, blockIdx.x);
+    float* __restrict__ p = it.param;
+    const float* __restrict__ g = it.grad;
+    float* __restrict__ m = it.exp_avg;
+    float* __restrict__ v = it.exp_avg_sq;
+    const float c = clip ? clip[1] : 1.0f;
+    const float decay = 1.0f - it.lr * it.weight_decay, step_size = it.lr / it.bc1, bc2_sqrt = it.bc2_sqrt;
+    const int64_t base = ((int64_t)blockIdx.x - it.first_block) * kOptBlock;
+#pragma unroll
+    for (int k = 0; k < kOptBlock / 256; ++k) {
+        const int64_t e = base + (int64_t)k * 256 + threadIdx.x;
+        if (e < it.numel) {
+            const float gr = g[e] * c;
+            float pe = p[e] * decay;
+            const float me = m[e] + (gr - m[e]) * one_minus_beta1;         // lerp, as torch's fused kernel
+            const float ve = beta2 * v[e] + one_minus_beta2 * gr * gr;
+            const float denom = sqrtf(ve) / bc2_sqrt + eps;
+            pe -= step_size * (me / denom);
+            p[e] = pe; m[e] = me; v[e] = ve;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mpf_clip_adamw_step(const MpfOptItem* items_device, int n_items, int64_t total_blocks, float max_norm, double beta1,
+                                   double beta2, double eps, float* partial, float* norm_clip, void* stream)
+{
+    if (n_items == 0 || total_blocks == 0) return 0;
+    if (!items_device || !partial || !norm_clip) return mpf::fail(MPF_E_NULL, "clip_adamw_step: NULL buffer");
+    if (n_items < 0 || total_blocks < 0 || total_blocks > 0x7fffffffLL) return mpf::fail(MPF_E_SHAPE, "clip_adamw_step: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    mpf::set_kernel("opt_adamw_kernel");
+    hipLaunchKernelGGL(opt_sqnorm_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, items_device, n_items, partial);
+    hipLaunchKernelGGL(opt_clip_coef_kernel, dim3(1), dim3(1024), 0, st, partial, total_blocks, max_norm, norm_clip);
+    // the coefficients are formed in double like torch's (1 - 0.999f would be off by 5e-5 relative)
+    hipLaunchKernelGGL(opt_adamw_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, items_device, n_items, norm_clip,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
+    return mpf::check(hipGetLastError(), "mpf_clip_adamw_step");
+}
