@@ -79,10 +79,12 @@ class EncoderFn(Function):
             ws = ([wv], [wso, waw], [wo], [w1], [w2])
             groups += [(w_, False) for w_ in ws] + [(w_, True) for w_ in ws]
         planes = split_weights_grouped(groups)
+        # the 288-wide bias of every layer in one concatenation
+        b288_all = torch.cat([params[i * PARAMS_PER_LAYER + k] for i in range(nl) for k in (1, 3)]).view(nl, -1)
         for i in range(nl):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             pv, p288, po, p1, p2 = planes[10 * i:10 * i + 5]
-            b288 = torch.cat((bso, baw), 0)
+            b288 = b288_all[i]
             value = gemm3(x, pv, bv)
             if q is None:       # layer 0; later layers get src + pos from the previous layer's norm2 pass
                 q = (x.view(N, S, C) + pos_full).view(R, C)
@@ -116,7 +118,6 @@ class EncoderFn(Function):
         saved = t[2 + nl * PARAMS_PER_LAYER:]
         g = gout.reshape(R, C).contiguous()
         no = M * L * P * 2
-        d_level = torch.zeros_like(level_embed)
         rps, aligned = rows_per_split(sizes)
         split_level = None
         if aligned:
@@ -126,6 +127,7 @@ class EncoderFn(Function):
                 split_level = meta["level_idx"][::rps].repeat(N)          # level of every split's rows
                 meta[key] = split_level
         dparams = [None] * (nl * PARAMS_PER_LAYER)
+        lvls = [None] * nl
         gq = None
         for i in reversed(range(nl)):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
@@ -144,7 +146,6 @@ class EncoderFn(Function):
             dp[6], dp[7] = _wgrad(ds1, ao, rps)
             # d(raw): the softmax / offset-normaliser backward is the epilogue of the push kernel
             gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C))
-            w288 = torch.cat((wso, waw), 0)
             dq = gemm3(draw, t288)
             # dW288^T = q^T . draw (288 on the 96-wide tile side) + per-split column sums of draw: the
             # bias gradient and, summed per level, the level_embed gradient
@@ -155,7 +156,7 @@ class EncoderFn(Function):
             else:
                 lvl = torch.stack([sl.sum((0, 1)) for sl in draw.view(N, S, -1).split(sizes, 1)])   # [L, 288]
             db288 = lvl.sum(0)
-            d_level += lvl @ w288
+            lvls[i] = lvl
             dp[0], dp[1], dp[2], dp[3] = dw288[:no], db288[:no], dw288[no:], db288[no:]
             gv2 = gv.view(R, C)
             # grad wrt this layer's input: through value_proj + the residual; the (src + pos) path (dq)
@@ -164,4 +165,7 @@ class EncoderFn(Function):
             gq = dq
             dp[4], dp[5] = _wgrad(gv2, x, rps)
             dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp
+        # d level_embed = sum_i lvl_i . [W_offsets_i ; W_weights_i]: one stacked product for all layers
+        w288_all = torch.cat([params[i * PARAMS_PER_LAYER + k] for i in range(nl) for k in (0, 2)]).view(nl, -1, C)
+        d_level = torch.bmm(torch.stack(lvls), w288_all).sum(0)
         return (g.view(N, S, C), None, d_level, None, *dparams)
