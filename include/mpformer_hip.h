@@ -491,6 +491,12 @@ int mpf_clip_adamw_step(const MpfOptItem* items_device, int n_items, int64_t tot
                         double beta2, double eps, float* partial, float* norm_clip, void* stream);
 
 /*
+ * out[b, c, r] = in[b, r, c] (fp32, R % 4 == 0, C % 4 == 0): the channels-last <-> NCHW relayout of the
+ * pixel decoder's convolution outputs around nn.GroupNorm (msdeformattn.py:245-281), LDS-tiled.
+ */
+int mpf_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream);
+
+/*
  * Sum of the split partials of mpf_gemm3_nt in one launch and a fixed order: c_out[j] = sum_s
  * c_part[s][j] (j < c_numel) and s_out[j] = sum_s s_part[s][j] (j < s_numel; s_numel may be 0).
  */

@@ -5,6 +5,8 @@ torch computes the per-(image, group) moments with one workgroup per row; at bat
 ``mpf_group_stats`` (rows cut into chunks, Chan merge), the affine apply is one element-wise pass, and the
 backward is aten's ``native_group_norm_backward`` on the saved mean / rstd.  Same parameters and state-dict
 keys as ``nn.GroupNorm``; other devices / dtypes / layouts take the stock implementation."""
+import os
+
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -20,6 +22,39 @@ def _workspace(device, nbytes):
         w = torch.empty(int(nbytes) + 1024, dtype=torch.uint8, device=device)
         _ws[device] = w
     return w
+
+
+def _transpose(src, B, R, C):
+    out = torch.empty(B * R * C, dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        code = _lib.lib().mpf_transpose_f32(src.data_ptr(), out.data_ptr(), B, R, C, torch.cuda.current_stream(src.device).cuda_stream)
+    _lib.check(code, "mpf_transpose_f32")
+    return out
+
+
+class _ToNCHW(Function):
+    """channels_last [N, C, H, W] -> contiguous NCHW (and back for the gradient) with the LDS-tiled native
+    transpose instead of aten's strided copy (150-180 us for a 134 MB map; ~50 us here)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        ctx.dims = (N, C, H, W)
+        return _transpose(x, N, H * W, C).view(N, C, H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.dims
+        g = g.contiguous()
+        return _transpose(g, N, C, H * W).view(N, H, W, C).permute(0, 3, 1, 2)
+
+
+def to_nchw(x):
+    if (x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)
+            and not x.is_contiguous() and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0
+            and os.environ.get("MPF_FAST_TRANSPOSE", "1") == "1"):
+        return _ToNCHW.apply(x)
+    return x.contiguous()
 
 
 class _GroupNormFn(Function):
@@ -59,7 +94,7 @@ class GroupNorm(nn.GroupNorm):
     def forward(self, x):
         C = x.shape[1]
         if x.is_cuda and x.dtype == torch.float32 and not x.is_contiguous():
-            x = x.contiguous()      # channels_last conv outputs: aten's GroupNorm makes the same NCHW copy first
+            x = to_nchw(x)          # channels_last conv outputs: aten's GroupNorm makes the same NCHW copy first
         if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and self.affine and x.dim() >= 3
                 and ((C // self.num_groups) * (x.numel() // (x.shape[0] * C))) % 4 == 0):
             return _GroupNormFn.apply(x, self.weight, self.bias, self.num_groups, self.eps)

@@ -60,3 +60,15 @@ def test_group_norm_matches_torch(shape):
     torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(gn.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(gn.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 16, 24), (1, 8, 2, 2), (2, 256, 64, 64), (3, 36, 10, 6)])
+def test_to_nchw_matches_contiguous(shape):
+    from mp_former_amd.groupnorm import to_nchw
+    torch.manual_seed(0)
+    x = torch.randn(shape, device="cuda:0").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = to_nchw(x)
+    assert y.is_contiguous() and torch.equal(y, x.detach().contiguous())
+    g = torch.randn(shape, device="cuda:0")
+    y.backward(g)
+    assert torch.equal(x.grad, g)
