@@ -491,10 +491,12 @@ int mpf_clip_adamw_step(const MpfOptItem* items_device, int n_items, int64_t tot
                         double beta2, double eps, float* partial, float* norm_clip, void* stream);
 
 /*
- * out[b, c, r] = in[b, r, c] (fp32, R % 4 == 0, C % 4 == 0): the channels-last <-> NCHW relayout of the
+ * out[b, c, r] = in[b, r, c] (fp32, R % 4 == 0, C % 4 == 0; batch strides in elements, the [R, C] / [C, R]
+ * matrices themselves dense): the channels-last <-> NCHW relayout of the
  * pixel decoder's convolution outputs around nn.GroupNorm (msdeformattn.py:245-281), LDS-tiled.
  */
-int mpf_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream);
+int mpf_transpose_f32(const float* in, int64_t in_batch_stride, float* out, int64_t out_batch_stride, int B, int R, int C,
+                      void* stream);
 
 /*
  * Sum of the split partials of mpf_gemm3_nt in one launch and a fixed order: c_out[j] = sum_s

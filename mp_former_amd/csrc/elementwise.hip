@@ -494,12 +494,13 @@ extern "C" int mpf_clip_adamw_step(const MpfOptItem* items_device, int n_items, 
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C)
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, int64_t in_bs, float* __restrict__ out,
+                                                            int64_t out_bs, int R, int C)
 {
     __shared__ float tile[64][65];
     const int b = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const float* src = in + (int64_t)b * R * C;
-    float* dst = out + (int64_t)b * R * C;
+    const float* src = in + (int64_t)b * in_bs;
+    float* dst = out + (int64_t)b * out_bs;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 float4 columns x 16 rows per pass
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -532,13 +533,16 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int mpf_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream)
+extern "C" int mpf_transpose_f32(const float* in, int64_t in_batch_stride, float* out, int64_t out_batch_stride, int B, int R, int C,
+                                 void* stream)
 {
     if (B == 0 || R == 0 || C == 0) return 0;
     if (!in || !out) return mpf::fail(MPF_E_NULL, "transpose_f32: NULL buffer");
-    if (B < 0 || R < 0 || C < 0 || B > 65535 || R % 4 || C % 4 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15))
+    if (B < 0 || R < 0 || C < 0 || B > 65535 || R % 4 || C % 4 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) || in_batch_stride % 4 ||
+        out_batch_stride % 4)
         return mpf::fail(MPF_E_SHAPE, "transpose_f32: R and C must be multiples of 4, buffers 16-B aligned, B <= 65535");
     mpf::set_kernel("transpose_f32_kernel");
-    hipLaunchKernelGGL(transpose_f32_kernel, dim3((C + 63) / 64, (R + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, in, out, R, C);
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((C + 63) / 64, (R + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, in, in_batch_stride,
+                       out, out_batch_stride, R, C);
     return mpf::check(hipGetLastError(), "mpf_transpose_f32");
 }

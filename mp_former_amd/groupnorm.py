@@ -24,10 +24,11 @@ def _workspace(device, nbytes):
     return w
 
 
-def _transpose(src, B, R, C):
+def _transpose(src, B, R, C, in_bs=None):
     out = torch.empty(B * R * C, dtype=torch.float32, device=src.device)
     with torch.cuda.device(src.device):
-        code = _lib.lib().mpf_transpose_f32(src.data_ptr(), out.data_ptr(), B, R, C, torch.cuda.current_stream(src.device).cuda_stream)
+        code = _lib.lib().mpf_transpose_f32(src.data_ptr(), R * C if in_bs is None else in_bs, out.data_ptr(), R * C, B, R, C,
+                                            torch.cuda.current_stream(src.device).cuda_stream)
     _lib.check(code, "mpf_transpose_f32")
     return out
 
@@ -40,7 +41,7 @@ class _ToNCHW(Function):
     def forward(ctx, x):
         N, C, H, W = x.shape
         ctx.dims = (N, C, H, W)
-        return _transpose(x, N, H * W, C).view(N, C, H, W)
+        return _transpose(x, N, H * W, C, x.stride(0)).view(N, C, H, W)
 
     @staticmethod
     def backward(ctx, g):
@@ -50,7 +51,10 @@ class _ToNCHW(Function):
 
 
 def to_nchw(x):
-    if (x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)
+    # channel-last planes (unit channel stride, dense [H*W, C] per image; the batch stride is free: a level of the
+    # encoder memory is such a view)
+    if (x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda and x.stride(1) == 1 and x.stride(3) == x.shape[1]
+            and x.stride(2) == x.shape[3] * x.shape[1] and x.stride(0) % 4 == 0
             and not x.is_contiguous() and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0
             and os.environ.get("MPF_FAST_TRANSPOSE", "1") == "1"):
         return _ToNCHW.apply(x)

@@ -18,7 +18,7 @@ from torch import nn
 from torch.nn.init import normal_
 
 from . import encoder_fused
-from .groupnorm import GroupNorm
+from .groupnorm import GroupNorm, to_nchw
 from .linear import linear_tall
 from .msda import MSDeformAttn, attach_host_shapes
 
@@ -304,7 +304,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
         for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
             x = features[f].float()
             cur_fpn = self.lateral_convs[idx](x)
-            y = cur_fpn + F.interpolate(out[-1], size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)
+            top = to_nchw(out[-1]) if os.environ.get("MPF_FPN_NCHW_TOP", "1") == "1" else out[-1]
+            y = cur_fpn + F.interpolate(top, size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)
             out.append(self.output_convs[idx](y))
         multi_scale_features = out[:self.maskformer_num_feature_levels]
         return self.mask_features(out[-1]), out[0], multi_scale_features
