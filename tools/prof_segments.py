@@ -34,7 +34,7 @@ for si in range(warmup, len(ends) - 1):
     i_decb = first(lambda n: "attn_bwd" in n, i_bwd)
     i_encb = first(lambda n: "msda_bwd_push" in n, i_decb)
     last_enc = max([i for i, n in enumerate(names) if "gemm3_nt" in n] or [i_encb])
-    i_opt = first(lambda n: "multi_tensor" in n and "Norm" in n, last_enc)
+    i_opt = first(lambda n: ("multi_tensor" in n and "Norm" in n) or "opt_sqnorm_kernel" in n, last_enc)
     cuts = [("backbone fwd", 0, i_pix), ("pixel decoder fwd", i_pix, i_dec), ("decoder fwd", i_dec, i_crit),
             ("criterion fwd (+matching)", i_crit, i_bwd), ("criterion bwd", i_bwd, i_decb), ("decoder bwd", i_decb, i_encb),
             ("encoder bwd", i_encb, last_enc + 1), ("input proj + backbone bwd", last_enc + 1, i_opt), ("clip + AdamW", i_opt, len(seg))]
