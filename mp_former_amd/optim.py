@@ -34,6 +34,8 @@ class ClipAdamW(torch.optim.Optimizer):
         if len(b) != 2:
             raise ValueError("ClipAdamW: betas and eps must be the same in every parameter group")
         self.max_norm = float(max_norm)
+        self._beta1, self._beta2 = (float(x) for x in self.param_groups[0]["betas"])
+        self._key = None
         self._scratch = None
         self.norm_clip = None          # device tensor [2] = (gradient norm, clip coefficient) of the last step
 
@@ -43,47 +45,84 @@ class ClipAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        rows, keep = [], []
-        blk = 0
-        dev = None
+        plist, glist = [], []
         for group in self.param_groups:
-            beta1, beta2 = group["betas"]
             for p in group["params"]:
-                g = p.grad
-                if g is None or p.numel() == 0:
-                    continue
-                if g.is_sparse:
-                    raise RuntimeError("ClipAdamW does not support sparse gradients")
-                if not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or not _dense(p):
-                    raise RuntimeError("mp_former_amd ClipAdamW: dense fp32 CUDA parameters only (no CPU fallback)")
-                if g.stride() != p.stride():          # the update is element-wise over raw memory: same layout needed
-                    g = torch.empty_like(p).copy_(g)
-                    keep.append(g)
-                st = self.state[p]
-                if not st:
-                    st["step"] = torch.zeros((), dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p)           # preserve_format: the parameter's layout
-                    st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
-                t = float(st["step"])
-                dev = p.device if dev is None else dev
-                if p.device != dev:
-                    raise RuntimeError("ClipAdamW: all parameters must live on one device")
-                rows.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), blk,
-                             group["lr"], group["weight_decay"], 1.0 - beta1 ** t, (1.0 - beta2 ** t) ** 0.5))
-                blk += (p.numel() + 2047) // 2048
-        if not rows:
+                if p.grad is not None and p.numel():
+                    plist.append((p, group))
+        if not plist:
             return loss
-        table = np.array(rows, dtype=_ITEM)
-        items = upload(table.view(np.int64).reshape(-1), dev)
+        key = tuple(id(p) for p, _ in plist)
+        if key != self._key:
+            self._build(plist, key)
+        keep = []
+        for p, _ in plist:
+            g = p.grad
+            if g.is_sparse:
+                raise RuntimeError("ClipAdamW does not support sparse gradients")
+            if g.dtype != torch.float32 or g.device != p.device:
+                raise RuntimeError("mp_former_amd ClipAdamW: fp32 gradients on the parameter's device only")
+            if g.stride() != p.stride():          # the update is element-wise over raw memory: same layout needed
+                g = torch.empty_like(p).copy_(g)
+                keep.append(g)
+            glist.append(g.data_ptr())
+        t = self._table
+        t["grad"] = glist
+        t["lr"] = [g["lr"] for g in self._groups]                 # schedulers rewrite these between steps
+        t["wd"] = [g["weight_decay"] for g in self._groups]
+        self._steps += 1.0
+        t["bc1"] = 1.0 - self._beta1 ** self._steps
+        t["bc2_sqrt"] = np.sqrt(1.0 - self._beta2 ** self._steps)
+        dev = plist[0][0].device
+        items = upload(t.view(np.int64).reshape(-1), dev)
+        blk = self._blocks
         if self._scratch is None or self._scratch.numel() < blk or self._scratch.device != dev:
             self._scratch = torch.empty(blk, dtype=torch.float32, device=dev)
         self.norm_clip = torch.empty(2, dtype=torch.float32, device=dev)
-        beta1, beta2 = self.param_groups[0]["betas"]
         with torch.cuda.device(dev):
-            code = _lib.lib().mpf_clip_adamw_step(items.data_ptr(), len(rows), blk, self.max_norm, beta1, beta2,
+            code = _lib.lib().mpf_clip_adamw_step(items.data_ptr(), len(plist), blk, self.max_norm, self._beta1, self._beta2,
                                                   self.param_groups[0]["eps"], self._scratch.data_ptr(),
                                                   self.norm_clip.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(code, "mpf_clip_adamw_step")
         return loss
 
+    def _build(self, plist, key):
+        """static part of the launch table (parameter / moment pointers, sizes, lr, weight decay) for this set of
+        parameters; rebuilt only when the set of parameters that have a gradient changes"""
+        self._sync_steps()
+        rows, blk, dev = [], 0, plist[0][0].device
+        steps = []
+        for p, group in plist:
+            if not p.is_cuda or p.dtype != torch.float32 or not _dense(p):
+                raise RuntimeError("mp_former_amd ClipAdamW: dense fp32 CUDA parameters only (no CPU fallback)")
+            if p.device != dev:
+                raise RuntimeError("ClipAdamW: all parameters must live on one device")
+            st = self.state[p]
+            if not st:
+                st["step"] = torch.zeros((), dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p)           # preserve_format: the parameter's layout
+                st["exp_avg_sq"] = torch.zeros_like(p)
+            steps.append(float(st["step"]))
+            rows.append((p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), blk,
+                         group["lr"], group["weight_decay"], 1.0, 1.0))
+            blk += (p.numel() + 2047) // 2048
+        self._table = np.array(rows, dtype=_ITEM)
+        self._steps = np.asarray(steps, dtype=np.float64)
+        self._plist = [p for p, _ in plist]
+        self._groups = [g for _, g in plist]
+        self._blocks = blk
+        self._key = key
+
+    def _sync_steps(self):
+        """write the host-side step counts back into the per-parameter state (state_dict layout of torch.optim.AdamW)"""
+        if self._key is not None:
+            for p, n in zip(self._plist, self._steps):
+                self.state[p]["step"] = torch.tensor(float(n), dtype=torch.float32)
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._key = None          # moments were replaced: rebuild the table on the next step

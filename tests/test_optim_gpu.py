@@ -28,6 +28,8 @@ def test_clip_adamw_matches_torch(max_norm):
         for p, q, g in zip(pa, pb, grads):
             p.grad = g.clone()
             q.grad = g.clone()
+        if it == 1:                       # a scheduler changes the learning rate between steps
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 5e-3
         if it == 2:                       # a parameter without gradient is skipped by both
             pa[4].grad = None
             pb[4].grad = None
