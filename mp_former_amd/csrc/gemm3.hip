@@ -443,6 +443,7 @@ struct G3N {
     float* csum_b;
     int64_t lda, ldb, ldb2;
     int R, Mdim, Ndim, b2_rows, rows_per_split, nsplit, tiles_m, tiles_n, ntiles, transpose_out;
+    unsigned a_bytes, b_bytes;      // sizes of the operands (for the buffer descriptors; both < 4 GiB)
 };
 
 // BF: the operands are bf16 matrices (p.a / p.b point to 2-byte elements): one plane, one product —
@@ -468,16 +469,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
     const int wr = wave >> 1, wc = wave & 1;
 
 
-    // staging maps: A units (kc, m) = (tid / 128 + {0, 2}, tid % 128); B units u = tid + {0, 256}
-    const int am = tid & 127, akc = tid >> 7;
+    // staging maps: A units (kc, m) = (tid / 128 + {0, 2}, tid % 128); B units u = tid + {0, 256}.
+    // The k-chunk of a thread is the same for its whole wave (kBM = 128 = two waves; BN = 128 likewise), so
+    // the row part of every load address is SCALAR: loads become "scalar row pointer + per-lane column"
+    // (global_load with an SGPR base), with no per-load 64-bit vector arithmetic.
+    const int am = tid & 127, akc = __builtin_amdgcn_readfirstlane(tid >> 7);
     const bool a_col_ok = m0 + am < p.Mdim;
-    const float* acol = p.a + min(m0 + am, p.Mdim - 1);
-    const unsigned short* acol16 = reinterpret_cast<const unsigned short*>(p.a) + min(m0 + am, p.Mdim - 1);
-    const unsigned short* bcol16[2];
-    int bn_[2], bkc_[2];
+    const int acolx = min(m0 + am, p.Mdim - 1);
+    int bn_[2], bkc_[2], bcolx[2];
     bool b_ok[2], b_col_ok[2];
-    const float* bcol[2];
-    const float* b2col[2];
     int b2row[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -485,47 +485,52 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
         b_ok[i] = u < kBunits;
         bn_[i] = u % BN;
         bkc_[i] = min(u / BN, 3);
+        if (BN == 128) bkc_[i] = __builtin_amdgcn_readfirstlane(bkc_[i]);
         b_col_ok[i] = b_ok[i] && n0 + bn_[i] < p.Ndim;
-        bcol[i] = p.b + min(n0 + bn_[i], p.Ndim - 1);
-        bcol16[i] = reinterpret_cast<const unsigned short*>(p.b) + min(n0 + bn_[i], p.Ndim - 1);
-        b2col[i] = p.b2 ? p.b2 + min(n0 + bn_[i], p.Ndim - 1) : nullptr;
+        bcolx[i] = min(n0 + bn_[i], p.Ndim - 1);
         b2row[i] = p.b2 ? (r_begin + bkc_[i] * 8) % p.b2_rows : 0;
     }
+    // buffer descriptors: voffset = the lane's column (bytes), soffset = the row (bytes, scalar when the k-chunk
+    // is wave-uniform); rows past the end of the matrix read as zero in hardware
+    constexpr int ES = BF ? 2 : 4;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
+    const int acolb = acolx * ES, bcolb0 = bcolx[0] * ES, bcolb1 = bcolx[1] * ES;
+    const int ldab = (int)p.lda * ES, ldbb = (int)p.ldb * ES;
+    auto ld = [&](const __amdgpu_buffer_rsrc_t rs, int colb, int rowb, bool uniform) -> float {
+        const int vo = uniform ? colb : colb + rowb, so = uniform ? rowb : 0;
+        if (BF) return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0) << 16);
+        return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+    };
 
     float xa0[8], xa1[8], xb0[8], xb1[8];
     float csa = 0.f, csb0 = 0.f, csb1 = 0.f;
     const bool want_csa = p.csum_a && tn == 0, want_csb = p.csum_b && tm == 0;
 
-// loads are UNCONDITIONAL (row index clamped, value masked): a load behind a run-time condition makes
-// hipcc branch around it and wait for it separately
-#define G3N_LOAD(r0)                                                                                   \
+// loads are UNCONDITIONAL; TAIL (the last, possibly partial, step of a split) masks the rows that belong to the
+// next split — rows past the matrix already read as zero
+#define G3N_LOAD(r0, TAIL)                                                                             \
     {                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
             const int ra0 = (r0) + akc * 8 + j, ra1 = ra0 + 16;                                        \
             const int rb0 = (r0) + bkc_[0] * 8 + j, rb1 = (r0) + bkc_[1] * 8 + j;                      \
-            float va0, va1, vb0, vb1;                                                                  \
-            if (BF) {                                                                                  \
-                va0 = __uint_as_float((unsigned)acol16[(int64_t)min(ra0, r_end - 1) * p.lda] << 16);   \
-                va1 = __uint_as_float((unsigned)acol16[(int64_t)min(ra1, r_end - 1) * p.lda] << 16);   \
-                vb0 = __uint_as_float((unsigned)bcol16[0][(int64_t)min(rb0, r_end - 1) * p.ldb] << 16); \
-                vb1 = __uint_as_float((unsigned)bcol16[1][(int64_t)min(rb1, r_end - 1) * p.ldb] << 16); \
-            } else {                                                                                   \
-                va0 = acol[(int64_t)min(ra0, r_end - 1) * p.lda];                                      \
-                va1 = acol[(int64_t)min(ra1, r_end - 1) * p.lda];                                      \
-                vb0 = bcol[0][(int64_t)min(rb0, r_end - 1) * p.ldb];                                   \
-                vb1 = bcol[1][(int64_t)min(rb1, r_end - 1) * p.ldb];                                   \
-            }                                                                                          \
+            float va0 = ld(ars, acolb, ra0 * ldab, true), va1 = ld(ars, acolb, ra1 * ldab, true);      \
+            float vb0 = ld(brs, bcolb0, rb0 * ldbb, BN == 128), vb1 = ld(brs, bcolb1, rb1 * ldbb, BN == 128); \
             if (!BF && p.b2) {                                                                         \
                 int q0 = b2row[0] + j, q1 = b2row[1] + j;                                              \
                 q0 = q0 >= p.b2_rows ? q0 - p.b2_rows : q0;                                            \
                 q1 = q1 >= p.b2_rows ? q1 - p.b2_rows : q1;                                            \
-                vb0 += b2col[0][(int64_t)q0 * p.ldb2];                                                 \
-                vb1 += b2col[1][(int64_t)q1 * p.ldb2];                                                 \
+                vb0 += (p.b2 + (int64_t)q0 * p.ldb2)[bcolx[0]];                                        \
+                vb1 += (p.b2 + (int64_t)q1 * p.ldb2)[bcolx[1]];                                        \
             }                                                                                          \
-            xa0[j] = ra0 < r_end ? va0 : 0.f;                                                          \
-            xa1[j] = ra1 < r_end ? va1 : 0.f;                                                          \
-            xb0[j] = rb0 < r_end ? vb0 : 0.f;                                                          \
-            xb1[j] = (b_ok[1] && rb1 < r_end) ? vb1 : 0.f;                                             \
+            if (TAIL) {                                                                                \
+                va0 = ra0 < r_end ? va0 : 0.f;                                                         \
+                va1 = ra1 < r_end ? va1 : 0.f;                                                         \
+                vb0 = rb0 < r_end ? vb0 : 0.f;                                                         \
+                vb1 = rb1 < r_end ? vb1 : 0.f;                                                         \
+            }                                                                                          \
+            xa0[j] = va0; xa1[j] = va1; xb0[j] = vb0;                                                  \
+            xb1[j] = b_ok[1] ? vb1 : 0.f;                                                              \
         }                                                                                              \
         if (!BF && p.b2) {                                                                             \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
     const int a_frag = wr * 64 * 16;
     const int b_frag = kAbytes + wc * (BN / 2) * 16;
 
-    G3N_LOAD(r_begin);
+    if (r_begin + kBK <= r_end) G3N_LOAD(r_begin, false) else G3N_LOAD(r_begin, true);
     for (int r0 = r_begin; r0 < r_end; r0 += kBK) {
         __syncthreads();
         {
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
             }
         }
         __syncthreads();
-        if (r0 + kBK < r_end) G3N_LOAD(r0 + kBK);
+        if (r0 + 2 * kBK <= r_end) G3N_LOAD(r0 + kBK, false) else if (r0 + kBK < r_end) G3N_LOAD(r0 + kBK, true);
         acc.template step<kAKc, kBKc, BF>(lds, a_frag, b_frag, lane);
     }
 
@@ -759,6 +764,12 @@ extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t
     p.R = R; p.Mdim = Mdim; p.Ndim = Ndim; p.b2_rows = b2_rows; p.rows_per_split = rows_per_split;
     p.nsplit = (R + rows_per_split - 1) / rows_per_split;
     p.transpose_out = transpose_out;
+    {
+        const uint64_t ab = ((uint64_t)(R - 1) * lda + Mdim) * 4, bb = ((uint64_t)(R - 1) * ldb + Ndim) * 4;
+        if (ab >= (1ull << 32) || bb >= (1ull << 32) || lda * 4 >= (1ll << 31) || ldb * 4 >= (1ll << 31))
+            return mpf::fail(MPF_E_TOO_LARGE, "gemm3_nt: an operand spans 4 GiB or more");
+        p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    }
     p.tiles_m = (Mdim + kBM - 1) / kBM;
     const int waste128 = ((Ndim + 127) / 128) * 128 - Ndim, waste96 = ((Ndim + 95) / 96) * 96 - Ndim;
     const bool use96 = waste96 < waste128;
@@ -847,6 +858,11 @@ extern "C" int mpf_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64
     p.lda = lda; p.ldb = ldb; p.ldb2 = 0;
     p.R = R; p.Mdim = Mdim; p.Ndim = Ndim; p.b2_rows = 0; p.rows_per_split = rows_per_split;
     p.transpose_out = 0;
+    {
+        const uint64_t ab = ((uint64_t)(R - 1) * lda + Mdim) * 2, bb = ((uint64_t)(R - 1) * ldb + Ndim) * 2;
+        if (ab >= (1ull << 32) || bb >= (1ull << 32)) return mpf::fail(MPF_E_TOO_LARGE, "gemm_nt_bf16: an operand spans 4 GiB or more");
+        p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    }
     p.tiles_m = (Mdim + kBM - 1) / kBM;
     p.tiles_n = (Ndim + 127) / 128;
     p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
