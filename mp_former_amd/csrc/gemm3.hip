@@ -491,7 +491,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
         b2row[i] = p.b2 ? (r_begin + bkc_[i] * 8) % p.b2_rows : 0;
     }
     // buffer descriptors: voffset = the lane's column (bytes), soffset = the row (bytes, scalar when the k-chunk
-    // is wave-uniform); rows past the end of the matrix read as zero in hardware
+    // is wave-uniform)
     constexpr int ES = BF ? 2 : 4;
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
@@ -507,15 +507,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
     float csa = 0.f, csb0 = 0.f, csb1 = 0.f;
     const bool want_csa = p.csum_a && tn == 0, want_csb = p.csum_b && tm == 0;
 
-// loads are UNCONDITIONAL; TAIL (the last, possibly partial, step of a split) masks the rows that belong to the
-// next split — rows past the matrix already read as zero
+// loads are UNCONDITIONAL; TAIL (the last, possibly partial, step of a split) clamps the row (never reads
+// past the matrix) and masks the rows that are not this split's
 #define G3N_LOAD(r0, TAIL)                                                                             \
     {                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                \
             const int ra0 = (r0) + akc * 8 + j, ra1 = ra0 + 16;                                        \
             const int rb0 = (r0) + bkc_[0] * 8 + j, rb1 = (r0) + bkc_[1] * 8 + j;                      \
-            float va0 = ld(ars, acolb, ra0 * ldab, true), va1 = ld(ars, acolb, ra1 * ldab, true);      \
-            float vb0 = ld(brs, bcolb0, rb0 * ldbb, BN == 128), vb1 = ld(brs, bcolb1, rb1 * ldbb, BN == 128); \
+            const int ca0 = TAIL ? min(ra0, r_end - 1) : ra0, ca1 = TAIL ? min(ra1, r_end - 1) : ra1;  \
+            const int cb0 = TAIL ? min(rb0, r_end - 1) : rb0, cb1 = TAIL ? min(rb1, r_end - 1) : rb1;  \
+            float va0 = ld(ars, acolb, ca0 * ldab, true), va1 = ld(ars, acolb, ca1 * ldab, true);      \
+            float vb0 = ld(brs, bcolb0, cb0 * ldbb, BN == 128), vb1 = ld(brs, bcolb1, cb1 * ldbb, BN == 128); \
             if (!BF && p.b2) {                                                                         \
                 int q0 = b2row[0] + j, q1 = b2row[1] + j;                                              \
                 q0 = q0 >= p.b2_rows ? q0 - p.b2_rows : q0;                                            \
