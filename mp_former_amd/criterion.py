@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _rng
-from .dist import global_num_masks
+from .dist import distributed, global_num_masks, global_num_masks_device
 from .matcher import GTMasks
 from ._h2d import upload
 from .lsa import MAX_DIM as LSA_MAX_DIM, lsa_assign
@@ -101,7 +101,9 @@ class SetCriterion(nn.Module):
         dev = outs[0]["pred_logits"].device
         K = self.num_classes
         P = self.num_points
-        num_masks = global_num_masks(sum(len(t["labels"]) for t in targets), dev)   # criterion.py:224-237
+        n_local = sum(len(t["labels"]) for t in targets)
+        # criterion.py:224-237; across ranks the value stays on the device (no .item(): no host synchronisation)
+        num_masks = global_num_masks_device(n_local, dev) if distributed() else global_num_masks(n_local, dev)
 
         use_dn = bool(self.training and dn_out)
         dn_outs = []
@@ -216,9 +218,12 @@ class SetCriterion(nn.Module):
                 per_mask = sums[:, 0] / P                                                  # mean_p BCE (criterion.py:48-65)
                 per_dice = 1 - (2 * sums[:, 1] + 1) / (sums[:, 2] + sums[:, 3] + 1)        # criterion.py:21-40
                 z = torch.zeros(G, dtype=torch.float32, device=dev)
-                norm = torch.full((G,), float(num_masks), device=dev)
-                if use_dn:
-                    norm[L:] = float(num_masks * scalar)
+                if torch.is_tensor(num_masks):
+                    norm = num_masks * upload([1.0] * L + ([float(scalar)] * L if use_dn else []), dev, torch.float32)
+                else:
+                    norm = torch.full((G,), float(num_masks), device=dev)
+                    if use_dn:
+                        norm[L:] = float(num_masks * scalar)
                 g_mask = z.index_add(0, gid_d, per_mask) / norm
                 g_dice = z.index_add(0, gid_d, per_dice) / norm
             else:

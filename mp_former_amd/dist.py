@@ -41,6 +41,21 @@ def global_num_masks(local_count, device):
     return max(n / ws, 1.0)
 
 
+def global_num_masks_device(local_count, device):
+    """The same value as a [1] tensor on ``device`` WITHOUT synchronising the host: the count goes up through
+    pinned staging, the all-reduce is enqueued on the stream and the clamp runs on the device.  The reference
+    (criterion.py:236-237) and ``global_num_masks`` call ``.item()``, which drains the stream once per step on
+    every rank — the only host synchronisation the multi-GPU step would have left."""
+    if device.type == "cuda":
+        from ._h2d import upload
+        t = upload([float(local_count)], device, torch.float32)
+    else:
+        t = torch.tensor([float(local_count)], dtype=torch.float32, device=device)
+    if distributed():
+        dist.all_reduce(t)
+    return (t / world_size()).clamp_(min=1.0)
+
+
 def max_over_ranks(value, device):
     """MAX all-reduce of a python float (bench.py: step time = slowest rank)."""
     if not distributed():

@@ -28,6 +28,7 @@ def _worker(rank, world, port, q):
     out["num_masks"] = mdist.global_num_masks([3, 8][rank], dev)
     # clamp: no GT anywhere -> 1
     out["num_masks_empty"] = mdist.global_num_masks(0, dev)
+    out["num_masks_dev"] = float(mdist.global_num_masks_device([3, 8][rank], dev))      # the no-sync form of the criterion
     out["max"] = mdist.max_over_ranks([0.25, 0.75][rank], dev)
     # DDP: gradients are averaged over ranks
     torch.manual_seed(0)
@@ -65,6 +66,7 @@ def test_world2_gloo():
     for r in range(2):
         assert res[r]["num_masks"] == pytest.approx(5.5)
         assert res[r]["num_masks_empty"] == 1.0
+        assert res[r]["num_masks_dev"] == pytest.approx(5.5)
         assert res[r]["max"] == pytest.approx(0.75)
         torch.testing.assert_close(torch.tensor(res[r]["grad"]), torch.tensor(res[r]["grad_ref"]))
     torch.testing.assert_close(torch.tensor(res[0]["grad"]), torch.tensor(res[1]["grad"]))

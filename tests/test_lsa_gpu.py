@@ -135,3 +135,30 @@ def test_criterion_device_assignment_equals_host_route():
     for n in g_host:
         a, b = g_host[n].double(), g_dev[n].double()
         assert (a - b).norm().item() <= 1e-4 * (a.norm().item() + 1e-12), n
+
+
+def test_criterion_device_num_masks_path(monkeypatch):
+    """multi-GPU form of the loss normaliser (num_masks kept on the device, no .item()): same losses"""
+    from conftest import fifo_to_tags, load_head_fixture
+    from test_head_gpu import _build
+    from mp_former_amd import _rng
+    import mp_former_amd.criterion as crit
+    dev = torch.device("cuda:0")
+    z, cfg, pp, dp, feats, targets, replay = load_head_fixture("head_small")
+    h = _build(cfg, pp, dp, dev)
+    feats = {k: v.to(dev) for k, v in feats.items()}
+    targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+
+    def run():
+        _rng.install_replay(fifo_to_tags(replay, cfg, True))
+        try:
+            losses, _ = h(feats, targets)
+        finally:
+            _rng.install_replay(None)
+        return {k: float(v.detach()) for k, v in losses.items()}
+
+    ref = run()
+    monkeypatch.setattr(crit, "distributed", lambda: True)       # world size stays 1: same value, tensor route
+    got = run()
+    for k in ref:
+        assert abs(ref[k] - got[k]) <= 1e-5 * max(1.0, abs(ref[k])), (k, ref[k], got[k])
