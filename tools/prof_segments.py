@@ -8,7 +8,7 @@ with open(trace) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-adam = [i for i, (s, e, n) in enumerate(rows) if "FusedAdam" in n]
+adam = [i for i, (s, e, n) in enumerate(rows) if ("FusedAdam" in n or "opt_adamw_kernel" in n)]
 # last FusedAdam launch of each step = step end
 ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or rows[adam[i + 1]][0] - rows[adam[i]][1] > 5e6]
 acc = collections.OrderedDict()
