@@ -162,3 +162,48 @@ def test_criterion_device_num_masks_path(monkeypatch):
     got = run()
     for k in ref:
         assert abs(ref[k] - got[k]) <= 1e-5 * max(1.0, abs(ref[k])), (k, ref[k], got[k])
+
+
+@pytest.mark.parametrize("counts", [(12, 0), (0, 0), (1, 25), (10, 10)])
+def test_criterion_device_assignment_edge_counts(counts):
+    """no ground truth in an image / in the batch, more targets than queries (T > Q: every query matched), T == Q:
+    device solver == host SciPy route, with fresh (seeded) draws"""
+    import os
+    from mp_former_amd.head import MPFormerHead
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    h = MPFormerHead(num_classes=7, num_queries=10, enc_layers=1, dec_layers=2, num_points=112).to(dev).train()
+    size = 64
+    feats = {k: torch.randn(2, c, size // s, size // s, device=dev) for k, (c, s) in
+             {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}.items()}
+    g = torch.Generator().manual_seed(1)
+    targets = []
+    for T in counts:
+        masks = torch.zeros(T, size, size, dtype=torch.bool)
+        for t in range(T):
+            y0, x0 = int(torch.randint(0, size - 8, (1,), generator=g)), int(torch.randint(0, size - 8, (1,), generator=g))
+            masks[t, y0:y0 + 4 + t % 5, x0:x0 + 3 + t % 7] = True
+        targets.append({"labels": torch.randint(0, 7, (T,), generator=g).to(dev), "masks": masks.to(dev),
+                        "boxes": torch.zeros(T, 4, device=dev)})
+
+    def run(device_lsa):
+        os.environ["MPF_DEVICE_LSA"] = "1" if device_lsa else "0"
+        torch.manual_seed(123)
+        h.zero_grad(set_to_none=True)
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                losses, _ = h(feats, targets)
+            total = sum(losses.values())
+            total.backward()
+        finally:
+            os.environ.pop("MPF_DEVICE_LSA", None)
+        grads = torch.cat([p.grad.flatten().float() for p in h.parameters() if p.grad is not None])
+        return {k: float(v.detach()) for k, v in losses.items()}, grads
+
+    l_host, g_host = run(False)
+    l_dev, g_dev = run(True)
+    assert set(l_host) == set(l_dev) and len(l_dev) == 6 * 3
+    for k in l_host:
+        assert abs(l_host[k] - l_dev[k]) <= 2e-3 * max(1.0, abs(l_host[k])), (k, l_host[k], l_dev[k])
+    assert torch.isfinite(g_dev).all()
+    assert (g_host - g_dev).norm().item() <= 2e-2 * (g_host.norm().item() + 1e-9)
