@@ -518,6 +518,19 @@ int mpf_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, voi
                      int Ndim, int rows_per_split, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * mpf_small_gemm_bf16 with BLOCKED operands — three [R, 256] buffers standing for one [R, 768] matrix (the
+ * q | k | v projections of nn.MultiheadAttention's packed in_proj, mask2former_transformer_decoder.py:42-52):
+ *   a_blk > 0: the 768-long dimension of A is cut into blocks of a_blk, a_bs elements apart — the contraction
+ *              index if A is contraction-contiguous (a_ks == 1; Kc % 32 == 0), the row index if it is
+ *              row-contiguous (a_rs == 1); gate is addressed like a;
+ *   c_blk > 0: output column j goes to c[(j / c_blk) * c_bs + i * ldc + j % c_blk] (c_in must be NULL).
+ * a_blk % 32 == 0, c_blk % 64 == 0; 0 = not blocked.
+ */
+int mpf_small_gemm_bf16_blocked(const void* a, int64_t a_rs, int64_t a_ks, int a_blk, int64_t a_bs, const void* gate, const void* b,
+                                int64_t b_rs, int64_t b_ks, const void* bias, const void* c_in, int64_t ldcin, void* c, int64_t ldc,
+                                int c_blk, int64_t c_bs, void* rowsum_a, int I, int J, int Kc, int relu, void* stream);
+
+/*
  * y = relu?(x + bias[c] + res) over a dense channel-last activation (channel = fastest dimension,
  * C % 8 == 0): the folded FrozenBatchNorm shift, the residual add and the ReLU of a ResNet
  * bottleneck (detectron2 BottleneckBlock, used by configs/coco/instance-segmentation/Base-COCO-

@@ -69,6 +69,9 @@ SIGNATURES = {
     "mpf_clip_adamw_step": (_c_int, [_c_vp, _c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                      _c_vp, _c_vp, _c_vp]),
     "mpf_transpose_f32": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
+    "mpf_small_gemm_bf16_blocked": (_c_int, [_c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64,
+                                             ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, ctypes.c_int64,
+                                             _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_bias_act": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_res_ln256_forward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
                                        _c_vp, _c_int, _c_vp, _c_vp]),

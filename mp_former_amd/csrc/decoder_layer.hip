@@ -107,6 +107,16 @@ int lin_dw(const void* dy, const void* gate, const void* x, void* dw, void* db, 
     return mpf_small_gemm_bf16(dy, 1, J, gate, x, 1, Kin, nullptr, nullptr, 0, dw, Kin, db, J, Kin, R, 0, st);
 }
 
+inline const char* at(const void* p, size_t bytes) { return static_cast<const char*>(p) + bytes; }
+
+// q | k | v of the self-attention stand side by side in memory (packed in_proj weight / bias, the three
+// activation buffers, the three gradient buffers): the three GEMMs of each kind become ONE blocked GEMM
+bool packed_weights(const MpfDecoderLayer* L)
+{
+    const size_t w = (size_t)kE * kE * 2, b = (size_t)kE * 2;
+    return L->sa_wk == at(L->sa_wq, w) && L->sa_wv == at(L->sa_wq, 2 * w) && L->sa_bk == at(L->sa_bq, b) && L->sa_bv == at(L->sa_bq, 2 * b);
+}
+
 }  // namespace
 
 #define MPF_TRY(expr)                \
@@ -144,9 +154,15 @@ extern "C" int mpf_decoder_layer_forward(const MpfDecoderLayer* L, void* st)
     MPF_TRY(mpf_res_ln256_forward(L->x0, f.t, MPF_BF16, L->ca_gamma, L->ca_beta, L->s1, f.x1, L->xb1, L->mean1, L->rstd1, R,
                                   L->eps, nullptr, 0, nullptr, st));
     // self-attention (:1791-1795) + post-norm
-    MPF_TRY(lin_fwd(L->xb1, L->sa_wq, L->sa_bq, L->q_s, R, kE, kE, 0, st));
-    MPF_TRY(lin_fwd(L->xb1, L->sa_wk, L->sa_bk, L->k_s, R, kE, kE, 0, st));
-    MPF_TRY(lin_fwd(L->xb1, L->sa_wv, L->sa_bv, L->v_s, R, kE, kE, 0, st));
+    const size_t act = (size_t)R * kE * 2;
+    if (packed_weights(L) && L->k_s == at(L->q_s, act) && L->v_s == at(L->q_s, 2 * act)) {
+        MPF_TRY(mpf_small_gemm_bf16_blocked(L->xb1, kE, 1, 0, 0, nullptr, L->sa_wq, kE, 1, L->sa_bq, nullptr, 0, L->q_s, kE, kE,
+                                            (int64_t)R * kE, nullptr, R, 3 * kE, kE, 0, st));
+    } else {
+        MPF_TRY(lin_fwd(L->xb1, L->sa_wq, L->sa_bq, L->q_s, R, kE, kE, 0, st));
+        MPF_TRY(lin_fwd(L->xb1, L->sa_wk, L->sa_bk, L->k_s, R, kE, kE, 0, st));
+        MPF_TRY(lin_fwd(L->xb1, L->sa_wv, L->sa_bv, L->v_s, R, kE, kE, 0, st));
+    }
     MPF_TRY(mpf_attn_transpose2(L->k_s, L->v_s, L->kT_s, f.vT_s, Qt, Qt, N, kE, st));
     MPF_TRY(mpf_attn_forward(L->q_s, L->k_s, f.vT_s, L->mask_s, 0, L->o_s, L->lse_s, Qt, Qt, N, H, 32, scale, L->attn_ws,
                              L->attn_ws_bytes, st));
@@ -195,12 +211,27 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
     MPF_TRY(mpf_attn_transpose2(L->q_s, b.dout, b.qT, b.doT, Qt, LqP, N, kE, st));
     MPF_TRY(mpf_attn_backward(L->q_s, L->k_s, L->v_s, L->kT_s, b.qT, b.dout, b.doT, L->mask_s, 0, L->lse_s, b.delta, b.dq, b.dk_s,
                               b.dv_s, Qt, LqP, Qt, N, H, 32, scale, L->attn_ws, L->attn_ws_bytes, st));
-    MPF_TRY(lin_dx(b.dq, nullptr, L->sa_wq, nullptr, b.dxb, R, kE, kE, st));
-    MPF_TRY(lin_dx(b.dk_s, nullptr, L->sa_wk, b.dxb, b.dxb, R, kE, kE, st));
-    MPF_TRY(lin_dx(b.dv_s, nullptr, L->sa_wv, b.dxb, b.dxb, R, kE, kE, st));
-    MPF_TRY(lin_dw(b.dq, nullptr, L->xb1, G->d_sa_wq, G->d_sa_bq, R, kE, kE, st));
-    MPF_TRY(lin_dw(b.dk_s, nullptr, L->xb1, G->d_sa_wk, G->d_sa_bk, R, kE, kE, st));
-    MPF_TRY(lin_dw(b.dv_s, nullptr, L->xb1, G->d_sa_wv, G->d_sa_bv, R, kE, kE, st));
+    const size_t act = (size_t)R * kE * 2, wsz = (size_t)kE * kE * 2, bsz = (size_t)kE * 2;
+    const bool grads_packed = b.dk_s == at(b.dq, act) && b.dv_s == at(b.dq, 2 * act);
+    if (packed_weights(L) && grads_packed) {
+        // dxb = [dq | dk | dv] . W_in (contraction over the 768 packed outputs, blocked over the three buffers)
+        MPF_TRY(mpf_small_gemm_bf16_blocked(b.dq, kE, 1, kE, (int64_t)R * kE, nullptr, L->sa_wq, 1, kE, nullptr, nullptr, 0, b.dxb, kE,
+                                            0, 0, nullptr, R, kE, 3 * kE, 0, st));
+    } else {
+        MPF_TRY(lin_dx(b.dq, nullptr, L->sa_wq, nullptr, b.dxb, R, kE, kE, st));
+        MPF_TRY(lin_dx(b.dk_s, nullptr, L->sa_wk, b.dxb, b.dxb, R, kE, kE, st));
+        MPF_TRY(lin_dx(b.dv_s, nullptr, L->sa_wv, b.dxb, b.dxb, R, kE, kE, st));
+    }
+    if (grads_packed && G->d_sa_wk == at(G->d_sa_wq, wsz) && G->d_sa_wv == at(G->d_sa_wq, 2 * wsz) &&
+        G->d_sa_bk == at(G->d_sa_bq, bsz) && G->d_sa_bv == at(G->d_sa_bq, 2 * bsz)) {
+        // dW_in [768, 256] = [dq | dk | dv]^T . xb1 and its 768 bias gradients in one GEMM (rows of A blocked)
+        MPF_TRY(mpf_small_gemm_bf16_blocked(b.dq, 1, kE, kE, (int64_t)R * kE, nullptr, L->xb1, 1, kE, nullptr, nullptr, 0, G->d_sa_wq,
+                                            kE, 0, 0, G->d_sa_bq, 3 * kE, kE, R, 0, st));
+    } else {
+        MPF_TRY(lin_dw(b.dq, nullptr, L->xb1, G->d_sa_wq, G->d_sa_bq, R, kE, kE, st));
+        MPF_TRY(lin_dw(b.dk_s, nullptr, L->xb1, G->d_sa_wk, G->d_sa_bk, R, kE, kE, st));
+        MPF_TRY(lin_dw(b.dv_s, nullptr, L->xb1, G->d_sa_wv, G->d_sa_bv, R, kE, kE, st));
+    }
     // cross-attention block: x1 = LN(x0 + Wo attn(Wq xb0, k_c, v_c))
     MPF_TRY(mpf_res_ln256_backward(L->s1, L->mean1, L->rstd1, L->ca_gamma, b.ds_b, b.dxb, nullptr, G->d_x0, b.dt, dln, dln + kE, R, st));
     MPF_TRY(lin_dx(b.dt, nullptr, L->ca_wo, nullptr, b.dout, R, kE, kE, st));

@@ -37,6 +37,8 @@ struct SG {
     u16* c;
     u16* rowsum;
     int64_t a_rs, a_ks, b_rs, b_ks, ldc, ldcin;
+    int64_t a_bs, c_bs;              // block strides (elements) of the blocked forms, see mpf_small_gemm_bf16_blocked
+    int a_blk, c_blk;
     int I, J, Kc, relu, n_it, n_waves;
 };
 
@@ -107,8 +109,11 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SG p)
     const int li = lane & 15, g = lane >> 4;
     const int i = it * 16 + li;
     const int ic = min(i, p.I - 1);
-    const u16* __restrict__ arow = p.a + (int64_t)ic * p.a_rs;
-    const u16* __restrict__ grow = GATE ? p.gate + (int64_t)ic * p.a_rs : nullptr;
+    // row-contiguous A with blocked rows: row i lives in block i / a_blk (the packed q | k | v gradient of the
+    // self-attention in-projection, three [R, 256] buffers a_bs apart)
+    const int64_t arow_off = (!AC && p.a_blk) ? (int64_t)(ic / p.a_blk) * p.a_bs + (ic % p.a_blk) : (int64_t)ic * p.a_rs;
+    const u16* __restrict__ arow = p.a + arow_off;
+    const u16* __restrict__ grow = GATE ? p.gate + arow_off : nullptr;
     const u16* __restrict__ brow[NJ];
     const int j0 = jt * 16 * NJ;
 #pragma unroll
@@ -125,8 +130,10 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SG p)
             const int k = min(s0 + 4 * u, nsteps - 1) * 32 + 8 * g;
 #pragma unroll
             for (int n = 0; n < NJ; ++n) fb[u][n] = load_frag<BC, MASK>(brow[n], p.b_ks, k, p.Kc);
-            fa[u] = load_frag<AC, MASK>(arow, p.a_ks, k, p.Kc);
-            if (GATE) fg[u] = load_frag<AC, MASK>(grow, p.a_ks, k, p.Kc);
+            // contraction-contiguous A with a blocked contraction index (blocks of a_blk, a_bs apart)
+            const int ka = (AC && p.a_blk) ? (int)((k / p.a_blk) * p.a_bs) + (k % p.a_blk) : k;
+            fa[u] = load_frag<AC, MASK>(arow, p.a_ks, ka, (AC && p.a_blk) ? 0x7fffffff : p.Kc);
+            if (GATE) fg[u] = load_frag<AC, MASK>(grow, p.a_ks, ka, (AC && p.a_blk) ? 0x7fffffff : p.Kc);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -189,7 +196,8 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SG p)
         uint2 o;
         o.x = f2bf(v[0]) | (f2bf(v[1]) << 16);
         o.y = f2bf(v[2]) | (f2bf(v[3]) << 16);
-        *reinterpret_cast<uint2*>(p.c + (int64_t)i * p.ldc + j) = o;
+        const int64_t co = p.c_blk ? (int64_t)(j / p.c_blk) * p.c_bs + (j % p.c_blk) : j;      // column-blocked output
+        *reinterpret_cast<uint2*>(p.c + (int64_t)i * p.ldc + co) = o;
     }
 }
 
@@ -222,10 +230,14 @@ void launch(const SG& p, bool ac, bool bc, int blocks, hipStream_t st)
 
 }  // namespace
 
-extern "C" int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, const void* gate, const void* b,
-                                   int64_t b_rs, int64_t b_ks, const void* bias, const void* c_in, int64_t ldcin, void* c,
-                                   int64_t ldc, void* rowsum_a, int I, int J, int Kc, int relu, void* stream)
+extern "C" int mpf_small_gemm_bf16_blocked(const void* a, int64_t a_rs, int64_t a_ks, int a_blk, int64_t a_bs, const void* gate,
+                                           const void* b, int64_t b_rs, int64_t b_ks, const void* bias, const void* c_in,
+                                           int64_t ldcin, void* c, int64_t ldc, int c_blk, int64_t c_bs, void* rowsum_a, int I,
+                                           int J, int Kc, int relu, void* stream)
 {
+    if (a_blk < 0 || c_blk < 0 || (a_blk && a_blk % 32) || (c_blk && c_blk % 64) || (a_blk && a_ks == 1 && Kc % 32) ||
+        (c_blk && c_in))
+        return mpf::fail(MPF_E_SHAPE, "small_gemm_blocked: a_blk % 32, c_blk % 64 (and Kc % 32 for a blocked contraction) must be 0");
     if (I < 0 || J < 0 || Kc < 0) return mpf::fail(MPF_E_SHAPE, "small_gemm: negative size");
     if (I == 0 || J == 0) return 0;
     if (!a || !b || !c) return mpf::fail(MPF_E_NULL, "small_gemm: a, b, c must not be null");
@@ -249,6 +261,7 @@ extern "C" int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, co
     p.c = static_cast<u16*>(c);
     p.rowsum = static_cast<u16*>(rowsum_a);
     p.a_rs = a_rs; p.a_ks = a_ks; p.b_rs = b_rs; p.b_ks = b_ks; p.ldc = ldc;
+    p.a_blk = a_blk; p.a_bs = a_bs; p.c_blk = c_blk; p.c_bs = c_bs;
     p.I = I; p.J = J; p.Kc = Kc; p.relu = relu;
     p.n_it = (I + 15) / 16;
     // widest tile that still gives the chip >= 256 blocks
@@ -265,4 +278,12 @@ extern "C" int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, co
     const double bytes = 2.0 * ((double)I * Kc * (gate ? 2 : 1) + (double)J * Kc + (double)I * J);
     mpf::prof_end("small_gemm_kernel", st, bytes);
     return mpf::check(hipGetLastError(), "small_gemm launch");
+}
+
+extern "C" int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, const void* gate, const void* b,
+                                   int64_t b_rs, int64_t b_ks, const void* bias, const void* c_in, int64_t ldcin, void* c,
+                                   int64_t ldc, void* rowsum_a, int I, int J, int Kc, int relu, void* stream)
+{
+    return mpf_small_gemm_bf16_blocked(a, a_rs, a_ks, 0, 0, gate, b, b_rs, b_ks, bias, c_in, ldcin, c, ldc, 0, 0, rowsum_a, I, J, Kc,
+                                       relu, stream);
 }

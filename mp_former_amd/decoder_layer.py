@@ -137,11 +137,16 @@ class DecoderLayerFn(Function):
         d_x0 = torch.empty((Qt, N, E), dtype=torch.float32, device=dev)
         d_xb0 = torch.empty((Qt, N, E), dtype=torch.bfloat16, device=dev)
         d_kv = torch.empty((2,) + tuple(k_c.shape), dtype=torch.bfloat16, device=dev)
+        wnames = [n for n in PARAM_NAMES if n not in _LN]
         wshapes = [p.shape for n, p in zip(PARAM_NAMES, params) if n not in _LN]
-        offs, tot = [], 0
-        for s_ in wshapes:
-            offs.append(tot)
-            tot += (s_.numel() + 127) & ~127
+        # arena order: the q / k / v weight gradients side by side, then their bias gradients (the native layer then
+        # produces them with one GEMM), the rest in parameter order
+        order = sorted(range(len(wnames)), key=lambda i: ({"sa_wq": 0, "sa_wk": 1, "sa_wv": 2, "sa_bq": 3, "sa_bk": 4, "sa_bv": 5}
+                                                           .get(wnames[i], 6 + i)))
+        offs, tot = [0] * len(wnames), 0
+        for i in order:
+            offs[i] = tot
+            tot += (wshapes[i].numel() + 127) & ~127
         wg = torch.empty(tot, dtype=torch.bfloat16, device=dev)
         d_ln = torch.empty((6, 256), dtype=torch.float32, device=dev)
         G = MpfDecoderLayerGrad()

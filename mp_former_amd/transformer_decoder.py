@@ -47,13 +47,16 @@ class _CastParams(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, chunks, *params):
-        srcs, outs = [], []
+        srcs, dsts, outs = [], [], []
         for p, c in zip(params, chunks):
             d = p.detach()
-            parts = [d] if c == 1 else list(d.chunk(c, 0))
-            srcs += parts
-            outs += [torch.empty_like(t, dtype=dtype if dtype is not None else t.dtype) for t in parts]
-        torch._foreach_copy_(outs, srcs)
+            full = torch.empty_like(d, dtype=dtype if dtype is not None else d.dtype)
+            srcs.append(d)
+            dsts.append(full)
+            # row blocks of ONE buffer: the blocks of a packed in-projection stay side by side in memory (the native
+            # decoder layer then runs q | k | v as one GEMM)
+            outs += [full] if c == 1 else list(full.chunk(c, 0))
+        torch._foreach_copy_(dsts, srcs)
         ctx.chunks = chunks
         ctx.shapes = [p.shape for p in params]
         return tuple(outs)
