@@ -71,3 +71,22 @@ def test_missing_library_fails_loudly(built, monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmpformer_hip.so")
     with pytest.raises(_lib.NativeLibraryError):
         _lib.lib()
+
+
+def test_shipped_miopen_find_db_is_wired(monkeypatch, tmp_path):
+    """the tuned MIOpen solver choice travels with the package: importing it points MIOPEN_USER_DB_PATH at the
+    shipped find-db unless the user already chose one (or switched it off)"""
+    import glob
+    import os
+    from mp_former_amd import _miopen
+    files = glob.glob(os.path.join(os.path.dirname(_miopen.__file__), "miopen_db", "gfx950*.ufdb.txt"))
+    assert files and os.path.getsize(files[0]) > 1000
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.delenv("MPF_MIOPEN_DB", raising=False)
+    path = _miopen.use_shipped_find_db()
+    assert path and os.path.isdir(path) and os.environ["MIOPEN_USER_DB_PATH"] == path
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(tmp_path))
+    assert _miopen.use_shipped_find_db() == str(tmp_path)           # a user setting wins
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("MPF_MIOPEN_DB", "0")
+    assert _miopen.use_shipped_find_db() is None and "MIOPEN_USER_DB_PATH" not in os.environ
