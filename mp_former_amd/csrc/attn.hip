@@ -496,11 +496,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const __hip_bfloat16* _
 
 // Key splits of the forward / dQ kernels: one WAVE per (32 queries, head, image, split) and each wave
 // walks its keys in dependent 32-key steps, so the chip needs several thousand waves to hide the load
-// latency of a step: aim at ~4096 waves, at least 64 keys and at most 1024 keys per split.
+// latency of a step: aim at ~2048 waves (measured at config B: 1024 / 2048 / 4096 / 8192 waves -> 39.3 / 38.95 / 39.15 /
+// 39.2 ms per step; more splits also mean more partials for the combine kernels), at least 64 keys and at most 1024
+// keys per split.
 static int attn_splits(int Lq, int Lk, int N, int H)
 {
     const int qtiles = (Lq + 31) / 32;
-    int splits = (4096 + qtiles * H * N - 1) / (qtiles * H * N);
+    int splits = (2048 + qtiles * H * N - 1) / (qtiles * H * N);
     const int max_splits = (Lk + 63) / 64, min_splits = (Lk + 1023) / 1024;
     splits = splits > max_splits ? max_splits : splits;
     splits = splits < min_splits ? min_splits : splits;
