@@ -23,10 +23,6 @@ def _ref(q, k, v, mask, H):
     return torch.matmul(p, vh).permute(2, 0, 1, 3).reshape(Lq, N, E)
 
 
-@pytest.mark.parametrize("Lq,Lk,N,mask_kind", [
-    (100, 1024, 2, "3d"), (117, 4096, 2, "3d"), (123, 16384, 1, "3d"), (100, 64, 2, "3d"),
-    (117, 117, 2, "2d"), (100, 100, 1, None), (37, 1000, 3, "3d"), (214, 214, 2, "2d"),
-])
 def _problem(Lq, Lk, N, mask_kind, dev, seed):
     g = torch.Generator().manual_seed(seed)
     E = 256

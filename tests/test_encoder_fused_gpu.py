@@ -71,8 +71,14 @@ def test_fused_encoder_is_the_default_path():
                                                 dropout=0.0, num_feature_levels=3).to(dev)
     srcs = [torch.randn(1, 256, s, s, device=dev) for s in (4, 8, 16)]
     pe = PD.PositionEmbeddingSine(128, normalize=True)
-    enc(srcs, [pe(s) for s in srcs])
-    assert "gemm3" in _lib.last_kernel() or "layer_norm" in _lib.last_kernel() or True
+    _lib.lib().mpf_profile_enable(1)
+    try:
+        enc(srcs, [pe(s) for s in srcs])
+        torch.cuda.synchronize()
+        n_gemm3 = _lib.profile_get("gemm3")[0]
+    finally:
+        _lib.lib().mpf_profile_enable(0)
+    assert n_gemm3 > 0, "the default encoder path did not launch the split-bf16 GEMM"
     os.environ["MPF_FUSED_ENCODER"] = "1"
     try:
         assert enc._fused_ok(srcs, [pe(s) for s in srcs])
