@@ -62,6 +62,21 @@ int mpf_msda_forward(const void* value, const int64_t* spatial_shapes,
                      int dtype, void* stream);
 
 /*
+ * The same operation with spatial_shapes ALSO given from host memory (host_spatial_shapes [num_levels, 2] int64,
+ * may be NULL): the production kernel (mp_former_amd/csrc/msda_block.hip) tiles the queries in 2-D blocks of their level
+ * and sizes its launch from the level geometry, which a pure device-pointer signature cannot provide without a
+ * device->host copy.  Levels must be stored back to back (level_start_index = running sum of H_l*W_l; the caller
+ * checks).  With host_spatial_shapes == NULL, or shapes outside fp32 / 32 channels / 4 points / <= 4 levels, this is
+ * mpf_msda_forward.
+ */
+int mpf_msda_forward_hs(const void* value, const int64_t* spatial_shapes,
+                        const int64_t* level_start_index, const int64_t* host_spatial_shapes,
+                        const void* sampling_loc, const void* attn_weight, void* output,
+                        int batch, int spatial_size, int num_heads, int channels,
+                        int num_levels, int num_query, int num_point,
+                        int dtype, void* stream);
+
+/*
  * Multi-scale deformable attention, backward.
  * Replaces ms_deform_attn_backward (pybind: ops/src/vision.cpp:20; host
  * ops/src/cuda/ms_deform_attn_cuda.cu:88-158; kernels ms_deform_im2col_cuda.cuh:306-925,
@@ -260,6 +275,11 @@ int mpf_msda_forward_raw(const void* value, const int64_t* spatial_shapes, const
                          const void* raw, const void* ref_points, void* loc_out, void* attn_out, void* output,
                          int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                          int num_point, int dtype, void* stream);
+int mpf_msda_forward_raw_hs(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                            const int64_t* host_spatial_shapes,
+                            const void* raw, const void* ref_points, void* loc_out, void* attn_out, void* output,
+                            int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                            int num_point, int dtype, void* stream);
 int mpf_msda_backward_ws_raw(const void* value, const int64_t* host_spatial_shapes,
                              const void* sampling_loc, const void* attn_weight, const void* grad_output,
                              void* grad_value, void* grad_raw,

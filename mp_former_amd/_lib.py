@@ -82,6 +82,8 @@ SIGNATURES = {
     "mpf_group_stats": (_c_int, [_c_vp, _c_int, ctypes.c_int64, ctypes.c_float, _c_vp, _c_vp, _c_vp, ctypes.c_size_t, _c_vp]),
     "mpf_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),
+    "mpf_msda_forward_hs": (_c_int, [_c_vp] * 7 + [_c_int] * 8 + [_c_vp]),
+    "mpf_msda_forward_raw_hs": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_forward_raw": (_c_int, [_c_vp] * 8 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward_ws_raw": (_c_int, [_c_vp] * 7 + [_c_int] * 8 + [_c_vp, ctypes.c_size_t, _c_vp]),
     "mpf_msda_backward_workspace_bytes": (ctypes.c_size_t, [_c_int] * 5 + [_c_vp]),

@@ -18,4 +18,12 @@ void prof_end(const char* name, hipStream_t st, double algorithmic_bytes);
 int set_msda_option(const char* key, int v);
 int set_binned_option(const char* key, int v);
 int set_gemm3_option(const char* key, int v);
+int set_block_option(const char* key, int v);
+// spatially blocked MSDA (msda_block.hip); return -1000 when the problem is outside their shapes
+int msda_block_forward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, void* out, int N, int S, int M,
+                       int D, int L, int Lq, int P, int dtype, hipStream_t st);
+size_t msda_block_workspace_bytes(const int64_t* host_shapes, int N, int M, int L, int Lq, int P);
+int msda_block_backward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, const void* go, void* gv,
+                        void* gl, void* ga, void* graw, int N, int S, int M, int D, int L, int Lq, int P, int dtype, void* workspace,
+                        size_t workspace_bytes, hipStream_t st);
 }  // namespace mpf

@@ -511,12 +511,12 @@ bool tiled_ok(int batch, int S, int M, int D, int L, int Lq, int P, int dtype, i
 
 }  // namespace
 
-extern "C" int mpf_msda_forward(const void* value, const int64_t* spatial_shapes,
-                                const int64_t* level_start_index, const void* sampling_loc,
-                                const void* attn_weight, void* output,
-                                int batch, int spatial_size, int num_heads, int channels,
-                                int num_levels, int num_query, int num_point,
-                                int dtype, void* stream)
+static int forward_impl(const void* value, const int64_t* spatial_shapes,
+                        const int64_t* level_start_index, const int64_t* host_spatial_shapes, const void* sampling_loc,
+                        const void* attn_weight, void* output,
+                        int batch, int spatial_size, int num_heads, int channels,
+                        int num_levels, int num_query, int num_point,
+                        int dtype, void* stream)
 {
     const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels,
               Lq = num_query, P = num_point;
@@ -526,6 +526,12 @@ extern "C" int mpf_msda_forward(const void* value, const int64_t* spatial_shapes
     hipStream_t st = (hipStream_t)stream;
     hipError_t err;
     int variant = g_fwd_variant;
+    if (variant == 0 && host_spatial_shapes) {
+        // production path: spatially blocked kernel (msda_block.hip); -1000 = not its shapes
+        const int r = mpf::msda_block_forward(value, host_spatial_shapes, sampling_loc, attn_weight, output, N, S, M, D, L, Lq, P,
+                                              dtype, st);
+        if (r != -1000) return r;
+    }
     if (variant == 0) variant = 3;  // measured: 32 lanes x 4 B beats 8 lanes x 16 B (profiles/)
     if (variant == 2 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 4)) variant = 1;
     if (variant == 3 && !tiled_ok(N, S, M, D, L, Lq, P, dtype, 1)) variant = 1;
@@ -569,6 +575,28 @@ extern "C" int mpf_msda_forward(const void* value, const int64_t* spatial_shapes
     }
     mpf::prof_end(mpf_last_kernel(), st, alg_bytes);
     return mpf::check(err, "mpf_msda_forward");
+}
+
+extern "C" int mpf_msda_forward(const void* value, const int64_t* spatial_shapes,
+                                const int64_t* level_start_index, const void* sampling_loc,
+                                const void* attn_weight, void* output,
+                                int batch, int spatial_size, int num_heads, int channels,
+                                int num_levels, int num_query, int num_point,
+                                int dtype, void* stream)
+{
+    return forward_impl(value, spatial_shapes, level_start_index, nullptr, sampling_loc, attn_weight, output, batch, spatial_size,
+                        num_heads, channels, num_levels, num_query, num_point, dtype, stream);
+}
+
+extern "C" int mpf_msda_forward_hs(const void* value, const int64_t* spatial_shapes,
+                                   const int64_t* level_start_index, const int64_t* host_spatial_shapes,
+                                   const void* sampling_loc, const void* attn_weight, void* output,
+                                   int batch, int spatial_size, int num_heads, int channels,
+                                   int num_levels, int num_query, int num_point,
+                                   int dtype, void* stream)
+{
+    return forward_impl(value, spatial_shapes, level_start_index, host_spatial_shapes, sampling_loc, attn_weight, output, batch,
+                        spatial_size, num_heads, channels, num_levels, num_query, num_point, dtype, stream);
 }
 
 extern "C" int mpf_msda_backward(const void* value, const int64_t* spatial_shapes,
@@ -694,10 +722,11 @@ __global__ __launch_bounds__(kThreads) void msda_prep_kernel(const float* __rest
 }
 }  // namespace
 
-extern "C" int mpf_msda_forward_raw(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                    const void* raw, const void* ref_points, void* loc_out, void* attn_out, void* output,
-                                    int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
-                                    int num_point, int dtype, void* stream)
+static int forward_raw_impl(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                            const int64_t* host_spatial_shapes,
+                            const void* raw, const void* ref_points, void* loc_out, void* attn_out, void* output,
+                            int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                            int num_point, int dtype, void* stream)
 {
     const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query, P = num_point;
     if (int e = check_args(N, S, M, D, L, Lq, P, dtype)) return e;
@@ -710,10 +739,33 @@ extern "C" int mpf_msda_forward_raw(const void* value, const int64_t* spatial_sh
     mpf::set_kernel("msda_prep_kernel");
     hipLaunchKernelGGL(msda_prep_kernel, dim3((groups + gpb - 1) / gpb), dim3(kThreads), 0, st, (const float*)raw,
                        (const float*)ref_points, spatial_shapes, (float*)loc_out, (float*)attn_out, groups, M, L, Lq, P);
+    if (g_fwd_variant == 0 && host_spatial_shapes) {
+        const int r = mpf::msda_block_forward(value, host_spatial_shapes, loc_out, attn_out, output, N, S, M, D, L, Lq, P, dtype, st);
+        if (r != -1000) return r;
+    }
     mpf::prof_begin(st);
     mpf::set_kernel("msda_fwd_tiled_f32<32,1>");
     hipError_t err = launch_fwd_tiled<32, 1>((const float*)value, spatial_shapes, level_start_index, (const float*)loc_out,
                                              (const float*)attn_out, (float*)output, N, S, M, L, Lq, P, st);
     mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)N * S * M * D + (double)N * Lq * M * L * P * 3 + (double)N * Lq * M * D));
     return mpf::check(err, "mpf_msda_forward_raw");
+}
+
+extern "C" int mpf_msda_forward_raw(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                    const void* raw, const void* ref_points, void* loc_out, void* attn_out, void* output,
+                                    int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                    int num_point, int dtype, void* stream)
+{
+    return forward_raw_impl(value, spatial_shapes, level_start_index, nullptr, raw, ref_points, loc_out, attn_out, output, batch,
+                            spatial_size, num_heads, channels, num_levels, num_query, num_point, dtype, stream);
+}
+
+extern "C" int mpf_msda_forward_raw_hs(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                       const int64_t* host_spatial_shapes,
+                                       const void* raw, const void* ref_points, void* loc_out, void* attn_out, void* output,
+                                       int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                       int num_point, int dtype, void* stream)
+{
+    return forward_raw_impl(value, spatial_shapes, level_start_index, host_spatial_shapes, raw, ref_points, loc_out, attn_out, output,
+                            batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, dtype, stream);
 }

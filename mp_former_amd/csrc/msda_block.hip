@@ -1,0 +1,954 @@
+// Multi-scale deformable attention for MI355X, second generation: spatially blocked forward / backward.
+// fp32, 32 channels per head, 4 points per level (the shapes every Mask2Former / MP-Former config uses);
+// anything else takes the kernels of msda.hip.
+//
+// Reference semantics: mask2former/modeling/pixel_decoder/ops/src/cuda/ms_deform_im2col_cuda.cuh
+// :242-304 (forward), :306-408 + :92-164 (backward).
+//
+// Why a second design.  The first-generation kernels gather every corner row of every sample from L2
+// (48 rows of 128 B per (query, head): 12 288*e*S bytes against 800*e*S algorithmic) and the backward
+// streams one 16-byte entry per (sample, pixel row) through HBM.  Both ran at L2-gather / issue rates:
+// 0.16 and 0.044 of the HBM roofline (profiles/r01r_*).  Here:
+//
+//   forward / "push" (grad_attn, grad_loc):  a workgroup owns ONE head x a 2-D block of 8x8 spatially
+//     adjacent queries (queries of the pixel decoder ARE the pixels of the levels).  Per level it
+//     decodes its 256 samples (one per thread), reduces their bounding box, and — if the box fits the
+//     LDS budget, which it does whenever the offsets are a few pixels — stages the box's value rows
+//     ONCE with direct global->LDS loads (1 KB per wave instruction) and samples from LDS
+//     (ds_read_b128, 8 lanes x 16 B per row, 8 rows per wave instruction).  A level whose box does not
+//     fit (coarse queries looking into the finest map, adversarial offsets) takes buffer-load gathers
+//     from L2 exactly like the first generation — a per-(workgroup, level) uniform decision, no
+//     per-sample divergence.  Corners outside the image read a zero row (LDS) / an out-of-range buffer
+//     offset (global): no branches, no masking.
+//
+//   grad_value:  the scatter-add is re-stated as a tiny dense product per destination tile.  A tile is
+//     4x4 pixels of one (image, head, level).  For the samples s whose 2x2 footprint touches the tile,
+//         grad_value[pixel, :] = sum_s  hat(px - x_s) * hat(py - y_s) * a_s  *  grad_out[q_s, :]
+//     with hat(t) = max(0, 1 - |t|) — the bilinear weight of ANY pixel in closed form (zero outside the
+//     footprint, so no corner bookkeeping and the image border needs no special case).  That is
+//     D[16 px x 32 ch] += A[16 px x 4 samples] * B[4 samples x 32 ch] on v_mfma_f32_16x16x4_f32
+//     (exact fp32 FMA chain, cdna_hip_programming.md §3): each lane computes its A element in ~8 VALU
+//     ops, B is a plain 8-byte load from the sample's grad_out row, accumulators stay in registers —
+//     no LDS accumulators, no atomics, no read-modify-write ordering, every grad_value element is
+//     written once.  The lists "samples per tile" are 4-byte entries (query, point) appended by the
+//     push kernel into fixed-capacity per-tile runs (one returning integer add per (workgroup, tile));
+//     run overflow goes to a spill list that a small atomic kernel applies afterwards (never taken
+//     with pixel-decoder-like offsets; exercised by the tests).
+#include <hip/hip_runtime.h>
+#include <limits.h>
+
+#include <algorithm>
+#include <stdint.h>
+
+#include "mpf_common.h"
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kD = 32;
+constexpr int kP = 4;
+constexpr int kMaxL = 4;          // templated level counts 1..4
+constexpr int kMaxBand = 16;      // horizontal bands of the pull kernel's workgroup order
+constexpr int kQB = 64;           // queries per workgroup (8 x 8 block, or 64 consecutive queries)
+constexpr int kSlots = 256;       // LDS hash slots of the push kernel (distinct destination tiles per workgroup)
+constexpr unsigned kEmpty = 0xFFFFFFFFu;
+constexpr int kOobOff = (int)0x80000000u;
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+struct GeomB {
+    int L, M, Lq, S, N;
+    int H[kMaxL], W[kMaxL], start[kMaxL];
+    // query blocks: nql "query levels" (the value levels when the queries are the pixels, else one strip)
+    int nql, bw_log2, bh;
+    int qH[kMaxL], qW[kMaxL], qstart[kMaxL], qnbx[kMaxL], qblk_base[kMaxL];
+    int blocks_per_b;
+    // destination tiles (4 x 4 pixels) and their entry runs
+    int ntx[kMaxL], tile_base[kMaxL], cap[kMaxL], ent_base[kMaxL];
+    int tiles_per_bm, ent_per_bm;
+    // pull launch geometry: waves per tile; workgroups (16 waves) per (image, head) ordered band-major, level-minor
+    int wpt[kMaxL], nband, wg_per_bm;
+    int band_wg_base[kMaxBand * kMaxL];
+};
+
+// pixel coordinate of a sampling location; explicitly rounded (no FMA contraction) so that every kernel
+// derives the same footprint for a sample
+__device__ __forceinline__ float pix(float loc, int size) { return __fsub_rn(__fmul_rn(loc, (float)size), 0.5f); }
+
+__device__ __forceinline__ int xcd_index(int n)
+{
+    const int per_xcd = (n + 7) >> 3;
+    return ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+}
+
+template <int CTRL, int RM>
+__device__ __forceinline__ int dpp_keep(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xf, false); }
+
+// wave-wide min / max through DPP (VALU only); result is wave-uniform
+__device__ __forceinline__ int wave_min(int v)
+{
+    v = min(v, dpp_keep<0xB1, 0xf>(v));
+    v = min(v, dpp_keep<0x4E, 0xf>(v));
+    v = min(v, dpp_keep<0x141, 0xf>(v));
+    v = min(v, dpp_keep<0x140, 0xf>(v));
+    v = min(v, dpp_keep<0x142, 0xa>(v));
+    v = min(v, dpp_keep<0x143, 0xc>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+    v = max(v, dpp_keep<0xB1, 0xf>(v));
+    v = max(v, dpp_keep<0x4E, 0xf>(v));
+    v = max(v, dpp_keep<0x141, 0xf>(v));
+    v = max(v, dpp_keep<0x140, 0xf>(v));
+    v = max(v, dpp_keep<0x142, 0xa>(v));
+    v = max(v, dpp_keep<0x143, 0xc>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_addf(float v)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(t);
+}
+// sum over the 8 consecutive lanes that share one sample; valid in every lane of the group
+__device__ __forceinline__ float sum8(float v)
+{
+    v = dpp_addf<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_addf<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_addf<0x141>(v);     // row_half_mirror: lane i <-> 7 - i inside each group of 8
+    return v;
+}
+
+struct Dec {
+    int x0, y0;
+    float lx, ly;
+    bool in;
+};
+
+__device__ __forceinline__ Dec decode(float2 xy, int H, int W, bool valid)
+{
+    Dec d;
+    const float x = pix(xy.x, W), y = pix(xy.y, H);
+    d.in = valid && (y > -1.f && x > -1.f && y < (float)H && x < (float)W);
+    const float xf = floorf(x), yf = floorf(y);
+    d.x0 = (int)xf; d.y0 = (int)yf; d.lx = x - xf; d.ly = y - yf;
+    if (!d.in) { d.x0 = 0; d.y0 = 0; d.lx = 0.f; d.ly = 0.f; }
+    return d;
+}
+
+// LDS layout shared by the forward and the push kernel
+//   [0, 4096)      float4 s_f[256]   per-sample floats (forward: 4 corner weights; push: lx, ly, a, -)
+//   [4096, 8192)   int4   s_o[256]   per-sample corner byte offsets (LDS offsets or value-buffer offsets)
+//   [8192, 8320)   int    s_bb[kMaxL*4] bounding boxes   (+ padding)
+//   [8320, 8448)   128 B of zeros (the row every out-of-image corner reads)
+//   [8448, ...)    region rows
+constexpr int kOffBB = 8192, kOffZero = 8320, kOffReg = 8448;
+
+struct BlockCtx {
+    int b, m, ql, by, bx;
+};
+
+// stage `rows` (= rw * rh) value rows of the box (ymin.., xmin..) of level l into the region buffer with
+// direct global->LDS loads: a wave instruction moves 8 rows (lane = (row, 16-byte piece)).
+__device__ __forceinline__ void stage_region(const float* __restrict__ value, unsigned char* smem, const GeomB& g, int b, int m,
+                                             int l, int xmin, int ymin, int rw, int rows, int tid)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const float inv_rw = 1.0f / (float)rw;
+    const int nchunk = (rows + 31) >> 5;
+    const int W = g.W[l];
+    const float* base = value + ((int64_t)(b * g.S + g.start[l]) * g.M + m) * kD + (lane & 7) * 4;
+    for (int c = 0; c < nchunk; ++c) {
+        const int r = min(c * 32 + wave * 8 + (lane >> 3), rows - 1);
+        const int ry = (int)(((float)r + 0.5f) * inv_rw);
+        const int rx = r - ry * rw;
+        const float* src = base + (int64_t)((ymin + ry) * W + (xmin + rx)) * (g.M * kD);
+        unsigned char* dst = smem + kOffReg + (c * 32 + wave * 8) * 128;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+// corner byte offsets of a sample for the two gather paths
+__device__ __forceinline__ int4 corner_offsets(const GeomB& g, const Dec& d, int l, bool lds_path, int xmin, int ymin, int rw,
+                                               int b, int m)
+{
+    const int H = g.H[l], W = g.W[l];
+    const bool y0v = d.in && d.y0 >= 0, y1v = d.in && d.y0 + 1 <= H - 1, x0v = d.in && d.x0 >= 0, x1v = d.in && d.x0 + 1 <= W - 1;
+    int4 o;
+    if (lds_path) {
+        const int base = kOffReg + ((d.y0 - ymin) * rw + (d.x0 - xmin)) * 128;
+        o.x = (y0v && x0v) ? base : kOffZero;
+        o.y = (y0v && x1v) ? base + 128 : kOffZero;
+        o.z = (y1v && x0v) ? base + rw * 128 : kOffZero;
+        o.w = (y1v && x1v) ? base + rw * 128 + 128 : kOffZero;
+    } else {
+        const int sx = g.M * 128, sy = W * sx;
+        const int base = ((b * g.S + g.start[l]) * g.M + m) * 128 + d.y0 * sy + d.x0 * sx;
+        o.x = (y0v && x0v) ? base : kOobOff;
+        o.y = (y0v && x1v) ? base + sx : kOobOff;
+        o.z = (y1v && x0v) ? base + sy : kOobOff;
+        o.w = (y1v && x1v) ? base + sy + sx : kOobOff;
+    }
+    return o;
+}
+
+__device__ __forceinline__ float4 lds_row(const unsigned char* smem, int off) { return *reinterpret_cast<const float4*>(smem + off); }
+__device__ __forceinline__ float4 buf_row(__amdgpu_buffer_rsrc_t rs, int off)
+{
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    return make_float4(__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3]));
+}
+
+__device__ __forceinline__ void block_of(const GeomB& g, int blk, BlockCtx& c)
+{
+    const int qb = blk % g.blocks_per_b, bm = blk / g.blocks_per_b;
+    c.m = bm % g.M; c.b = bm / g.M;
+    int ql = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxL; ++k) if (k < g.nql && qb >= g.qblk_base[k]) ql = k;
+    const int r = qb - g.qblk_base[ql];
+    c.ql = ql; c.by = r / g.qnbx[ql]; c.bx = r - c.by * g.qnbx[ql];
+}
+
+// query index of block-local query qi (or -1 when the block sticks out of its level)
+__device__ __forceinline__ int query_of(const GeomB& g, const BlockCtx& c, int qi)
+{
+    const int qy = qi >> g.bw_log2, qx = qi & ((1 << g.bw_log2) - 1);
+    const int gy = c.by * g.bh + qy, gx = (c.bx << g.bw_log2) + qx;
+    return (gy < g.qH[c.ql] && gx < g.qW[c.ql]) ? g.qstart[c.ql] + gy * g.qW[c.ql] + gx : -1;
+}
+
+// --------------------------------------------------------------------------------------------------
+// forward
+// --------------------------------------------------------------------------------------------------
+template <int NL>
+__global__ __launch_bounds__(kT) void msda_fwd_block_kernel(const float* __restrict__ value, const float* __restrict__ loc,
+                                                            const float* __restrict__ attn, float* __restrict__ out, GeomB g,
+                                                            int nblocks, int region_cap, unsigned value_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4* s_f = reinterpret_cast<float4*>(smem);
+    int4* s_o = reinterpret_cast<int4*>(smem + 4096);
+    int* s_bb = reinterpret_cast<int*>(smem + kOffBB);
+
+    const int blk = xcd_index(nblocks);
+    if (blk >= nblocks) return;
+    BlockCtx c;
+    block_of(g, blk, c);
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < kMaxL * 4) s_bb[tid] = (tid & 2) ? INT_MIN : INT_MAX;
+    if (tid >= 32 && tid < 64) reinterpret_cast<float*>(smem + kOffZero)[tid - 32] = 0.f;
+
+    // decode role: thread = (query tid >> 2, point tid & 3), one sample per level
+    const int q_d = query_of(g, c, tid >> 2);
+    const int LP = NL * kP;
+    float2 xy[NL];
+    float at[NL];
+    {
+        const int64_t gi0 = ((int64_t)(c.b * g.Lq + max(q_d, 0)) * g.M + c.m) * LP + (tid & 3);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            xy[l] = reinterpret_cast<const float2*>(loc)[gi0 + l * kP];
+            at[l] = attn[gi0 + l * kP];
+        }
+    }
+    __syncthreads();
+    Dec dec[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        dec[l] = decode(xy[l], g.H[l], g.W[l], q_d >= 0);
+        const Dec& d = dec[l];
+        const int H = g.H[l], W = g.W[l];
+        // box over the corners that exist (clamped to the image)
+        const int xa = d.in ? max(d.x0, 0) : INT_MAX, ya = d.in ? max(d.y0, 0) : INT_MAX;
+        const int xb = d.in ? min(d.x0 + 1, W - 1) : INT_MIN, yb = d.in ? min(d.y0 + 1, H - 1) : INT_MIN;
+        const int x_lo = wave_min(xa), y_lo = wave_min(ya), x_hi = wave_max(xb), y_hi = wave_max(yb);
+        if (lane == 0) {
+            atomicMin(&s_bb[l * 4 + 0], x_lo); atomicMin(&s_bb[l * 4 + 1], y_lo);
+            atomicMax(&s_bb[l * 4 + 2], x_hi); atomicMax(&s_bb[l * 4 + 3], y_hi);
+        }
+    }
+    __syncthreads();
+
+    // sampling role: 8 lanes per sample (16 B of the 128-B row each); lane group grp owns queries grp, grp + 32
+    const int grp = tid >> 3, sub16 = (tid & 7) * 16;
+    f2v acc[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(value), 0, value_bytes, 0x00020000);
+    const f4v* s_fv = reinterpret_cast<const f4v*>(smem);
+
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int xmin = s_bb[l * 4 + 0], ymin = s_bb[l * 4 + 1], xmax = s_bb[l * 4 + 2], ymax = s_bb[l * 4 + 3];
+        const bool any = xmax >= xmin;
+        const int rw = xmax - xmin + 1, rows = any ? rw * (ymax - ymin + 1) : 0;
+        const bool lds_path = rows <= region_cap;     // wave-uniform (also when the level has no sample at all)
+        {
+            const Dec& d = dec[l];
+            const float hx = 1.f - d.lx, hy = 1.f - d.ly, a = d.in ? at[l] : 0.f;
+            s_f[tid] = make_float4(hy * hx * a, hy * d.lx * a, d.ly * hx * a, d.ly * d.lx * a);
+            s_o[tid] = corner_offsets(g, d, l, lds_path, xmin, ymin, rw, c.b, c.m);
+        }
+        if (lds_path && rows > 0) stage_region(value, smem, g, c.b, c.m, l, xmin, ymin, rw, rows, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // explicit 2-wide FMAs (v_pk_fma_f32 with the weight broadcast by op_sel): left to itself the compiler packs
+        // ACROSS corners and pays a v_mov per operand
+        auto accumulate = [&](int qq, const f4v& w, const f4v& v0, const f4v& v1, const f4v& v2, const f4v& v3) {
+            acc[qq][0] = __builtin_elementwise_fma(f2v{w.x, w.x}, v0.xy, acc[qq][0]);
+            acc[qq][1] = __builtin_elementwise_fma(f2v{w.x, w.x}, v0.zw, acc[qq][1]);
+            acc[qq][0] = __builtin_elementwise_fma(f2v{w.y, w.y}, v1.xy, acc[qq][0]);
+            acc[qq][1] = __builtin_elementwise_fma(f2v{w.y, w.y}, v1.zw, acc[qq][1]);
+            acc[qq][0] = __builtin_elementwise_fma(f2v{w.z, w.z}, v2.xy, acc[qq][0]);
+            acc[qq][1] = __builtin_elementwise_fma(f2v{w.z, w.z}, v2.zw, acc[qq][1]);
+            acc[qq][0] = __builtin_elementwise_fma(f2v{w.w, w.w}, v3.xy, acc[qq][0]);
+            acc[qq][1] = __builtin_elementwise_fma(f2v{w.w, w.w}, v3.zw, acc[qq][1]);
+        };
+        if (lds_path) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+                for (int p = 0; p < kP; ++p) {
+                    const int s = (grp + 32 * qq) * kP + p;
+                    const f4v w = s_fv[s];
+                    const int4 o = s_o[s];
+                    const f4v v0 = *reinterpret_cast<const f4v*>(smem + o.x + sub16), v1 = *reinterpret_cast<const f4v*>(smem + o.y + sub16);
+                    const f4v v2 = *reinterpret_cast<const f4v*>(smem + o.z + sub16), v3 = *reinterpret_cast<const f4v*>(smem + o.w + sub16);
+                    accumulate(qq, w, v0, v1, v2, v3);
+                }
+            }
+        } else {
+            // L2 gathers: two samples (8 rows) in flight per lane group, then a scheduling fence so that the compiler
+            // does not hoist all 32 row loads (128 registers) to the top
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+                for (int p = 0; p < kP; p += 2) {
+                    const int s = (grp + 32 * qq) * kP + p;
+                    const f4v wa = s_fv[s], wb = s_fv[s + 1];
+                    const int4 oa = s_o[s], ob = s_o[s + 1];
+                    const float4 a0 = buf_row(vrs, oa.x + sub16), a1 = buf_row(vrs, oa.y + sub16);
+                    const float4 a2 = buf_row(vrs, oa.z + sub16), a3 = buf_row(vrs, oa.w + sub16);
+                    const float4 b0 = buf_row(vrs, ob.x + sub16), b1 = buf_row(vrs, ob.y + sub16);
+                    const float4 b2 = buf_row(vrs, ob.z + sub16), b3 = buf_row(vrs, ob.w + sub16);
+                    accumulate(qq, wa, f4v{a0.x, a0.y, a0.z, a0.w}, f4v{a1.x, a1.y, a1.z, a1.w}, f4v{a2.x, a2.y, a2.z, a2.w},
+                               f4v{a3.x, a3.y, a3.z, a3.w});
+                    accumulate(qq, wb, f4v{b0.x, b0.y, b0.z, b0.w}, f4v{b1.x, b1.y, b1.z, b1.w}, f4v{b2.x, b2.y, b2.z, b2.w},
+                               f4v{b3.x, b3.y, b3.z, b3.w});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (l + 1 < NL) __syncthreads();
+    }
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const int q = query_of(g, c, grp + 32 * qq);
+        if (q >= 0)
+            *reinterpret_cast<float4*>(out + ((int64_t)(c.b * g.Lq + q) * g.M + c.m) * kD + (tid & 7) * 4) =
+                make_float4(acc[qq][0].x, acc[qq][0].y, acc[qq][1].x, acc[qq][1].y);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// backward, kernel 1 ("push"): grad_attn / grad_loc (or their raw-projection form) + tile entry lists
+// --------------------------------------------------------------------------------------------------
+// LDS hash: slot of `key`, or -1 when the table is full
+__device__ __forceinline__ int hash_slot(unsigned* keys, unsigned key)
+{
+    unsigned s = (key * 2654435761u) >> 24;          // 8 bits
+#pragma unroll 1
+    for (int probe = 0; probe < kSlots; ++probe) {
+        const unsigned old = atomicCAS(&keys[s], kEmpty, key);
+        if (old == kEmpty || old == key) return (int)s;
+        s = (s + 1) & (kSlots - 1);
+    }
+    return -1;
+}
+
+// LDS of the push kernel:
+//   [0, 64)   bounding boxes   [128, 256) the zero row   [256, 8448) grad_out rows of the 64 queries
+//   [8448, 8448 + region)  staged value rows   then the hash table (keys, counts, run bases)
+// Thread = one sample per level, (query tid >> 2, point tid & 3): the thread that decodes a sample also reduces it — it
+// walks the 32 channels of its four corner rows and of its query's grad_out row with 16-byte LDS reads (8 per row), so
+// grad_attn / grad_loc need no cross-lane reduction and no descriptor round trip through LDS.  Lanes rotate the order
+// in which they visit the eight 16-byte pieces of a row (piece (k + phi) mod 8, phi from the query index) so that the
+// four queries of a 16-lane LDS service group, whose rows are 128 B apart, do not meet on the same banks.
+constexpr int kPOffZero = 128, kPOffG = 256;
+
+template <int NL>
+__global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
+    const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
+    const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
+    float* __restrict__ grad_raw, int* __restrict__ tile_count, unsigned* __restrict__ entries,
+    int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB g, int nblocks, int region_cap, int region_bytes,
+    unsigned value_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* s_bb = reinterpret_cast<int*>(smem);
+    constexpr int LP = NL * kP;
+    unsigned* s_keys = reinterpret_cast<unsigned*>(smem + kOffReg + region_bytes);   // [kSlots]
+    int* s_cnt = reinterpret_cast<int*>(s_keys + kSlots);                            // [kSlots]
+    int* s_base = s_cnt + kSlots;                                                    // [kSlots]
+
+    const int blk = xcd_index(nblocks);
+    if (blk >= nblocks) return;
+    BlockCtx c;
+    block_of(g, blk, c);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < kMaxL * 4) s_bb[tid] = (tid & 2) ? INT_MIN : INT_MAX;
+    if (tid >= 32 && tid < 64) reinterpret_cast<float*>(smem + kPOffZero)[tid - 32] = 0.f;
+    for (int i = tid; i < kSlots; i += kT) { s_keys[i] = kEmpty; s_cnt[i] = 0; }
+
+    const int qi_d = tid >> 2, p_d = tid & 3;
+    const int q_d = query_of(g, c, qi_d);
+    float2 xy[NL];
+    float at[NL];
+    {
+        const int64_t gi0 = ((int64_t)(c.b * g.Lq + max(q_d, 0)) * g.M + c.m) * LP + p_d;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            xy[l] = reinterpret_cast<const float2*>(loc)[gi0 + l * kP];
+            at[l] = attn[gi0 + l * kP];
+        }
+    }
+    // grad_out rows of the block's queries -> LDS (8 rows per wave instruction)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 16 + i * 8 + (lane >> 3);
+        const int q = max(query_of(g, c, row), 0);
+        const float* src = grad_out + ((int64_t)(c.b * g.Lq + q) * g.M + c.m) * kD + (lane & 7) * 4;
+        unsigned char* dst = smem + kPOffG + (wave * 16 + i * 8) * 128;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+    __syncthreads();
+    const int bm = c.b * g.M + c.m;
+    Dec dec[NL];
+    {
+        // entry bookkeeping: per level up to 4 destination tiles: hash slot (-1 = no entry, kSlots = position taken from
+        // the global counter because the table was full) and index inside the workgroup's run
+        int tslot[NL][4], tidx[NL][4];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            dec[l] = decode(xy[l], g.H[l], g.W[l], q_d >= 0);
+            const Dec& d = dec[l];
+            const int H = g.H[l], W = g.W[l];
+            const int xa = d.in ? max(d.x0, 0) : INT_MAX, ya = d.in ? max(d.y0, 0) : INT_MAX;
+            const int xb = d.in ? min(d.x0 + 1, W - 1) : INT_MIN, yb = d.in ? min(d.y0 + 1, H - 1) : INT_MIN;
+            const int x_lo = wave_min(xa), y_lo = wave_min(ya), x_hi = wave_max(xb), y_hi = wave_max(yb);
+            if (lane == 0) {
+                atomicMin(&s_bb[l * 4 + 0], x_lo); atomicMin(&s_bb[l * 4 + 1], y_lo);
+                atomicMax(&s_bb[l * 4 + 2], x_hi); atomicMax(&s_bb[l * 4 + 3], y_hi);
+            }
+            // destination tiles of the footprint [xa, xb] x [ya, yb]
+            const int txa = xa >> 2, txb = xb >> 2, tya = ya >> 2, tyb = yb >> 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ty = (e >> 1) ? tyb : tya, tx = (e & 1) ? txb : txa;
+                const bool act = d.in && !((e & 1) && txb == txa) && !((e >> 1) && tyb == tya);
+                tslot[l][e] = -1; tidx[l][e] = 0;
+                if (act) {
+                    const int key = bm * g.tiles_per_bm + g.tile_base[l] + ty * g.ntx[l] + tx;
+                    const int slot = hash_slot(s_keys, (unsigned)key);
+                    tslot[l][e] = slot >= 0 ? slot : kSlots;
+                    tidx[l][e] = slot >= 0 ? atomicAdd(&s_cnt[slot], 1) : atomicAdd(&tile_count[key], 1);
+                }
+            }
+        }
+        __syncthreads();
+        // one returning add per touched tile reserves the workgroup's run
+        for (int i = tid; i < kSlots; i += kT)
+            if (s_keys[i] != kEmpty) s_base[i] = atomicAdd(&tile_count[s_keys[i]], s_cnt[i]);
+        __syncthreads();
+        // entries: (query << 2 | point) appended to the run of every destination tile
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const Dec& d = dec[l];
+            const int txa = max(d.x0, 0) >> 2, txb = min(d.x0 + 1, g.W[l] - 1) >> 2;
+            const int tya = max(d.y0, 0) >> 2, tyb = min(d.y0 + 1, g.H[l] - 1) >> 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int slot = tslot[l][e];
+                if (slot < 0) continue;
+                const int local = ((e >> 1) ? tyb : tya) * g.ntx[l] + ((e & 1) ? txb : txa);
+                const int pos = (slot < kSlots ? s_base[slot] : 0) + tidx[l][e];
+                const unsigned ent = ((unsigned)q_d << 2) | (unsigned)p_d;
+                if (pos < g.cap[l]) {
+                    entries[(int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)local * g.cap[l] + pos] = ent;
+                } else {
+                    const int k = atomicAdd(ovf_count, 1);
+                    ovf[k] = make_uint2((unsigned)(bm * g.tiles_per_bm + g.tile_base[l] + local), ent);
+                }
+            }
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(value), 0, value_bytes, 0x00020000);
+    // rotated piece order of this lane
+    int ok[8];
+    {
+        const int phi = (qi_d >> 1) & 7;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ok[k] = ((k + phi) & 7) * 16;
+    }
+    const int g_base = kPOffG + qi_d * 128;
+    float ra[NL], rx[NL], ry[NL];
+
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int xmin = s_bb[l * 4 + 0], ymin = s_bb[l * 4 + 1], xmax = s_bb[l * 4 + 2], ymax = s_bb[l * 4 + 3];
+        const bool any = xmax >= xmin;
+        const int rw = xmax - xmin + 1, rows = any ? rw * (ymax - ymin + 1) : 0;
+        const bool lds_path = rows <= region_cap;
+        int4 o = corner_offsets(g, dec[l], l, lds_path, xmin, ymin, rw, c.b, c.m);
+        if (lds_path) {
+            // corner_offsets() addresses the forward kernel's LDS map; only its zero row sits elsewhere here
+            o.x = o.x == kOffZero ? kPOffZero : o.x; o.y = o.y == kOffZero ? kPOffZero : o.y;
+            o.z = o.z == kOffZero ? kPOffZero : o.z; o.w = o.w == kOffZero ? kPOffZero : o.w;
+        }
+        if (l > 0) __syncthreads();                    // the previous level's readers are done with the region
+        if (lds_path && rows > 0) stage_region(value, smem, g, c.b, c.m, l, xmin, ymin, rw, rows, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f2v t0 = {0.f, 0.f}, t1 = {0.f, 0.f}, t2 = {0.f, 0.f}, t3 = {0.f, 0.f};
+        if (lds_path) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f4v gk = *reinterpret_cast<const f4v*>(smem + g_base + ok[k]);
+                const f4v v0 = *reinterpret_cast<const f4v*>(smem + o.x + ok[k]);
+                const f4v v1 = *reinterpret_cast<const f4v*>(smem + o.y + ok[k]);
+                const f4v v2 = *reinterpret_cast<const f4v*>(smem + o.z + ok[k]);
+                const f4v v3 = *reinterpret_cast<const f4v*>(smem + o.w + ok[k]);
+                t0 = __builtin_elementwise_fma(gk.xy, v0.xy, t0); t0 = __builtin_elementwise_fma(gk.zw, v0.zw, t0);
+                t1 = __builtin_elementwise_fma(gk.xy, v1.xy, t1); t1 = __builtin_elementwise_fma(gk.zw, v1.zw, t1);
+                t2 = __builtin_elementwise_fma(gk.xy, v2.xy, t2); t2 = __builtin_elementwise_fma(gk.zw, v2.zw, t2);
+                t3 = __builtin_elementwise_fma(gk.xy, v3.xy, t3); t3 = __builtin_elementwise_fma(gk.zw, v3.zw, t3);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f4v gk = *reinterpret_cast<const f4v*>(smem + g_base + ok[k]);
+                const float4 a0 = buf_row(vrs, o.x + ok[k]), a1 = buf_row(vrs, o.y + ok[k]);
+                const float4 a2 = buf_row(vrs, o.z + ok[k]), a3 = buf_row(vrs, o.w + ok[k]);
+                const f4v v0 = {a0.x, a0.y, a0.z, a0.w}, v1 = {a1.x, a1.y, a1.z, a1.w};
+                const f4v v2 = {a2.x, a2.y, a2.z, a2.w}, v3 = {a3.x, a3.y, a3.z, a3.w};
+                t0 = __builtin_elementwise_fma(gk.xy, v0.xy, t0); t0 = __builtin_elementwise_fma(gk.zw, v0.zw, t0);
+                t1 = __builtin_elementwise_fma(gk.xy, v1.xy, t1); t1 = __builtin_elementwise_fma(gk.zw, v1.zw, t1);
+                t2 = __builtin_elementwise_fma(gk.xy, v2.xy, t2); t2 = __builtin_elementwise_fma(gk.zw, v2.zw, t2);
+                t3 = __builtin_elementwise_fma(gk.xy, v3.xy, t3); t3 = __builtin_elementwise_fma(gk.zw, v3.zw, t3);
+            }
+        }
+        {
+            const float s0 = t0.x + t0.y, s1 = t1.x + t1.y, s2 = t2.x + t2.y, s3 = t3.x + t3.y;
+            const float lx = dec[l].lx, ly = dec[l].ly, hx = 1.f - lx, hy = 1.f - ly;
+            const float a = dec[l].in ? at[l] : 0.f;
+            ra[l] = hy * (hx * s0 + lx * s1) + ly * (hx * s2 + lx * s3);
+            rx[l] = (float)g.W[l] * a * (hy * (s1 - s0) + ly * (s3 - s2));
+            ry[l] = (float)g.H[l] * a * (hx * (s2 - s0) + lx * (s3 - s1));
+        }
+    }
+    if (q_d < 0) return;
+
+    // ---- per-sample gradients out -------------------------------------------------------------------------
+    if (grad_raw) {
+        // module-level form: gradients wrt the raw projection outputs [M*L*P*2 offsets | M*L*P logits]:
+        //   loc = ref + off / (W_l, H_l)  =>  d off = d loc / (W_l, H_l);  attn = softmax  =>  d logit = a (dA - sum_j a_j dA_j)
+        float dot = 0.f;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) dot += at[l] * ra[l];
+        dot = dpp_addf<0xB1>(dot);            // + the other three points of the query (quad)
+        dot = dpp_addf<0x4E>(dot);
+        const int no = g.M * LP * 2, nr = g.M * LP * 3;
+        float* row = grad_raw + (int64_t)(c.b * g.Lq + q_d) * nr;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int lp = l * kP + p_d;
+            reinterpret_cast<float2*>(row + c.m * LP * 2)[lp] = make_float2(rx[l] / (float)g.W[l], ry[l] / (float)g.H[l]);
+            row[no + c.m * LP + lp] = at[l] * (ra[l] - dot);
+        }
+        return;
+    }
+    const int64_t gi0 = ((int64_t)(c.b * g.Lq + q_d) * g.M + c.m) * LP + p_d;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        grad_attn[gi0 + l * kP] = ra[l];
+        reinterpret_cast<float2*>(grad_loc)[gi0 + l * kP] = make_float2(rx[l], ry[l]);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// backward, kernel 2 ("pull"): grad_value of one 4x4-pixel tile = hat-weight matrix x grad_out rows (fp32 MFMA)
+// --------------------------------------------------------------------------------------------------
+// Work decomposition.  A unit = (tile, part): one WAVE walks every wpt-th step (4 entries) of the tile's run, so the
+// heavy tiles of the coarse levels (16x the samples of a fine tile) are split over wpt = 16 / 4 / 1 waves and every
+// wave of the launch has a similar trip count.  A workgroup is 16 waves = 16 / wpt tiles; partial tiles are summed
+// through LDS.  Workgroups are ordered (image, head) -> horizontal band of the image -> level, so the grad_out rows and
+// the loc / attn records of a band (shared by the tiles of ALL levels that cover it) are fetched from HBM once and
+// then hit in the XCD's L2; each XCD walks a contiguous range of that order.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kTP = 1024;
+
+struct PullGather {
+    float2 xy;
+    float a;
+    float2 g;
+};
+
+template <int NL>
+__global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
+    const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
+    const int* __restrict__ tile_count, const unsigned* __restrict__ entries, float* __restrict__ grad_value, GeomB g, int nwg,
+    unsigned loc_bytes, unsigned go_bytes)
+{
+    __shared__ float s_red[15][8][64];                 // partial accumulators of the waves with part > 0
+    const int wg = xcd_index(nwg);
+    if (wg >= nwg) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (bm, band, level)
+    const int bm = wg / g.wg_per_bm;
+    const int r = wg - bm * g.wg_per_bm;
+    int slot = 0;
+#pragma unroll 1
+    for (int k = 1; k < g.nband * NL; ++k) if (r >= g.band_wg_base[k]) slot = k;
+    const int band = slot / NL, l = slot - band * NL;
+    const int wpt = g.wpt[l];
+    const int W = g.W[l], H = g.H[l];
+    const int nty = (H + 3) >> 2, ntx = g.ntx[l];
+    const int row0 = band * nty / g.nband, row1 = (band + 1) * nty / g.nband;
+    const int unit = (r - g.band_wg_base[slot]) * 16 + wave;
+    const int part = unit % wpt, tb = unit / wpt;             // tile inside the (band, level) group
+    const bool live = tb < (row1 - row0) * ntx;
+    const int ty = row0 + tb / ntx, tx = tb - (tb / ntx) * ntx;
+    const int local = ty * ntx + tx;
+    const int b = bm / g.M, m = bm - b * g.M;
+    constexpr int LP = NL * kP;
+    const int MLP = g.M * LP;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int kgrp = lane >> 4, j = lane & 15;
+    int n = 0;
+    if (live) n = min(tile_count[bm * g.tiles_per_bm + g.tile_base[l] + local], g.cap[l]);
+    if (n > 0) {
+        const unsigned* ent = entries + (int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)local * g.cap[l];
+        // lane (i = lane & 15, k = lane >> 4): pixel i of the tile, sample k of the step
+        const float fpx = (float)(tx * 4 + (j & 3)), fpy = (float)(ty * 4 + (j >> 2));
+        const float fW = (float)W, fH = (float)H;
+        const int nsteps = (n + 3) >> 2;
+        const __amdgpu_buffer_rsrc_t rs_loc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(loc), 0, loc_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_att = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(attn), 0, loc_bytes >> 1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_out), 0, go_bytes, 0x00020000);
+        const int gi_base = (b * g.Lq * g.M + m) * LP + l * kP;              // sample index of (q = 0, p = 0)
+        const int so_loc = gi_base * 8, so_att = gi_base * 4;
+        const int so_go = (b * g.Lq * g.M + m) * (kD * 4);
+        const int M128 = g.M * (kD * 4);
+        auto entry = [&](int s) { return ent[min(s * 4 + kgrp, n - 1)]; };     // unconditional, clamped
+        auto gather = [&](unsigned e) {
+            const int q = (int)(e >> 2), pt = (int)(e & 3);
+            const int si = q * MLP + pt;
+            PullGather r_;
+            const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(rs_loc, si * 8, so_loc, 0);
+            r_.xy = make_float2(__int_as_float(v2[0]), __int_as_float(v2[1]));
+            r_.a = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_att, si * 4, so_att, 0));
+            const auto g2 = __builtin_amdgcn_raw_buffer_load_b64(rs_go, q * M128 + j * 8, so_go, 0);
+            r_.g = make_float2(__int_as_float(g2[0]), __int_as_float(g2[1]));
+            return r_;
+        };
+        // software pipeline, two stages ahead: entries of step s + 2 and the gathers of step s + 1 are in flight while
+        // step s is multiplied
+        int s = part;
+        unsigned e_b = entry(s + wpt);
+        PullGather ga = gather(entry(s));
+        for (; s < nsteps; s += wpt) {
+            const unsigned e_c = entry(s + 2 * wpt);
+            const PullGather gb = gather(e_b);
+            const float x = fmaf(ga.xy.x, fW, -0.5f), y = fmaf(ga.xy.y, fH, -0.5f);
+            // hat weights: zero for every pixel outside the 2x2 footprint, hence also for out-of-range samples
+            const float wx = fmaxf(0.f, 1.f - fabsf(fpx - x)), wy = fmaxf(0.f, 1.f - fabsf(fpy - y));
+            const float av = (s * 4 + kgrp < n) ? ga.a : 0.f;
+            const float wgt = wy * wx * av;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, ga.g.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, ga.g.y, acc1, 0, 0, 0);
+            ga = gb; e_b = e_c;
+        }
+    }
+    if (wpt > 1) {
+        // tiles of coarse levels are split over the waves of the workgroup: sum the partial tiles
+        if (part > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s_red[wave - 1][q][lane] = acc0[q]; s_red[wave - 1][4 + q][lane] = acc1[q]; }
+        }
+        __syncthreads();
+        if (part == 0) {
+            for (int k = 1; k < wpt; ++k) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc0[q] += s_red[wave + k - 1][q][lane]; acc1[q] += s_red[wave + k - 1][4 + q][lane]; }
+            }
+        }
+    }
+    if (!live || part != 0) return;
+    // D layout: lane holds pixels i = 4 * (lane >> 4) + r (r = 0..3), column j = lane & 15 -> channels 2j (acc0), 2j + 1 (acc1)
+    const int py = ty * 4 + kgrp;
+    if (py < H) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int px = tx * 4 + q;
+            if (px < W)
+                *reinterpret_cast<float2*>(grad_value + ((int64_t)(b * g.S + g.start[l] + py * W + px) * g.M + m) * kD + j * 2) =
+                    make_float2(acc0[q], acc1[q]);
+        }
+    }
+}
+
+// spill entries (run overflow): plain atomics, after the pull kernel has written the tiles
+template <int NL>
+__global__ __launch_bounds__(kT) void msda_bwd_spill_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
+                                                            const float* __restrict__ grad_out, const int* __restrict__ ovf_count,
+                                                            const uint2* __restrict__ ovf, float* __restrict__ grad_value, GeomB g)
+{
+    constexpr int LP = NL * kP;
+    const int n = *ovf_count;
+    const int c = threadIdx.x & 31;
+    for (int i = blockIdx.x * (kT / 32) + (threadIdx.x >> 5); i < n; i += gridDim.x * (kT / 32)) {
+        const uint2 o = ovf[i];
+        const int key = (int)o.x, q = (int)(o.y >> 2), p = (int)(o.y & 3);
+        const int bm = key / g.tiles_per_bm;
+        int r = key - bm * g.tiles_per_bm, l = 0;
+#pragma unroll
+        for (int k = 1; k < NL; ++k) if (r >= g.tile_base[k]) l = k;
+        r -= g.tile_base[l];
+        const int ty = r / g.ntx[l], tx = r - ty * g.ntx[l];
+        const int b = bm / g.M, m = bm - b * g.M;
+        const int W = g.W[l], H = g.H[l];
+        const int64_t gi = ((int64_t)(b * g.Lq + q) * g.M + m) * LP + l * kP + p;
+        const float2 xy = reinterpret_cast<const float2*>(loc)[gi];
+        const float a = attn[gi];
+        const float x = pix(xy.x, W), y = pix(xy.y, H);
+        if (!(y > -1.f && x > -1.f && y < (float)H && x < (float)W)) continue;
+        const float gq = grad_out[((int64_t)(b * g.Lq + q) * g.M + m) * kD + c];
+        const int x0 = (int)floorf(x), y0 = (int)floorf(y);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int px = x0 + (k & 1), py = y0 + (k >> 1);
+            if (px < tx * 4 || px > tx * 4 + 3 || py < ty * 4 || py > ty * 4 + 3 || px > W - 1 || py > H - 1) continue;
+            const float wgt = fmaxf(0.f, 1.f - fabsf((float)px - x)) * fmaxf(0.f, 1.f - fabsf((float)py - y)) * a;
+            atomicAdd(grad_value + ((int64_t)(b * g.S + g.start[l] + py * W + px) * g.M + m) * kD + c, wgt * gq);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------------------
+int g_region_rows = 217;      // usable rows of the staged box; the buffer adds 31 rows of slack for the last stage pass
+int g_block_disable = 0;
+
+bool build_geom(GeomB& g, const int64_t* hs, int N, int S, int M, int L, int Lq)
+{
+    if (L < 1 || L > kMaxL) return false;
+    g.L = L; g.M = M; g.Lq = Lq; g.S = S; g.N = N;
+    int64_t start = 0;
+    int tbase = 0, ebase = 0, wgb = 0;
+    for (int l = 0; l < kMaxL; ++l) {
+        g.H[l] = g.W[l] = 1; g.start[l] = 0; g.ntx[l] = 1; g.tile_base[l] = 0; g.cap[l] = 1; g.ent_base[l] = 0; g.wpt[l] = 1;
+        g.qH[l] = g.qW[l] = 1; g.qstart[l] = 0; g.qnbx[l] = 1; g.qblk_base[l] = 0;
+    }
+    for (int l = 0; l < L; ++l) {
+        const int64_t H = hs[2 * l], W = hs[2 * l + 1];
+        if (H <= 0 || W <= 0 || H > 16384 || W > 16384) return false;
+        g.H[l] = (int)H; g.W[l] = (int)W; g.start[l] = (int)start;
+        start += H * W;
+        g.ntx[l] = (int)((W + 3) / 4);
+        const int nty = (int)((H + 3) / 4), ntiles = g.ntx[l] * nty;
+        // expected entries of a tile when the samples follow the queries: Lq * P * 16 / (H W) samples, x (5/4)^2 for
+        // footprints straddling tile borders; run capacity = twice that + slack, the rest spills
+        const double expect = (double)Lq * kP * 16.0 / ((double)H * W) * 1.5625;
+        int64_t cap = (int64_t)(2.0 * expect) + 64;
+        cap = (cap + 3) & ~(int64_t)3;
+        g.cap[l] = (int)cap;
+        g.tile_base[l] = tbase; tbase += ntiles;
+        if ((int64_t)ebase + (int64_t)ntiles * cap >= (1ll << 31)) return false;
+        g.ent_base[l] = ebase; ebase += (int)(ntiles * cap);
+        // waves per tile: aim at ~32 steps (128 entries) per wave
+        g.wpt[l] = expect > 1400.0 ? 16 : (expect > 700.0 ? 8 : (expect > 350.0 ? 4 : (expect > 175.0 ? 2 : 1)));
+    }
+    (void)wgb;
+    if (start != S) return false;
+    {   // bands = tile rows of the level with the fewest tile rows (at most kMaxBand)
+        int nband = kMaxBand;
+        for (int l = 0; l < L; ++l) nband = std::min(nband, (g.H[l] + 3) / 4);
+        g.nband = nband;
+        int base = 0;
+        for (int k = 0; k < kMaxBand * kMaxL; ++k) g.band_wg_base[k] = 0;
+        for (int bnd = 0; bnd < nband; ++bnd)
+            for (int l = 0; l < L; ++l) {
+                const int nty = (g.H[l] + 3) / 4;
+                const int rows = (bnd + 1) * nty / nband - bnd * nty / nband;
+                g.band_wg_base[bnd * L + l] = base;
+                base += (rows * g.ntx[l] * g.wpt[l] + 15) / 16;
+            }
+        g.wg_per_bm = base;
+    }
+    g.tiles_per_bm = tbase; g.ent_per_bm = ebase;
+    if ((int64_t)N * M * tbase >= (1ll << 31)) return false;
+    // query blocks
+    int bbase = 0;
+    if (Lq == S) {
+        g.nql = L; g.bw_log2 = 3; g.bh = 8;
+        for (int l = 0; l < L; ++l) {
+            g.qH[l] = g.H[l]; g.qW[l] = g.W[l]; g.qstart[l] = g.start[l];
+            g.qnbx[l] = (g.W[l] + 7) / 8;
+            g.qblk_base[l] = bbase;
+            bbase += g.qnbx[l] * ((g.H[l] + 7) / 8);
+        }
+    } else {
+        g.nql = 1; g.bw_log2 = 6; g.bh = 1;
+        g.qH[0] = 1; g.qW[0] = Lq; g.qstart[0] = 0; g.qnbx[0] = (Lq + 63) / 64; g.qblk_base[0] = 0;
+        bbase = g.qnbx[0];
+    }
+    g.blocks_per_b = bbase;
+    return true;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+bool block_ok(int N, int S, int M, int D, int L, int Lq, int P, int dtype)
+{
+    if (g_block_disable) return false;
+    if (dtype != MPF_F32 || D != kD || P != kP || L < 1 || L > kMaxL) return false;
+    if ((int64_t)N * S * M * D * 4 >= (1ll << 31) || (int64_t)N * Lq * M * L * P * 8 >= (1ll << 31) ||
+        (int64_t)N * Lq * M * D * 4 >= (1ll << 31))
+        return false;
+    if ((int64_t)Lq >= (1 << 29)) return false;
+    return true;
+}
+
+int region_bytes() { return ((g_region_rows + 31) / 32) * 32 * 128; }     // whole stage passes of 32 rows
+
+template <int NL>
+hipError_t launch_fwd(const float* value, const float* loc, const float* attn, float* out, const GeomB& g, hipStream_t st)
+{
+    const int nblocks = g.N * g.M * g.blocks_per_b;
+    const int grid = ((nblocks + 7) / 8) * 8;
+    const size_t lds = kOffReg + region_bytes();
+    hipLaunchKernelGGL(msda_fwd_block_kernel<NL>, dim3(grid), dim3(kT), lds, st, value, loc, attn, out, g, nblocks, g_region_rows,
+                       (unsigned)((size_t)g.N * g.S * g.M * kD * 4));
+    return hipGetLastError();
+}
+
+struct WsLayout {
+    size_t off_count, off_ovf_count, off_entries, off_ovf, total;
+    int ntiles;
+};
+
+WsLayout ws_layout(const GeomB& g)
+{
+    WsLayout w;
+    w.ntiles = g.N * g.M * g.tiles_per_bm;
+    w.off_count = 0;
+    w.off_ovf_count = (size_t)w.ntiles * 4;
+    w.off_entries = align256(w.off_ovf_count + 4);
+    w.off_ovf = align256(w.off_entries + (size_t)g.N * g.M * g.ent_per_bm * 4);
+    w.total = w.off_ovf + (size_t)g.N * g.Lq * g.M * g.L * kP * 4 * 8;
+    return w;
+}
+
+template <int NL>
+hipError_t launch_bwd(const float* value, const float* loc, const float* attn, const float* go, float* gv, float* gl, float* ga,
+                      float* graw, const GeomB& g, void* workspace, hipStream_t st)
+{
+    const WsLayout w = ws_layout(g);
+    char* ws = (char*)workspace;
+    int* tile_count = (int*)(ws + w.off_count);
+    int* ovf_count = (int*)(ws + w.off_ovf_count);
+    unsigned* entries = (unsigned*)(ws + w.off_entries);
+    uint2* ovf = (uint2*)(ws + w.off_ovf);
+    hipError_t err = hipMemsetAsync(ws, 0, w.off_ovf_count + 4, st);
+    if (err != hipSuccess) return err;
+    const int nblocks = g.N * g.M * g.blocks_per_b;
+    const int grid = ((nblocks + 7) / 8) * 8;
+    constexpr int LP = NL * kP;
+    const size_t lds = kOffReg + region_bytes() + kSlots * 12;
+    const double esz = 4.0;
+    mpf::prof_begin(st);
+    hipLaunchKernelGGL(msda_bwd_push_block_kernel<NL>, dim3(grid), dim3(kT), lds, st, value, loc, attn, go, gl, ga, graw, tile_count,
+                       entries, ovf_count, ovf, g, nblocks, g_region_rows, region_bytes(), (unsigned)((size_t)g.N * g.S * g.M * kD * 4));
+    mpf::prof_end("msda_bwd_push_block_kernel", st,
+                  esz * ((double)g.N * g.S * g.M * kD + (double)g.N * g.Lq * g.M * LP * 6 + (double)g.N * g.Lq * g.M * kD));
+    const int nwg = g.N * g.M * g.wg_per_bm;
+    mpf::prof_begin(st);
+    hipLaunchKernelGGL(msda_bwd_pull_mfma_kernel<NL>, dim3(((nwg + 7) / 8) * 8), dim3(kTP), 0, st, loc, attn, go, tile_count, entries,
+                       gv, g, nwg, (unsigned)((size_t)g.N * g.Lq * g.M * LP * 8), (unsigned)((size_t)g.N * g.Lq * g.M * kD * 4));
+    mpf::prof_end("msda_bwd_pull_mfma_kernel", st, esz * ((double)g.N * g.Lq * g.M * kD + (double)g.N * g.S * g.M * kD));
+    hipLaunchKernelGGL(msda_bwd_spill_kernel<NL>, dim3(64), dim3(kT), 0, st, loc, attn, go, ovf_count, ovf, gv, g);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+namespace mpf {
+
+// forward through the blocked kernel; returns -1000 when the problem is outside its shapes (caller falls back)
+int msda_block_forward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, void* out, int N, int S, int M,
+                       int D, int L, int Lq, int P, int dtype, hipStream_t st)
+{
+    if (!host_shapes || !block_ok(N, S, M, D, L, Lq, P, dtype)) return -1000;
+    GeomB g;
+    if (!build_geom(g, host_shapes, N, S, M, L, Lq)) return -1000;
+    mpf::prof_begin(st);
+    mpf::set_kernel("msda_fwd_block_kernel");
+    hipError_t err;
+    switch (L) {
+        case 1: err = launch_fwd<1>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st); break;
+        case 2: err = launch_fwd<2>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st); break;
+        case 3: err = launch_fwd<3>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st); break;
+        default: err = launch_fwd<4>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st); break;
+    }
+    mpf::prof_end("msda_fwd_block_kernel", st, 4.0 * ((double)N * S * M * D + (double)N * Lq * M * L * P * 3 + (double)N * Lq * M * D));
+    return mpf::check(err, "msda_fwd_block_kernel");
+}
+
+size_t msda_block_workspace_bytes(const int64_t* host_shapes, int N, int M, int L, int Lq, int P)
+{
+    if (!host_shapes || P != kP || L < 1 || L > kMaxL) return 0;
+    int64_t S = 0;
+    for (int l = 0; l < L; ++l) S += host_shapes[2 * l] * host_shapes[2 * l + 1];
+    GeomB g;
+    if (S >= (1ll << 31) || !build_geom(g, host_shapes, N, (int)S, M, L, Lq)) return 0;
+    return ws_layout(g).total;
+}
+
+int msda_block_backward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, const void* go, void* gv,
+                        void* gl, void* ga, void* graw, int N, int S, int M, int D, int L, int Lq, int P, int dtype, void* workspace,
+                        size_t workspace_bytes, hipStream_t st)
+{
+    if (!host_shapes || !block_ok(N, S, M, D, L, Lq, P, dtype)) return -1000;
+    GeomB g;
+    if (!build_geom(g, host_shapes, N, S, M, L, Lq)) return -1000;
+    if (workspace_bytes < ws_layout(g).total) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: workspace too small");
+    mpf::set_kernel("msda_bwd_block(push+pull)");
+    hipError_t err;
+    switch (L) {
+        case 1: err = launch_bwd<1>((const float*)value, (const float*)loc, (const float*)attn, (const float*)go, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
+        case 2: err = launch_bwd<2>((const float*)value, (const float*)loc, (const float*)attn, (const float*)go, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
+        case 3: err = launch_bwd<3>((const float*)value, (const float*)loc, (const float*)attn, (const float*)go, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
+        default: err = launch_bwd<4>((const float*)value, (const float*)loc, (const float*)attn, (const float*)go, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
+    }
+    return mpf::check(err, "msda_bwd_block");
+}
+
+int set_block_option(const char* key, int v)
+{
+    if (!strcmp(key, "msda_region_rows")) {
+        if (v < 8 || v > 1000) return MPF_E_SHAPE;
+        g_region_rows = v;
+        return 0;
+    }
+    if (!strcmp(key, "msda_block_disable")) { g_block_disable = v; return 0; }
+    return 1;
+}
+
+}  // namespace mpf

@@ -571,7 +571,9 @@ extern "C" size_t mpf_msda_backward_workspace_bytes(int batch, int num_heads, in
     if (!build_geom(g, host_spatial_shapes, batch, (int)S, num_heads, num_levels, num_query, num_point)) return 0;
     const size_t T = (size_t)batch * num_heads * g.tiles_per_bm * 4;   // bins: tile x (pixel row mod 4)
     const size_t max_entries = (size_t)batch * num_query * num_heads * num_levels * num_point * 4;
-    return align256((3 * T + 1) * sizeof(int)) + max_entries * sizeof(Entry);
+    const size_t binned = align256((3 * T + 1) * sizeof(int)) + max_entries * sizeof(Entry);
+    const size_t blocked = mpf::msda_block_workspace_bytes(host_spatial_shapes, batch, num_heads, num_levels, num_query, num_point);
+    return binned > blocked ? binned : blocked;
 }
 
 static int backward_ws_impl(const void* value, const int64_t* host_spatial_shapes,
@@ -587,6 +589,12 @@ static int backward_ws_impl(const void* value, const int64_t* host_spatial_shape
         return mpf::fail(MPF_E_NULL, "msda_backward_ws: NULL buffer");
     if (dtype != MPF_F32 || D != kD) return mpf::fail(MPF_E_DTYPE, "msda_backward_ws: fp32 with 32 channels per head only");
     if (N <= 0 || S <= 0 || M <= 0 || L <= 0 || Lq <= 0 || P <= 0) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: bad sizes");
+    {   // production path: spatially blocked push + MFMA pull (msda_block.hip); -1000 = not its shapes
+        const int r = mpf::msda_block_backward(value, host_spatial_shapes, sampling_loc, attn_weight, grad_output, grad_value,
+                                               grad_sampling_loc, grad_attn_weight, grad_raw, N, S, M, D, L, Lq, P, dtype, workspace,
+                                               workspace_bytes, (hipStream_t)stream);
+        if (r != -1000) return r;
+    }
     Geom g;
     if (!build_geom(g, host_spatial_shapes, N, S, M, L, Lq, P))
         return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: unsupported level geometry (L <= 8, L*P <= 32, sum HW == S)");

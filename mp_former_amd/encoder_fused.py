@@ -67,6 +67,7 @@ class EncoderFn(Function):
         M, L, P = meta["n_heads"], meta["n_levels"], meta["n_points"]
         shapes, lsi, ref, normalizer, level_idx = meta["shapes"], meta["lsi"], meta["ref"], meta["normalizer"], meta["level_idx"]
         pos_full = pos_const + level_embed.index_select(0, level_idx)           # [S, C]
+        host_shapes = getattr(shapes, "_mpf_host", None)
         x = src.reshape(R, C)
         saved = []
         no = M * L * P * 2
@@ -90,7 +91,7 @@ class EncoderFn(Function):
                 q = (x.view(N, S, C) + pos_full).view(R, C)
             raw = gemm3(q, p288, b288)
             # softmax over the 12 logits, loc = ref + offset / (W_l, H_l) happen inside the MSDA kernel
-            ao, loc, attn = ms_deform_attn_forward_raw(value.view(N, S, M, C // M), shapes, lsi, raw, ref)
+            ao, loc, attn = ms_deform_attn_forward_raw(value.view(N, S, M, C // M), shapes, lsi, raw, ref, host_shapes)
             ao = ao.view(R, C)
             s1 = gemm3(ao, po, bo, cin=x)
             x1, mean1, rstd1, _ = ln256_forward(s1, g1, b1, _EPS)

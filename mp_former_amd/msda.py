@@ -62,19 +62,25 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
-    """-> output [N, Lq, M*D]; freshly allocated, computed on the current stream."""
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
+                           host_shapes=None):
+    """-> output [N, Lq, M*D]; freshly allocated, computed on the current stream.  The spatially blocked
+    production kernel needs the level geometry on the host (`host_shapes`, or the copy attached by
+    `attach_host_shapes`); without it the first-generation gather kernel runs (no device->host copy is
+    ever made here: the forward never blocks)."""
     _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                    ("attn_weight", attn_weight)])
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+    hs = host_shapes if host_shapes is not None else _attached_host_shapes(spatial_shapes, level_start_index)
     with torch.cuda.device(value.device):
-        code = _lib.lib().mpf_msda_forward(
+        code = _lib.lib().mpf_msda_forward_hs(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            hs.data_ptr() if hs is not None else None,
             sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
             N, S, M, D, L, Lq, P, _DTYPES[value.dtype], _stream(value))
-    _lib.check(code, "mpf_msda_forward")
+    _lib.check(code, "mpf_msda_forward_hs")
     return out
 
 
@@ -85,24 +91,47 @@ BWD_MODE = "auto"
 _workspaces = {}
 
 
-def attach_host_shapes(spatial_shapes, shapes_list):
-    """Remember the host-side (H, W) list on a device `spatial_shapes` tensor so that the binned
-    backward needs no device->host copy (the pixel decoder builds the tensor from python ints)."""
-    spatial_shapes._mpf_host = torch.as_tensor(shapes_list, dtype=torch.int64).contiguous()
+def _contiguous_starts(hs):
+    return torch.cat((hs.new_zeros(1), (hs[:, 0] * hs[:, 1]).cumsum(0)[:-1]))
+
+
+def attach_host_shapes(spatial_shapes, shapes_list, level_start_index=None):
+    """Remember the host-side (H, W) list on a device `spatial_shapes` tensor so that the blocked kernels
+    need no device->host copy (the pixel decoder builds the tensor from python ints).  The blocked
+    kernels assume levels stored back to back; the device `level_start_index` the copy belongs to is
+    remembered too (by identity), so a caller passing a DIFFERENT level_start_index later is detected
+    host-side and takes the kernels that honour it (the attached copy used to bypass that check)."""
+    hs = torch.as_tensor(shapes_list, dtype=torch.int64).contiguous()
+    spatial_shapes._mpf_host = hs
+    spatial_shapes._mpf_lsi = None
+    if level_start_index is not None:
+        if not torch.equal(level_start_index.cpu(), _contiguous_starts(hs)):
+            raise ValueError("attach_host_shapes: level_start_index is not the running sum of H*W")
+        spatial_shapes._mpf_lsi = level_start_index
     return spatial_shapes
+
+
+def _attached_host_shapes(spatial_shapes, level_start_index):
+    """The attached host copy, if it is known to describe `level_start_index` too (no device sync)."""
+    hs = getattr(spatial_shapes, "_mpf_host", None)
+    if hs is None:
+        return None
+    known = getattr(spatial_shapes, "_mpf_lsi", None)
+    if known is not None and known is not level_start_index and known.data_ptr() != level_start_index.data_ptr():
+        return None          # a different level_start_index: unknown layout -> kernels that read it from the device
+    return hs
 
 
 def _host_shapes(spatial_shapes, level_start_index):
     """Host copy of spatial_shapes: the attached copy if the caller provided one, else a (blocking)
     device->host copy — the price of the reference's all-device signature.  Returns None when the
-    levels are not stored back to back (then the binned path does not apply)."""
-    hs = getattr(spatial_shapes, "_mpf_host", None)
-    if hs is not None:
+    levels are not stored back to back (then the blocked / binned paths do not apply)."""
+    hs = _attached_host_shapes(spatial_shapes, level_start_index)
+    if hs is not None and getattr(spatial_shapes, "_mpf_lsi", None) is not None:
         return hs
     hs = spatial_shapes.cpu().contiguous()
     lsi = level_start_index.cpu()
-    expect = torch.cat((hs.new_zeros(1), (hs[:, 0] * hs[:, 1]).cumsum(0)[:-1]))
-    return hs if torch.equal(lsi, expect) else None
+    return hs if torch.equal(lsi, _contiguous_starts(hs)) else None
 
 
 def _workspace(device, nbytes):
@@ -157,7 +186,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [gv, gl, ga]
 
 
-def ms_deform_attn_forward_raw(value, spatial_shapes, level_start_index, raw, ref_points):
+def ms_deform_attn_forward_raw(value, spatial_shapes, level_start_index, raw, ref_points, host_shapes=None):
     """Module-level forward (mpf_msda_forward_raw): value [N,S,M,32] fp32, raw [N*Lq, M*L*P*3] (sampling
     offsets | attention logits of ops/modules/ms_deform_attn.py:103-106), ref_points [Lq,2] (the same
     point for every level) -> (out [N,Lq,M*32], loc [N,Lq,M,L,P,2], attn [N,Lq,M,L,P])."""
@@ -170,11 +199,12 @@ def ms_deform_attn_forward_raw(value, spatial_shapes, level_start_index, raw, re
     loc = torch.empty((N, Lq, M, L, P, 2), dtype=value.dtype, device=value.device)
     attn = torch.empty((N, Lq, M, L, P), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
-        code = _lib.lib().mpf_msda_forward_raw(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), raw.data_ptr(), ref_points.data_ptr(),
+        code = _lib.lib().mpf_msda_forward_raw_hs(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            host_shapes.data_ptr() if host_shapes is not None else None, raw.data_ptr(), ref_points.data_ptr(),
             loc.data_ptr(), attn.data_ptr(), out.data_ptr(),
             N, S, M, D, L, Lq, P, _DTYPES[value.dtype], _stream(value))
-    _lib.check(code, "mpf_msda_forward_raw")
+    _lib.check(code, "mpf_msda_forward_raw_hs")
     return out, loc, attn
 
 
@@ -205,11 +235,13 @@ class MSDeformAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
+        ctx.host_shapes = _attached_host_shapes(value_spatial_shapes, value_level_start_index)
+        if ctx.host_shapes is not None and getattr(value_spatial_shapes, "_mpf_lsi", None) is None:
+            ctx.host_shapes = None      # attached without its level_start_index: layout not vouched for
         output = ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
-                                        sampling_locations, attention_weights, ctx.im2col_step)
+                                        sampling_locations, attention_weights, ctx.im2col_step, ctx.host_shapes)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
-        ctx.host_shapes = getattr(value_spatial_shapes, "_mpf_host", None)
         return output
 
     @staticmethod

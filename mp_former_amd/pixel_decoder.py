@@ -172,8 +172,11 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         key = (tuple(shapes_list), srcs[0].device)
         cached = self._shape_cache.get(key)
         if cached is None:
-            ss = attach_host_shapes(torch.as_tensor(shapes_list, dtype=torch.long, device=srcs[0].device), shapes_list)
+            ss = torch.as_tensor(shapes_list, dtype=torch.long, device=srcs[0].device)
             lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+            # host copy of the geometry + the level starts it vouches for (lsi is the running sum by construction: no sync)
+            attach_host_shapes(ss, shapes_list)
+            ss._mpf_lsi = lsi
             cached = (ss, lsi)
             self._shape_cache[key] = cached
         spatial_shapes, level_start_index = cached

@@ -15,6 +15,9 @@ from conftest import MSDA_CFG, MSDA_TESTPY, load_msda_fixture, smooth_points
 pytestmark = pytest.mark.gpu
 
 VARIANTS = {"auto": 0, "binned": 0, "generic": 1, "tiled_v4": 2, "tiled_v1": 3, "tiled_v2": 4}
+# "auto": the production path — spatially blocked forward / push + MFMA pull (csrc/msda_block.hip), host level geometry
+#         attached the way the pixel decoder attaches it; "binned": the first-generation atomics-free backward
+#         (blocked kernels disabled); the others force one first-generation kernel family.
 
 
 @pytest.fixture(scope="module")
@@ -29,6 +32,7 @@ def _reset_variants():
     yield
     _lib.set_option("msda_fwd_variant", 0)
     _lib.set_option("msda_bwd_variant", 0)
+    _lib.set_option("msda_block_disable", 0)
     msda.BWD_MODE = "auto"
 
 
@@ -38,9 +42,12 @@ def _run(z, dtype, dev, variant="auto"):
     _lib.set_option("msda_bwd_variant", VARIANTS[variant])
     # "auto": atomics-free binned backward where applicable; "binned": require it; else hardware atomics
     msda.BWD_MODE = variant if variant in ("auto", "binned") else "atomic"
+    _lib.set_option("msda_block_disable", 0 if variant == "auto" else 1)
     t = lambda k: torch.from_numpy(np.ascontiguousarray(z[k])).to(dtype).to(dev)  # noqa: E731
     shapes = torch.from_numpy(z["shapes"]).to(dev)
     lsi = torch.from_numpy(z["level_start"]).to(dev)
+    if variant == "auto":
+        msda.attach_host_shapes(shapes, z["shapes"].tolist(), lsi)
     v, loc, a, g = t("value"), t("loc"), t("attn"), t("grad_out")
     out = ms_deform_attn_forward(v, shapes, lsi, loc, a, 128)
     kf = _lib.last_kernel()
@@ -80,10 +87,11 @@ def test_fp32_matches_reference_golden(dev, name, variant):
     z = load_msda_fixture(name)
     (out, gv, gl, ga), (kf, kb) = _run(z, torch.float32, dev, variant)
     D = z["value"].shape[-1]
-    if D == 32 and variant != "generic":
+    L, P = z["loc"].shape[3], z["loc"].shape[4]
+    if D == 32 and variant == "auto" and P == 4 and L <= 4:
+        assert "block" in kf and "block" in kb, (kf, kb)
+    elif D == 32 and variant != "generic":
         assert "tiled" in kf and ("tiled" in kb or "binned" in kb), (kf, kb)
-        if variant == "auto":
-            assert "binned" in kb, kb
     else:
         assert "generic<float>" in kf and "generic<float>" in kb
     for got, key in ((out, "out"), (ga, "grad_attn")):
@@ -110,7 +118,7 @@ def _random_problem(N, lv, M=8, D=32, P=4, seed=0, oob=True):
                 attn=attn.numpy(), grad_out=go.numpy())
 
 
-@pytest.mark.parametrize("variant", ["binned", "tiled_v4", "tiled_v1", "tiled_v2", "generic"])
+@pytest.mark.parametrize("variant", ["auto", "binned", "tiled_v4", "tiled_v1", "tiled_v2", "generic"])
 def test_fp32_vs_oracle_config_A(dev, oracle_msda, variant):
     """config A (256x256 -> levels 8,16,32; S=1344), N=2, vs the C oracle on the same seeded input."""
     z = _random_problem(2, [(8, 8), (16, 16), (32, 32)], seed=1)
@@ -133,7 +141,7 @@ def test_fp32_full_size_config_B_vs_oracle_and_properties(dev, oracle_msda):
     from mp_former_amd import ms_deform_attn_forward
     z = _random_problem(1, [(32, 32), (64, 64), (128, 128)], seed=2)
     (out, gv, gl, ga), (kf, kb) = _run(z, torch.float32, dev)
-    assert "tiled" in kf and "binned" in kb
+    assert "block" in kf and "block" in kb, (kf, kb)
     ref = oracle_msda.msda_forward(z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"])
     np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5)
     rgv, rgl, rga = oracle_msda.msda_backward(z["value"], z["shapes"], z["level_start"], z["loc"],
@@ -142,7 +150,12 @@ def test_fp32_full_size_config_B_vs_oracle_and_properties(dev, oracle_msda):
     np.testing.assert_allclose(ga, rga, rtol=1e-4, atol=1e-4)
     ok = smooth_points(z)
     np.testing.assert_allclose(gl[ok], rgl[ok], rtol=1e-3, atol=5e-3)
-    # the atomics-free and the atomic formulations agree
+    # the blocked kernels, the first-generation atomics-free backward and the atomic formulation agree
+    (out0, gv0, gl0, ga0), (kf0, kb0) = _run(z, torch.float32, dev, "binned")
+    assert "tiled" in kf0 and "binned" in kb0, (kf0, kb0)
+    np.testing.assert_allclose(out0, out, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gv0, gv, rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(ga0, ga, rtol=1e-4, atol=1e-5)
     (out1, gv1, gl1, ga1), (_, kb1) = _run(z, torch.float32, dev, "tiled_v1")
     assert "tiled" in kb1
     np.testing.assert_allclose(out1, out, rtol=1e-5, atol=1e-6)
@@ -166,7 +179,7 @@ def test_fp32_config_E_shape_batch2(dev, oracle_msda):
     stress shape; compare a strided subset of queries with the oracle run on that subset."""
     z = _random_problem(2, [(32, 64), (64, 128), (128, 256)], seed=3)
     (out, gv, gl, ga), (kf, kb) = _run(z, torch.float32, dev)
-    assert "tiled" in kf
+    assert "block" in kf and "block" in kb, (kf, kb)
     sub = slice(0, None, 37)
     zs = dict(z)
     zs["loc"] = np.ascontiguousarray(z["loc"][:, sub])
@@ -280,7 +293,7 @@ def test_raw_forms_match_softmax_plus_op(shapes, N):
     (W_l, H_l) and their backward folded into the kernels; ops/modules/ms_deform_attn.py:103-117)
     against torch softmax / division around the plain op."""
     import torch
-    from mp_former_amd import msda
+    from mp_former_amd import _lib, msda
     dev = torch.device("cuda:0")
     torch.manual_seed(5)
     M, D, L, P = 8, 32, len(shapes), 4
@@ -292,7 +305,8 @@ def test_raw_forms_match_softmax_plus_op(shapes, N):
     raw[:, :M * L * P * 2] *= 3.0                      # offsets of a few pixels, some out of range
     ref = torch.rand(S, 2, device=dev)
     go = torch.randn(N, S, M * D, device=dev)
-    out, loc, attn = msda.ms_deform_attn_forward_raw(value, ss, lsi, raw, ref)
+    out, loc, attn = msda.ms_deform_attn_forward_raw(value, ss, lsi, raw, ref, ss._mpf_host)
+    assert "block" in _lib.last_kernel(), _lib.last_kernel()
     # reference composition
     r = raw.detach().clone().requires_grad_(True)
     v = value.detach().clone().requires_grad_(True)

@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
-"""Per-kernel breakdown of the binned MSDA backward (in-library HIP-event profiler)."""
+"""Per-kernel breakdown of the MSDA forward + backward at config B, N=2 (in-library HIP-event profiler).
+usage: bench_msda_breakdown.py [init|trained|uniform] [cfg] [N]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.bench_msda import problem
-from mp_former_amd import _lib, ms_deform_attn_backward, msda
+from mp_former_amd import _lib, ms_deform_attn_backward, ms_deform_attn_forward, msda
 dev = torch.device("cuda:0")
 mode = sys.argv[1] if len(sys.argv) > 1 else "init"
-value, shapes, lsi, loc, attn, go, S = problem("B", 2, dev, mode)
-msda.BWD_MODE = "binned"
-if len(sys.argv) > 2:
-    _lib.set_option("msda_push_ablate", int(sys.argv[2]))
+cfg = sys.argv[2] if len(sys.argv) > 2 else "B"
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+value, shapes, lsi, loc, attn, go, S = problem(cfg, N, dev, mode)
+ss = msda.attach_host_shapes(shapes, shapes.tolist(), lsi)
 for _ in range(3):
-    ms_deform_attn_backward(value, shapes, lsi, loc, attn, go, 128)
+    ms_deform_attn_forward(value, ss, lsi, loc, attn, 128)
+    ms_deform_attn_backward(value, ss, lsi, loc, attn, go, 128)
 torch.cuda.synchronize()
 _lib.profile_enable(True)
 for _ in range(10):
-    ms_deform_attn_backward(value, shapes, lsi, loc, attn, go, 128)
+    ms_deform_attn_forward(value, ss, lsi, loc, attn, 128)
+    ms_deform_attn_backward(value, ss, lsi, loc, attn, go, 128)
 torch.cuda.synchronize()
-for k in ("push", "fill", "pull"):
-    n, ms, by = _lib.profile_get("msda_bwd_" + k)
-    print(f"{k:5s} launches={n} avg={ms / max(n, 1) * 1e3:8.1f} us")
+for k in ("msda_fwd", "msda_bwd_push", "msda_bwd_fill", "msda_bwd_pull"):
+    n, ms, by = _lib.profile_get(k)
+    if n:
+        print(f"{k:14s} launches={n} avg={ms / n * 1e3:8.1f} us")
