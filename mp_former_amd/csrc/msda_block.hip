@@ -593,12 +593,6 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTP = 1024;
 
-struct PullGather {
-    float2 xy;
-    float a;
-    float2 g;
-};
-
 template <int NL>
 __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
@@ -606,15 +600,22 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
     unsigned loc_bytes, unsigned go_bytes)
 {
     __shared__ float s_red[15][8][64];                 // partial accumulators of the waves with part > 0
+    __shared__ float4 s_rec[16][64];                   // per wave: the 64 sample records of the current chunk
     const int wg = xcd_index(nwg);
     if (wg >= nwg) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroup -> (bm, band, level)
     const int bm = wg / g.wg_per_bm;
     const int r = wg - bm * g.wg_per_bm;
-    int slot = 0;
-#pragma unroll 1
-    for (int k = 1; k < g.nband * NL; ++k) if (r >= g.band_wg_base[k]) slot = k;
+    // (band, level) group of this workgroup: the lanes compare r with the group bases in parallel (a scalar loop would
+    // be one dependent kernarg load per group — thousands of cycles per wave)
+    int slot;
+    {
+        const int nslot = g.nband * NL;
+        const int base_k = g.band_wg_base[min(lane, nslot - 1)];
+        const unsigned long long ge = __ballot(lane < nslot && r >= base_k);
+        slot = __builtin_amdgcn_readfirstlane(__popcll(ge) - 1);
+    }
     const int band = slot / NL, l = slot - band * NL;
     const int wpt = g.wpt[l];
     const int W = g.W[l], H = g.H[l];
@@ -632,12 +633,17 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
     const int kgrp = lane >> 4, j = lane & 15;
     int n = 0;
     if (live) n = min(tile_count[bm * g.tiles_per_bm + g.tile_base[l] + local], g.cap[l]);
-    if (n > 0) {
-        const unsigned* ent = entries + (int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)local * g.cap[l];
-        // lane (i = lane & 15, k = lane >> 4): pixel i of the tile, sample k of the step
+    const int nchunks = (n + 63) >> 6;
+    if (part < nchunks) {
+        // Two lane roles.  "Sample role" (once per chunk of 64 entries): lane = entry; one coalesced load of the entries,
+        // one gather of loc / attn per lane (64 samples in flight per instruction), pixel coordinates computed once per
+        // sample, the record {x, y, a, grad_out row offset} parked in LDS.  "MFMA role" (16 steps of 4 samples): lane =
+        // (pixel i = lane & 15, sample k = lane >> 4) reads its sample's record back (one 16-byte LDS read, a broadcast
+        // inside the 16-lane group), loads its 8 bytes of the sample's grad_out row and forms its hat weight.
+        const unsigned* ent = entries + (int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)local * g.cap[l];   // this tile's run
         const float fpx = (float)(tx * 4 + (j & 3)), fpy = (float)(ty * 4 + (j >> 2));
         const float fW = (float)W, fH = (float)H;
-        const int nsteps = (n + 3) >> 2;
+        const __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(ent), 0, (unsigned)n * 4u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_loc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(loc), 0, loc_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_att = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(attn), 0, loc_bytes >> 1, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_out), 0, go_bytes, 0x00020000);
@@ -645,34 +651,61 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
         const int so_loc = gi_base * 8, so_att = gi_base * 4;
         const int so_go = (b * g.Lq * g.M + m) * (kD * 4);
         const int M128 = g.M * (kD * 4);
-        auto entry = [&](int s) { return ent[min(s * 4 + kgrp, n - 1)]; };     // unconditional, clamped
-        auto gather = [&](unsigned e) {
-            const int q = (int)(e >> 2), pt = (int)(e & 3);
-            const int si = q * MLP + pt;
-            PullGather r_;
+        // entries beyond n read as 0 through the buffer's bounds check (num_records = n * 4) — no branch around the load
+        auto load_entry = [&](int c) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_ent, (c * 64 + lane) * 4, 0, 0); };
+        struct LA { float x, y, a; };
+        auto gather_la = [&](unsigned e) {
+            const int si = (int)(e >> 2) * MLP + (int)(e & 3);
             const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(rs_loc, si * 8, so_loc, 0);
-            r_.xy = make_float2(__int_as_float(v2[0]), __int_as_float(v2[1]));
-            r_.a = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_att, si * 4, so_att, 0));
-            const auto g2 = __builtin_amdgcn_raw_buffer_load_b64(rs_go, q * M128 + j * 8, so_go, 0);
-            r_.g = make_float2(__int_as_float(g2[0]), __int_as_float(g2[1]));
-            return r_;
+            LA t;
+            t.x = __int_as_float(v2[0]); t.y = __int_as_float(v2[1]);
+            t.a = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_att, si * 4, so_att, 0));
+            return t;
         };
-        // software pipeline, two stages ahead: entries of step s + 2 and the gathers of step s + 1 are in flight while
-        // step s is multiplied
-        int s = part;
-        unsigned e_b = entry(s + wpt);
-        PullGather ga = gather(entry(s));
-        for (; s < nsteps; s += wpt) {
-            const unsigned e_c = entry(s + 2 * wpt);
-            const PullGather gb = gather(e_b);
-            const float x = fmaf(ga.xy.x, fW, -0.5f), y = fmaf(ga.xy.y, fH, -0.5f);
-            // hat weights: zero for every pixel outside the 2x2 footprint, hence also for out-of-range samples
-            const float wx = fmaxf(0.f, 1.f - fabsf(fpx - x)), wy = fmaxf(0.f, 1.f - fabsf(fpy - y));
-            const float av = (s * 4 + kgrp < n) ? ga.a : 0.f;
-            const float wgt = wy * wx * av;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, ga.g.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, ga.g.y, acc1, 0, 0, 0);
-            ga = gb; e_b = e_c;
+        const char* rec_base = reinterpret_cast<const char*>(&s_rec[wave][0]) + kgrp * 16;
+        int c = part;
+        unsigned e_cur = load_entry(c);
+        unsigned e_nxt = load_entry(c + wpt);
+        LA la = gather_la(e_cur);
+#pragma unroll 1
+        for (; c < nchunks; c += wpt) {
+            // next chunk: gathers and the entries after it go out before this chunk's 16 steps
+            const LA la_n = gather_la(e_nxt);
+            const unsigned e_nn = load_entry(c + 2 * wpt);
+            {
+                const bool valid = c * 64 + lane < n;
+                float4 rec;
+                rec.x = fmaf(la.x, fW, -0.5f);
+                rec.y = fmaf(la.y, fH, -0.5f);
+                rec.z = valid ? la.a : 0.f;
+                rec.w = __int_as_float(valid ? (int)(e_cur >> 2) * M128 + j * 0 : kOobOff);
+                s_rec[wave][lane] = rec;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int nst = min(16, (n - c * 64 + 3) >> 2);
+            // all 16 grad_out row loads of the chunk go out first (row offsets only), then the steps read their record
+            float2 gq[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int goff = *reinterpret_cast<const int*>(rec_base + s * 64 + 12);
+                const auto g2 = __builtin_amdgcn_raw_buffer_load_b64(rs_go, goff + j * 8, so_go, 0);
+                gq[s] = make_float2(__int_as_float(g2[0]), __int_as_float(g2[1]));
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (s < nst) {
+                    const float4 rec = *reinterpret_cast<const float4*>(rec_base + s * 64);
+                    // hat weights: zero for every pixel outside the 2x2 footprint, hence also for out-of-range samples
+                    const float wx = fmaxf(0.f, 1.f - fabsf(fpx - rec.x)), wy = fmaxf(0.f, 1.f - fabsf(fpy - rec.y));
+                    const float wgt = wy * wx * rec.z;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, gq[s].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, gq[s].y, acc1, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            e_cur = e_nxt; e_nxt = e_nn; la = la_n;
         }
     }
     if (wpt > 1) {
@@ -772,7 +805,7 @@ bool build_geom(GeomB& g, const int64_t* hs, int N, int S, int M, int L, int Lq)
         g.tile_base[l] = tbase; tbase += ntiles;
         if ((int64_t)ebase + (int64_t)ntiles * cap >= (1ll << 31)) return false;
         g.ent_base[l] = ebase; ebase += (int)(ntiles * cap);
-        // waves per tile: aim at ~32 steps (128 entries) per wave
+        // waves per tile: aim at ~2 chunks (128 entries) per wave
         g.wpt[l] = expect > 1400.0 ? 16 : (expect > 700.0 ? 8 : (expect > 350.0 ? 4 : (expect > 175.0 ? 2 : 1)));
     }
     (void)wgb;
