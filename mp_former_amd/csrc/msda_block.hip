@@ -72,6 +72,18 @@ struct GeomB {
     int band_wg_base[kMaxBand * kMaxL];
 };
 
+// a[i] for a run-time i without a run-time kernarg offset: every element is read at its constant offset (hipcc batches
+// those into one or two wide scalar loads) and selected; g.x[i] with a run-time i is one DEPENDENT scalar load per use —
+// a dozen serialized round trips (~5000 cycles) in a kernel prologue
+template <int N>
+__device__ __forceinline__ int sel(const int (&a)[N], int i)
+{
+    int v = a[0];
+#pragma unroll
+    for (int k = 1; k < N; ++k) v = i == k ? a[k] : v;
+    return v;
+}
+
 // pixel coordinate of a sampling location; explicitly rounded (no FMA contraction) so that every kernel
 // derives the same footprint for a sample
 __device__ __forceinline__ float pix(float loc, int size) { return __fsub_rn(__fmul_rn(loc, (float)size), 0.5f); }
@@ -148,7 +160,7 @@ __device__ __forceinline__ Dec decode(float2 xy, int H, int W, bool valid)
 constexpr int kOffBB = 8192, kOffZero = 8320, kOffReg = 8448;
 
 struct BlockCtx {
-    int b, m, ql, by, bx;
+    int b, m, ql, by, bx, qH, qW, qstart;
 };
 
 // stage `rows` (= rw * rh) value rows of the box (ymin.., xmin..) of level l into the region buffer with
@@ -210,8 +222,9 @@ __device__ __forceinline__ void block_of(const GeomB& g, int blk, BlockCtx& c)
     int ql = 0;
 #pragma unroll
     for (int k = 1; k < kMaxL; ++k) if (k < g.nql && qb >= g.qblk_base[k]) ql = k;
-    const int r = qb - g.qblk_base[ql];
-    c.ql = ql; c.by = r / g.qnbx[ql]; c.bx = r - c.by * g.qnbx[ql];
+    const int r = qb - sel(g.qblk_base, ql), nbx = sel(g.qnbx, ql);
+    c.ql = ql; c.by = r / nbx; c.bx = r - c.by * nbx;
+    c.qH = sel(g.qH, ql); c.qW = sel(g.qW, ql); c.qstart = sel(g.qstart, ql);
 }
 
 // query index of block-local query qi (or -1 when the block sticks out of its level)
@@ -219,7 +232,7 @@ __device__ __forceinline__ int query_of(const GeomB& g, const BlockCtx& c, int q
 {
     const int qy = qi >> g.bw_log2, qx = qi & ((1 << g.bw_log2) - 1);
     const int gy = c.by * g.bh + qy, gx = (c.bx << g.bw_log2) + qx;
-    return (gy < g.qH[c.ql] && gx < g.qW[c.ql]) ? g.qstart[c.ql] + gy * g.qW[c.ql] + gx : -1;
+    return (gy < c.qH && gx < c.qW) ? c.qstart + gy * c.qW + gx : -1;
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -369,40 +382,50 @@ __device__ __forceinline__ int hash_slot(unsigned* keys, unsigned key)
     return -1;
 }
 
-// LDS of the push kernel:
-//   [0, 64)   bounding boxes   [128, 256) the zero row   [256, 8448) grad_out rows of the 64 queries
-//   [8448, 8448 + region)  staged value rows   then the hash table (keys, counts, run bases)
+// LDS of the push kernel (rows padded to a pitch of 144 B):
+//   [0, 64)   bounding boxes   [128, 272) the zero row   [512, 9728) grad_out rows of the 64 queries
+//   [9728, 9728 + cap * 144)  staged value rows; the hash table (keys, counts) lives in the same bytes before the first
+//   box is written, the run bases after the last one is read.
 // Thread = one sample per level, (query tid >> 2, point tid & 3): the thread that decodes a sample also reduces it — it
-// walks the 32 channels of its four corner rows and of its query's grad_out row with 16-byte LDS reads (8 per row), so
-// grad_attn / grad_loc need no cross-lane reduction and no descriptor round trip through LDS.  Lanes rotate the order
-// in which they visit the eight 16-byte pieces of a row (piece (k + phi) mod 8, phi from the query index) so that the
-// four queries of a 16-lane LDS service group, whose rows are 128 B apart, do not meet on the same banks.
-constexpr int kPOffZero = 128, kPOffG = 256;
+// walks the 32 channels of its four corner rows and of its query's grad_out row with 16-byte LDS reads (8 per row, all
+// at immediate offsets), so grad_attn / grad_loc need no cross-lane reduction and no descriptor round trip through LDS.
+// Lanes of a 16-lane LDS service group read the SAME piece of DIFFERENT rows; with 128-B rows every second row would
+// sit on the same banks, the 144-B pitch (9 x 16 B, odd) makes rows collide only when their indices agree mod 16.
+// Boxes are staged through registers (global_load -> ds_write; the direct-to-LDS path cannot pad): the loads of level
+// l + 1 are issued before level l is reduced and written after it, so their latency hides behind the arithmetic; the
+// returning adds that reserve the entry runs are consumed at the very end for the same reason.
+constexpr int kPitch = 144, kPOffZero = 128, kPOffG = 512, kPOffReg = kPOffG + kQB * kPitch;
+constexpr int kPStage = 7;        // 16-byte pieces per thread and level: covers 7 * 256 / 8 = 224 rows
 
 template <int NL>
 __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
     const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
     const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
     float* __restrict__ grad_raw, int* __restrict__ tile_count, unsigned* __restrict__ entries,
-    int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB g, int nblocks, int region_cap, int region_bytes,
-    unsigned value_bytes)
+    int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB g, int nblocks, int region_cap, unsigned value_bytes, int ablate, unsigned long long* __restrict__ dbg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* s_bb = reinterpret_cast<int*>(smem);
     constexpr int LP = NL * kP;
-    unsigned* s_keys = reinterpret_cast<unsigned*>(smem + kOffReg + region_bytes);   // [kSlots]
+    unsigned* s_keys = reinterpret_cast<unsigned*>(smem + kPOffReg);                 // [kSlots]   (aliases the box)
     int* s_cnt = reinterpret_cast<int*>(s_keys + kSlots);                            // [kSlots]
-    int* s_base = s_cnt + kSlots;                                                    // [kSlots]
+    int* s_base = reinterpret_cast<int*>(smem + kPOffReg);                           // [kSlots]   (after the last level)
 
     const int blk = xcd_index(nblocks);
     if (blk >= nblocks) return;
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (dbg && threadIdx.x == 0) dbg[(size_t)blk * 16 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
     BlockCtx c;
     block_of(g, blk, c);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < kMaxL * 4) s_bb[tid] = (tid & 2) ? INT_MIN : INT_MAX;
-    if (tid >= 32 && tid < 64) reinterpret_cast<float*>(smem + kPOffZero)[tid - 32] = 0.f;
-    for (int i = tid; i < kSlots; i += kT) { s_keys[i] = kEmpty; s_cnt[i] = 0; }
+    if (tid >= 64 && tid < 64 + kPitch / 4) reinterpret_cast<float*>(smem + kPOffZero)[tid - 64] = 0.f;
+    s_keys[tid] = kEmpty; s_cnt[tid] = 0;                      // kSlots == kT
+    if (tid == 0) s_cnt[kSlots] = 0;
 
     const int qi_d = tid >> 2, p_d = tid & 3;
     const int q_d = query_of(g, c, qi_d);
@@ -412,149 +435,275 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
         const int64_t gi0 = ((int64_t)(c.b * g.Lq + max(q_d, 0)) * g.M + c.m) * LP + p_d;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            xy[l] = reinterpret_cast<const float2*>(loc)[gi0 + l * kP];
-            at[l] = attn[gi0 + l * kP];
+            if (ablate & 16) {
+                xy[l] = make_float2(((float)(tid & 7) + 0.5f + p_d) / (float)g.W[l] + 0.3f, (tid >> 5) / (float)g.H[l] + 0.4f);
+                at[l] = 0.08f;
+            } else {
+                xy[l] = reinterpret_cast<const float2*>(loc)[gi0 + l * kP];
+                at[l] = attn[gi0 + l * kP];
+            }
         }
     }
-    // grad_out rows of the block's queries -> LDS (8 rows per wave instruction)
+    // grad_out rows of the block's queries: 512 pieces, two per thread
+    f4v gst0, gst1;
+    {
+        const int q0 = max(query_of(g, c, tid >> 3), 0), q1 = max(query_of(g, c, (tid + kT) >> 3), 0);
+        gst0 = *reinterpret_cast<const f4v*>(grad_out + ((int64_t)(c.b * g.Lq + q0) * g.M + c.m) * kD + (tid & 7) * 4);
+        gst1 = *reinterpret_cast<const f4v*>(grad_out + ((int64_t)(c.b * g.Lq + q1) * g.M + c.m) * kD + (tid & 7) * 4);
+    }
+    stamp();     // 1: prologue + loads issued
+    __syncthreads();
+    stamp();     // 2: first barrier (loads of loc / attn not yet awaited)
+    // grad_out rows -> LDS (their loads went out together with loc / attn)
+    *reinterpret_cast<f4v*>(smem + kPOffG + (tid >> 3) * kPitch + (tid & 7) * 16) = gst0;
+    *reinterpret_cast<f4v*>(smem + kPOffG + ((tid + kT) >> 3) * kPitch + (tid & 7) * 16) = gst1;
+    const int bm = c.b * g.M + c.m;
+    int x0[NL], y0[NL];
+    float lx[NL], ly[NL];
+    unsigned in_mask = 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = wave * 16 + i * 8 + (lane >> 3);
-        const int q = max(query_of(g, c, row), 0);
-        const float* src = grad_out + ((int64_t)(c.b * g.Lq + q) * g.M + c.m) * kD + (lane & 7) * 4;
-        unsigned char* dst = smem + kPOffG + (wave * 16 + i * 8) * 128;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    for (int l = 0; l < NL; ++l) {
+        const Dec d = decode(xy[l], g.H[l], g.W[l], q_d >= 0);
+        x0[l] = d.x0; y0[l] = d.y0; lx[l] = d.lx; ly[l] = d.ly;
+        in_mask |= d.in ? (1u << l) : 0u;
+        const int H = g.H[l], W = g.W[l];
+        const int xa = d.in ? max(d.x0, 0) : INT_MAX, ya = d.in ? max(d.y0, 0) : INT_MAX;
+        const int xb = d.in ? min(d.x0 + 1, W - 1) : INT_MIN, yb = d.in ? min(d.y0 + 1, H - 1) : INT_MIN;
+        const int x_lo = wave_min(xa), y_lo = wave_min(ya), x_hi = wave_max(xb), y_hi = wave_max(yb);
+        if (lane == 0) {
+            atomicMin(&s_bb[l * 4 + 0], x_lo); atomicMin(&s_bb[l * 4 + 1], y_lo);
+            atomicMax(&s_bb[l * 4 + 2], x_hi); atomicMax(&s_bb[l * 4 + 3], y_hi);
+        }
     }
     __syncthreads();
-    const int bm = c.b * g.M + c.m;
-    Dec dec[NL];
-    {
-        // entry bookkeeping: per level up to 4 destination tiles: hash slot (-1 = no entry, kSlots = position taken from
-        // the global counter because the table was full) and index inside the workgroup's run
-        int tslot[NL][4], tidx[NL][4];
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            dec[l] = decode(xy[l], g.H[l], g.W[l], q_d >= 0);
-            const Dec& d = dec[l];
-            const int H = g.H[l], W = g.W[l];
-            const int xa = d.in ? max(d.x0, 0) : INT_MAX, ya = d.in ? max(d.y0, 0) : INT_MAX;
-            const int xb = d.in ? min(d.x0 + 1, W - 1) : INT_MIN, yb = d.in ? min(d.y0 + 1, H - 1) : INT_MIN;
-            const int x_lo = wave_min(xa), y_lo = wave_min(ya), x_hi = wave_max(xb), y_hi = wave_max(yb);
-            if (lane == 0) {
-                atomicMin(&s_bb[l * 4 + 0], x_lo); atomicMin(&s_bb[l * 4 + 1], y_lo);
-                atomicMax(&s_bb[l * 4 + 2], x_hi); atomicMax(&s_bb[l * 4 + 3], y_hi);
-            }
-            // destination tiles of the footprint [xa, xb] x [ya, yb]
-            const int txa = xa >> 2, txb = xb >> 2, tya = ya >> 2, tyb = yb >> 2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ty = (e >> 1) ? tyb : tya, tx = (e & 1) ? txb : txa;
-                const bool act = d.in && !((e & 1) && txb == txa) && !((e >> 1) && tyb == tya);
-                tslot[l][e] = -1; tidx[l][e] = 0;
-                if (act) {
-                    const int key = bm * g.tiles_per_bm + g.tile_base[l] + ty * g.ntx[l] + tx;
-                    const int slot = hash_slot(s_keys, (unsigned)key);
-                    tslot[l][e] = slot >= 0 ? slot : kSlots;
-                    tidx[l][e] = slot >= 0 ? atomicAdd(&s_cnt[slot], 1) : atomicAdd(&tile_count[key], 1);
-                }
-            }
-        }
-        __syncthreads();
-        // one returning add per touched tile reserves the workgroup's run
-        for (int i = tid; i < kSlots; i += kT)
-            if (s_keys[i] != kEmpty) s_base[i] = atomicAdd(&tile_count[s_keys[i]], s_cnt[i]);
-        __syncthreads();
-        // entries: (query << 2 | point) appended to the run of every destination tile
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const Dec& d = dec[l];
-            const int txa = max(d.x0, 0) >> 2, txb = min(d.x0 + 1, g.W[l] - 1) >> 2;
-            const int tya = max(d.y0, 0) >> 2, tyb = min(d.y0 + 1, g.H[l] - 1) >> 2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int slot = tslot[l][e];
-                if (slot < 0) continue;
-                const int local = ((e >> 1) ? tyb : tya) * g.ntx[l] + ((e & 1) ? txb : txa);
-                const int pos = (slot < kSlots ? s_base[slot] : 0) + tidx[l][e];
-                const unsigned ent = ((unsigned)q_d << 2) | (unsigned)p_d;
-                if (pos < g.cap[l]) {
-                    entries[(int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)local * g.cap[l] + pos] = ent;
-                } else {
-                    const int k = atomicAdd(ovf_count, 1);
-                    ovf[k] = make_uint2((unsigned)(bm * g.tiles_per_bm + g.tile_base[l] + local), ent);
-                }
-            }
-        }
-    }
 
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(value), 0, value_bytes, 0x00020000);
-    // rotated piece order of this lane
-    int ok[8];
-    {
-        const int phi = (qi_d >> 1) & 7;
+    // box of level l -> registers (piece idx = tid + 256 i: row idx >> 3, piece idx & 7); rows beyond the box read nothing
+    float4 stg[kPStage];
+    auto box = [&](int l, int& xmin, int& ymin, int& rw, int& rows, bool& lds_path) {
+        xmin = s_bb[l * 4 + 0]; ymin = s_bb[l * 4 + 1];
+        const int xmax = s_bb[l * 4 + 2], ymax = s_bb[l * 4 + 3];
+        rw = xmax - xmin + 1;
+        rows = xmax >= xmin ? rw * (ymax - ymin + 1) : 0;
+        lds_path = rows <= region_cap;
+    };
+    auto fetch = [&](int l) {
+        int xmin, ymin, rw, rows;
+        bool lds_path;
+        box(l, xmin, ymin, rw, rows, lds_path);
+        if (!lds_path || (ablate & 4)) rows = 0;
+        const float inv_rw = 1.0f / (float)max(rw, 1);
+        const int lvl = ((c.b * g.S + g.start[l]) * g.M + c.m) * 128;
+        const int W = g.W[l];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ok[k] = ((k + phi) & 7) * 16;
-    }
-    const int g_base = kPOffG + qi_d * 128;
-    float ra[NL], rx[NL], ry[NL];
+        for (int i = 0; i < kPStage; ++i) {
+            const int idx = tid + i * kT, r = idx >> 3;
+            const int ry = (int)(((float)r + 0.5f) * inv_rw), rx = r - ry * rw;
+            const int off = r < rows ? lvl + ((ymin + ry) * W + xmin + rx) * (g.M * 128) + (idx & 7) * 16 : kOobOff;
+            stg[i] = buf_row(vrs, off);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < kPStage; ++i) {
+            const int idx = tid + i * kT, r = idx >> 3;
+            if (r < region_cap) *reinterpret_cast<float4*>(smem + kPOffReg + r * kPitch + (idx & 7) * 16) = stg[i];
+        }
+    };
+    stamp();     // 3: decode + box reduction (waited for loc/attn/g)
+    fetch(0);
+    stamp();     // 4: first box requested
 
+    // ---- destination tiles of every sample: one LDS counter per tile -------------------------------------------------
+    // per level up to 4 tiles; tpk = (slot << 16 | index in the workgroup's run), -1 = no entry.  The tiles under the
+    // workgroup's boxes are enumerated directly (slot = level offset + position inside the box's tile grid): every sample
+    // issues its four counter adds unconditionally (absent tiles add 0 to a dummy slot), i.e. back to back instead of one
+    // dependent LDS round trip per branch.  Only when the boxes cover more than kSlots tiles (scattered samples) does the
+    // compare-and-swap hash take over; a full hash takes the position from the tile's global counter.
+    int tpk[NL][4];
+    int tbx[NL], tby[NL], tbw[NL], tof[NL + 1];
+    tof[0] = 0;
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         const int xmin = s_bb[l * 4 + 0], ymin = s_bb[l * 4 + 1], xmax = s_bb[l * 4 + 2], ymax = s_bb[l * 4 + 3];
         const bool any = xmax >= xmin;
-        const int rw = xmax - xmin + 1, rows = any ? rw * (ymax - ymin + 1) : 0;
-        const bool lds_path = rows <= region_cap;
-        int4 o = corner_offsets(g, dec[l], l, lds_path, xmin, ymin, rw, c.b, c.m);
-        if (lds_path) {
-            // corner_offsets() addresses the forward kernel's LDS map; only its zero row sits elsewhere here
-            o.x = o.x == kOffZero ? kPOffZero : o.x; o.y = o.y == kOffZero ? kPOffZero : o.y;
-            o.z = o.z == kOffZero ? kPOffZero : o.z; o.w = o.w == kOffZero ? kPOffZero : o.w;
+        tbx[l] = xmin >> 2; tby[l] = ymin >> 2;
+        tbw[l] = any ? (xmax >> 2) - tbx[l] + 1 : 0;
+        tof[l + 1] = tof[l] + (any ? tbw[l] * ((ymax >> 2) - tby[l] + 1) : 0);
+    }
+    const bool direct = tof[NL] <= kSlots;             // workgroup-uniform
+    int* s_cnt1 = s_cnt;                               // [kSlots + 1]: the last one is the dummy
+    if (direct) {
+        int ret[NL][4];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const bool in = (in_mask >> l) & 1;
+            const int H = g.H[l], W = g.W[l];
+            const int txa = max(x0[l], 0) >> 2, txb = min(x0[l] + 1, W - 1) >> 2, tya = max(y0[l], 0) >> 2, tyb = min(y0[l] + 1, H - 1) >> 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ty = (e >> 1) ? tyb : tya, tx = (e & 1) ? txb : txa;
+                const bool act = in && !((e & 1) && txb == txa) && !((e >> 1) && tyb == tya) && !(ablate & 1);
+                const int slot = act ? tof[l] + (ty - tby[l]) * tbw[l] + (tx - tbx[l]) : kSlots;
+                tpk[l][e] = act ? slot : -1;
+                ret[l][e] = atomicAdd(&s_cnt1[slot], act ? 1 : 0);
+            }
         }
-        if (l > 0) __syncthreads();                    // the previous level's readers are done with the region
-        if (lds_path && rows > 0) stage_region(value, smem, g, c.b, c.m, l, xmin, ymin, rw, rows, tid);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tpk[l][e] = tpk[l][e] >= 0 ? ((tpk[l][e] << 16) | ret[l][e]) : -1;
+    } else {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const bool in = (in_mask >> l) & 1;
+            const int H = g.H[l], W = g.W[l];
+            const int txa = max(x0[l], 0) >> 2, txb = min(x0[l] + 1, W - 1) >> 2, tya = max(y0[l], 0) >> 2, tyb = min(y0[l] + 1, H - 1) >> 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ty = (e >> 1) ? tyb : tya, tx = (e & 1) ? txb : txa;
+                const bool act = in && !((e & 1) && txb == txa) && !((e >> 1) && tyb == tya) && !(ablate & 1);
+                tpk[l][e] = -1;
+                if (act) {
+                    const int key = bm * g.tiles_per_bm + g.tile_base[l] + ty * g.ntx[l] + tx;
+                    const int slot = hash_slot(s_keys, (unsigned)key);
+                    if (slot >= 0) {
+                        tpk[l][e] = (slot << 16) | atomicAdd(&s_cnt[slot], 1);
+                    } else {
+                        // table full: position straight from the tile's global counter, entry written now
+                        const int pos = atomicAdd(&tile_count[key], 1);
+                        const unsigned ent = ((unsigned)q_d << 2) | (unsigned)p_d;
+                        if (pos < g.cap[l]) {
+                            entries[(int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)(ty * g.ntx[l] + tx) * g.cap[l] + pos] = ent;
+                        } else {
+                            const int k = atomicAdd(ovf_count, 1);
+                            ovf[k] = make_uint2((unsigned)key, ent);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    stamp();     // 5: tile counting
+    __syncthreads();
+    // one returning add per touched tile reserves the workgroup's run; the result is needed only at the very end
+    int my_base = 0;
+    {
+        unsigned key = s_keys[tid];
+        if (direct) {
+            // slot -> tile: level by offset, then row / column inside the box's tile grid
+            int l = 0;
+#pragma unroll
+            for (int k = 1; k < NL; ++k) l = tid >= tof[k] ? k : l;
+            int bx_ = tbx[0], by_ = tby[0], bw_ = tbw[0], of_ = 0, tb_ = g.tile_base[0], nt_ = g.ntx[0];
+#pragma unroll
+            for (int k = 1; k < NL; ++k)
+                if (l == k) { bx_ = tbx[k]; by_ = tby[k]; bw_ = tbw[k]; of_ = tof[k]; tb_ = g.tile_base[k]; nt_ = g.ntx[k]; }
+            const int rel = tid - of_, ry = rel / max(bw_, 1), rx = rel - ry * bw_;
+            key = tid < tof[NL] && s_cnt[tid] > 0 ? (unsigned)(bm * g.tiles_per_bm + tb_ + (by_ + ry) * nt_ + bx_ + rx) : kEmpty;
+        }
+        if (key != kEmpty) my_base = atomicAdd(&tile_count[key], s_cnt[tid]);
+    }
+    __syncthreads();
+    stamp();     // 6: reservation issued
+    // the first box -> LDS
+    commit();
+    __syncthreads();
+    stamp();     // 7: first box in LDS
+
+    const int g_base = kPOffG + qi_d * kPitch;
+    float ra[NL], rx[NL], ry[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        int xmin, ymin, rw, rows;
+        bool lds_path;
+        box(l, xmin, ymin, rw, rows, lds_path);
+        if (l + 1 < NL) fetch(l + 1);                  // next box: in flight while this level is reduced
+        const bool in = (in_mask >> l) & 1;
+        const int H = g.H[l], W = g.W[l];
+        const bool y0v = in && y0[l] >= 0, y1v = in && y0[l] + 1 <= H - 1, x0v = in && x0[l] >= 0, x1v = in && x0[l] + 1 <= W - 1;
         f2v t0 = {0.f, 0.f}, t1 = {0.f, 0.f}, t2 = {0.f, 0.f}, t3 = {0.f, 0.f};
-        if (lds_path) {
+        if (ablate & 2) {
+        } else if (lds_path) {
+            const int base = kPOffReg + ((y0[l] - ymin) * rw + (x0[l] - xmin)) * kPitch;
+            const int o0 = (y0v && x0v) ? base : kPOffZero, o1 = (y0v && x1v) ? base + kPitch : kPOffZero;
+            const int o2 = (y1v && x0v) ? base + rw * kPitch : kPOffZero, o3 = (y1v && x1v) ? base + rw * kPitch + kPitch : kPOffZero;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const f4v gk = *reinterpret_cast<const f4v*>(smem + g_base + ok[k]);
-                const f4v v0 = *reinterpret_cast<const f4v*>(smem + o.x + ok[k]);
-                const f4v v1 = *reinterpret_cast<const f4v*>(smem + o.y + ok[k]);
-                const f4v v2 = *reinterpret_cast<const f4v*>(smem + o.z + ok[k]);
-                const f4v v3 = *reinterpret_cast<const f4v*>(smem + o.w + ok[k]);
+                const f4v gk = *reinterpret_cast<const f4v*>(smem + g_base + k * 16);
+                const f4v v0 = *reinterpret_cast<const f4v*>(smem + o0 + k * 16);
+                const f4v v1 = *reinterpret_cast<const f4v*>(smem + o1 + k * 16);
+                const f4v v2 = *reinterpret_cast<const f4v*>(smem + o2 + k * 16);
+                const f4v v3 = *reinterpret_cast<const f4v*>(smem + o3 + k * 16);
                 t0 = __builtin_elementwise_fma(gk.xy, v0.xy, t0); t0 = __builtin_elementwise_fma(gk.zw, v0.zw, t0);
                 t1 = __builtin_elementwise_fma(gk.xy, v1.xy, t1); t1 = __builtin_elementwise_fma(gk.zw, v1.zw, t1);
                 t2 = __builtin_elementwise_fma(gk.xy, v2.xy, t2); t2 = __builtin_elementwise_fma(gk.zw, v2.zw, t2);
                 t3 = __builtin_elementwise_fma(gk.xy, v3.xy, t3); t3 = __builtin_elementwise_fma(gk.zw, v3.zw, t3);
+                if (k & 1) __builtin_amdgcn_sched_barrier(0);      // 10 row pieces in flight per lane, not 40
             }
         } else {
+            // box too large for LDS: the four corner rows come from L2, out-of-image corners read 0 through the bounds check
+            const int sx = g.M * 128, sy = W * sx;
+            const int base = ((c.b * g.S + g.start[l]) * g.M + c.m) * 128 + y0[l] * sy + x0[l] * sx;
+            const int o0 = (y0v && x0v) ? base : kOobOff, o1 = (y0v && x1v) ? base + sx : kOobOff;
+            const int o2 = (y1v && x0v) ? base + sy : kOobOff, o3 = (y1v && x1v) ? base + sy + sx : kOobOff;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const f4v gk = *reinterpret_cast<const f4v*>(smem + g_base + ok[k]);
-                const float4 a0 = buf_row(vrs, o.x + ok[k]), a1 = buf_row(vrs, o.y + ok[k]);
-                const float4 a2 = buf_row(vrs, o.z + ok[k]), a3 = buf_row(vrs, o.w + ok[k]);
+                const f4v gk = *reinterpret_cast<const f4v*>(smem + g_base + k * 16);
+                const float4 a0 = buf_row(vrs, o0 + k * 16), a1 = buf_row(vrs, o1 + k * 16);
+                const float4 a2 = buf_row(vrs, o2 + k * 16), a3 = buf_row(vrs, o3 + k * 16);
                 const f4v v0 = {a0.x, a0.y, a0.z, a0.w}, v1 = {a1.x, a1.y, a1.z, a1.w};
                 const f4v v2 = {a2.x, a2.y, a2.z, a2.w}, v3 = {a3.x, a3.y, a3.z, a3.w};
                 t0 = __builtin_elementwise_fma(gk.xy, v0.xy, t0); t0 = __builtin_elementwise_fma(gk.zw, v0.zw, t0);
                 t1 = __builtin_elementwise_fma(gk.xy, v1.xy, t1); t1 = __builtin_elementwise_fma(gk.zw, v1.zw, t1);
                 t2 = __builtin_elementwise_fma(gk.xy, v2.xy, t2); t2 = __builtin_elementwise_fma(gk.zw, v2.zw, t2);
                 t3 = __builtin_elementwise_fma(gk.xy, v3.xy, t3); t3 = __builtin_elementwise_fma(gk.zw, v3.zw, t3);
+                if (k & 1) __builtin_amdgcn_sched_barrier(0);      // at most 8 row loads in flight per lane (registers)
             }
         }
         {
             const float s0 = t0.x + t0.y, s1 = t1.x + t1.y, s2 = t2.x + t2.y, s3 = t3.x + t3.y;
-            const float lx = dec[l].lx, ly = dec[l].ly, hx = 1.f - lx, hy = 1.f - ly;
-            const float a = dec[l].in ? at[l] : 0.f;
-            ra[l] = hy * (hx * s0 + lx * s1) + ly * (hx * s2 + lx * s3);
-            rx[l] = (float)g.W[l] * a * (hy * (s1 - s0) + ly * (s3 - s2));
-            ry[l] = (float)g.H[l] * a * (hx * (s2 - s0) + lx * (s3 - s1));
+            const float lx_ = lx[l], ly_ = ly[l], hx = 1.f - lx_, hy = 1.f - ly_;
+            const float a = in ? at[l] : 0.f;
+            ra[l] = hy * (hx * s0 + lx_ * s1) + ly_ * (hx * s2 + lx_ * s3);
+            rx[l] = (float)W * a * (hy * (s1 - s0) + ly_ * (s3 - s2));
+            ry[l] = (float)H * a * (hx * (s2 - s0) + lx_ * (s3 - s1));
+        }
+        stamp();                                       // 8, 10, 12: level reduced
+        __syncthreads();                               // every reader is done with this box
+        if (l + 1 < NL) {
+            commit();
+            __syncthreads();
+        }
+        stamp();                                       // 9, 11, 13: next box in LDS
+    }
+
+    // ---- entries: (query << 2 | point) appended to the run of every destination tile ----------------------------------
+    s_base[tid] = my_base;
+    __syncthreads();
+    stamp();     // 14: run bases known
+    if (q_d < 0) return;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int txa = max(x0[l], 0) >> 2, txb = min(x0[l] + 1, g.W[l] - 1) >> 2;
+        const int tya = max(y0[l], 0) >> 2, tyb = min(y0[l] + 1, g.H[l] - 1) >> 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (tpk[l][e] < 0) continue;
+            const int local = ((e >> 1) ? tyb : tya) * g.ntx[l] + ((e & 1) ? txb : txa);
+            const int pos = s_base[tpk[l][e] >> 16] + (tpk[l][e] & 0xFFFF);
+            const unsigned ent = ((unsigned)q_d << 2) | (unsigned)p_d;
+            if (pos < g.cap[l]) {
+                entries[(int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)local * g.cap[l] + pos] = ent;
+            } else {
+                const int k = atomicAdd(ovf_count, 1);
+                ovf[k] = make_uint2((unsigned)(bm * g.tiles_per_bm + g.tile_base[l] + local), ent);
+            }
         }
     }
-    if (q_d < 0) return;
 
     // ---- per-sample gradients out -------------------------------------------------------------------------
+    if ((ablate & 8) && ra[0] != 12345.f) return;
     if (grad_raw) {
         // module-level form: gradients wrt the raw projection outputs [M*L*P*2 offsets | M*L*P logits]:
         //   loc = ref + off / (W_l, H_l)  =>  d off = d loc / (W_l, H_l);  attn = softmax  =>  d logit = a (dA - sum_j a_j dA_j)
@@ -609,19 +758,21 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
     const int r = wg - bm * g.wg_per_bm;
     // (band, level) group of this workgroup: the lanes compare r with the group bases in parallel (a scalar loop would
     // be one dependent kernarg load per group — thousands of cycles per wave)
-    int slot;
+    int slot, slot_base;
     {
         const int nslot = g.nband * NL;
         const int base_k = g.band_wg_base[min(lane, nslot - 1)];
         const unsigned long long ge = __ballot(lane < nslot && r >= base_k);
         slot = __builtin_amdgcn_readfirstlane(__popcll(ge) - 1);
+        slot_base = __builtin_amdgcn_readlane(base_k, slot);
     }
     const int band = slot / NL, l = slot - band * NL;
-    const int wpt = g.wpt[l];
-    const int W = g.W[l], H = g.H[l];
-    const int nty = (H + 3) >> 2, ntx = g.ntx[l];
+    const int wpt = sel(g.wpt, l);
+    const int W = sel(g.W, l), H = sel(g.H, l);
+    const int nty = (H + 3) >> 2, ntx = sel(g.ntx, l);
+    const int tile_base = sel(g.tile_base, l), cap = sel(g.cap, l), ent_base = sel(g.ent_base, l), start = sel(g.start, l);
     const int row0 = band * nty / g.nband, row1 = (band + 1) * nty / g.nband;
-    const int unit = (r - g.band_wg_base[slot]) * 16 + wave;
+    const int unit = (r - slot_base) * 16 + wave;
     const int part = unit % wpt, tb = unit / wpt;             // tile inside the (band, level) group
     const bool live = tb < (row1 - row0) * ntx;
     const int ty = row0 + tb / ntx, tx = tb - (tb / ntx) * ntx;
@@ -632,7 +783,7 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const int kgrp = lane >> 4, j = lane & 15;
     int n = 0;
-    if (live) n = min(tile_count[bm * g.tiles_per_bm + g.tile_base[l] + local], g.cap[l]);
+    if (live) n = min(tile_count[bm * g.tiles_per_bm + tile_base + local], cap);
     const int nchunks = (n + 63) >> 6;
     if (part < nchunks) {
         // Two lane roles.  "Sample role" (once per chunk of 64 entries): lane = entry; one coalesced load of the entries,
@@ -640,7 +791,7 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
         // sample, the record {x, y, a, grad_out row offset} parked in LDS.  "MFMA role" (16 steps of 4 samples): lane =
         // (pixel i = lane & 15, sample k = lane >> 4) reads its sample's record back (one 16-byte LDS read, a broadcast
         // inside the 16-lane group), loads its 8 bytes of the sample's grad_out row and forms its hat weight.
-        const unsigned* ent = entries + (int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)local * g.cap[l];   // this tile's run
+        const unsigned* ent = entries + (int64_t)bm * g.ent_per_bm + ent_base + (int64_t)local * cap;   // this tile's run
         const float fpx = (float)(tx * 4 + (j & 3)), fpy = (float)(ty * 4 + (j >> 2));
         const float fW = (float)W, fH = (float)H;
         const __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(ent), 0, (unsigned)n * 4u, 0x00020000);
@@ -730,7 +881,7 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
         for (int q = 0; q < 4; ++q) {
             const int px = tx * 4 + q;
             if (px < W)
-                *reinterpret_cast<float2*>(grad_value + ((int64_t)(b * g.S + g.start[l] + py * W + px) * g.M + m) * kD + j * 2) =
+                *reinterpret_cast<float2*>(grad_value + ((int64_t)(b * g.S + start + py * W + px) * g.M + m) * kD + j * 2) =
                     make_float2(acc0[q], acc1[q]);
         }
     }
@@ -776,8 +927,11 @@ __global__ __launch_bounds__(kT) void msda_bwd_spill_kernel(const float* __restr
 // --------------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------------
-int g_region_rows = 217;      // usable rows of the staged box; the buffer adds 31 rows of slack for the last stage pass
+int g_region_rows = 217;      // forward: usable rows of the staged box (the buffer is rounded up to whole 32-row stage passes)
+int g_push_rows = 216;        // push: rows of its box buffer (pitch 144 B): 9728 + 216 * 144 = 40832 B -> four workgroups per CU
 int g_block_disable = 0;
+unsigned long long* g_dbg = nullptr;   // benchmarking only: s_memtime phase stamps of the push kernel, [workgroup][16]
+int g_push_ablate = 0;       // benchmarking only: 1 = no tile entries, 2 = no reduction, 4 = no box staging
 
 bool build_geom(GeomB& g, const int64_t* hs, int N, int S, int M, int L, int Lq)
 {
@@ -904,11 +1058,11 @@ hipError_t launch_bwd(const float* value, const float* loc, const float* attn, c
     const int nblocks = g.N * g.M * g.blocks_per_b;
     const int grid = ((nblocks + 7) / 8) * 8;
     constexpr int LP = NL * kP;
-    const size_t lds = kOffReg + region_bytes() + kSlots * 12;
+    const size_t lds = kPOffReg + (size_t)g_push_rows * kPitch;
     const double esz = 4.0;
     mpf::prof_begin(st);
     hipLaunchKernelGGL(msda_bwd_push_block_kernel<NL>, dim3(grid), dim3(kT), lds, st, value, loc, attn, go, gl, ga, graw, tile_count,
-                       entries, ovf_count, ovf, g, nblocks, g_region_rows, region_bytes(), (unsigned)((size_t)g.N * g.S * g.M * kD * 4));
+                       entries, ovf_count, ovf, g, nblocks, g_push_rows, (unsigned)((size_t)g.N * g.S * g.M * kD * 4), g_push_ablate, g_dbg);
     mpf::prof_end("msda_bwd_push_block_kernel", st,
                   esz * ((double)g.N * g.S * g.M * kD + (double)g.N * g.Lq * g.M * LP * 6 + (double)g.N * g.Lq * g.M * kD));
     const int nwg = g.N * g.M * g.wg_per_bm;
@@ -921,6 +1075,12 @@ hipError_t launch_bwd(const float* value, const float* loc, const float* attn, c
 }
 
 }  // namespace
+
+extern "C" int mpf_debug_set_buffer(void* p)
+{
+    g_dbg = (unsigned long long*)p;
+    return 0;
+}
 
 namespace mpf {
 
@@ -980,7 +1140,13 @@ int set_block_option(const char* key, int v)
         g_region_rows = v;
         return 0;
     }
+    if (!strcmp(key, "msda_push_rows")) {
+        if (v < 16 || v > kPStage * 32) return MPF_E_SHAPE;
+        g_push_rows = v;
+        return 0;
+    }
     if (!strcmp(key, "msda_block_disable")) { g_block_disable = v; return 0; }
+    if (!strcmp(key, "msda_push_ablate2")) { g_push_ablate = v; return 0; }
     return 1;
 }
 
