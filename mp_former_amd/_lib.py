@@ -8,6 +8,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmpformer_hip.so")
+# development only: A/B a second build of the library in one process run (tools/ab_lib.sh)
+LIB_PATH = os.environ.get("MPF_LIB_PATH", LIB_PATH)
 ABI_VERSION = 1
 
 MPF_F32, MPF_F64, MPF_BF16, MPF_U8, MPF_BITS = 0, 1, 2, 3, 4
