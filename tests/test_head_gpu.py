@@ -42,7 +42,7 @@ def test_head_matches_reference_golden_fp32(name):
         _lib.profile_enable(True)
         mf, _, ms = h.pixel_decoder.forward_features(feats)
         # the native kernels are what ran (deformable attention + the encoder's split-bf16 GEMMs)
-        assert _lib.profile_get("msda_fwd_tiled")[0] >= 1 and _lib.profile_get("gemm3_tn")[0] >= 1, _lib.last_kernel()
+        assert _lib.profile_get("msda_fwd_block")[0] >= 1 and _lib.profile_get("gemm3_tn")[0] >= 1, _lib.last_kernel()
         _lib.profile_enable(False)
         np.testing.assert_allclose(_sub(mf, 5), z["mask_features_s5"], rtol=2e-3, atol=5e-4)
         for i, t in enumerate(ms):
@@ -69,7 +69,7 @@ def test_head_matches_reference_golden_fp32(name):
         np.testing.assert_allclose(float(total), float(z["total_loss"]), rtol=5e-4)
         _lib.profile_enable(True)
         total.backward()
-        assert _lib.profile_get("msda_bwd")[0] >= 1 and _lib.profile_get("gemm3_nt")[0] >= 1, _lib.last_kernel()
+        assert _lib.profile_get("msda_bwd_pull_mfma")[0] >= 1 and _lib.profile_get("gemm3_nt")[0] >= 1, _lib.last_kernel()
         _lib.profile_enable(False)
         for k, v in feats.items():
             n = float(z[f"grad_feat_{k}_norm"])
@@ -175,6 +175,114 @@ def test_head_baseline_config_shapes_run(name, size, chans, classes, queries, n)
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
     assert not [k for k, p in h.named_parameters() if p.grad is None]
-    for kern in ("msda_fwd_tiled", "msda_bwd_pull", "attn_fwd_kernel", "attn_bwd_kv", "match_cost", "mask_loss_fwd", "attn_mask"):
+    for kern in ("msda_fwd_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost", "mask_loss_fwd", "attn_mask"):
         assert _lib.profile_get(kern)[0] > 0, kern
     _lib.profile_enable(False)
+
+
+def _rel_l2(got, want):
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    want = np.asarray(want, dtype=np.float64).reshape(-1)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+@pytest.mark.parametrize("name", ["head_small", "head_ragged"])
+def test_head_amp_path_matches_reference_golden(name):
+    """The path bench.py times — bf16 autocast with every default switch (natively sequenced decoder layers, MFMA
+    attention, small-row GEMMs, device-side assignment) — against the PINNED goldens of the imported reference (fp32),
+    with the reference's draws replayed: every one of the 6 x (1 + #aux) losses per key, and the gradients of the
+    backbone features, of the pixel decoder and of the decoder per tensor (relative L2).  The tolerance is bf16's:
+    8 mantissa bits through 3 decoder layers; an assignment flipped by rounding would show up as an O(1) error in the
+    losses of that output."""
+    from mp_former_amd import _lib, _rng
+    dev = torch.device("cuda:0")
+    z, cfg, pp, dp, feats, targets, replay = load_head_fixture(name)
+    h = _build(cfg, pp, dp, dev)
+    feats = {k: v.to(dev).requires_grad_(True) for k, v in feats.items()}
+    targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+    use_dn = "dn_pred_logits" in z
+    _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
+    _lib.profile_enable(True)
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            losses, _ = h(feats, targets)            # weighted, like maskformer_model.py:226-231
+            total = sum(losses.values())
+        assert _rng.remaining() == 0
+        total.backward()
+        torch.cuda.synchronize()
+        for kern in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "small_gemm", "lsa_kernel", "msda_fwd_block",
+                     "msda_bwd_pull_mfma", "gemm3"):
+            assert _lib.profile_get(kern)[0] > 0, f"{kern} did not run on the AMP path"
+    finally:
+        _lib.profile_enable(False)
+        _rng.install_replay(None)
+    wd = h.criterion.weight_dict
+    ref_keys = sorted(k[5:] for k in z if k.startswith("loss."))
+    assert sorted(losses) == ref_keys
+    bad = {}
+    for k in ref_keys:
+        want = float(z["loss." + k]) * wd[k]
+        got = float(losses[k])
+        if abs(got - want) > 2e-2 * abs(want) + 2e-3:
+            bad[k] = (got, want)
+    assert not bad, f"AMP losses off the fp32 goldens: {bad}"
+    np.testing.assert_allclose(float(total), float(z["total_loss"]), rtol=1e-2)
+    errs = {}
+    for k, v in feats.items():
+        errs["grad_feat_" + k] = _rel_l2(_sub(v.grad, 7), z[f"grad_feat_{k}_s7"])
+    pg = dict(h.pixel_decoder.named_parameters())
+    for k in [k for k in z if k.startswith("grad_pix.") and "_s11" not in k]:
+        errs[k] = _rel_l2(pg[k[9:]].grad.cpu().numpy(), z[k])
+    dg = dict(h.predictor.named_parameters())
+    for k in [k for k in z if k.startswith("grad_dec.")]:
+        g = dg[k[9:]].grad
+        g = torch.zeros_like(dg[k[9:]]) if g is None else g
+        errs[k] = _rel_l2(g.float().cpu().numpy(), z[k])
+    bad = {k: round(e, 4) for k, e in errs.items() if not e <= 5e-2}
+    assert not bad, f"AMP gradients, relative L2 vs the reference goldens: {bad}\nall: { {k: round(e, 4) for k, e in errs.items()} }"
+
+
+@pytest.mark.parametrize("name,classes,n", [("B_coco_instance_R50_1024", 80, 2), ("C_coco_panoptic_R50_1024", 133, 2)])
+def test_head_full_size_configs_B_C(name, classes, n):
+    """BASELINE.json configs B and C at full size (1024x1024, R50 channel counts, 100 queries, per-GPU batch 2; C = the
+    panoptic class count, its DDP part is tests/test_dist_*): one AMP forward + backward of the whole head.  Size-
+    independent properties: finite losses, all 60 keys, every parameter gets a finite gradient, the production
+    kernels are the ones that ran, and a second run on the same draws gives the same losses (the atomics-free MSDA
+    backward and the device assignment make the step reproducible up to fp32 reassociation in the tile lists)."""
+    from mp_former_amd import _lib, _rng
+    from mp_former_amd.head import MPFormerHead
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    H = W = 1024
+    shapes = {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}
+    h = MPFormerHead(num_classes=classes, num_queries=100, feature_shapes=shapes).to(dev).train()
+    feats = {k: torch.randn(n, c, H // s, W // s, device=dev) for k, (c, s) in shapes.items()}
+    targets = []
+    for b in range(n):
+        T = 5 + 9 * b
+        m = torch.zeros(T, H, W, dtype=torch.bool, device=dev)
+        for t in range(T):
+            m[t, 60 * t:60 * t + 180, 50 * t:50 * t + 260] = True
+        targets.append({"labels": (torch.arange(T, device=dev) * 7) % classes, "masks": m, "boxes": torch.zeros(T, 4, device=dev)})
+
+    def run(seed):
+        torch.manual_seed(seed)
+        h.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            losses, _ = h(feats, targets)
+        sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        return {k: float(v) for k, v in losses.items()}
+
+    _lib.profile_enable(True)
+    l0 = run(11)
+    for kern in ("msda_fwd_block", "msda_bwd_push_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost",
+                 "mask_loss_fwd", "attn_mask", "lsa_kernel", "gemm3"):
+        assert _lib.profile_get(kern)[0] > 0, kern
+    _lib.profile_enable(False)
+    assert len(l0) == 60 and all(np.isfinite(v) for v in l0.values()), l0
+    bad = [k for k, p in h.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
+    assert not bad, bad
+    l1 = run(11)
+    for k in l0:
+        np.testing.assert_allclose(l1[k], l0[k], rtol=2e-3, atol=1e-4, err_msg=k)
