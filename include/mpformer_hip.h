@@ -608,6 +608,8 @@ int mpf_group_stats(const float* x, int rows, int64_t row_len, float eps, float*
  */
 int mpf_profile_enable(int on);
 int mpf_profile_get(const char* name_substr, int* count, double* total_ms, double* total_bytes);
+/* summed ALGORITHMIC floating-point operations of the same launches (kernels that are priced against the MFMA peak) */
+int mpf_profile_get_flops(const char* name_substr, double* total_flops);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@ SIGNATURES = {
     "mpf_last_kernel": (ctypes.c_char_p, []),
     "mpf_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
     "mpf_profile_enable": (_c_int, [_c_int]),
+    "mpf_profile_get_flops": (_c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]),
     "mpf_profile_get": (_c_int, [ctypes.c_char_p, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_double),
                                  ctypes.POINTER(ctypes.c_double)]),
     "mpf_point_sample": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_vp]),
@@ -136,6 +137,13 @@ def last_kernel():
 
 def profile_enable(on=True):
     check(lib().mpf_profile_enable(1 if on else 0), "mpf_profile_enable")
+
+
+def profile_get_flops(name_substr):
+    """-> summed algorithmic flops of the logged launches matching the name."""
+    fl = ctypes.c_double(0)
+    check(lib().mpf_profile_get_flops(name_substr.encode(), ctypes.byref(fl)), "mpf_profile_get_flops")
+    return fl.value
 
 
 def profile_get(name_substr):

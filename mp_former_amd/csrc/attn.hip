@@ -539,7 +539,8 @@ extern "C" int mpf_attn_forward(const void* q, const void* k, const void* vt, co
     mpf::prof_begin(st);
     mpf::set_kernel("attn_fwd_kernel<2>");
     hipLaunchKernelGGL(attn_fwd_kernel<QS>, dim3(qtiles * p.splits, H, N), dim3(64), 0, st, p);
-    mpf::prof_end("attn_fwd_kernel<2>", st, 2.0 * ((double)Lk * N * p.E * 2 + (double)Lq * N * p.E) + (mask ? (double)N * Lq * Lk : 0.0));
+    mpf::prof_end("attn_fwd_kernel<2>", st, 2.0 * ((double)Lk * N * p.E * 2 + (double)Lq * N * p.E) + (mask ? (double)N * Lq * Lk : 0.0),
+                  4.0 * Lq * (double)Lk * p.E * N);      // QK^T + PV
     const int total = N * H * Lq * kHD;
     hipLaunchKernelGGL(attn_combine_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p.part_o, p.part_ml,
                        (__hip_bfloat16*)out, lse, Lq, N, H, p.E, p.splits);
@@ -573,13 +574,13 @@ extern "C" int mpf_attn_backward(const void* q, const void* k, const void* v, co
     mpf::prof_begin(st);
     mpf::set_kernel("attn_bwd_kv_kernel");
     hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((Lk + 31) / 32, H, N), dim3(64), 0, st, p);
-    mpf::prof_end("attn_bwd_kv_kernel", st, bytes * 0.5);
+    mpf::prof_end("attn_bwd_kv_kernel", st, bytes * 0.5, 8.0 * Lq * (double)Lk * p.E * N);   // S, dP, dV, dK
     constexpr int QS = 2;
     const int qtiles = (Lq + 16 * QS - 1) / (16 * QS);
     mpf::prof_begin(st);
     mpf::set_kernel("attn_bwd_q_kernel<2>");
     hipLaunchKernelGGL(attn_bwd_q_kernel<QS>, dim3(qtiles * p.splits, H, N), dim3(64), 0, st, p);
-    mpf::prof_end("attn_bwd_q_kernel<2>", st, bytes * 0.5);
+    mpf::prof_end("attn_bwd_q_kernel<2>", st, bytes * 0.5, 6.0 * Lq * (double)Lk * p.E * N);  // S, dP, dQ
     const int total = N * H * Lq * kHD;
     hipLaunchKernelGGL(attn_sum_splits_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p.part_dq,
                        (__hip_bfloat16*)dq, Lq, N, H, p.E, p.splits);

@@ -32,7 +32,7 @@ void set_kernel(const char* name) { g_kernel.store(name, std::memory_order_relax
 
 // ---- in-library launch profiler: HIP events recorded on the launch stream around each kernel ----
 namespace {
-struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes; };
+struct ProfRec { const char* name; hipEvent_t e0, e1; double bytes, flops; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 std::atomic<int> g_prof_on{0};
@@ -50,14 +50,14 @@ void prof_begin(hipStream_t st)
     t_e0 = e;
 }
 
-void prof_end(const char* name, hipStream_t st, double algorithmic_bytes)
+void prof_end(const char* name, hipStream_t st, double algorithmic_bytes, double flops)
 {
     if (!prof_enabled() || !t_e0) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back({name, t_e0, e, algorithmic_bytes});
+    g_prof.push_back({name, t_e0, e, algorithmic_bytes, flops});
     t_e0 = nullptr;
 }
 }  // namespace mpf
@@ -84,6 +84,17 @@ extern "C" int mpf_profile_get(const char* name_substr, int* count, double* tota
         ms += t; by += r.bytes; ++n;
     }
     *count = n; *total_ms = ms; *total_bytes = by;
+    return 0;
+}
+
+extern "C" int mpf_profile_get_flops(const char* name_substr, double* total_flops)
+{
+    if (!name_substr || !total_flops) return MPF_E_NULL;
+    std::lock_guard<std::mutex> lk(mpf::g_prof_mu);
+    double fl = 0;
+    for (auto& r : mpf::g_prof)
+        if (strstr(r.name, name_substr)) fl += r.flops;
+    *total_flops = fl;
     return 0;
 }
 

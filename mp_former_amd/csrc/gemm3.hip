@@ -746,7 +746,7 @@ extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2
         if (a2) hipLaunchKernelGGL((gemm3_tn_kernel<128, true>), dim3(grid), dim3(kThreads), 0, st, p);
         else hipLaunchKernelGGL((gemm3_tn_kernel<128, false>), dim3(grid), dim3(kThreads), 0, st, p);
     }
-    mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + 6.0 * (double)N * K);
+    mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + 6.0 * (double)N * K, 2.0 * M * (double)N * K);
     return mpf::check(hipGetLastError(), "mpf_gemm3_tn");
 }
 
@@ -786,7 +786,8 @@ extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t
         mpf::set_kernel("gemm3_nt_kernel<128>");
         hipLaunchKernelGGL(gemm3_nt_kernel<128>, dim3(grid), dim3(kThreads), 0, st, p);
     }
-    mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)R * Mdim + (double)R * Ndim + (double)p.nsplit * Mdim * Ndim));
+    mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)R * Mdim + (double)R * Ndim + (double)p.nsplit * Mdim * Ndim),
+                  2.0 * R * (double)Mdim * Ndim);
     return mpf::check(hipGetLastError(), "mpf_gemm3_nt");
 }
 

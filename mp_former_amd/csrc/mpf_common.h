@@ -13,7 +13,7 @@ int check(hipError_t err, const char* where);
 void set_kernel(const char* name);
 // launch profiler (mpf_profile_enable): events on the launch stream around the kernel only
 void prof_begin(hipStream_t st);
-void prof_end(const char* name, hipStream_t st, double algorithmic_bytes);
+void prof_end(const char* name, hipStream_t st, double algorithmic_bytes, double flops = 0.0);
 // per-subsystem option hooks: return 0 if handled, 1 if the key is not theirs, <0 on bad value
 int set_msda_option(const char* key, int v);
 int set_binned_option(const char* key, int v);

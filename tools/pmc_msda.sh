@@ -1,23 +1,66 @@
 #!/bin/bash
-# HBM traffic of the MSDA backward kernels from rocprofv3 PMC counters (separate passes, as the guide
-# prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass).  Run on the GPU box from the repo root.
+# HBM traffic of the MSDA kernels at config B, N = 2 from rocprofv3 PMC counters (separate passes, as the guide
+# prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass), with FETCH_SIZE / WRITE_SIZE calibrated on kernels that
+# move a known byte count in the same access shapes (tools/ubench/fetch_calib.hip).  Run on the GPU box from the repo
+# root; writes gpurun_out/r02_msda_bwd_pmc_configB_N2.json (copy it to profiles/).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
-  d=/tmp/pmc_$(echo $c | tr ' ' '_')
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -o p -- python3 tools/bench_msda_breakdown.py init > /dev/null 2>&1
+mkdir -p gpurun_out
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+  t=$(echo $c | tr ' ' '_')
+  rm -rf /tmp/pmcm_$t /tmp/pmcc_$t
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcm_$t -o p -- python3 tools/bench_msda_breakdown.py init > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcc_$t -o p -- tools/ubench/fetch_calib > /dev/null 2>&1
 done
-python3 - <<PY
-import csv, collections, json, re, glob
-res = collections.defaultdict(dict)
-for d in glob.glob("/tmp/pmc_*"):
-    rows = list(csv.DictReader(open(d + "/p_counter_collection.csv")))
-    agg = collections.defaultdict(list)
-    for r in rows:
-        m = re.search(r"(msda_\w+|tile_scan_kernel)", r["Kernel_Name"])
-        if m:
-            agg[(m.group(1), r["Counter_Name"])].append(float(r["Counter_Value"]))
-    for (k, c), v in agg.items():
-        res[k][c] = sum(v) / len(v); res[k]["launches"] = len(v)
-json.dump(res, open("gpurun_out/msda_bwd_pmc.json", "w"), indent=1)
-print(json.dumps(res, indent=1))
+python3 - <<'PY'
+import csv, collections, glob, hashlib, json, re
+def load(prefix, regex):
+    res = collections.defaultdict(dict)
+    for d in glob.glob(f"/tmp/{prefix}_*"):
+        fs = glob.glob(d + "/**/p_counter_collection.csv", recursive=True)
+        if not fs:
+            continue
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(fs[0])):
+            m = re.search(regex, r["Kernel_Name"])
+            if m:
+                agg[(m.group(1), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in agg.items():
+            v = v[len(v) // 3:]
+            res[k][c] = sum(v) / len(v); res[k]["launches"] = len(v)
+    return res
+cal = load("pmcc", r"(calib_\w+)")
+msda = load("pmcm", r"(msda_\w+_kernel)")
+EXPECT = 512 * 1024 * 1024
+factors = {}
+for k, v in cal.items():
+    if k == "calib_write16":
+        factors[k] = EXPECT / (v["WRITE_SIZE"] * 1024.0)
+    else:
+        factors[k] = EXPECT / (v["FETCH_SIZE"] * 1024.0)
+# dominant read shape per kernel: 128-B rows fetched as 8 lanes x 16 B (forward, push) or 16 lanes x 8 B (pull)
+shape = {"msda_fwd_block_kernel": "calib_rows16", "msda_bwd_push_block_kernel": "calib_rows16", "msda_bwd_pull_mfma_kernel": "calib_rows8"}
+out = {"config": "B (1024x1024: S = 21504), N = 2, init-like offsets (tools/bench_msda_breakdown.py init)",
+       "source_sha256": hashlib.sha256(open("mp_former_amd/csrc/msda_block.hip", "rb").read()).hexdigest(),
+       "calibration_bytes_per_counter_byte": factors, "kernels": {}}
+total = 0.0
+for k, v in msda.items():
+    f = factors.get(shape.get(k, "calib_rows16"), 1.0)
+    fw = factors.get("calib_write16", 1.0)
+    rd = v.get("FETCH_SIZE", 0.0) * 1024.0 * f
+    wr = v.get("WRITE_SIZE", 0.0) * 1024.0 * fw
+    e = dict(v)
+    e.update({"read_bytes_corrected": rd, "write_bytes_corrected": wr, "read_factor": f, "write_factor": fw})
+    if "TCC_HIT_sum" in v:
+        e["l2_hit_rate"] = v["TCC_HIT_sum"] / max(v["TCC_HIT_sum"] + v["TCC_MISS_sum"], 1.0)
+    if "TCP_TCC_READ_REQ_sum" in v:
+        e["l1_hit_rate"] = 1.0 - v["TCP_TCC_READ_REQ_sum"] / max(v["TCP_TOTAL_CACHE_ACCESSES_sum"], 1.0)
+    out["kernels"][k] = e
+    if "bwd" in k:
+        total += rd + wr
+out["hbm_bytes_per_call"] = round(total)
+out["algorithmic_bytes_per_call"] = 1344 * 4 * 21504 * 2
+out["note"] = ("FETCH_SIZE x read_factor + WRITE_SIZE x write_factor of push + pull (+ spill); factors from tools/ubench/fetch_calib "
+               "(known 512 MiB per launch in the kernels' access shapes)")
+json.dump(out, open("gpurun_out/r02_msda_bwd_pmc_configB_N2.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
 PY
