@@ -182,8 +182,9 @@ def main():
     from mp_former_amd import dist as mdist
     mdist.init_from_env("nccl", dev)                     # nccl == RCCL on ROCm
 
-    from mp_former_amd import _lib
+    from mp_former_amd import _lib, _miopen
     _lib.lib()   # fail loudly if the native library is missing
+    _miopen.use_shipped_find_db(check_version=True)      # tuned MIOpen solver choice (private copy; logs a version mismatch)
 
     torch.manual_seed(rank)
     if os.environ.get("MPF_CONV_FIND", "0") == "1":      # let MIOpen time its solvers per conv shape (slow warm-up)
@@ -315,6 +316,7 @@ def main():
                              gemm_entry("gemm3_tn_kernel", n_g, ms_g, fl_g), gemm_entry("gemm3_nt_kernel", n_gn, ms_gn, fl_gn)]},
             "cpu_baseline": None,
         }
+        out["config"]["miopen_find_db"] = "mismatch (MIOpen ignored the shipped db)" if _miopen.db_mismatch() else "shipped"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_size)
         print(json.dumps(out), flush=True)

@@ -382,6 +382,14 @@ typedef struct MpfLsaProblem {
 int mpf_lsa_assign(const float* cost, const MpfLsaProblem* problems, int n_problems, int max_dim, int64_t max_entries,
                    int32_t* row_out, int32_t* col_out, int64_t* aff_a, int64_t* aff_b, int64_t* scatter_dst,
                    const int64_t* scatter_src, void* stream);
+/*
+ * The same with a device status word: `status` (may be NULL) is OR-ed with 1 when some problem has no finite assignment
+ * (an all-infinite row, NaN costs) — the case in which scipy.optimize.linear_sum_assignment raises ValueError in the
+ * reference.  The caller zeroes the word and reads it back when convenient (no synchronisation here).
+ */
+int mpf_lsa_assign_status(const float* cost, const MpfLsaProblem* problems, int n_problems, int max_dim, int64_t max_entries,
+                          int32_t* row_out, int32_t* col_out, int64_t* aff_a, int64_t* aff_b, int64_t* scatter_dst,
+                          const int64_t* scatter_src, int32_t* status, void* stream);
 
 /*
  * One decoder layer of the masked-attention transformer decoder — cross-attention, self-attention, FFN,

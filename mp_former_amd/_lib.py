@@ -59,6 +59,7 @@ SIGNATURES = {
     "mpf_decoder_layer_forward": (_c_int, [_c_vp, _c_vp]),
     "mpf_decoder_layer_backward": (_c_int, [_c_vp, _c_vp, _c_vp]),
     "mpf_lsa_assign": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, ctypes.c_int64] + [_c_vp] * 7),
+    "mpf_lsa_assign_status": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, ctypes.c_int64] + [_c_vp] * 8),
     "mpf_mask_block_empty": (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),
     "mpf_gemm_nt_bf16_workspace_bytes": (ctypes.c_size_t, [_c_int] * 4),
     "mpf_gemm_nt_bf16": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp,

@@ -77,6 +77,12 @@ extern "C" int mpf_attn_mask(const void* masks, int dtype, int64_t stride_n, int
     if ((size_t)hl * wl > 96 * 1024) return mpf::fail(MPF_E_TOO_LARGE, "attn_mask: level larger than 96K positions");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)hl * wl;
+    if (lds > 64 * 1024) {
+        // more dynamic LDS than the default per-kernel limit: opt in explicitly (160 KB per CU on gfx950)
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mask_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mask_kernel<__hip_bfloat16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e1 != hipSuccess || e2 != hipSuccess) return mpf::check(e1 != hipSuccess ? e1 : e2, "mpf_attn_mask(hipFuncSetAttribute)");
+    }
     mpf::prof_begin(st);
     if (dtype == MPF_F32) {
         mpf::set_kernel("attn_mask_kernel<float>");

@@ -281,6 +281,7 @@ extern "C" int mpf_point_sample(const void* src, int src_dtype, int h, int w, co
     if (int e = check_common(src, rows, coords, out, n, P, h, w)) return e;
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (n > 65535) return mpf::fail(MPF_E_TOO_LARGE, "loss kernels: more than 65535 rows in one launch (grid.y)");
     dim3 grid((P + kThreads - 1) / kThreads, n);
     mpf::prof_begin(st);
     if (src_dtype == MPF_F32) {
@@ -335,6 +336,7 @@ extern "C" int mpf_mask_loss_forward(const void* pred, int pred_dtype, int h, in
     if (gt_dtype == MPF_BITS && ((int64_t)H * W) % 32 != 0) return mpf::fail(MPF_E_SHAPE, "mask_loss_forward: bit-packed masks need H*W % 32 == 0");
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (n > 65535) return mpf::fail(MPF_E_TOO_LARGE, "loss kernels: more than 65535 rows in one launch (grid.y)");
     dim3 grid(chunks, n);
     const bool bits = gt_dtype == MPF_BITS;
     mpf::prof_begin(st);
@@ -375,6 +377,7 @@ extern "C" int mpf_mask_loss_backward(const void* pred, int pred_dtype, int h, i
     if (H <= 0 || W <= 0) return mpf::fail(MPF_E_SHAPE, "mask_loss_backward: bad sizes");
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (n > 65535) return mpf::fail(MPF_E_TOO_LARGE, "loss kernels: more than 65535 rows in one launch (grid.y)");
     dim3 grid((P + kThreads * 4 - 1) / (kThreads * 4), n);
     mpf::prof_begin(st);
     if (pred_dtype == MPF_F32) {
@@ -412,6 +415,7 @@ extern "C" int mpf_mask_loss_backward_dense(const void* pred, int pred_dtype, in
     const int nb = (h + max_rows - 1) / max_rows;
     const int band_rows = (h + nb - 1) / nb;
     const size_t lds = (size_t)band_rows * w * 4;
+    if (n > 65535) return mpf::fail(MPF_E_TOO_LARGE, "loss kernels: more than 65535 rows in one launch (grid.y)");
     const dim3 grid(nb, n);
     mpf::prof_begin(st);
     if (pred_dtype == MPF_F32) {

@@ -37,6 +37,7 @@ struct LsaOut {
     int64_t* aff_b;
     int64_t* scatter_dst;
     const int64_t* scatter_src;
+    int32_t* status;          // OR-ed with 1 when a problem has no finite assignment (SciPy raises ValueError there)
 };
 
 __device__ __forceinline__ double wave_min_f64(double x)
@@ -79,12 +80,26 @@ __global__ __launch_bounds__(64) void lsa_kernel(const float* __restrict__ cost_
     const float* __restrict__ cg = cost_all + P.cost_off;
     // internal cost(i, j): i < nr, j < nc
     const int64_t si = tr ? 1 : P.row_stride, sj = tr ? P.row_stride : 1;
+    // SciPy refuses a matrix with NaN or -inf entries up front ("matrix contains invalid numeric entries"): scan it (the
+    // LDS staging pass reads every entry anyway) and report through the status word; the solve below still runs and simply
+    // never takes such an entry
+    bool invalid = false;
     if (LDS_COST) {
+        // stage the matrix once (in solver orientation): every row scan then reads LDS instead of L2
         for (int e = lane; e < nr * nc; e += 64) {
             const int i = e / nc, j = e - i * nc;
-            cst[e] = cg[i * si + j * sj];
+            const float c = cg[i * si + j * sj];
+            invalid |= (c != c) || c == -INFINITY;
+            cst[e] = c;
+        }
+    } else if (out.status) {
+        for (int e = lane; e < nr * nc; e += 64) {
+            const int i = e / nc, j = e - i * nc;
+            const float c = cg[i * si + j * sj];
+            invalid |= (c != c) || c == -INFINITY;
         }
     }
+    if (invalid && out.status) atomicOr(out.status, 1);
     for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
     for (int j = lane; j < nc; j += 64) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
     __syncthreads();
@@ -118,7 +133,10 @@ __global__ __launch_bounds__(64) void lsa_kernel(const float* __restrict__ cost_
             const int index = lu >= 0 ? lu : f;
             minVal = m;
             if (!(m < INFINITY)) {           // infeasible (SciPy raises); leave the rows unassigned
-                if (lane == 0) sh_sink = -2;
+                if (lane == 0) {
+                    sh_sink = -2;
+                    if (out.status) atomicOr(out.status, 1);
+                }
                 __syncthreads();
                 break;
             }
@@ -181,9 +199,21 @@ __global__ __launch_bounds__(64) void lsa_kernel(const float* __restrict__ cost_
 
 }  // namespace
 
+extern "C" int mpf_lsa_assign_status(const float* cost, const MpfLsaProblem* problems, int n_problems, int max_dim,
+                                     int64_t max_entries, int32_t* row_out, int32_t* col_out, int64_t* aff_a, int64_t* aff_b,
+                                     int64_t* scatter_dst, const int64_t* scatter_src, int32_t* status, void* stream);
+
 extern "C" int mpf_lsa_assign(const float* cost, const MpfLsaProblem* problems, int n_problems, int max_dim, int64_t max_entries,
                               int32_t* row_out, int32_t* col_out, int64_t* aff_a, int64_t* aff_b, int64_t* scatter_dst,
                               const int64_t* scatter_src, void* stream)
+{
+    return mpf_lsa_assign_status(cost, problems, n_problems, max_dim, max_entries, row_out, col_out, aff_a, aff_b, scatter_dst,
+                                 scatter_src, nullptr, stream);
+}
+
+extern "C" int mpf_lsa_assign_status(const float* cost, const MpfLsaProblem* problems, int n_problems, int max_dim,
+                                     int64_t max_entries, int32_t* row_out, int32_t* col_out, int64_t* aff_a, int64_t* aff_b,
+                                     int64_t* scatter_dst, const int64_t* scatter_src, int32_t* status, void* stream)
 {
     if (n_problems == 0) return 0;
     if (!cost || !problems) return mpf::fail(MPF_E_NULL, "lsa_assign: NULL buffer");
@@ -191,7 +221,7 @@ extern "C" int mpf_lsa_assign(const float* cost, const MpfLsaProblem* problems, 
     if (max_dim > kMaxDim) return mpf::fail(MPF_E_TOO_LARGE, "lsa_assign: a problem has more than 512 rows or columns");
     if (scatter_dst && !scatter_src) return mpf::fail(MPF_E_NULL, "lsa_assign: scatter_dst without scatter_src");
     hipStream_t st = (hipStream_t)stream;
-    LsaOut o{row_out, col_out, aff_a, aff_b, scatter_dst, scatter_src};
+    LsaOut o{row_out, col_out, aff_a, aff_b, scatter_dst, scatter_src, status};
     mpf::prof_begin(st);
     mpf::set_kernel("lsa_kernel");
     if (max_entries <= kCostLds)

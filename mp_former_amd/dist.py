@@ -23,8 +23,16 @@ def init_from_env(backend=None, device=None):
     rank = int(os.environ.get("RANK", "0"))
     force = os.environ.get("MPF_FORCE_DIST", "0") == "1" and "MASTER_ADDR" in os.environ   # 1-GPU test of the N>1 path
     if (world > 1 or force) and not dist.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl" and "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
+            # ROCr reads the variable when HIP initialises: setting it here only helps if nothing has touched the GPU
+            # yet (bench.py exports it before importing torch; torch.distributed.run children inherit the launcher's env)
+            if torch.cuda.is_initialized():
+                import warnings
+                warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY=0 was not in the environment when HIP initialised: RCCL's "
+                              "buffer sharing between processes needs it on this driver (hipIpcGetMemHandle: invalid "
+                              "argument otherwise) — export it before the first torch.cuda call")
+            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"   # dmabuf IPC only on this driver
         kwargs = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, world

@@ -10,6 +10,40 @@ FIELDS = ("cost_off", "n_rows", "n_cols", "row_stride", "out_pos", "col_base", "
           "scatter_base")
 MAX_DIM = 512
 
+# Failure reporting without a host synchronisation: the kernel ORs 1 into a device word when a problem has no
+# finite assignment (NaN / all-infinite costs — scipy.optimize.linear_sum_assignment raises ValueError there, matcher.py:151);
+# the word is copied to pinned host memory behind the launch and LOOKED AT on the next call (or by check_status()), i.e.
+# one step late at worst, instead of training on with unassigned pairs.
+_status = {}     # device -> {"dev": int32[1], "host": pinned int32[1], "event": Event or None}
+
+
+def _status_of(dev):
+    st = _status.get(dev)
+    if st is None:
+        st = {"dev": torch.zeros(1, dtype=torch.int32, device=dev), "host": torch.zeros(1, dtype=torch.int32).pin_memory(),
+              "event": None}
+        _status[dev] = st
+    return st
+
+
+def check_status(dev=None, block=False):
+    """Raise ValueError if an earlier device assignment was infeasible.  Non-blocking unless ``block``."""
+    for d, st in list(_status.items()):
+        if dev is not None and d != dev:
+            continue
+        ev = st["event"]
+        if ev is None:
+            continue
+        if block:
+            ev.synchronize()
+        if ev.query():
+            st["event"] = None
+            if int(st["host"][0]) != 0:
+                st["dev"].zero_()
+                st["host"].zero_()
+                raise ValueError("device linear_sum_assignment: cost matrix is infeasible or contains invalid numeric entries "
+                                 "(NaN / no finite assignment) — the reference's SciPy call raises here (matcher.py:151)")
+
 
 def lsa_assign(cost, problems, n_slots, want_rows=True, want_cols=True, want_a=False, want_b=False, scatter_dst=None,
                scatter_src=None, into=None):
@@ -38,12 +72,18 @@ def lsa_assign(cost, problems, n_slots, want_rows=True, want_cols=True, want_a=F
     max_entries = int((problems[:, 1] * problems[:, 2]).max())
     if max_dim > MAX_DIM:
         raise RuntimeError(f"device assignment handles up to {MAX_DIM} rows / columns per problem, got {max_dim}")
+    check_status(dev)                       # a failure of an earlier step surfaces here
+    st = _status_of(dev)
     pd = upload(problems.reshape(-1), dev)
     p = lambda k: out[k].data_ptr() if k in out else None  # noqa: E731
     with torch.cuda.device(dev):
-        code = _lib.lib().mpf_lsa_assign(cost.data_ptr(), pd.data_ptr(), n, max_dim, max_entries, p("rows"), p("cols"), p("a"), p("b"),
-                                         scatter_dst.data_ptr() if scatter_dst is not None else None,
-                                         scatter_src.data_ptr() if scatter_src is not None else None,
-                                         torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(code, "mpf_lsa_assign")
+        code = _lib.lib().mpf_lsa_assign_status(cost.data_ptr(), pd.data_ptr(), n, max_dim, max_entries, p("rows"), p("cols"), p("a"),
+                                                p("b"), scatter_dst.data_ptr() if scatter_dst is not None else None,
+                                                scatter_src.data_ptr() if scatter_src is not None else None,
+                                                st["dev"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(code, "mpf_lsa_assign_status")
+    if st["event"] is None:                 # one read-back in flight at a time (16 bytes, pinned, behind the kernel)
+        st["host"].copy_(st["dev"], non_blocking=True)
+        st["event"] = torch.cuda.Event()
+        st["event"].record(torch.cuda.current_stream(dev))
     return out

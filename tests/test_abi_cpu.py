@@ -83,8 +83,19 @@ def test_shipped_miopen_find_db_is_wired(monkeypatch, tmp_path):
     assert files and os.path.getsize(files[0]) > 1000
     monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
     monkeypatch.delenv("MPF_MIOPEN_DB", raising=False)
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "cache"))
     path = _miopen.use_shipped_find_db()
     assert path and os.path.isdir(path) and os.environ["MIOPEN_USER_DB_PATH"] == path
+    # MIOpen appends to its user db: it must get a private copy, never the tracked directory
+    assert os.path.realpath(path) != os.path.realpath(os.path.join(os.path.dirname(_miopen.__file__), "miopen_db"))
+    assert sorted(os.listdir(path)) == sorted(os.listdir(os.path.join(os.path.dirname(_miopen.__file__), "miopen_db")))
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    assert _miopen.use_shipped_find_db() == path                    # idempotent: a second rank finds the same copy
+    assert _miopen.shipped_version() == (3, 5, 0)
+    open(os.path.join(path, "gfx950100.HIP.9_9_9_deadbeef.ufdb.txt"), "w").write("x")
+    assert _miopen.db_mismatch(path)                                # a db file of another build name is reported
+    os.remove(os.path.join(path, "gfx950100.HIP.9_9_9_deadbeef.ufdb.txt"))
+    assert not _miopen.db_mismatch(path)
     monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(tmp_path))
     assert _miopen.use_shipped_find_db() == str(tmp_path)           # a user setting wins
     monkeypatch.delenv("MIOPEN_USER_DB_PATH")

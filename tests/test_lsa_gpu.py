@@ -207,3 +207,25 @@ def test_criterion_device_assignment_edge_counts(counts):
         assert abs(l_host[k] - l_dev[k]) <= 2e-3 * max(1.0, abs(l_host[k])), (k, l_host[k], l_dev[k])
     assert torch.isfinite(g_dev).all()
     assert (g_host - g_dev).norm().item() <= 2e-2 * (g_host.norm().item() + 1e-9)
+
+
+def test_infeasible_cost_matrix_is_reported_like_scipy():
+    """A NaN / all-infinite cost matrix: SciPy raises ValueError (matcher.py:151); the device solver sets its status
+    word, which the next call (or check_status) turns into the same exception — no silent training on unassigned pairs."""
+    import scipy.optimize
+    from mp_former_amd import lsa as L
+    dev = torch.device("cuda:0")
+    L.check_status(dev, block=True)
+    good = torch.rand(6, 4, device=dev)
+    bad = good.clone()
+    bad[2, :] = float("nan")
+    with pytest.raises(ValueError):
+        scipy.optimize.linear_sum_assignment(bad.cpu().numpy())
+    prob = np.array([[0, 6, 4, 4, 0, 0, 0, 0, 0, 0, 0]], dtype=np.int64)
+    L.lsa_assign(good.contiguous(), prob, 4)
+    L.check_status(dev, block=True)                       # feasible: nothing raised
+    L.lsa_assign(bad.contiguous(), prob, 4)
+    with pytest.raises(ValueError, match="invalid numeric entries|infeasible"):
+        L.check_status(dev, block=True)
+    L.lsa_assign(good.contiguous(), prob, 4)              # the flag was cleared
+    L.check_status(dev, block=True)
