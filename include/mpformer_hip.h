@@ -358,6 +358,23 @@ int mpf_decoder_inputs_backward(const void* g_src, const void* g_kin, int g_dtyp
                                 int N, int C, void* stream);
 
 /*
+ * Fused mask head -> next-layer attention mask (forward_prediction_heads, mask2former_transformer_decoder.py:1859-1877:
+ * einsum("bqc,bchw->bqhw") + bilinear resize to the level grid + sigmoid < 0.5, detached), bf16.  The resize commutes
+ * with the channel contraction, so the pixel-decoder features are resized once per step and level:
+ *   mpf_pool_features: mask_features [N, 256, h, w] (MPF_F32 / MPF_BF16)  ->  out [N, hl*wl, 256] bf16 (pixel-major),
+ *                      F.interpolate(mode="bilinear", align_corners=False) semantics;
+ * and each layer only multiplies its mask embeddings with that:
+ *   mpf_mask_head_bits: mask_embed bf16, element (n, q, c) at n*stride_n + q*stride_q + c;  pooled [N, HW, 256] bf16;
+ *                       out [N, Q, HW] bytes: 1 = do not attend (logit < 0), rows q < pad copied from mp_rows [N, pad, HW]
+ *                       (mask-piloted rows, :1814-1816), rows that would be all 1 cleared to 0 (:1780);
+ *                       flags [N*Q] int32, zero on entry, zero again on return (scratch for the all-masked rule).
+ * The [N, Q, h, w] map of the reference is never formed.  HW must be a multiple of 16.
+ */
+int mpf_pool_features(const void* mask_features, int dtype, void* out_bf16, int N, int C, int h, int w, int hl, int wl, void* stream);
+int mpf_mask_head_bits(const void* mask_embed, int64_t stride_n, int64_t stride_q, const void* pooled, const uint8_t* mp_rows,
+                       int pad, uint8_t* out, int32_t* flags, int N, int Q, int HW, void* stream);
+
+/*
  * Linear sum assignment (the Hungarian step of HungarianMatcher.memory_efficient_forward, matcher.py:
  * 149-151, where the reference calls scipy.optimize.linear_sum_assignment on a host copy of the cost
  * matrix) solved on the device, one wavefront per problem, with SciPy's algorithm and tie-breaking

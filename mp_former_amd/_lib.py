@@ -58,6 +58,8 @@ SIGNATURES = {
     "mpf_decoder_layer_scratch_bytes": (ctypes.c_uint64, [_c_int] * 6),
     "mpf_decoder_layer_forward": (_c_int, [_c_vp, _c_vp]),
     "mpf_decoder_layer_backward": (_c_int, [_c_vp, _c_vp, _c_vp]),
+    "mpf_pool_features": (_c_int, [_c_vp, _c_int, _c_vp] + [_c_int] * 6 + [_c_vp]),
+    "mpf_mask_head_bits": (_c_int, [_c_vp, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 3 + [_c_vp]),
     "mpf_lsa_assign": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, ctypes.c_int64] + [_c_vp] * 7),
     "mpf_lsa_assign_status": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, ctypes.c_int64] + [_c_vp] * 8),
     "mpf_mask_block_empty": (_c_int, [_c_vp, _c_vp] + [_c_int] * 5 + [_c_vp]),

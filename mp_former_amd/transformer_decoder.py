@@ -157,6 +157,48 @@ def native_attn_mask(masks, size, mp_rows=None):
     return out
 
 
+def pool_features(mask_features, size):
+    """F.interpolate(mask_features [N,256,h,w], size, mode="bilinear", align_corners=False) as a pixel-major bf16
+    matrix [N, hl*wl, 256] — the B operand of the fused mask head (csrc/mask_head.hip).  Once per step and level."""
+    N, C, h, w = mask_features.shape
+    hl, wl = size
+    mf = mask_features if mask_features.is_contiguous() else mask_features.contiguous()
+    dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}[mf.dtype]
+    out = torch.empty((N, hl * wl, C), dtype=torch.bfloat16, device=mf.device)
+    with torch.cuda.device(mf.device):
+        code = _lib.lib().mpf_pool_features(mf.data_ptr(), dt, out.data_ptr(), N, C, h, w, hl, wl,
+                                            torch.cuda.current_stream(mf.device).cuda_stream)
+    _lib.check(code, "mpf_pool_features")
+    return out
+
+
+_mask_flags = {}
+
+
+def mask_head_bits(mask_embed, pooled, mp_rows=None):
+    """mask_embed bf16 [Qtot, N, 256] (sequence-first, as the MLP leaves it) x pooled [N, HW, 256] -> bool [N, Qtot, HW]
+    attention mask of the next layer: sign of the product (sigmoid < 0.5), MP rows, all-masked-row rule
+    (decoder :1869-1875, :1814-1816, :1780) without ever forming the [N, Qtot, H/4, W/4] map."""
+    Q, N, C = mask_embed.shape
+    HW = pooled.shape[1]
+    assert mask_embed.dtype == torch.bfloat16 and pooled.dtype == torch.bfloat16 and mask_embed.stride(2) == 1
+    pad = 0 if mp_rows is None else mp_rows.shape[1]
+    if pad:
+        mp_rows = mp_rows.contiguous()
+    dev = mask_embed.device
+    flags = _mask_flags.get((dev, N * Q))
+    if flags is None:
+        flags = torch.zeros(N * Q, dtype=torch.int32, device=dev)          # zero on entry, zeroed again by the kernel
+        _mask_flags[(dev, N * Q)] = flags
+    out = torch.empty((N, Q, HW), dtype=torch.bool, device=dev)
+    with torch.cuda.device(dev):
+        code = _lib.lib().mpf_mask_head_bits(mask_embed.data_ptr(), mask_embed.stride(1), mask_embed.stride(0), pooled.data_ptr(),
+                                             mp_rows.data_ptr() if pad else None, pad, out.data_ptr(), flags.data_ptr(), N, Q, HW,
+                                             torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(code, "mpf_mask_head_bits")
+    return out
+
+
 def linear(x, w, b=None, relu=False):
     """relu?(F.linear(x, w, b)).  bf16 activations with a few hundred rows (the query side of the decoder
     under autocast) run on the small-row MFMA GEMM with the ReLU / its backward gate / the bias gradient
@@ -431,7 +473,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         W = self._weights()
         return self._heads(W, output, mask_features.to(W["class_embed.weight"].dtype), attn_mask_target_size, mp_rows)
 
-    def _next_attn_mask(self, W, output, mask_features, attn_mask_target_size, mp_rows=None):
+    def _next_attn_mask(self, W, output, mask_features, attn_mask_target_size, mp_rows=None, pooled=None):
         """The attention mask the NEXT layer needs (:1869-1875), from this layer's mask prediction,
         outside autograd (the reference detaches it, :1875).  The differentiable predictions of all
         layers are produced together by ``_heads_batched`` after the last layer."""
@@ -441,8 +483,11 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             x = d16 if amp else d32
             e = linear(x, W["mask_embed.layers.0.weight"].detach(), W["mask_embed.layers.0.bias"].detach(), relu=True)
             e = linear(e, W["mask_embed.layers.1.weight"].detach(), W["mask_embed.layers.1.bias"].detach(), relu=True)
-            me = linear(e, W["mask_embed.layers.2.weight"].detach(), W["mask_embed.layers.2.bias"].detach()).transpose(0, 1)
-            m = torch.einsum("bqc,bchw->bqhw", me, mask_features.detach())
+            me = linear(e, W["mask_embed.layers.2.weight"].detach(), W["mask_embed.layers.2.bias"].detach())     # [Qtot, N, C]
+            if pooled is not None:
+                # fused mask head (csrc/mask_head.hip): product with the features already resized to this level
+                return mask_head_bits(me, pooled, mp_rows)
+            m = torch.einsum("bqc,bchw->bqhw", me.transpose(0, 1), mask_features.detach())
             return native_attn_mask(m, attn_mask_target_size, mp_rows)
 
     def _heads_batched(self, W, outputs, mask_features):
@@ -542,7 +587,18 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         H = self.num_heads
         output = output.float().contiguous()            # fp32 residual stream [Qtot, N, C]
         xb = output.to(adt) if amp else output           # operand copy for the GEMMs (bf16 under AMP)
-        attn_mask = self._next_attn_mask(W, output, mask_features, size_list[0], rows(0))
+        # fused mask head (AMP, 256 channels): the features resized ONCE per step to each level grid; the per-layer mask
+        # is then a [Qtot x 256] x [256 x HW_l] MFMA product whose sign goes straight to the byte mask
+        pooled = [None] * self.num_feature_levels
+        if (amp and adt == torch.bfloat16 and mask_features.shape[1] == 256 and os.environ.get("MPF_FUSED_MASK_HEAD", "1") == "1"
+                and all((hh * ww) % 16 == 0 for hh, ww in size_list)):
+            with torch.no_grad():
+                done = {}
+                for lv, sz in enumerate(size_list):
+                    if sz not in done:
+                        done[sz] = pool_features(mask_features.detach(), sz)
+                    pooled[lv] = done[sz]
+        attn_mask = self._next_attn_mask(W, output, mask_features, size_list[0], rows(0), pooled[0])
         streams = [output]
 
         def post_norm(norm, x32, t2):
@@ -576,7 +632,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             nxt = (i + 1) % self.num_feature_levels
             streams.append(output)
             if i + 1 < self.num_layers:
-                attn_mask = self._next_attn_mask(W, output, mask_features, size_list[nxt], rows(nxt, i))
+                attn_mask = self._next_attn_mask(W, output, mask_features, size_list[nxt], rows(nxt, i), pooled[nxt])
         predictions_class, predictions_mask = self._heads_batched(W, streams, mask_features)
 
         nq = self.num_queries

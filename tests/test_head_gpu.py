@@ -175,7 +175,7 @@ def test_head_baseline_config_shapes_run(name, size, chans, classes, queries, n)
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
     assert not [k for k, p in h.named_parameters() if p.grad is None]
-    for kern in ("msda_fwd_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost", "mask_loss_fwd", "attn_mask"):
+    for kern in ("msda_fwd_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost", "mask_loss_fwd", "mask_head_bits", "pool_features"):
         assert _lib.profile_get(kern)[0] > 0, kern
     _lib.profile_enable(False)
 
@@ -277,7 +277,7 @@ def test_head_full_size_configs_B_C(name, classes, n):
     _lib.profile_enable(True)
     l0 = run(11)
     for kern in ("msda_fwd_block", "msda_bwd_push_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost",
-                 "mask_loss_fwd", "attn_mask", "lsa_kernel", "gemm3"):
+                 "mask_loss_fwd", "mask_head_bits", "pool_features", "lsa_kernel", "gemm3"):
         assert _lib.profile_get(kern)[0] > 0, kern
     _lib.profile_enable(False)
     assert len(l0) == 60 and all(np.isfinite(v) for v in l0.values()), l0

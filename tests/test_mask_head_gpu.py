@@ -1,0 +1,78 @@
+"""Fused mask head (csrc/mask_head.hip) against the reference formula of forward_prediction_heads
+(mask2former_transformer_decoder.py:1869-1875): einsum("bqc,bchw->bqhw") -> F.interpolate(bilinear, align_corners=False)
+-> sigmoid < 0.5, plus the mask-piloted row overwrite (:1814-1816) and the all-masked-row rule (:1780)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(me, mf, size, mp_rows):
+    # me [Q, N, C] bf16, mf [N, C, h, w] bf16 -> bool [N, Q, hl*wl]; float64 accumulate so that only genuine near-zero
+    # logits can disagree with the bf16-operand / fp32-accumulate product
+    m = torch.einsum("qnc,nchw->nqhw", me.double(), mf.double())
+    r = F.interpolate(m, size=size, mode="bilinear", align_corners=False)
+    am = (r.sigmoid() < 0.5).flatten(2)
+    if mp_rows is not None:
+        am[:, :mp_rows.shape[1]] = mp_rows
+    am[torch.where(am.sum(-1) == am.shape[-1])] = False
+    return am, r.flatten(2)
+
+
+@pytest.mark.parametrize("N,Q,h,w,size,pad", [(2, 117, 64, 64, (32, 32), 17), (1, 100, 64, 96, (16, 24), 0), (2, 213, 40, 40, (20, 20), 13),
+                                                (1, 30, 32, 32, (8, 8), 3)])
+def test_fused_mask_head_matches_reference_formula(N, Q, h, w, size, pad):
+    from mp_former_amd import transformer_decoder as TD
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Q)
+    me = (torch.randn(Q, N, 256, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    mf = torch.randn(N, 256, h, w, generator=g).to(torch.bfloat16).to(dev)
+    HW = size[0] * size[1]
+    mp_rows = None
+    if pad:
+        mp_rows = (torch.rand(N, pad, HW, generator=g) < 0.6).to(dev)
+        mp_rows[:, 0] = True                       # an all-masked MP row: must come out all False
+    me[5] = me[5].abs() * 0 + 1.0                  # a row with constant positive embedding ...
+    mf_row = mf.float().sum(1, keepdim=True)
+    pooled = TD.pool_features(mf, size)
+    # pooled features vs F.interpolate on the bf16 features (fp32 math), rounded to bf16
+    want_p = F.interpolate(mf.float(), size=size, mode="bilinear", align_corners=False).flatten(2).transpose(1, 2)
+    torch.testing.assert_close(pooled.float(), want_p.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-2)
+    got = TD.mask_head_bits(me, pooled, mp_rows)
+    want, logits = _reference(me, mf, size, mp_rows)
+    assert got.dtype == torch.bool and got.shape == want.shape
+    diff = got != want
+    # disagreements are allowed only where the logit is within rounding of zero (bf16 pooled operand: 2^-8 relative of
+    # the terms' magnitude); rows touched by the MP overwrite / all-masked rule must agree exactly
+    scale = torch.einsum("qnc,nchw->nqhw", me.double().abs(), mf.double().abs())
+    scale = F.interpolate(scale, size=size, mode="bilinear", align_corners=False).flatten(2)
+    near = logits.abs() <= 2.0 ** -7 * scale
+    if pad:
+        assert not diff[:, :pad].any()
+    bad = diff & ~near
+    # a row flipped by the all-masked rule because of a near-zero logit would differ everywhere: exclude rows whose
+    # open pixels are all near-zero
+    rows_fragile = ((~want) & ~near).sum(-1) == 0
+    bad &= ~rows_fragile[..., None]
+    assert int(bad.sum()) == 0, f"{int(bad.sum())} mask bits differ away from zero logits (of {diff.numel()}; {int(diff.sum())} near zero)"
+    assert float(diff.float().mean()) < 5e-3
+
+
+def test_all_masked_row_is_cleared_and_flags_reset():
+    from mp_former_amd import transformer_decoder as TD
+    dev = torch.device("cuda:0")
+    N, Q, HW = 2, 20, 256
+    pooled = torch.ones(N, HW, 256, dtype=torch.bfloat16, device=dev)
+    me = torch.ones(Q, N, 256, dtype=torch.bfloat16, device=dev)
+    me[3] = -1.0                                    # logits < 0 everywhere: fully masked -> attends everywhere
+    for _ in range(2):                              # second call: the scratch flags must have been reset
+        got = TD.mask_head_bits(me, pooled, None)
+        assert not got.any()
+    me[3, 0, :] = 1.0
+    me[4, 1, :] = -1.0
+    pooled[1, :7] = -1.0                            # image 1: pixels 0..6 flip sign
+    got = TD.mask_head_bits(me, pooled, None)
+    assert not got[0].any()
+    assert got[1, 0, :7].all() and not got[1, 0, 7:].any()          # positive embedding, negative features
+    assert (~got[1, 4, :7]).all() and got[1, 4, 7:].all()           # negative embedding
