@@ -270,7 +270,7 @@ def main():
             if not n or ms <= 0:
                 return {"kernel": name, "launches": 0}
             tf = fl / (ms * 1e-3) / 1e12
-            return {"kernel": name, "launches_per_step": n / P, "ms_per_step": round(ms / P, 3), "bound": "hbm/L2 stream of K, V, mask",
+            return {"kernel": name, "launches_per_step": n / max(P, 1), "ms_per_step": round(ms / max(P, 1), 3), "bound": "hbm/L2 stream of K, V, mask",
                     "mfma_tflops": round(tf, 2), "mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS, "mfma_frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 5),
                     "kv_mask_GBps": round(by / (ms * 1e-3) / 1e9, 1), "hbm_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
@@ -281,7 +281,7 @@ def main():
             # an fp32 product costs six bf16 MFMA products here (three planes per operand, terms >= 2^-16 kept), so the
             # kernel's own ceiling is the dense bf16 peak / 6
             peak = MFMA_BF16_PEAK_TFLOPS / 6.0
-            return {"kernel": name, "launches_per_step": n / P, "ms_per_step": round(ms / P, 3), "bound": "mfma",
+            return {"kernel": name, "launches_per_step": n / max(P, 1), "ms_per_step": round(ms / max(P, 1), 3), "bound": "mfma",
                     "unit": "TFLOP/s (fp32-equivalent)", "achieved": round(tf, 1), "peak": round(peak, 1), "frac": round(tf / peak, 4),
                     "bf16_mfma_tflops": round(6.0 * tf, 1), "bf16_mfma_frac": round(6.0 * tf / MFMA_BF16_PEAK_TFLOPS, 4)}
 
