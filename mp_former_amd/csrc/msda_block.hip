@@ -740,7 +740,8 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
 // the loc / attn records of a band (shared by the tiles of ALL levels that cover it) are fetched from HBM once and
 // then hit in the XCD's L2; each XCD walks a contiguous range of that order.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kTP = 1024;
+constexpr int kTP = 256;          // pull workgroup: kWP waves
+constexpr int kWP = kTP / 64;
 
 template <int NL>
 __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
@@ -748,8 +749,8 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
     const int* __restrict__ tile_count, const unsigned* __restrict__ entries, float* __restrict__ grad_value, GeomB g, int nwg,
     unsigned loc_bytes, unsigned go_bytes)
 {
-    __shared__ float s_red[15][8][64];                 // partial accumulators of the waves with part > 0
-    __shared__ float4 s_rec[16][64];                   // per wave: the 64 sample records of the current chunk
+    __shared__ float s_red[kWP - 1][8][64];            // partial accumulators of the waves with part > 0
+    __shared__ float4 s_rec[kWP][64];                   // per wave: the 64 sample records of the current chunk
     const int wg = xcd_index(nwg);
     if (wg >= nwg) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
     const int nty = (H + 3) >> 2, ntx = sel(g.ntx, l);
     const int tile_base = sel(g.tile_base, l), cap = sel(g.cap, l), ent_base = sel(g.ent_base, l), start = sel(g.start, l);
     const int row0 = band * nty / g.nband, row1 = (band + 1) * nty / g.nband;
-    const int unit = (r - slot_base) * 16 + wave;
+    const int unit = (r - slot_base) * kWP + wave;
     const int part = unit % wpt, tb = unit / wpt;             // tile inside the (band, level) group
     const bool live = tb < (row1 - row0) * ntx;
     const int ty = row0 + tb / ntx, tx = tb - (tb / ntx) * ntx;
@@ -960,7 +961,7 @@ bool build_geom(GeomB& g, const int64_t* hs, int N, int S, int M, int L, int Lq)
         if ((int64_t)ebase + (int64_t)ntiles * cap >= (1ll << 31)) return false;
         g.ent_base[l] = ebase; ebase += (int)(ntiles * cap);
         // waves per tile: aim at ~2 chunks (128 entries) per wave
-        g.wpt[l] = expect > 1400.0 ? 16 : (expect > 700.0 ? 8 : (expect > 350.0 ? 4 : (expect > 175.0 ? 2 : 1)));
+        g.wpt[l] = std::min(kWP, expect > 1400.0 ? 16 : (expect > 700.0 ? 4 : (expect > 350.0 ? 2 : 1)));
     }
     (void)wgb;
     if (start != S) return false;
@@ -975,7 +976,7 @@ bool build_geom(GeomB& g, const int64_t* hs, int N, int S, int M, int L, int Lq)
                 const int nty = (g.H[l] + 3) / 4;
                 const int rows = (bnd + 1) * nty / nband - bnd * nty / nband;
                 g.band_wg_base[bnd * L + l] = base;
-                base += (rows * g.ntx[l] * g.wpt[l] + 15) / 16;
+                base += (rows * g.ntx[l] * g.wpt[l] + kWP - 1) / kWP;
             }
         g.wg_per_bm = base;
     }
