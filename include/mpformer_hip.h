@@ -363,6 +363,7 @@ int mpf_decoder_inputs_backward(const void* g_src, const void* g_kin, int g_dtyp
  * with the channel contraction, so the pixel-decoder features are resized once per step and level:
  *   mpf_pool_features: mask_features [N, 256, h, w] (MPF_F32 / MPF_BF16)  ->  out [N, hl*wl, 256] bf16 (pixel-major),
  *                      F.interpolate(mode="bilinear", align_corners=False) semantics;
+ *   mpf_pool_features_cl: the same for channel-last features: image n = [h*w][256] at mask_features + n*batch_stride;
  * and each layer only multiplies its mask embeddings with that:
  *   mpf_mask_head_bits: mask_embed bf16, element (n, q, c) at n*stride_n + q*stride_q + c;  pooled [N, HW, 256] bf16;
  *                       out [N, Q, HW] bytes: 1 = do not attend (logit < 0), rows q < pad copied from mp_rows [N, pad, HW]
@@ -371,6 +372,8 @@ int mpf_decoder_inputs_backward(const void* g_src, const void* g_kin, int g_dtyp
  * The [N, Q, h, w] map of the reference is never formed.  HW must be a multiple of 16.
  */
 int mpf_pool_features(const void* mask_features, int dtype, void* out_bf16, int N, int C, int h, int w, int hl, int wl, void* stream);
+int mpf_pool_features_cl(const void* mask_features, int64_t batch_stride, int dtype, void* out_bf16, int N, int C, int h, int w,
+                         int hl, int wl, void* stream);
 int mpf_mask_head_bits(const void* mask_embed, int64_t stride_n, int64_t stride_q, const void* pooled, const uint8_t* mp_rows,
                        int pad, uint8_t* out, int32_t* flags, int N, int Q, int HW, void* stream);
 
@@ -623,6 +626,30 @@ int mpf_mask_loss_backward_dense(const void* pred, int pred_dtype, int h, int w,
 size_t mpf_group_stats_workspace_bytes(int rows, int64_t row_len);
 int mpf_group_stats(const float* x, int rows, int64_t row_len, float eps, float* mean, float* rstd,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * GroupNorm of the pixel decoder on channel-last planes (the layout the fp32 convolutions produce), forward and
+ * backward (replaces nn.GroupNorm(32, conv_dim) of msdeformattn.py:245-281 and, optionally, what follows it).
+ * A plane is x[n] = [HW][C] floats at x + n * x_bs (dense pixel rows; the batch stride is free, in elements).
+ * Needs C % 4 == 0, (C/G) % 4 == 0, 256 % (C/4) == 0 (mpf_gn_cl_supported).
+ *   forward:  mean / rstd [N*G] (saved for the backward) and y = (x - mean) * rstd * gamma + beta, then
+ *             relu != 0: y = max(y, 0)                 (detectron2 Conv2d(norm=GN, activation=relu), msdeformattn.py:268)
+ *             top != NULL: y += bilinear 2x upsampling (align_corners=False) of top[n] = [HW/4][C] at
+ *             top + n * top_bs; W = width of the OUTPUT plane   (the FPN top-down sum, msdeformattn.py:349-351)
+ *   backward: dx, dgamma[C], dbeta[C] (either may be NULL) from gy; with relu != 0 gy is gated by y > 0 (recomputed).
+ *             The gradient of `top` is mpf_upsample2x_cl_backward(gy): dtop[n] = [Ht*Wt][C].
+ * Statistics: (count, mean, M2) per 128-pixel chunk merged with Chan's formula (fp64 across chunks).
+ */
+int mpf_gn_cl_supported(int HW, int C, int G);
+size_t mpf_gn_cl_workspace_bytes(int N, int HW, int C, int G);
+int mpf_gn_cl_forward(const float* x, int64_t x_bs, const float* gamma, const float* beta, int N, int HW, int C, int G,
+                      float eps, int relu, const float* top, int64_t top_bs, int W, float* y, int64_t y_bs, float* mean,
+                      float* rstd, void* workspace, size_t workspace_bytes, void* stream);
+int mpf_gn_cl_backward(const float* gy, int64_t gy_bs, const float* x, int64_t x_bs, const float* gamma, const float* beta,
+                       const float* mean, const float* rstd, int N, int HW, int C, int G, int relu, float* dx,
+                       int64_t dx_bs, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+int mpf_upsample2x_cl_backward(const float* gy, int64_t gy_bs, int N, int Ht, int Wt, int C, float* dtop, int64_t dtop_bs,
+                               void* stream);
 
 /*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP

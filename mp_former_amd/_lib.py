@@ -59,6 +59,7 @@ SIGNATURES = {
     "mpf_decoder_layer_forward": (_c_int, [_c_vp, _c_vp]),
     "mpf_decoder_layer_backward": (_c_int, [_c_vp, _c_vp, _c_vp]),
     "mpf_pool_features": (_c_int, [_c_vp, _c_int, _c_vp] + [_c_int] * 6 + [_c_vp]),
+    "mpf_pool_features_cl": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_mask_head_bits": (_c_int, [_c_vp, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_vp, _c_int, _c_vp, _c_vp] + [_c_int] * 3 + [_c_vp]),
     "mpf_lsa_assign": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, ctypes.c_int64] + [_c_vp] * 7),
     "mpf_lsa_assign_status": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, ctypes.c_int64] + [_c_vp] * 8),
@@ -84,6 +85,13 @@ SIGNATURES = {
     "mpf_res_ln256_backward": (_c_int, [_c_vp] * 11 + [_c_int, _c_vp]),
     "mpf_mask_loss_backward_dense": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
                                               _c_vp, _c_int, _c_vp, _c_int, _c_int, _c_vp]),
+    "mpf_gn_cl_supported": (_c_int, [_c_int, _c_int, _c_int]),
+    "mpf_gn_cl_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    "mpf_gn_cl_forward": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, _c_int,
+                                   _c_vp, ctypes.c_int64, _c_int, _c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, ctypes.c_size_t, _c_vp]),
+    "mpf_gn_cl_backward": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int,
+                                    _c_int, _c_int, _c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, ctypes.c_size_t, _c_vp]),
+    "mpf_upsample2x_cl_backward": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_int, _c_vp, ctypes.c_int64, _c_vp]),
     "mpf_group_stats_workspace_bytes": (ctypes.c_size_t, [_c_int, ctypes.c_int64]),
     "mpf_group_stats": (_c_int, [_c_vp, _c_int, ctypes.c_int64, ctypes.c_float, _c_vp, _c_vp, _c_vp, ctypes.c_size_t, _c_vp]),
     "mpf_msda_forward": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp]),

@@ -70,6 +70,47 @@ __global__ __launch_bounds__(kT) void pool_features_kernel(const T* __restrict__
     }
 }
 
+// the same resize for channel-last features [N, h*w, 256] (what the pixel decoder's last convolution leaves): a pixel's
+// channels are contiguous on both sides, so no transpose — 32 lanes x 8 channels per output pixel, 8 pixels per workgroup
+__device__ __forceinline__ void ld8(const float* p, float v[8])
+{
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const __hip_bfloat16* p, float v[8])
+{
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kT) void pool_features_cl_kernel(const T* __restrict__ mf, int64_t mf_bs, __hip_bfloat16* __restrict__ out,
+                                                              int h, int w, int hl, int wl)
+{
+    const int n = blockIdx.y, p = blockIdx.x * 8 + (threadIdx.x >> 5), c = (threadIdx.x & 31) * 8;
+    if (p >= hl * wl) return;
+    const int oy = p / wl, ox = p - oy * wl;
+    const float sy = (float)h / (float)hl, sx = (float)w / (float)wl;
+    const float fy = fmaxf(0.f, ((float)oy + 0.5f) * sy - 0.5f);
+    const float fx = fmaxf(0.f, ((float)ox + 0.5f) * sx - 0.5f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const T* base = mf + (int64_t)n * mf_bs + c;
+    float a[8], b[8], d[8], e[8];
+    ld8(base + ((int64_t)y0 * w + x0) * kC, a);
+    ld8(base + ((int64_t)y0 * w + x1) * kC, b);
+    ld8(base + ((int64_t)y1 * w + x0) * kC, d);
+    ld8(base + ((int64_t)y1 * w + x1) * kC, e);
+    __hip_bfloat16 r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        r[i] = __float2bfloat16((1.f - ly) * ((1.f - lx) * a[i] + lx * b[i]) + ly * ((1.f - lx) * d[i] + lx * e[i]));
+    *reinterpret_cast<uint4*>(out + ((int64_t)n * hl * wl + p) * kC + c) = *reinterpret_cast<const uint4*>(r);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // sign(mask_embed . pooled features) -> byte mask, MP rows, per-row open flags
 // grid (pixel blocks of 128, N); 4 waves; wave w owns query tiles w, w + 4, ... of the current 128-query group
@@ -174,6 +215,28 @@ extern "C" int mpf_pool_features(const void* mask_features, int dtype, void* out
                            (__hip_bfloat16*)out_bf16, h, w, hl, wl, xblocks);
     mpf::prof_end("pool_features_kernel", st, (double)N * kC * ((double)h * w * (dtype == MPF_F32 ? 4 : 2) + (double)hl * wl * 2));
     return mpf::check(hipGetLastError(), "mpf_pool_features");
+}
+
+extern "C" int mpf_pool_features_cl(const void* mask_features, int64_t batch_stride, int dtype, void* out_bf16, int N, int C, int h,
+                                    int w, int hl, int wl, void* stream)
+{
+    if (!mask_features || !out_bf16) return mpf::fail(MPF_E_NULL, "pool_features_cl: NULL buffer");
+    if (C != kC) return mpf::fail(MPF_E_SHAPE, "pool_features_cl: 256 channels only");
+    if (N <= 0 || N > 65535 || h <= 0 || w <= 0 || hl <= 0 || wl <= 0 || batch_stride % 8 != 0)
+        return mpf::fail(MPF_E_SHAPE, "pool_features_cl: bad sizes");
+    if (dtype != MPF_F32 && dtype != MPF_BF16) return mpf::fail(MPF_E_DTYPE, "pool_features_cl: f32 or bf16 input");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((hl * wl + 7) / 8, N);
+    mpf::prof_begin(st);
+    mpf::set_kernel("pool_features_cl_kernel");
+    if (dtype == MPF_F32)
+        hipLaunchKernelGGL(pool_features_cl_kernel<float>, grid, dim3(kT), 0, st, (const float*)mask_features, batch_stride,
+                           (__hip_bfloat16*)out_bf16, h, w, hl, wl);
+    else
+        hipLaunchKernelGGL(pool_features_cl_kernel<__hip_bfloat16>, grid, dim3(kT), 0, st, (const __hip_bfloat16*)mask_features,
+                           batch_stride, (__hip_bfloat16*)out_bf16, h, w, hl, wl);
+    mpf::prof_end("pool_features_cl_kernel", st, (double)N * kC * ((double)h * w * (dtype == MPF_F32 ? 4 : 2) + (double)hl * wl * 2));
+    return mpf::check(hipGetLastError(), "mpf_pool_features_cl");
 }
 
 extern "C" int mpf_mask_head_bits(const void* mask_embed, int64_t stride_n, int64_t stride_q, const void* pooled,

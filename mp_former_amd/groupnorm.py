@@ -1,10 +1,12 @@
-"""nn.GroupNorm of the pixel decoder (msdeformattn.py:245-281) with chip-filling statistics.
+"""nn.GroupNorm of the pixel decoder (msdeformattn.py:245-281).
 
-torch computes the per-(image, group) moments with one workgroup per row; at batch 2 x 32 groups that is
-64 workgroups on 256 CUs (216 us for the 134 MB maps at 256x256).  Here the statistics come from
-``mpf_group_stats`` (rows cut into chunks, Chan merge), the affine apply is one element-wise pass, and the
-backward is aten's ``native_group_norm_backward`` on the saved mean / rstd.  Same parameters and state-dict
-keys as ``nn.GroupNorm``; other devices / dtypes / layouts take the stock implementation."""
+Channel-last planes (what MIOpen's fp32 convolutions return) take csrc/groupnorm_cl.hip: chunked statistics
+with a Chan merge, ONE apply pass (optionally fused with the following ReLU or with the FPN top-down sum
+``+ upsample2x(top)``) and a native backward, all without leaving the layout (``MPF_GN_CL=0`` turns this off).
+Contiguous NCHW input takes round 1's path: ``mpf_group_stats`` (rows cut into chunks; torch's
+one-workgroup-per-row moments fill 64 of 256 CUs at batch 2), an element-wise apply, and aten's
+``native_group_norm_backward``.  Same parameters and state-dict keys as ``nn.GroupNorm``; other devices /
+dtypes take the stock implementation."""
 import os
 
 import torch
@@ -94,9 +96,93 @@ class _GroupNormFn(Function):
         return gx, gw, gb, None, None
 
 
+def is_cl_plane(x):
+    """[N, C, H, W] fp32 whose images are dense [H*W, C] planes (channels_last; the batch stride is free: a level of
+    the encoder memory is such a view)."""
+    return (x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda and x.stride(1) == 1 and x.stride(3) == x.shape[1]
+            and x.stride(2) == x.shape[3] * x.shape[1] and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+
+
+def _cl_empty(N, C, H, W, device):
+    return torch.empty((N, H, W, C), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+class _GroupNormCLFn(Function):
+    """GroupNorm on channel-last planes (csrc/groupnorm_cl.hip): statistics + ONE apply pass, optionally fused with
+    the ReLU of detectron2's Conv2d wrapper or with the FPN top-down sum ``+ upsample2x(top)``; the backward is
+    two passes over (gy, x) plus a gather for the gradient of ``top``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps, relu, top):
+        N, C, H, W = x.shape
+        lib = _lib.lib()
+        mean = torch.empty(N * groups, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(N * groups, dtype=torch.float32, device=x.device)
+        y = _cl_empty(N, C, H, W, x.device)
+        ws = _workspace(x.device, lib.mpf_gn_cl_workspace_bytes(N, H * W, C, groups))
+        with torch.cuda.device(x.device):
+            code = lib.mpf_gn_cl_forward(x.data_ptr(), x.stride(0), weight.data_ptr(), bias.data_ptr(), N, H * W, C, groups, float(eps),
+                                         1 if relu else 0, top.data_ptr() if top is not None else None,
+                                         top.stride(0) if top is not None else 0, W, y.data_ptr(), y.stride(0), mean.data_ptr(),
+                                         rstd.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(code, "mpf_gn_cl_forward")
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        ctx.groups, ctx.relu, ctx.has_top = groups, bool(relu), top is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        if not is_cl_plane(gy):
+            gy = gy.contiguous(memory_format=torch.channels_last)
+            if not is_cl_plane(gy):          # N == 1 or C == 1: the memory-format query is ambiguous; force the planes
+                gy = gy.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        lib = _lib.lib()
+        dx = _cl_empty(N, C, H, W, x.device)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _workspace(x.device, lib.mpf_gn_cl_workspace_bytes(N, H * W, C, ctx.groups))
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        dtop = None
+        with torch.cuda.device(x.device):
+            code = lib.mpf_gn_cl_backward(gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), weight.data_ptr(), bias.data_ptr(),
+                                          mean.data_ptr(), rstd.data_ptr(), N, H * W, C, ctx.groups, 1 if ctx.relu else 0,
+                                          dx.data_ptr(), dx.stride(0), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+            _lib.check(code, "mpf_gn_cl_backward")
+            if ctx.has_top and ctx.needs_input_grad[6]:
+                dtop = _cl_empty(N, C, H // 2, W // 2, x.device)
+                code = lib.mpf_upsample2x_cl_backward(gy.data_ptr(), gy.stride(0), N, H // 2, W // 2, C, dtop.data_ptr(),
+                                                      dtop.stride(0), stream)
+                _lib.check(code, "mpf_upsample2x_cl_backward")
+        return dx, dg, db, None, None, None, dtop
+
+
+def cl_enabled():
+    return os.environ.get("MPF_GN_CL", "1") == "1"
+
+
 class GroupNorm(nn.GroupNorm):
+    def cl_ok(self, x, top=None):
+        """The channel-last kernels apply: fp32 planes, affine, supported (C, G); ``top`` (FPN top-down map) exactly
+        half the size."""
+        if not (cl_enabled() and self.affine and is_cl_plane(x) and self.weight.dtype == torch.float32):
+            return False
+        N, C, H, W = x.shape
+        if not _lib.lib().mpf_gn_cl_supported(H * W, C, self.num_groups):
+            return False
+        if top is not None:
+            return (is_cl_plane(top) and top.shape[0] == N and top.shape[1] == C and top.shape[2] * 2 == H
+                    and top.shape[3] * 2 == W)
+        return True
+
+    def forward_cl(self, x, relu=False, top=None):
+        return _GroupNormCLFn.apply(x, self.weight, self.bias, self.num_groups, self.eps, relu, top)
+
     def forward(self, x):
         C = x.shape[1]
+        if self.cl_ok(x):
+            return self.forward_cl(x)
         if x.is_cuda and x.dtype == torch.float32 and not x.is_contiguous():
             x = to_nchw(x)          # channels_last conv outputs: aten's GroupNorm makes the same NCHW copy first
         if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and self.affine and x.dim() >= 3

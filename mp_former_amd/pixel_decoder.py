@@ -204,6 +204,8 @@ class _ConvNorm(nn.Conv2d):
 
     def forward(self, x):
         x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if isinstance(self.norm, GroupNorm) and self.activation in (None, F.relu) and self.norm.cl_ok(x):
+            return self.norm.forward_cl(x, relu=self.activation is F.relu)     # norm (+ ReLU) in one pass, channel-last
         if self.norm is not None:
             x = self.norm(x)
         if self.activation is not None:
@@ -306,6 +308,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
                for i, z in enumerate(torch.split(y, sizes, dim=1))]
         for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
             x = features[f].float()
+            lat = self.lateral_convs[idx]
+            if isinstance(lat.norm, GroupNorm) and lat.activation is None:
+                z = F.conv2d(x, lat.weight, lat.bias, lat.stride, lat.padding, lat.dilation, lat.groups)
+                if lat.norm.cl_ok(z, out[-1]):
+                    # norm(lateral) + upsample2x(top) in the norm's apply pass (msdeformattn.py:349-351)
+                    out.append(self.output_convs[idx](lat.norm.forward_cl(z, top=out[-1])))
+                    continue
             cur_fpn = self.lateral_convs[idx](x)
             top = to_nchw(out[-1]) if os.environ.get("MPF_FPN_NCHW_TOP", "1") == "1" else out[-1]
             y = cur_fpn + F.interpolate(top, size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)

@@ -162,14 +162,61 @@ def pool_features(mask_features, size):
     matrix [N, hl*wl, 256] — the B operand of the fused mask head (csrc/mask_head.hip).  Once per step and level."""
     N, C, h, w = mask_features.shape
     hl, wl = size
-    mf = mask_features if mask_features.is_contiguous() else mask_features.contiguous()
-    dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}[mf.dtype]
-    out = torch.empty((N, hl * wl, C), dtype=torch.bfloat16, device=mf.device)
-    with torch.cuda.device(mf.device):
-        code = _lib.lib().mpf_pool_features(mf.data_ptr(), dt, out.data_ptr(), N, C, h, w, hl, wl,
-                                            torch.cuda.current_stream(mf.device).cuda_stream)
+    dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}[mask_features.dtype]
+    out = torch.empty((N, hl * wl, C), dtype=torch.bfloat16, device=mask_features.device)
+    stream = torch.cuda.current_stream(mask_features.device).cuda_stream
+    with torch.cuda.device(mask_features.device):
+        if _is_planes(mask_features) and not mask_features.is_contiguous():
+            # channel-last features (the pixel decoder's layout): no transpose needed
+            code = _lib.lib().mpf_pool_features_cl(mask_features.data_ptr(), mask_features.stride(0), dt, out.data_ptr(), N, C, h, w,
+                                                   hl, wl, stream)
+            _lib.check(code, "mpf_pool_features_cl")
+            return out
+        mf = mask_features if mask_features.is_contiguous() else mask_features.contiguous()
+        code = _lib.lib().mpf_pool_features(mf.data_ptr(), dt, out.data_ptr(), N, C, h, w, hl, wl, stream)
     _lib.check(code, "mpf_pool_features")
     return out
+
+
+def _is_planes(x):
+    """[N, C, H, W] whose images are dense [H*W, C] planes (channels_last), 16-byte aligned."""
+    return (x.dim() == 4 and x.stride(1) == 1 and x.stride(3) == x.shape[1] and x.stride(2) == x.shape[3] * x.shape[1]
+            and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
+
+
+class _MaskProductCL(torch.autograd.Function):
+    """einsum("bqc,bchw->bqhw") for channel-last features: the features enter the batched GEMM as its transposed operand
+    and their gradient leaves it as [N, H*W, C] planes again, so nothing between the last convolution of the pixel decoder
+    and the mask logits (forward or backward) changes layout."""
+
+    @staticmethod
+    def forward(ctx, me, mf):
+        N, C, H, W = mf.shape
+        ctx.save_for_backward(me, mf)
+        planes = mf.permute(0, 2, 3, 1).reshape(N, H * W, C)               # view
+        return torch.bmm(me, planes.transpose(1, 2)).view(N, me.shape[1], H, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        me, mf = ctx.saved_tensors
+        N, C, H, W = mf.shape
+        g = g.reshape(N, me.shape[1], H * W)
+        g_me = g_mf = None
+        if ctx.needs_input_grad[0]:
+            g_me = torch.bmm(g, mf.permute(0, 2, 3, 1).reshape(N, H * W, C))
+        if ctx.needs_input_grad[1]:
+            g_mf = torch.bmm(g.transpose(1, 2), me).view(N, H, W, C).permute(0, 3, 1, 2)
+        return g_me, g_mf
+
+
+def mask_product(me, mask_features):
+    """outputs_mask = einsum("bqc,bchw->bqhw", mask_embed, mask_features) (decoder :1869)."""
+    if _is_planes(mask_features) and not mask_features.is_contiguous() and me.dtype == mask_features.dtype and me.is_cuda:
+        amp = torch.is_autocast_enabled()
+        if not amp or me.dtype == torch.get_autocast_gpu_dtype():      # operands already in the dtype autocast would pick
+            with torch.autocast(device_type="cuda", enabled=False):
+                return _MaskProductCL.apply(me, mask_features)
+    return torch.einsum("bqc,bchw->bqhw", me, mask_features)
 
 
 _mask_flags = {}
@@ -465,7 +512,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         e = F.relu(F.linear(x, W["mask_embed.layers.0.weight"], W["mask_embed.layers.0.bias"]))
         e = F.relu(F.linear(e, W["mask_embed.layers.1.weight"], W["mask_embed.layers.1.bias"]))
         mask_embed = F.linear(e, W["mask_embed.layers.2.weight"], W["mask_embed.layers.2.bias"]).transpose(0, 1)
-        outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
+        outputs_mask = mask_product(mask_embed, mask_features)
         am = native_attn_mask(outputs_mask.detach(), attn_mask_target_size, mp_rows)
         return outputs_class, outputs_mask, am
 
@@ -487,7 +534,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             if pooled is not None:
                 # fused mask head (csrc/mask_head.hip): product with the features already resized to this level
                 return mask_head_bits(me, pooled, mp_rows)
-            m = torch.einsum("bqc,bchw->bqhw", me.transpose(0, 1), mask_features.detach())
+            m = mask_product(me.transpose(0, 1), mask_features.detach())
             return native_attn_mask(m, attn_mask_target_size, mp_rows)
 
     def _heads_batched(self, W, outputs, mask_features):
@@ -508,7 +555,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         e = F.relu(F.linear(x, W["mask_embed.layers.0.weight"], W["mask_embed.layers.0.bias"]))
         e = F.relu(F.linear(e, W["mask_embed.layers.1.weight"], W["mask_embed.layers.1.bias"]))
         me = F.linear(e, W["mask_embed.layers.2.weight"], W["mask_embed.layers.2.bias"]).transpose(0, 1)   # [N, L*Qt, C]
-        pm = torch.einsum("bqc,bchw->bqhw", me, mask_features)                               # [N, L*Qt, H, W]
+        pm = mask_product(me, mask_features)                                                 # [N, L*Qt, H, W]
         cls = cls.view(L, Qt, N, -1)
         return [cls[l].transpose(0, 1) for l in range(L)], [pm[:, l * Qt:(l + 1) * Qt] for l in range(L)]
 

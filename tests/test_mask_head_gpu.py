@@ -76,3 +76,42 @@ def test_all_masked_row_is_cleared_and_flags_reset():
     assert not got[0].any()
     assert got[1, 0, :7].all() and not got[1, 0, 7:].any()          # positive embedding, negative features
     assert (~got[1, 4, :7]).all() and got[1, 4, 7:].all()           # negative embedding
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("N,h,w,size", [(2, 64, 64, (32, 32)), (1, 40, 56, (10, 14)), (2, 24, 24, (24, 24))])
+def test_pool_features_channel_last_equals_nchw(dtype, N, h, w, size):
+    """The channel-last resize (mpf_pool_features_cl) evaluates the same expression as the NCHW one: bit-equal output."""
+    from mp_former_amd import _lib, transformer_decoder as TD
+    dev = torch.device("cuda:0")
+    torch.manual_seed(h + w)
+    mf = torch.randn(N, 256, h, w, device=dev).to(dtype)
+    a = TD.pool_features(mf, size)
+    assert _lib.last_kernel() == "pool_features_kernel"
+    b = TD.pool_features(mf.contiguous(memory_format=torch.channels_last) if N > 1 else
+                         mf.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2), size)
+    assert _lib.last_kernel() == "pool_features_cl_kernel"
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_mask_product_channel_last_matches_einsum(dtype):
+    """mask_product on channel-last features = einsum("bqc,bchw->bqhw"), values and both gradients; the feature
+    gradient comes back as channel-last planes."""
+    from mp_former_amd import transformer_decoder as TD
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    N, Q, C, H, W = 2, 77, 256, 24, 40
+    me = torch.randn(N, Q, C, device=dev).to(dtype).requires_grad_(True)
+    mf = torch.randn(N, H, W, C, device=dev).to(dtype).permute(0, 3, 1, 2).requires_grad_(True)
+    assert TD._is_planes(mf) and not mf.is_contiguous()
+    out = TD.mask_product(me, mf)
+    ref = torch.einsum("bqc,bchw->bqhw", me.double(), mf.double())
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    torch.testing.assert_close(out.double(), ref, rtol=tol, atol=tol * 16)
+    g = torch.randn_like(out)
+    g_me, g_mf = torch.autograd.grad(out, [me, mf], g)
+    r_me, r_mf = torch.autograd.grad(ref, [me, mf], g.double())
+    assert TD._is_planes(g_mf)
+    torch.testing.assert_close(g_me.double(), r_me.double(), rtol=tol, atol=tol * float(r_me.abs().max()))
+    torch.testing.assert_close(g_mf.double(), r_mf.double(), rtol=tol, atol=tol * float(r_mf.abs().max()))
