@@ -33,6 +33,10 @@ def _row_slice_of(t):
     root = t._base
     if root is None or t.dim() != 4 or not root.is_contiguous():
         return None
+    if t.requires_grad and not root.requires_grad:
+        # a base outside the graph (e.g. a view made inside a custom Function's forward): addressing the maps through
+        # it would silently drop their gradient
+        return None
     N, Q, h, w = t.shape
     s0, s1, s2, s3 = t.stride()
     if s3 != 1 or s2 != w or s1 != h * w or s0 % (h * w) != 0:

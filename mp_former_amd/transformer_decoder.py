@@ -194,13 +194,14 @@ class _MaskProductCL(torch.autograd.Function):
         N, C, H, W = mf.shape
         ctx.save_for_backward(me, mf)
         planes = mf.permute(0, 2, 3, 1).reshape(N, H * W, C)               # view
-        return torch.bmm(me, planes.transpose(1, 2)).view(N, me.shape[1], H, W)
+        # [N, Q, H*W]; the caller reshapes: a view made in here would hide this node from the views taken of it later
+        # (their ._base would be the raw GEMM result, which point_sample.MapSet follows to address the maps)
+        return torch.bmm(me, planes.transpose(1, 2))
 
     @staticmethod
     def backward(ctx, g):
         me, mf = ctx.saved_tensors
         N, C, H, W = mf.shape
-        g = g.reshape(N, me.shape[1], H * W)
         g_me = g_mf = None
         if ctx.needs_input_grad[0]:
             g_me = torch.bmm(g, mf.permute(0, 2, 3, 1).reshape(N, H * W, C))
@@ -215,7 +216,8 @@ def mask_product(me, mask_features):
         amp = torch.is_autocast_enabled()
         if not amp or me.dtype == torch.get_autocast_gpu_dtype():      # operands already in the dtype autocast would pick
             with torch.autocast(device_type="cuda", enabled=False):
-                return _MaskProductCL.apply(me, mask_features)
+                N, C, H, W = mask_features.shape
+                return _MaskProductCL.apply(me, mask_features).view(N, me.shape[1], H, W)
     return torch.einsum("bqc,bchw->bqhw", me, mask_features)
 
 

@@ -287,6 +287,10 @@ def test_head_full_size_configs_B_C(name, classes, n):
     assert len(l0) == 60 and all(np.isfinite(v) for v in l0.values()), l0
     bad = [k for k, p in h.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
     assert not bad, bad
+    # the stride-4 FPN branch only feeds mask_features: its gradients are those of the mask losses through the mask product
+    for k, p in h.named_parameters():
+        if any(s in k for s in ("adapter_1", "layer_1", "mask_features")):
+            assert float(p.grad.abs().sum()) > 0, f"{k}: zero gradient — the mask losses did not reach the pixel decoder"
     l1 = run(11)
     for k in l0:
         np.testing.assert_allclose(l1[k], l0[k], rtol=2e-3, atol=1e-4, err_msg=k)
