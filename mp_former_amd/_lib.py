@@ -129,6 +129,10 @@ def lib():
         if v != ABI_VERSION:
             raise NativeLibraryError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
         _lib = l
+        # MPF_OPTIONS="key=value,key=value": mpf_set_option at load (A/B runs of a kernel switch without code changes)
+        for kv in filter(None, os.environ.get("MPF_OPTIONS", "").split(",")):
+            k, _, v = kv.partition("=")
+            set_option(k.strip(), int(v))
     return _lib
 
 

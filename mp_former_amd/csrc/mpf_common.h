@@ -20,8 +20,9 @@ int set_binned_option(const char* key, int v);
 int set_gemm3_option(const char* key, int v);
 int set_block_option(const char* key, int v);
 // spatially blocked MSDA (msda_block.hip); return -1000 when the problem is outside their shapes
+// raw != NULL: loc / attn are outputs computed from the raw projection + reference points (msda_prep fused in)
 int msda_block_forward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, void* out, int N, int S, int M,
-                       int D, int L, int Lq, int P, int dtype, hipStream_t st);
+                       int D, int L, int Lq, int P, int dtype, hipStream_t st, const void* raw = nullptr, const void* ref = nullptr);
 size_t msda_block_workspace_bytes(const int64_t* host_shapes, int N, int M, int L, int Lq, int P);
 int msda_block_backward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, const void* go, void* gv,
                         void* gl, void* ga, void* graw, int N, int S, int M, int D, int L, int Lq, int P, int dtype, void* workspace,

@@ -735,6 +735,12 @@ static int forward_raw_impl(const void* value, const int64_t* spatial_shapes, co
     if (!tiled_ok(N, S, M, D, L, Lq, P, dtype, 1) || L * P > 32)
         return mpf::fail(MPF_E_DTYPE, "msda_forward_raw: fp32 with 32 channels per head and L*P <= 32 only");
     hipStream_t st = (hipStream_t)stream;
+    if (g_fwd_variant == 0 && host_spatial_shapes) {
+        // softmax / location arithmetic inside the blocked forward kernel (loc_out / attn_out written by it)
+        const int r = mpf::msda_block_forward(value, host_spatial_shapes, loc_out, attn_out, output, N, S, M, D, L, Lq, P, dtype, st, raw,
+                                              ref_points);
+        if (r != -1000) return r;
+    }
     const int groups = N * Lq * M, gpb = kThreads / (L * P);
     mpf::set_kernel("msda_prep_kernel");
     hipLaunchKernelGGL(msda_prep_kernel, dim3((groups + gpb - 1) / gpb), dim3(kThreads), 0, st, (const float*)raw,

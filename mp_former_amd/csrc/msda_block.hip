@@ -238,10 +238,26 @@ __device__ __forceinline__ int query_of(const GeomB& g, const BlockCtx& c, int q
 // --------------------------------------------------------------------------------------------------
 // forward
 // --------------------------------------------------------------------------------------------------
-template <int NL>
-__global__ __launch_bounds__(kT) void msda_fwd_block_kernel(const float* __restrict__ value, const float* __restrict__ loc,
-                                                            const float* __restrict__ attn, float* __restrict__ out, GeomB g,
-                                                            int nblocks, int region_cap, unsigned value_bytes)
+// RAW: the kernel also does the job of msda_prep_kernel (msda.hip) — loc / attn are OUTPUTS (the backward reads them)
+// computed from the 288-wide projection `raw` [N*Lq][M*LP*2 offsets | M*LP logits] and the reference points `ref`
+// [Lq][2]: attn = softmax over the L*P logits of a (query, head) (the thread holds its point's logit of every level;
+// the 4 points of a query are a DPP quad), loc = ref + offset / (W_l, H_l)   (ms_deform_attn.py:106-119)
+__device__ __forceinline__ float quad_max(float v)
+{
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)));
+}
+__device__ __forceinline__ float quad_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+}
+
+template <int NL, bool RAW>
+__global__ __launch_bounds__(kT) void msda_fwd_block_kernel(const float* __restrict__ value, const float* loc_,
+                                                            const float* attn_, float* __restrict__ out, GeomB g,
+                                                            int nblocks, int region_cap, unsigned value_bytes,
+                                                            const float* __restrict__ raw, const float* __restrict__ ref)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4* s_f = reinterpret_cast<float4*>(smem);
@@ -263,10 +279,41 @@ __global__ __launch_bounds__(kT) void msda_fwd_block_kernel(const float* __restr
     float at[NL];
     {
         const int64_t gi0 = ((int64_t)(c.b * g.Lq + max(q_d, 0)) * g.M + c.m) * LP + (tid & 3);
+        if (RAW) {
+            const float* r = raw + (int64_t)(c.b * g.Lq + max(q_d, 0)) * (g.M * LP * 3);
+            const float2 rp = reinterpret_cast<const float2*>(ref)[max(q_d, 0)];
+            float lg[NL];
+            float2 of[NL];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            xy[l] = reinterpret_cast<const float2*>(loc)[gi0 + l * kP];
-            at[l] = attn[gi0 + l * kP];
+            for (int l = 0; l < NL; ++l) {
+                of[l] = reinterpret_cast<const float2*>(r + c.m * LP * 2)[l * kP + (tid & 3)];
+                lg[l] = r[g.M * LP * 2 + c.m * LP + l * kP + (tid & 3)];
+            }
+            float mx = lg[0];
+#pragma unroll
+            for (int l = 1; l < NL; ++l) mx = fmaxf(mx, lg[l]);
+            mx = quad_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) { at[l] = expf(lg[l] - mx); sum += at[l]; }
+            sum = quad_sum(sum);
+            float* loc_w = const_cast<float*>(loc_);
+            float* attn_w = const_cast<float*>(attn_);
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                at[l] = at[l] / sum;
+                xy[l] = make_float2(rp.x + of[l].x / (float)g.W[l], rp.y + of[l].y / (float)g.H[l]);
+                if (q_d >= 0) {
+                    reinterpret_cast<float2*>(loc_w)[gi0 + l * kP] = xy[l];
+                    attn_w[gi0 + l * kP] = at[l];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                xy[l] = reinterpret_cast<const float2*>(loc_)[gi0 + l * kP];
+                at[l] = attn_[gi0 + l * kP];
+            }
         }
     }
     __syncthreads();
@@ -931,6 +978,7 @@ __global__ __launch_bounds__(kT) void msda_bwd_spill_kernel(const float* __restr
 int g_region_rows = 217;      // forward: usable rows of the staged box (the buffer is rounded up to whole 32-row stage passes)
 int g_push_rows = 216;        // push: rows of its box buffer (pitch 144 B): 9728 + 216 * 144 = 40832 B -> four workgroups per CU
 int g_block_disable = 0;
+int g_fuse_prep = 1;        // mpf_set_option("msda_fuse_prep"): softmax / location arithmetic inside the forward kernel
 unsigned long long* g_dbg = nullptr;   // benchmarking only: s_memtime phase stamps of the push kernel, [workgroup][16]
 int g_push_ablate = 0;       // benchmarking only: 1 = no tile entries, 2 = no reduction, 4 = no box staging
 
@@ -1017,13 +1065,19 @@ bool block_ok(int N, int S, int M, int D, int L, int Lq, int P, int dtype)
 int region_bytes() { return ((g_region_rows + 31) / 32) * 32 * 128; }     // whole stage passes of 32 rows
 
 template <int NL>
-hipError_t launch_fwd(const float* value, const float* loc, const float* attn, float* out, const GeomB& g, hipStream_t st)
+hipError_t launch_fwd(const float* value, const float* loc, const float* attn, float* out, const GeomB& g, hipStream_t st,
+                      const float* raw = nullptr, const float* ref = nullptr)
 {
     const int nblocks = g.N * g.M * g.blocks_per_b;
     const int grid = ((nblocks + 7) / 8) * 8;
     const size_t lds = kOffReg + region_bytes();
-    hipLaunchKernelGGL(msda_fwd_block_kernel<NL>, dim3(grid), dim3(kT), lds, st, value, loc, attn, out, g, nblocks, g_region_rows,
-                       (unsigned)((size_t)g.N * g.S * g.M * kD * 4));
+    const unsigned vb = (unsigned)((size_t)g.N * g.S * g.M * kD * 4);
+    if (raw)
+        hipLaunchKernelGGL((msda_fwd_block_kernel<NL, true>), dim3(grid), dim3(kT), lds, st, value, loc, attn, out, g, nblocks,
+                           g_region_rows, vb, raw, ref);
+    else
+        hipLaunchKernelGGL((msda_fwd_block_kernel<NL, false>), dim3(grid), dim3(kT), lds, st, value, loc, attn, out, g, nblocks,
+                           g_region_rows, vb, raw, ref);
     return hipGetLastError();
 }
 
@@ -1087,19 +1141,21 @@ namespace mpf {
 
 // forward through the blocked kernel; returns -1000 when the problem is outside its shapes (caller falls back)
 int msda_block_forward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, void* out, int N, int S, int M,
-                       int D, int L, int Lq, int P, int dtype, hipStream_t st)
+                       int D, int L, int Lq, int P, int dtype, hipStream_t st, const void* raw, const void* ref)
 {
     if (!host_shapes || !block_ok(N, S, M, D, L, Lq, P, dtype)) return -1000;
+    if (raw && (g_fuse_prep == 0 || (int64_t)N * Lq * M * L * P * 12 >= (1ll << 31))) return -1000;
     GeomB g;
     if (!build_geom(g, host_shapes, N, S, M, L, Lq)) return -1000;
     mpf::prof_begin(st);
-    mpf::set_kernel("msda_fwd_block_kernel");
+    mpf::set_kernel(raw ? "msda_fwd_block_kernel<raw>" : "msda_fwd_block_kernel");
     hipError_t err;
+    const float *rw = (const float*)raw, *rf = (const float*)ref;
     switch (L) {
-        case 1: err = launch_fwd<1>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st); break;
-        case 2: err = launch_fwd<2>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st); break;
-        case 3: err = launch_fwd<3>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st); break;
-        default: err = launch_fwd<4>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st); break;
+        case 1: err = launch_fwd<1>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st, rw, rf); break;
+        case 2: err = launch_fwd<2>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st, rw, rf); break;
+        case 3: err = launch_fwd<3>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st, rw, rf); break;
+        default: err = launch_fwd<4>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st, rw, rf); break;
     }
     mpf::prof_end("msda_fwd_block_kernel", st, 4.0 * ((double)N * S * M * D + (double)N * Lq * M * L * P * 3 + (double)N * Lq * M * D));
     return mpf::check(err, "msda_fwd_block_kernel");
@@ -1147,6 +1203,7 @@ int set_block_option(const char* key, int v)
         return 0;
     }
     if (!strcmp(key, "msda_block_disable")) { g_block_disable = v; return 0; }
+    if (!strcmp(key, "msda_fuse_prep")) { g_fuse_prep = v; return 0; }
     if (!strcmp(key, "msda_push_ablate2")) { g_push_ablate = v; return 0; }
     return 1;
 }

@@ -287,8 +287,9 @@ def test_module_matches_oracle_module_math(dev, oracle_msda):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fuse_prep", [1, 0])
 @pytest.mark.parametrize("shapes,N", [(((6, 4), (3, 2), (12, 8)), 2), (((16, 16), (8, 8), (32, 32)), 1)])
-def test_raw_forms_match_softmax_plus_op(shapes, N):
+def test_raw_forms_match_softmax_plus_op(shapes, N, fuse_prep):
     """mpf_msda_forward_raw / mpf_msda_backward_ws_raw (softmax over the logits, loc = ref + offset /
     (W_l, H_l) and their backward folded into the kernels; ops/modules/ms_deform_attn.py:103-117)
     against torch softmax / division around the plain op."""
@@ -305,8 +306,12 @@ def test_raw_forms_match_softmax_plus_op(shapes, N):
     raw[:, :M * L * P * 2] *= 3.0                      # offsets of a few pixels, some out of range
     ref = torch.rand(S, 2, device=dev)
     go = torch.randn(N, S, M * D, device=dev)
-    out, loc, attn = msda.ms_deform_attn_forward_raw(value, ss, lsi, raw, ref, ss._mpf_host)
-    assert "block" in _lib.last_kernel(), _lib.last_kernel()
+    _lib.set_option("msda_fuse_prep", fuse_prep)       # 1: softmax / locations inside the blocked forward kernel
+    try:
+        out, loc, attn = msda.ms_deform_attn_forward_raw(value, ss, lsi, raw, ref, ss._mpf_host)
+    finally:
+        _lib.set_option("msda_fuse_prep", 1)
+    assert _lib.last_kernel() == ("msda_fwd_block_kernel<raw>" if fuse_prep else "msda_fwd_block_kernel"), _lib.last_kernel()
     # reference composition
     r = raw.detach().clone().requires_grad_(True)
     v = value.detach().clone().requires_grad_(True)
