@@ -307,7 +307,10 @@ def main():
                          "also": [
                              {"kernel": "msda_fwd_block_kernel", "launches": n_f, "avg_us": round(ms_f * 1e3 / max(n_f, 1), 1),
                               "bound": "hbm", "achieved": round(by_f / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0, 1), "unit": "GB/s",
-                              "frac": round(by_f / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms_f > 0 else 0.0, 4)},
+                              "frac": round(by_f / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms_f > 0 else 0.0, 4),
+                              "algorithmic_bytes_per_launch": round(by_f / max(n_f, 1)),
+                              "note": "raw form: SURVEY 8(d)'s 800*e*S*N plus the 288*e*Lq*N bytes of sampling locations / "
+                                      "attention weights the launch writes for the backward (the msda_prep pass fused in)"},
                              # masked cross- / self-attention on bf16 MFMA tiles: the north-star asks for the MFMA rate
                              # against the gfx950 peak AND the K / V / mask stream rate (the kernels are bound by the
                              # latter at ~120 queries: 4 MFMAs per 32 keys)

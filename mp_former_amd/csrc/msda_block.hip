@@ -1157,7 +1157,10 @@ int msda_block_forward(const void* value, const int64_t* host_shapes, const void
         case 3: err = launch_fwd<3>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st, rw, rf); break;
         default: err = launch_fwd<4>((const float*)value, (const float*)loc, (const float*)attn, (float*)out, g, st, rw, rf); break;
     }
-    mpf::prof_end("msda_fwd_block_kernel", st, 4.0 * ((double)N * S * M * D + (double)N * Lq * M * L * P * 3 + (double)N * Lq * M * D));
+    // value + loc/attn (read) + out; the raw form also WRITES loc / attn for the backward (the traffic of
+    // the msda_prep launch it replaces)
+    mpf::prof_end("msda_fwd_block_kernel", st,
+                  4.0 * ((double)N * S * M * D + (double)N * Lq * M * L * P * 3 * (raw ? 2 : 1) + (double)N * Lq * M * D));
     return mpf::check(err, "msda_fwd_block_kernel");
 }
 
