@@ -631,7 +631,7 @@ int mpf_group_stats(const float* x, int rows, int64_t row_len, float eps, float*
  * GroupNorm of the pixel decoder on channel-last planes (the layout the fp32 convolutions produce), forward and
  * backward (replaces nn.GroupNorm(32, conv_dim) of msdeformattn.py:245-281 and, optionally, what follows it).
  * A plane is x[n] = [HW][C] floats at x + n * x_bs (dense pixel rows; the batch stride is free, in elements).
- * Needs C % 4 == 0, (C/G) % 4 == 0, 256 % (C/4) == 0 (mpf_gn_cl_supported).
+ * Needs C % 32 == 0, C/G a power of two in 4..32, 256 % (C/4) == 0 (mpf_gn_cl_supported).
  *   forward:  mean / rstd [N*G] (saved for the backward) and y = (x - mean) * rstd * gamma + beta, then
  *             relu != 0: y = max(y, 0)                 (detectron2 Conv2d(norm=GN, activation=relu), msdeformattn.py:268)
  *             top != NULL: y += bilinear 2x upsampling (align_corners=False) of top[n] = [HW/4][C] at

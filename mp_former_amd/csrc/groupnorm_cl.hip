@@ -240,45 +240,47 @@ __global__ __launch_bounds__(kT) void gn_cl_bwd_stats_kernel(const BwdArgs A, co
     }
 }
 
-// one workgroup per image, 1024 threads = channels x chunk slices: chunk sums (fp64) -> group sums -> the coefficients
-// of dx = A*gy + B*x + D and this image's share of the parameter gradients (dgb[n][2][C]; summed over the images by the
-// first workgroup of the apply pass)
+// workgroup = (image, 32 channels), 1024 threads = 32 channels x 32 chunk slices: chunk sums (fp64) -> group sums -> the
+// coefficients of dx = A*gy + B*x + D and this image's share of the parameter gradients (dgb[n][2][C]; summed over the
+// images by the first workgroup of the apply pass)
+constexpr int kRedCh = 32;
 __global__ __launch_bounds__(1024) void gn_cl_bwd_reduce_kernel(const BwdArgs A, const Plane P, float* __restrict__ dgb)
 {
     __shared__ double s_1[1024], s_2[1024];
-    const int n = blockIdx.x;
-    const int slices = 1024 / P.C;                 // C in {64, 128, 256, 512, 1024}
-    const int c = threadIdx.x % P.C, sl = threadIdx.x / P.C;
+    const int n = blockIdx.y;
+    const int cl = threadIdx.x % kRedCh, sl = threadIdx.x / kRedCh;
+    const int c = blockIdx.x * kRedCh + cl;
     const int cpg = P.C / P.G, g = c / cpg;
     double sgy = 0.0, sgx = 0.0;
-    for (int ch = sl; ch < P.chunks; ch += slices) {
+    for (int ch = sl; ch < P.chunks; ch += 1024 / kRedCh) {
         const float* o = A.part + ((int64_t)n * P.chunks + ch) * 2 * P.C;
         sgy += (double)o[c];
         sgx += (double)o[P.C + c];
     }
     s_1[threadIdx.x] = sgy; s_2[threadIdx.x] = sgx;
     __syncthreads();
-    if (sl == 0)
-        for (int k = 1; k < slices; ++k) { sgy += s_1[k * P.C + c]; sgx += s_2[k * P.C + c]; }
-    __syncthreads();
+    // tree over the 32 slices (stride = kRedCh threads)
+    for (int h = 512; h >= kRedCh; h >>= 1) {
+        if (threadIdx.x < h) { s_1[threadIdx.x] += s_1[threadIdx.x + h]; s_2[threadIdx.x] += s_2[threadIdx.x + h]; }
+        __syncthreads();
+    }
+    if (sl != 0) return;
+    sgy = s_1[cl]; sgx = s_2[cl];
     const float gm = A.gamma[c];
     const double mu = A.mean[n * P.G + g], rs = A.rstd[n * P.G + g];
     const double t2 = (sgx - mu * sgy) * rs;       // sum gy * xhat
-    if (sl == 0) { s_1[c] = (double)gm * sgy; s_2[c] = (double)gm * t2; }
-    __syncthreads();
-    if (sl == 0) {
-        const double m = (double)cpg * (double)P.HW;
-        double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < cpg; ++k) { s1 += s_1[g * cpg + k]; s2 += s_2[g * cpg + k]; }
-        // dx = rs * (gm*gy - s1/m - xhat * s2/m),  xhat = (x - mu) * rs
-        const double Bc = -rs * rs * s2 / m;
-        float* o = A.coef + (int64_t)n * 3 * P.C;
-        o[c] = (float)(rs * (double)gm);
-        o[P.C + c] = (float)Bc;
-        o[2 * P.C + c] = (float)(-rs * s1 / m - Bc * mu);
-        dgb[((int64_t)n * 2) * P.C + c] = (float)t2;
-        dgb[((int64_t)n * 2 + 1) * P.C + c] = (float)sgy;
-    }
+    // group sums: the cpg channels of a group are adjacent lanes of this half-wave (cpg divides 32)
+    double s1 = (double)gm * sgy, s2 = (double)gm * t2;
+    for (int o = 1; o < cpg; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    const double m = (double)cpg * (double)P.HW;
+    // dx = rs * (gm*gy - s1/m - xhat * s2/m),  xhat = (x - mu) * rs
+    const double Bc = -rs * rs * s2 / m;
+    float* o = A.coef + (int64_t)n * 3 * P.C;
+    o[c] = (float)(rs * (double)gm);
+    o[P.C + c] = (float)Bc;
+    o[2 * P.C + c] = (float)(-rs * s1 / m - Bc * mu);
+    dgb[((int64_t)n * 2) * P.C + c] = (float)t2;
+    dgb[((int64_t)n * 2 + 1) * P.C + c] = (float)sgy;
 }
 
 template <bool RELU>
@@ -374,7 +376,7 @@ bool make_plane(int HW, int C, int G, Plane& P)
 {
     if (HW <= 0 || C <= 0 || G <= 0 || C % G != 0 || C % 4 != 0 || C > 1024) return false;
     const int cpg = C / G, tpc = C / 4;
-    if (cpg % 4 != 0 || kT % tpc != 0 || G > kT || 1024 % C != 0) return false;
+    if (cpg % 4 != 0 || kT % tpc != 0 || G > kT || C % 32 != 0 || cpg > 32 || (cpg & (cpg - 1)) != 0) return false;
     P.HW = HW; P.C = C; P.G = G; P.tpc = tpc; P.pr = kT / tpc;
     P.chunks = (HW + kStatPix - 1) / kStatPix;
     return true;
@@ -407,7 +409,7 @@ extern "C" int mpf_gn_cl_forward(const float* x, int64_t x_bs, const float* gamm
     if (!x || !gamma || !beta || !y || !mean || !rstd || !workspace) return mpf::fail(MPF_E_NULL, "gn_cl_forward: NULL buffer");
     Plane P;
     if (N <= 0 || !make_plane(HW, C, G, P))
-        return mpf::fail(MPF_E_SHAPE, "gn_cl_forward: needs C % 4 == 0, (C/G) % 4 == 0, 256 % (C/4) == 0");
+        return mpf::fail(MPF_E_SHAPE, "gn_cl_forward: needs C % 32 == 0, C/G a power of two in 4..32, 256 % (C/4) == 0");
     if (x_bs % 4 != 0 || y_bs % 4 != 0 || top_bs % 4 != 0) return mpf::fail(MPF_E_SHAPE, "gn_cl_forward: batch strides must be multiples of 4");
     if (top && (W <= 0 || W % 2 != 0 || HW % W != 0 || (HW / W) % 2 != 0))
         return mpf::fail(MPF_E_SHAPE, "gn_cl_forward: the fused top-down sum needs an exact 2x upsampling (even H and W)");
@@ -438,7 +440,7 @@ extern "C" int mpf_gn_cl_backward(const float* gy, int64_t gy_bs, const float* x
     if (!gy || !x || !gamma || !beta || !mean || !rstd || !dx || !workspace) return mpf::fail(MPF_E_NULL, "gn_cl_backward: NULL buffer");
     Plane P;
     if (N <= 0 || !make_plane(HW, C, G, P))
-        return mpf::fail(MPF_E_SHAPE, "gn_cl_backward: needs C % 4 == 0, (C/G) % 4 == 0, 256 % (C/4) == 0");
+        return mpf::fail(MPF_E_SHAPE, "gn_cl_backward: needs C % 32 == 0, C/G a power of two in 4..32, 256 % (C/4) == 0");
     if (x_bs % 4 != 0 || gy_bs % 4 != 0 || dx_bs % 4 != 0) return mpf::fail(MPF_E_SHAPE, "gn_cl_backward: batch strides must be multiples of 4");
     if (workspace_bytes < bwd_ws(N, P)) return mpf::fail(MPF_E_SHAPE, "gn_cl_backward: workspace too small");
     float* part = (float*)workspace;
@@ -449,7 +451,7 @@ extern "C" int mpf_gn_cl_backward(const float* gy, int64_t gy_bs, const float* x
     else hipLaunchKernelGGL(gn_cl_bwd_stats_kernel<false>, dim3(P.chunks, N), dim3(kT), 0, st, A, P);
     mpf::prof_end("gn_cl_bwd_stats_kernel", st, 8.0 * (double)N * HW * C);
     float* dgb = A.coef + (size_t)N * 3 * C;
-    hipLaunchKernelGGL(gn_cl_bwd_reduce_kernel, dim3(N), dim3(1024), 0, st, A, P, dgb);
+    hipLaunchKernelGGL(gn_cl_bwd_reduce_kernel, dim3(C / kRedCh, N), dim3(1024), 0, st, A, P, dgb);
     const dim3 grid((HW + kApplyPix - 1) / kApplyPix, N);
     mpf::prof_begin(st);
     mpf::set_kernel("gn_cl_bwd_apply_kernel");
