@@ -48,9 +48,11 @@ struct G3 {
     float* c;
     int64_t lda, ldc, ldcin, ldcin2, ldgate, plane;
     int M, N, K, a2_rows, relu, tiles_n, ntiles;
+    int tm0, ntiles2, tiles_n2;      // mixed launch: row blocks >= tm0 are cut into ntiles2 tiles of 64 columns (tiles_n2 per row block)
 };
 
 int g_ablate = 0;      // mpf_set_option("gemm3_ablate"): reserved for timing experiments
+int g_mixed = 1;       // mpf_set_option("gemm3_mixed_tiles"): 128 x 64 tiles for the last partial round
 
 #ifdef G3_TIMING
 // phase timing (build with -DG3_TIMING; tools/bench_gemm3.py --phases): s_memtime deltas of wave 0 of every
@@ -271,23 +273,15 @@ __device__ __forceinline__ void g3_epilogue(const G3& p, const Acc<NJ, false>& a
     });
 }
 
+// one output tile: 128 rows x BN columns starting at (m0, n0)
 template <int BN, bool A2>
-__global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
+__device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, const int m0, const int n0)
 {
     constexpr int NJ = BN / 32;                  // 16-column MFMA tiles per wave
     constexpr int kBKc = BN * 16;                // bytes per (plane, k-chunk) of the B image
     constexpr int kAbytes = 12 * kAKc;
     constexpr int kBunits = 3 * BN * 4;          // 16-B units of a B stage
     constexpr int kBiter = (kBunits + kThreads - 1) / kThreads;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kAbytes + 12 * kBKc];
-
-    // XCD-aware tile order: each XCD walks a contiguous run of tiles (column tiles of one row block
-    // are neighbours, so the A rows they share stay in that XCD's L2)
-    const int per_xcd = (p.ntiles + 7) >> 3;
-    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (tile >= p.ntiles) return;
-    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * kBM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -319,8 +313,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
     // one step of distance the staging and the MFMAs serialise), in two alternating register sets;
     // B (L2-resident planes) one step ahead.
     float4 raE[4], raO[4], ra2[4];
-    uint4 rb0, rb1, rb2, rb3, rb4 = make_uint4(0, 0, 0, 0), rb5 = make_uint4(0, 0, 0, 0);
-    static_assert(kBiter >= 4 && kBiter <= 6, "B staging assumes 4..6 units per thread");
+    uint4 rb0, rb1, rb2, rb3 = make_uint4(0, 0, 0, 0), rb4 = make_uint4(0, 0, 0, 0), rb5 = make_uint4(0, 0, 0, 0);
+    static_assert(kBiter >= 3 && kBiter <= 6 && (kBiter > 3 || kBunits == 3 * kThreads), "B staging assumes 3..6 units per thread");
 #define G3_LOAD_A(ra, k0)                                                                    \
     {                                                                                        \
         ra[0] = *reinterpret_cast<const float4*>(ap0 + (k0));                                \
@@ -339,7 +333,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
         rb0 = *reinterpret_cast<const uint4*>(bsrc[0] + (k0));                               \
         rb1 = *reinterpret_cast<const uint4*>(bsrc[1] + (k0));                               \
         rb2 = *reinterpret_cast<const uint4*>(bsrc[2] + (k0));                               \
-        rb3 = *reinterpret_cast<const uint4*>(bsrc[3] + (k0));                               \
+        if constexpr (kBiter > 3) rb3 = *reinterpret_cast<const uint4*>(bsrc[3] + (k0));     \
         if constexpr (kBiter > 4) rb4 = *reinterpret_cast<const uint4*>(bsrc[4] + (k0));     \
         if constexpr (kBiter > 5) rb5 = *reinterpret_cast<const uint4*>(bsrc[5] + (k0));     \
     }
@@ -360,7 +354,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
         *reinterpret_cast<uint4*>(lds + bdst[0]) = rb0;                                      \
         *reinterpret_cast<uint4*>(lds + bdst[1]) = rb1;                                      \
         *reinterpret_cast<uint4*>(lds + bdst[2]) = rb2;                                      \
-        *reinterpret_cast<uint4*>(lds + bdst[3]) = rb3;                                      \
+        if constexpr (kBiter > 3) *reinterpret_cast<uint4*>(lds + bdst[3]) = rb3;            \
         if constexpr (kBiter > 4)                                                            \
             if (kBunits >= 5 * kThreads || tid + 4 * kThreads < kBunits) *reinterpret_cast<uint4*>(lds + bdst[4]) = rb4; \
         if constexpr (kBiter > 5)                                                            \
@@ -424,6 +418,47 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
 #endif
 
     g3_epilogue<NJ>(p, acc, lane, m0 + wr * 64, n0 + wc * (BN / 2));
+}
+#undef G3_LOAD_A
+#undef G3_LOAD_B
+#undef G3_WRITE
+
+template <int BN, bool A2>
+__global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 12 * BN * 16];
+    // XCD-aware tile order: each XCD walks a contiguous run of tiles (column tiles of one row block
+    // are neighbours, so the A rows they share stay in that XCD's L2)
+    const int per_xcd = (p.ntiles + 7) >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (tile >= p.ntiles) return;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    g3_tn_tile<BN, A2>(p, lds, tm * kBM, tn * BN);
+}
+
+// Mixed launch against the tail effect: 128 x 128 tiles for as many row blocks as fill WHOLE rounds of the chip's
+// 2 x 256 workgroup slots, the remaining row blocks as 128 x 64 tiles (twice as many, half as long).  M = 43 008,
+// N = 256: 672 tiles = 1.31 rounds ran as 2; here 512 tiles + 320 half tiles = 1 + 0.5.  The half tiles come last in
+// block order, so they start as the full tiles drain.
+template <bool A2>
+__global__ __launch_bounds__(kThreads, 2) void gemm3_tn_mixed_kernel(G3 p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 12 * 128 * 16];
+    const int g1 = ((p.ntiles + 7) >> 3) << 3;          // blocks of the first region (multiple of 8)
+    if ((int)blockIdx.x < g1) {
+        const int per_xcd = g1 >> 3;
+        const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+        if (tile >= p.ntiles) return;
+        const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+        g3_tn_tile<128, A2>(p, lds, tm * kBM, tn * 128);
+    } else {
+        const int b = (int)blockIdx.x - g1;
+        const int per_xcd = (p.ntiles2 + 7) >> 3;
+        const int tile = (b & 7) * per_xcd + (b >> 3);
+        if (tile >= p.ntiles2) return;
+        const int tm = tile / p.tiles_n2, tn = tile - tm * p.tiles_n2;
+        g3_tn_tile<64, A2>(p, lds, (p.tm0 + tm) * kBM, tn * 64);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -684,6 +719,7 @@ __global__ __launch_bounds__(256) void gemm3_split_grouped_kernel(const MpfSplit
 
 int mpf::set_gemm3_option(const char* key, int v)
 {
+    if (!strcmp(key, "gemm3_mixed_tiles")) { g_mixed = v; return 0; }
     if (strcmp(key, "gemm3_ablate") != 0) return 1;
     g_ablate = v;
     return 0;
@@ -735,6 +771,34 @@ extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2
     const bool use96 = waste96 < waste128;
     p.tiles_n = use96 ? (N + 95) / 96 : (N + 127) / 128;
     p.ntiles = tiles_m * p.tiles_n;
+    p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
+    // tail effect: when the last round of 128 x 128 tiles would fill at most half of the chip's workgroup slots, its row
+    // blocks are cut into 128 x 64 tiles instead (gemm3_tn_mixed_kernel)
+    if (!use96 && N % 64 == 0 && g_mixed) {
+        static int slots = 0;
+        if (!slots) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+                slots = 2 * cus;
+            else
+                slots = 512;
+        }
+        const int rounds = p.ntiles / slots, rem = p.ntiles - rounds * slots;
+        if (rounds >= 1 && rem > 0 && 2 * rem <= slots && slots % p.tiles_n == 0) {
+            const int main_blocks = rounds * (slots / p.tiles_n);
+            p.tm0 = main_blocks;
+            p.tiles_n2 = N / 64;
+            p.ntiles2 = (tiles_m - main_blocks) * p.tiles_n2;
+            p.ntiles = main_blocks * p.tiles_n;
+            const int grid_mixed = ((p.ntiles + 7) / 8) * 8 + ((p.ntiles2 + 7) / 8) * 8;
+            mpf::prof_begin(st);
+            mpf::set_kernel("gemm3_tn_kernel<128+64>");
+            if (a2) hipLaunchKernelGGL(gemm3_tn_mixed_kernel<true>, dim3(grid_mixed), dim3(kThreads), 0, st, p);
+            else hipLaunchKernelGGL(gemm3_tn_mixed_kernel<false>, dim3(grid_mixed), dim3(kThreads), 0, st, p);
+            mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + 6.0 * (double)N * K, 2.0 * M * (double)N * K);
+            return mpf::check(hipGetLastError(), "mpf_gemm3_tn");
+        }
+    }
     const int grid = ((p.ntiles + 7) / 8) * 8;
     mpf::prof_begin(st);
     if (use96) {

@@ -1,0 +1,106 @@
+"""Split-bf16 fp32 GEMM (csrc/gemm3.hip) against fp64: the claim of DESIGN.md section 4 — three bf16 planes per
+operand, six products, error NOT above the library's fp32 GEMM — as a test, on ragged shapes with every epilogue,
+on the mixed 128/64-column tiling, and for the weight-gradient (NT) form."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_tn(a, a2, w, b, cin, cin2, relu, gate):
+    x = a.double()
+    if a2 is not None:
+        x = x + a2.double()[torch.arange(a.shape[0], device=a.device) % a2.shape[0]]
+    y = x @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    if cin is not None:
+        y = y + cin.double()
+    if cin2 is not None:
+        y = y + cin2.double()
+    if relu:
+        y = y.relu()
+    if gate is not None:
+        y = torch.where(gate > 0, y, torch.zeros_like(y))
+    return y
+
+
+@pytest.mark.parametrize("M,N,K,opts", [
+    (300, 288, 64, "bias a2 cin relu"), (129, 100, 32, "bias cin cin2"), (128, 256, 256, "bias"),
+    (1000, 1024, 256, "bias relu"), (777, 256, 1024, "cin gate"), (5, 4, 32, ""),
+])
+def test_gemm3_tn_fp32_accuracy(M, N, K, opts):
+    from mp_former_amd.gemm3 import gemm3, split_weight
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev) if "bias" in opts else None
+    a2 = torch.randn(7, K, device=dev) if "a2" in opts else None
+    cin = torch.randn(M, N, device=dev) if "cin" in opts else None
+    cin2 = torch.randn(M, N, device=dev) if "cin2" in opts else None
+    gate = torch.randn(M, N, device=dev) if "gate" in opts else None
+    relu = "relu" in opts
+    ref = _ref_tn(a, a2, w, b, cin, cin2, relu, gate)
+    got = gemm3(a, split_weight(w), b, a2=a2, cin=cin, cin2=cin2, gate=gate, relu=relu)
+    # the library's fp32 path on the same problem
+    x32 = a if a2 is None else a + a2[torch.arange(M, device=dev) % 7]
+    lib = x32 @ w.t()
+    for t in (b, cin, cin2):
+        if t is not None:
+            lib = lib + t
+    if relu:
+        lib = lib.relu()
+    if gate is not None:
+        lib = torch.where(gate > 0, lib, torch.zeros_like(lib))
+    e3 = (got.double() - ref).abs()
+    el = (lib.double() - ref).abs()
+    scale = float(ref.abs().max()) + 1.0
+    assert float(e3.max()) <= 4e-6 * scale, (float(e3.max()), scale)                      # fp32-accurate outright ...
+    assert float(e3.mean()) <= 1.25 * float(el.mean()) + 1e-9, (float(e3.mean()), float(el.mean()))   # ... and not worse than the library
+
+
+@pytest.mark.parametrize("N,K", [(256, 64), (1024, 32), (256, 1024)])
+def test_gemm3_tn_mixed_tiles_bit_equal(N, K):
+    """The 128 x 64 tiles of the last partial round (gemm3_tn_mixed_kernel) accumulate every output element in the same
+    order as the 128 x 128 tiles: identical bits."""
+    from mp_former_amd import _lib
+    from mp_former_amd.gemm3 import gemm3, split_weight
+    dev = torch.device("cuda:0")
+    torch.manual_seed(N + K)
+    slots = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+    tiles_n = N // 128
+    M = 128 * (slots // tiles_n + max(1, slots // (4 * tiles_n))) - 37        # one full round + a quarter round, ragged last block
+    a = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev)
+    b = torch.randn(N, device=dev)
+    cin = torch.randn(M, N, device=dev)
+    planes = split_weight(w)
+    got = gemm3(a, planes, b, cin=cin, relu=True)
+    assert _lib.last_kernel() == "gemm3_tn_kernel<128+64>", _lib.last_kernel()
+    _lib.set_option("gemm3_mixed_tiles", 0)
+    try:
+        want = gemm3(a, planes, b, cin=cin, relu=True)
+        assert _lib.last_kernel() == "gemm3_tn_kernel<128>"
+    finally:
+        _lib.set_option("gemm3_mixed_tiles", 1)
+    assert torch.equal(got, want)
+    ref = (a.double() @ w.double().t() + b.double() + cin.double()).relu()
+    assert float((got.double() - ref).abs().max()) <= 4e-6 * (float(ref.abs().max()) + 1.0) * max(1.0, (K / 256) ** 0.5)
+
+
+@pytest.mark.parametrize("R,M,N,rps", [(4096, 256, 256, 512), (3000, 256, 1024, 512), (2048, 288, 256, 256), (1000, 100, 36, 128)])
+def test_gemm3_nt_weight_gradient_accuracy(R, M, N, rps):
+    from mp_former_amd.gemm3 import gemm3_nt, nt_reduce
+    dev = torch.device("cuda:0")
+    torch.manual_seed(R + M + N)
+    g = torch.randn(R, M, device=dev)
+    x = torch.randn(R, N, device=dev)
+    c, ca, _ = gemm3_nt(g, x, rps, want_csum_a=True)
+    dw, db = nt_reduce(c, ca)
+    ref = g.double().t() @ x.double()
+    lib = g.t() @ x
+    e3, el = (dw.double() - ref).abs(), (lib.double() - ref).abs()
+    assert float(e3.max()) <= 1e-5 * (float(ref.abs().max()) + 1.0)
+    assert float(e3.mean()) <= 1.25 * float(el.mean()) + 1e-9, (float(e3.mean()), float(el.mean()))
+    torch.testing.assert_close(db.double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
