@@ -18,6 +18,7 @@ inactive; ``MPF_FUSED_ENCODER=0`` selects the layer-by-layer modules (same resul
 tests/test_encoder_fused_gpu.py).
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -51,8 +52,28 @@ def rows_per_split(sizes):
     return 512, False
 
 
+_slots = {}
+
+
+def _balanced_rps(R, M, N, device, base=512):
+    """Rows per split of a weight-gradient GEMM such that its (tile, split) workgroups fill WHOLE rounds of the chip's
+    2 x CU workgroup slots: with 512-row splits a 256 x 256 gradient at R = 43 008 is 336 workgroups (0.66 of a round)
+    and a 256 x 1024 one 1 344 (2.6 rounds, run as 3).  Same tiles, same products — only the split boundaries move."""
+    slots = _slots.get(device)
+    if slots is None:
+        slots = 2 * torch.cuda.get_device_properties(device).multi_processor_count
+        _slots[device] = slots
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    rounds = max(1, -(-tiles * max(1, R // base) // slots))          # rounds the 512-row splits would take
+    ns = max(1, rounds * slots // tiles)
+    rps = max(128, ((-(-R // ns)) + 31) // 32 * 32)
+    return rps
+
+
 def _wgrad(g2, x2, rps):
     """dW[out, in] = g2^T . x2 and the bias gradient colsum(g2), both from the split-K NT GEMM."""
+    if os.environ.get("MPF_WGRAD_BALANCE", "1") == "1":
+        rps = _balanced_rps(g2.shape[0], g2.shape[1], x2.shape[1], g2.device)
     c, ca, _ = gemm3_nt(g2, x2, rps, want_csum_a=True)
     return nt_reduce(c, ca)
 
