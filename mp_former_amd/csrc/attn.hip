@@ -455,23 +455,59 @@ __global__ __launch_bounds__(256) void attn_transpose2_kernel(const __hip_bfloat
                                                                __hip_bfloat16* __restrict__ aT, __hip_bfloat16* __restrict__ bT,
                                                                int L, int LP, int NE)
 {
-    // tile of 64 sequence positions x 64 columns through LDS
-    __shared__ __hip_bfloat16 ta[64][66], tb[64][66];
+    // tile of 64 sequence positions x 64 columns through LDS: 16-byte global loads (8 columns of a row) and stores (8
+    // positions of a column); the transpose itself is 2-byte LDS writes into [column][position] rows of 72 elements
+    // (144 B: the 16-byte reads of consecutive columns start 36 banks apart)
+    __shared__ __attribute__((aligned(16))) unsigned short ta[64][72], tb[64][72];
     const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const bool vec = (NE % 8 == 0) && (LP % 8 == 0) &&
+                     (((uintptr_t)a | (uintptr_t)b | (uintptr_t)aT | (uintptr_t)bT) & 15) == 0;
+    if (vec) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int u = threadIdx.x + it * 256;                 // 512 pieces: (row r, 8-column group cg)
+            const int r = u >> 3, cg = u & 7;
+            const int l = l0 + r, c = c0 + cg * 8;
+            uint4 va = make_uint4(0u, 0u, 0u, 0u), vb = va;
+            if (l < L && c < NE) {
+                va = *reinterpret_cast<const uint4*>(a + (int64_t)l * NE + c);
+                vb = *reinterpret_cast<const uint4*>(b + (int64_t)l * NE + c);
+            }
+            const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ta[cg * 8 + 2 * k][r] = (unsigned short)(wa[k] & 0xffffu);
+                ta[cg * 8 + 2 * k + 1][r] = (unsigned short)(wa[k] >> 16);
+                tb[cg * 8 + 2 * k][r] = (unsigned short)(wb[k] & 0xffffu);
+                tb[cg * 8 + 2 * k + 1][r] = (unsigned short)(wb[k] >> 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int u = threadIdx.x + it * 256;                 // (column cc, 8-position group lg)
+            const int cc = u >> 3, lg = u & 7;
+            const int c = c0 + cc, l = l0 + lg * 8;
+            if (c < NE && l < LP) {
+                *reinterpret_cast<uint4*>(aT + (int64_t)c * LP + l) = *reinterpret_cast<const uint4*>(&ta[cc][lg * 8]);
+                *reinterpret_cast<uint4*>(bT + (int64_t)c * LP + l) = *reinterpret_cast<const uint4*>(&tb[cc][lg * 8]);
+            }
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 4 rows per pass
-    const __hip_bfloat16 zero = __float2bfloat16(0.f);
     for (int r = ty; r < 64; r += 4) {
         const int l = l0 + r, c = c0 + tx;
         const bool ok = l < L && c < NE;
-        ta[r][tx] = ok ? a[(int64_t)l * NE + c] : zero;
-        tb[r][tx] = ok ? b[(int64_t)l * NE + c] : zero;
+        ta[tx][r] = ok ? reinterpret_cast<const unsigned short*>(a)[(int64_t)l * NE + c] : (unsigned short)0;
+        tb[tx][r] = ok ? reinterpret_cast<const unsigned short*>(b)[(int64_t)l * NE + c] : (unsigned short)0;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
         const int c = c0 + r, l = l0 + tx;
         if (c < NE && l < LP) {
-            aT[(int64_t)c * LP + l] = ta[tx][r];
-            bT[(int64_t)c * LP + l] = tb[tx][r];
+            reinterpret_cast<unsigned short*>(aT)[(int64_t)c * LP + l] = ta[r][tx];
+            reinterpret_cast<unsigned short*>(bT)[(int64_t)c * LP + l] = tb[r][tx];
         }
     }
 }
