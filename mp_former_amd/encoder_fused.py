@@ -55,16 +55,19 @@ def rows_per_split(sizes):
 _slots = {}
 
 
-def _balanced_rps(R, M, N, device, base=512):
-    """Rows per split of a weight-gradient GEMM such that its (tile, split) workgroups fill WHOLE rounds of the chip's
-    2 x CU workgroup slots: with 512-row splits a 256 x 256 gradient at R = 43 008 is 336 workgroups (0.66 of a round)
-    and a 256 x 1024 one 1 344 (2.6 rounds, run as 3).  Same tiles, same products — only the split boundaries move."""
+def _balanced_rps(R, M, N, device, base=1 << 30):
+    """Rows per split of a weight-gradient GEMM such that its (tile, split) workgroups fill ONE whole round of the chip's
+    2 x CU workgroup slots (more rounds only if the output alone has more tiles than slots): with round 1's 512-row
+    splits a 256 x 256 gradient at R = 43 008 was 336 workgroups (0.66 of a round) and a 256 x 1024 one 1 344 (2.6
+    rounds, run as 3) with 84 partial results to sum; now 492 / 512 workgroups and 123 / 32 partials.  Same tiles, same
+    products — only the split boundaries move (``MPF_WGRAD_BASE=512`` restores the old choice)."""
     slots = _slots.get(device)
     if slots is None:
         slots = 2 * torch.cuda.get_device_properties(device).multi_processor_count
         _slots[device] = slots
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    rounds = max(1, -(-tiles * max(1, R // base) // slots))          # rounds the 512-row splits would take
+    base = int(os.environ.get("MPF_WGRAD_BASE", base))
+    rounds = max(1, -(-tiles * max(1, R // base) // slots))          # rounds that `base`-row splits would take
     ns = max(1, rounds * slots // tiles)
     rps = max(128, ((-(-R // ns)) + 31) // 32 * 32)
     return rps
