@@ -25,8 +25,18 @@ def _build(cfg, pp, dp, dev):
     return h.to(dev).train()
 
 
+def _planes_leaf(v, dev):
+    """the same values as channels_last planes [N][H*W][C] (what the bf16 backbone hands over), as a leaf"""
+    N, C, H, W = v.shape
+    return v.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2).requires_grad_(True)
+
+
+@pytest.mark.parametrize("layout", ["nchw", "channels_last"])
 @pytest.mark.parametrize("name", HEAD_FIXTURES)
-def test_head_matches_reference_golden_fp32(name):
+def test_head_matches_reference_golden_fp32(name, layout):
+    """layout = channels_last feeds the features as [N][H*W][C] planes: the convolutions then return planes and the
+    pixel decoder takes the channel-last GroupNorm / fused FPN-sum kernels and the channel-last mask product — the
+    route bench.py runs; nchw is the reference's layout (round-1 kernels for the norms)."""
     from mp_former_amd import _lib, _rng
     dev = torch.device("cuda:0")
     z, cfg, pp, dp, feats, targets, replay = load_head_fixture(name)
@@ -37,12 +47,18 @@ def test_head_matches_reference_golden_fp32(name):
     use_dn = "dn_pred_logits" in z
     _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
     try:
-        feats = {k: v.to(dev).requires_grad_(True) for k, v in feats.items()}
+        if layout == "channels_last":
+            feats = {k: _planes_leaf(v, dev) for k, v in feats.items()}
+        else:
+            feats = {k: v.to(dev).requires_grad_(True) for k, v in feats.items()}
         targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
         _lib.profile_enable(True)
         mf, _, ms = h.pixel_decoder.forward_features(feats)
         # the native kernels are what ran (deformable attention + the encoder's split-bf16 GEMMs)
         assert _lib.profile_get("msda_fwd_block")[0] >= 1 and _lib.profile_get("gemm3_tn")[0] >= 1, _lib.last_kernel()
+        if layout == "channels_last":
+            assert _lib.profile_get("gn_cl_apply")[0] >= 5, "the channel-last GroupNorm kernels did not run"
+            assert mf.stride(1) == 1, "mask_features left the channel-last layout"
         _lib.profile_enable(False)
         np.testing.assert_allclose(_sub(mf, 5), z["mask_features_s5"], rtol=2e-3, atol=5e-4)
         for i, t in enumerate(ms):
@@ -198,7 +214,7 @@ def test_head_amp_path_matches_reference_golden(name):
     dev = torch.device("cuda:0")
     z, cfg, pp, dp, feats, targets, replay = load_head_fixture(name)
     h = _build(cfg, pp, dp, dev)
-    feats = {k: v.to(dev).requires_grad_(True) for k, v in feats.items()}
+    feats = {k: _planes_leaf(v, dev) for k, v in feats.items()}      # channel-last planes, as the bf16 backbone delivers them
     targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
     use_dn = "dn_pred_logits" in z
     _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
@@ -211,7 +227,7 @@ def test_head_amp_path_matches_reference_golden(name):
         total.backward()
         torch.cuda.synchronize()
         for kern in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "small_gemm", "lsa_kernel", "msda_fwd_block",
-                     "msda_bwd_pull_mfma", "gemm3"):
+                     "msda_bwd_pull_mfma", "gemm3", "gn_cl_apply", "gn_cl_bwd_apply"):
             assert _lib.profile_get(kern)[0] > 0, f"{kern} did not run on the AMP path"
     finally:
         _lib.profile_enable(False)
