@@ -43,21 +43,39 @@ __device__ __forceinline__ bf16x8 ld8_rows(const __hip_bfloat16* base, int row, 
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     return row < limit ? v : z;
 }
-// 4 consecutive elements of a row starting at i (zero past `limit`); aligned: i and limit multiples of 4
-__device__ __forceinline__ bf16x4 ld4_clamped(const __hip_bfloat16* row, int i, int limit, bool aligned)
+// 4 consecutive elements of a row starting at i (zero past `limit`); AL: i and limit multiples of 4.  AL is a
+// COMPILE-TIME switch: as a run-time flag it put every one of these loads behind a branch, i.e. exactly the serialised
+// round trips the comment above is about (9 per 32-key step in the forward kernel).
+template <bool AL>
+__device__ __forceinline__ bf16x4 ld4_clamped(const __hip_bfloat16* row, int i, int limit)
 {
     const bf16x4 z = {0, 0, 0, 0};
-    if (aligned) {
+    if constexpr (AL) {
         const bf16x4 v = *reinterpret_cast<const bf16x4*>(row + max(min(i, limit - 4), 0));
         return i < limit ? v : z;
-    }
-    bf16x4 r;
+    } else {
+        bf16x4 r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const __bf16 e = *reinterpret_cast<const __bf16*>(row + min(i + j, limit - 1));
-        r[j] = i + j < limit ? e : (__bf16)0.f;
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 e = *reinterpret_cast<const __bf16*>(row + min(i + j, limit - 1));
+            r[j] = i + j < limit ? e : (__bf16)0.f;
+        }
+        return r;
     }
-    return r;
+}
+
+// the 4 mask bytes of keys key0 .. key0 + 3 of one query row as a word (nonzero byte = masked), clamped reads
+template <bool AL>
+__device__ __forceinline__ uint32_t ld_mask4(const uint8_t* mrow, int key0, int limit)
+{
+    if constexpr (AL) {
+        return *reinterpret_cast<const uint32_t*>(mrow + max(min(key0, limit - 4), 0));
+    } else {
+        uint32_t mw = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mw |= (mrow[min(key0 + r, limit - 1)] ? 0xFFu : 0u) << (8 * r);
+        return mw;
+    }
 }
 
 constexpr int kHD = 32;          // head dim
@@ -89,7 +107,7 @@ struct AttnParams {
 };
 
 // QS = number of 16-row query sub-tiles per wave
-template <int QS>
+template <int QS, bool AL, bool MK>
 __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p)
 {
     const int lane = threadIdx.x, c16 = lane & 15, g = lane >> 4;
@@ -103,8 +121,6 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p)
     const __hip_bfloat16* qb = p.q + (int64_t)n * p.E + h * kHD;
     const __hip_bfloat16* kb = p.k + (int64_t)n * p.E + h * kHD;
     const __hip_bfloat16* vb = p.vt + ((int64_t)n * p.E + h * kHD) * p.Lk;
-    const bool mask_aligned = (p.Lk & 3) == 0;
-
     bf16x8 bq[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
@@ -118,42 +134,46 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p)
         m[s] = kNegInf; l[s] = 0.f;
     }
 
-    for (int kk = kb0; kk < kb1; kk += 32) {
-        // ---- S^T tiles: keys kk+16t .. +15 ----------------------------------------------------------
-        bf16x8 ak[2];
+    // Operands of one 32-key step, ALL requested before the first MFMA (clamped addresses, no branches)
+    struct Step {
+        bf16x8 ak[2], av[2];
+        uint32_t mw[QS][2];
+    };
+    auto load_step = [&](Step& st, const int kk) {
+        // S^T tiles: keys kk+16t .. +15
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            ak[t] = ld8_rows(kb, kk + 16 * t + c16, kb1, rowE, 8 * g);
-        }
+        for (int t = 0; t < 2; ++t) st.ak[t] = ld8_rows(kb, kk + 16 * t + c16, kb1, rowE, 8 * g);
         // V^T fragments: rows d = 16*dt + c16, keys {kk+4g..+3} and {kk+16+4g..+3}
-        bf16x8 av[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             const __hip_bfloat16* vr = vb + (int64_t)(16 * dt + c16) * p.Lk;
             // (Lk % 4 == 0: 8-byte aligned, whole quads in range or not)
-            const bf16x4 lo = ld4_clamped(vr, kk + 4 * g, kb1, mask_aligned), hi = ld4_clamped(vr, kk + 16 + 4 * g, kb1, mask_aligned);
-            av[dt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const bf16x4 lo = ld4_clamped<AL>(vr, kk + 4 * g, kb1), hi = ld4_clamped<AL>(vr, kk + 16 + 4 * g, kb1);
+            st.av[dt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
+        for (int s = 0; s < QS; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                st.mw[s][t] = 0;
+                if constexpr (MK) {
+                    const int qi = q0 + 16 * s + c16;
+                    const uint8_t* mrow = p.mask + (int64_t)n * p.mask_stride_n + (int64_t)min(qi, p.Lq - 1) * p.Lk;
+                    st.mw[s][t] = ld_mask4<AL>(mrow, kk + 16 * t + 4 * g, kb1);
+                }
+            }
+    };
+    auto compute_step = [&](const Step& st, const int kk) {
+#pragma unroll
         for (int s = 0; s < QS; ++s) {
-            const int qi = q0 + 16 * s + c16;
             float sc[8];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 acc = {0, 0, 0, 0};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[t], bq[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.ak[t], bq[s], acc, 0, 0, 0);
                 // lane (query c16, group g) holds keys kk + 16t + 4g + r
                 const int key0 = kk + 16 * t + 4 * g;
-                uint32_t mw = 0;
-                if (p.mask) {            // (uniform) mask bytes of keys key0..key0+3 for query qi, clamped reads
-                    const uint8_t* mrow = p.mask + (int64_t)n * p.mask_stride_n + (int64_t)min(qi, p.Lq - 1) * p.Lk;
-                    if (mask_aligned) {
-                        mw = *reinterpret_cast<const uint32_t*>(mrow + max(min(key0, kb1 - 4), 0));
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) mw |= (mrow[min(key0 + r, kb1 - 1)] ? 0xFFu : 0u) << (8 * r);
-                    }
-                }
+                const uint32_t mw = st.mw[s][t];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool dead = (key0 + r >= kb1) || ((mw >> (8 * r)) & 0xFFu);
@@ -179,9 +199,17 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 o[s][dt] *= alpha;
-                o[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[dt], bp, o[s][dt], 0, 0, 0);
+                o[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.av[dt], bp, o[s][dt], 0, 0, 0);
             }
         }
+    };
+    // (requesting step i + 1 before the MFMAs of step i — two alternating Step sets — was measured: no gain, the four
+    // resident waves per SIMD already cover the round trip; the step is bound by its ~300 VALU instructions of softmax
+    // bookkeeping against 8 MFMAs)
+    Step st;
+    for (int kk = kb0; kk < kb1; kk += 32) {
+        load_step(st, kk);
+        compute_step(st, kk);
     }
     // ---- write the partial result of this split -------------------------------------------------------
 #pragma unroll
@@ -253,12 +281,14 @@ __device__ __forceinline__ bf16x8 load8(const __hip_bfloat16* p) { return *reint
 __device__ __forceinline__ bf16x8 zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
 
 // two 8-byte pieces (4 + 4 consecutive elements) of a row -> one MFMA fragment
-__device__ __forceinline__ bf16x8 load4x2(const __hip_bfloat16* row, int i0, int i1, int limit, bool aligned)
+template <bool AL>
+__device__ __forceinline__ bf16x8 load4x2(const __hip_bfloat16* row, int i0, int i1, int limit)
 {
-    const bf16x4 lo = ld4_clamped(row, i0, limit, aligned), hi = ld4_clamped(row, i1, limit, aligned);
+    const bf16x4 lo = ld4_clamped<AL>(row, i0, limit), hi = ld4_clamped<AL>(row, i1, limit);
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+template <bool MK>
 __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
 {
     const int lane = threadIdx.x, c16 = lane & 15, g = lane >> 4;
@@ -300,6 +330,28 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
                 ls[qt][r] = qi < p.Lq ? lv : 0.f;
                 de[qt][r] = qi < p.Lq ? dv_ : 0.f;
             }
+        // everything this step reads is requested before its first MFMA: the mask bytes (keys on the lane axis: one
+        // byte per (query row, key)) and the transposed Q / dO fragments of the dV / dK products
+        uint8_t mb[2][2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mb[kt][qt][r] = 0;
+                    if constexpr (MK) {
+                        const int qi = qq + 16 * qt + 4 * g + r, key = kb + 16 * kt + c16;
+                        mb[kt][qt][r] = p.mask[(int64_t)n * p.mask_stride_n + (int64_t)min(qi, p.Lq - 1) * p.Lk + min(key, p.Lk - 1)];
+                    }
+                }
+        bf16x8 adoT[2], aqT[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int64_t ro = (int64_t)(16 * dt + c16) * p.LqP;
+            adoT[dt] = load4x2<true>(doTb + ro, qq + 4 * g, qq + 16 + 4 * g, p.LqP);
+            aqT[dt] = load4x2<true>(qTb + ro, qq + 4 * g, qq + 16 + 4 * g, p.LqP);
+        }
         bf16x8 bp[2], bds[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -312,9 +364,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qi = qq + 16 * qt + 4 * g + r;
-                    bool dead = (qi >= p.Lq) || (key >= p.Lk) || (ls[qt][r] == kNegInf);
-                    if (p.mask)          // (uniform branch; the byte is read on clamped indices, unconditionally)
-                        dead = dead || p.mask[(int64_t)n * p.mask_stride_n + (int64_t)min(qi, p.Lq - 1) * p.Lk + min(key, p.Lk - 1)] != 0;
+                    const bool dead = (qi >= p.Lq) || (key >= p.Lk) || (ls[qt][r] == kNegInf) || (mb[kt][qt][r] != 0);
                     const float pr = dead ? 0.f : __expf(sacc[r] * p.scale - ls[qt][r]);
                     const float ds = pr * (dpacc[r] - de[qt][r]) * p.scale;
                     bp[kt][4 * qt + r] = (__bf16)pr;
@@ -324,13 +374,10 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            const int64_t ro = (int64_t)(16 * dt + c16) * p.LqP;
-            const bf16x8 adoT = load4x2(doTb + ro, qq + 4 * g, qq + 16 + 4 * g, p.LqP, true);
-            const bf16x8 aqT = load4x2(qTb + ro, qq + 4 * g, qq + 16 + 4 * g, p.LqP, true);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                dvt[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adoT, bp[kt], dvt[kt][dt], 0, 0, 0);
-                dkt[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqT, bds[kt], dkt[kt][dt], 0, 0, 0);
+                dvt[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adoT[dt], bp[kt], dvt[kt][dt], 0, 0, 0);
+                dkt[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqT[dt], bds[kt], dkt[kt][dt], 0, 0, 0);
             }
         }
     }
@@ -350,7 +397,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
     }
 }
 
-template <int QS>
+template <int QS, bool AL, bool MK>
 __global__ __launch_bounds__(64) void attn_bwd_q_kernel(AttnBwdParams p)
 {
     const int lane = threadIdx.x, c16 = lane & 15, g = lane >> 4;
@@ -363,7 +410,6 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(AttnBwdParams p)
     const int64_t rowE = (int64_t)p.N * p.E;
     const int64_t hoff = (int64_t)n * p.E + h * kHD;
     const __hip_bfloat16* kTb = p.kT + ((int64_t)n * p.E + h * kHD) * p.Lk;
-    const bool aligned = (p.Lk & 3) == 0;
     bf16x8 bq[QS], bdo[QS];
     float ls[QS], de[QS];
     f32x4 dq[QS][2];
@@ -376,37 +422,44 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(AttnBwdParams p)
         de[s] = qi < p.Lq ? p.delta[((int64_t)n * p.H + h) * p.Lq + qi] : 0.f;
         dq[s][0] = f32x4{0, 0, 0, 0}; dq[s][1] = f32x4{0, 0, 0, 0};
     }
-    for (int kk = kb0; kk < kb1; kk += 32) {
+    // operands of one 32-key step, all requested before the first MFMA (as in the forward)
+    struct Step {
         bf16x8 ak[2], av[2], akT[2];
+        uint32_t mw[QS][2];
+    };
+    auto load_step = [&](Step& st, const int kk) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = kk + 16 * t + c16;
-            ak[t] = ld8_rows(p.k + hoff, key, kb1, rowE, 8 * g);
-            av[t] = ld8_rows(p.v + hoff, key, kb1, rowE, 8 * g);
+            st.ak[t] = ld8_rows(p.k + hoff, key, kb1, rowE, 8 * g);
+            st.av[t] = ld8_rows(p.v + hoff, key, kb1, rowE, 8 * g);
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-            akT[dt] = load4x2(kTb + (int64_t)(16 * dt + c16) * p.Lk, kk + 4 * g, kk + 16 + 4 * g, kb1, aligned);
+            st.akT[dt] = load4x2<AL>(kTb + (int64_t)(16 * dt + c16) * p.Lk, kk + 4 * g, kk + 16 + 4 * g, kb1);
+#pragma unroll
+        for (int s = 0; s < QS; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                st.mw[s][t] = 0;
+                if constexpr (MK) {
+                    const int qi = q0 + 16 * s + c16;
+                    const uint8_t* mrow = p.mask + (int64_t)n * p.mask_stride_n + (int64_t)min(qi, p.Lq - 1) * p.Lk;
+                    st.mw[s][t] = ld_mask4<AL>(mrow, kk + 16 * t + 4 * g, kb1);
+                }
+            }
+    };
+    auto compute_step = [&](const Step& st, const int kk) {
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
-            const int qi = q0 + 16 * s + c16;
             bf16x8 bds;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 z = {0, 0, 0, 0};
-                const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[t], bq[s], z, 0, 0, 0);
-                const f32x4 dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[t], bdo[s], z, 0, 0, 0);
+                const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.ak[t], bq[s], z, 0, 0, 0);
+                const f32x4 dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.av[t], bdo[s], z, 0, 0, 0);
                 const int key0 = kk + 16 * t + 4 * g;
-                uint32_t mw = 0;
-                if (p.mask) {
-                    const uint8_t* mrow = p.mask + (int64_t)n * p.mask_stride_n + (int64_t)min(qi, p.Lq - 1) * p.Lk;
-                    if (aligned) {
-                        mw = *reinterpret_cast<const uint32_t*>(mrow + max(min(key0, kb1 - 4), 0));
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) mw |= (mrow[min(key0 + r, kb1 - 1)] ? 0xFFu : 0u) << (8 * r);
-                    }
-                }
+                const uint32_t mw = st.mw[s][t];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool dead = (key0 + r >= kb1) || ((mw >> (8 * r)) & 0xFFu) || (ls[s] == kNegInf);
@@ -416,8 +469,16 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(AttnBwdParams p)
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                dq[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(akT[dt], bds, dq[s][dt], 0, 0, 0);
+                dq[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.akT[dt], bds, dq[s][dt], 0, 0, 0);
         }
+    };
+    // (requesting step i + 1 before the MFMAs of step i — two alternating Step sets — was measured: no gain, the four
+    // resident waves per SIMD already cover the round trip; the step is bound by its ~300 VALU instructions of softmax
+    // bookkeeping against 8 MFMAs)
+    Step st;
+    for (int kk = kb0; kk < kb1; kk += 32) {
+        load_step(st, kk);
+        compute_step(st, kk);
     }
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
@@ -574,7 +635,14 @@ extern "C" int mpf_attn_forward(const void* q, const void* k, const void* vt, co
     const int qtiles = (Lq + 16 * QS - 1) / (16 * QS);
     mpf::prof_begin(st);
     mpf::set_kernel("attn_fwd_kernel<2>");
-    hipLaunchKernelGGL(attn_fwd_kernel<QS>, dim3(qtiles * p.splits, H, N), dim3(64), 0, st, p);
+    {
+        const dim3 grid(qtiles * p.splits, H, N);
+        const bool al = (Lk & 3) == 0 && ((uintptr_t)p.vt & 7) == 0 && (!mask || ((uintptr_t)mask & 3) == 0);
+        if (al && mask) hipLaunchKernelGGL((attn_fwd_kernel<QS, true, true>), grid, dim3(64), 0, st, p);
+        else if (al) hipLaunchKernelGGL((attn_fwd_kernel<QS, true, false>), grid, dim3(64), 0, st, p);
+        else if (mask) hipLaunchKernelGGL((attn_fwd_kernel<QS, false, true>), grid, dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<QS, false, false>), grid, dim3(64), 0, st, p);
+    }
     mpf::prof_end("attn_fwd_kernel<2>", st, 2.0 * ((double)Lk * N * p.E * 2 + (double)Lq * N * p.E) + (mask ? (double)N * Lq * Lk : 0.0),
                   4.0 * Lq * (double)Lk * p.E * N);      // QK^T + PV
     const int total = N * H * Lq * kHD;
@@ -609,13 +677,21 @@ extern "C" int mpf_attn_backward(const void* q, const void* k, const void* v, co
     const double bytes = 2.0 * (4.0 * Lk * N * p.E + 4.0 * Lq * N * p.E) + (mask ? 2.0 * N * Lq * Lk : 0.0);
     mpf::prof_begin(st);
     mpf::set_kernel("attn_bwd_kv_kernel");
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((Lk + 31) / 32, H, N), dim3(64), 0, st, p);
+    if (mask) hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, dim3((Lk + 31) / 32, H, N), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(attn_bwd_kv_kernel<false>, dim3((Lk + 31) / 32, H, N), dim3(64), 0, st, p);
     mpf::prof_end("attn_bwd_kv_kernel", st, bytes * 0.5, 8.0 * Lq * (double)Lk * p.E * N);   // S, dP, dV, dK
     constexpr int QS = 2;
     const int qtiles = (Lq + 16 * QS - 1) / (16 * QS);
     mpf::prof_begin(st);
     mpf::set_kernel("attn_bwd_q_kernel<2>");
-    hipLaunchKernelGGL(attn_bwd_q_kernel<QS>, dim3(qtiles * p.splits, H, N), dim3(64), 0, st, p);
+    {
+        const dim3 grid(qtiles * p.splits, H, N);
+        const bool al = (Lk & 3) == 0 && ((uintptr_t)p.kT & 7) == 0 && (!mask || ((uintptr_t)mask & 3) == 0);
+        if (al && mask) hipLaunchKernelGGL((attn_bwd_q_kernel<QS, true, true>), grid, dim3(64), 0, st, p);
+        else if (al) hipLaunchKernelGGL((attn_bwd_q_kernel<QS, true, false>), grid, dim3(64), 0, st, p);
+        else if (mask) hipLaunchKernelGGL((attn_bwd_q_kernel<QS, false, true>), grid, dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((attn_bwd_q_kernel<QS, false, false>), grid, dim3(64), 0, st, p);
+    }
     mpf::prof_end("attn_bwd_q_kernel<2>", st, bytes * 0.5, 6.0 * Lq * (double)Lk * p.E * N);  // S, dP, dQ
     const int total = N * H * Lq * kHD;
     hipLaunchKernelGGL(attn_sum_splits_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p.part_dq,
