@@ -48,6 +48,7 @@ struct G3 {
     float* c;
     int64_t lda, ldc, ldcin, ldcin2, ldgate, plane;
     int M, N, K, a2_rows, relu, tiles_n, ntiles;
+    int bias_cm, cin_cm, cin2_cm, gate_cm;   // 1, or 0 when the operand is absent (it then points at g3_const)
     int tm0, ntiles2, tiles_n2;      // mixed launch: row blocks >= tm0 are cut into ntiles2 tiles of 64 columns (tiles_n2 per row block)
 };
 
@@ -246,31 +247,51 @@ struct Acc<4, true> {
 };
 
 // epilogue of the TN kernels: bias / addends / ReLU / gate, 16-byte stores (m_wave, n_wave: first row / column of the wave tile)
+// Every operand of the epilogue is read UNCONDITIONALLY: an absent one points at a 16-byte block of zeros (addends, bias)
+// or ones (gate) with leading dimension and column multiplier 0, and rows / columns past the edge are clamped (only the
+// store is predicated).  With `if (p.cin) load` per quad hipcc branched around each load and waited for it on its own:
+// up to 64 dependent memory round trips per wave in the epilogue of a kernel whose main loop takes 8.  Loads of one
+// 16-column group (bias + 4 row tiles x 3 operands) are requested together.
+__device__ float g3_const[8] = {0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, 1.f};
+
 template <int NJ>
 __device__ __forceinline__ void g3_epilogue(const G3& p, const Acc<NJ, false>& acc, int lane, int m_wave, int n_wave)
 {
-    acc.quads(lane, [&](int mo, int no, float4 o) {
-        const int m = m_wave + mo, n = n_wave + no;
-        if (m >= p.M || n >= p.N) return;
-        if (p.bias) {
-            const float4 bz = *reinterpret_cast<const float4*>(p.bias + n);
+    const int r16 = lane & 15, g = lane >> 4;
+    int64_t mrow[4];
+    bool mok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m_wave + i * 16 + r16;
+        mok[i] = m < p.M;
+        mrow[i] = min(m, p.M - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n_wave + j * 16 + g * 4;
+        const bool nok = n < p.N;                    // N % 4 == 0: a quad is inside or outside as a whole
+        const int nc = min(n, p.N - 4);
+        const float4 bz = *reinterpret_cast<const float4*>(p.bias + nc * p.bias_cm);
+        float4 ci[4], c2[4], gt[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ci[i] = *reinterpret_cast<const float4*>(p.cin + mrow[i] * p.ldcin + nc * p.cin_cm);
+            c2[i] = *reinterpret_cast<const float4*>(p.cin2 + mrow[i] * p.ldcin2 + nc * p.cin2_cm);
+            gt[i] = *reinterpret_cast<const float4*>(p.gate + mrow[i] * p.ldgate + nc * p.gate_cm);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 o = make_float4(acc.v[i][j][0], acc.v[i][j][1], acc.v[i][j][2], acc.v[i][j][3]);
+            // same order of additions as before: bias, addend 1, addend 2
             o = make_float4(o.x + bz.x, o.y + bz.y, o.z + bz.z, o.w + bz.w);
+            o = make_float4(o.x + ci[i].x, o.y + ci[i].y, o.z + ci[i].z, o.w + ci[i].w);
+            o = make_float4(o.x + c2[i].x, o.y + c2[i].y, o.z + c2[i].z, o.w + c2[i].w);
+            if (p.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+            // ReLU backward: pass the gradient where the saved activation is > 0
+            o = make_float4(gt[i].x > 0.f ? o.x : 0.f, gt[i].y > 0.f ? o.y : 0.f, gt[i].z > 0.f ? o.z : 0.f, gt[i].w > 0.f ? o.w : 0.f);
+            if (mok[i] && nok) *reinterpret_cast<float4*>(p.c + mrow[i] * p.ldc + n) = o;
         }
-        if (p.cin) {
-            const float4 ci = *reinterpret_cast<const float4*>(p.cin + (int64_t)m * p.ldcin + n);
-            o = make_float4(o.x + ci.x, o.y + ci.y, o.z + ci.z, o.w + ci.w);
-        }
-        if (p.cin2) {
-            const float4 ci = *reinterpret_cast<const float4*>(p.cin2 + (int64_t)m * p.ldcin2 + n);
-            o = make_float4(o.x + ci.x, o.y + ci.y, o.z + ci.z, o.w + ci.w);
-        }
-        if (p.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-        if (p.gate) {               // ReLU backward: pass the gradient where the saved activation is > 0
-            const float4 gt = *reinterpret_cast<const float4*>(p.gate + (int64_t)m * p.ldgate + n);
-            o = make_float4(gt.x > 0.f ? o.x : 0.f, gt.y > 0.f ? o.y : 0.f, gt.z > 0.f ? o.z : 0.f, gt.w > 0.f ? o.w : 0.f);
-        }
-        *reinterpret_cast<float4*>(p.c + (int64_t)m * p.ldc + n) = o;
-    });
+    }
 }
 
 // one output tile: 128 rows x BN columns starting at (m0, n0)
@@ -765,6 +786,19 @@ extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2
     p.cin2 = c_in2; p.gate = gate; p.ldcin2 = ldcin2; p.ldgate = ldgate;
     p.lda = lda; p.ldc = ldc; p.ldcin = ldcin; p.plane = (int64_t)N * K;
     p.M = M; p.N = N; p.K = K; p.a2_rows = a2_rows; p.relu = relu;
+    {
+        static const float* consts = nullptr;
+        if (!consts) {
+            void* sym = nullptr;
+            if (hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g3_const)); e != hipSuccess) return mpf::check(e, "gemm3_tn: constants");
+            consts = (const float*)sym;
+        }
+        p.bias_cm = bias ? 1 : 0; p.cin_cm = c_in ? 1 : 0; p.cin2_cm = c_in2 ? 1 : 0; p.gate_cm = gate ? 1 : 0;
+        if (!bias) p.bias = consts;
+        if (!c_in) { p.cin = consts; p.ldcin = 0; }
+        if (!c_in2) { p.cin2 = consts; p.ldcin2 = 0; }
+        if (!gate) { p.gate = consts + 4; p.ldgate = 0; }
+    }
     const int tiles_m = (M + kBM - 1) / kBM;
     // 96-wide column tiles when they waste fewer columns (e.g. N = 288 = 3 x 96)
     const int waste128 = ((N + 127) / 128) * 128 - N, waste96 = ((N + 95) / 96) * 96 - N;
