@@ -500,6 +500,19 @@ int mpf_grouped_scale_cast(const MpfScaleCastItem* items_device, int n_items, in
                            void* stream);
 
 /*
+ * 3x3 convolution (stride 1, zero padding 1, no groups / dilation) of channel-last fp32 images on the split-bf16 GEMM:
+ * the FPN output convolution of the pixel decoder (msdeformattn.py:272-281 / :351), forward and input gradient.
+ *   x [n_img][H][W][Cin] -> y [n_img][H][W][Cout] (+ bias[Cout]); one GEMM with K = 9*Cin whose A rows are read at the
+ *   tap's (dy, dx) shift, taps off the image contributing zeros.
+ *   w_planes = mpf_gemm3_split of the [Cout][9*Cin] matrix W2[co][(ky*3+kx)*Cin + ci] = W[co][ci][ky][kx].
+ *   transposed != 0: the input gradient dx = conv_transpose(dy, W): call with x := dy (Cin := Cout of the forward),
+ *   w_planes = split of W2t[ci][(ky*3+kx)*Cout + co] = W[co][ci][ky][kx]; the taps are then walked with the opposite sign.
+ * Cin % 32 == 0, Cout % 4 == 0.
+ */
+int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const float* bias, float* y, int n_img, int H, int W, int Cin,
+                      int Cout, int transposed, void* stream);
+
+/*
  * mpf_gemm3_split for a LIST of weight matrices in one launch (all Linear weights of the encoder, both
  * orientations, once per step).  Item i: src fp32 [rows, cols] contiguous -> three bf16 planes at dst,
  * dst + plane_stride, dst + 2 * plane_stride (elements), written as [rows][dst_ld] (transpose = 0) or

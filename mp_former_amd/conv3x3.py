@@ -1,0 +1,74 @@
+"""The 3x3 / stride 1 / padding 1 fp32 convolution of the FPN output stage (msdeformattn.py:272-281) on the split-bf16
+GEMM: forward and input gradient are ONE GEMM each with K = 9 * Cin over channel-last planes (``mpf_gemm3_conv3x3``:
+the A rows of a K step are read at the tap's (dy, dx) shift, taps off the image contribute zeros); the weight
+gradient stays MIOpen's (``aten.convolution_backward``), which is already at the rate the NT kernel would reach.
+``MPF_CONV3X3_GEMM3=0`` keeps the library convolution."""
+import os
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .gemm3 import split_weights_grouped
+from .groupnorm import is_cl_plane
+
+
+def enabled():
+    return os.environ.get("MPF_CONV3X3_GEMM3", "1") == "1"
+
+
+def supported(x, weight):
+    """fp32 channel-last planes that are dense across the batch, 3x3 kernel, channel counts the GEMM takes."""
+    if not (enabled() and is_cl_plane(x) and weight.dtype == torch.float32 and weight.dim() == 4):
+        return False
+    N, C, H, W = x.shape
+    Cout, Cin, kh, kw = weight.shape
+    return (kh == 3 and kw == 3 and Cin == C and C % 32 == 0 and Cout % 32 == 0 and x.stride(0) == H * W * C
+            and N * H * W * max(C, Cout) < 2 ** 31 and H >= 2 and W >= 2)
+
+
+def _planes(N, C, H, W, device):
+    return torch.empty((N, H, W, C), dtype=torch.float32, device=device).permute(0, 3, 1, 2)
+
+
+class _Conv3x3Fn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        # W2[co][(ky*3+kx)*Cin + ci] for the forward, W2t[ci][(ky*3+kx)*Cout + co] for the input gradient: one split launch
+        w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+        w2t = weight.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout)
+        pf, pb = split_weights_grouped([([w2.contiguous()], False), ([w2t.contiguous()], False)])
+        y = _planes(N, Cout, H, W, x.device)
+        with torch.cuda.device(x.device):
+            code = _lib.lib().mpf_gemm3_conv3x3(x.data_ptr(), pf.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                                N, H, W, Cin, Cout, 0, torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(code, "mpf_gemm3_conv3x3")
+        ctx.save_for_backward(x, weight, pb)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, pb = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        if not (is_cl_plane(gy) and gy.stride(0) == H * W * Cout):
+            gy = gy.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _planes(N, Cin, H, W, x.device)
+            with torch.cuda.device(x.device):
+                code = _lib.lib().mpf_gemm3_conv3x3(gy.data_ptr(), pb.data_ptr(), None, dx.data_ptr(), N, H, W, Cout, Cin, 1,
+                                                    torch.cuda.current_stream(x.device).cuda_stream)
+            _lib.check(code, "mpf_gemm3_conv3x3")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            _, dw, db = torch.ops.aten.convolution_backward(
+                gy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                [False, bool(ctx.needs_input_grad[1]), bool(ctx.has_bias and ctx.needs_input_grad[2])])
+        return dx, dw, db
+
+
+def conv3x3(x, weight, bias=None):
+    return _Conv3x3Fn.apply(x, weight, bias)

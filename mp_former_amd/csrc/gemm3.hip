@@ -49,6 +49,7 @@ struct G3 {
     int64_t lda, ldc, ldcin, ldcin2, ldgate, plane;
     int M, N, K, a2_rows, relu, tiles_n, ntiles;
     int bias_cm, cin_cm, cin2_cm, gate_cm;   // 1, or 0 when the operand is absent (it then points at g3_const)
+    int cv_H, cv_W, cv_cin, cv_sign;          // 3x3 convolution mode (gemm3_conv_kernel): image size, channels per tap, +1 / -1
     int tm0, ntiles2, tiles_n2;      // mixed launch: row blocks >= tm0 are cut into ntiles2 tiles of 64 columns (tiles_n2 per row block)
 };
 
@@ -295,7 +296,10 @@ __device__ __forceinline__ void g3_epilogue(const G3& p, const Acc<NJ, false>& a
 }
 
 // one output tile: 128 rows x BN columns starting at (m0, n0)
-template <int BN, bool A2>
+// CV: A is a channel-last image [N_img*H*W][Cin] and K runs over (tap, channel) of a 3x3 window — K step kt reads the
+// rows shifted by the tap's (dy, dx) (sign = -1: the transposed convolution of the input gradient); taps that fall off
+// the image contribute zeros (the loads stay unconditional on clamped rows, the registers are zeroed before the split).
+template <int BN, bool A2, bool CV = false>
 __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, const int m0, const int n0)
 {
     constexpr int NJ = BN / 32;                  // 16-column MFMA tiles per wave
@@ -320,6 +324,13 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         a2p0 = p.a2 + (int64_t)(min(m0 + arow0, p.M - 1) % p.a2_rows) * p.K + akc * 8;
         a2p1 = p.a2 + (int64_t)(min(m0 + arow1, p.M - 1) % p.a2_rows) * p.K + akc * 8;
     }
+    int cy0 = 0, cx0 = 0, cy1 = 0, cx1 = 0, mr0 = 0, mr1 = 0;
+    if constexpr (CV) {
+        mr0 = min(m0 + arow0, p.M - 1); mr1 = min(m0 + arow1, p.M - 1);
+        cx0 = mr0 % p.cv_W; cy0 = (mr0 / p.cv_W) % p.cv_H;
+        cx1 = mr1 % p.cv_W; cy1 = (mr1 / p.cv_W) % p.cv_H;
+    }
+    (void)ap0; (void)ap1;
     const unsigned short* bsrc[kBiter];
     int bdst[kBiter];
 #pragma unroll
@@ -343,6 +354,23 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         ra[2] = *reinterpret_cast<const float4*>(ap1 + (k0));                                \
         ra[3] = *reinterpret_cast<const float4*>(ap1 + (k0) + 4);                            \
     }
+    // conv mode: loads of K step k0 (tap = k0 / Cin) and the validity of the two rows' taps (bit 0 / bit 1 of vm)
+#define G3_LOAD_A_CV(ra, vm, k0)                                                             \
+    {                                                                                        \
+        const int tap_ = (k0) / p.cv_cin, kk_ = (k0) - tap_ * p.cv_cin;                      \
+        const int dy_ = (tap_ / 3 - 1) * p.cv_sign, dx_ = (tap_ % 3 - 1) * p.cv_sign;        \
+        const int sh_ = dy_ * p.cv_W + dx_;                                                  \
+        const bool v0_ = (unsigned)(cy0 + dy_) < (unsigned)p.cv_H && (unsigned)(cx0 + dx_) < (unsigned)p.cv_W; \
+        const bool v1_ = (unsigned)(cy1 + dy_) < (unsigned)p.cv_H && (unsigned)(cx1 + dx_) < (unsigned)p.cv_W; \
+        /* 32-bit element offsets from the uniform base (host checks M * lda < 2^31): saddr + voffset addressing */ \
+        const unsigned o0_ = (unsigned)(min(max(mr0 + sh_, 0), p.M - 1) * (int)p.lda + akc * 8 + kk_); \
+        const unsigned o1_ = (unsigned)(min(max(mr1 + sh_, 0), p.M - 1) * (int)p.lda + akc * 8 + kk_); \
+        ra[0] = *reinterpret_cast<const float4*>(p.a + o0_);                                 \
+        ra[1] = *reinterpret_cast<const float4*>(p.a + o0_ + 4);                             \
+        ra[2] = *reinterpret_cast<const float4*>(p.a + o1_);                                 \
+        ra[3] = *reinterpret_cast<const float4*>(p.a + o1_ + 4);                             \
+        vm = (v0_ ? 1 : 0) | (v1_ ? 2 : 0);                                                  \
+    }
 #define G3_LOAD_B(k0)                                                                        \
     {                                                                                        \
         if constexpr (A2) {                                                                  \
@@ -358,17 +386,30 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         if constexpr (kBiter > 4) rb4 = *reinterpret_cast<const uint4*>(bsrc[4] + (k0));     \
         if constexpr (kBiter > 5) rb5 = *reinterpret_cast<const uint4*>(bsrc[5] + (k0));     \
     }
-#define G3_WRITE(ra)                                                                         \
+#define G3_LA(ra, vm, k0)                                                                    \
+    {                                                                                        \
+        if constexpr (CV) G3_LOAD_A_CV(ra, vm, k0) else G3_LOAD_A(ra, k0)                    \
+    }
+#define G3_WRITE(ra, vm)                                                                     \
     {                                                                                        \
         uint4 h, m, l;                                                                       \
-        if constexpr (A2) {                                                                  \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) ra[i] = add4(ra[i], ra2[i]);       \
+        /* (temporaries, not writes into ra[]: a float4 array written under a condition goes to scratch) */ \
+        float4 w0_ = ra[0], w1_ = ra[1], w2_ = ra[2], w3_ = ra[3];                           \
+        if constexpr (CV) {                                                                  \
+            const float s0_ = (vm & 1) ? 1.f : 0.f, s1_ = (vm & 2) ? 1.f : 0.f;              \
+            w0_ = make_float4(w0_.x * s0_, w0_.y * s0_, w0_.z * s0_, w0_.w * s0_);           \
+            w1_ = make_float4(w1_.x * s0_, w1_.y * s0_, w1_.z * s0_, w1_.w * s0_);           \
+            w2_ = make_float4(w2_.x * s1_, w2_.y * s1_, w2_.z * s1_, w2_.w * s1_);           \
+            w3_ = make_float4(w3_.x * s1_, w3_.y * s1_, w3_.z * s1_, w3_.w * s1_);           \
         }                                                                                    \
-        split8(ra[0], ra[1], &h, &m, &l);                                                    \
+        if constexpr (A2) {                                                                  \
+            w0_ = add4(w0_, ra2[0]); w1_ = add4(w1_, ra2[1]); w2_ = add4(w2_, ra2[2]); w3_ = add4(w3_, ra2[3]); \
+        }                                                                                    \
+        split8(w0_, w1_, &h, &m, &l);                                                        \
         *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + aslot0 * 16) = h;             \
         *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + aslot0 * 16) = m;             \
         *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKc + aslot0 * 16) = l;             \
-        split8(ra[2], ra[3], &h, &m, &l);                                                    \
+        split8(w2_, w3_, &h, &m, &l);                                                        \
         *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + aslot1 * 16) = h;             \
         *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + aslot1 * 16) = m;             \
         *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKc + aslot1 * 16) = l;             \
@@ -399,19 +440,20 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
-    G3_LOAD_A(raE, 0);
+    int vmE = 3, vmO = 3;
+    G3_LA(raE, vmE, 0);
     G3_LOAD_B(0);
-    G3_LOAD_A(raO, min(kBK, klast));
+    G3_LA(raO, vmO, min(kBK, klast));
     for (int kt = 0; kt < nk; kt += 2) {
         __syncthreads();
         G3_T(0);
-        G3_WRITE(raE);
+        G3_WRITE(raE, vmE);
         G3_T(1);
         __syncthreads();
         G3_T(2);
         G3_LOAD_B(min((kt + 1) * kBK, klast));      // B first: the next write waits for it with the A loads still in flight
         __builtin_amdgcn_sched_barrier(0);
-        G3_LOAD_A(raE, min((kt + 2) * kBK, klast));
+        G3_LA(raE, vmE, min((kt + 2) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
         G3_T(3);
         acc.template step<kAKc, kBKc>(lds, a_frag, b_frag, lane);
@@ -419,13 +461,13 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         if (kt + 1 >= nk) break;
         __syncthreads();
         G3_T(0);
-        G3_WRITE(raO);
+        G3_WRITE(raO, vmO);
         G3_T(1);
         __syncthreads();
         G3_T(2);
         G3_LOAD_B(min((kt + 2) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
-        G3_LOAD_A(raO, min((kt + 3) * kBK, klast));
+        G3_LA(raO, vmO, min((kt + 3) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
         G3_T(3);
         acc.template step<kAKc, kBKc>(lds, a_frag, b_frag, lane);
@@ -441,6 +483,8 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
     g3_epilogue<NJ>(p, acc, lane, m0 + wr * 64, n0 + wc * (BN / 2));
 }
 #undef G3_LOAD_A
+#undef G3_LOAD_A_CV
+#undef G3_LA
 #undef G3_LOAD_B
 #undef G3_WRITE
 
@@ -455,6 +499,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
     if (tile >= p.ntiles) return;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     g3_tn_tile<BN, A2>(p, lds, tm * kBM, tn * BN);
+}
+
+// 3x3 convolution (stride 1, zero padding 1) of channel-last images as ONE GEMM with K = 9 * Cin (g3_tn_tile<.., CV>)
+__global__ __launch_bounds__(kThreads, 2) void gemm3_conv_kernel(G3 p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 12 * 128 * 16];
+    const int per_xcd = (p.ntiles + 7) >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (tile >= p.ntiles) return;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    g3_tn_tile<128, false, true>(p, lds, tm * kBM, tn * 128);
 }
 
 // Mixed launch against the tail effect: 128 x 128 tiles for as many row blocks as fill WHOLE rounds of the chip's
@@ -846,6 +901,38 @@ extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2
     }
     mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + 6.0 * (double)N * K, 2.0 * M * (double)N * K);
     return mpf::check(hipGetLastError(), "mpf_gemm3_tn");
+}
+
+extern "C" int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const float* bias, float* y, int n_img, int H, int W, int Cin,
+                                 int Cout, int transposed, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!x || !w_planes || !y) return mpf::fail(MPF_E_NULL, "gemm3_conv3x3: NULL buffer");
+    if (n_img <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 != 0 || Cout % 4 != 0)
+        return mpf::fail(MPF_E_SHAPE, "gemm3_conv3x3: Cin must be a multiple of 32, Cout of 4");
+    const int64_t M64 = (int64_t)n_img * H * W;
+    if (M64 >= (1ll << 31) / 4 || M64 * Cin >= (1ll << 40)) return mpf::fail(MPF_E_TOO_LARGE, "gemm3_conv3x3: image too large");
+    G3 p;
+    static const float* consts = nullptr;
+    if (!consts) {
+        void* sym = nullptr;
+        if (hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g3_const)); e != hipSuccess) return mpf::check(e, "gemm3_conv3x3: constants");
+        consts = (const float*)sym;
+    }
+    p.a = x; p.a2 = nullptr; p.bp = (const unsigned short*)w_planes; p.c = y;
+    p.bias = bias ? bias : consts; p.bias_cm = bias ? 1 : 0;
+    p.cin = consts; p.ldcin = 0; p.cin_cm = 0; p.cin2 = consts; p.ldcin2 = 0; p.cin2_cm = 0; p.gate = consts + 4; p.ldgate = 0; p.gate_cm = 0;
+    p.M = (int)M64; p.N = Cout; p.K = 9 * Cin; p.lda = Cin; p.ldc = Cout; p.plane = (int64_t)Cout * p.K;
+    p.a2_rows = 0; p.relu = 0;
+    p.cv_H = H; p.cv_W = W; p.cv_cin = Cin; p.cv_sign = transposed ? -1 : 1;
+    p.tiles_n = (Cout + 127) / 128;
+    p.ntiles = ((p.M + kBM - 1) / kBM) * p.tiles_n;
+    p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
+    mpf::prof_begin(st);
+    mpf::set_kernel("gemm3_conv_kernel");
+    hipLaunchKernelGGL(gemm3_conv_kernel, dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
+    mpf::prof_end("gemm3_conv_kernel", st, 4.0 * ((double)p.M * Cin + (double)p.M * Cout) + 6.0 * (double)Cout * p.K, 2.0 * p.M * (double)Cout * p.K);
+    return mpf::check(hipGetLastError(), "mpf_gemm3_conv3x3");
 }
 
 extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t ldb, const float* b2, int64_t ldb2, int b2_rows,

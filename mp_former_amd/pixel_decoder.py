@@ -18,6 +18,7 @@ from torch import nn
 from torch.nn.init import normal_
 
 from . import encoder_fused
+from . import conv3x3
 from .groupnorm import GroupNorm, to_nchw
 from .linear import linear_tall
 from .msda import MSDeformAttn, attach_host_shapes
@@ -203,7 +204,11 @@ class _ConvNorm(nn.Conv2d):
         self.activation = activation
 
     def forward(self, x):
-        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and self.dilation == (1, 1)
+                and self.groups == 1 and conv3x3.supported(x, self.weight)):
+            x = conv3x3.conv3x3(x, self.weight, self.bias)          # forward / input gradient on the split-bf16 GEMM
+        else:
+            x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
         if isinstance(self.norm, GroupNorm) and self.activation in (None, F.relu) and self.norm.cl_ok(x):
             return self.norm.forward_cl(x, relu=self.activation is F.relu)     # norm (+ ReLU) in one pass, channel-last
         if self.norm is not None:

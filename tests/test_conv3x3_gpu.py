@@ -1,0 +1,36 @@
+"""3x3 convolution on the split-bf16 GEMM (mpf_gemm3_conv3x3) against F.conv2d in fp64: forward, input gradient,
+weight / bias gradients; odd sizes, batch > 1 (taps must not leak across image or row boundaries)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,C,Co,H,W,bias", [(2, 64, 64, 9, 7, True), (1, 32, 96, 5, 12, False), (3, 256, 256, 16, 16, True),
+                                               (2, 256, 256, 37, 21, False)])
+def test_conv3x3_matches_conv2d(N, C, Co, H, W, bias):
+    from mp_former_amd import _lib
+    from mp_former_amd.conv3x3 import conv3x3, supported
+    dev = torch.device("cuda:0")
+    torch.manual_seed(N + C + H)
+    x = torch.randn(N, H, W, C, device=dev).permute(0, 3, 1, 2).requires_grad_(True)
+    w = (torch.randn(Co, C, 3, 3, device=dev) / (3 * C ** 0.5)).requires_grad_(True)
+    b = torch.randn(Co, device=dev).requires_grad_(True) if bias else None
+    assert supported(x, w)
+    y = conv3x3(x, w, b)
+    assert _lib.last_kernel() == "gemm3_conv_kernel"
+    xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    br = b.detach().double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, 1, 1)
+    lib = F.conv2d(x.detach(), w.detach(), b.detach() if bias else None, 1, 1)
+    e3, el = (y.double() - yr).abs(), (lib.double() - yr).abs()
+    assert float(e3.max()) <= 4e-6 * (float(yr.abs().max()) + 1.0)
+    assert float(e3.mean()) <= 4.0 * float(el.mean()) + 1e-8        # same order as the library fp32 convolution (K = 9 Cin terms)
+    g = torch.randn_like(y)
+    y.backward(g)
+    yr.backward(g.double())
+    assert float((x.grad.double() - xr.grad).abs().max()) <= 4e-6 * (float(xr.grad.abs().max()) + 1.0)
+    torch.testing.assert_close(w.grad.double(), wr.grad, rtol=1e-4, atol=1e-4 * float(wr.grad.abs().max()))
+    if bias:
+        torch.testing.assert_close(b.grad.double(), br.grad, rtol=1e-4, atol=1e-4 * float(br.grad.abs().max()))
