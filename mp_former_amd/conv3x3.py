@@ -72,3 +72,55 @@ class _Conv3x3Fn(Function):
 
 def conv3x3(x, weight, bias=None):
     return _Conv3x3Fn.apply(x, weight, bias)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 1x1 convolutions of the pixel decoder (input projections, FPN lateral, mask_features: msdeformattn.py:245-262, :266-271,
+# :284-291) on channel-last planes ARE matrix products [N*H*W, Cin] x [Cin, Cout]: forward and input gradient on
+# mpf_gemm3_tn, weight + bias gradient on the split-over-rows mpf_gemm3_nt (bias gradient = its column sums).
+# ---------------------------------------------------------------------------------------------------------------------
+def supported_1x1(x, weight):
+    if not (os.environ.get("MPF_CONV1X1_GEMM3", "1") == "1" and is_cl_plane(x) and weight.dtype == torch.float32 and weight.dim() == 4):
+        return False
+    N, C, H, W = x.shape
+    Cout, Cin, kh, kw = weight.shape
+    return kh == 1 and kw == 1 and Cin == C and C % 32 == 0 and Cout % 32 == 0 and x.stride(0) == H * W * C
+
+
+class _Conv1x1Fn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from .gemm3 import gemm3
+        N, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        w2 = weight.view(Cout, Cin)
+        pf, pb = split_weights_grouped([([w2], False), ([w2], True)])
+        x2 = x.permute(0, 2, 3, 1).reshape(N * H * W, Cin)                      # view of the planes
+        y2 = gemm3(x2, pf, bias)
+        ctx.save_for_backward(x2, pb)
+        ctx.dims, ctx.has_bias = (N, Cin, Cout, H, W), bias is not None
+        return y2.view(N, H, W, Cout).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .encoder_fused import _balanced_rps
+        from .gemm3 import gemm3, gemm3_nt, nt_reduce
+        x2, pb = ctx.saved_tensors
+        N, Cin, Cout, H, W = ctx.dims
+        g2 = gy.permute(0, 2, 3, 1).reshape(N * H * W, Cout)
+        if g2.stride(1) != 1 or g2.stride(0) != Cout:
+            g2 = g2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm3(g2, pb).view(N, H, W, Cin).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            c, ca, _ = gemm3_nt(g2, x2, _balanced_rps(g2.shape[0], Cout, Cin, g2.device), want_csum_a=True)
+            dw, db = nt_reduce(c, ca)
+            dw = dw.view(Cout, Cin, 1, 1)
+            if not ctx.has_bias:
+                db = None
+        return dx, dw, db
+
+
+def conv1x1(x, weight, bias=None):
+    return _Conv1x1Fn.apply(x, weight, bias)

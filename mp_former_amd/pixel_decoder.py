@@ -194,6 +194,17 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         return memory, spatial_shapes, level_start_index
 
 
+def _conv(m, x):
+    """m(x) for an nn.Conv2d-like module, on the split-bf16 GEMM when the input is channel-last planes and the shape is one
+    the GEMM forms take (3x3 / stride 1 / pad 1, or 1x1), else the library convolution."""
+    if m.groups == 1 and m.dilation == (1, 1) and m.stride == (1, 1):
+        if m.kernel_size == (3, 3) and m.padding == (1, 1) and conv3x3.supported(x, m.weight):
+            return conv3x3.conv3x3(x, m.weight, m.bias)
+        if m.kernel_size == (1, 1) and m.padding == (0, 0) and conv3x3.supported_1x1(x, m.weight):
+            return conv3x3.conv1x1(x, m.weight, m.bias)
+    return F.conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups)
+
+
 class _ConvNorm(nn.Conv2d):
     """detectron2.layers.Conv2d: conv -> optional norm -> optional activation; the norm lives under
     the attribute ``norm`` (state-dict keys ``<name>.norm.weight``)."""
@@ -204,11 +215,7 @@ class _ConvNorm(nn.Conv2d):
         self.activation = activation
 
     def forward(self, x):
-        if (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and self.dilation == (1, 1)
-                and self.groups == 1 and conv3x3.supported(x, self.weight)):
-            x = conv3x3.conv3x3(x, self.weight, self.bias)          # forward / input gradient on the split-bf16 GEMM
-        else:
-            x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        x = _conv(self, x)
         if isinstance(self.norm, GroupNorm) and self.activation in (None, F.relu) and self.norm.cl_ok(x):
             return self.norm.forward_cl(x, relu=self.activation is F.relu)     # norm (+ ReLU) in one pass, channel-last
         if self.norm is not None:
@@ -304,7 +311,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
         srcs, pos = [], []
         for idx, f in enumerate(self.transformer_in_features[::-1]):
             x = features[f].float()
-            srcs.append(self.input_proj[idx](x))
+            proj = self.input_proj[idx]
+            srcs.append(proj[1](_conv(proj[0], x)) if len(proj) == 2 else proj(x))
             pos.append(self.pe_layer(x))
         y, spatial_shapes, level_start_index = self.transformer(srcs, pos)
         bs = y.shape[0]
@@ -315,7 +323,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             x = features[f].float()
             lat = self.lateral_convs[idx]
             if isinstance(lat.norm, GroupNorm) and lat.activation is None:
-                z = F.conv2d(x, lat.weight, lat.bias, lat.stride, lat.padding, lat.dilation, lat.groups)
+                z = _conv(lat, x)
                 if lat.norm.cl_ok(z, out[-1]):
                     # norm(lateral) + upsample2x(top) in the norm's apply pass (msdeformattn.py:349-351)
                     out.append(self.output_convs[idx](lat.norm.forward_cl(z, top=out[-1])))

@@ -34,3 +34,28 @@ def test_conv3x3_matches_conv2d(N, C, Co, H, W, bias):
     torch.testing.assert_close(w.grad.double(), wr.grad, rtol=1e-4, atol=1e-4 * float(wr.grad.abs().max()))
     if bias:
         torch.testing.assert_close(b.grad.double(), br.grad, rtol=1e-4, atol=1e-4 * float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize("N,C,Co,H,W,bias", [(2, 256, 256, 24, 20, True), (1, 512, 256, 9, 7, False), (2, 64, 96, 5, 5, True)])
+def test_conv1x1_matches_conv2d(N, C, Co, H, W, bias):
+    from mp_former_amd import _lib
+    from mp_former_amd.conv3x3 import conv1x1, supported_1x1
+    dev = torch.device("cuda:0")
+    torch.manual_seed(C + H)
+    x = torch.randn(N, H, W, C, device=dev).permute(0, 3, 1, 2).requires_grad_(True)
+    w = (torch.randn(Co, C, 1, 1, device=dev) / C ** 0.5).requires_grad_(True)
+    b = torch.randn(Co, device=dev).requires_grad_(True) if bias else None
+    assert supported_1x1(x, w)
+    y = conv1x1(x, w, b)
+    assert "gemm3_tn" in _lib.last_kernel()
+    xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    br = b.detach().double().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br)
+    assert float((y.double() - yr).abs().max()) <= 4e-6 * (float(yr.abs().max()) + 1.0)
+    g = torch.randn(N, Co, H, W, device=dev)          # NCHW-contiguous gradient: the backward relayouts it
+    y.backward(g)
+    yr.backward(g.double())
+    assert float((x.grad.double() - xr.grad).abs().max()) <= 4e-6 * (float(xr.grad.abs().max()) + 1.0)
+    torch.testing.assert_close(w.grad.double(), wr.grad, rtol=1e-4, atol=1e-5 * float(wr.grad.abs().max()) + 1e-6)
+    if bias:
+        torch.testing.assert_close(b.grad.double(), br.grad, rtol=1e-4, atol=1e-5 * float(br.grad.abs().max()) + 1e-6)
