@@ -511,6 +511,13 @@ int mpf_grouped_scale_cast(const MpfScaleCastItem* items_device, int n_items, in
  */
 int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const float* bias, float* y, int n_img, int H, int W, int Cin,
                       int Cout, int transposed, void* stream);
+/*
+ * Its weight gradient (W % 8 == 0, Cin % 128 == 0): c_part[s][co][(ky*3+kx)*Cin + ci] = the contribution of the rows of split
+ * s (rows_per_split % 32 == 0) to sum_r dy[r][co] * x[r shifted by the tap][ci]; csum_dy[s][co] (may be NULL) = the
+ * column sums of dy (bias gradient).  Sum the splits with mpf_gemm3_nt_reduce.
+ */
+int mpf_gemm3_conv3x3_wgrad(const float* dy, const float* x, float* c_part, float* csum_dy, int n_img, int H, int W, int Cin, int Cout,
+                            int rows_per_split, void* stream);
 
 /*
  * mpf_gemm3_split for a LIST of weight matrices in one launch (all Linear weights of the encoder, both

@@ -64,10 +64,33 @@ class _Conv3x3Fn(Function):
                                                     torch.cuda.current_stream(x.device).cuda_stream)
             _lib.check(code, "mpf_gemm3_conv3x3")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            _, dw, db = torch.ops.aten.convolution_backward(
-                gy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                [False, bool(ctx.needs_input_grad[1]), bool(ctx.has_bias and ctx.needs_input_grad[2])])
+            if W % 8 == 0 and Cin % 128 == 0 and os.environ.get("MPF_CONV3X3_WGRAD", "1") == "1":
+                dw, db = _wgrad_native(gy, x, N, H, W, Cin, Cout, ctx.has_bias)
+            else:
+                _, dw, db = torch.ops.aten.convolution_backward(
+                    gy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                    [False, bool(ctx.needs_input_grad[1]), bool(ctx.has_bias and ctx.needs_input_grad[2])])
         return dx, dw, db
+
+
+def _wgrad_native(gy, x, N, H, W, Cin, Cout, has_bias):
+    """dW [Cout, Cin, 3, 3] (as a channels_last-strided view of [Cout, 3, 3, Cin]) and the bias gradient on the split-bf16 NT
+    kernel's convolution mode: one launch over (output tile, row split) + the fixed-order sum of the splits."""
+    from .gemm3 import nt_reduce
+    R = N * H * W
+    tiles = ((Cout + 127) // 128) * (9 * Cin // 128)
+    slots = 2 * torch.cuda.get_device_properties(x.device).multi_processor_count
+    ns = max(1, (3 * slots) // tiles)                       # ~3 rounds of workgroups: measured best at 256 -> 256 channels
+    rps = max(128, ((-(-R // ns)) + 31) // 32 * 32)
+    ns = -(-R // rps)
+    c = torch.empty((ns, Cout, 9 * Cin), dtype=torch.float32, device=x.device)
+    ca = torch.empty((ns, Cout), dtype=torch.float32, device=x.device) if has_bias else None
+    with torch.cuda.device(x.device):
+        code = _lib.lib().mpf_gemm3_conv3x3_wgrad(gy.data_ptr(), x.data_ptr(), c.data_ptr(), ca.data_ptr() if has_bias else None, N, H, W,
+                                                  Cin, Cout, rps, torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(code, "mpf_gemm3_conv3x3_wgrad")
+    dw2, db = nt_reduce(c, ca)
+    return dw2.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), db
 
 
 def conv3x3(x, weight, bias=None):

@@ -555,11 +555,16 @@ struct G3N {
     int64_t lda, ldb, ldb2;
     int R, Mdim, Ndim, b2_rows, rows_per_split, nsplit, tiles_m, tiles_n, ntiles, transpose_out;
     unsigned a_bytes, b_bytes;      // sizes of the operands (for the buffer descriptors; both < 4 GiB)
+    int cv_H, cv_W, cv_cin;         // CV: weight gradient of a 3x3 convolution (B = the input image, columns = (tap, channel))
 };
 
 // BF: the operands are bf16 matrices (p.a / p.b point to 2-byte elements): one plane, one product —
 // the weight gradient of a bf16 Linear with many rows (the K / V projections of the cross-attention).
-template <int BN, bool BF = false>
+// CV (BN = 128, fp32): the weight gradient of a 3x3 / stride 1 / padding 1 convolution of channel-last images,
+//   dW2[co][tap * Cin + ci] = sum_r dY[r][co] * X[r + dy(tap) * W + dx(tap)][ci]   (taps off the image contribute nothing):
+// the column tile fixes the tap (Cin % 128 == 0), so the row shift of the B operand is a per-workgroup scalar, and with
+// W % 8 == 0 the 8 rows of a k-chunk lie in one image row, so a row's validity is wave-uniform as well.
+template <int BN, bool BF = false, bool CV = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
 {
     constexpr int NJ = BN / 32;
@@ -599,7 +604,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
         if (BN == 128) bkc_[i] = __builtin_amdgcn_readfirstlane(bkc_[i]);
         b_col_ok[i] = b_ok[i] && n0 + bn_[i] < p.Ndim;
         bcolx[i] = min(n0 + bn_[i], p.Ndim - 1);
-        b2row[i] = p.b2 ? (r_begin + bkc_[i] * 8) % p.b2_rows : 0;
+        if constexpr (CV) bcolx[i] = (n0 % p.cv_cin) + bn_[i];          // channel of the input image
+        b2row[i] = (!CV && p.b2) ? (r_begin + bkc_[i] * 8) % p.b2_rows : 0;
+    }
+    // CV: tap of this column tile and the image coordinates of the first row of the thread's two k-chunks
+    int cv_dy = 0, cv_dx = 0, cv_sh = 0, cv_x[2] = {0, 0}, cv_y[2] = {0, 0};
+    if constexpr (CV) {
+        const int tap = n0 / p.cv_cin;
+        cv_dy = tap / 3 - 1; cv_dx = tap % 3 - 1;
+        cv_sh = cv_dy * p.cv_W + cv_dx;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rb = r_begin + bkc_[i] * 8;
+            cv_x[i] = rb % p.cv_W;
+            cv_y[i] = (rb / p.cv_W) % p.cv_H;
+        }
     }
     // buffer descriptors: voffset = the lane's column (bytes), soffset = the row (bytes, scalar when the k-chunk
     // is wave-uniform)
@@ -628,8 +647,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
             const int ca0 = TAIL ? min(ra0, r_end - 1) : ra0, ca1 = TAIL ? min(ra1, r_end - 1) : ra1;  \
             const int cb0 = TAIL ? min(rb0, r_end - 1) : rb0, cb1 = TAIL ? min(rb1, r_end - 1) : rb1;  \
             float va0 = ld(ars, acolb, ca0 * ldab, true), va1 = ld(ars, acolb, ca1 * ldab, true);      \
-            float vb0 = ld(brs, bcolb0, cb0 * ldbb, BN == 128), vb1 = ld(brs, bcolb1, cb1 * ldbb, BN == 128); \
-            if (!BF && p.b2) {                                                                         \
+            float vb0, vb1;                                                                            \
+            if constexpr (CV) {                                                                        \
+                const int sb0 = min(max(cb0 + cv_sh, 0), p.R - 1), sb1 = min(max(cb1 + cv_sh, 0), p.R - 1); \
+                vb0 = ld(brs, bcolb0, sb0 * ldbb, true); vb1 = ld(brs, bcolb1, sb1 * ldbb, true);      \
+                const bool ok0 = (unsigned)(cv_y[0] + cv_dy) < (unsigned)p.cv_H && (unsigned)(cv_x[0] + j + cv_dx) < (unsigned)p.cv_W; \
+                const bool ok1 = (unsigned)(cv_y[1] + cv_dy) < (unsigned)p.cv_H && (unsigned)(cv_x[1] + j + cv_dx) < (unsigned)p.cv_W; \
+                vb0 = ok0 ? vb0 : 0.f; vb1 = ok1 ? vb1 : 0.f;                                          \
+            } else {                                                                                   \
+                vb0 = ld(brs, bcolb0, cb0 * ldbb, BN == 128); vb1 = ld(brs, bcolb1, cb1 * ldbb, BN == 128); \
+            }                                                                                          \
+            if (!BF && !CV && p.b2) {                                                                  \
                 int q0 = b2row[0] + j, q1 = b2row[1] + j;                                              \
                 q0 = q0 >= p.b2_rows ? q0 - p.b2_rows : q0;                                            \
                 q1 = q1 >= p.b2_rows ? q1 - p.b2_rows : q1;                                            \
@@ -645,10 +673,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
             xa0[j] = va0; xa1[j] = va1; xb0[j] = vb0;                                                  \
             xb1[j] = b_ok[1] ? vb1 : 0.f;                                                              \
         }                                                                                              \
-        if (!BF && p.b2) {                                                                             \
+        if (!BF && !CV && p.b2) {                                                                      \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
                 b2row[i] += kBK;                                                                       \
                 while (b2row[i] >= p.b2_rows) b2row[i] -= p.b2_rows;                                   \
+            }                                                                                          \
+        }                                                                                              \
+        if constexpr (CV) {      /* the next K step is 32 rows further */                              \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
+                cv_x[i] += kBK;                                                                        \
+                while (cv_x[i] >= p.cv_W) { cv_x[i] -= p.cv_W; cv_y[i] = cv_y[i] + 1 == p.cv_H ? 0 : cv_y[i] + 1; } \
             }                                                                                          \
         }                                                                                              \
     }
@@ -1020,6 +1054,35 @@ __global__ __launch_bounds__(256) void nt_reduce_kernel(const float* __restrict_
 }
 
 }  // namespace
+
+extern "C" int mpf_gemm3_conv3x3_wgrad(const float* dy, const float* x, float* c_part, float* csum_dy, int n_img, int H, int W, int Cin,
+                                       int Cout, int rows_per_split, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!dy || !x || !c_part) return mpf::fail(MPF_E_NULL, "gemm3_conv3x3_wgrad: NULL buffer");
+    if (n_img <= 0 || H <= 0 || W <= 0 || W % 8 != 0 || Cin <= 0 || Cin % 128 != 0 || Cout <= 0 || rows_per_split <= 0 ||
+        rows_per_split % kBK != 0)
+        return mpf::fail(MPF_E_SHAPE, "gemm3_conv3x3_wgrad: needs W % 8 == 0, Cin % 128 == 0, rows_per_split % 32 == 0");
+    const int64_t R64 = (int64_t)n_img * H * W;
+    if (R64 * (Cin > Cout ? Cin : Cout) * 4 >= (1ll << 32)) return mpf::fail(MPF_E_TOO_LARGE, "gemm3_conv3x3_wgrad: an operand spans 4 GiB or more");
+    G3N p;
+    p.a = dy; p.b = x; p.b2 = nullptr; p.c = c_part; p.csum_a = csum_dy; p.csum_b = nullptr;
+    p.lda = Cout; p.ldb = Cin; p.ldb2 = 0;
+    p.R = (int)R64; p.Mdim = Cout; p.Ndim = 9 * Cin; p.b2_rows = 0; p.rows_per_split = rows_per_split;
+    p.nsplit = (p.R + rows_per_split - 1) / rows_per_split;
+    p.transpose_out = 0;
+    p.a_bytes = (unsigned)(R64 * Cout * 4); p.b_bytes = (unsigned)(R64 * Cin * 4);
+    p.cv_H = H; p.cv_W = W; p.cv_cin = Cin;
+    p.tiles_m = (Cout + kBM - 1) / kBM;
+    p.tiles_n = 9 * Cin / 128;
+    p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
+    mpf::prof_begin(st);
+    mpf::set_kernel("gemm3_nt_kernel<conv3x3>");
+    hipLaunchKernelGGL((gemm3_nt_kernel<128, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
+    mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)p.R * Cout + (double)p.R * Cin + (double)p.nsplit * Cout * 9 * Cin),
+                  2.0 * p.R * (double)Cout * 9 * Cin);
+    return mpf::check(hipGetLastError(), "mpf_gemm3_conv3x3_wgrad");
+}
 
 extern "C" size_t mpf_gemm_nt_bf16_workspace_bytes(int R, int Mdim, int Ndim, int rows_per_split)
 {

@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("N,C,Co,H,W,bias", [(2, 64, 64, 9, 7, True), (1, 32, 96, 5, 12, False), (3, 256, 256, 16, 16, True),
-                                               (2, 256, 256, 37, 21, False)])
+                                               (2, 256, 256, 37, 21, False), (2, 128, 128, 10, 24, True), (2, 256, 256, 64, 64, True)])
 def test_conv3x3_matches_conv2d(N, C, Co, H, W, bias):
     from mp_former_amd import _lib
     from mp_former_amd.conv3x3 import conv3x3, supported
