@@ -242,6 +242,7 @@ def main():
     n_g, ms_g, _, fl_g = prof("gemm3_tn_kernel")
     n_gn, ms_gn, _, fl_gn = prof("gemm3_nt_kernel<1")          # fp32 (three-plane) weight gradients; "<128, bf16>" is one product
     n_gc, ms_gc, _, fl_gc = prof("gemm3_conv_kernel")          # 3x3 FPN convolution (forward + input gradient) as K = 9*Cin GEMMs
+    n_gw, ms_gw, _, fl_gw = prof("gemm3_nt_kernel<conv3x3>")   # ... and its weight gradient
     _lib.profile_enable(False)
     S_tok = sum((a.size // s) ** 2 for s in (8, 16, 32))
     n_b = n_pull                                   # one push + one pull launch per MSDA backward call
@@ -318,7 +319,8 @@ def main():
                              attn_entry("attn_fwd_kernel"), attn_entry("attn_bwd_kv_kernel"), attn_entry("attn_bwd_q_kernel"),
                              # the encoder's fp32 Linear layers as split-bf16 MFMA products (csrc/gemm3.hip)
                              gemm_entry("gemm3_tn_kernel", n_g, ms_g, fl_g), gemm_entry("gemm3_nt_kernel", n_gn, ms_gn, fl_gn),
-                             gemm_entry("gemm3_conv_kernel", n_gc, ms_gc, fl_gc)]},
+                             gemm_entry("gemm3_conv_kernel", n_gc, ms_gc, fl_gc),
+                             gemm_entry("gemm3_nt_kernel<conv3x3>", n_gw, ms_gw, fl_gw)]},
             "cpu_baseline": None,
         }
         out["config"]["miopen_find_db"] = "mismatch (MIOpen ignored the shipped db)" if _miopen.db_mismatch() else "shipped"

@@ -42,6 +42,10 @@ def test_ddp_over_rccl_world1_matches_plain_run():
     plain = _run("plain")
     ddp = _run("ddp")
     assert len(ddp["losses"]) == 3
-    for a, b in zip(plain["losses"], ddp["losses"]):
-        assert abs(a - b) <= 2e-3 * max(1.0, abs(a)), (plain, ddp)
+    # step 1 sees identical parameters: equal up to the reduction order of the loss sums; the later steps inherit the
+    # run-to-run spread of the gradients (float atomics in the LayerNorm parameter gradients, the library's split
+    # reductions) amplified by AdamW — two PLAIN runs differ by up to 2.5e-3 at step 3
+    assert abs(plain["losses"][0] - ddp["losses"][0]) <= 1e-5 * max(1.0, abs(plain["losses"][0])), (plain, ddp)
+    for a, b in zip(plain["losses"][1:], ddp["losses"][1:]):
+        assert abs(a - b) <= 1e-2 * max(1.0, abs(a)), (plain, ddp)
     assert abs(plain["checksum"] - ddp["checksum"]) <= 1e-5 * plain["checksum"], (plain["checksum"], ddp["checksum"])
