@@ -572,6 +572,14 @@ int mpf_transpose_f32(const float* in, int64_t in_batch_stride, float* out, int6
  */
 int mpf_gemm3_nt_reduce(const float* c_part, int64_t c_numel, const float* s_part, int64_t s_numel, int nsplit,
                         float* c_out, float* s_out, void* stream);
+/*
+ * The same with the column sums also grouped by a key per split (level_of_split[s] in [0, n_levels), n_levels <= 4):
+ * lvl_out[l][j] = sum of s_part[s][j] over the splits of level l, s_out[j] = their total.  In the fused encoder the
+ * splits of the 288-wide weight gradient never straddle a feature level, so lvl_out is the per-level column sum the
+ * level_embed gradient needs (msdeformattn.py:74-77) and s_out the bias gradient.
+ */
+int mpf_gemm3_nt_reduce_levels(const float* c_part, int64_t c_numel, const float* s_part, int64_t s_numel, int nsplit,
+                               const int64_t* level_of_split, int n_levels, float* c_out, float* lvl_out, float* s_out, void* stream);
 
 /*
  * Weight gradient of a bf16 Linear with MANY rows (the key / value projections of the cross-attention,

@@ -1130,6 +1130,68 @@ extern "C" int mpf_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64
     return mpf::check(hipGetLastError(), "mpf_gemm_nt_bf16");
 }
 
+// the same sum with the column sums ALSO grouped by a per-split key (the feature level of a split's rows):
+// lvl_out[l][j] = sum over the splits of level l of s_part[s][j], s_out = sum over l.  Replaces zeros + index_add_ (float
+// atomics) + two torch reductions per encoder layer; fixed order.
+__global__ __launch_bounds__(256) void nt_reduce_levels_kernel(const float* __restrict__ c_part, int64_t cn, const float* __restrict__ s_part,
+                                                               int64_t sn, int nsplit, const int64_t* __restrict__ level_of_split, int L,
+                                                               float* __restrict__ c_out, float* __restrict__ lvl_out,
+                                                               float* __restrict__ s_out)
+{
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t cq = cn >> 1, sq = sn >> 1;
+    if (q >= cq + sq) return;
+    if (q < cq) {
+        const float* src = c_part + 2 * q;
+        float2 acc = make_float2(0.f, 0.f);
+        int sp = 0;
+        for (; sp + 8 <= nsplit; sp += 8) {
+            float2 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const float2*>(src + (int64_t)(sp + k) * cn);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { acc.x += t[k].x; acc.y += t[k].y; }
+        }
+        for (; sp < nsplit; ++sp) {
+            const float2 t = *reinterpret_cast<const float2*>(src + (int64_t)sp * cn);
+            acc.x += t.x; acc.y += t.y;
+        }
+        *reinterpret_cast<float2*>(c_out + 2 * q) = acc;
+        return;
+    }
+    const int64_t j = 2 * (q - cq);
+    float2 acc[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float2 t = *reinterpret_cast<const float2*>(s_part + (int64_t)sp * sn + j);
+        const int lv = (int)level_of_split[sp];
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+            if (lv == l) { acc[l].x += t.x; acc[l].y += t.y; }
+    }
+    float2 tot = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+        if (l < L) {
+            *reinterpret_cast<float2*>(lvl_out + (int64_t)l * sn + j) = acc[l];
+            tot.x += acc[l].x; tot.y += acc[l].y;
+        }
+    *reinterpret_cast<float2*>(s_out + j) = tot;
+}
+
+extern "C" int mpf_gemm3_nt_reduce_levels(const float* c_part, int64_t c_numel, const float* s_part, int64_t s_numel, int nsplit,
+                                          const int64_t* level_of_split, int n_levels, float* c_out, float* lvl_out, float* s_out,
+                                          void* stream)
+{
+    if (!c_part || !c_out || !s_part || !s_out || !lvl_out || !level_of_split) return mpf::fail(MPF_E_NULL, "gemm3_nt_reduce_levels: NULL buffer");
+    if (nsplit <= 0 || c_numel <= 0 || s_numel <= 0 || c_numel % 4 || s_numel % 4 || n_levels < 1 || n_levels > 4)
+        return mpf::fail(MPF_E_SHAPE, "gemm3_nt_reduce_levels: sizes must be positive multiples of 4, 1..4 levels");
+    const int64_t quads = (c_numel + s_numel) / 2;
+    mpf::set_kernel("nt_reduce_levels_kernel");
+    hipLaunchKernelGGL(nt_reduce_levels_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c_part, c_numel,
+                       s_part, s_numel, nsplit, level_of_split, n_levels, c_out, lvl_out, s_out);
+    return mpf::check(hipGetLastError(), "mpf_gemm3_nt_reduce_levels");
+}
+
 extern "C" int mpf_gemm3_nt_reduce(const float* c_part, int64_t c_numel, const float* s_part, int64_t s_numel, int nsplit,
                                    float* c_out, float* s_out, void* stream)
 {

@@ -23,7 +23,7 @@ import os
 import torch
 from torch.autograd import Function
 
-from .gemm3 import gemm3, gemm3_nt, nt_reduce, split_weights_grouped
+from .gemm3 import gemm3, gemm3_nt, nt_reduce, nt_reduce_levels, split_weights_grouped
 from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
 from .resln import ln256_backward, ln256_forward
 
@@ -175,12 +175,15 @@ class EncoderFn(Function):
             # dW288^T = q^T . draw (288 on the 96-wide tile side) + per-split column sums of draw: the
             # bias gradient and, summed per level, the level_embed gradient
             cpart, _, cs = gemm3_nt(q, draw, rps, want_csum_b=True, transpose_out=True)
-            dw288 = cpart.sum(0)
-            if aligned:
-                lvl = torch.zeros((L, draw.shape[1]), dtype=torch.float32, device=g.device).index_add_(0, split_level, cs)
+            if aligned and L <= 4 and cpart[0].numel() % 4 == 0:
+                dw288, lvl, db288 = nt_reduce_levels(cpart, cs, split_level, L)     # one launch, fixed order
             else:
-                lvl = torch.stack([sl.sum((0, 1)) for sl in draw.view(N, S, -1).split(sizes, 1)])   # [L, 288]
-            db288 = lvl.sum(0)
+                dw288 = cpart.sum(0)
+                if aligned:
+                    lvl = torch.zeros((L, draw.shape[1]), dtype=torch.float32, device=g.device).index_add_(0, split_level, cs)
+                else:
+                    lvl = torch.stack([sl.sum((0, 1)) for sl in draw.view(N, S, -1).split(sizes, 1)])   # [L, 288]
+                db288 = lvl.sum(0)
             lvls[i] = lvl
             dp[0], dp[1], dp[2], dp[3] = dw288[:no], db288[:no], dw288[no:], db288[no:]
             gv2 = gv.view(R, C)

@@ -135,3 +135,19 @@ def nt_reduce(c_part, s_part=None):
                                               c.data_ptr(), _p(s), _stream(c_part))
     _lib.check(code, "mpf_gemm3_nt_reduce")
     return c, s
+
+
+def nt_reduce_levels(c_part, s_part, level_of_split, n_levels):
+    """(sum over splits of c_part, per-level sums of s_part [n_levels, n], their total [n]) in ONE launch, fixed order;
+    level_of_split: int64 [ns] on the device."""
+    ns = c_part.shape[0]
+    c = torch.empty(c_part.shape[1:], dtype=torch.float32, device=c_part.device)
+    n = s_part.shape[1]
+    lvl = torch.empty((n_levels, n), dtype=torch.float32, device=c_part.device)
+    s = torch.empty((n,), dtype=torch.float32, device=c_part.device)
+    assert level_of_split.dtype == torch.int64 and level_of_split.numel() == ns and c.numel() % 4 == 0 and n % 4 == 0 and n_levels <= 4
+    with torch.cuda.device(c_part.device):
+        code = _lib.lib().mpf_gemm3_nt_reduce_levels(c_part.data_ptr(), c.numel(), s_part.data_ptr(), n, ns, level_of_split.data_ptr(),
+                                                     n_levels, c.data_ptr(), lvl.data_ptr(), s.data_ptr(), _stream(c_part))
+    _lib.check(code, "mpf_gemm3_nt_reduce_levels")
+    return c, lvl, s
