@@ -108,7 +108,9 @@ __device__ __forceinline__ float4 load4(const TT* p)
     }
 }
 
-template <typename TT>
+// HAS_T / PLUS are compile-time: as run-time pointer tests every optional load sat behind its own branch and was waited
+// for on its own (x, then t, then — after both reductions — the positional addend: three dependent round trips per row)
+template <typename TT, bool HAS_T, bool PLUS>
 __global__ __launch_bounds__(256) void res_ln256_fwd_kernel(const float* __restrict__ x, const TT* __restrict__ t,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ s_out, float* __restrict__ y32, __bf16* __restrict__ y16,
@@ -119,7 +121,9 @@ __global__ __launch_bounds__(256) void res_ln256_fwd_kernel(const float* __restr
     if (row >= rows) return;
     const int c = (threadIdx.x & 63) * 4;
     float4 v = *reinterpret_cast<const float4*>(x + (int64_t)row * 256 + c);
-    if (t) {
+    float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (PLUS) pp = *reinterpret_cast<const float4*>(padd + (int64_t)(row % padd_rows) * 256 + c);
+    if constexpr (HAS_T) {
         const float4 u = load4(t + (int64_t)row * 256 + c);
         v = make_float4(v.x + u.x, v.y + u.y, v.z + u.z, v.w + u.w);
     }
@@ -132,13 +136,12 @@ __global__ __launch_bounds__(256) void res_ln256_fwd_kernel(const float* __restr
     const float4 o = make_float4(d.x * rs * g.x + b.x, d.y * rs * g.y + b.y, d.z * rs * g.z + b.z, d.w * rs * g.w + b.w);
     if (y32) *reinterpret_cast<float4*>(y32 + (int64_t)row * 256 + c) = o;
     if (y16) *reinterpret_cast<bf16x4v*>(y16 + (int64_t)row * 256 + c) = bf16x4v{(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
-    if (y_plus) {       // y + positional term (row-periodic): the query input of the next deformable-attention layer
-        const float4 pp = *reinterpret_cast<const float4*>(padd + (int64_t)(row % padd_rows) * 256 + c);
+    if constexpr (PLUS)   // y + positional term (row-periodic): the query input of the next deformable-attention layer
         *reinterpret_cast<float4*>(y_plus + (int64_t)row * 256 + c) = make_float4(o.x + pp.x, o.y + pp.y, o.z + pp.z, o.w + pp.w);
-    }
     if ((threadIdx.x & 63) == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+template <bool G32, bool G16, bool GP>
 __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restrict__ s, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ gy32, const __bf16* __restrict__ gy16,
@@ -151,19 +154,21 @@ __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restr
     const float4 g = *reinterpret_cast<const float4*>(gamma + c);
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+#pragma unroll 2
     for (int row = r0 + wave; row < r1; row += 4) {
+        // all operands of the row requested together (G32 / G16 / GP compile-time: no load behind a branch)
         float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy32) dy = *reinterpret_cast<const float4*>(gy32 + (int64_t)row * 256 + c);
-        if (gy16) {
+        const float4 sv = *reinterpret_cast<const float4*>(s + (int64_t)row * 256 + c);
+        const float mu = mean[row], rs = rstd[row];
+        if constexpr (G32) dy = *reinterpret_cast<const float4*>(gy32 + (int64_t)row * 256 + c);
+        if constexpr (G16) {
             const float4 u = load4(gy16 + (int64_t)row * 256 + c);
             dy = make_float4(dy.x + u.x, dy.y + u.y, dy.z + u.z, dy.w + u.w);
         }
-        if (gy_plus) {
+        if constexpr (GP) {
             const float4 u = *reinterpret_cast<const float4*>(gy_plus + (int64_t)row * 256 + c);
             dy = make_float4(dy.x + u.x, dy.y + u.y, dy.z + u.z, dy.w + u.w);
         }
-        const float4 sv = *reinterpret_cast<const float4*>(s + (int64_t)row * 256 + c);
-        const float mu = mean[row], rs = rstd[row];
         const float4 xh = make_float4((sv.x - mu) * rs, (sv.y - mu) * rs, (sv.z - mu) * rs, (sv.w - mu) * rs);
         const float4 dg = make_float4(dy.x * g.x, dy.y * g.y, dy.z * g.z, dy.w * g.w);
         const float s1 = wave_sum(dg.x + dg.y + dg.z + dg.w) * (1.f / 256.f);
@@ -195,12 +200,16 @@ extern "C" int mpf_res_ln256_forward(const float* x, const void* t, int t_dtype,
     if (rows < 0 || (y_plus && (!padd || padd_rows <= 0))) return mpf::fail(MPF_E_SHAPE, "res_ln256_forward: bad rows / missing addend");
     const dim3 grid((rows + 3) / 4);
     mpf::set_kernel("res_ln256_fwd_kernel");
-    if (t && t_dtype == MPF_BF16)
-        hipLaunchKernelGGL(res_ln256_fwd_kernel<__bf16>, grid, dim3(256), 0, st, x, (const __bf16*)t, gamma, beta, s_out, y32, (__bf16*)y16, mean, rstd, rows, eps, padd, padd_rows, y_plus);
-    else if (!t || t_dtype == MPF_F32)
-        hipLaunchKernelGGL(res_ln256_fwd_kernel<float>, grid, dim3(256), 0, st, x, (const float*)t, gamma, beta, s_out, y32, (__bf16*)y16, mean, rstd, rows, eps, padd, padd_rows, y_plus);
+#define RLN_FWD(TT, HT, PL)                                                                                                        \
+    hipLaunchKernelGGL((res_ln256_fwd_kernel<TT, HT, PL>), grid, dim3(256), 0, st, x, (const TT*)t, gamma, beta, s_out, y32, (__bf16*)y16, \
+                       mean, rstd, rows, eps, padd, padd_rows, y_plus)
+    const bool plus = y_plus != nullptr;
+    if (t && t_dtype == MPF_BF16) { if (plus) RLN_FWD(__bf16, true, true); else RLN_FWD(__bf16, true, false); }
+    else if (t && t_dtype == MPF_F32) { if (plus) RLN_FWD(float, true, true); else RLN_FWD(float, true, false); }
+    else if (!t) { if (plus) RLN_FWD(float, false, true); else RLN_FWD(float, false, false); }
     else
         return mpf::fail(MPF_E_DTYPE, "res_ln256_forward: t dtype must be MPF_F32 or MPF_BF16");
+#undef RLN_FWD
     return mpf::check(hipGetLastError(), "mpf_res_ln256_forward");
 }
 
@@ -218,8 +227,19 @@ extern "C" int mpf_res_ln256_backward(const float* s, const float* mean, const f
     rpb = ((rpb + 3) / 4) * 4;
     const dim3 grid((rows + rpb - 1) / rpb);
     mpf::set_kernel("res_ln256_bwd_kernel");
-    hipLaunchKernelGGL(res_ln256_bwd_kernel, grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16, gy_plus, ds32,
-                       (__bf16*)ds16, dgamma, dbeta, rows, rpb);
+#define RLN_BWD(A, B, C)                                                                                                          \
+    hipLaunchKernelGGL((res_ln256_bwd_kernel<A, B, C>), grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16, gy_plus, \
+                       ds32, (__bf16*)ds16, dgamma, dbeta, rows, rpb)
+    switch ((gy32 ? 4 : 0) | (gy16 ? 2 : 0) | (gy_plus ? 1 : 0)) {
+        case 1: RLN_BWD(false, false, true); break;
+        case 2: RLN_BWD(false, true, false); break;
+        case 3: RLN_BWD(false, true, true); break;
+        case 4: RLN_BWD(true, false, false); break;
+        case 5: RLN_BWD(true, false, true); break;
+        case 6: RLN_BWD(true, true, false); break;
+        default: RLN_BWD(true, true, true); break;
+    }
+#undef RLN_BWD
     return mpf::check(hipGetLastError(), "mpf_res_ln256_backward");
 }
 
