@@ -11,6 +11,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
+template <bool RES>
 __global__ __launch_bounds__(256) void bias_act_bf16_kernel(const bf16x8* __restrict__ x, const float* __restrict__ bias,
                                                             const bf16x8* __restrict__ res, bf16x8* __restrict__ y,
                                                             int64_t n8, int C, int relu)
@@ -22,13 +23,13 @@ __global__ __launch_bounds__(256) void bias_act_bf16_kernel(const bf16x8* __rest
         const float4 b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
         const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         bf16x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (res) r = res[i];
+        if constexpr (RES) r = res[i];            // (compile-time: a load behind `if (res)` is waited for on its own)
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             // same rounding points as the unfused ops: (x + b) -> bf16, (+ res) -> bf16
             float t = (float)(__bf16)((float)v[j] + b[j]);
-            if (res) t = (float)(__bf16)(t + (float)r[j]);
+            if constexpr (RES) t = (float)(__bf16)(t + (float)r[j]);
             o[j] = (__bf16)(relu ? fmaxf(t, 0.f) : t);
         }
         y[i] = o;
@@ -64,8 +65,12 @@ extern "C" int mpf_bias_act(const void* x, const float* bias, const void* res, v
         const int64_t n8 = numel / 8;
         const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
         mpf::set_kernel("bias_act_bf16_kernel");
-        hipLaunchKernelGGL(bias_act_bf16_kernel, dim3(blocks), dim3(256), 0, st, (const bf16x8*)x, bias, (const bf16x8*)res,
-                           (bf16x8*)y, n8, C, relu);
+        if (res)
+            hipLaunchKernelGGL(bias_act_bf16_kernel<true>, dim3(blocks), dim3(256), 0, st, (const bf16x8*)x, bias, (const bf16x8*)res,
+                               (bf16x8*)y, n8, C, relu);
+        else
+            hipLaunchKernelGGL(bias_act_bf16_kernel<false>, dim3(blocks), dim3(256), 0, st, (const bf16x8*)x, bias, (const bf16x8*)res,
+                               (bf16x8*)y, n8, C, relu);
     } else if (dtype == MPF_F32) {
         const int64_t n4 = numel / 4;
         const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
