@@ -240,8 +240,10 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     const int q = row % Lq, nh = row / Lq, h = nh % H, n = nh / H;
     const int64_t sstride = (int64_t)N * H * Lq;
     float M = kNegInf;
+#pragma unroll 8
     for (int s = 0; s < splits; ++s) M = fmaxf(M, part_ml[(s * sstride + row) * 2]);
     float L = 0.f, O = 0.f;
+#pragma unroll 8
     for (int s = 0; s < splits; ++s) {
         const float ms = part_ml[(s * sstride + row) * 2];
         const float w = (ms == kNegInf) ? 0.f : __expf(ms - M);
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(256) void attn_sum_splits_kernel(const float* __res
     const int d = idx & 31, row = idx >> 5;
     const int q = row % Lq, nh = row / Lq, h = nh % H, n = nh / H;
     float acc = 0.f;
+#pragma unroll 8
     for (int s = 0; s < splits; ++s) acc += part[((int64_t)s * N * H * Lq + row) * kHD + d];
     out[((int64_t)q * N + n) * E + h * kHD + d] = __float2bfloat16(acc);
 }
