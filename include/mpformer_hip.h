@@ -520,6 +520,21 @@ int mpf_gemm3_conv3x3_wgrad(const float* dy, const float* x, float* c_part, floa
                             int rows_per_split, void* stream);
 
 /*
+ * mpf_gemm3_tn with a bf16 A operand and / or a bf16 result (a_dtype / c_dtype = MPF_F32 | MPF_BF16; no second addend / gate /
+ * row-periodic addend): a bf16 activation (a backbone feature map under autocast, the bf16 gradient of mask_features) is
+ * exactly its own first plane, so it enters the fp32 GEMM without a cast pass and at three products per K step; a bf16
+ * result (rounded to nearest even) is what the bf16 producer of that activation expects as its gradient.
+ */
+int mpf_gemm3_tn_ex(const void* a, int a_dtype, int64_t lda, const void* b_planes, const float* bias, const float* c_in, int64_t ldcin,
+                    void* c, int c_dtype, int64_t ldc, int M, int N, int K, int relu, void* stream);
+/*
+ * ... and the weight-gradient form with ONE bf16 operand (a = dY or b = x in bf16, the other fp32; Ndim % 128 == 0):
+ * c_part / csum_a as mpf_gemm3_nt (sum the splits with mpf_gemm3_nt_reduce).
+ */
+int mpf_gemm3_nt_ex(const void* a, int a_dtype, int64_t lda, const void* b, int b_dtype, int64_t ldb, float* c_part, float* csum_a,
+                    int R, int Mdim, int Ndim, int rows_per_split, void* stream);
+
+/*
  * mpf_gemm3_split for a LIST of weight matrices in one launch (all Linear weights of the encoder, both
  * orientations, once per step).  Item i: src fp32 [rows, cols] contiguous -> three bf16 planes at dst,
  * dst + plane_stride, dst + 2 * plane_stride (elements), written as [rows][dst_ld] (transpose = 0) or

@@ -102,24 +102,43 @@ def conv3x3(x, weight, bias=None):
 # :284-291) on channel-last planes ARE matrix products [N*H*W, Cin] x [Cin, Cout]: forward and input gradient on
 # mpf_gemm3_tn, weight + bias gradient on the split-over-rows mpf_gemm3_nt (bias gradient = its column sums).
 # ---------------------------------------------------------------------------------------------------------------------
+def _planes_any(x):
+    """[N, C, H, W] fp32 / bf16 whose images are dense [H*W, C] planes, dense across the batch, 16-byte aligned rows"""
+    if not (x.dim() == 4 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    N, C, H, W = x.shape
+    return (x.stride(1) == 1 and x.stride(3) == C and x.stride(2) == W * C and x.stride(0) == H * W * C
+            and x.data_ptr() % 16 == 0 and (C * x.element_size()) % 16 == 0)
+
+
 def supported_1x1(x, weight):
-    if not (os.environ.get("MPF_CONV1X1_GEMM3", "1") == "1" and is_cl_plane(x) and weight.dtype == torch.float32 and weight.dim() == 4):
+    if not (os.environ.get("MPF_CONV1X1_GEMM3", "1") == "1" and _planes_any(x) and weight.dtype == torch.float32 and weight.dim() == 4):
         return False
     N, C, H, W = x.shape
     Cout, Cin, kh, kw = weight.shape
-    return kh == 1 and kw == 1 and Cin == C and C % 32 == 0 and Cout % 32 == 0 and x.stride(0) == H * W * C
+    if x.dtype == torch.bfloat16 and os.environ.get("MPF_CONV1X1_BF16_IN", "1") != "1":
+        return False
+    return kh == 1 and kw == 1 and Cin == C and C % 32 == 0 and Cout % 32 == 0
 
 
 class _Conv1x1Fn(Function):
+    """x may be bf16 (a backbone feature map under autocast: it enters the fp32 GEMM as its own first plane — no cast pass,
+    three products instead of six — and receives a bf16 gradient straight from the GEMM epilogue); out_dtype bf16 makes the
+    result bf16 (rounded once: what ``.to(bfloat16)`` of the fp32 result would give) and the incoming gradient is then
+    consumed in bf16 as well."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        from .gemm3 import gemm3
+    def forward(ctx, x, weight, bias, out_dtype):
+        from .gemm3 import gemm3, gemm3_ex
         N, Cin, H, W = x.shape
         Cout = weight.shape[0]
         w2 = weight.view(Cout, Cin)
         pf, pb = split_weights_grouped([([w2], False), ([w2], True)])
         x2 = x.permute(0, 2, 3, 1).reshape(N * H * W, Cin)                      # view of the planes
-        y2 = gemm3(x2, pf, bias)
+        if x.dtype == torch.float32 and out_dtype == torch.float32:
+            y2 = gemm3(x2, pf, bias)
+        else:
+            y2 = gemm3_ex(x2, pf, bias, out_dtype=out_dtype)
         ctx.save_for_backward(x2, pb)
         ctx.dims, ctx.has_bias = (N, Cin, Cout, H, W), bias is not None
         return y2.view(N, H, W, Cout).permute(0, 3, 1, 2)
@@ -127,23 +146,34 @@ class _Conv1x1Fn(Function):
     @staticmethod
     def backward(ctx, gy):
         from .encoder_fused import _balanced_rps
-        from .gemm3 import gemm3, gemm3_nt, nt_reduce
+        from .gemm3 import gemm3, gemm3_ex, gemm3_nt, gemm3_nt_ex, nt_reduce
         x2, pb = ctx.saved_tensors
         N, Cin, Cout, H, W = ctx.dims
         g2 = gy.permute(0, 2, 3, 1).reshape(N * H * W, Cout)
         if g2.stride(1) != 1 or g2.stride(0) != Cout:
             g2 = g2.contiguous()
+        if g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16:
+            g2 = g2.float()                                                     # (not a case of the pixel decoder)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = gemm3(g2, pb).view(N, H, W, Cin).permute(0, 3, 1, 2)
+            if g2.dtype == torch.float32 and x2.dtype == torch.float32:
+                dx2 = gemm3(g2, pb)
+            else:
+                dx2 = gemm3_ex(g2, pb, out_dtype=x2.dtype)                       # bf16 input -> bf16 gradient, no cast pass
+            dx = dx2.view(N, H, W, Cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            c, ca, _ = gemm3_nt(g2, x2, _balanced_rps(g2.shape[0], Cout, Cin, g2.device), want_csum_a=True)
+            rps = _balanced_rps(g2.shape[0], Cout, Cin, g2.device)
+            mixed = g2.dtype != x2.dtype
+            if mixed and Cin % 128 == 0:
+                c, ca = gemm3_nt_ex(g2, x2, rps, want_csum_a=True)
+            else:
+                c, ca, _ = gemm3_nt(g2.float() if mixed else g2, x2.float() if mixed else x2, rps, want_csum_a=True)
             dw, db = nt_reduce(c, ca)
             dw = dw.view(Cout, Cin, 1, 1)
             if not ctx.has_bias:
                 db = None
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def conv1x1(x, weight, bias=None):
-    return _Conv1x1Fn.apply(x, weight, bias)
+def conv1x1(x, weight, bias=None, out_dtype=torch.float32):
+    return _Conv1x1Fn.apply(x, weight, bias, out_dtype)

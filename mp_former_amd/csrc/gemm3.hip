@@ -49,6 +49,7 @@ struct G3 {
     int64_t lda, ldc, ldcin, ldcin2, ldgate, plane;
     int M, N, K, a2_rows, relu, tiles_n, ntiles;
     int bias_cm, cin_cm, cin2_cm, gate_cm;   // 1, or 0 when the operand is absent (it then points at g3_const)
+    unsigned short* c16;                      // bf16 output instead of c (NULL: fp32)
     int cv_H, cv_W, cv_cin, cv_sign;          // 3x3 convolution mode (gemm3_conv_kernel): image size, channels per tap, +1 / -1
     int tm0, ntiles2, tiles_n2;      // mixed launch: row blocks >= tm0 are cut into ntiles2 tiles of 64 columns (tiles_n2 per row block)
 };
@@ -125,11 +126,30 @@ struct Acc {
     }
 
     // a_base / b_base: byte offset of the wave's first row in the A / B image
-    template <int AKC, int BKC, bool ONE = false>
+    template <int AKC, int BKC, bool ONE = false, bool A1 = false>
     __device__ __forceinline__ void step(const unsigned char* lds, int a_base, int b_base, int lane)
     {
         const int r16 = lane & 15, g = lane >> 4;
         const int a_frag = a_base + g * AKC + (r16 ^ (2 * g)) * 16, b_frag = b_base + g * BKC + (r16 ^ (2 * g)) * 16;
+        if (A1) {       // A is a bf16 matrix (its plane 0 is exact), B a split fp32 one: three products, smallest first
+            bf16x8 fa0[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa0[i] = as_frag(*reinterpret_cast<const uint4*>(lds + a_frag + i * 256));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                bf16x8 fb[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fb[pl] = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + pl * 4 * BKC + j * 256));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2], fa0[i], v[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa0[i], v[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa0[i], v[i][j], 0, 0, 0);
+            }
+            return;
+        }
         if (ONE) {      // bf16 operands: plane 0 is the whole value
             bf16x8 fa0[4];
 #pragma unroll
@@ -195,7 +215,8 @@ struct Acc<4, true> {
                 for (int e = 0; e < 16; ++e) v[i][j][e] = 0.f;
     }
 
-    template <int AKC, int BKC, bool ONE = false>
+    // A1 / B1: that operand is a bf16 matrix (only its plane 0 is non-zero): the products with its planes 1, 2 are skipped
+    template <int AKC, int BKC, bool ONE = false, bool A1 = false, bool B1 = false>
     __device__ __forceinline__ void step(const unsigned char* lds, int a_base, int b_base, int lane)
     {
         const int r32 = lane & 31, gh = lane >> 5;
@@ -221,12 +242,14 @@ struct Acc<4, true> {
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    fa[pl][t] = as_frag(*reinterpret_cast<const uint4*>(lds + a_base + (pl * 4 + kc) * AKC + t * 512 + sw));
-                    fb[pl][t] = as_frag(*reinterpret_cast<const uint4*>(lds + b_base + (pl * 4 + kc) * BKC + t * 512 + sw));
+                    if (pl == 0 || !A1) fa[pl][t] = as_frag(*reinterpret_cast<const uint4*>(lds + a_base + (pl * 4 + kc) * AKC + t * 512 + sw));
+                    if (pl == 0 || !B1) fb[pl][t] = as_frag(*reinterpret_cast<const uint4*>(lds + b_base + (pl * 4 + kc) * BKC + t * 512 + sw));
                 }
 #define G3_MMA32(PB, PA)                                                                                          \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int i = 0; i < 2; ++i)                   \
-        v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][j], fa[PA][i], v[i][j], 0, 0, 0);
+    if ((PA == 0 || !A1) && (PB == 0 || !B1)) {                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int i = 0; i < 2; ++i)               \
+            v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][j], fa[PA][i], v[i][j], 0, 0, 0);            \
+    }
             G3_MMA32(0, 2) G3_MMA32(2, 0) G3_MMA32(1, 1) G3_MMA32(0, 1) G3_MMA32(1, 0) G3_MMA32(0, 0)
 #undef G3_MMA32
         }
@@ -290,7 +313,21 @@ __device__ __forceinline__ void g3_epilogue(const G3& p, const Acc<NJ, false>& a
             if (p.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
             // ReLU backward: pass the gradient where the saved activation is > 0
             o = make_float4(gt[i].x > 0.f ? o.x : 0.f, gt[i].y > 0.f ? o.y : 0.f, gt[i].z > 0.f ? o.z : 0.f, gt[i].w > 0.f ? o.w : 0.f);
-            if (mok[i] && nok) *reinterpret_cast<float4*>(p.c + mrow[i] * p.ldc + n) = o;
+            if (mok[i] && nok) {
+                if (p.c16) {                 // (uniform; stores only) round to nearest even
+                    unsigned w[4];
+                    const float e[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        unsigned u = __float_as_uint(e[t]);
+                        u += 0x7fffu + ((u >> 16) & 1u);
+                        w[t] = u >> 16;
+                    }
+                    *reinterpret_cast<uint2*>(p.c16 + mrow[i] * p.ldc + n) = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+                } else {
+                    *reinterpret_cast<float4*>(p.c + mrow[i] * p.ldc + n) = o;
+                }
+            }
         }
     }
 }
@@ -299,9 +336,12 @@ __device__ __forceinline__ void g3_epilogue(const G3& p, const Acc<NJ, false>& a
 // CV: A is a channel-last image [N_img*H*W][Cin] and K runs over (tap, channel) of a 3x3 window — K step kt reads the
 // rows shifted by the tap's (dy, dx) (sign = -1: the transposed convolution of the input gradient); taps that fall off
 // the image contribute zeros (the loads stay unconditional on clamped rows, the registers are zeroed before the split).
-template <int BN, bool A2, bool CV = false>
+// ABF: A is a bf16 matrix (p.a points at 2-byte elements, lda in elements): its rows go to plane 0 of the LDS image as they
+// are (one 16-byte load per row and k-chunk, no split) and a K step is three products instead of six.
+template <int BN, bool A2, bool CV = false, bool ABF = false>
 __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, const int m0, const int n0)
 {
+    static_assert(!(ABF && (A2 || CV)), "bf16 A: no addend, no convolution mode");
     constexpr int NJ = BN / 32;                  // 16-column MFMA tiles per wave
     constexpr int kBKc = BN * 16;                // bytes per (plane, k-chunk) of the B image
     constexpr int kAbytes = 12 * kAKc;
@@ -316,8 +356,13 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
     const int akc = tid & 3;
     const int arow0 = tid >> 2, arow1 = 64 + (tid >> 2);
     const int aslot0 = arow0 ^ (2 * akc), aslot1 = arow1 ^ (2 * akc);       // LDS slot swizzle (see header)
-    const float* ap0 = p.a + (int64_t)min(m0 + arow0, p.M - 1) * p.lda + akc * 8;
-    const float* ap1 = p.a + (int64_t)min(m0 + arow1, p.M - 1) * p.lda + akc * 8;
+    // (ABF: the same expressions on 2-byte elements — half the byte offsets)
+    const float* ap0 = ABF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p.a) +
+                                                              (int64_t)min(m0 + arow0, p.M - 1) * p.lda + akc * 8)
+                           : p.a + (int64_t)min(m0 + arow0, p.M - 1) * p.lda + akc * 8;
+    const float* ap1 = ABF ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p.a) +
+                                                              (int64_t)min(m0 + arow1, p.M - 1) * p.lda + akc * 8)
+                           : p.a + (int64_t)min(m0 + arow1, p.M - 1) * p.lda + akc * 8;
     const float* a2p0 = nullptr;
     const float* a2p1 = nullptr;
     if (p.a2) {
@@ -388,7 +433,10 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
     }
 #define G3_LA(ra, vm, k0)                                                                    \
     {                                                                                        \
-        if constexpr (CV) G3_LOAD_A_CV(ra, vm, k0) else G3_LOAD_A(ra, k0)                    \
+        if constexpr (ABF) {        /* 8 bf16 = 16 bytes per row: (k0) elements = (k0) / 2 floats */ \
+            ra[0] = *reinterpret_cast<const float4*>(ap0 + (k0) / 2);                        \
+            ra[2] = *reinterpret_cast<const float4*>(ap1 + (k0) / 2);                        \
+        } else if constexpr (CV) G3_LOAD_A_CV(ra, vm, k0) else G3_LOAD_A(ra, k0)             \
     }
 #define G3_WRITE(ra, vm)                                                                     \
     {                                                                                        \
@@ -405,6 +453,10 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         if constexpr (A2) {                                                                  \
             w0_ = add4(w0_, ra2[0]); w1_ = add4(w1_, ra2[1]); w2_ = add4(w2_, ra2[2]); w3_ = add4(w3_, ra2[3]); \
         }                                                                                    \
+        if constexpr (ABF) {                                                                 \
+            *reinterpret_cast<float4*>(lds + (0 * 4 + akc) * kAKc + aslot0 * 16) = w0_;      \
+            *reinterpret_cast<float4*>(lds + (0 * 4 + akc) * kAKc + aslot1 * 16) = w2_;      \
+        } else {                                                                             \
         split8(w0_, w1_, &h, &m, &l);                                                        \
         *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + aslot0 * 16) = h;             \
         *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + aslot0 * 16) = m;             \
@@ -413,6 +465,7 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + aslot1 * 16) = h;             \
         *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + aslot1 * 16) = m;             \
         *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKc + aslot1 * 16) = l;             \
+        }                                                                                    \
         *reinterpret_cast<uint4*>(lds + bdst[0]) = rb0;                                      \
         *reinterpret_cast<uint4*>(lds + bdst[1]) = rb1;                                      \
         *reinterpret_cast<uint4*>(lds + bdst[2]) = rb2;                                      \
@@ -456,7 +509,7 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         G3_LA(raE, vmE, min((kt + 2) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
         G3_T(3);
-        acc.template step<kAKc, kBKc>(lds, a_frag, b_frag, lane);
+        acc.template step<kAKc, kBKc, false, ABF>(lds, a_frag, b_frag, lane);
         G3_T(4);
         if (kt + 1 >= nk) break;
         __syncthreads();
@@ -470,7 +523,7 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         G3_LA(raO, vmO, min((kt + 3) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
         G3_T(3);
-        acc.template step<kAKc, kBKc>(lds, a_frag, b_frag, lane);
+        acc.template step<kAKc, kBKc, false, ABF>(lds, a_frag, b_frag, lane);
         G3_T(4);
     }
 #ifdef G3_TIMING
@@ -499,6 +552,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
     if (tile >= p.ntiles) return;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     g3_tn_tile<BN, A2>(p, lds, tm * kBM, tn * BN);
+}
+
+// A in bf16 (g3_tn_tile<.., ABF>): activations that ARE bf16 (the backbone's feature maps under autocast, the bf16
+// gradient of mask_features) enter the fp32 GEMM without a cast pass and at three products per K step
+template <int BN>
+__global__ __launch_bounds__(kThreads, 2) void gemm3_tn_abf_kernel(G3 p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 12 * BN * 16];
+    const int per_xcd = (p.ntiles + 7) >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (tile >= p.ntiles) return;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    g3_tn_tile<BN, false, false, true>(p, lds, tm * kBM, tn * BN);
 }
 
 // 3x3 convolution (stride 1, zero padding 1) of channel-last images as ONE GEMM with K = 9 * Cin (g3_tn_tile<.., CV>)
@@ -564,9 +630,12 @@ struct G3N {
 //   dW2[co][tap * Cin + ci] = sum_r dY[r][co] * X[r + dy(tap) * W + dx(tap)][ci]   (taps off the image contribute nothing):
 // the column tile fixes the tap (Cin % 128 == 0), so the row shift of the B operand is a per-workgroup scalar, and with
 // W % 8 == 0 the 8 rows of a k-chunk lie in one image row, so a row's validity is wave-uniform as well.
-template <int BN, bool BF = false, bool CV = false>
+// A16 / B16 (BN = 128, fp32 result): that operand is a bf16 matrix (2-byte elements, its lda / ldb in elements): loaded with
+// 2-byte reads into plane 0 only, and the products with its planes 1, 2 are skipped (three instead of six).
+template <int BN, bool BF = false, bool CV = false, bool A16 = false, bool B16 = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
 {
+    static_assert(!((A16 || B16) && (BF || CV || BN != 128)), "mixed-precision operands: plain 128-column tiles only");
     constexpr int NJ = BN / 32;
     constexpr int kBKc = BN * 16;
     constexpr int kAbytes = 12 * kAKc;
@@ -622,15 +691,24 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
     }
     // buffer descriptors: voffset = the lane's column (bytes), soffset = the row (bytes, scalar when the k-chunk
     // is wave-uniform)
-    constexpr int ES = BF ? 2 : 4;
+    constexpr int ESA = (BF || A16) ? 2 : 4, ESB = (BF || B16) ? 2 : 4;
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
-    const int acolb = acolx * ES, bcolb0 = bcolx[0] * ES, bcolb1 = bcolx[1] * ES;
-    const int ldab = (int)p.lda * ES, ldbb = (int)p.ldb * ES;
-    auto ld = [&](const __amdgpu_buffer_rsrc_t rs, int colb, int rowb, bool uniform) -> float {
+    const int acolb = acolx * ESA, bcolb0 = bcolx[0] * ESB, bcolb1 = bcolx[1] * ESB;
+    const int ldab = (int)p.lda * ESA, ldbb = (int)p.ldb * ESB;
+    auto ld16 = [&](const __amdgpu_buffer_rsrc_t rs, int colb, int rowb, bool uniform) -> float {
         const int vo = uniform ? colb : colb + rowb, so = uniform ? rowb : 0;
-        if (BF) return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0) << 16);
+        return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0) << 16);
+    };
+    auto ld32 = [&](const __amdgpu_buffer_rsrc_t rs, int colb, int rowb, bool uniform) -> float {
+        const int vo = uniform ? colb : colb + rowb, so = uniform ? rowb : 0;
         return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+    };
+    auto ld = [&](const __amdgpu_buffer_rsrc_t rs, int colb, int rowb, bool uniform) -> float {     // the B operand (and CV)
+        return (BF || B16) ? ld16(rs, colb, rowb, uniform) : ld32(rs, colb, rowb, uniform);
+    };
+    auto lda_ = [&](const __amdgpu_buffer_rsrc_t rs, int colb, int rowb, bool uniform) -> float {  // the A operand
+        return (BF || A16) ? ld16(rs, colb, rowb, uniform) : ld32(rs, colb, rowb, uniform);
     };
 
     float xa0[8], xa1[8], xb0[8], xb1[8];
@@ -646,7 +724,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
             const int rb0 = (r0) + bkc_[0] * 8 + j, rb1 = (r0) + bkc_[1] * 8 + j;                      \
             const int ca0 = TAIL ? min(ra0, r_end - 1) : ra0, ca1 = TAIL ? min(ra1, r_end - 1) : ra1;  \
             const int cb0 = TAIL ? min(rb0, r_end - 1) : rb0, cb1 = TAIL ? min(rb1, r_end - 1) : rb1;  \
-            float va0 = ld(ars, acolb, ca0 * ldab, true), va1 = ld(ars, acolb, ca1 * ldab, true);      \
+            float va0 = lda_(ars, acolb, ca0 * ldab, true), va1 = lda_(ars, acolb, ca1 * ldab, true);  \
             float vb0, vb1;                                                                            \
             if constexpr (CV) {                                                                        \
                 const int sb0 = min(max(cb0 + cv_sh, 0), p.R - 1), sb1 = min(max(cb1 + cv_sh, 0), p.R - 1); \
@@ -700,21 +778,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
             uint4 h, m, l;
             split8(make_float4(xa0[0], xa0[1], xa0[2], xa0[3]), make_float4(xa0[4], xa0[5], xa0[6], xa0[7]), &h, &m, &l);
             *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = h;
-            if (!BF) *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = m;
-            if (!BF) *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = l;
+            if (!BF && !A16) *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = m;
+            if (!BF && !A16) *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = l;
             split8(make_float4(xa1[0], xa1[1], xa1[2], xa1[3]), make_float4(xa1[4], xa1[5], xa1[6], xa1[7]), &h, &m, &l);
             *reinterpret_cast<uint4*>(lds + (0 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = h;
-            if (!BF) *reinterpret_cast<uint4*>(lds + (1 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = m;
-            if (!BF) *reinterpret_cast<uint4*>(lds + (2 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = l;
+            if (!BF && !A16) *reinterpret_cast<uint4*>(lds + (1 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = m;
+            if (!BF && !A16) *reinterpret_cast<uint4*>(lds + (2 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = l;
             split8(make_float4(xb0[0], xb0[1], xb0[2], xb0[3]), make_float4(xb0[4], xb0[5], xb0[6], xb0[7]), &h, &m, &l);
             *reinterpret_cast<uint4*>(lds + kAbytes + (0 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = h;
-            if (!BF) *reinterpret_cast<uint4*>(lds + kAbytes + (1 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = m;
-            if (!BF) *reinterpret_cast<uint4*>(lds + kAbytes + (2 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = l;
+            if (!BF && !B16) *reinterpret_cast<uint4*>(lds + kAbytes + (1 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = m;
+            if (!BF && !B16) *reinterpret_cast<uint4*>(lds + kAbytes + (2 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = l;
             if (b_ok[1]) {
                 split8(make_float4(xb1[0], xb1[1], xb1[2], xb1[3]), make_float4(xb1[4], xb1[5], xb1[6], xb1[7]), &h, &m, &l);
                 *reinterpret_cast<uint4*>(lds + kAbytes + (0 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = h;
-                if (!BF) *reinterpret_cast<uint4*>(lds + kAbytes + (1 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = m;
-                if (!BF) *reinterpret_cast<uint4*>(lds + kAbytes + (2 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = l;
+                if (!BF && !B16) *reinterpret_cast<uint4*>(lds + kAbytes + (1 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = m;
+                if (!BF && !B16) *reinterpret_cast<uint4*>(lds + kAbytes + (2 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = l;
             }
             if (want_csa) {
 #pragma unroll
@@ -727,7 +805,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
         }
         __syncthreads();
         if (r0 + 2 * kBK <= r_end) G3N_LOAD(r0 + kBK, false) else if (r0 + kBK < r_end) G3N_LOAD(r0 + kBK, true);
-        acc.template step<kAKc, kBKc, BF>(lds, a_frag, b_frag, lane);
+        if constexpr (A16 || B16) acc.template step<kAKc, kBKc, false, A16, B16>(lds, a_frag, b_frag, lane);
+        else acc.template step<kAKc, kBKc, BF>(lds, a_frag, b_frag, lane);
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
@@ -874,7 +953,7 @@ extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2
     p.a = a; p.a2 = a2; p.bp = (const unsigned short*)b_planes; p.bias = bias; p.cin = c_in; p.c = c;
     p.cin2 = c_in2; p.gate = gate; p.ldcin2 = ldcin2; p.ldgate = ldgate;
     p.lda = lda; p.ldc = ldc; p.ldcin = ldcin; p.plane = (int64_t)N * K;
-    p.M = M; p.N = N; p.K = K; p.a2_rows = a2_rows; p.relu = relu;
+    p.M = M; p.N = N; p.K = K; p.a2_rows = a2_rows; p.relu = relu; p.c16 = nullptr;
     {
         static const float* consts = nullptr;
         if (!consts) {
@@ -937,6 +1016,57 @@ extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2
     return mpf::check(hipGetLastError(), "mpf_gemm3_tn");
 }
 
+extern "C" int mpf_gemm3_tn_ex(const void* a, int a_dtype, int64_t lda, const void* b_planes, const float* bias, const float* c_in,
+                               int64_t ldcin, void* c, int c_dtype, int64_t ldc, int M, int N, int K, int relu, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!a || !b_planes || !c) return mpf::fail(MPF_E_NULL, "gemm3_tn_ex: NULL buffer");
+    if ((a_dtype != MPF_F32 && a_dtype != MPF_BF16) || (c_dtype != MPF_F32 && c_dtype != MPF_BF16))
+        return mpf::fail(MPF_E_DTYPE, "gemm3_tn_ex: a / c must be MPF_F32 or MPF_BF16");
+    const int aal = a_dtype == MPF_BF16 ? 8 : 4;
+    if (M <= 0 || N <= 0 || K <= 0 || K % kBK != 0 || N % 4 != 0 || lda % aal != 0 || ldc % 4 != 0 || (c_in && ldcin % 4 != 0) ||
+        ((uintptr_t)a & 15))
+        return mpf::fail(MPF_E_SHAPE, "gemm3_tn_ex: K must be a multiple of 32, N / ldc of 4, 16-byte aligned A rows");
+    if (a_dtype == MPF_F32 && c_dtype == MPF_F32)
+        return mpf_gemm3_tn((const float*)a, lda, nullptr, 0, b_planes, bias, c_in, ldcin, nullptr, 0, nullptr, 0, (float*)c, ldc, M, N, K, relu, stream);
+    static const float* consts = nullptr;
+    if (!consts) {
+        void* sym = nullptr;
+        if (hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g3_const)); e != hipSuccess) return mpf::check(e, "gemm3_tn_ex: constants");
+        consts = (const float*)sym;
+    }
+    G3 p;
+    p.a = (const float*)a; p.a2 = nullptr; p.bp = (const unsigned short*)b_planes;
+    p.bias = bias ? bias : consts; p.bias_cm = bias ? 1 : 0;
+    p.cin = c_in ? c_in : consts; p.ldcin = c_in ? ldcin : 0; p.cin_cm = c_in ? 1 : 0;
+    p.cin2 = consts; p.ldcin2 = 0; p.cin2_cm = 0; p.gate = consts + 4; p.ldgate = 0; p.gate_cm = 0;
+    p.c = c_dtype == MPF_F32 ? (float*)c : nullptr; p.c16 = c_dtype == MPF_BF16 ? (unsigned short*)c : nullptr;
+    p.lda = lda; p.ldc = ldc; p.plane = (int64_t)N * K;
+    p.M = M; p.N = N; p.K = K; p.a2_rows = 0; p.relu = relu;
+    p.cv_H = p.cv_W = p.cv_cin = 0; p.cv_sign = 1;
+    p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
+    const int tiles_m = (M + kBM - 1) / kBM;
+    const int waste128 = ((N + 127) / 128) * 128 - N, waste96 = ((N + 95) / 96) * 96 - N;
+    const bool use96 = waste96 < waste128;
+    p.tiles_n = use96 ? (N + 95) / 96 : (N + 127) / 128;
+    p.ntiles = tiles_m * p.tiles_n;
+    const dim3 grid(((p.ntiles + 7) / 8) * 8);
+    mpf::prof_begin(st);
+    if (a_dtype == MPF_BF16) {
+        mpf::set_kernel("gemm3_tn_kernel<a16>");
+        if (use96) hipLaunchKernelGGL(gemm3_tn_abf_kernel<96>, grid, dim3(kThreads), 0, st, p);
+        else hipLaunchKernelGGL(gemm3_tn_abf_kernel<128>, grid, dim3(kThreads), 0, st, p);
+    } else {
+        mpf::set_kernel("gemm3_tn_kernel<c16>");
+        if (use96) hipLaunchKernelGGL((gemm3_tn_kernel<96, false>), grid, dim3(kThreads), 0, st, p);
+        else hipLaunchKernelGGL((gemm3_tn_kernel<128, false>), grid, dim3(kThreads), 0, st, p);
+    }
+    // flops: the fp32 GEMM it stands for (a bf16 A needs 3 of the 6 products)
+    mpf::prof_end(mpf_last_kernel(), st, (a_dtype == MPF_BF16 ? 2.0 : 4.0) * (double)M * K + (c_dtype == MPF_BF16 ? 2.0 : 4.0) * (double)M * N + 6.0 * (double)N * K,
+                  2.0 * M * (double)N * K);
+    return mpf::check(hipGetLastError(), "mpf_gemm3_tn_ex");
+}
+
 extern "C" int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const float* bias, float* y, int n_img, int H, int W, int Cin,
                                  int Cout, int transposed, void* stream)
 {
@@ -957,7 +1087,7 @@ extern "C" int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const flo
     p.bias = bias ? bias : consts; p.bias_cm = bias ? 1 : 0;
     p.cin = consts; p.ldcin = 0; p.cin_cm = 0; p.cin2 = consts; p.ldcin2 = 0; p.cin2_cm = 0; p.gate = consts + 4; p.ldgate = 0; p.gate_cm = 0;
     p.M = (int)M64; p.N = Cout; p.K = 9 * Cin; p.lda = Cin; p.ldc = Cout; p.plane = (int64_t)Cout * p.K;
-    p.a2_rows = 0; p.relu = 0;
+    p.a2_rows = 0; p.relu = 0; p.c16 = nullptr;
     p.cv_H = H; p.cv_W = W; p.cv_cin = Cin; p.cv_sign = transposed ? -1 : 1;
     p.tiles_n = (Cout + 127) / 128;
     p.ntiles = ((p.M + kBM - 1) / kBM) * p.tiles_n;
@@ -1054,6 +1184,43 @@ __global__ __launch_bounds__(256) void nt_reduce_kernel(const float* __restrict_
 }
 
 }  // namespace
+
+extern "C" int mpf_gemm3_nt_ex(const void* a, int a_dtype, int64_t lda, const void* b, int b_dtype, int64_t ldb, float* c_part,
+                               float* csum_a, int R, int Mdim, int Ndim, int rows_per_split, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!a || !b || !c_part) return mpf::fail(MPF_E_NULL, "gemm3_nt_ex: NULL buffer");
+    const bool a16 = a_dtype == MPF_BF16, b16 = b_dtype == MPF_BF16;
+    if ((!a16 && a_dtype != MPF_F32) || (!b16 && b_dtype != MPF_F32) || (a16 && b16))
+        return mpf::fail(MPF_E_DTYPE, "gemm3_nt_ex: operands are MPF_F32 or MPF_BF16, at most one of them bf16 (both: mpf_gemm_nt_bf16)");
+    if (!a16 && !b16)
+        return mpf_gemm3_nt((const float*)a, lda, (const float*)b, ldb, nullptr, 0, 0, c_part, csum_a, nullptr, R, Mdim, Ndim, rows_per_split, 0, stream);
+    if (R <= 0 || Mdim <= 0 || Ndim <= 0 || Ndim % 128 != 0 || rows_per_split <= 0 || rows_per_split % kBK != 0)
+        return mpf::fail(MPF_E_SHAPE, "gemm3_nt_ex: Ndim must be a multiple of 128, rows_per_split a positive multiple of 32");
+    G3N p;
+    p.a = (const float*)a; p.b = (const float*)b; p.b2 = nullptr; p.c = c_part; p.csum_a = csum_a; p.csum_b = nullptr;
+    p.lda = lda; p.ldb = ldb; p.ldb2 = 0;
+    p.R = R; p.Mdim = Mdim; p.Ndim = Ndim; p.b2_rows = 0; p.rows_per_split = rows_per_split;
+    p.nsplit = (R + rows_per_split - 1) / rows_per_split;
+    p.transpose_out = 0;
+    p.cv_H = p.cv_W = p.cv_cin = 0;
+    {
+        const uint64_t ab = ((uint64_t)(R - 1) * lda + Mdim) * (a16 ? 2 : 4), bb = ((uint64_t)(R - 1) * ldb + Ndim) * (b16 ? 2 : 4);
+        if (ab >= (1ull << 32) || bb >= (1ull << 32)) return mpf::fail(MPF_E_TOO_LARGE, "gemm3_nt_ex: an operand spans 4 GiB or more");
+        p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    }
+    p.tiles_m = (Mdim + kBM - 1) / kBM;
+    p.tiles_n = Ndim / 128;
+    p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
+    const dim3 grid(((p.ntiles + 7) / 8) * 8);
+    mpf::prof_begin(st);
+    mpf::set_kernel(a16 ? "gemm3_nt_kernel<a16>" : "gemm3_nt_kernel<b16>");
+    if (a16) hipLaunchKernelGGL((gemm3_nt_kernel<128, false, false, true, false>), grid, dim3(kThreads), 0, st, p);
+    else hipLaunchKernelGGL((gemm3_nt_kernel<128, false, false, false, true>), grid, dim3(kThreads), 0, st, p);
+    mpf::prof_end(mpf_last_kernel(), st, (a16 ? 2.0 : 4.0) * (double)R * Mdim + (b16 ? 2.0 : 4.0) * (double)R * Ndim + 4.0 * (double)p.nsplit * Mdim * Ndim,
+                  2.0 * R * (double)Mdim * Ndim);
+    return mpf::check(hipGetLastError(), "mpf_gemm3_nt_ex");
+}
 
 extern "C" int mpf_gemm3_conv3x3_wgrad(const float* dy, const float* x, float* c_part, float* csum_dy, int n_img, int H, int W, int Cin,
                                        int Cout, int rows_per_split, void* stream)

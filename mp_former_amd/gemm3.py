@@ -151,3 +151,37 @@ def nt_reduce_levels(c_part, s_part, level_of_split, n_levels):
                                                      n_levels, c.data_ptr(), lvl.data_ptr(), s.data_ptr(), _stream(c_part))
     _lib.check(code, "mpf_gemm3_nt_reduce_levels")
     return c, lvl, s
+
+
+def gemm3_ex(a, planes, bias=None, cin=None, relu=False, out_dtype=torch.float32):
+    """gemm3 with a bf16 or fp32 A [M, K] (row stride free, rows 16-byte aligned) and a bf16 or fp32 result: a bf16
+    activation enters the fp32 GEMM as its own first plane (no cast pass, three products instead of six)."""
+    assert a.is_cuda and a.dim() == 2 and a.stride(1) == 1 and a.dtype in (torch.float32, torch.bfloat16)
+    M, K = a.shape
+    N = planes.shape[1]
+    assert planes.shape[2] == K and planes.dtype == torch.bfloat16 and planes.is_contiguous()
+    c = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}
+    with torch.cuda.device(a.device):
+        code = _lib.lib().mpf_gemm3_tn_ex(a.data_ptr(), dt[a.dtype], a.stride(0), planes.data_ptr(), _p(bias), _p(cin),
+                                          _rows(cin, N) if cin is not None else 0, c.data_ptr(), dt[out_dtype], N, M, N, K,
+                                          1 if relu else 0, _stream(a))
+    _lib.check(code, "mpf_gemm3_tn_ex")
+    return c
+
+
+def gemm3_nt_ex(a, b, rows_per_split, want_csum_a=False):
+    """gemm3_nt with ONE bf16 operand: a [R, M], b [R, N] (fp32 or bf16, not both bf16; N % 128 == 0) -> (c_part [ns, M, N],
+    csum_a [ns, M] or None).  The bf16 operand is its own first plane: three products per step."""
+    assert a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] == b.shape[0]
+    R, M = a.shape
+    N = b.shape[1]
+    ns = (R + rows_per_split - 1) // rows_per_split
+    c = torch.empty((ns, M, N), dtype=torch.float32, device=a.device)
+    ca = torch.empty((ns, M), dtype=torch.float32, device=a.device) if want_csum_a else None
+    dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}
+    with torch.cuda.device(a.device):
+        code = _lib.lib().mpf_gemm3_nt_ex(a.data_ptr(), dt[a.dtype], a.stride(0), b.data_ptr(), dt[b.dtype], b.stride(0), c.data_ptr(),
+                                          _p(ca), R, M, N, rows_per_split, _stream(a))
+    _lib.check(code, "mpf_gemm3_nt_ex")
+    return c, ca

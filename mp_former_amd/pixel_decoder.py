@@ -194,15 +194,18 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         return memory, spatial_shapes, level_start_index
 
 
-def _conv(m, x):
+def _conv(m, x, out_dtype=torch.float32):
     """m(x) for an nn.Conv2d-like module, on the split-bf16 GEMM when the input is channel-last planes and the shape is one
-    the GEMM forms take (3x3 / stride 1 / pad 1, or 1x1), else the library convolution."""
+    the GEMM forms take (3x3 / stride 1 / pad 1, or 1x1), else the library convolution.  x may be a bf16 feature map (1x1
+    only; anything else gets the ``.float()`` of msdeformattn.py:320); out_dtype = bf16 asks the 1x1 form for a bf16 result."""
     if m.groups == 1 and m.dilation == (1, 1) and m.stride == (1, 1):
+        if m.kernel_size == (1, 1) and m.padding == (0, 0) and conv3x3.supported_1x1(x, m.weight):
+            return conv3x3.conv1x1(x, m.weight, m.bias, out_dtype)
+        x = x.float()
         if m.kernel_size == (3, 3) and m.padding == (1, 1) and conv3x3.supported(x, m.weight):
             return conv3x3.conv3x3(x, m.weight, m.bias)
-        if m.kernel_size == (1, 1) and m.padding == (0, 0) and conv3x3.supported_1x1(x, m.weight):
-            return conv3x3.conv1x1(x, m.weight, m.bias)
-    return F.conv2d(x, m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups)
+    y = F.conv2d(x.float(), m.weight, m.bias, m.stride, m.padding, m.dilation, m.groups)
+    return y.to(out_dtype) if out_dtype != torch.float32 else y
 
 
 class _ConvNorm(nn.Conv2d):
@@ -304,15 +307,16 @@ class MSDeformAttnPixelDecoder(nn.Module):
 
     def forward_features(self, features):
         # the reference pins the whole pixel decoder to fp32 even under AMP (msdeformattn.py:314,320)
+        amp_bf16 = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
         with torch.autocast(device_type="cuda", enabled=False):
-            return self._forward_features_fp32(features)
+            return self._forward_features_fp32(features, amp_bf16 and os.environ.get("MPF_MASK_FEATURES_BF16", "1") == "1")
 
-    def _forward_features_fp32(self, features):
+    def _forward_features_fp32(self, features, mask_features_bf16=False):
         srcs, pos = [], []
         for idx, f in enumerate(self.transformer_in_features[::-1]):
-            x = features[f].float()
+            x = features[f]                       # (bf16 under autocast: the 1x1 GEMM form takes it as it is; else .float())
             proj = self.input_proj[idx]
-            srcs.append(proj[1](_conv(proj[0], x)) if len(proj) == 2 else proj(x))
+            srcs.append(proj[1](_conv(proj[0], x)) if len(proj) == 2 else proj(x.float()))
             pos.append(self.pe_layer(x))
         y, spatial_shapes, level_start_index = self.transformer(srcs, pos)
         bs = y.shape[0]
@@ -320,7 +324,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         out = [z.transpose(1, 2).reshape(bs, -1, srcs[i].shape[2], srcs[i].shape[3])
                for i, z in enumerate(torch.split(y, sizes, dim=1))]
         for idx, f in enumerate(self.in_features[:self.num_fpn_levels][::-1]):
-            x = features[f].float()
+            x = features[f]
             lat = self.lateral_convs[idx]
             if isinstance(lat.norm, GroupNorm) and lat.activation is None:
                 z = _conv(lat, x)
@@ -328,9 +332,17 @@ class MSDeformAttnPixelDecoder(nn.Module):
                     # norm(lateral) + upsample2x(top) in the norm's apply pass (msdeformattn.py:349-351)
                     out.append(self.output_convs[idx](lat.norm.forward_cl(z, top=out[-1])))
                     continue
-            cur_fpn = self.lateral_convs[idx](x)
+            cur_fpn = self.lateral_convs[idx](x.float())
             top = to_nchw(out[-1]) if os.environ.get("MPF_FPN_NCHW_TOP", "1") == "1" else out[-1]
             y = cur_fpn + F.interpolate(top, size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)
             out.append(self.output_convs[idx](y))
         multi_scale_features = out[:self.maskformer_num_feature_levels]
-        return self.mask_features(out[-1]), out[0], multi_scale_features
+        mfc = self.mask_features
+        if (mask_features_bf16 and mfc.norm is None and mfc.activation is None and mfc.kernel_size == (1, 1)
+                and conv3x3.supported_1x1(out[-1], mfc.weight)):
+            # under bf16 autocast the only consumer (the decoder) casts mask_features to bf16 first thing: emit them in bf16
+            # from the GEMM epilogue (the same single rounding) and take their gradient in bf16 — two 134 MB cast passes less
+            mf = _conv(mfc, out[-1], torch.bfloat16)
+        else:
+            mf = mfc(out[-1])
+        return mf, out[0], multi_scale_features

@@ -59,3 +59,33 @@ def test_conv1x1_matches_conv2d(N, C, Co, H, W, bias):
     torch.testing.assert_close(w.grad.double(), wr.grad, rtol=1e-4, atol=1e-5 * float(wr.grad.abs().max()) + 1e-6)
     if bias:
         torch.testing.assert_close(b.grad.double(), br.grad, rtol=1e-4, atol=1e-5 * float(br.grad.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("N,C,Co,H,W,mode", [(2, 256, 256, 24, 20, "bf16_in"), (1, 512, 256, 9, 8, "bf16_in"), (2, 256, 256, 16, 12, "bf16_out"),
+                                              (2, 96, 64, 6, 6, "bf16_in")])
+def test_conv1x1_bf16_input_or_output(N, C, Co, H, W, mode):
+    """bf16 feature map in (no cast pass, bf16 input gradient out of the GEMM epilogue) / bf16 result out (its gradient taken
+    in bf16): the values of the fp32 convolution on the same numbers, rounded once."""
+    from mp_former_amd.conv3x3 import conv1x1, supported_1x1
+    dev = torch.device("cuda:0")
+    torch.manual_seed(C + W)
+    xdt = torch.bfloat16 if mode == "bf16_in" else torch.float32
+    odt = torch.bfloat16 if mode == "bf16_out" else torch.float32
+    x = torch.randn(N, H, W, C, device=dev).to(xdt).permute(0, 3, 1, 2).requires_grad_(True)
+    w = (torch.randn(Co, C, 1, 1, device=dev) / C ** 0.5).requires_grad_(True)
+    b = torch.randn(Co, device=dev).requires_grad_(True)
+    assert supported_1x1(x, w)
+    y = conv1x1(x, w, b, odt)
+    assert y.dtype == odt
+    xr, wr, br = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br)
+    tol = 2.0 ** -8 if odt == torch.bfloat16 else 4e-6
+    assert float((y.double() - yr).abs().max()) <= tol * (float(yr.abs().max()) + 1.0)
+    g = torch.randn(N, Co, H, W, device=dev).to(odt)
+    y.backward(g)
+    yr.backward(g.double())
+    assert x.grad.dtype == xdt
+    tolx = 2.0 ** -8 if xdt == torch.bfloat16 else 4e-6
+    assert float((x.grad.double() - xr.grad).abs().max()) <= tolx * (float(xr.grad.abs().max()) + 1.0)
+    torch.testing.assert_close(w.grad.double(), wr.grad, rtol=1e-4, atol=1e-5 * float(wr.grad.abs().max()) + 1e-6)
+    torch.testing.assert_close(b.grad.double(), br.grad, rtol=1e-4, atol=1e-5 * float(br.grad.abs().max()) + 1e-6)

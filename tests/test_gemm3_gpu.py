@@ -104,3 +104,51 @@ def test_gemm3_nt_weight_gradient_accuracy(R, M, N, rps):
     assert float(e3.max()) <= 1e-5 * (float(ref.abs().max()) + 1.0)
     assert float(e3.mean()) <= 1.25 * float(el.mean()) + 1e-9, (float(e3.mean()), float(el.mean()))
     torch.testing.assert_close(db.double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K,adt,cdt", [(300, 288, 64, "bf16", "f32"), (4099, 256, 512, "bf16", "f32"), (1000, 256, 256, "f32", "bf16"),
+                                            (129, 128, 2048, "bf16", "bf16"), (640, 96, 96, "bf16", "f32")])
+def test_gemm3_tn_bf16_operand_and_result(M, N, K, adt, cdt):
+    """mpf_gemm3_tn_ex: a bf16 A is its own first plane (three products), a bf16 result is the fp32 result rounded once."""
+    from mp_former_amd import _lib
+    from mp_former_amd.gemm3 import gemm3, gemm3_ex, split_weight
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + K)
+    T = {"bf16": torch.bfloat16, "f32": torch.float32}
+    a = torch.randn(M, K, device=dev).to(T[adt])
+    w = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev)
+    cin = torch.randn(M, N, device=dev)
+    planes = split_weight(w)
+    got = gemm3_ex(a, planes, b, cin=cin, relu=True, out_dtype=T[cdt])
+    assert _lib.last_kernel() == ("gemm3_tn_kernel<a16>" if adt == "bf16" else "gemm3_tn_kernel<c16>"), _lib.last_kernel()
+    ref = (a.double() @ w.double().t() + b.double() + cin.double()).relu()
+    full = gemm3(a.float(), planes, b, cin=cin, relu=True)          # the six-product kernel on the same values
+    scale = float(ref.abs().max()) + 1.0
+    if cdt == "f32":
+        assert float((got.double() - ref).abs().max()) <= 4e-6 * scale * max(1.0, (K / 256) ** 0.5)
+        assert float((got - full).abs().max()) <= 4e-6 * scale * max(1.0, (K / 256) ** 0.5)
+    else:
+        assert got.dtype == torch.bfloat16
+        assert torch.equal(got, full.to(torch.bfloat16)) or float((got.float() - full).abs().max()) <= 2.0 ** -8 * scale
+
+
+@pytest.mark.parametrize("R,M,N,rps,which", [(4096, 256, 256, 512, "a"), (3000, 256, 1024, 352, "b"), (2048, 100, 128, 256, "b"),
+                                              (1000, 288, 2048, 128, "a")])
+def test_gemm3_nt_one_bf16_operand(R, M, N, rps, which):
+    from mp_former_amd import _lib
+    from mp_former_amd.gemm3 import gemm3_nt_ex, nt_reduce
+    dev = torch.device("cuda:0")
+    torch.manual_seed(R + N)
+    g = torch.randn(R, M, device=dev)
+    x = torch.randn(R, N, device=dev)
+    if which == "a":
+        g = g.to(torch.bfloat16)
+    else:
+        x = x.to(torch.bfloat16)
+    c, ca = gemm3_nt_ex(g, x, rps, want_csum_a=True)
+    assert _lib.last_kernel() == f"gemm3_nt_kernel<{which}16>", _lib.last_kernel()
+    dw, db = nt_reduce(c, ca)
+    ref = g.double().t() @ x.double()
+    assert float((dw.double() - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1.0)
+    torch.testing.assert_close(db.double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
