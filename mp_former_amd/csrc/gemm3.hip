@@ -1328,12 +1328,31 @@ __global__ __launch_bounds__(256) void nt_reduce_levels_kernel(const float* __re
     }
     const int64_t j = 2 * (q - cq);
     float2 acc[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
-    for (int sp = 0; sp < nsplit; ++sp) {
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8) {                       // 8 splits in flight (loads first, then the selects)
+        float2 t[8];
+        int lv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            t[k] = *reinterpret_cast<const float2*>(s_part + (int64_t)(sp + k) * sn + j);
+            lv[k] = (int)level_of_split[sp + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                acc[l].x += lv[k] == l ? t[k].x : 0.f;
+                acc[l].y += lv[k] == l ? t[k].y : 0.f;
+            }
+    }
+    for (; sp < nsplit; ++sp) {
         const float2 t = *reinterpret_cast<const float2*>(s_part + (int64_t)sp * sn + j);
         const int lv = (int)level_of_split[sp];
 #pragma unroll
-        for (int l = 0; l < 4; ++l)
-            if (lv == l) { acc[l].x += t.x; acc[l].y += t.y; }
+        for (int l = 0; l < 4; ++l) {
+            acc[l].x += lv == l ? t.x : 0.f;
+            acc[l].y += lv == l ? t.y : 0.f;
+        }
     }
     float2 tot = make_float2(0.f, 0.f);
 #pragma unroll
