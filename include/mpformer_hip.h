@@ -647,6 +647,12 @@ int mpf_res_ln256_forward(const float* x, const void* t, int t_dtype, const floa
 int mpf_res_ln256_backward(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
                            const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta,
                            int rows, void* stream);
+/* The same with dgamma / dbeta reduced through per-workgroup partials in a fixed order (no float atomics: deterministic, and
+ * the two vectors need no zero-initialisation).  workspace: mpf_res_ln256_backward_workspace_bytes(rows) bytes. */
+size_t mpf_res_ln256_backward_workspace_bytes(int rows);
+int mpf_res_ln256_backward_ws(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                              const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta, int rows,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Same gradient as mpf_mask_loss_backward, written WITHOUT global atomics and without an fp32 image:

@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void res_ln256_fwd_kernel(const float* __restr
     if ((threadIdx.x & 63) == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-template <bool G32, bool G16, bool GP>
+// PART: the block's dgamma / dbeta sums go to partial[block][2][256] (summed in a fixed order by ln_partial_reduce_kernel)
+// instead of float atomics into zero-initialised vectors: deterministic, no pre-zeroing, no contended atomics
+template <bool G32, bool G16, bool GP, bool PART = false>
 __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restrict__ s, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ gy32, const __bf16* __restrict__ gy16,
@@ -189,8 +191,36 @@ __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restr
     *reinterpret_cast<float4*>(&red[1][wave][c]) = ab;
     __syncthreads();
     const int col = threadIdx.x;
-    atomicAdd(dgamma + col, red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]);
-    atomicAdd(dbeta + col, red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col]);
+    const float sg = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+    const float sb = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+    if constexpr (PART) {       // dgamma doubles as the partial buffer pointer
+        dgamma[(int64_t)blockIdx.x * 512 + col] = sg;
+        dgamma[(int64_t)blockIdx.x * 512 + 256 + col] = sb;
+    } else {
+        atomicAdd(dgamma + col, sg);
+        atomicAdd(dbeta + col, sb);
+    }
+}
+
+// out[which][col] = sum over blocks of partial[block][which][col]; grid = 2 (which), 256 threads x 4 block slices via LDS
+__global__ __launch_bounds__(1024) void ln_partial_reduce_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta)
+{
+    __shared__ float red[4][256];
+    const int which = blockIdx.x, col = threadIdx.x & 255, sl = threadIdx.x >> 8;
+    float acc = 0.f;
+    int b = sl;
+    for (; b + 28 < blocks; b += 32) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = partial[(int64_t)(b + 4 * k) * 512 + which * 256 + col];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += t[k];
+    }
+    for (; b < blocks; b += 4) acc += partial[(int64_t)b * 512 + which * 256 + col];
+    red[sl][col] = acc;
+    __syncthreads();
+    if (sl == 0) (which ? dbeta : dgamma)[col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
 }
 
 }  // namespace
@@ -246,6 +276,47 @@ extern "C" int mpf_res_ln256_backward(const float* s, const float* mean, const f
     }
 #undef RLN_BWD
     return mpf::check(hipGetLastError(), "mpf_res_ln256_backward");
+}
+
+extern "C" size_t mpf_res_ln256_backward_workspace_bytes(int rows)
+{
+    if (rows <= 0) return 0;
+    int rpb = (rows + 1023) / 1024;
+    rpb = ((rpb + 3) / 4) * 4;
+    return (size_t)((rows + rpb - 1) / rpb) * 512 * sizeof(float);
+}
+
+// the same backward with the parameter gradients reduced WITHOUT atomics (deterministic; dgamma / dbeta need no zeroing)
+extern "C" int mpf_res_ln256_backward_ws(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                                         const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta,
+                                         int rows, void* workspace, size_t workspace_bytes, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) return 0;
+    if (!s || !mean || !rstd || !gamma || (!gy32 && !gy16 && !gy_plus) || (!ds32 && !ds16) || !dgamma || !dbeta || !workspace)
+        return mpf::fail(MPF_E_NULL, "res_ln256_backward_ws: NULL buffer");
+    if (rows < 0 || workspace_bytes < mpf_res_ln256_backward_workspace_bytes(rows))
+        return mpf::fail(MPF_E_SHAPE, "res_ln256_backward_ws: bad rows / workspace too small");
+    int rpb = (rows + 1023) / 1024;
+    rpb = ((rpb + 3) / 4) * 4;
+    const dim3 grid((rows + rpb - 1) / rpb);
+    float* part = (float*)workspace;
+    mpf::set_kernel("res_ln256_bwd_kernel");
+#define RLN_BWDP(A, B, C)                                                                                                         \
+    hipLaunchKernelGGL((res_ln256_bwd_kernel<A, B, C, true>), grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16,    \
+                       gy_plus, ds32, (__bf16*)ds16, part, part, rows, rpb)
+    switch ((gy32 ? 4 : 0) | (gy16 ? 2 : 0) | (gy_plus ? 1 : 0)) {
+        case 1: RLN_BWDP(false, false, true); break;
+        case 2: RLN_BWDP(false, true, false); break;
+        case 3: RLN_BWDP(false, true, true); break;
+        case 4: RLN_BWDP(true, false, false); break;
+        case 5: RLN_BWDP(true, false, true); break;
+        case 6: RLN_BWDP(true, true, false); break;
+        default: RLN_BWDP(true, true, true); break;
+    }
+#undef RLN_BWDP
+    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(2), dim3(1024), 0, st, (const float*)part, (int)grid.x, dgamma, dbeta);
+    return mpf::check(hipGetLastError(), "mpf_res_ln256_backward_ws");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -97,11 +97,21 @@ def ln256_forward(x, gamma, beta, eps, padd=None):
 def ln256_backward(s, mean, rstd, gamma, gy, gy_plus=None):
     """Raw backward: -> (ds fp32, dgamma, dbeta) with g = gy (+ gy_plus)."""
     ds = torch.empty_like(s)
-    dgb = torch.zeros((2, 256), dtype=torch.float32, device=s.device)
+    dgb = torch.empty((2, 256), dtype=torch.float32, device=s.device)
+    lib = _lib.lib()
+    nbytes = lib.mpf_res_ln256_backward_workspace_bytes(s.shape[0])
+    ws = _ln_ws.get(s.device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes) + 1024, dtype=torch.uint8, device=s.device)
+        _ln_ws[s.device] = ws
     with torch.cuda.device(s.device):
-        code = _lib.lib().mpf_res_ln256_backward(
+        # parameter gradients through per-workgroup partials, fixed order (no atomics, no zero-fill)
+        code = lib.mpf_res_ln256_backward_ws(
             s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), gy.data_ptr(), None,
             gy_plus.data_ptr() if gy_plus is not None else None, ds.data_ptr(), None, dgb[0].data_ptr(), dgb[1].data_ptr(),
-            s.shape[0], _stream(s))
-    _lib.check(code, "mpf_res_ln256_backward")
+            s.shape[0], ws.data_ptr(), ws.numel(), _stream(s))
+    _lib.check(code, "mpf_res_ln256_backward_ws")
     return ds, dgb[0], dgb[1]
+
+
+_ln_ws = {}
