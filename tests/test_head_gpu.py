@@ -176,7 +176,8 @@ def test_head_baseline_config_shapes_run(name, size, chans, classes, queries, n)
     H, W = size
     shapes = {f"res{i + 2}": (c, s) for i, (c, s) in enumerate(zip(chans, (4, 8, 16, 32)))}
     h = MPFormerHead(num_classes=classes, num_queries=queries, feature_shapes=shapes).to(dev).train()
-    feats = {k: torch.randn(n, c, H // s, W // s, device=dev) for k, (c, s) in shapes.items()}
+    # what the bf16 backbone hands over under autocast: bf16 channel-last planes (the route bench.py times)
+    feats = {k: torch.randn(n, H // s, W // s, c, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2) for k, (c, s) in shapes.items()}
     targets = []
     for b in range(n):
         T = 4 + 3 * b
@@ -276,7 +277,8 @@ def test_head_full_size_configs_B_C(name, classes, n):
     H = W = 1024
     shapes = {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}
     h = MPFormerHead(num_classes=classes, num_queries=100, feature_shapes=shapes).to(dev).train()
-    feats = {k: torch.randn(n, c, H // s, W // s, device=dev) for k, (c, s) in shapes.items()}
+    # what the bf16 backbone hands over under autocast: bf16 channel-last planes (the route bench.py times)
+    feats = {k: torch.randn(n, H // s, W // s, c, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2) for k, (c, s) in shapes.items()}
     targets = []
     for b in range(n):
         T = 5 + 9 * b
@@ -297,7 +299,8 @@ def test_head_full_size_configs_B_C(name, classes, n):
     _lib.profile_enable(True)
     l0 = run(11)
     for kern in ("msda_fwd_block", "msda_bwd_push_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost",
-                 "mask_loss_fwd", "mask_head_bits", "pool_features", "lsa_kernel", "gemm3"):
+                 "mask_loss_fwd", "mask_head_bits", "pool_features", "lsa_kernel", "gemm3", "gemm3_conv_kernel",
+                 "gemm3_nt_kernel<conv3x3>", "gemm3_tn_kernel<a16>", "gemm3_nt_kernel<b16>", "gn_cl_apply", "gn_cl_bwd_apply"):
         assert _lib.profile_get(kern)[0] > 0, kern
     _lib.profile_enable(False)
     assert len(l0) == 60 and all(np.isfinite(v) for v in l0.values()), l0
