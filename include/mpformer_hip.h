@@ -260,6 +260,10 @@ int mpf_attn_backward(const void* q, const void* k, const void* v, const void* k
  */
 int mpf_attn_transpose2(const void* a, const void* b, void* aT, void* bT, int L, int LP, int N, int E, void* stream);
 int mpf_attn_delta(const void* dout, const void* out, float* delta, int Lq, int N, int H, void* stream);
+/* mpf_attn_transpose2(q, dout -> qT, doT; E = 32 * H) and mpf_attn_delta(dout, out) in ONE launch: everything the attention
+ * backward derives from the query side (nn.MultiheadAttention backward, mask2former_transformer_decoder.py:42-52, :100-112) */
+int mpf_attn_bwd_prep(const void* q, const void* dout, const void* out, void* qT, void* doT, float* delta, int Lq, int LqP, int N,
+                      int H, void* stream);
 
 /*
  * Module-level forms of the two ops above (ops/modules/ms_deform_attn.py:103-117 folded in): the
@@ -620,6 +624,25 @@ int mpf_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, voi
 int mpf_small_gemm_bf16_blocked(const void* a, int64_t a_rs, int64_t a_ks, int a_blk, int64_t a_bs, const void* gate, const void* b,
                                 int64_t b_rs, int64_t b_ks, const void* bias, const void* c_in, int64_t ldcin, void* c, int64_t ldc,
                                 int c_blk, int64_t c_bs, void* rowsum_a, int I, int J, int Kc, int relu, void* stream);
+
+/*
+ * Up to 8 independent WEIGHT-GRADIENT problems of mpf_small_gemm_bf16 in one launch (both operands row-contiguous:
+ * a_rs == 1 and b_rs == 1, i.e. dW[J_out, K_in] = dY^T . x with dY and x read along their rows; no bias / c_in / ReLU).
+ * The six dW GEMMs of a decoder layer's backward (FFNLayer, SelfAttentionLayer, CrossAttentionLayer of
+ * mask2former_transformer_decoder.py:42-52, :100-112, :165-169) are independent of the dX chain and of each other;
+ * as separate launches each is mostly launch + memory latency.  Fields as the arguments of
+ * mpf_small_gemm_bf16_blocked (a_blk / a_bs: row-blocked A).  Kc % 32 must agree across the items.
+ */
+typedef struct {
+    const void* a;
+    const void* gate;
+    const void* b;
+    void* c;
+    void* rowsum_a;
+    int64_t a_rs, a_ks, a_bs, b_rs, b_ks, ldc;
+    int a_blk, I, J, Kc;
+} MpfSmallGemmItem;
+int mpf_small_gemm_bf16_group(const MpfSmallGemmItem* items, int n_items, void* stream);
 
 /*
  * y = relu?(x + bias[c] + res) over a dense channel-last activation (channel = fastest dimension,

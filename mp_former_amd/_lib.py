@@ -47,6 +47,7 @@ SIGNATURES = {
     "mpf_attn_backward": (_c_int, [_c_vp] * 8 + [_c_int] + [_c_vp] * 5 + [_c_int] * 6 + [ctypes.c_float, _c_vp, ctypes.c_size_t, _c_vp]),
     "mpf_attn_transpose2": (_c_int, [_c_vp] * 4 + [_c_int] * 4 + [_c_vp]),
     "mpf_attn_delta": (_c_int, [_c_vp] * 3 + [_c_int] * 3 + [_c_vp]),
+    "mpf_attn_bwd_prep": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [_c_vp]),
     "mpf_gemm3_split": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "mpf_gemm3_tn": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64,
                            _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_int, _c_vp]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     "mpf_small_gemm_bf16_blocked": (_c_int, [_c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64,
                                              ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, ctypes.c_int64,
                                              _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
+    "mpf_small_gemm_bf16_group": (_c_int, [_c_vp, _c_int, _c_vp]),
     "mpf_bias_act": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_res_ln256_forward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
                                        _c_vp, _c_int, _c_vp, _c_vp]),

@@ -81,9 +81,8 @@ class _AttnCore(Function):
         dv = torch.empty_like(vb)
         ws = _workspace(dev, lib.mpf_attn_workspace_bytes(Lq, Lk, N, H))
         with torch.cuda.device(dev):
-            _lib.check(lib.mpf_attn_delta(gob.data_ptr(), out.data_ptr(), delta.data_ptr(), Lq, N, H, stream), "mpf_attn_delta")
-            _lib.check(lib.mpf_attn_transpose2(qb.data_ptr(), gob.data_ptr(), qT.data_ptr(), doT.data_ptr(), Lq, LqP, N, E, stream),
-                       "mpf_attn_transpose2")
+            _lib.check(lib.mpf_attn_bwd_prep(qb.data_ptr(), gob.data_ptr(), out.data_ptr(), qT.data_ptr(), doT.data_ptr(),
+                                             delta.data_ptr(), Lq, LqP, N, H, stream), "mpf_attn_bwd_prep")      # Q^T, dO^T, delta
             code = lib.mpf_attn_backward(qb.data_ptr(), kb.data_ptr(), vb.data_ptr(), kT.data_ptr(), qT.data_ptr(),
                                          gob.data_ptr(), doT.data_ptr(), m.data_ptr() if m is not None else None,
                                          1 if (m is not None and m.dim() == 3) else 0, lse.data_ptr(), delta.data_ptr(),

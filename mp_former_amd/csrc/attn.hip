@@ -515,15 +515,15 @@ __global__ __launch_bounds__(256) void attn_sum_splits_kernel(const float* __res
 //               the backward), zero padded to LP >= L;
 //   delta     : delta[n, h, q] = sum_d dO[q, n, h*32+d] * O[q, n, h*32+d].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_transpose2_kernel(const __hip_bfloat16* __restrict__ a, const __hip_bfloat16* __restrict__ b,
-                                                               __hip_bfloat16* __restrict__ aT, __hip_bfloat16* __restrict__ bT,
-                                                               int L, int LP, int NE)
+__device__ __forceinline__ void transpose2_tile(const __hip_bfloat16* __restrict__ a, const __hip_bfloat16* __restrict__ b,
+                                                __hip_bfloat16* __restrict__ aT, __hip_bfloat16* __restrict__ bT,
+                                                int L, int LP, int NE, const int bx, const int by)
 {
     // tile of 64 sequence positions x 64 columns through LDS: 16-byte global loads (8 columns of a row) and stores (8
     // positions of a column); the transpose itself is 2-byte LDS writes into [column][position] rows of 72 elements
     // (144 B: the 16-byte reads of consecutive columns start 36 banks apart)
     __shared__ __attribute__((aligned(16))) unsigned short ta[64][72], tb[64][72];
-    const int l0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int l0 = bx * 64, c0 = by * 64;
     const bool vec = (NE % 8 == 0) && (LP % 8 == 0) &&
                      (((uintptr_t)a | (uintptr_t)b | (uintptr_t)aT | (uintptr_t)bT) & 15) == 0;
     if (vec) {
@@ -576,10 +576,17 @@ __global__ __launch_bounds__(256) void attn_transpose2_kernel(const __hip_bfloat
     }
 }
 
-__global__ __launch_bounds__(256) void attn_delta_kernel(const __hip_bfloat16* __restrict__ dout, const __hip_bfloat16* __restrict__ out,
-                                                          float* __restrict__ delta, int Lq, int N, int H)
+__global__ __launch_bounds__(256) void attn_transpose2_kernel(const __hip_bfloat16* __restrict__ a, const __hip_bfloat16* __restrict__ b,
+                                                               __hip_bfloat16* __restrict__ aT, __hip_bfloat16* __restrict__ bT,
+                                                               int L, int LP, int NE)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;               // over Lq*N*H*32, 32 lanes per (q,n,h)
+    transpose2_tile(a, b, aT, bT, L, LP, NE, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+__device__ __forceinline__ void delta_block(const __hip_bfloat16* __restrict__ dout, const __hip_bfloat16* __restrict__ out,
+                                            float* __restrict__ delta, int Lq, int N, int H, const int block)
+{
+    const int idx = block * 256 + threadIdx.x;                    // over Lq*N*H*32, 32 lanes per (q,n,h)
     const int d = idx & 31, row = idx >> 5;
     const int total = Lq * N * H;
     float v = 0.f;
@@ -590,6 +597,23 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const __hip_bfloat16* _
         const int h = row % H, n = (row / H) % N, q = row / (H * N);
         delta[((int64_t)n * H + h) * Lq + q] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void attn_delta_kernel(const __hip_bfloat16* __restrict__ dout, const __hip_bfloat16* __restrict__ out,
+                                                          float* __restrict__ delta, int Lq, int N, int H)
+{
+    delta_block(dout, out, delta, Lq, N, H, (int)blockIdx.x);
+}
+
+// What the attention backward needs from the query side, in one launch: Q^T and dO^T (blocks < n_tiles) and delta (the rest)
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const __hip_bfloat16* __restrict__ q, const __hip_bfloat16* __restrict__ dout,
+                                                             const __hip_bfloat16* __restrict__ out, __hip_bfloat16* __restrict__ qT,
+                                                             __hip_bfloat16* __restrict__ doT, float* __restrict__ delta, int Lq,
+                                                             int LqP, int N, int H, int tiles_x, int n_tiles)
+{
+    const int b = (int)blockIdx.x;
+    if (b < n_tiles) transpose2_tile(q, dout, qT, doT, Lq, LqP, N * H * kHD, b % tiles_x, b / tiles_x);
+    else delta_block(dout, out, delta, Lq, N, H, b - n_tiles);
 }
 
 }  // namespace
@@ -712,6 +736,22 @@ extern "C" int mpf_attn_transpose2(const void* a, const void* b, void* aT, void*
     hipLaunchKernelGGL(attn_transpose2_kernel, dim3((LP + 63) / 64, (NE + 63) / 64), dim3(256), 0, st,
                        (const __hip_bfloat16*)a, (const __hip_bfloat16*)b, (__hip_bfloat16*)aT, (__hip_bfloat16*)bT, L, LP, NE);
     return mpf::check(hipGetLastError(), "mpf_attn_transpose2");
+}
+
+extern "C" int mpf_attn_bwd_prep(const void* q, const void* dout, const void* out, void* qT, void* doT, float* delta, int Lq, int LqP,
+                                 int N, int H, void* stream)
+{
+    if (!q || !dout || !out || !qT || !doT || !delta) return mpf::fail(MPF_E_NULL, "attn_bwd_prep: NULL buffer");
+    if (Lq <= 0 || LqP < Lq || N <= 0 || H <= 0) return mpf::fail(MPF_E_SHAPE, "attn_bwd_prep: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int NE = N * H * kHD;
+    const int tiles_x = (LqP + 63) / 64, n_tiles = tiles_x * ((NE + 63) / 64);
+    const int delta_blocks = (Lq * N * H * kHD + 255) / 256;
+    mpf::set_kernel("attn_bwd_prep_kernel");
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(n_tiles + delta_blocks), dim3(256), 0, st, (const __hip_bfloat16*)q,
+                       (const __hip_bfloat16*)dout, (const __hip_bfloat16*)out, (__hip_bfloat16*)qT, (__hip_bfloat16*)doT, delta, Lq,
+                       LqP, N, H, tiles_x, n_tiles);
+    return mpf::check(hipGetLastError(), "mpf_attn_bwd_prep");
 }
 
 extern "C" int mpf_attn_delta(const void* dout, const void* out, float* delta, int Lq, int N, int H, void* stream)

@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int kE = 256;
+constexpr int kMaxDw = 8;        // weight-gradient problems per layer (6 with packed in-projection gradients, 8 without)
 
 struct Carve {
     char* p;
@@ -47,7 +48,10 @@ FwdScratch fwd_scratch(void* base, int Qt, int N, int S)
 }
 
 struct BwdScratch {
-    void *dt, *dxb, *dh, *dout, *dq, *dk_s, *dv_s, *qT, *doT;
+    // dt3 / dt2 / dt1: the gradients entering the FFN / self-attention / cross-attention output projections, dq / dq_c the
+    // in-projection gradients of the two attentions — each in its own buffer, because the weight gradients that read them
+    // are issued together at the end of the layer (one grouped launch)
+    void *dt3, *dt2, *dt1, *dxb, *dh, *dout, *dq, *dk_s, *dv_s, *dq_c, *qT, *doT;
     float *ds_a, *ds_b, *delta;
     size_t bytes;
 };
@@ -58,13 +62,16 @@ BwdScratch bwd_scratch(void* base, int Qt, int N, int H, int F)
     BwdScratch b;
     const size_t R = (size_t)Qt * N;
     const size_t LqP = (size_t)((Qt + 31) / 32 * 32);
-    b.dt = c.take<uint16_t>(R * kE);
+    b.dt3 = c.take<uint16_t>(R * kE);
+    b.dt2 = c.take<uint16_t>(R * kE);
+    b.dt1 = c.take<uint16_t>(R * kE);
     b.dxb = c.take<uint16_t>(R * kE);
     b.dh = c.take<uint16_t>(R * F);
     b.dout = c.take<uint16_t>(R * kE);
     b.dq = c.take<uint16_t>(R * kE);
     b.dk_s = c.take<uint16_t>(R * kE);
     b.dv_s = c.take<uint16_t>(R * kE);
+    b.dq_c = c.take<uint16_t>(R * kE);
     b.qT = c.take<uint16_t>((size_t)N * kE * LqP);
     b.doT = c.take<uint16_t>((size_t)N * kE * LqP);
     b.ds_a = c.take<float>(R * kE);
@@ -107,6 +114,17 @@ int lin_dw(const void* dy, const void* gate, const void* x, void* dw, void* db, 
     return mpf_small_gemm_bf16(dy, 1, J, gate, x, 1, Kin, nullptr, nullptr, 0, dw, Kin, db, J, Kin, R, 0, st);
 }
 
+// the same problem as a descriptor of the grouped launch
+MpfSmallGemmItem dw_item(const void* dy, const void* gate, const void* x, void* dw, void* db, int R, int J, int Kin, int a_blk = 0,
+                         int64_t a_bs = 0)
+{
+    MpfSmallGemmItem m;
+    m.a = dy; m.gate = gate; m.b = x; m.c = dw; m.rowsum_a = db;
+    m.a_rs = 1; m.a_ks = a_blk ? kE : J; m.a_bs = a_bs; m.b_rs = 1; m.b_ks = Kin; m.ldc = Kin;
+    m.a_blk = a_blk; m.I = J; m.J = Kin; m.Kc = R;
+    return m;
+}
+
 inline const char* at(const void* p, size_t bytes) { return static_cast<const char*>(p) + bytes; }
 
 // q | k | v of the self-attention stand side by side in memory (packed in_proj weight / bias, the three
@@ -118,6 +136,19 @@ bool packed_weights(const MpfDecoderLayer* L)
 }
 
 }  // namespace
+
+namespace {
+// A/B switches (mpf_set_option): decoder_dw_group = 0 issues the weight gradients as separate launches (round-1 form)
+int g_dw_group = 1;
+}  // namespace
+
+namespace mpf {
+int set_decoder_option(const char* key, int v)
+{
+    if (!strcmp(key, "decoder_dw_group")) { g_dw_group = v != 0; return 0; }
+    return 1;
+}
+}  // namespace mpf
 
 #define MPF_TRY(expr)                \
     do {                             \
@@ -195,20 +226,23 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
     const float scale = 0.17677669529663687f;
     float* dln = G->d_ln;
     MPF_TRY(mpf::check(hipMemsetAsync(dln, 0, 6 * kE * sizeof(float), (hipStream_t)st), "decoder_layer_backward memset"));
+    // The weight gradients depend only on the dY buffers of the chain below (each kept in its own scratch buffer), so they
+    // are collected here and issued as ONE grouped launch after the chain.
+    MpfSmallGemmItem dw[kMaxDw];
+    int ndw = 0;
     // FFN block: x3 = LN(x2 + W2 relu(W1 xb2))
-    MPF_TRY(mpf_res_ln256_backward(L->s3, L->mean3, L->rstd3, L->ff_gamma, G->g_x3, G->g_xb3, nullptr, b.ds_a, b.dt, dln + 4 * kE,
+    MPF_TRY(mpf_res_ln256_backward(L->s3, L->mean3, L->rstd3, L->ff_gamma, G->g_x3, G->g_xb3, nullptr, b.ds_a, b.dt3, dln + 4 * kE,
                                    dln + 5 * kE, R, st));
-    MPF_TRY(lin_dx(b.dt, nullptr, L->ff_w2, nullptr, b.dh, R, kE, F, st));
-    MPF_TRY(lin_dw(b.dt, nullptr, L->h, G->d_ff_w2, G->d_ff_b2, R, kE, F, st));
+    MPF_TRY(lin_dx(b.dt3, nullptr, L->ff_w2, nullptr, b.dh, R, kE, F, st));
+    dw[ndw++] = dw_item(b.dt3, nullptr, L->h, G->d_ff_w2, G->d_ff_b2, R, kE, F);
     MPF_TRY(lin_dx(b.dh, L->h, L->ff_w1, nullptr, b.dxb, R, F, kE, st));
-    MPF_TRY(lin_dw(b.dh, L->h, L->xb2, G->d_ff_w1, G->d_ff_b1, R, F, kE, st));
+    dw[ndw++] = dw_item(b.dh, L->h, L->xb2, G->d_ff_w1, G->d_ff_b1, R, F, kE);
     // self-attention block: x2 = LN(x1 + Wo attn(Wq xb1, Wk xb1, Wv xb1))
-    MPF_TRY(mpf_res_ln256_backward(L->s2, L->mean2, L->rstd2, L->sa_gamma, b.ds_a, b.dxb, nullptr, b.ds_b, b.dt, dln + 2 * kE,
+    MPF_TRY(mpf_res_ln256_backward(L->s2, L->mean2, L->rstd2, L->sa_gamma, b.ds_a, b.dxb, nullptr, b.ds_b, b.dt2, dln + 2 * kE,
                                    dln + 3 * kE, R, st));
-    MPF_TRY(lin_dx(b.dt, nullptr, L->sa_wo, nullptr, b.dout, R, kE, kE, st));
-    MPF_TRY(lin_dw(b.dt, nullptr, L->o_s, G->d_sa_wo, G->d_sa_bo, R, kE, kE, st));
-    MPF_TRY(mpf_attn_delta(b.dout, L->o_s, b.delta, Qt, N, H, st));
-    MPF_TRY(mpf_attn_transpose2(L->q_s, b.dout, b.qT, b.doT, Qt, LqP, N, kE, st));
+    MPF_TRY(lin_dx(b.dt2, nullptr, L->sa_wo, nullptr, b.dout, R, kE, kE, st));
+    dw[ndw++] = dw_item(b.dt2, nullptr, L->o_s, G->d_sa_wo, G->d_sa_bo, R, kE, kE);
+    MPF_TRY(mpf_attn_bwd_prep(L->q_s, b.dout, L->o_s, b.qT, b.doT, b.delta, Qt, LqP, N, H, st));
     MPF_TRY(mpf_attn_backward(L->q_s, L->k_s, L->v_s, L->kT_s, b.qT, b.dout, b.doT, L->mask_s, 0, L->lse_s, b.delta, b.dq, b.dk_s,
                               b.dv_s, Qt, LqP, Qt, N, H, 32, scale, L->attn_ws, L->attn_ws_bytes, st));
     const size_t act = (size_t)R * kE * 2, wsz = (size_t)kE * kE * 2, bsz = (size_t)kE * 2;
@@ -224,23 +258,29 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
     }
     if (grads_packed && G->d_sa_wk == at(G->d_sa_wq, wsz) && G->d_sa_wv == at(G->d_sa_wq, 2 * wsz) &&
         G->d_sa_bk == at(G->d_sa_bq, bsz) && G->d_sa_bv == at(G->d_sa_bq, 2 * bsz)) {
-        // dW_in [768, 256] = [dq | dk | dv]^T . xb1 and its 768 bias gradients in one GEMM (rows of A blocked)
-        MPF_TRY(mpf_small_gemm_bf16_blocked(b.dq, 1, kE, kE, (int64_t)R * kE, nullptr, L->xb1, 1, kE, nullptr, nullptr, 0, G->d_sa_wq,
-                                            kE, 0, 0, G->d_sa_bq, 3 * kE, kE, R, 0, st));
+        // dW_in [768, 256] = [dq | dk | dv]^T . xb1 and its 768 bias gradients as one problem (rows of A blocked)
+        dw[ndw++] = dw_item(b.dq, nullptr, L->xb1, G->d_sa_wq, G->d_sa_bq, R, 3 * kE, kE, kE, (int64_t)R * kE);
     } else {
-        MPF_TRY(lin_dw(b.dq, nullptr, L->xb1, G->d_sa_wq, G->d_sa_bq, R, kE, kE, st));
-        MPF_TRY(lin_dw(b.dk_s, nullptr, L->xb1, G->d_sa_wk, G->d_sa_bk, R, kE, kE, st));
-        MPF_TRY(lin_dw(b.dv_s, nullptr, L->xb1, G->d_sa_wv, G->d_sa_bv, R, kE, kE, st));
+        dw[ndw++] = dw_item(b.dq, nullptr, L->xb1, G->d_sa_wq, G->d_sa_bq, R, kE, kE);
+        dw[ndw++] = dw_item(b.dk_s, nullptr, L->xb1, G->d_sa_wk, G->d_sa_bk, R, kE, kE);
+        dw[ndw++] = dw_item(b.dv_s, nullptr, L->xb1, G->d_sa_wv, G->d_sa_bv, R, kE, kE);
     }
     // cross-attention block: x1 = LN(x0 + Wo attn(Wq xb0, k_c, v_c))
-    MPF_TRY(mpf_res_ln256_backward(L->s1, L->mean1, L->rstd1, L->ca_gamma, b.ds_b, b.dxb, nullptr, G->d_x0, b.dt, dln, dln + kE, R, st));
-    MPF_TRY(lin_dx(b.dt, nullptr, L->ca_wo, nullptr, b.dout, R, kE, kE, st));
-    MPF_TRY(lin_dw(b.dt, nullptr, L->o_c, G->d_ca_wo, G->d_ca_bo, R, kE, kE, st));
-    MPF_TRY(mpf_attn_delta(b.dout, L->o_c, b.delta, Qt, N, H, st));
-    MPF_TRY(mpf_attn_transpose2(L->q_c, b.dout, b.qT, b.doT, Qt, LqP, N, kE, st));
-    MPF_TRY(mpf_attn_backward(L->q_c, L->k_c, L->v_c, L->kT_c, b.qT, b.dout, b.doT, L->mask_c, 1, L->lse_c, b.delta, b.dq, G->d_k_c,
+    MPF_TRY(mpf_res_ln256_backward(L->s1, L->mean1, L->rstd1, L->ca_gamma, b.ds_b, b.dxb, nullptr, G->d_x0, b.dt1, dln, dln + kE, R, st));
+    MPF_TRY(lin_dx(b.dt1, nullptr, L->ca_wo, nullptr, b.dout, R, kE, kE, st));
+    dw[ndw++] = dw_item(b.dt1, nullptr, L->o_c, G->d_ca_wo, G->d_ca_bo, R, kE, kE);
+    MPF_TRY(mpf_attn_bwd_prep(L->q_c, b.dout, L->o_c, b.qT, b.doT, b.delta, Qt, LqP, N, H, st));
+    MPF_TRY(mpf_attn_backward(L->q_c, L->k_c, L->v_c, L->kT_c, b.qT, b.dout, b.doT, L->mask_c, 1, L->lse_c, b.delta, b.dq_c, G->d_k_c,
                               G->d_v_c, Qt, LqP, S, N, H, 32, scale, L->attn_ws, L->attn_ws_bytes, st));
-    MPF_TRY(lin_dx(b.dq, nullptr, L->ca_wq, nullptr, G->d_xb0, R, kE, kE, st));
-    MPF_TRY(lin_dw(b.dq, nullptr, L->xb0, G->d_ca_wq, G->d_ca_bq, R, kE, kE, st));
+    MPF_TRY(lin_dx(b.dq_c, nullptr, L->ca_wq, nullptr, G->d_xb0, R, kE, kE, st));
+    dw[ndw++] = dw_item(b.dq_c, nullptr, L->xb0, G->d_ca_wq, G->d_ca_bq, R, kE, kE);
+    if (g_dw_group) {
+        MPF_TRY(mpf_small_gemm_bf16_group(dw, ndw, st));
+    } else {
+        for (int t = 0; t < ndw; ++t)
+            MPF_TRY(mpf_small_gemm_bf16_blocked(dw[t].a, dw[t].a_rs, dw[t].a_ks, dw[t].a_blk, dw[t].a_bs, dw[t].gate, dw[t].b, dw[t].b_rs,
+                                                dw[t].b_ks, nullptr, nullptr, 0, dw[t].c, dw[t].ldc, 0, 0, dw[t].rowsum_a, dw[t].I,
+                                                dw[t].J, dw[t].Kc, 0, st));
+    }
     return 0;
 }

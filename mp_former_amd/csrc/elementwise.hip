@@ -202,25 +202,33 @@ __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restr
     }
 }
 
-// out[which][col] = sum over blocks of partial[block][which][col]; grid = 2 (which), 256 threads x 4 block slices via LDS
+// out[which][col] = sum over blocks of partial[block][which][col] in a fixed order; grid = (2 "which", 8 groups of 32 columns),
+// 1024 threads = 32 columns x 32 block slices (a wave reads two 128-byte row pieces), slices merged through LDS.  (Two
+// workgroups walking all blocks were latency-bound: 245 dependent-ish reads per thread, 29 us for 2 MB.)
 __global__ __launch_bounds__(1024) void ln_partial_reduce_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta)
 {
-    __shared__ float red[4][256];
-    const int which = blockIdx.x, col = threadIdx.x & 255, sl = threadIdx.x >> 8;
+    __shared__ float red[32][33];
+    const int which = blockIdx.x, c = threadIdx.x & 31, col = blockIdx.y * 32 + c, sl = threadIdx.x >> 5;
+    const float* src = partial + which * 256 + col;
     float acc = 0.f;
     int b = sl;
-    for (; b + 28 < blocks; b += 32) {
+    for (; b + 224 < blocks; b += 256) {
         float t[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = partial[(int64_t)(b + 4 * k) * 512 + which * 256 + col];
+        for (int k = 0; k < 8; ++k) t[k] = src[(int64_t)(b + 32 * k) * 512];
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc += t[k];
     }
-    for (; b < blocks; b += 4) acc += partial[(int64_t)b * 512 + which * 256 + col];
-    red[sl][col] = acc;
+    for (; b < blocks; b += 32) acc += src[(int64_t)b * 512];
+    red[sl][c] = acc;
     __syncthreads();
-    if (sl == 0) (which ? dbeta : dgamma)[col] = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+    if (sl == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += red[k][c];
+        (which ? dbeta : dgamma)[col] = t;
+    }
 }
 
 }  // namespace
@@ -315,7 +323,7 @@ extern "C" int mpf_res_ln256_backward_ws(const float* s, const float* mean, cons
         default: RLN_BWDP(true, true, true); break;
     }
 #undef RLN_BWDP
-    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(2), dim3(1024), 0, st, (const float*)part, (int)grid.x, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(2, 8), dim3(1024), 0, st, (const float*)part, (int)grid.x, dgamma, dbeta);
     return mpf::check(hipGetLastError(), "mpf_res_ln256_backward_ws");
 }
 

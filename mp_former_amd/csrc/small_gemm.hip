@@ -99,13 +99,11 @@ __device__ __forceinline__ float sum_words(const Frag& f)
 // U = 4 / NJ of a wave's steps are loaded together before their MFMAs: a 256-deep contraction is ONE
 // memory latency per wave, a 2048-deep one four.  The partial tiles are summed through LDS by wave 0.
 template <int NJ, bool AC, bool BC, bool GATE, bool MASK>
-__global__ __launch_bounds__(256) void small_gemm_kernel(const SG p)
+__device__ __forceinline__ void sg_tile(const SG& p, const int block, float4 (*red)[NJ][64], float (*red_rs)[64])
 {
     constexpr int U = 4 / NJ;
-    __shared__ float4 red[3][NJ][64];
-    __shared__ float red_rs[3][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int it = blockIdx.x % p.n_it, jt = blockIdx.x / p.n_it;
+    const int it = block % p.n_it, jt = block / p.n_it;
     const int li = lane & 15, g = lane >> 4;
     const int i = it * 16 + li;
     const int ic = min(i, p.I - 1);
@@ -201,6 +199,45 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const SG p)
     }
 }
 
+template <int NJ, bool AC, bool BC, bool GATE, bool MASK>
+__global__ __launch_bounds__(256) void small_gemm_kernel(const SG p)
+{
+    __shared__ float4 red[3][NJ][64];
+    __shared__ float red_rs[3][64];
+    sg_tile<NJ, AC, BC, GATE, MASK>(p, (int)blockIdx.x, red, red_rs);
+}
+
+// Several independent weight-gradient problems (both operands row-contiguous: dY and x read along their rows) in ONE
+// launch: the six dW GEMMs of a decoder layer's backward are 6-9 us each as launches of 16-128 blocks, mostly latency.
+// A block finds its problem from the running block counts; the tile width and the gate are per problem.
+constexpr int kGroupMax = 8;
+struct SGGroup {
+    SG it[kGroupMax];
+    int first[kGroupMax + 1];        // first block of problem g (first[n] = grid size)
+    int nj[kGroupMax];
+    int n;
+};
+
+template <bool MASK>
+__global__ __launch_bounds__(256) void small_gemm_group_kernel(const SGGroup g)
+{
+    __shared__ float4 red[3 * 4 * 64];
+    __shared__ float red_rs[3][64];
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < kGroupMax; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.first[t]) k = t;
+    const SG& p = g.it[k];
+    const int block = (int)blockIdx.x - g.first[k];
+    const bool gate = p.gate != nullptr;
+    const int nj = g.nj[k];
+#define SG_CASE(NJ_, G_) sg_tile<NJ_, false, false, G_, MASK>(p, block, reinterpret_cast<float4(*)[NJ_][64]>(red), red_rs)
+    if (nj == 4) { if (gate) SG_CASE(4, true); else SG_CASE(4, false); }
+    else if (nj == 2) { if (gate) SG_CASE(2, true); else SG_CASE(2, false); }
+    else { if (gate) SG_CASE(1, true); else SG_CASE(1, false); }
+#undef SG_CASE
+}
+
 template <int NJ, bool AC, bool BC>
 void launch2(const SG& p, bool gate, bool mask, int blocks, hipStream_t st)
 {
@@ -230,28 +267,32 @@ void launch(const SG& p, bool ac, bool bc, int blocks, hipStream_t st)
 
 }  // namespace
 
-extern "C" int mpf_small_gemm_bf16_blocked(const void* a, int64_t a_rs, int64_t a_ks, int a_blk, int64_t a_bs, const void* gate,
-                                           const void* b, int64_t b_rs, int64_t b_ks, const void* bias, const void* c_in,
-                                           int64_t ldcin, void* c, int64_t ldc, int c_blk, int64_t c_bs, void* rowsum_a, int I,
-                                           int J, int Kc, int relu, void* stream)
+namespace {
+
+// validates one problem and fills its descriptor; *nj_out = the tile width chosen for it.  Returns 1 for an empty problem.
+int sg_fill(SG& p, int* nj_out, const void* a, int64_t a_rs, int64_t a_ks, int a_blk, int64_t a_bs, const void* gate, const void* b,
+            int64_t b_rs, int64_t b_ks, const void* bias, const void* c_in, int64_t ldcin, void* c, int64_t ldc, int c_blk,
+            int64_t c_bs, void* rowsum_a, int I, int J, int Kc, int relu, int* err)
 {
+    *err = 0;
+#define SG_FAIL(code, msg) { *err = mpf::fail(code, msg); return 0; }
     if (a_blk < 0 || c_blk < 0 || (a_blk && a_blk % 32) || (c_blk && c_blk % 64) || (a_blk && a_ks == 1 && Kc % 32) ||
         (c_blk && c_in))
-        return mpf::fail(MPF_E_SHAPE, "small_gemm_blocked: a_blk % 32, c_blk % 64 (and Kc % 32 for a blocked contraction) must be 0");
-    if (I < 0 || J < 0 || Kc < 0) return mpf::fail(MPF_E_SHAPE, "small_gemm: negative size");
-    if (I == 0 || J == 0) return 0;
-    if (!a || !b || !c) return mpf::fail(MPF_E_NULL, "small_gemm: a, b, c must not be null");
-    if (Kc == 0) return mpf::fail(MPF_E_SHAPE, "small_gemm: empty contraction");
+        SG_FAIL(MPF_E_SHAPE, "small_gemm_blocked: a_blk % 32, c_blk % 64 (and Kc % 32 for a blocked contraction) must be 0");
+    if (I < 0 || J < 0 || Kc < 0) SG_FAIL(MPF_E_SHAPE, "small_gemm: negative size");
+    if (I == 0 || J == 0) return 1;
+    if (!a || !b || !c) SG_FAIL(MPF_E_NULL, "small_gemm: a, b, c must not be null");
+    if (Kc == 0) SG_FAIL(MPF_E_SHAPE, "small_gemm: empty contraction");
     const bool ac = a_ks == 1, bc = b_ks == 1;
     if ((!ac && a_rs != 1) || (!bc && b_rs != 1))
-        return mpf::fail(MPF_E_SHAPE, "small_gemm: each operand needs a unit row or contraction stride");
+        SG_FAIL(MPF_E_SHAPE, "small_gemm: each operand needs a unit row or contraction stride");
     if ((ac && (Kc % 8 || a_rs % 8 || ((uintptr_t)a & 15) || (gate && ((uintptr_t)gate & 15)))) ||
         (bc && (Kc % 8 || b_rs % 8 || ((uintptr_t)b & 15))))
-        return mpf::fail(MPF_E_SHAPE, "small_gemm: contraction-contiguous operands need 16-B aligned rows, Kc % 8 == 0");
+        SG_FAIL(MPF_E_SHAPE, "small_gemm: contraction-contiguous operands need 16-B aligned rows, Kc % 8 == 0");
     if (J % 4 || ldc % 4 || ((uintptr_t)c & 7) || (bias && ((uintptr_t)bias & 7)) ||
         (c_in && (ldcin % 4 || ((uintptr_t)c_in & 7))))
-        return mpf::fail(MPF_E_SHAPE, "small_gemm: J and ldc must be multiples of 4 (8-B stores)");
-    SG p;
+        SG_FAIL(MPF_E_SHAPE, "small_gemm: J and ldc must be multiples of 4 (8-B stores)");
+#undef SG_FAIL
     p.a = static_cast<const u16*>(a);
     p.gate = static_cast<const u16*>(gate);
     p.b = static_cast<const u16*>(b);
@@ -268,6 +309,24 @@ extern "C" int mpf_small_gemm_bf16_blocked(const void* a, int64_t a_rs, int64_t 
     int nj = 4;
     while (nj > 1 && (int64_t)p.n_it * ((J + 16 * nj - 1) / (16 * nj)) < 256) nj >>= 1;
     p.n_waves = p.n_it * ((J + 16 * nj - 1) / (16 * nj));
+    *nj_out = nj;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mpf_small_gemm_bf16_blocked(const void* a, int64_t a_rs, int64_t a_ks, int a_blk, int64_t a_bs, const void* gate,
+                                           const void* b, int64_t b_rs, int64_t b_ks, const void* bias, const void* c_in,
+                                           int64_t ldcin, void* c, int64_t ldc, int c_blk, int64_t c_bs, void* rowsum_a, int I,
+                                           int J, int Kc, int relu, void* stream)
+{
+    SG p;
+    int nj = 1, err = 0;
+    const int empty = sg_fill(p, &nj, a, a_rs, a_ks, a_blk, a_bs, gate, b, b_rs, b_ks, bias, c_in, ldcin, c, ldc, c_blk, c_bs, rowsum_a,
+                              I, J, Kc, relu, &err);
+    if (err) return err;
+    if (empty) return 0;
+    const bool ac = a_ks == 1, bc = b_ks == 1;
     const int blocks = p.n_waves;
     hipStream_t st = static_cast<hipStream_t>(stream);
     mpf::prof_begin(st);
@@ -286,4 +345,41 @@ extern "C" int mpf_small_gemm_bf16(const void* a, int64_t a_rs, int64_t a_ks, co
 {
     return mpf_small_gemm_bf16_blocked(a, a_rs, a_ks, 0, 0, gate, b, b_rs, b_ks, bias, c_in, ldcin, c, ldc, 0, 0, rowsum_a, I, J, Kc,
                                        relu, stream);
+}
+
+extern "C" int mpf_small_gemm_bf16_group(const MpfSmallGemmItem* items, int n_items, void* stream)
+{
+    if (n_items < 0 || n_items > kGroupMax) return mpf::fail(MPF_E_SHAPE, "small_gemm_group: at most 8 problems per launch");
+    if (n_items == 0) return 0;
+    if (!items) return mpf::fail(MPF_E_NULL, "small_gemm_group: NULL items");
+    SGGroup g;
+    g.n = 0;
+    g.first[0] = 0;
+    bool mask = false;
+    double bytes = 0.0;
+    for (int t = 0; t < n_items; ++t) {
+        const MpfSmallGemmItem& m = items[t];
+        if (m.a_rs != 1 || m.b_rs != 1)
+            return mpf::fail(MPF_E_SHAPE, "small_gemm_group: row-contiguous operands only (the weight-gradient form)");
+        int nj = 1, err = 0;
+        const int empty = sg_fill(g.it[g.n], &nj, m.a, m.a_rs, m.a_ks, m.a_blk, m.a_bs, m.gate, m.b, m.b_rs, m.b_ks, nullptr, nullptr, 0,
+                                  m.c, m.ldc, 0, 0, m.rowsum_a, m.I, m.J, m.Kc, 0, &err);
+        if (err) return err;
+        if (empty) continue;
+        if (g.n > 0 && ((m.Kc & 31) != 0) != mask) return mpf::fail(MPF_E_SHAPE, "small_gemm_group: Kc % 32 must agree across the group");
+        mask = (m.Kc & 31) != 0;
+        g.nj[g.n] = nj;
+        g.first[g.n + 1] = g.first[g.n] + g.it[g.n].n_waves;
+        bytes += 2.0 * ((double)m.I * m.Kc * (m.gate ? 2 : 1) + (double)m.J * m.Kc + (double)m.I * m.J);
+        ++g.n;
+    }
+    if (g.n == 0) return 0;
+    for (int t = g.n; t < kGroupMax; ++t) { g.first[t + 1] = g.first[g.n]; g.nj[t] = 1; g.it[t] = g.it[0]; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mpf::prof_begin(st);
+    if (mask) small_gemm_group_kernel<true><<<g.first[g.n], 256, 0, st>>>(g);
+    else small_gemm_group_kernel<false><<<g.first[g.n], 256, 0, st>>>(g);
+    mpf::set_kernel("small_gemm_group_kernel");
+    mpf::prof_end("small_gemm_group_kernel", st, bytes);
+    return mpf::check(hipGetLastError(), "small_gemm_group launch");
 }

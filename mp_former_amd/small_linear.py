@@ -6,6 +6,8 @@ makes of the nn.Linear / nn.MultiheadAttention projections of mask2former_transf
 with the ReLU, its backward gate and the bias gradient folded into the three GEMMs of the layer.
 Same rounding points as the library path: fp32 accumulation, bf16 results.  GPU only.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -30,6 +32,36 @@ def small_gemm(a, a_rs, a_ks, b, b_rs, b_ks, I, J, Kc, bias=None, gate=None, rel
             I, J, Kc, 1 if relu else 0, _stream(a))
     _lib.check(code, "mpf_small_gemm_bf16")
     return c, rs
+
+
+class MpfSmallGemmItem(ctypes.Structure):
+    """include/mpformer_hip.h MpfSmallGemmItem."""
+    _fields_ = [("a", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("b", ctypes.c_void_p), ("c", ctypes.c_void_p),
+                ("rowsum_a", ctypes.c_void_p), ("a_rs", ctypes.c_int64), ("a_ks", ctypes.c_int64), ("a_bs", ctypes.c_int64),
+                ("b_rs", ctypes.c_int64), ("b_ks", ctypes.c_int64), ("ldc", ctypes.c_int64), ("a_blk", ctypes.c_int),
+                ("I", ctypes.c_int), ("J", ctypes.c_int), ("Kc", ctypes.c_int)]
+
+
+def weight_grads_grouped(problems):
+    """[(dy [R, J], x [R, K], gate or None)] -> [(dW [J, K], db [J])]: up to 8 weight-gradient problems
+    dW = (dy gated)^T . x in ONE launch (mpf_small_gemm_bf16_group)."""
+    items = (MpfSmallGemmItem * len(problems))()
+    outs = []
+    for it, (dy, x, gate) in zip(items, problems):
+        R, J = dy.shape
+        K = x.shape[1]
+        dw = torch.empty((J, K), dtype=torch.bfloat16, device=dy.device)
+        db = torch.empty((J,), dtype=torch.bfloat16, device=dy.device)
+        it.a, it.gate, it.b, it.c, it.rowsum_a = dy.data_ptr(), (gate.data_ptr() if gate is not None else None), x.data_ptr(), \
+            dw.data_ptr(), db.data_ptr()
+        it.a_rs, it.a_ks, it.a_bs, it.b_rs, it.b_ks, it.ldc = 1, dy.stride(0), 0, 1, x.stride(0), K
+        it.a_blk, it.I, it.J, it.Kc = 0, J, K, R
+        outs.append((dw, db))
+    dev = problems[0][0].device
+    with torch.cuda.device(dev):
+        code = _lib.lib().mpf_small_gemm_bf16_group(items, len(problems), _stream(problems[0][0]))
+    _lib.check(code, "mpf_small_gemm_bf16_group")
+    return outs
 
 
 def usable(x, w, b=None):

@@ -75,3 +75,24 @@ def test_attention_backward_matches_fp32_autograd(Lq, Lk, N, mask_kind):
         scale = b.abs().max().item()
         err = (a.float() - b).abs().max().item()
         assert err < 3e-2 * scale + 1e-3, (name, err, scale)
+
+
+def test_bwd_prep_equals_transpose_plus_delta():
+    """mpf_attn_bwd_prep (one launch) == mpf_attn_transpose2(q, dO) + mpf_attn_delta(dO, O), bit for bit."""
+    from mp_former_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    for Lq, N in [(115, 2), (230, 1), (33, 3)]:
+        H, E = 8, 256
+        LqP = (Lq + 31) // 32 * 32
+        q, do, o = (torch.randn(Lq, N, E, device=dev).bfloat16() for _ in range(3))
+        st = torch.cuda.current_stream(dev).cuda_stream
+        a = [torch.full((N, E, LqP), 7.0, dtype=torch.bfloat16, device=dev) for _ in range(4)]
+        d = [torch.full((N, H, Lq), 7.0, dtype=torch.float32, device=dev) for _ in range(2)]
+        _lib.check(lib.mpf_attn_transpose2(q.data_ptr(), do.data_ptr(), a[0].data_ptr(), a[1].data_ptr(), Lq, LqP, N, E, st), "t2")
+        _lib.check(lib.mpf_attn_delta(do.data_ptr(), o.data_ptr(), d[0].data_ptr(), Lq, N, H, st), "delta")
+        _lib.check(lib.mpf_attn_bwd_prep(q.data_ptr(), do.data_ptr(), o.data_ptr(), a[2].data_ptr(), a[3].data_ptr(), d[1].data_ptr(),
+                                         Lq, LqP, N, H, st), "prep")
+        assert torch.equal(a[0], a[2]) and torch.equal(a[1], a[3]) and torch.equal(d[0], d[1])
+        assert torch.equal(a[2][:, :, :Lq], q.permute(1, 2, 0)) and (a[2][:, :, Lq:] == 0).all()

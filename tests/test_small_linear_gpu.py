@@ -132,3 +132,28 @@ def test_tall_linear_grads():
     assert torch.equal(y, yl)
     for got, lib in ((x.grad, xl.grad), (w.grad, wl.grad), (b.grad, bl.grad)):
         assert (got.float() - lib.float()).abs().max().item() <= 2 ** -6 * lib.float().abs().max().item()
+
+
+def test_grouped_weight_gradients_equal_the_single_launches():
+    """mpf_small_gemm_bf16_group: the dW problems of a decoder layer in one launch — bit-identical to one launch each."""
+    from mp_former_amd.small_linear import small_gemm, weight_grads_grouped
+    torch.manual_seed(11)
+    dev = torch.device("cuda:0")
+    R = 230
+    shapes = [(256, 2048, False), (2048, 256, True), (256, 256, False), (768, 256, False), (256, 256, False), (40, 64, True)]
+    probs = []
+    for J, K, gated in shapes:
+        dy = torch.randn(R, J, device=dev).bfloat16()
+        x = torch.randn(R, K, device=dev).bfloat16()
+        gate = torch.randn(R, J, device=dev).bfloat16() if gated else None
+        probs.append((dy, x, gate))
+    outs = weight_grads_grouped(probs)
+    for (dy, x, gate), (dw, db) in zip(probs, outs):
+        J, K = dy.shape[1], x.shape[1]
+        dw1, db1 = small_gemm(dy, 1, dy.stride(0), x, 1, x.stride(0), J, K, R, gate=gate, rowsum=True)
+        assert torch.equal(dw, dw1) and torch.equal(db, db1)
+        g = dy.double() * (gate.double() > 0) if gate is not None else dy.double()
+        ref = g.t() @ x.double()
+        assert (dw.double() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    with pytest.raises(RuntimeError):
+        weight_grads_grouped(probs + probs)          # more than 8 problems
