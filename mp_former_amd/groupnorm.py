@@ -158,6 +158,81 @@ class _GroupNormCLFn(Function):
         return dx, dg, db, None, None, None, dtop
 
 
+class _GroupNormFlattenFn(Function):
+    """GroupNorm of several channel-last maps written straight into ONE [N, sum(H_l W_l), C] buffer — the encoder's
+    ``src_flatten`` (msdeformattn.py:319-322 + :60-66: input_proj GroupNorm, flatten(2).transpose(1, 2), cat over levels)
+    without the per-level outputs and the concatenation pass.  args = (x_0, weight_0, bias_0, x_1, ...)."""
+
+    @staticmethod
+    def forward(ctx, groups, eps, *args):
+        xs, ws, bs = args[0::3], args[1::3], args[2::3]
+        N, C = xs[0].shape[:2]
+        sizes = [int(x.shape[2]) * int(x.shape[3]) for x in xs]
+        S = sum(sizes)
+        dev = xs[0].device
+        lib = _lib.lib()
+        out = torch.empty((N, S, C), dtype=torch.float32, device=dev)
+        stats = []
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        off = 0
+        with torch.cuda.device(dev):
+            for x, w, b, hw in zip(xs, ws, bs, sizes):
+                mean = torch.empty(N * groups, dtype=torch.float32, device=dev)
+                rstd = torch.empty(N * groups, dtype=torch.float32, device=dev)
+                wsb = _workspace(dev, lib.mpf_gn_cl_workspace_bytes(N, hw, C, groups))
+                code = lib.mpf_gn_cl_forward(x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr(), N, hw, C, groups, float(eps), 0,
+                                             None, 0, int(x.shape[3]), out.data_ptr() + off * C * 4, S * C, mean.data_ptr(),
+                                             rstd.data_ptr(), wsb.data_ptr(), wsb.numel(), stream)
+                _lib.check(code, "mpf_gn_cl_forward")
+                stats += [mean, rstd]
+                off += hw
+        ctx.save_for_backward(*xs, *ws, *bs, *stats)
+        ctx.groups, ctx.sizes, ctx.nl = groups, sizes, len(xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        nl = ctx.nl
+        sv = ctx.saved_tensors
+        xs, ws, bs, stats = sv[:nl], sv[nl:2 * nl], sv[2 * nl:3 * nl], sv[3 * nl:]
+        g = g.contiguous()
+        N, S, C = g.shape
+        dev = g.device
+        lib = _lib.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        grads = []
+        off = 0
+        with torch.cuda.device(dev):
+            for l, (x, w, b, hw) in enumerate(zip(xs, ws, bs, ctx.sizes)):
+                H, W = int(x.shape[2]), int(x.shape[3])
+                dx = _cl_empty(N, C, H, W, dev)
+                dg = torch.empty(C, dtype=torch.float32, device=dev)
+                db = torch.empty(C, dtype=torch.float32, device=dev)
+                wsb = _workspace(dev, lib.mpf_gn_cl_workspace_bytes(N, hw, C, ctx.groups))
+                code = lib.mpf_gn_cl_backward(g.data_ptr() + off * C * 4, S * C, x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr(),
+                                              stats[2 * l].data_ptr(), stats[2 * l + 1].data_ptr(), N, hw, C, ctx.groups, 0,
+                                              dx.data_ptr(), dx.stride(0), dg.data_ptr(), db.data_ptr(), wsb.data_ptr(), wsb.numel(),
+                                              stream)
+                _lib.check(code, "mpf_gn_cl_backward")
+                grads += [dx, dg, db]
+                off += hw
+        return (None, None) + tuple(grads)
+
+
+def group_norm_flatten(norms, xs):
+    """[GroupNorm_l(x_l)] flattened and concatenated over levels -> [N, sum(HW_l), C] in one buffer; None if a level does
+    not qualify for the channel-last kernels (the caller then takes the per-level route)."""
+    g0 = norms[0]
+    for n, x in zip(norms, xs):
+        if not (isinstance(n, GroupNorm) and n.cl_ok(x) and n.num_groups == g0.num_groups and n.eps == g0.eps
+                and x.shape[:2] == xs[0].shape[:2]):
+            return None
+    args = []
+    for n, x in zip(norms, xs):
+        args += [x, n.weight, n.bias]
+    return _GroupNormFlattenFn.apply(g0.num_groups, g0.eps, *args)
+
+
 def cl_enabled():
     return os.environ.get("MPF_GN_CL", "1") == "1"
 

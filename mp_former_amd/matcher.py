@@ -20,6 +20,7 @@ from torch import nn
 from . import _rng
 from . import _lib
 from ._h2d import upload
+from ._targets import stacked_masks
 from .point_sample import MapSet, match_cost, point_sample_offsets
 
 
@@ -39,7 +40,10 @@ class GTMasks:
         self.tmax = max(self.counts) if self.counts else 0
         ms = [t["masks"] for t in targets if t["masks"].shape[0] > 0]
         if ms:
-            m = torch.cat([x if x.dtype == torch.bool else (x > 0) for x in ms]).contiguous()
+            if all(x.dtype == torch.bool and x.shape[1:] == ms[0].shape[1:] for x in ms):
+                m = stacked_masks(ms)             # the decoder's mask-piloted setup has usually stacked them already
+            else:
+                m = torch.cat([x if x.dtype == torch.bool else (x > 0) for x in ms]).contiguous()
             self.u8 = m.view(torch.uint8)
         else:
             H, W = targets[0]["masks"].shape[-2:]

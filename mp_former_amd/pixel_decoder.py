@@ -19,7 +19,7 @@ from torch.nn.init import normal_
 
 from . import encoder_fused
 from . import conv3x3
-from .groupnorm import GroupNorm, to_nchw
+from .groupnorm import group_norm_flatten, GroupNorm, to_nchw
 from .linear import linear_tall
 from .msda import MSDeformAttn, attach_host_shapes
 
@@ -168,7 +168,9 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             self._shape_cache[key] = meta
         return meta
 
-    def forward(self, srcs, pos_embeds):
+    def forward(self, srcs, pos_embeds, src_flatten=None):
+        """srcs: the projected levels [N, C, H_l, W_l]; src_flatten: their flatten(2).transpose(1, 2) concatenation if the
+        caller already has it in one buffer (then srcs only give the shapes)."""
         shapes_list = [(int(s.shape[2]), int(s.shape[3])) for s in srcs]
         key = (tuple(shapes_list), srcs[0].device)
         cached = self._shape_cache.get(key)
@@ -181,10 +183,17 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
             cached = (ss, lsi)
             self._shape_cache[key] = cached
         spatial_shapes, level_start_index = cached
-        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        if src_flatten is None:
+            src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         if self._fused_ok(srcs, pos_embeds):
             meta = self._fused_meta(shapes_list, spatial_shapes, level_start_index, srcs[0].device)
-            pos_const = torch.cat([p[0].flatten(1).t() for p in pos_embeds], 0).contiguous()
+            # [S, C] positional rows: a function of the (cached) embeddings only — rebuilt when they change, not per step
+            pkey = tuple((p.data_ptr(), tuple(p.shape), p._version) for p in pos_embeds)     # (the held views pin the storage)
+            hit = self._shape_cache.get("pos_const")
+            if hit is None or hit[0] != pkey:
+                hit = (pkey, torch.cat([p[0].flatten(1).t() for p in pos_embeds], 0).contiguous(), list(pos_embeds))
+                self._shape_cache["pos_const"] = hit
+            pos_const = hit[1]
             params = [t for layer in self.encoder.layers for t in encoder_fused.layer_params(layer)]
             memory = encoder_fused.EncoderFn.apply(src_flatten, pos_const, self.level_embed, meta, *params)
             return memory, spatial_shapes, level_start_index
@@ -312,13 +321,24 @@ class MSDeformAttnPixelDecoder(nn.Module):
             return self._forward_features_fp32(features, amp_bf16 and os.environ.get("MPF_MASK_FEATURES_BF16", "1") == "1")
 
     def _forward_features_fp32(self, features, mask_features_bf16=False):
-        srcs, pos = [], []
+        srcs, pos, convs = [], [], []
         for idx, f in enumerate(self.transformer_in_features[::-1]):
             x = features[f]                       # (bf16 under autocast: the 1x1 GEMM form takes it as it is; else .float())
             proj = self.input_proj[idx]
-            srcs.append(proj[1](_conv(proj[0], x)) if len(proj) == 2 else proj(x.float()))
+            convs.append(_conv(proj[0], x) if len(proj) == 2 else None)
             pos.append(self.pe_layer(x))
-        y, spatial_shapes, level_start_index = self.transformer(srcs, pos)
+        src_flatten = None
+        if all(c is not None for c in convs) and os.environ.get("MPF_GN_FLATTEN", "1") == "1":
+            # conv1x1 -> GroupNorm -> flatten -> concat (msdeformattn.py:319-322, :60-66): the norm's apply pass writes
+            # each level straight into its rows of the encoder's [N, S, C] input
+            src_flatten = group_norm_flatten([p[1] for p in self.input_proj], convs)
+        if src_flatten is not None:
+            srcs = convs                          # (shapes only)
+        else:
+            for idx, f in enumerate(self.transformer_in_features[::-1]):
+                proj = self.input_proj[idx]
+                srcs.append(proj[1](convs[idx]) if convs[idx] is not None else proj(features[f].float()))
+        y, spatial_shapes, level_start_index = self.transformer(srcs, pos, src_flatten)
         bs = y.shape[0]
         sizes = [int(s.shape[2]) * int(s.shape[3]) for s in srcs]
         out = [z.transpose(1, 2).reshape(bs, -1, srcs[i].shape[2], srcs[i].shape[3])

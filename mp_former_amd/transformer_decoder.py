@@ -27,6 +27,7 @@ from torch import Tensor, nn
 
 from . import _lib, _rng
 from ._h2d import upload
+from ._targets import stacked_masks
 from .attention import attention_core
 from .resln import res_ln
 from .small_linear import small_linear, tall_linear, tall_usable as _tall_ok, usable as _small_ok
@@ -470,7 +471,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         rows = []
         gts = [t["masks"] for t in targets if len(t["masks"]) > 0]
         same = all(g.shape[1:] == gts[0].shape[1:] and g.dtype == gts[0].dtype for g in gts)
-        all_masks = torch.cat(gts) if same else None
+        all_masks = stacked_masks(gts) if same else None      # (shared with the matcher's copy: _targets.py)
         for size in size_list:
             pm = torch.ones(bs, pad, size[0] * size[1], dtype=torch.bool, device=device)
             gt = gt_block_or(all_masks, size) if same else torch.cat([gt_block_or(g, size) for g in gts])

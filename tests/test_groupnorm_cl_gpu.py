@@ -80,3 +80,37 @@ def test_group_norm_module_routes_channel_last_and_matches_nchw():
     ref = F.group_norm(x.double(), 32, gn.weight.double(), gn.bias.double(), gn.eps)
     torch.testing.assert_close(y_cl.double(), ref, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(y_nchw.double(), ref, rtol=1e-4, atol=1e-3)
+
+
+def test_group_norm_flatten_equals_per_level_norm_and_cat():
+    """group_norm_flatten: input_proj GroupNorm of three levels written straight into the encoder's [N, S, C] input
+    (msdeformattn.py:319-322, :60-66) == per-level GroupNorm + flatten(2).transpose(1, 2) + cat, values and gradients."""
+    from mp_former_amd.groupnorm import GroupNorm, group_norm_flatten
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    N, C = 2, 256
+    sizes = [(8, 8), (16, 12), (32, 24)]
+    norms, xs = [], []
+    for i, (H, W) in enumerate(sizes):
+        gn = GroupNorm(32, C).to(dev)
+        with torch.no_grad():
+            gn.weight.uniform_(0.5, 1.5); gn.bias.normal_()
+        norms.append(gn)
+        xs.append(_planes(N, C, H, W, dev, batch_pad=256 * i).detach().requires_grad_(True))
+    y = group_norm_flatten(norms, xs)
+    assert y is not None and y.shape == (N, sum(h * w for h, w in sizes), C) and y.is_contiguous()
+    g = torch.randn_like(y)
+    y.backward(g)
+    got = [(x.grad.clone(), n.weight.grad.clone(), n.bias.grad.clone()) for x, n in zip(xs, norms)]
+    for x, n in zip(xs, norms):
+        x.grad = None; n.weight.grad = None; n.bias.grad = None
+    y2 = torch.cat([n.forward_cl(x).flatten(2).transpose(1, 2) for n, x in zip(norms, xs)], 1)
+    assert torch.equal(y, y2)
+    y2.backward(g)
+    for (dx, dw, db), x, n in zip(got, xs, norms):
+        assert torch.equal(dx, x.grad) and torch.equal(dw, n.weight.grad) and torch.equal(db, n.bias.grad)
+    ref = torch.cat([F.group_norm(x.detach().double(), 32, n.weight.double(), n.bias.double(), n.eps).flatten(2).transpose(1, 2)
+                     for n, x in zip(norms, xs)], 1)
+    assert (y.double() - ref).abs().max() < 1e-4
+    # a level that does not qualify (NCHW-contiguous input) -> None: the caller keeps the per-level route
+    assert group_norm_flatten(norms, [xs[0].detach().contiguous(), xs[1], xs[2]]) is None

@@ -33,8 +33,11 @@ want = ("aten::add", "aten::add_", "aten::copy_", "aten::fill_", "aten::zero_", 
         "aten::clamp_min", "aten::relu", "aten::cat", "aten::div", "aten::_to_copy", "aten::contiguous", "aten::clone", "aten::mul_")
 rows = []
 for e in prof.key_averages(group_by_input_shape=True):
-    if (e.key in want or "--all" in sys.argv) and e.self_device_time_total > 0:
+    if "--aten" in sys.argv:
+        if e.key.startswith("aten::") and e.self_device_time_total > 0 and "convolution" not in e.key:
+            rows.append((e.self_device_time_total / 1e3, e.count, e.key, str(e.input_shapes)[:150]))
+    elif (e.key in want or "--all" in sys.argv) and e.self_device_time_total > 0:
         rows.append((e.self_device_time_total / 1e3, e.count, e.key, str(e.input_shapes)[:110]))
 rows.sort(reverse=True)
-for t, c, k, sh in rows[:(70 if '--all' in sys.argv else 45)]:
+for t, c, k, sh in rows[:(200 if '--aten' in sys.argv else 70 if '--all' in sys.argv else 45)]:
     print(f"{t:7.3f} ms x{c:4d}  {k:26s} {sh}")
