@@ -259,6 +259,22 @@ int mpf_attn_backward(const void* q, const void* k, const void* v, const void* k
  * delta[n, h, q] = sum_d dout[q, n, h*32+d] * out[q, n, h*32+d].
  */
 int mpf_attn_transpose2(const void* a, const void* b, void* aT, void* bT, int L, int LP, int N, int E, void* stream);
+/*
+ * The same entry points for K / V (and dK / dV) that are COLUMN BLOCKS of a wider matrix: the key / value projections of
+ * the three decoder layers that attend to one feature level (mask2former_transformer_decoder.py:1784-1789, level =
+ * i % 3) are one [S * N, 256] x [256, 768] product, and a layer reads its 256 columns in place.  Strides in elements
+ * between sequence positions (row) and between images (img); multiples of 8; 0, 0 = dense [L, N, E].
+ */
+int mpf_attn_transpose2_strided(const void* a, const void* b, int64_t in_row_stride, int64_t in_img_stride, void* aT, void* bT, int L,
+                                int LP, int N, int E, void* stream);
+int mpf_attn_forward_kv(const void* q, const void* k, int64_t k_row_stride, int64_t k_img_stride, const void* vt, const uint8_t* mask,
+                        int mask_per_image, void* out, float* lse, int Lq, int Lk, int N, int H, int head_dim, float scale,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int mpf_attn_backward_kv(const void* q, const void* k, const void* v, int64_t kv_row_stride, int64_t kv_img_stride, const void* kT,
+                         const void* qT, const void* dout, const void* doutT, const uint8_t* mask, int mask_per_image,
+                         const float* lse, const float* delta, void* dq, void* dk, void* dv, int64_t dkv_row_stride,
+                         int64_t dkv_img_stride, int Lq, int LqP, int Lk, int N, int H, int head_dim, float scale, void* workspace,
+                         size_t workspace_bytes, void* stream);
 int mpf_attn_delta(const void* dout, const void* out, float* delta, int Lq, int N, int H, void* stream);
 /* mpf_attn_transpose2(q, dout -> qT, doT; E = 32 * H) and mpf_attn_delta(dout, out) in ONE launch: everything the attention
  * backward derives from the query side (nn.MultiheadAttention backward, mask2former_transformer_decoder.py:42-52, :100-112) */
@@ -462,6 +478,9 @@ typedef struct MpfDecoderLayer {
     uint64_t scratch_bytes, attn_ws_bytes;
     int32_t Qt, N, H, S, ffn_dim;
     float eps;
+    /* element strides of k_c / v_c between sequence positions and between images; 0, 0 = dense [S, N, E].  A packed
+       [S, N, 3E] projection shared by the three layers of a level is (N * 3E, 3E) with k_c pointing at the layer's columns */
+    int64_t kv_row_stride, kv_img_stride;
 } MpfDecoderLayer;
 
 typedef struct MpfDecoderLayerGrad {
@@ -478,6 +497,7 @@ typedef struct MpfDecoderLayerGrad {
     void *d_sa_wq, *d_sa_bq, *d_sa_wk, *d_sa_bk, *d_sa_wv, *d_sa_bv, *d_sa_wo, *d_sa_bo;
     void *d_ff_w1, *d_ff_b1, *d_ff_w2, *d_ff_b2;
     float* d_ln;
+    int64_t dkv_row_stride, dkv_img_stride;   /* strides of d_k_c / d_v_c as above (0, 0 = dense) */
 } MpfDecoderLayerGrad;
 
 uint64_t mpf_decoder_layer_struct_bytes(int which); /* 0: sizeof(MpfDecoderLayer), 1: sizeof(MpfDecoderLayerGrad) */

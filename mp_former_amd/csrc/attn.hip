@@ -104,6 +104,7 @@ struct AttnParams {
     float* part_ml;               // [splits, N, H, Lq, 2]    (max, sum)
     int Lq, Lk, N, H, E, splits, keys_per_split;
     float scale;
+    int64_t k_row, k_img;         // element strides of k between sequence positions / images (N*E, E when dense)
 };
 
 // QS = number of 16-row query sub-tiles per wave
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p)
     const int kb1 = min(p.Lk, kb0 + p.keys_per_split);
     const int64_t rowE = (int64_t)p.N * p.E;                       // stride between sequence positions
     const __hip_bfloat16* qb = p.q + (int64_t)n * p.E + h * kHD;
-    const __hip_bfloat16* kb = p.k + (int64_t)n * p.E + h * kHD;
+    const __hip_bfloat16* kb = p.k + (int64_t)n * p.k_img + h * kHD;
     const __hip_bfloat16* vb = p.vt + ((int64_t)n * p.E + h * kHD) * p.Lk;
     bf16x8 bq[QS];
 #pragma unroll
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnParams p)
     auto load_step = [&](Step& st, const int kk) {
         // S^T tiles: keys kk+16t .. +15
 #pragma unroll
-        for (int t = 0; t < 2; ++t) st.ak[t] = ld8_rows(kb, kk + 16 * t + c16, kb1, rowE, 8 * g);
+        for (int t = 0; t < 2; ++t) st.ak[t] = ld8_rows(kb, kk + 16 * t + c16, kb1, p.k_row, 8 * g);
         // V^T fragments: rows d = 16*dt + c16, keys {kk+4g..+3} and {kk+16+4g..+3}
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -277,6 +278,8 @@ struct AttnBwdParams {
     float* part_dq;                                // [splits, N, H, Lq, 32]
     int Lq, LqP, Lk, N, H, E, splits, keys_per_split;
     float scale;
+    int64_t kv_row, kv_img;        // element strides of k, v between sequence positions / images (N*E, E when dense)
+    int64_t dkv_row, dkv_img;      // ... and of dk, dv
 };
 
 __device__ __forceinline__ bf16x8 load8(const __hip_bfloat16* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -297,12 +300,13 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
     const int kb = blockIdx.x * 32, h = blockIdx.y, n = blockIdx.z;
     const int64_t rowE = (int64_t)p.N * p.E;
     const int64_t hoff = (int64_t)n * p.E + h * kHD;
+    const int64_t kvoff = (int64_t)n * p.kv_img + h * kHD, dkvoff = (int64_t)n * p.dkv_img + h * kHD;
     bf16x8 bk[2], bv[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         const int key = kb + 16 * kt + c16;
-        bk[kt] = ld8_rows(p.k + hoff, key, p.Lk, rowE, 8 * g);
-        bv[kt] = ld8_rows(p.v + hoff, key, p.Lk, rowE, 8 * g);
+        bk[kt] = ld8_rows(p.k + kvoff, key, p.Lk, p.kv_row, 8 * g);
+        bv[kt] = ld8_rows(p.v + kvoff, key, p.Lk, p.kv_row, 8 * g);
     }
     f32x4 dkt[2][2], dvt[2][2];
 #pragma unroll
@@ -392,8 +396,8 @@ __global__ __launch_bounds__(64) void attn_bwd_kv_kernel(AttnBwdParams p)
             for (int dt = 0; dt < 2; ++dt) {
                 const bf16x4 kk = {(__bf16)dkt[kt][dt][0], (__bf16)dkt[kt][dt][1], (__bf16)dkt[kt][dt][2], (__bf16)dkt[kt][dt][3]};
                 const bf16x4 vv = {(__bf16)dvt[kt][dt][0], (__bf16)dvt[kt][dt][1], (__bf16)dvt[kt][dt][2], (__bf16)dvt[kt][dt][3]};
-                *reinterpret_cast<bf16x4*>(p.dk + hoff + (int64_t)key * rowE + 16 * dt + 4 * g) = kk;
-                *reinterpret_cast<bf16x4*>(p.dv + hoff + (int64_t)key * rowE + 16 * dt + 4 * g) = vv;
+                *reinterpret_cast<bf16x4*>(p.dk + dkvoff + (int64_t)key * p.dkv_row + 16 * dt + 4 * g) = kk;
+                *reinterpret_cast<bf16x4*>(p.dv + dkvoff + (int64_t)key * p.dkv_row + 16 * dt + 4 * g) = vv;
             }
         }
     }
@@ -411,6 +415,7 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(AttnBwdParams p)
     const int kb1 = min(p.Lk, kb0 + p.keys_per_split);
     const int64_t rowE = (int64_t)p.N * p.E;
     const int64_t hoff = (int64_t)n * p.E + h * kHD;
+    const int64_t kvoff = (int64_t)n * p.kv_img + h * kHD;
     const __hip_bfloat16* kTb = p.kT + ((int64_t)n * p.E + h * kHD) * p.Lk;
     bf16x8 bq[QS], bdo[QS];
     float ls[QS], de[QS];
@@ -433,8 +438,8 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(AttnBwdParams p)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = kk + 16 * t + c16;
-            st.ak[t] = ld8_rows(p.k + hoff, key, kb1, rowE, 8 * g);
-            st.av[t] = ld8_rows(p.v + hoff, key, kb1, rowE, 8 * g);
+            st.ak[t] = ld8_rows(p.k + kvoff, key, kb1, p.kv_row, 8 * g);
+            st.av[t] = ld8_rows(p.v + kvoff, key, kb1, p.kv_row, 8 * g);
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -517,14 +522,19 @@ __global__ __launch_bounds__(256) void attn_sum_splits_kernel(const float* __res
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void transpose2_tile(const __hip_bfloat16* __restrict__ a, const __hip_bfloat16* __restrict__ b,
                                                 __hip_bfloat16* __restrict__ aT, __hip_bfloat16* __restrict__ bT,
-                                                int L, int LP, int NE, const int bx, const int by)
+                                                int L, int LP, int NE, const int bx, const int by, const int E = 0,
+                                                const int64_t in_row = 0, const int64_t in_img = 0)
 {
+    // input element (position l, column c = n * E + e) at l * in_row + n * in_img + e; E == 0: dense rows of NE columns
+    auto src = [&](int l, int c) -> int64_t {
+        return E ? (int64_t)l * in_row + (int64_t)(c / E) * in_img + (c % E) : (int64_t)l * NE + c;
+    };
     // tile of 64 sequence positions x 64 columns through LDS: 16-byte global loads (8 columns of a row) and stores (8
     // positions of a column); the transpose itself is 2-byte LDS writes into [column][position] rows of 72 elements
     // (144 B: the 16-byte reads of consecutive columns start 36 banks apart)
     __shared__ __attribute__((aligned(16))) unsigned short ta[64][72], tb[64][72];
     const int l0 = bx * 64, c0 = by * 64;
-    const bool vec = (NE % 8 == 0) && (LP % 8 == 0) &&
+    const bool vec = (NE % 8 == 0) && (LP % 8 == 0) && (E % 8 == 0) && (in_row % 8 == 0) && (in_img % 8 == 0) &&
                      (((uintptr_t)a | (uintptr_t)b | (uintptr_t)aT | (uintptr_t)bT) & 15) == 0;
     if (vec) {
 #pragma unroll
@@ -534,8 +544,8 @@ __device__ __forceinline__ void transpose2_tile(const __hip_bfloat16* __restrict
             const int l = l0 + r, c = c0 + cg * 8;
             uint4 va = make_uint4(0u, 0u, 0u, 0u), vb = va;
             if (l < L && c < NE) {
-                va = *reinterpret_cast<const uint4*>(a + (int64_t)l * NE + c);
-                vb = *reinterpret_cast<const uint4*>(b + (int64_t)l * NE + c);
+                va = *reinterpret_cast<const uint4*>(a + src(l, c));
+                vb = *reinterpret_cast<const uint4*>(b + src(l, c));
             }
             const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
@@ -563,8 +573,8 @@ __device__ __forceinline__ void transpose2_tile(const __hip_bfloat16* __restrict
     for (int r = ty; r < 64; r += 4) {
         const int l = l0 + r, c = c0 + tx;
         const bool ok = l < L && c < NE;
-        ta[tx][r] = ok ? reinterpret_cast<const unsigned short*>(a)[(int64_t)l * NE + c] : (unsigned short)0;
-        tb[tx][r] = ok ? reinterpret_cast<const unsigned short*>(b)[(int64_t)l * NE + c] : (unsigned short)0;
+        ta[tx][r] = ok ? reinterpret_cast<const unsigned short*>(a)[src(l, c)] : (unsigned short)0;
+        tb[tx][r] = ok ? reinterpret_cast<const unsigned short*>(b)[src(l, c)] : (unsigned short)0;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
@@ -578,9 +588,9 @@ __device__ __forceinline__ void transpose2_tile(const __hip_bfloat16* __restrict
 
 __global__ __launch_bounds__(256) void attn_transpose2_kernel(const __hip_bfloat16* __restrict__ a, const __hip_bfloat16* __restrict__ b,
                                                                __hip_bfloat16* __restrict__ aT, __hip_bfloat16* __restrict__ bT,
-                                                               int L, int LP, int NE)
+                                                               int L, int LP, int NE, int E, int64_t in_row, int64_t in_img)
 {
-    transpose2_tile(a, b, aT, bT, L, LP, NE, (int)blockIdx.x, (int)blockIdx.y);
+    transpose2_tile(a, b, aT, bT, L, LP, NE, (int)blockIdx.x, (int)blockIdx.y, E, in_row, in_img);
 }
 
 __device__ __forceinline__ void delta_block(const __hip_bfloat16* __restrict__ dout, const __hip_bfloat16* __restrict__ out,
@@ -644,7 +654,17 @@ extern "C" int mpf_attn_forward(const void* q, const void* k, const void* vt, co
                                 void* out, float* lse, int Lq, int Lk, int N, int H, int head_dim, float scale,
                                 void* workspace, size_t workspace_bytes, void* stream)
 {
+    return mpf_attn_forward_kv(q, k, 0, 0, vt, mask, mask_per_image, out, lse, Lq, Lk, N, H, head_dim, scale, workspace,
+                               workspace_bytes, stream);
+}
+
+extern "C" int mpf_attn_forward_kv(const void* q, const void* k, int64_t k_row_stride, int64_t k_img_stride, const void* vt,
+                                   const uint8_t* mask, int mask_per_image, void* out, float* lse, int Lq, int Lk, int N, int H,
+                                   int head_dim, float scale, void* workspace, size_t workspace_bytes, void* stream)
+{
     if (!q || !k || !vt || !out || !workspace) return mpf::fail(MPF_E_NULL, "attn_forward: NULL buffer");
+    if (k_row_stride < 0 || k_img_stride < 0 || (k_row_stride | k_img_stride) % 8 || ((uintptr_t)k & 15))
+        return mpf::fail(MPF_E_SHAPE, "attn_forward: K strides must be non-negative multiples of 8 elements, K 16-byte aligned");
     if (head_dim != kHD) return mpf::fail(MPF_E_SHAPE, "attn_forward: head_dim must be 32");
     if (Lq <= 0 || Lk <= 0 || N <= 0 || H <= 0) return mpf::fail(MPF_E_SHAPE, "attn_forward: bad sizes");
     if (workspace_bytes < mpf_attn_workspace_bytes(Lq, Lk, N, H)) return mpf::fail(MPF_E_SHAPE, "attn_forward: workspace too small");
@@ -653,6 +673,8 @@ extern "C" int mpf_attn_forward(const void* q, const void* k, const void* vt, co
     p.q = (const __hip_bfloat16*)q; p.k = (const __hip_bfloat16*)k; p.vt = (const __hip_bfloat16*)vt;
     p.mask = mask; p.mask_stride_n = mask_per_image ? (int64_t)Lq * Lk : 0;
     p.Lq = Lq; p.Lk = Lk; p.N = N; p.H = H; p.E = H * kHD; p.scale = scale;
+    p.k_row = k_row_stride ? k_row_stride : (int64_t)N * p.E;
+    p.k_img = k_row_stride ? k_img_stride : p.E;
     p.splits = attn_splits(Lq, Lk, N, H);
     p.keys_per_split = (((Lk + p.splits - 1) / p.splits) + 31) & ~31;
     p.splits = (Lk + p.keys_per_split - 1) / p.keys_per_split;          // (rounding up to 32 keys may need fewer)
@@ -684,8 +706,22 @@ extern "C" int mpf_attn_backward(const void* q, const void* k, const void* v, co
                                  int Lq, int LqP, int Lk, int N, int H, int head_dim, float scale,
                                  void* workspace, size_t workspace_bytes, void* stream)
 {
+    return mpf_attn_backward_kv(q, k, v, 0, 0, kT, qT, dout, doutT, mask, mask_per_image, lse, delta, dq, dk, dv, 0, 0, Lq, LqP, Lk, N, H,
+                                head_dim, scale, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mpf_attn_backward_kv(const void* q, const void* k, const void* v, int64_t kv_row_stride, int64_t kv_img_stride,
+                                    const void* kT, const void* qT, const void* dout, const void* doutT, const uint8_t* mask,
+                                    int mask_per_image, const float* lse, const float* delta, void* dq, void* dk, void* dv,
+                                    int64_t dkv_row_stride, int64_t dkv_img_stride, int Lq, int LqP, int Lk, int N, int H,
+                                    int head_dim, float scale, void* workspace, size_t workspace_bytes, void* stream)
+{
     if (!q || !k || !v || !kT || !qT || !dout || !doutT || !lse || !delta || !dq || !dk || !dv || !workspace)
         return mpf::fail(MPF_E_NULL, "attn_backward: NULL buffer");
+    if (kv_row_stride < 0 || kv_img_stride < 0 || dkv_row_stride < 0 || dkv_img_stride < 0 ||
+        (kv_row_stride | kv_img_stride | dkv_row_stride | dkv_img_stride) % 8 ||
+        (((uintptr_t)k | (uintptr_t)v | (uintptr_t)dk | (uintptr_t)dv) & 15))
+        return mpf::fail(MPF_E_SHAPE, "attn_backward: K / V strides must be non-negative multiples of 8 elements, buffers 16-byte aligned");
     if (head_dim != kHD) return mpf::fail(MPF_E_SHAPE, "attn_backward: head_dim must be 32");
     if (Lq <= 0 || Lk <= 0 || N <= 0 || H <= 0 || LqP < Lq || (LqP & 31)) return mpf::fail(MPF_E_SHAPE, "attn_backward: bad sizes");
     if (workspace_bytes < mpf_attn_workspace_bytes(Lq, Lk, N, H)) return mpf::fail(MPF_E_SHAPE, "attn_backward: workspace too small");
@@ -698,6 +734,10 @@ extern "C" int mpf_attn_backward(const void* q, const void* k, const void* v, co
     p.lse = lse; p.delta = delta;
     p.dk = (__hip_bfloat16*)dk; p.dv = (__hip_bfloat16*)dv; p.part_dq = (float*)workspace;
     p.Lq = Lq; p.LqP = LqP; p.Lk = Lk; p.N = N; p.H = H; p.E = H * kHD; p.scale = scale;
+    p.kv_row = kv_row_stride ? kv_row_stride : (int64_t)N * p.E;
+    p.kv_img = kv_row_stride ? kv_img_stride : p.E;
+    p.dkv_row = dkv_row_stride ? dkv_row_stride : (int64_t)N * p.E;
+    p.dkv_img = dkv_row_stride ? dkv_img_stride : p.E;
     p.splits = attn_splits(Lq, Lk, N, H);
     p.keys_per_split = (((Lk + p.splits - 1) / p.splits) + 31) & ~31;
     p.splits = (Lk + p.keys_per_split - 1) / p.keys_per_split;          // (rounding up to 32 keys may need fewer)
@@ -728,13 +768,21 @@ extern "C" int mpf_attn_backward(const void* q, const void* k, const void* v, co
 
 extern "C" int mpf_attn_transpose2(const void* a, const void* b, void* aT, void* bT, int L, int LP, int N, int E, void* stream)
 {
+    return mpf_attn_transpose2_strided(a, b, 0, 0, aT, bT, L, LP, N, E, stream);
+}
+
+extern "C" int mpf_attn_transpose2_strided(const void* a, const void* b, int64_t in_row_stride, int64_t in_img_stride, void* aT,
+                                           void* bT, int L, int LP, int N, int E, void* stream)
+{
     if (!a || !b || !aT || !bT) return mpf::fail(MPF_E_NULL, "attn_transpose2: NULL buffer");
-    if (L <= 0 || LP < L || N <= 0 || E <= 0) return mpf::fail(MPF_E_SHAPE, "attn_transpose2: bad sizes");
+    if (L <= 0 || LP < L || N <= 0 || E <= 0 || in_row_stride < 0 || in_img_stride < 0)
+        return mpf::fail(MPF_E_SHAPE, "attn_transpose2: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int NE = N * E;
     mpf::set_kernel("attn_transpose2_kernel");
     hipLaunchKernelGGL(attn_transpose2_kernel, dim3((LP + 63) / 64, (NE + 63) / 64), dim3(256), 0, st,
-                       (const __hip_bfloat16*)a, (const __hip_bfloat16*)b, (__hip_bfloat16*)aT, (__hip_bfloat16*)bT, L, LP, NE);
+                       (const __hip_bfloat16*)a, (const __hip_bfloat16*)b, (__hip_bfloat16*)aT, (__hip_bfloat16*)bT, L, LP, NE,
+                       in_row_stride ? E : 0, in_row_stride, in_img_stride);
     return mpf::check(hipGetLastError(), "mpf_attn_transpose2");
 }
 

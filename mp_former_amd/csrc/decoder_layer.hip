@@ -178,9 +178,9 @@ extern "C" int mpf_decoder_layer_forward(const MpfDecoderLayer* L, void* st)
     const float scale = 0.17677669529663687f;       // 1 / sqrt(32)
     // cross-attention (:1784-1789) + post-norm
     MPF_TRY(lin_fwd(L->xb0, L->ca_wq, L->ca_bq, L->q_c, R, kE, kE, 0, st));
-    MPF_TRY(mpf_attn_transpose2(L->k_c, L->v_c, L->kT_c, f.vT_c, S, S, N, kE, st));
-    MPF_TRY(mpf_attn_forward(L->q_c, L->k_c, f.vT_c, L->mask_c, 1, L->o_c, L->lse_c, Qt, S, N, H, 32, scale, L->attn_ws,
-                             L->attn_ws_bytes, st));
+    MPF_TRY(mpf_attn_transpose2_strided(L->k_c, L->v_c, L->kv_row_stride, L->kv_img_stride, L->kT_c, f.vT_c, S, S, N, kE, st));
+    MPF_TRY(mpf_attn_forward_kv(L->q_c, L->k_c, L->kv_row_stride, L->kv_img_stride, f.vT_c, L->mask_c, 1, L->o_c, L->lse_c, Qt, S, N,
+                                H, 32, scale, L->attn_ws, L->attn_ws_bytes, st));
     MPF_TRY(lin_fwd(L->o_c, L->ca_wo, L->ca_bo, f.t, R, kE, kE, 0, st));
     MPF_TRY(mpf_res_ln256_forward(L->x0, f.t, MPF_BF16, L->ca_gamma, L->ca_beta, L->s1, f.x1, L->xb1, L->mean1, L->rstd1, R,
                                   L->eps, nullptr, 0, nullptr, st));
@@ -270,8 +270,9 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
     MPF_TRY(lin_dx(b.dt1, nullptr, L->ca_wo, nullptr, b.dout, R, kE, kE, st));
     dw[ndw++] = dw_item(b.dt1, nullptr, L->o_c, G->d_ca_wo, G->d_ca_bo, R, kE, kE);
     MPF_TRY(mpf_attn_bwd_prep(L->q_c, b.dout, L->o_c, b.qT, b.doT, b.delta, Qt, LqP, N, H, st));
-    MPF_TRY(mpf_attn_backward(L->q_c, L->k_c, L->v_c, L->kT_c, b.qT, b.dout, b.doT, L->mask_c, 1, L->lse_c, b.delta, b.dq_c, G->d_k_c,
-                              G->d_v_c, Qt, LqP, S, N, H, 32, scale, L->attn_ws, L->attn_ws_bytes, st));
+    MPF_TRY(mpf_attn_backward_kv(L->q_c, L->k_c, L->v_c, L->kv_row_stride, L->kv_img_stride, L->kT_c, b.qT, b.dout, b.doT, L->mask_c, 1,
+                                 L->lse_c, b.delta, b.dq_c, G->d_k_c, G->d_v_c, G->dkv_row_stride, G->dkv_img_stride, Qt, LqP, S, N, H,
+                                 32, scale, L->attn_ws, L->attn_ws_bytes, st));
     MPF_TRY(lin_dx(b.dq_c, nullptr, L->ca_wq, nullptr, G->d_xb0, R, kE, kE, st));
     dw[ndw++] = dw_item(b.dq_c, nullptr, L->xb0, G->d_ca_wq, G->d_ca_bq, R, kE, kE);
     if (g_dw_group) {

@@ -29,7 +29,8 @@ class MpfDecoderLayer(ctypes.Structure):
     _fields_ = ([(n, _vp) for n in PARAM_NAMES] + [(n, _vp) for n in ("x0", "xb0", "k_c", "v_c", "mask_c", "mask_s")]
                 + [(n, _vp) for n in _SAVED] + [("x3", _vp), ("xb3", _vp), ("scratch", _vp), ("attn_ws", _vp),
                                                 ("scratch_bytes", _u64), ("attn_ws_bytes", _u64)]
-                + [(n, _i32) for n in ("Qt", "N", "H", "S", "ffn_dim")] + [("eps", ctypes.c_float)])
+                + [(n, _i32) for n in ("Qt", "N", "H", "S", "ffn_dim")] + [("eps", ctypes.c_float)]
+                + [("kv_row_stride", ctypes.c_int64), ("kv_img_stride", ctypes.c_int64)])
 
 
 _WGRADS = tuple("d_" + n for n in PARAM_NAMES if n not in _LN)
@@ -37,7 +38,7 @@ _WGRADS = tuple("d_" + n for n in PARAM_NAMES if n not in _LN)
 
 class MpfDecoderLayerGrad(ctypes.Structure):
     _fields_ = ([(n, _vp) for n in ("g_x3", "g_xb3", "d_x0", "d_xb0", "d_k_c", "d_v_c")] + [(n, _vp) for n in _WGRADS]
-                + [("d_ln", _vp)])
+                + [("d_ln", _vp), ("dkv_row_stride", ctypes.c_int64), ("dkv_img_stride", ctypes.c_int64)])
 
 
 _checked = False
@@ -67,9 +68,55 @@ def _al(n):
     return (n + 255) & ~255
 
 
+class ColumnPack:
+    """The gradient of a [S, N, n * E] matrix whose n column blocks went to n different consumers (the key / value
+    projections of the decoder layers that share a feature level): ONE buffer, allocated when the first consumer's
+    backward asks for its block; each consumer writes its block in place, so no zero-padded slice gradients are summed."""
+
+    def __init__(self, shape, dtype, device, block):
+        self.shape, self.dtype, self.device, self.block = tuple(shape), dtype, device, block
+        self.buf = None
+
+    def block_view(self, j):
+        if self.buf is None:
+            self.buf = torch.empty(self.shape, dtype=self.dtype, device=self.device)
+        return self.buf[..., j * self.block:(j + 1) * self.block]
+
+
+class _SplitColsFn(Function):
+    @staticmethod
+    def forward(ctx, y, pack, n):
+        ctx.pack, ctx.n = pack, n
+        E = pack.block
+        return tuple(y[..., j * E:(j + 1) * E] for j in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        pack = ctx.pack
+        for j, g in enumerate(gs):
+            want = pack.block_view(j)
+            if g is None:
+                want.zero_()
+            elif not (g.data_ptr() == want.data_ptr() and g.stride() == want.stride() and g.dtype == want.dtype):
+                want.copy_(g)                      # a consumer that did not write in place
+        buf, pack.buf = pack.buf, None
+        return buf, None, None
+
+
+def split_cols(y, n):
+    """y [S, N, n * E] -> [(view_j [S, N, E], (pack, j))]: column-block views for n consumers plus the handle through which
+    a consumer's backward (DecoderLayerFn) writes its block of the gradient in place."""
+    pack = ColumnPack(y.shape, y.dtype, y.device, y.shape[-1] // n)
+    if not y.requires_grad:
+        E = pack.block
+        return [(y[..., j * E:(j + 1) * E], None) for j in range(n)]
+    views = _SplitColsFn.apply(y, pack, n)
+    return [(v, (pack, j)) for j, v in enumerate(views)]
+
+
 class DecoderLayerFn(Function):
     @staticmethod
-    def forward(ctx, x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, *params):
+    def forward(ctx, x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, kv_pack, *params):
         lib = _lib_checked()
         Qt, N, E = x0.shape
         S = k_c.shape[0]
@@ -78,7 +125,10 @@ class DecoderLayerFn(Function):
         dev = x0.device
         assert E == 256 and nheads * 32 == E and len(params) == len(PARAM_NAMES)
         assert x0.dtype == torch.float32 and x0.is_contiguous() and xb0.dtype == torch.bfloat16 and xb0.is_contiguous()
-        assert k_c.dtype == torch.bfloat16 and k_c.is_contiguous() and v_c.is_contiguous() and k_c.shape == v_c.shape == (S, N, E)
+        # k_c / v_c: dense [S, N, E] or column blocks of a wider projection (same strides for both, rows 16-byte aligned)
+        assert k_c.dtype == v_c.dtype == torch.bfloat16 and k_c.shape == v_c.shape == (S, N, E) and k_c.stride() == v_c.stride()
+        assert k_c.stride(2) == 1 and k_c.stride(0) % 8 == 0 and k_c.stride(1) % 8 == 0
+        assert k_c.data_ptr() % 16 == 0 and v_c.data_ptr() % 16 == 0
         assert mask_c.dtype == torch.bool and mask_c.is_contiguous() and mask_c.shape == (N, Qt, S)
         if mask_s is not None:
             assert mask_s.dtype == torch.bool and mask_s.shape == (Qt, Qt)
@@ -108,6 +158,8 @@ class DecoderLayerFn(Function):
         L.mask_s = mask_s.data_ptr() if mask_s is not None else None
         L.x3, L.xb3 = x3.data_ptr(), xb3.data_ptr()
         L.Qt, L.N, L.H, L.S, L.ffn_dim, L.eps = Qt, N, nheads, S, F_, float(eps)
+        if not k_c.is_contiguous():
+            L.kv_row_stride, L.kv_img_stride = k_c.stride(0), k_c.stride(1)
         sc = _scratch_buf(dev, max(lib.mpf_decoder_layer_scratch_bytes(Qt, N, nheads, S, F_, 0),
                                    lib.mpf_decoder_layer_scratch_bytes(Qt, N, nheads, S, F_, 1)))
         ws = _attn_workspace(dev, max(lib.mpf_attn_workspace_bytes(Qt, S, N, nheads), lib.mpf_attn_workspace_bytes(Qt, Qt, N, nheads)))
@@ -118,6 +170,7 @@ class DecoderLayerFn(Function):
         _lib.check(code, "mpf_decoder_layer_forward")
         ctx.save_for_backward(xb0, k_c, v_c, mask_c, mask_s, arena, *params)
         ctx.layer = L
+        ctx.kv_pack = kv_pack
         ctx.dims = (Qt, N, E, S, F_, nheads)
         return x3, xb3
 
@@ -136,7 +189,15 @@ class DecoderLayerFn(Function):
             g_xb3 = g_xb3.to(torch.bfloat16).contiguous()
         d_x0 = torch.empty((Qt, N, E), dtype=torch.float32, device=dev)
         d_xb0 = torch.empty((Qt, N, E), dtype=torch.bfloat16, device=dev)
-        d_kv = torch.empty((2,) + tuple(k_c.shape), dtype=torch.bfloat16, device=dev)
+        G = MpfDecoderLayerGrad()
+        if ctx.kv_pack is not None:       # our blocks of the packed dK / dV of the level, written in place
+            (pk, jk), (pv, jv) = ctx.kv_pack
+            d_k, d_v = pk.block_view(jk), pv.block_view(jv)
+            assert d_k.stride() == d_v.stride()
+            G.dkv_row_stride, G.dkv_img_stride = d_k.stride(0), d_k.stride(1)
+        else:
+            d_kv = torch.empty((2,) + tuple(k_c.shape), dtype=torch.bfloat16, device=dev)
+            d_k, d_v = d_kv[0], d_kv[1]
         wnames = [n for n in PARAM_NAMES if n not in _LN]
         wshapes = [p.shape for n, p in zip(PARAM_NAMES, params) if n not in _LN]
         # arena order: the q / k / v weight gradients side by side, then their bias gradients (the native layer then
@@ -149,10 +210,9 @@ class DecoderLayerFn(Function):
             tot += (wshapes[i].numel() + 127) & ~127
         wg = torch.empty(tot, dtype=torch.bfloat16, device=dev)
         d_ln = torch.empty((6, 256), dtype=torch.float32, device=dev)
-        G = MpfDecoderLayerGrad()
         G.g_x3 = g_x3.data_ptr() if g_x3 is not None else None
         G.g_xb3 = g_xb3.data_ptr() if g_xb3 is not None else None
-        G.d_x0, G.d_xb0, G.d_k_c, G.d_v_c = d_x0.data_ptr(), d_xb0.data_ptr(), d_kv[0].data_ptr(), d_kv[1].data_ptr()
+        G.d_x0, G.d_xb0, G.d_k_c, G.d_v_c = d_x0.data_ptr(), d_xb0.data_ptr(), d_k.data_ptr(), d_v.data_ptr()
         wbase = wg.data_ptr()
         for n, o in zip(_WGRADS, offs):
             setattr(G, n, wbase + 2 * o)
@@ -173,11 +233,12 @@ class DecoderLayerFn(Function):
                 s_ = wshapes[wi]
                 grads.append(wg[offs[wi]:offs[wi] + s_.numel()].view(s_))
                 wi += 1
-        return (d_x0, d_xb0, d_kv[0], d_kv[1], None, None, None, None, *grads)
+        return (d_x0, d_xb0, d_k, d_v, None, None, None, None, None, *grads)
 
 
-def decoder_layer(x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, params):
-    """(x3 fp32, xb3 bf16) = one decoder layer; ``params``: the 22 tensors of PARAM_NAMES."""
+def decoder_layer(x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, params, kv_pack=None):
+    """(x3 fp32, xb3 bf16) = one decoder layer; ``params``: the 22 tensors of PARAM_NAMES.  ``kv_pack`` = the
+    ``split_cols`` handles of k_c and v_c when they are column blocks of a level's packed projection."""
     if not x0.is_cuda:
         raise RuntimeError("mp_former_amd decoder layer runs on the GPU only (no CPU fallback)")
-    return DecoderLayerFn.apply(x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, *params)
+    return DecoderLayerFn.apply(x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, kv_pack, *params)

@@ -316,7 +316,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
 
     def forward_features(self, features):
         # the reference pins the whole pixel decoder to fp32 even under AMP (msdeformattn.py:314,320)
-        amp_bf16 = torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16
+        amp_bf16 = torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
         with torch.autocast(device_type="cuda", enabled=False):
             return self._forward_features_fp32(features, amp_bf16 and os.environ.get("MPF_MASK_FEATURES_BF16", "1") == "1")
 

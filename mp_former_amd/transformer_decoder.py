@@ -31,7 +31,7 @@ from ._targets import stacked_masks
 from .attention import attention_core
 from .resln import res_ln
 from .small_linear import small_linear, tall_linear, tall_usable as _tall_ok, usable as _small_ok
-from .decoder_layer import decoder_layer
+from .decoder_layer import decoder_layer, split_cols
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
 
 
@@ -85,6 +85,39 @@ class _CastParams(torch.autograd.Function):
         if dsts:
             torch._foreach_copy_(dsts, srcs)
         return (None, None, *res)
+
+
+class _GatherRows(torch.autograd.Function):
+    """Row-wise concatenations of groups of tensors in ONE multi-tensor launch: ``sizes[g]`` consecutive inputs form
+    output g.  The gradient of an input is a row-block VIEW of its output's gradient (no launch).  Used to put the key
+    (value) projection weights of the decoder layers that share a feature level side by side."""
+
+    @staticmethod
+    def forward(ctx, sizes, *ts):
+        outs, dsts, k = [], [], 0
+        for n in sizes:
+            grp = ts[k:k + n]
+            k += n
+            full = torch.empty((sum(t.shape[0] for t in grp),) + tuple(grp[0].shape[1:]), dtype=grp[0].dtype, device=grp[0].device)
+            r = 0
+            for t in grp:
+                dsts.append(full[r:r + t.shape[0]])
+                r += t.shape[0]
+            outs.append(full)
+        torch._foreach_copy_(dsts, [t.detach() for t in ts])
+        ctx.sizes, ctx.rows = sizes, [t.shape[0] for t in ts]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        res, k = [], 0
+        for n, g in zip(ctx.sizes, gs):
+            r = 0
+            for rows in ctx.rows[k:k + n]:
+                res.append(None if g is None else g[r:r + rows])
+                r += rows
+            k += n
+        return (None, *res)
 
 
 class _DecoderInputs(torch.autograd.Function):
@@ -215,7 +248,7 @@ def mask_product(me, mask_features):
     """outputs_mask = einsum("bqc,bchw->bqhw", mask_embed, mask_features) (decoder :1869)."""
     if _is_planes(mask_features) and not mask_features.is_contiguous() and me.dtype == mask_features.dtype and me.is_cuda:
         amp = torch.is_autocast_enabled()
-        if not amp or me.dtype == torch.get_autocast_gpu_dtype():      # operands already in the dtype autocast would pick
+        if not amp or me.dtype == torch.get_autocast_dtype("cuda"):      # operands already in the dtype autocast would pick
             with torch.autocast(device_type="cuda", enabled=False):
                 N, C, H, W = mask_features.shape
                 return _MaskProductCL.apply(me, mask_features).view(N, me.shape[1], H, W)
@@ -503,6 +536,31 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             return out
         return dict(named)
 
+    def _kv_batched(self, W, kin, src):
+        """Key / value projections of ALL decoder layers before the layer loop (they depend on the encoder memory only,
+        :1784-1789 with level = i % num_feature_levels): the layers that attend to one level share their input, so their
+        projections are ONE GEMM with the weights side by side ([S, N, 3 * 256] for 9 layers / 3 levels) instead of one
+        per layer — 6 GEMMs instead of 18 forward, and likewise for the input and weight gradients.  Layer i reads its 256
+        columns in place (strided K / V in the attention kernels) and its backward writes its columns of the packed
+        gradient.  -> {layer: ((k_c, handle), (v_c, handle))}"""
+        nl, nlev = self.num_layers, self.num_feature_levels
+        groups = [[i for i in range(nl) if i % nlev == l] for l in range(nlev)]
+        ws, sizes = [], []
+        for which in (1, 2):                                   # k rows, then v rows of the packed in-projections
+            for key in ("in_proj_weight", "in_proj_bias"):
+                for g in groups:
+                    ws += [W[f"transformer_cross_attention_layers.{i}.multihead_attn.{key}"][which] for i in g]
+                    sizes.append(len(g))
+        cat = _GatherRows.apply(sizes, *ws)                    # [wk_l..., bk_l..., wv_l..., bv_l...]
+        out = {}
+        for l, g in enumerate(groups):
+            wk, bk, wv, bv = cat[l], cat[nlev + l], cat[2 * nlev + l], cat[3 * nlev + l]
+            ks = split_cols(linear(kin[l], wk, bk), len(g))
+            vs = split_cols(linear(src[l], wv, bv), len(g))
+            for j, i in enumerate(g):
+                out[i] = (ks[j], vs[j])
+        return out
+
     def _heads(self, W, output, mask_features, attn_mask_target_size, mp_rows=None):
         """forward_prediction_heads (:1859-1877).  Returns (outputs_class, outputs_mask,
         attn_mask[N,Qtot,HW] bool) where the attention mask already has the MP rows written (:1814-1816)
@@ -659,6 +717,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         fused = (amp and adt == torch.bfloat16 and output.shape[-1] == 256 and H == 8
                  and isinstance(W["transformer_cross_attention_layers.0.multihead_attn.in_proj_weight"], tuple)
                  and os.environ.get("MPF_FUSED_DECODER", "1") == "1")
+        kv = self._kv_batched(W, kin, src) if fused and os.environ.get("MPF_KV_BATCH", "1") == "1" else None
         for i in range(self.num_layers):
             level = i % self.num_feature_levels
             if fused:
@@ -667,8 +726,11 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
                 ff = f"transformer_ffn_layers.{i}."
                 cw, cb = W[ca + "in_proj_weight"], W[ca + "in_proj_bias"]
                 sw, sb = W[sa + "in_proj_weight"], W[sa + "in_proj_bias"]
-                k_c = linear(kin[level], cw[1], cb[1])
-                v_c = linear(src[level], cw[2], cb[2])
+                if kv is not None:
+                    (k_c, pk), (v_c, pv) = kv[i]
+                    kv_pack = (pk, pv) if pk is not None and pv is not None else None
+                else:
+                    k_c, v_c, kv_pack = linear(kin[level], cw[1], cb[1]), linear(src[level], cw[2], cb[2]), None
                 n1, n2, n3 = (self.transformer_cross_attention_layers[i].norm, self.transformer_self_attention_layers[i].norm,
                               self.transformer_ffn_layers[i].norm)
                 output, xb = decoder_layer(
@@ -676,7 +738,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
                     (cw[0], cb[0], W[ca + "out_proj.weight"], W[ca + "out_proj.bias"], n1.weight, n1.bias,
                      sw[0], sb[0], sw[1], sb[1], sw[2], sb[2], W[sa + "out_proj.weight"], W[sa + "out_proj.bias"], n2.weight, n2.bias,
                      W[ff + "linear1.weight"], W[ff + "linear1.bias"], W[ff + "linear2.weight"], W[ff + "linear2.bias"],
-                     n3.weight, n3.bias))
+                     n3.weight, n3.bias), kv_pack)
             else:
                 output, xb = self._layer_by_ops(W, i, level, output, xb, kin, src, attn_mask, tgt_mask, post_norm)
             nxt = (i + 1) % self.num_feature_levels

@@ -96,3 +96,56 @@ def test_bwd_prep_equals_transpose_plus_delta():
                                          Lq, LqP, N, H, st), "prep")
         assert torch.equal(a[0], a[2]) and torch.equal(a[1], a[3]) and torch.equal(d[0], d[1])
         assert torch.equal(a[2][:, :, :Lq], q.permute(1, 2, 0)) and (a[2][:, :, Lq:] == 0).all()
+
+
+def test_strided_kv_entry_points_equal_the_dense_ones():
+    """mpf_attn_{transpose2_strided, forward_kv, backward_kv}: K / V (dK / dV) as 256-column blocks of a packed
+    [Lk, N, 768] projection give bit-identical results to dense [Lk, N, 256] copies of the same blocks."""
+    from mp_former_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    H, E, hd = 8, 256, 32
+    for Lq, Lk, N, j in [(115, 1024, 2, 1), (40, 200, 1, 2), (230, 4096, 2, 0)]:
+        LqP = (Lq + 31) // 32 * 32
+        st = torch.cuda.current_stream(dev).cuda_stream
+        q, do = (torch.randn(Lq, N, E, device=dev).bfloat16() for _ in range(2))
+        Kp, Vp = (torch.randn(Lk, N, 3 * E, device=dev).bfloat16() for _ in range(2))
+        ks, vs = Kp[..., j * E:(j + 1) * E], Vp[..., j * E:(j + 1) * E]
+        kd, vd = ks.contiguous(), vs.contiguous()
+        mask = torch.rand(N, Lq, Lk, device=dev) < 0.4
+        mask[:, :, 0] = False
+        ws = torch.empty(lib.mpf_attn_workspace_bytes(Lq, Lk, N, H) + 1024, dtype=torch.uint8, device=dev)
+
+        def run(k, v, strided):
+            rs, im = (k.stride(0), k.stride(1)) if strided else (0, 0)
+            kt, vt = (torch.empty(N, E, Lk, dtype=torch.bfloat16, device=dev) for _ in range(2))
+            _lib.check(lib.mpf_attn_transpose2_strided(k.data_ptr(), v.data_ptr(), rs, im, kt.data_ptr(), vt.data_ptr(), Lk, Lk, N, E, st), "t")
+            out = torch.empty(Lq, N, E, dtype=torch.bfloat16, device=dev)
+            lse = torch.empty(N, H, Lq, dtype=torch.float32, device=dev)
+            _lib.check(lib.mpf_attn_forward_kv(q.data_ptr(), k.data_ptr(), rs, im, vt.data_ptr(), mask.data_ptr(), 1, out.data_ptr(),
+                                               lse.data_ptr(), Lq, Lk, N, H, hd, hd ** -0.5, ws.data_ptr(), ws.numel(), st), "f")
+            qT, doT = (torch.empty(N, E, LqP, dtype=torch.bfloat16, device=dev) for _ in range(2))
+            delta = torch.empty(N, H, Lq, dtype=torch.float32, device=dev)
+            _lib.check(lib.mpf_attn_bwd_prep(q.data_ptr(), do.data_ptr(), out.data_ptr(), qT.data_ptr(), doT.data_ptr(), delta.data_ptr(),
+                                             Lq, LqP, N, H, st), "p")
+            dq = torch.empty_like(q)
+            if strided:
+                dKp, dVp = (torch.full((Lk, N, 3 * E), 3.0, dtype=torch.bfloat16, device=dev) for _ in range(2))
+                dk, dv = dKp[..., j * E:(j + 1) * E], dVp[..., j * E:(j + 1) * E]
+            else:
+                dKp = dVp = None
+                dk, dv = torch.empty_like(kd), torch.empty_like(vd)
+            drs, dim_ = (dk.stride(0), dk.stride(1)) if strided else (0, 0)
+            _lib.check(lib.mpf_attn_backward_kv(q.data_ptr(), k.data_ptr(), v.data_ptr(), rs, im, kt.data_ptr(), qT.data_ptr(), do.data_ptr(),
+                                                doT.data_ptr(), mask.data_ptr(), 1, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(),
+                                                dk.data_ptr(), dv.data_ptr(), drs, dim_, Lq, LqP, Lk, N, H, hd, hd ** -0.5,
+                                                ws.data_ptr(), ws.numel(), st), "b")
+            return kt, vt, out, lse, dq, dk, dv, dKp, dVp
+
+        a, b = run(kd, vd, False), run(ks, vs, True)
+        for x, y in zip(a[:7], b[:7]):
+            assert torch.equal(x, y)
+        for full in b[7:]:                  # the neighbouring column blocks are untouched
+            other = [c for c in range(3) if c != j]
+            assert all((full[..., c * E:(c + 1) * E] == 3.0).all() for c in other)
