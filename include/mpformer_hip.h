@@ -646,6 +646,34 @@ int mpf_small_gemm_bf16_blocked(const void* a, int64_t a_rs, int64_t a_ks, int a
                                 int c_blk, int64_t c_bs, void* rowsum_a, int I, int J, int Kc, int relu, void* stream);
 
 /*
+ * The end of SetCriterion (mask2former/modeling/criterion.py) as four launches instead of ~100 tensor-expression launches
+ * over vectors of 10-500 elements.
+ *
+ * Class losses (loss_labels, :123-139) of L outputs at once:
+ *   ce[l] = sum_r w[t_r] * (logsumexp(x_r) - x_r[t_r]) / sum_r w[t_r],   r over the N * Q rows of output l
+ * logits: MPF_F32 or MPF_BF16, element (l, n, q, c) at l*sl + n*sn + q*sq + c (a strided view of the batched heads' output);
+ * target int64 [L, N, Q] (target_per_output = 1) or [N, Q] shared by the outputs (0); weight fp32 [C] (empty_weight);
+ * C <= 256.  The forward keeps lse [L, N*Q] and wsum [L] for the backward, which writes the DENSE gradient [L, N, Q, C] in
+ * the logits' dtype: grad_ce[l] / wsum[l] * w[t] * (softmax - onehot).  Fixed summation order (reproducible).
+ */
+int mpf_class_loss_forward(const void* logits, int dtype, int64_t sl, int64_t sn, int64_t sq, const int64_t* target,
+                           int target_per_output, const float* weight, int L, int N, int Q, int C, float* lse, float* ce,
+                           float* wsum, void* stream);
+int mpf_class_loss_backward(const void* logits, int dtype, int64_t sl, int64_t sn, int64_t sq, const int64_t* target,
+                            int target_per_output, const float* weight, int L, int N, int Q, int C, const float* lse,
+                            const float* wsum, const float* grad_ce, void* dlogits, void* stream);
+/*
+ * Mask / dice losses (dice_loss :21-40, sigmoid_ce_loss :48-65, / num_masks :189-190) from the per-pair point sums of
+ * mpf_mask_loss_forward: sums [n, 4] = (sum BCE, sum sigmoid*t, sum sigmoid, sum t); group g (an output's matched or MP
+ * pairs) owns the pairs [runs[2g], runs[2g] + runs[2g+1]); out[g] = sum_i sums[i,0] / points / norm[g],
+ * out[G + g] = sum_i (1 - (2 sums[i,1] + 1) / (sums[i,2] + sums[i,3] + 1)) / norm[g].  Backward: dsums [n, 4].
+ */
+int mpf_mask_loss_finalize(const float* sums, const int64_t* runs, const float* norm, int n, int G, int points, float* out,
+                           void* stream);
+int mpf_mask_loss_finalize_backward(const float* sums, const int64_t* runs, const float* norm, int n, int G, int points,
+                                    const float* grad_out, float* dsums, void* stream);
+
+/*
  * Up to 8 independent WEIGHT-GRADIENT problems of mpf_small_gemm_bf16 in one launch (both operands row-contiguous:
  * a_rs == 1 and b_rs == 1, i.e. dW[J_out, K_in] = dY^T . x with dY and x read along their rows; no bias / c_in / ReLU).
  * The six dW GEMMs of a decoder layer's backward (FFNLayer, SelfAttentionLayer, CrossAttentionLayer of

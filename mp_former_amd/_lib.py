@@ -86,6 +86,12 @@ SIGNATURES = {
                                              ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, ctypes.c_int64,
                                              _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_small_gemm_bf16_group": (_c_int, [_c_vp, _c_int, _c_vp]),
+    "mpf_class_loss_forward": (_c_int, [_c_vp, _c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_int, _c_vp, _c_int, _c_int,
+                                        _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "mpf_class_loss_backward": (_c_int, [_c_vp, _c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_int, _c_vp, _c_int, _c_int,
+                                         _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "mpf_mask_loss_finalize": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
+    "mpf_mask_loss_finalize_backward": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),
     "mpf_bias_act": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_res_ln256_forward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
                                        _c_vp, _c_int, _c_vp, _c_vp]),

@@ -22,7 +22,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import _rng
+from . import _lib, _rng
 from .dist import distributed, global_num_masks, global_num_masks_device
 from .matcher import GTMasks
 from ._h2d import upload
@@ -50,6 +50,84 @@ def strided_stack(ts):
     if delta <= 0 or any(so[i + 1] - so[i] != delta for i in range(len(so) - 1)):
         return torch.stack(ts), ident
     return base.as_strided((len(ts),) + tuple(shape), (delta,) + tuple(stride), so[0]), order
+
+
+_DT = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}
+
+
+def _native_tail():
+    return os.environ.get("MPF_NATIVE_LOSS_TAIL", "1") == "1"
+
+
+class _ClassLossFn(torch.autograd.Function):
+    """ce[l] = F.cross_entropy(logits[l] (N*Q rows), target[l], weight) for all L outputs in one launch, and its gradient in
+    one launch (csrc/criterion_tail.hip; criterion.py:123-139).  logits: [L, N, Q, C] view with unit class stride, fp32 or
+    bf16 (the kernel reads it as it is and computes in fp32, like F.cross_entropy under autocast)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        L, N, Q, C = logits.shape
+        dev = logits.device
+        per_output = 1 if target.dim() == 3 else 0
+        target = target.contiguous()
+        weight = weight.float().contiguous()
+        lse = torch.empty((L, N * Q), dtype=torch.float32, device=dev)
+        out = torch.empty((2, L), dtype=torch.float32, device=dev)           # ce, wsum
+        with torch.cuda.device(dev):
+            code = _lib.lib().mpf_class_loss_forward(
+                logits.data_ptr(), _DT[logits.dtype], logits.stride(0), logits.stride(1), logits.stride(2), target.data_ptr(),
+                per_output, weight.data_ptr(), L, N, Q, C, lse.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(code, "mpf_class_loss_forward")
+        ctx.save_for_backward(logits, target, weight, lse, out)
+        ctx.per_output = per_output
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, weight, lse, out = ctx.saved_tensors
+        L, N, Q, C = logits.shape
+        dev = logits.device
+        g = g.float().contiguous()
+        d = torch.empty((L, N, Q, C), dtype=logits.dtype, device=dev)
+        with torch.cuda.device(dev):
+            code = _lib.lib().mpf_class_loss_backward(
+                logits.data_ptr(), _DT[logits.dtype], logits.stride(0), logits.stride(1), logits.stride(2), target.data_ptr(),
+                ctx.per_output, weight.data_ptr(), L, N, Q, C, lse.data_ptr(), out[1].data_ptr(), g.data_ptr(), d.data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(code, "mpf_class_loss_backward")
+        return d, None, None
+
+
+class _MaskLossFinalizeFn(torch.autograd.Function):
+    """(loss_mask[g], loss_dice[g]) of every group from the per-pair point sums, one launch each way
+    (csrc/criterion_tail.hip; criterion.py:21-40, :48-65, :189-190).  runs int64 [G, 2] = (first pair, count) per group."""
+
+    @staticmethod
+    def forward(ctx, sums, runs, norm, points):
+        n, G = sums.shape[0], norm.shape[0]
+        sums = sums.contiguous()
+        out = torch.empty((2, G), dtype=torch.float32, device=sums.device)
+        with torch.cuda.device(sums.device):
+            code = _lib.lib().mpf_mask_loss_finalize(sums.data_ptr(), runs.data_ptr(), norm.data_ptr(), n, G, points, out.data_ptr(),
+                                                     torch.cuda.current_stream(sums.device).cuda_stream)
+        _lib.check(code, "mpf_mask_loss_finalize")
+        ctx.save_for_backward(sums, runs, norm)
+        ctx.points = points
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sums, runs, norm = ctx.saved_tensors
+        n, G = sums.shape[0], norm.shape[0]
+        g = g.float().contiguous()
+        d = torch.empty_like(sums)
+        with torch.cuda.device(sums.device):
+            code = _lib.lib().mpf_mask_loss_finalize_backward(sums.data_ptr(), runs.data_ptr(), norm.data_ptr(), n, G, ctx.points,
+                                                              g.data_ptr(), d.data_ptr(),
+                                                              torch.cuda.current_stream(sums.device).cuda_stream)
+        _lib.check(code, "mpf_mask_loss_finalize_backward")
+        return d, None, None, None
 
 
 class LossDict(dict):
@@ -85,6 +163,9 @@ class SetCriterion(nn.Module):
         """logits [L,N,Q,K+1], target_classes [L,N,Q] (or [N,Q], shared) -> per-output weighted CE [L]
         (F.cross_entropy with class weights = sum w_y nll / sum w_y, criterion.py:123-139)."""
         L = logits.shape[0]
+        if (_native_tail() and logits.is_cuda and logits.dim() == 4 and logits.stride(3) == 1 and logits.dtype in _DT
+                and logits.shape[3] <= 256):
+            return _ClassLossFn.apply(logits, target_classes, self.empty_weight)
         if target_classes.dim() == 2:
             target_classes = target_classes[None].expand(L, -1, -1)
         lsm = F.log_softmax(logits.float(), -1)
@@ -215,17 +296,27 @@ class SetCriterion(nn.Module):
                     if P - num_uncertain > 0:
                         coords[:, num_uncertain:] = _rng.rand_cat(rand_parts, dev)
                 sums = MaskLossSums.apply(ms, pred_offs, grad_offs, gt, gt_rows, coords, *ms.bases)
-                per_mask = sums[:, 0] / P                                                  # mean_p BCE (criterion.py:48-65)
-                per_dice = 1 - (2 * sums[:, 1] + 1) / (sums[:, 2] + sums[:, 3] + 1)        # criterion.py:21-40
-                z = torch.zeros(G, dtype=torch.float32, device=dev)
+                mult = [1.0] * L + ([float(scalar)] * L if use_dn else [])
                 if torch.is_tensor(num_masks):
-                    norm = num_masks * upload([1.0] * L + ([float(scalar)] * L if use_dn else []), dev, torch.float32)
+                    norm = num_masks * upload(mult, dev, torch.float32)
                 else:
-                    norm = torch.full((G,), float(num_masks), device=dev)
-                    if use_dn:
-                        norm[L:] = float(num_masks * scalar)
-                g_mask = z.index_add(0, gid_d, per_mask) / norm
-                g_dice = z.index_add(0, gid_d, per_dice) / norm
+                    norm = upload([float(num_masks) * m for m in mult], dev, torch.float32)
+                # the pairs of a group are one run of the pair list (laid out above: per output, matched then MP pairs)
+                change = np.flatnonzero(np.diff(gid)) + 1
+                starts = np.concatenate([[0], change])
+                one_run_each = len(np.unique(gid[starts])) == len(starts)
+                if _native_tail() and one_run_each:
+                    runs = np.zeros((G, 2), dtype=np.int64)
+                    runs[gid[starts], 0] = starts
+                    runs[gid[starts], 1] = np.diff(np.concatenate([starts, [n_pairs]]))
+                    fin = _MaskLossFinalizeFn.apply(sums, upload(runs, dev), norm, P)
+                    g_mask, g_dice = fin[0], fin[1]
+                else:
+                    per_mask = sums[:, 0] / P                                                  # mean_p BCE (criterion.py:48-65)
+                    per_dice = 1 - (2 * sums[:, 1] + 1) / (sums[:, 2] + sums[:, 3] + 1)        # criterion.py:21-40
+                    z = torch.zeros(G, dtype=torch.float32, device=dev)
+                    g_mask = z.index_add(0, gid_d, per_mask) / norm
+                    g_dice = z.index_add(0, gid_d, per_dice) / norm
             else:
                 # no ground truth anywhere: sums over empty sets (still consume the draws for RNG parity)
                 _rng.rand_cat(over_parts, dev)
@@ -282,11 +373,9 @@ class SetCriterion(nn.Module):
             # the dict entries are views of a few vectors: weight the vectors (the per-key route costs a
             # select-backward = zeros + copy + add per key, ~180 launches per step)
             covered = {k for names, _ in groups for k in names}
-            total = None
-            for names, vec in groups:
-                w = upload([self.weight_dict.get(k, 0.0) if k in losses else 0.0 for k in names], vec.device, vec.dtype)
-                part = (vec * w).sum()
-                total = part if total is None else total + part
+            ws = [self.weight_dict.get(k, 0.0) if k in losses else 0.0 for names, _ in groups for k in names]
+            vec = torch.cat([v.float() for _, v in groups]) if len(groups) > 1 else groups[0][1].float()
+            total = torch.dot(vec, upload(ws, vec.device, torch.float32))
             rest = [k for k in losses if k in self.weight_dict and k not in covered]
             for k in rest:
                 total = total + losses[k] * self.weight_dict[k]

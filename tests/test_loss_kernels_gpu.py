@@ -202,3 +202,61 @@ def test_attn_mask_matches_reference_formula(size, hw):
         assert not got[1, 6].any() and not got[0, 1].any() and not got[0, 5].any()
         got2 = native_attn_mask(m, size, None)
         assert torch.equal(got2[:, pad:][~diff[:, pad:]], ref[:, pad:][~diff[:, pad:]])
+
+
+def test_class_loss_kernel_matches_cross_entropy():
+    """mpf_class_loss_forward / backward (csrc/criterion_tail.hip) == F.cross_entropy(logits^T, target, weight) per output,
+    values and gradients, for strided bf16 / fp32 logits and per-output / shared targets (criterion.py:123-139)."""
+    import torch.nn.functional as F
+    from mp_former_amd.criterion import _ClassLossFn
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    for dtype, L, N, Q, C, shared in [(torch.float32, 10, 2, 100, 81, False), (torch.bfloat16, 10, 2, 14, 81, True),
+                                      (torch.bfloat16, 3, 1, 7, 134, False), (torch.float32, 1, 3, 5, 2, True)]:
+        parent = (torch.randn(N, L * Q + 3, C, device=dev) * 3).to(dtype).requires_grad_(True)
+        logits = parent.as_strided((L, N, Q, C), (Q * C, (L * Q + 3) * C, C, 1), 0)        # output l = rows [l*Q, (l+1)*Q)
+        tgt = torch.randint(0, C, (N, Q) if shared else (L, N, Q), device=dev)
+        w = torch.ones(C, device=dev); w[-1] = 0.1
+        ce = _ClassLossFn.apply(logits, tgt, w)
+        g = torch.rand(L, device=dev) + 0.5
+        ce.backward(g)
+        got = parent.grad.clone(); parent.grad = None
+        ref_in = parent.detach().double().requires_grad_(True)
+        rl = ref_in.as_strided((L, N, Q, C), (Q * C, (L * Q + 3) * C, C, 1), 0)
+        t3 = tgt if tgt.dim() == 3 else tgt[None].expand(L, -1, -1)
+        ref = torch.stack([F.cross_entropy(rl[l].transpose(1, 2), t3[l], w.double()) for l in range(L)])
+        ref.backward(g.double())
+        assert torch.allclose(ce.double(), ref, rtol=2e-6, atol=1e-6), (ce, ref)
+        tol = 1e-6 if dtype == torch.float32 else 4e-3
+        assert (got.double() - ref_in.grad).abs().max() <= tol * ref_in.grad.abs().max() + 1e-9
+
+
+def test_mask_loss_finalize_kernel_matches_the_tensor_expression():
+    from mp_former_amd.criterion import _MaskLossFinalizeFn
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    G, P = 7, 12544
+    counts = [5, 0, 130, 1, 64, 65, 9]
+    order = [0, 4, 1, 5, 2, 6, 3]                  # groups laid out in a different order than their index
+    runs = torch.zeros(G, 2, dtype=torch.int64)
+    gid, pos = [], 0
+    for g in order:
+        runs[g, 0], runs[g, 1] = pos, counts[g]
+        gid += [g] * counts[g]
+        pos += counts[g]
+    n = pos
+    sums = (torch.rand(n, 4, device=dev) * 50).requires_grad_(True)
+    norm = torch.rand(G, device=dev) + 1
+    out = _MaskLossFinalizeFn.apply(sums, runs.to(dev), norm, P)
+    go = torch.rand(2, G, device=dev)
+    out.backward(go)
+    got = sums.grad.clone(); sums.grad = None
+    s = sums.detach().double().requires_grad_(True)
+    gi = torch.tensor(gid, device=dev)
+    z = torch.zeros(G, dtype=torch.float64, device=dev)
+    rm = z.index_add(0, gi, s[:, 0] / P) / norm.double()
+    rd = z.index_add(0, gi, 1 - (2 * s[:, 1] + 1) / (s[:, 2] + s[:, 3] + 1)) / norm.double()
+    (rm * go[0].double()).sum().backward(retain_graph=True)
+    (rd * go[1].double()).sum().backward()
+    assert torch.allclose(out[0].double(), rm, rtol=1e-5, atol=1e-7) and torch.allclose(out[1].double(), rd, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(got[:, :3].double(), s.grad[:, :3], rtol=1e-5, atol=1e-9)
