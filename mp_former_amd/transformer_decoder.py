@@ -544,17 +544,19 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         columns in place (strided K / V in the attention kernels) and its backward writes its columns of the packed
         gradient.  -> {layer: ((k_c, handle), (v_c, handle))}"""
         nl, nlev = self.num_layers, self.num_feature_levels
-        groups = [[i for i in range(nl) if i % nlev == l] for l in range(nlev)]
+        groups = [(l, [i for i in range(nl) if i % nlev == l]) for l in range(nlev)]
+        groups = [(l, g) for l, g in groups if g]              # (fewer layers than levels: some levels are never attended to)
+        ng = len(groups)
         ws, sizes = [], []
         for which in (1, 2):                                   # k rows, then v rows of the packed in-projections
             for key in ("in_proj_weight", "in_proj_bias"):
-                for g in groups:
+                for _, g in groups:
                     ws += [W[f"transformer_cross_attention_layers.{i}.multihead_attn.{key}"][which] for i in g]
                     sizes.append(len(g))
-        cat = _GatherRows.apply(sizes, *ws)                    # [wk_l..., bk_l..., wv_l..., bv_l...]
+        cat = _GatherRows.apply(sizes, *ws)                    # [wk_g..., bk_g..., wv_g..., bv_g...]
         out = {}
-        for l, g in enumerate(groups):
-            wk, bk, wv, bv = cat[l], cat[nlev + l], cat[2 * nlev + l], cat[3 * nlev + l]
+        for gi, (l, g) in enumerate(groups):
+            wk, bk, wv, bv = cat[gi], cat[ng + gi], cat[2 * ng + gi], cat[3 * ng + gi]
             ks = split_cols(linear(kin[l], wk, bk), len(g))
             vs = split_cols(linear(src[l], wv, bv), len(g))
             for j, i in enumerate(g):
