@@ -27,7 +27,7 @@ from .dist import distributed, global_num_masks, global_num_masks_device
 from .matcher import GTMasks
 from ._h2d import upload
 from .lsa import MAX_DIM as LSA_MAX_DIM, lsa_assign
-from .point_sample import MapSet, MaskLossSums, sample_select_uncertain
+from .point_sample import MapSet, MaskLossSums, MaskLossSumsCompact, sample_select_uncertain
 
 
 def strided_stack(ts):
@@ -173,6 +173,34 @@ class SetCriterion(nn.Module):
         w = self.empty_weight[target_classes]
         return (nll * w).flatten(1).sum(1) / w.flatten(1).sum(1)
 
+    @staticmethod
+    def _compact_layout(ms, bi, N):
+        """The maps are one batched product of (mask_embed, mask_features) (transformer_decoder.mask_product left the factors on
+        its result): lay the gradient planes of the pairs out back to back, image by image (each image's block padded to 16
+        rows), so that the loss backward can contract only those rows (point_sample.MaskLossSumsCompact).
+        -> (plane offsets of the pairs [n], (slots per image, rows per image, offset of the first row), (me, mf)) or None."""
+        if os.environ.get("MPF_COMPACT_MASK_GRAD", "1") != "1" or len(ms.bases) != 1:
+            return None
+        root = ms.bases[0]._base
+        fac = getattr(root, "_mpf_factors", None) if root is not None else None
+        if fac is None:
+            return None
+        me, mf = fac
+        base = ms.bases[0]
+        if not (me.dim() == 3 and mf.dim() == 4 and me.dtype == mf.dtype == ms.dtype and base.is_contiguous()
+                and tuple(base.shape) == (N, me.shape[1], mf.shape[2], mf.shape[3]) and (me.requires_grad or mf.requires_grad)):
+            return None
+        hw = ms.h * ms.w
+        slot = np.zeros(len(bi), dtype=np.int64)
+        slots, first = [], 0
+        for b in range(N):
+            idx = np.flatnonzero(bi == b)
+            slot[idx] = first + np.arange(len(idx))
+            npad = (len(idx) + 15) // 16 * 16
+            slots.append((first, len(idx), npad))
+            first += npad
+        return slot * hw, (slots, int(base.shape[1]), int(ms.t_off[0])), (me, mf)
+
     def forward(self, outputs, targets):
         dn_out = outputs["dn_out"]
         outs = [{"pred_logits": outputs["pred_logits"], "pred_masks": outputs["pred_masks"]}] + list(outputs.get("aux_outputs", []))
@@ -269,11 +297,15 @@ class SetCriterion(nn.Module):
 
         # ---- index arrays of the pairs -> device (one upload each); the solver fills the matched slots ----
         tc_main_d = torch.full((L, N, Q), K, dtype=torch.int64, device=dev) if dev_lsa else None
+        compact = None
         if n_pairs:
             g_offs = ms.grad_offsets(ti, bi, qi)
             p_offs = ms.offsets(ti, bi, qi)
             if not dev_lsa:
                 assert len(np.unique(g_offs)) == n_pairs, "a prediction plane is paired twice in one step"
+            compact = self._compact_layout(ms, bi, N)
+            if compact is not None:
+                g_offs = compact[0]             # plane i of the COMPACT gradient (pairs back to back, image by image)
             up = upload(np.concatenate([p_offs, g_offs, gid]), dev)
             pred_offs, grad_offs, gid_d = up[:n_pairs], up[n_pairs:2 * n_pairs], up[2 * n_pairs:]
             gt_rows = upload(gr.astype(np.int32), dev)
@@ -284,8 +316,10 @@ class SetCriterion(nn.Module):
                 pos = pr[:, 4]
                 pr[:, 6], pr[:, 7] = p_offs[pos], ms.s1[ms.base_of[ti[pos]]]
                 pr[:, 8], pr[:, 9] = g_offs[pos], ms.h * ms.w
-                lsa_assign(C, pr, n_pairs, want_rows=False, scatter_dst=tc_main_d, scatter_src=labels_dev,
-                           into={"cols": gt_rows, "a": pred_offs, "b": grad_offs})
+                into = {"cols": gt_rows, "a": pred_offs}
+                if compact is None:
+                    into["b"] = grad_offs           # (the compact gradient's plane does not depend on the matched query)
+                lsa_assign(C, pr, n_pairs, want_rows=False, scatter_dst=tc_main_d, scatter_src=labels_dev, into=into)
 
         # ---- stage 2: mask losses ----------------------------------------------------------------------
         if "masks" in self.losses:
@@ -295,7 +329,10 @@ class SetCriterion(nn.Module):
                     coords = sample_select_uncertain(ms, pred_offs, coords_over, num_uncertain, P)
                     if P - num_uncertain > 0:
                         coords[:, num_uncertain:] = _rng.rand_cat(rand_parts, dev)
-                sums = MaskLossSums.apply(ms, pred_offs, grad_offs, gt, gt_rows, coords, *ms.bases)
+                if compact is not None:
+                    sums = MaskLossSumsCompact.apply(ms, pred_offs, grad_offs, gt, gt_rows, coords, compact[1], *compact[2])
+                else:
+                    sums = MaskLossSums.apply(ms, pred_offs, grad_offs, gt, gt_rows, coords, *ms.bases)
                 mult = [1.0] * L + ([float(scalar)] * L if use_dn else [])
                 if torch.is_tensor(num_masks):
                     norm = num_masks * upload(mult, dev, torch.float32)

@@ -171,6 +171,25 @@ def match_cost(ms, offs, coords, coord_rows, tsamp, t_first, t_count, Tmax, w_ma
     return cost
 
 
+def _mask_loss_sums_forward(ctx, ms, pred_offs, gt, gt_rows, coords):
+    """forward of MaskLossSums / MaskLossSumsCompact; leaves (gt_u8, gt_hw, gdt, ms) on ctx"""
+    # gt: GTMasks (its bit-packed copy is used when present) or a [R, H, W] byte tensor
+    gt_u8 = gt if torch.is_tensor(gt) else (gt.bits if gt.bits is not None else gt.u8)
+    gdt = _lib.MPF_U8 if (torch.is_tensor(gt) or gt.bits is None) else _lib.MPF_BITS
+    n, P = coords.shape[0], coords.shape[1]
+    H, W = (gt.shape[-2:] if torch.is_tensor(gt) else (gt.H, gt.W))
+    ctx.gt_hw, ctx.gdt, ctx.gt_u8 = (H, W), gdt, gt_u8
+    partial = torch.empty((n, _CHUNKS, 4), dtype=torch.float32, device=ms.device)
+    if n:
+        with torch.cuda.device(ms.device):
+            code = _lib.lib().mpf_mask_loss_forward(
+                ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), gdt, H, W,
+                gt_rows.data_ptr(), coords.data_ptr(), partial.data_ptr(), n, P, _CHUNKS, _stream(ms.device))
+        _lib.check(code, "mpf_mask_loss_forward")
+    ctx.ms = ms
+    return partial.sum(1)
+
+
 class MaskLossSums(Function):
     """sums[i] = (sum_p BCE(x,t), sum_p sigmoid(x)*t, sum_p sigmoid(x), sum_p t) over the P points of
     pair i; x sampled from the plane at ms.base + pred_offs[i], t from gt_u8[gt_rows[i]]
@@ -183,22 +202,9 @@ class MaskLossSums(Function):
 
     @staticmethod
     def forward(ctx, ms, pred_offs, grad_offs, gt, gt_rows, coords, *tensors):
-        # gt: GTMasks (its bit-packed copy is used when present) or a [R, H, W] byte tensor
-        gt_u8 = gt if torch.is_tensor(gt) else (gt.bits if gt.bits is not None else gt.u8)
-        gdt = _lib.MPF_U8 if (torch.is_tensor(gt) or gt.bits is None) else _lib.MPF_BITS
-        n, P = coords.shape[0], coords.shape[1]
-        H, W = (gt.shape[-2:] if torch.is_tensor(gt) else (gt.H, gt.W))
-        ctx.gt_hw, ctx.gdt = (H, W), gdt
-        partial = torch.empty((n, _CHUNKS, 4), dtype=torch.float32, device=ms.device)
-        if n:
-            with torch.cuda.device(ms.device):
-                code = _lib.lib().mpf_mask_loss_forward(
-                    ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), gdt, H, W,
-                    gt_rows.data_ptr(), coords.data_ptr(), partial.data_ptr(), n, P, _CHUNKS, _stream(ms.device))
-            _lib.check(code, "mpf_mask_loss_forward")
-        ctx.ms = ms
-        ctx.save_for_backward(pred_offs, grad_offs, gt_u8, gt_rows, coords, *tensors)   # keeps the maps alive
-        return partial.sum(1)
+        sums = _mask_loss_sums_forward(ctx, ms, pred_offs, gt, gt_rows, coords)
+        ctx.save_for_backward(pred_offs, grad_offs, ctx.gt_u8, gt_rows, coords, *tensors)   # keeps the maps alive
+        return sums
 
     @staticmethod
     @once_differentiable
@@ -221,3 +227,91 @@ class MaskLossSums(Function):
             s = int(ms.g_start[i])
             grads.append(gbuf[s:s + t.numel()].view(t.shape))
         return (None, None, None, None, None, None, *grads)
+
+
+_split_k_ok = True
+
+
+def _long_k_product(a, b, chunk=2048):
+    """a [m, K] @ b [K, n] for a few hundred rows and K = h * w = 65 536: as ONE GEMM the library runs it on ceil(m/64) *
+    ceil(n/64) workgroups with no split over K (170 us for 8 GFLOP); as a batched GEMM over K chunks with fp32 partial
+    results + one sum it fills the chip.  Falls back to the plain product where the fp32-output batched GEMM is missing."""
+    global _split_k_ok
+    m, K = a.shape
+    if _split_k_ok and a.dtype == torch.bfloat16 and K % chunk == 0 and K // chunk > 1 and a.stride(1) == 1 and b.is_contiguous():
+        S = K // chunk
+        try:
+            part = torch.bmm(a.as_strided((S, m, chunk), (chunk, a.stride(0), 1)), b.view(S, chunk, b.shape[1]),
+                             out_dtype=torch.float32)
+            return part.sum(0).to(a.dtype)
+        except (RuntimeError, NotImplementedError, TypeError):
+            _split_k_ok = False
+    return torch.mm(a, b)
+
+
+class MaskLossSumsCompact(Function):
+    """MaskLossSums for maps that ARE a product: pred_masks = einsum("bqc,bchw->bqhw", mask_embed, mask_features)
+    (mask2former_transformer_decoder.py:1869), differentiated with respect to the FACTORS.
+
+    The loss touches ~1/4 of the N * 10 * Qtot rows of the batched prediction (matched + MP rows); the dense route
+    zero-fills a gradient of the whole [N, 10 Qtot, h, w] tensor and contracts all of it twice (d mask_embed over 65 536
+    pixels, d mask_features over all rows).  Here the scatter kernel writes the gradient planes of the n pairs back to back
+    (image by image), and both products run on those rows only:
+        d mask_features[b] = G_b^T . mask_embed[b, rows_b]          [hw, n_b] x [n_b, C]
+        d mask_embed[b, rows_b] = G_b . mask_features[b]            [n_b, hw] x [hw, C]
+    ``lay`` = (per-image (first slot, pairs, padded pairs) list, rows per image Qb, element offset of the maps' first row)."""
+
+    calls = 0          # (tests assert that this route, not the dense one, ran)
+
+    @staticmethod
+    def forward(ctx, ms, pred_offs, grad_offs, gt, gt_rows, coords, lay, me, mf):
+        MaskLossSumsCompact.calls += 1
+        sums = _mask_loss_sums_forward(ctx, ms, pred_offs, gt, gt_rows, coords)
+        ctx.save_for_backward(pred_offs, grad_offs, ctx.gt_u8, gt_rows, coords, me, mf)
+        ctx.lay = lay
+        return sums
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_sums):
+        ms = ctx.ms
+        pred_offs, grad_offs, gt_u8, gt_rows, coords, me, mf = ctx.saved_tensors
+        slots, Qb, root_off = ctx.lay
+        n, P = coords.shape[0], coords.shape[1]
+        H, W = ctx.gt_hw
+        hw = ms.h * ms.w
+        N, C = mf.shape[0], mf.shape[1]
+        total_slots = slots[-1][0] + slots[-1][2] if slots else 0
+        gcomp = torch.empty((total_slots, hw), dtype=ms.dtype, device=ms.device)
+        for first, nb, npad in slots:                       # the padding rows of an image's block enter the products as zeros
+            if npad > nb:
+                gcomp[first + nb:first + npad].zero_()
+        g = grad_sums.contiguous().float()
+        with torch.cuda.device(ms.device):
+            code = _lib.lib().mpf_mask_loss_backward_dense(
+                ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), ctx.gdt, H, W,
+                gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), gcomp.data_ptr(), _DT[ms.dtype], grad_offs.data_ptr(),
+                n, P, _stream(ms.device))
+        _lib.check(code, "mpf_mask_loss_backward_dense")
+        # row (b * Qb + q) of every pair, in slot order (grad_offs = slot * hw by construction)
+        row_of_pair = (pred_offs - root_off) // hw
+        slot_of_pair = grad_offs // hw
+        row_of_slot = torch.zeros(total_slots, dtype=torch.int64, device=ms.device)
+        row_of_slot[slot_of_pair] = row_of_pair
+        planes = mf.permute(0, 2, 3, 1).reshape(N, hw, C)                   # view of the channel-last features
+        d_me = torch.zeros_like(me) if ctx.needs_input_grad[7] else None
+        d_mf = torch.empty((N, hw, C), dtype=mf.dtype, device=mf.device) if ctx.needs_input_grad[8] else None
+        for b, (first, nb, npad) in enumerate(slots):
+            if npad == 0:
+                if d_mf is not None:
+                    d_mf[b].zero_()
+                continue
+            Gb = gcomp[first:first + npad]
+            q = row_of_slot[first:first + npad] - b * Qb                     # (padding slots: row 0 of the image, times zeros)
+            q = q.clamp_(0, Qb - 1)
+            if d_mf is not None:
+                torch.mm(Gb.t(), me[b].index_select(0, q), out=d_mf[b])
+            if d_me is not None:
+                d_me[b].index_copy_(0, q[:nb], _long_k_product(Gb, planes[b])[:nb])
+        g_mf = d_mf.view(N, ms.h, ms.w, C).permute(0, 3, 1, 2) if d_mf is not None else None
+        return (None, None, None, None, None, None, None, d_me, g_mf)

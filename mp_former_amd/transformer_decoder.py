@@ -251,7 +251,11 @@ def mask_product(me, mask_features):
         if not amp or me.dtype == torch.get_autocast_dtype("cuda"):      # operands already in the dtype autocast would pick
             with torch.autocast(device_type="cuda", enabled=False):
                 N, C, H, W = mask_features.shape
-                return _MaskProductCL.apply(me, mask_features).view(N, me.shape[1], H, W)
+                out = _MaskProductCL.apply(me, mask_features)
+                # the criterion's mask losses differentiate with respect to the factors on the rows they touch instead of
+                # through a dense gradient of this tensor (point_sample.MaskLossSumsCompact finds them here)
+                out._mpf_factors = (me, mask_features)
+                return out.view(N, me.shape[1], H, W)
     return torch.einsum("bqc,bchw->bqhw", me, mask_features)
 
 

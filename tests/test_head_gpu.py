@@ -220,6 +220,8 @@ def test_head_amp_path_matches_reference_golden(name):
     use_dn = "dn_pred_logits" in z
     _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
     _lib.profile_enable(True)
+    from mp_former_amd.point_sample import MaskLossSumsCompact
+    compact_before = MaskLossSumsCompact.calls
     try:
         with torch.autocast("cuda", dtype=torch.bfloat16):
             losses, _ = h(feats, targets)            # weighted, like maskformer_model.py:226-231
@@ -227,6 +229,8 @@ def test_head_amp_path_matches_reference_golden(name):
         assert _rng.remaining() == 0
         total.backward()
         torch.cuda.synchronize()
+        # the mask losses differentiate w.r.t. (mask_embed, mask_features) on the paired rows only (no dense map gradient)
+        assert MaskLossSumsCompact.calls == compact_before + 1, "the compact mask-gradient route did not run"
         for kern in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "small_gemm", "lsa_kernel", "msda_fwd_block",
                      "msda_bwd_pull_mfma", "gemm3", "gn_cl_apply", "gn_cl_bwd_apply"):
             assert _lib.profile_get(kern)[0] > 0, f"{kern} did not run on the AMP path"
