@@ -653,7 +653,8 @@ int mpf_small_gemm_bf16_blocked(const void* a, int64_t a_rs, int64_t a_ks, int a
  *   ce[l] = sum_r w[t_r] * (logsumexp(x_r) - x_r[t_r]) / sum_r w[t_r],   r over the N * Q rows of output l
  * logits: MPF_F32 or MPF_BF16, element (l, n, q, c) at l*sl + n*sn + q*sq + c (a strided view of the batched heads' output);
  * target int64 [L, N, Q] (target_per_output = 1) or [N, Q] shared by the outputs (0); weight fp32 [C] (empty_weight);
- * C <= 256.  The forward keeps lse [L, N*Q] and wsum [L] for the backward, which writes the DENSE gradient [L, N, Q, C] in
+ * C <= 256.  The forward keeps lse (a buffer of 3 * L * N * Q floats: the rows' log-sum-exp [L, N*Q], then their (w * nll, w)
+ * pairs — scratch) and wsum [L] for the backward, which writes the DENSE gradient [L, N, Q, C] in
  * the logits' dtype: grad_ce[l] / wsum[l] * w[t] * (softmax - onehot).  Fixed summation order (reproducible).
  */
 int mpf_class_loss_forward(const void* logits, int dtype, int64_t sl, int64_t sn, int64_t sq, const int64_t* target,

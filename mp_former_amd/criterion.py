@@ -71,7 +71,7 @@ class _ClassLossFn(torch.autograd.Function):
         per_output = 1 if target.dim() == 3 else 0
         target = target.contiguous()
         weight = weight.float().contiguous()
-        lse = torch.empty((L, N * Q), dtype=torch.float32, device=dev)
+        lse = torch.empty((3, L, N * Q), dtype=torch.float32, device=dev)    # log-sum-exp of the rows + the kernel's row scratch
         out = torch.empty((2, L), dtype=torch.float32, device=dev)           # ce, wsum
         with torch.cuda.device(dev):
             code = _lib.lib().mpf_class_loss_forward(

@@ -47,49 +47,59 @@ struct ClsArgs {
     int L, N, Q, C;
 };
 
-// one workgroup per output l: wave w walks rows w, w + 4, ... ; lanes cover the classes (C <= 64 * kCls)
+// lanes cover the classes (C <= 64 * kCls)
 constexpr int kCls = 4;            // classes per lane: C <= 256
 
+// one wave per row: log-sum-exp, and the row's weighted nll / weight into rowv [L * rows][2] (a per-output loop over its
+// 228 rows in one wave was a chain of dependent loads: 37 us)
 template <typename T>
-__global__ __launch_bounds__(256) void class_loss_fwd_kernel(ClsArgs a)
+__global__ __launch_bounds__(256) void class_loss_rows_kernel(ClsArgs a, float* __restrict__ rowv)
 {
-    __shared__ float red[2][4];
-    const int l = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int rows = a.N * a.Q;
-    const T* base = static_cast<const T*>(a.logits) + (int64_t)l * a.sl;
-    float acc_nll = 0.f, acc_w = 0.f;
-    for (int r = wv; r < rows; r += 4) {
-        const int n = r / a.Q, q = r - n * a.Q;
-        const T* row = base + (int64_t)n * a.sn + (int64_t)q * a.sq;
-        float x[kCls];
-        float mx = -INFINITY;
+    const int64_t gr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gr >= (int64_t)a.L * rows) return;
+    const int l = (int)(gr / rows), r = (int)(gr - (int64_t)l * rows);
+    const int n = r / a.Q, q = r - n * a.Q;
+    const T* row = static_cast<const T*>(a.logits) + (int64_t)l * a.sl + (int64_t)n * a.sn + (int64_t)q * a.sq;
+    float x[kCls];
+    float mx = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < kCls; ++k) {
-            const int c = lane + 64 * k;
-            x[k] = c < a.C ? ldf<T>(row + min(c, a.C - 1)) : -INFINITY;
-            mx = fmaxf(mx, x[k]);
-        }
-        mx = wave_max(mx);
-        float se = 0.f;
+    for (int k = 0; k < kCls; ++k) {
+        const int c = lane + 64 * k;
+        x[k] = c < a.C ? ldf<T>(row + min(c, a.C - 1)) : -INFINITY;
+        mx = fmaxf(mx, x[k]);
+    }
+    const int64_t t = a.target[(int64_t)l * a.tl + r];
+    const float xt = ldf<T>(row + t);
+    const float w = a.weight[t];
+    mx = wave_max(mx);
+    float se = 0.f;
 #pragma unroll
-        for (int k = 0; k < kCls; ++k) se += (lane + 64 * k < a.C) ? __expf(x[k] - mx) : 0.f;
-        se = wave_add(se);
-        const float lse = mx + __logf(se);
-        const int64_t t = a.target[(int64_t)l * a.tl + r];
-        const float xt = ldf<T>(row + t);
-        const float w = a.weight[t];
-        if (lane == 0) a.lse[(int64_t)l * rows + r] = lse;
-        acc_nll += w * (lse - xt);
-        acc_w += w;
+    for (int k = 0; k < kCls; ++k) se += (lane + 64 * k < a.C) ? __expf(x[k] - mx) : 0.f;
+    se = wave_add(se);
+    const float lse = mx + __logf(se);
+    if (lane == 0) {
+        a.lse[gr] = lse;
+        rowv[2 * gr] = w * (lse - xt);
+        rowv[2 * gr + 1] = w;
     }
-    if (lane == 0) { red[0][wv] = acc_nll; red[1][wv] = acc_w; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        const float w = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-        a.ce[l] = s / w;
-        a.wsum[l] = w;
+}
+
+// one wave per output: lane j adds rows j, j + 64, ... in order, then the butterfly (the same order every run)
+__global__ __launch_bounds__(64) void class_loss_reduce_kernel(const float* __restrict__ rowv, int rows, float* __restrict__ ce,
+                                                               float* __restrict__ wsum)
+{
+    const int l = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f, w = 0.f;
+    for (int r = lane; r < rows; r += 64) {
+        const float2 v = *reinterpret_cast<const float2*>(rowv + 2 * ((int64_t)l * rows + r));
+        s += v.x;
+        w += v.y;
     }
+    s = wave_add(s);
+    w = wave_add(w);
+    if (lane == 0) { ce[l] = s / w; wsum[l] = w; }
 }
 
 // d logits[l, n, q, c] = g[l] / wsum[l] * w[t] * (softmax_c - [c == t]); one wave per row, dense [L, N, Q, C] output in T
@@ -178,10 +188,14 @@ extern "C" int mpf_class_loss_forward(const void* logits, int dtype, int64_t sl,
     if (L < 0 || N <= 0 || Q <= 0 || C <= 0 || C > 64 * kCls) return mpf::fail(MPF_E_SHAPE, "class_loss_forward: needs 1 <= C <= 256");
     ClsArgs a{logits, target, weight, lse, ce, wsum, sl, sn, sq, target_per_output ? (int64_t)N * Q : 0, L, N, Q, C};
     hipStream_t st = (hipStream_t)stream;
-    mpf::set_kernel("class_loss_fwd_kernel");
-    if (dtype == MPF_BF16) hipLaunchKernelGGL(class_loss_fwd_kernel<__hip_bfloat16>, dim3(L), dim3(256), 0, st, a);
-    else if (dtype == MPF_F32) hipLaunchKernelGGL(class_loss_fwd_kernel<float>, dim3(L), dim3(256), 0, st, a);
+    const int64_t rows = (int64_t)L * N * Q;
+    float* rowv = lse + rows;                      // lse is [3, L, N * Q]: log-sum-exp, then (w * nll, w) per row
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    mpf::set_kernel("class_loss_rows_kernel");
+    if (dtype == MPF_BF16) hipLaunchKernelGGL(class_loss_rows_kernel<__hip_bfloat16>, grid, dim3(256), 0, st, a, rowv);
+    else if (dtype == MPF_F32) hipLaunchKernelGGL(class_loss_rows_kernel<float>, grid, dim3(256), 0, st, a, rowv);
     else return mpf::fail(MPF_E_DTYPE, "class_loss_forward: logits must be MPF_F32 or MPF_BF16");
+    hipLaunchKernelGGL(class_loss_reduce_kernel, dim3(L), dim3(64), 0, st, (const float*)rowv, N * Q, ce, wsum);
     return mpf::check(hipGetLastError(), "mpf_class_loss_forward");
 }
 
