@@ -619,9 +619,12 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         d32, d16 = res_ln(self.decoder_norm, X, None, want32=not amp, want16=amp)
         x = d16 if amp else d32
         cls = F.linear(x, W["class_embed.weight"], W["class_embed.bias"])                    # [L*Qt, N, K+1]
-        e = F.relu(F.linear(x, W["mask_embed.layers.0.weight"], W["mask_embed.layers.0.bias"]))
-        e = F.relu(F.linear(e, W["mask_embed.layers.1.weight"], W["mask_embed.layers.1.bias"]))
-        me = F.linear(e, W["mask_embed.layers.2.weight"], W["mask_embed.layers.2.bias"]).transpose(0, 1)   # [N, L*Qt, C]
+        # (2 000+ rows: `linear` takes the library forward / dX and the native split-over-rows weight + bias gradient — the
+        # library's dW for a [256, 2 280] x [2 280, 256] product is 4 workgroups walking the whole contraction)
+        lin = linear if os.environ.get("MPF_HEADS_TALL", "1") == "1" else F.linear
+        e = F.relu(lin(x, W["mask_embed.layers.0.weight"], W["mask_embed.layers.0.bias"]))
+        e = F.relu(lin(e, W["mask_embed.layers.1.weight"], W["mask_embed.layers.1.bias"]))
+        me = lin(e, W["mask_embed.layers.2.weight"], W["mask_embed.layers.2.bias"]).transpose(0, 1)   # [N, L*Qt, C]
         pm = mask_product(me, mask_features)                                                 # [N, L*Qt, H, W]
         cls = cls.view(L, Qt, N, -1)
         return [cls[l].transpose(0, 1) for l in range(L)], [pm[:, l * Qt:(l + 1) * Qt] for l in range(L)]
