@@ -1,0 +1,89 @@
+"""Host-side logic of the decoder / criterion mirrors that needs no GPU: the row-gather of the per-level key / value
+weights, the column-block views with their packed gradient, the shared stacked ground-truth masks."""
+import numpy as np
+import torch
+
+
+def test_gather_rows_concatenates_and_routes_gradients_as_views():
+    from mp_former_amd.transformer_decoder import _GatherRows
+    torch.manual_seed(0)
+    ws = [torch.randn(4, 6, requires_grad=True) for _ in range(5)] + [torch.randn(4, requires_grad=True) for _ in range(5)]
+    sizes = [3, 2, 3, 2]
+    outs = _GatherRows.apply(sizes, *ws)
+    assert [tuple(o.shape) for o in outs] == [(12, 6), (8, 6), (12,), (8,)]
+    assert torch.equal(outs[0], torch.cat(ws[0:3])) and torch.equal(outs[1], torch.cat(ws[3:5]))
+    assert torch.equal(outs[2], torch.cat(ws[5:8])) and torch.equal(outs[3], torch.cat(ws[8:10]))
+    gs = [torch.randn_like(o) for o in outs]
+    torch.autograd.backward(outs, gs)
+    assert torch.equal(ws[1].grad, gs[0][4:8]) and torch.equal(ws[4].grad, gs[1][4:8]) and torch.equal(ws[9].grad, gs[3][4:8])
+
+
+def test_split_cols_packs_the_gradient_in_place():
+    """split_cols: consumers that write their block of the packed gradient in place (what DecoderLayerFn.backward does) and
+    consumers that return an ordinary gradient both end up in ONE [S, N, 3E] gradient; an unused block is zero."""
+    from mp_former_amd.decoder_layer import split_cols
+    torch.manual_seed(1)
+    S, N, E = 5, 2, 8
+    y = torch.randn(S, N, 3 * E, requires_grad=True)
+    (k0, h0), (k1, h1), (k2, h2) = split_cols(y * 1.0, 3)
+    assert torch.equal(k1, y[..., E:2 * E]) and h1[1] == 1 and h0[0] is h1[0] is h2[0]
+
+    class InPlace(torch.autograd.Function):           # a consumer that writes its block of the pack, like the decoder layer
+        @staticmethod
+        def forward(ctx, x, handle):
+            ctx.handle = handle
+            return x.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            pack, j = ctx.handle
+            view = pack.block_view(j)
+            view.fill_(float(j + 1))
+            return view, None
+
+    loss = InPlace.apply(k0, h0) + (k1 * 2.0).sum()   # k2 unused
+    loss.backward()
+    want = torch.zeros(S, N, 3 * E)
+    want[..., :E] = 1.0
+    want[..., E:2 * E] = 2.0
+    assert torch.equal(y.grad, want)
+    with torch.no_grad():                             # no graph: plain views, no handles
+        views = split_cols(y.detach(), 3)
+    assert all(h is None for _, h in views)
+
+
+def test_stacked_masks_is_shared_within_a_step_and_follows_inplace_changes():
+    from mp_former_amd._targets import stacked_masks
+    a = torch.zeros(3, 4, 4, dtype=torch.bool)
+    b = torch.ones(2, 4, 4, dtype=torch.bool)
+    s1 = stacked_masks([a, b])
+    s2 = stacked_masks([a, b])
+    assert s1 is s2 and s1.shape == (5, 4, 4) and bool(s1[3:].all()) and not bool(s1[:3].any())
+    a[0, 0, 0] = True                                  # version counter changes -> rebuilt
+    s3 = stacked_masks([a, b])
+    assert s3 is not s1 and bool(s3[0, 0, 0])
+    assert stacked_masks([b, a]).shape == (5, 4, 4) and bool(stacked_masks([b, a])[:2].all())
+
+
+def test_compact_layout_orders_pairs_by_image():
+    """criterion._compact_layout: the gradient planes of the pairs back to back, image by image, each image padded to 16."""
+    from mp_former_amd.criterion import SetCriterion
+
+    class FakeMS:
+        pass
+
+    N, Q, h, w, C = 2, 7, 4, 4, 8
+    me = torch.randn(N, Q, C, requires_grad=True)
+    mf = torch.randn(N, C, h, w)
+    root = torch.randn(N, Q, h * w)
+    root._mpf_factors = (me, mf)
+    ms = FakeMS()
+    ms.bases = [root.view(N, Q, h, w)]
+    ms.h, ms.w, ms.dtype, ms.t_off = h, w, torch.float32, np.array([0])
+    bi = np.array([0, 1, 1, 0, 1, 0, 0])
+    offs, (slots, Qb, root_off), (me2, mf2) = SetCriterion._compact_layout(ms, bi, N)
+    assert me2 is me and mf2 is mf and Qb == Q and root_off == 0
+    assert slots == [(0, 4, 16), (16, 3, 16)]
+    assert list(offs // (h * w)) == [0, 16, 17, 1, 18, 2, 3]
+    del root._mpf_factors
+    assert SetCriterion._compact_layout(ms, bi, N) is None
