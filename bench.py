@@ -82,9 +82,15 @@ class TrainModel(torch.nn.Module):
         self.backbone = ResNet50()
         self.head = MPFormerHead(num_classes=num_classes, num_queries=num_queries)
 
+    on_head_backward_done = None      # callable: the gradients of every head parameter are final (FlatGradSync.launch)
+
     def forward(self, images, targets):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             feats = self.backbone(images.contiguous(memory_format=torch.channels_last))
+            if self.on_head_backward_done is not None and torch.is_grad_enabled():
+                fs = tuple(f for f in feats.values() if f.requires_grad)
+                cb = self.on_head_backward_done
+                torch.autograd.graph.register_multi_grad_hook(fs, lambda grads: cb(), mode="all")
             return self.head.total_loss(feats, targets)
 
 
@@ -191,7 +197,15 @@ def main():
         torch.backends.cudnn.benchmark = True
     model = TrainModel().to(dev).train()
     model.backbone.to(memory_format=torch.channels_last)
-    ddp = mdist.wrap_ddp(model, [local_rank])
+    # gradient exchange: two flat buckets (head, backbone) launched from ONE autograd hook (mp_former_amd.dist.FlatGradSync);
+    # MPF_GRAD_SYNC=ddp selects torch's DistributedDataParallel (per-parameter hooks, 25 MB buckets)
+    sync = None
+    if mdist.distributed() and os.environ.get("MPF_GRAD_SYNC", "flat") == "flat":
+        sync = mdist.FlatGradSync([list(model.head.parameters()), list(model.backbone.parameters())])
+        model.on_head_backward_done = lambda: sync.launch(0)
+        ddp = model
+    else:
+        ddp = mdist.wrap_ddp(model, [local_rank])
     opt = build_optimizer(model)
     params = [p for p in model.parameters() if p.requires_grad]
     batches = [synth_batch(a.batch, a.size, 80, 1000 * rank + i, dev) for i in range(4)]
@@ -201,6 +215,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = ddp(images, targets)
         loss.backward()
+        if sync is not None:
+            sync.finish()
         if not hasattr(opt, "max_norm"):      # stock AdamW: separate full-model clip (train_net.py:316-320)
             torch.nn.utils.clip_grad_norm_(params, 0.01, foreach=True)
         opt.step()

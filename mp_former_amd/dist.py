@@ -86,3 +86,90 @@ def wrap_ddp(model, device_ids=None):
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
         ddp.register_comm_hook(None, default_hooks.bf16_compress_hook)
     return ddp
+
+
+class FlatGradSync:
+    """Gradient averaging over the data-parallel ranks through a few FLAT buckets, without per-parameter hooks.
+
+    ``groups``: lists of parameters in the order in which their backward COMPLETES (for the training step: the head's
+    parameters, then the backbone's).  Each group owns one flat fp32 buffer; ``launch(i)`` copies the group's fresh
+    gradients into it with one multi-tensor copy and starts ONE asynchronous all-reduce (RCCL: ``AVG``), ``finish()`` does
+    the same for the groups not launched yet, waits, and leaves ``p.grad`` pointing at the averaged views (the optimizer
+    reads them in place).  The caller launches an early group from a single autograd hook — bench.py: when the gradients
+    of the backbone's feature maps are complete, so the head's 80 MB fly while the backbone back-propagates.
+
+    Why not DistributedDataParallel here: its reducer runs a hook and a scaled copy kernel per parameter (318 of them) and
+    bucket bookkeeping in the autograd thread — 1.6-3.5 ms per step at world size 1 on this step —
+    to overlap an exchange that xGMI finishes in about a millisecond.  Two flat buckets keep the overlap where it pays
+    (behind the backbone's backward) and drop the per-parameter work.  Parameters are broadcast from rank 0 once, as DDP
+    does.  A gradient that arrives for a group AFTER its launch would be lost: ``finish`` checks and raises.
+    """
+
+    def __init__(self, groups, broadcast=True):
+        self.world = world_size()
+        self.groups = []
+        for params in groups:
+            params = [p for p in params if p.requires_grad]
+            if not params:
+                continue
+            dev = params[0].device
+            offs, total = [], 0
+            for p in params:
+                if p.dtype != torch.float32 or p.device != dev:
+                    raise RuntimeError("FlatGradSync: fp32 parameters on one device per group")
+                offs.append(total)
+                total += (p.numel() + 63) // 64 * 64                     # 256-byte aligned slots
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            views = []
+            for p, o in zip(params, offs):
+                if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
+                    raise RuntimeError("FlatGradSync: dense parameters only")
+                views.append(flat[o:o + p.numel()].as_strided(p.shape, p.stride()))       # the parameter's own layout
+            self.groups.append({"params": params, "flat": flat, "views": views, "handle": None, "launched": False})
+        if broadcast and distributed():
+            for g in self.groups:
+                for p in g["params"]:
+                    dist.broadcast(p.data, src=0)
+
+    def _avg_op(self):
+        # RCCL / NCCL average in the collective; gloo has no AVG: sum, then one scale per bucket
+        return dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
+
+    @torch.no_grad()
+    def launch(self, i):
+        g = self.groups[i]
+        if g["launched"]:
+            return
+        srcs, dsts = [], []
+        for p, v in zip(g["params"], g["views"]):
+            if p.grad is None:
+                v.zero_()                                                 # unused this step: contributes zeros
+            elif p.grad.data_ptr() != v.data_ptr():
+                srcs.append(p.grad)
+                dsts.append(v)
+            p.grad = None            # (finish() puts the averaged view here; anything that shows up before is a late gradient)
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)
+        if distributed():
+            g["handle"] = dist.all_reduce(g["flat"], op=self._avg_op(), async_op=True)
+        g["launched"] = True
+
+    @torch.no_grad()
+    def finish(self):
+        for i, g in enumerate(self.groups):
+            if g["launched"]:
+                late = [j for j, p in enumerate(g["params"]) if p.grad is not None]
+                if late:
+                    raise RuntimeError(f"FlatGradSync: {len(late)} gradient(s) of group {i} arrived after its all-reduce was "
+                                       "launched — those parameters belong in a later group")
+            else:
+                self.launch(i)
+        for g in self.groups:
+            if g["handle"] is not None:
+                g["handle"].wait()
+                g["handle"] = None
+                if self._avg_op() != dist.ReduceOp.AVG:
+                    g["flat"].mul_(1.0 / self.world)
+            for p, v in zip(g["params"], g["views"]):
+                p.grad = v
+            g["launched"] = False

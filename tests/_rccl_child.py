@@ -18,7 +18,7 @@ def main():
     from mp_former_amd import dist as mdist
     from mp_former_amd.head import MPFormerHead
     from mp_former_amd.optim import ClipAdamW
-    if mode == "ddp":
+    if mode in ("ddp", "flat"):
         rank, world = mdist.init_from_env("nccl", dev)
         assert (rank, world) == (0, 1) and mdist.distributed(), "process group was not initialised"
         assert torch.distributed.get_backend() == "nccl"
@@ -37,7 +37,13 @@ def main():
                 return self.head.total_loss(feats, targets)
 
     model = M().to(dev).train()
-    ddp = mdist.wrap_ddp(model, [0])
+    sync = None
+    if mode == "flat":          # two flat buckets, the first launched from an autograd hook (what bench.py does at N > 1)
+        ps = [p for p in model.parameters() if p.requires_grad]
+        sync = mdist.FlatGradSync([ps[:len(ps) // 2], ps[len(ps) // 2:]])
+        ddp = model
+    else:
+        ddp = mdist.wrap_ddp(model, [0])
     if mode == "ddp":
         assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
     opt = ClipAdamW([{"params": [p for p in model.parameters() if p.requires_grad], "lr": 1e-4, "weight_decay": 0.05}],
@@ -58,6 +64,10 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = ddp(feats, targets)
         loss.backward()
+        if sync is not None:
+            sync.finish()
+            assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                       for g in sync.groups for p, v in zip(g["params"], g["views"]))
         opt.step()
         losses.append(float(loss.detach()))
     torch.cuda.synchronize()

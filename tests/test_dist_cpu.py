@@ -46,6 +46,43 @@ def _worker(rank, world, port, q):
         m2(torch.full((2, 8), float(rr + 1))).sum().backward()
         ref += m2[0].weight.grad / world
     out["grad_ref"] = ref.tolist()
+    # FlatGradSync: two flat buckets (a "head" launched early from an autograd hook, a "backbone" at finish), parameters
+    # that differ per rank before the broadcast, an unused parameter, a channels-last parameter
+    torch.manual_seed(10 + rank)                       # different initial weights per rank: the broadcast must fix that
+    backbone = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU()).to(memory_format=torch.channels_last)
+    head = torch.nn.ModuleDict({"a": torch.nn.Linear(4, 5), "unused": torch.nn.Linear(2, 2)})
+    sync = mdist.FlatGradSync([list(head.parameters()), list(backbone.parameters())])
+    out["w0_after_broadcast"] = backbone[0].weight.detach().flatten()[:4].tolist()
+    launched = []
+
+    def fwd(xin):
+        f = backbone(xin)
+        torch.autograd.graph.register_multi_grad_hook((f,), lambda grads: (launched.append(1), sync.launch(0)), mode="all")
+        return head["a"](f.mean((2, 3))).square().sum()
+
+    xin = torch.full((2, 3, 6, 6), float(rank + 1)) + torch.arange(6.0).view(1, 1, 1, 6)
+    fwd(xin).backward()
+    sync.finish()
+    out["flat_launched_early"] = len(launched)
+    out["flat_grads"] = {n: p.grad.flatten().tolist() for n, p in list(head.named_parameters()) + list(backbone.named_parameters())}
+    out["flat_strides_ok"] = all(p.grad.stride() == p.stride() for p in list(head.parameters()) + list(backbone.parameters()))
+    refg = {}
+    for rr in range(world):
+        b2 = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU())
+        h2 = torch.nn.ModuleDict({"a": torch.nn.Linear(4, 5), "unused": torch.nn.Linear(2, 2)})
+        b2.load_state_dict(backbone.state_dict()); h2.load_state_dict(head.state_dict())
+        xr = torch.full((2, 3, 6, 6), float(rr + 1)) + torch.arange(6.0).view(1, 1, 1, 6)
+        h2["a"](b2(xr).mean((2, 3))).square().sum().backward()
+        for n, p in list(h2.named_parameters()) + list(b2.named_parameters()):
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            refg[n] = refg.get(n, 0) + g.flatten() / world
+    out["flat_ref"] = {n: v.tolist() for n, v in refg.items()}
+    # a second step reuses the buckets (p.grad is the view now; zero_grad(set_to_none) as the bench does)
+    for p in list(head.parameters()) + list(backbone.parameters()):
+        p.grad = None
+    fwd(xin).backward()
+    sync.finish()
+    out["flat_grads_step2"] = {n: p.grad.flatten().tolist() for n, p in list(head.named_parameters()) + list(backbone.named_parameters())}
     q.put((rank, out))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -70,6 +107,27 @@ def test_world2_gloo():
         assert res[r]["max"] == pytest.approx(0.75)
         torch.testing.assert_close(torch.tensor(res[r]["grad"]), torch.tensor(res[r]["grad_ref"]))
     torch.testing.assert_close(torch.tensor(res[0]["grad"]), torch.tensor(res[1]["grad"]))
+    assert res[0]["w0_after_broadcast"] == res[1]["w0_after_broadcast"]
+    for r in range(2):
+        assert res[r]["flat_launched_early"] == 1 and res[r]["flat_strides_ok"]
+        assert set(res[r]["flat_grads"]) == set(res[r]["flat_ref"])
+        for n in res[r]["flat_ref"]:
+            torch.testing.assert_close(torch.tensor(res[r]["flat_grads"][n]), torch.tensor(res[r]["flat_ref"][n]), rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(torch.tensor(res[r]["flat_grads_step2"][n]), torch.tensor(res[r]["flat_ref"][n]), rtol=1e-5, atol=1e-6)
+        assert all(v == 0.0 for v in res[r]["flat_grads"]["unused.weight"])
+    assert res[0]["flat_grads"] == res[1]["flat_grads"]
+
+
+def test_flat_grad_sync_rejects_late_gradients():
+    """a gradient that shows up for a bucket after its all-reduce was launched must not be dropped silently"""
+    from mp_former_amd import dist as mdist
+    lin = torch.nn.Linear(3, 2)
+    sync = mdist.FlatGradSync([list(lin.parameters())], broadcast=False)
+    lin(torch.ones(1, 3)).sum().backward()
+    sync.launch(0)
+    lin(torch.ones(1, 3)).sum().backward()          # arrives after the launch
+    with pytest.raises(RuntimeError, match="arrived after"):
+        sync.finish()
 
 
 def test_world1_is_identity():

@@ -29,7 +29,7 @@ def _run(mode):
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MPF_FORCE_DIST"):
         env.pop(k, None)
-    if mode == "ddp":
+    if mode in ("ddp", "flat"):
         env.update(MPF_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_child.py"), mode], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, f"child ({mode}) failed:\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
@@ -49,3 +49,15 @@ def test_ddp_over_rccl_world1_matches_plain_run():
     for a, b in zip(plain["losses"][1:], ddp["losses"][1:]):
         assert abs(a - b) <= 1e-2 * max(1.0, abs(a)), (plain, ddp)
     assert abs(plain["checksum"] - ddp["checksum"]) <= 1e-5 * plain["checksum"], (plain["checksum"], ddp["checksum"])
+
+
+@pytest.mark.timeout(900)
+def test_flat_grad_sync_over_rccl_world1_matches_plain_run():
+    """mp_former_amd.dist.FlatGradSync (flat buckets + RCCL AVG all-reduce, what bench.py uses at N > 1) at world size 1:
+    the native clip + AdamW steps on the bucket views must reproduce the plain run."""
+    plain = _run("plain")
+    flat = _run("flat")
+    assert abs(plain["losses"][0] - flat["losses"][0]) <= 1e-5 * max(1.0, abs(plain["losses"][0])), (plain, flat)
+    for a, b in zip(plain["losses"][1:], flat["losses"][1:]):
+        assert abs(a - b) <= 1e-2 * max(1.0, abs(a)), (plain, flat)
+    assert abs(plain["checksum"] - flat["checksum"]) <= 1e-5 * plain["checksum"], (plain["checksum"], flat["checksum"])
