@@ -126,11 +126,17 @@ struct Acc {
     }
 
     // a_base / b_base: byte offset of the wave's first row in the A / B image
-    template <int AKC, int BKC, bool ONE = false, bool A1 = false>
+    // BROW: the B image is row-major — [plane][column n][k-chunk slot (kc ^ sigma(n))][16 B], sigma(n) = (-(n >> 2)) & 3 —
+    // the layout a DMA piece (64 lanes x 16 B, lane-linear in LDS) fills with 4 consecutive lanes reading the 64
+    // contiguous bytes of one weight row; sigma makes the 16-lane service groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...)
+    // hit 16 different bank quads.
+    template <int AKC, int BKC, bool ONE = false, bool A1 = false, bool BROW = false>
     __device__ __forceinline__ void step(const unsigned char* lds, int a_base, int b_base, int lane)
     {
         const int r16 = lane & 15, g = lane >> 4;
-        const int a_frag = a_base + g * AKC + (r16 ^ (2 * g)) * 16, b_frag = b_base + g * BKC + (r16 ^ (2 * g)) * 16;
+        constexpr int BJ = BROW ? 1024 : 256;        // bytes between the 16-column tiles of the B image
+        const int a_frag = a_base + g * AKC + (r16 ^ (2 * g)) * 16;
+        const int b_frag = BROW ? b_base + (r16 * 4 + (g ^ ((0 - (r16 >> 2)) & 3))) * 16 : b_base + g * BKC + (r16 ^ (2 * g)) * 16;
         if (A1) {       // A is a bf16 matrix (its plane 0 is exact), B a split fp32 one: three products, smallest first
             bf16x8 fa0[4];
 #pragma unroll
@@ -140,7 +146,7 @@ struct Acc {
                 bf16x8 fb[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    fb[pl] = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + pl * 4 * BKC + j * 256));
+                    fb[pl] = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + pl * 4 * BKC + j * BJ));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2], fa0[i], v[i][j], 0, 0, 0);
 #pragma unroll
@@ -156,7 +162,7 @@ struct Acc {
             for (int i = 0; i < 4; ++i) fa0[i] = as_frag(*reinterpret_cast<const uint4*>(lds + a_frag + i * 256));
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const bf16x8 fb0 = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + j * 256));
+                const bf16x8 fb0 = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + j * BJ));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0, fa0[i], v[i][j], 0, 0, 0);
             }
@@ -173,7 +179,7 @@ struct Acc {
             bf16x8 fb[3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
-                fb[pl] = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + pl * 4 * BKC + j * 256));
+                fb[pl] = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + pl * 4 * BKC + j * BJ));
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[2][i], v[i][j], 0, 0, 0);
 #pragma unroll
@@ -332,6 +338,15 @@ __device__ __forceinline__ void g3_epilogue(const G3& p, const Acc<NJ, false>& a
     }
 }
 
+// one DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_addr, lds_addr + 1024) (M0 = LDS address
+// of lane 0).  Inline asm, not __builtin_amdgcn_global_load_lds: hipcc treats the builtin as an LDS write it cannot
+// disambiguate and puts s_waitcnt vmcnt(0) in front of the next ds_read, which would drain the A loads in flight.
+// Address = scalar base (SGPR pair) + per-lane 32-bit byte offset: no 64-bit vector arithmetic per piece.
+__device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
+}
+
 // one output tile: 128 rows x BN columns starting at (m0, n0)
 // CV: A is a channel-last image [N_img*H*W][Cin] and K runs over (tap, channel) of a 3x3 window — K step kt reads the
 // rows shifted by the tap's (dy, dx) (sign = -1: the transposed convolution of the input gradient); taps that fall off
@@ -347,6 +362,12 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
     constexpr int kAbytes = 12 * kAKc;
     constexpr int kBunits = 3 * BN * 4;          // 16-B units of a B stage
     constexpr int kBiter = (kBunits + kThreads - 1) / kThreads;
+    // B (the pre-split weight planes, L2-resident) goes global -> LDS by DMA (global_load_lds, 64 lanes x 16 B = 1 KB per
+    // wave instruction) into one of TWO stages, no registers and no ds_write: the 16-byte LDS stores were a quarter of this
+    // kernel's time (a wave's ds_write_b128 occupies the VGPR -> LDS path for ~13 cycles; A + B were 12 per thread and K step)
+    constexpr int kBstage = 12 * kBKc;           // bytes of one B stage
+    constexpr int kPieces = kBstage / 1024;      // DMA pieces per stage (BN = 128: 24, 96: 18, 64: 12)
+    constexpr int kPW = (kPieces + 3) / 4;       // per wave (BN = 96: 5, the two surplus pieces repeat the last one)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -376,22 +397,27 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         cx1 = mr1 % p.cv_W; cy1 = (mr1 / p.cv_W) % p.cv_H;
     }
     (void)ap0; (void)ap1;
-    const unsigned short* bsrc[kBiter];
-    int bdst[kBiter];
+    // piece q = wave + 4 i covers LDS units [64 q, 64 q + 64) of a stage: plane q / (BN / 16), columns 16 (q % (BN / 16)) ..+15;
+    // lane -> column nl = lane >> 2, LDS slot lane & 3 = k-chunk ^ sigma(nl)
+    unsigned boff[kPW];        // byte offset of the lane's 16 bytes from p.bp at k = 0 (the planes span < 4 GiB)
+    int bpiece[kPW];           // LDS byte offset of the piece inside a stage (wave-uniform)
+    {
+        const int nl = lane >> 2, kc = (lane & 3) ^ ((0 - (nl >> 2)) & 3);
 #pragma unroll
-    for (int i = 0; i < kBiter; ++i) {
-        const int u = tid + i * kThreads;
-        const int kc = u & 3, n = (u >> 2) % BN, pl = min(u / (4 * BN), 2);      // (units past the end: clamped, not stored)
-        bsrc[i] = p.bp + (int64_t)pl * p.plane + (int64_t)min(n0 + n, p.N - 1) * p.K + kc * 8;
-        bdst[i] = kAbytes + (pl * 4 + kc) * kBKc + (n ^ (2 * kc)) * 16;
+        for (int i = 0; i < kPW; ++i) {
+            const int q = min(wave + 4 * i, kPieces - 1);
+            const int pl = q / (BN / 16), nb = (q % (BN / 16)) * 16;
+            boff[i] = (unsigned)(((int64_t)pl * p.plane + (int64_t)min(n0 + nb + nl, p.N - 1) * p.K + kc * 8) * 2);
+            bpiece[i] = __builtin_amdgcn_readfirstlane(q * 1024);
+        }
     }
+    const unsigned lds_b = (unsigned)(uintptr_t)(lds + kAbytes);           // LDS address of B stage 0
 
     // A is prefetched TWO K-steps ahead (HBM latency is longer than one step of MFMAs; measured: with
     // one step of distance the staging and the MFMAs serialise), in two alternating register sets;
     // B (L2-resident planes) one step ahead.
     float4 raE[4], raO[4], ra2[4];
-    uint4 rb0, rb1, rb2, rb3 = make_uint4(0, 0, 0, 0), rb4 = make_uint4(0, 0, 0, 0), rb5 = make_uint4(0, 0, 0, 0);
-    static_assert(kBiter >= 3 && kBiter <= 6 && (kBiter > 3 || kBunits == 3 * kThreads), "B staging assumes 3..6 units per thread");
+    (void)kBunits; (void)kBiter;
 #define G3_LOAD_A(ra, k0)                                                                    \
     {                                                                                        \
         ra[0] = *reinterpret_cast<const float4*>(ap0 + (k0));                                \
@@ -416,7 +442,9 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         ra[3] = *reinterpret_cast<const float4*>(p.a + o1_ + 4);                             \
         vm = (v0_ ? 1 : 0) | (v1_ ? 2 : 0);                                                  \
     }
-#define G3_LOAD_B(k0)                                                                        \
+    // B stage `stage` <- K step k0: kPW DMA pieces per wave (inline asm: the compiler neither tracks nor waits for them;
+    // G3_WAIT_B is the explicit wait).  The addend rows of A (A2) ride along as before.
+#define G3_LOAD_B(k0, stage)                                                                 \
     {                                                                                        \
         if constexpr (A2) {                                                                  \
             ra2[0] = *reinterpret_cast<const float4*>(a2p0 + (k0));                          \
@@ -424,12 +452,8 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
             ra2[2] = *reinterpret_cast<const float4*>(a2p1 + (k0));                          \
             ra2[3] = *reinterpret_cast<const float4*>(a2p1 + (k0) + 4);                      \
         }                                                                                    \
-        rb0 = *reinterpret_cast<const uint4*>(bsrc[0] + (k0));                               \
-        rb1 = *reinterpret_cast<const uint4*>(bsrc[1] + (k0));                               \
-        rb2 = *reinterpret_cast<const uint4*>(bsrc[2] + (k0));                               \
-        if constexpr (kBiter > 3) rb3 = *reinterpret_cast<const uint4*>(bsrc[3] + (k0));     \
-        if constexpr (kBiter > 4) rb4 = *reinterpret_cast<const uint4*>(bsrc[4] + (k0));     \
-        if constexpr (kBiter > 5) rb5 = *reinterpret_cast<const uint4*>(bsrc[5] + (k0));     \
+        _Pragma("unroll") for (int i_ = 0; i_ < kPW; ++i_)                                   \
+            glds16(p.bp + (k0), boff[i_], lds_b + (stage) * kBstage + bpiece[i_]);           \
     }
 #define G3_LA(ra, vm, k0)                                                                    \
     {                                                                                        \
@@ -466,14 +490,6 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + aslot1 * 16) = m;             \
         *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKc + aslot1 * 16) = l;             \
         }                                                                                    \
-        *reinterpret_cast<uint4*>(lds + bdst[0]) = rb0;                                      \
-        *reinterpret_cast<uint4*>(lds + bdst[1]) = rb1;                                      \
-        *reinterpret_cast<uint4*>(lds + bdst[2]) = rb2;                                      \
-        if constexpr (kBiter > 3) *reinterpret_cast<uint4*>(lds + bdst[3]) = rb3;            \
-        if constexpr (kBiter > 4)                                                            \
-            if (kBunits >= 5 * kThreads || tid + 4 * kThreads < kBunits) *reinterpret_cast<uint4*>(lds + bdst[4]) = rb4; \
-        if constexpr (kBiter > 5)                                                            \
-            if (kBunits >= 6 * kThreads || tid + 5 * kThreads < kBunits) *reinterpret_cast<uint4*>(lds + bdst[5]) = rb5; \
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -482,7 +498,7 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
     acc.zero();
 
     const int a_frag = wr * 64 * 16;                        // byte offset of the wave's first row in the A image
-    const int b_frag = kAbytes + wc * (BN / 2) * 16;        // ... and in the B image
+    const int b_frag = kAbytes + wc * (BN / 2) * 64;        // ... and of its first column in B stage 0 (row-major image)
 
     const int nk = p.K / kBK;
     // All loads are unconditional (the K index is clamped; a surplus load is never stored): with
@@ -494,38 +510,49 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
 #endif
     int vmE = 3, vmO = 3;
+    // order of the vector-memory operations of a step: [B DMA of the next step] [A loads two steps ahead].  Memory
+    // operations complete in order, so "at most the 4 (ABF: 2) youngest outstanding" = the DMA has landed.
+    constexpr int kAloads = ABF ? 2 : 4;
+#define G3_WAIT_B() { if constexpr (kAloads == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     G3_LA(raE, vmE, 0);
-    G3_LOAD_B(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G3_LOAD_B(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     G3_LA(raO, vmO, min(kBK, klast));
+    __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < nk; kt += 2) {
-        __syncthreads();
+        __syncthreads();                            // everyone is done with the A image and with B stage 1
         G3_T(0);
         G3_WRITE(raE, vmE);
         G3_T(1);
+        G3_WAIT_B();                                // my pieces of B stage 0 (K step kt)
         __syncthreads();
         G3_T(2);
-        G3_LOAD_B(min((kt + 1) * kBK, klast));      // B first: the next write waits for it with the A loads still in flight
+        G3_LOAD_B(min((kt + 1) * kBK, klast), 1);   // B first: the wait above counts on this order
         __builtin_amdgcn_sched_barrier(0);
         G3_LA(raE, vmE, min((kt + 2) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
         G3_T(3);
-        acc.template step<kAKc, kBKc, false, ABF>(lds, a_frag, b_frag, lane);
+        acc.template step<kAKc, kBKc, false, ABF, true>(lds, a_frag, b_frag, lane);
         G3_T(4);
         if (kt + 1 >= nk) break;
         __syncthreads();
         G3_T(0);
         G3_WRITE(raO, vmO);
         G3_T(1);
+        G3_WAIT_B();
         __syncthreads();
         G3_T(2);
-        G3_LOAD_B(min((kt + 2) * kBK, klast));
+        G3_LOAD_B(min((kt + 2) * kBK, klast), 0);
         __builtin_amdgcn_sched_barrier(0);
         G3_LA(raO, vmO, min((kt + 3) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
         G3_T(3);
-        acc.template step<kAKc, kBKc, false, ABF>(lds, a_frag, b_frag, lane);
+        acc.template step<kAKc, kBKc, false, ABF, true>(lds, a_frag, b_frag + kBstage, lane);
         G3_T(4);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (surplus DMA pieces of the clamped last steps must not outlive the LDS allocation)
+#undef G3_WAIT_B
 #ifdef G3_TIMING
     if (tid == 0) {
         for (int i = 0; i < 5; ++i) atomicAdd(&g3_dbg[i], tacc[i]);
@@ -544,7 +571,7 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
 template <int BN, bool A2>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 12 * BN * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 2 * 12 * BN * 16];       // A image + two B stages
     // XCD-aware tile order: each XCD walks a contiguous run of tiles (column tiles of one row block
     // are neighbours, so the A rows they share stay in that XCD's L2)
     const int per_xcd = (p.ntiles + 7) >> 3;
@@ -559,7 +586,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
 template <int BN>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_abf_kernel(G3 p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 12 * BN * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 2 * 12 * BN * 16];
     const int per_xcd = (p.ntiles + 7) >> 3;
     const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
@@ -570,7 +597,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_abf_kernel(G3 p)
 // 3x3 convolution (stride 1, zero padding 1) of channel-last images as ONE GEMM with K = 9 * Cin (g3_tn_tile<.., CV>)
 __global__ __launch_bounds__(kThreads, 2) void gemm3_conv_kernel(G3 p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 12 * 128 * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 2 * 12 * 128 * 16];
     const int per_xcd = (p.ntiles + 7) >> 3;
     const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
@@ -585,7 +612,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_conv_kernel(G3 p)
 template <bool A2>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_mixed_kernel(G3 p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 12 * 128 * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 2 * 12 * 128 * 16];
     const int g1 = ((p.ntiles + 7) >> 3) << 3;          // blocks of the first region (multiple of 8)
     if ((int)blockIdx.x < g1) {
         const int per_xcd = g1 >> 3;
