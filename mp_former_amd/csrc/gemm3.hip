@@ -130,8 +130,11 @@ struct Acc {
     // the layout a DMA piece (64 lanes x 16 B, lane-linear in LDS) fills with 4 consecutive lanes reading the 64
     // contiguous bytes of one weight row; sigma makes the 16-lane service groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...)
     // hit 16 different bank quads.
-    template <int AKC, int BKC, bool ONE = false, bool A1 = false, bool BROW = false>
-    __device__ __forceinline__ void step(const unsigned char* lds, int a_base, int b_base, int lane)
+    struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+    // hook(j) is called after the MFMAs of column tile j (plain six-product form only; tools/ubench/gemm3_pipe.hip)
+    template <int AKC, int BKC, bool ONE = false, bool A1 = false, bool BROW = false, typename Hook = NoHook>
+    __device__ __forceinline__ void step(const unsigned char* lds, int a_base, int b_base, int lane, Hook hook = Hook())
     {
         const int r16 = lane & 15, g = lane >> 4;
         constexpr int BJ = BROW ? 1024 : 256;        // bytes between the 16-column tiles of the B image
@@ -192,6 +195,7 @@ struct Acc {
             for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[0][i], v[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[0][i], v[i][j], 0, 0, 0);
+            hook(j);
         }
     }
 
