@@ -9,7 +9,8 @@ One "step" = one full training iteration on one synthetic batch already resident
   R50 backbone (stock PyTorch-ROCm, bf16 autocast)  ->  MSDeformAttn pixel decoder (fp32, native HIP
   deformable attention)  ->  masked-attention decoder with mask-piloted queries (bf16 autocast)  ->
   Hungarian matching + point-sampled CE / BCE / dice losses (60 terms)  ->  backward  ->  gradient
-  all-reduce over RCCL (DDP, N > 1)  ->  full-model grad-norm clip 0.01  ->  AdamW.
+  all-reduce over RCCL (two flat buckets launched from one autograd hook, mp_former_amd.dist.FlatGradSync; MPF_GRAD_SYNC=ddp
+  = torch DDP; N > 1)  ->  full-model grad-norm clip 0.01  ->  AdamW.
 Per-GPU batch is fixed at 2 images (IMS_PER_BATCH 16 on 8 GPUs): weak scaling.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
