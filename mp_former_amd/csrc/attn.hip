@@ -570,11 +570,24 @@ __device__ __forceinline__ void transpose2_tile(const __hip_bfloat16* __restrict
         return;
     }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 4 rows per pass
-    for (int r = ty; r < 64; r += 4) {
-        const int l = l0 + r, c = c0 + tx;
-        const bool ok = l < L && c < NE;
-        ta[tx][r] = ok ? reinterpret_cast<const unsigned short*>(a)[src(l, c)] : (unsigned short)0;
-        tb[tx][r] = ok ? reinterpret_cast<const unsigned short*>(b)[src(l, c)] : (unsigned short)0;
+    {
+        // all 32 loads of a thread requested together on clamped indices (a load behind `ok ? p[i] : 0` is a branch + a wait of
+        // its own: 16 dependent round trips made this path 12 us for the 114-query self-attention operands)
+        const int c = min(c0 + tx, NE - 1);
+        unsigned short va[16], vb[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int l = min(l0 + ty + 4 * k, L - 1);
+            va[k] = reinterpret_cast<const unsigned short*>(a)[src(l, c)];
+            vb[k] = reinterpret_cast<const unsigned short*>(b)[src(l, c)];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int r = ty + 4 * k;
+            const bool ok = l0 + r < L && c0 + tx < NE;
+            ta[tx][r] = ok ? va[k] : (unsigned short)0;
+            tb[tx][r] = ok ? vb[k] : (unsigned short)0;
+        }
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
