@@ -26,6 +26,9 @@
 #include <stdint.h>
 
 #include "mpf_common.h"
+#ifndef G3_PRIO
+#define G3_PRIO 1
+#endif
 
 namespace {
 
@@ -537,7 +540,9 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         G3_LA(raE, vmE, min((kt + 2) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
         G3_T(3);
+        __builtin_amdgcn_s_setprio(G3_PRIO);
         acc.template step<kAKc, kBKc, false, ABF, true>(lds, a_frag, b_frag, lane);
+        __builtin_amdgcn_s_setprio(0);
         G3_T(4);
         if (kt + 1 >= nk) break;
         __syncthreads();
@@ -552,7 +557,9 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         G3_LA(raO, vmO, min((kt + 3) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
         G3_T(3);
+        __builtin_amdgcn_s_setprio(G3_PRIO);
         acc.template step<kAKc, kBKc, false, ABF, true>(lds, a_frag, b_frag + kBstage, lane);
+        __builtin_amdgcn_s_setprio(0);
         G3_T(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (surplus DMA pieces of the clamped last steps must not outlive the LDS allocation)
@@ -836,8 +843,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
         }
         __syncthreads();
         if (r0 + 2 * kBK <= r_end) G3N_LOAD(r0 + kBK, false) else if (r0 + kBK < r_end) G3N_LOAD(r0 + kBK, true);
+        __builtin_amdgcn_s_setprio(G3_PRIO);        // the MFMA phase outranks the other workgroups' staging VALU on this SIMD
         if constexpr (A16 || B16) acc.template step<kAKc, kBKc, false, A16, B16>(lds, a_frag, b_frag, lane);
         else acc.template step<kAKc, kBKc, BF>(lds, a_frag, b_frag, lane);
+        __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
