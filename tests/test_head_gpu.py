@@ -231,7 +231,7 @@ def test_head_amp_path_matches_reference_golden(name):
         torch.cuda.synchronize()
         # the mask losses differentiate w.r.t. (mask_embed, mask_features) on the paired rows only (no dense map gradient)
         assert MaskLossSumsCompact.calls == compact_before + 1, "the compact mask-gradient route did not run"
-        for kern in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "small_gemm", "lsa_kernel", "msda_fwd_block",
+        for kern in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "small_gemm", "small_gemm_group_kernel", "lsa_kernel", "msda_fwd_block",
                      "msda_bwd_pull_mfma", "gemm3", "gn_cl_apply", "gn_cl_bwd_apply"):
             assert _lib.profile_get(kern)[0] > 0, f"{kern} did not run on the AMP path"
     finally:
