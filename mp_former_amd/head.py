@@ -25,6 +25,31 @@ def build_weight_dict(dec_layers, class_weight=2.0, mask_weight=5.0, dice_weight
     return wd
 
 
+def prepare_targets(instances, padded_hw):
+    """maskformer_model.py:281-299: per-image Detectron2 ``Instances`` (anything with ``image_size`` (h, w), ``gt_classes``,
+    ``gt_masks`` [T, h, w] and optionally ``gt_boxes.tensor`` xyxy) -> the target dicts of the hot path: ground-truth masks
+    zero-padded to the padded batch size (``images.tensor.shape[-2:]``), labels, boxes as normalised cxcywh (None without
+    boxes, as the reference).  ONE allocation + copy per image; no device synchronisation."""
+    h_pad, w_pad = int(padded_hw[0]), int(padded_hw[1])
+    out = []
+    for t in instances:
+        h, w = t.image_size
+        gm = t.gt_masks
+        gm = gm.tensor if hasattr(gm, "tensor") else gm              # detectron2 BitMasks or a plain tensor
+        if gm.shape[-2] > h_pad or gm.shape[-1] > w_pad:
+            raise ValueError(f"ground-truth masks {tuple(gm.shape[-2:])} larger than the padded batch ({h_pad}, {w_pad})")
+        padded = torch.zeros((gm.shape[0], h_pad, w_pad), dtype=gm.dtype, device=gm.device)
+        padded[:, :gm.shape[1], :gm.shape[2]] = gm
+        boxes = None
+        if hasattr(t, "gt_boxes"):
+            b = t.gt_boxes.tensor if hasattr(t.gt_boxes, "tensor") else t.gt_boxes
+            x0, y0, x1, y1 = b.unbind(-1)
+            cxcywh = torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0], dim=-1)            # util/box_ops.py:16-20
+            boxes = cxcywh / torch.as_tensor([w, h, w, h], dtype=torch.float, device=b.device)
+        out.append({"labels": t.gt_classes, "masks": padded, "boxes": boxes})
+    return out
+
+
 class MPFormerHead(nn.Module):
     """COCO-instance defaults (configs/coco/instance-segmentation/maskformer2_R50_bs16_50ep.yaml +
     run_50ep_no_noise_all_ly.sh): 100 queries, 80 classes, 6 encoder / 9 decoder layers, NUM_DN 1,

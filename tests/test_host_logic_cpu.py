@@ -87,3 +87,23 @@ def test_compact_layout_orders_pairs_by_image():
     assert list(offs // (h * w)) == [0, 16, 17, 1, 18, 2, 3]
     del root._mpf_factors
     assert SetCriterion._compact_layout(ms, bi, N) is None
+
+
+def test_prepare_targets_pads_masks_and_normalises_boxes():
+    """head.prepare_targets == maskformer_model.py:281-299 (masks zero-padded to the batch size, cxcywh / (w, h, w, h))."""
+    from types import SimpleNamespace
+    from mp_former_amd.head import prepare_targets
+    m0 = torch.rand(3, 20, 30) > 0.5
+    m1 = torch.rand(0, 16, 16) > 0.5
+    inst = [SimpleNamespace(image_size=(20, 30), gt_classes=torch.tensor([1, 5, 2]), gt_masks=m0,
+                            gt_boxes=SimpleNamespace(tensor=torch.tensor([[3.0, 2.0, 9.0, 12.0], [0.0, 0.0, 30.0, 20.0], [10.0, 5.0, 20.0, 15.0]]))),
+            SimpleNamespace(image_size=(16, 16), gt_classes=torch.zeros(0, dtype=torch.long), gt_masks=SimpleNamespace(tensor=m1))]
+    t = prepare_targets(inst, (32, 32))
+    assert t[0]["masks"].shape == (3, 32, 32) and t[0]["masks"].dtype == torch.bool
+    assert torch.equal(t[0]["masks"][:, :20, :30], m0) and not bool(t[0]["masks"][:, 20:].any()) and not bool(t[0]["masks"][:, :, 30:].any())
+    want = torch.tensor([[6.0 / 30, 7.0 / 20, 6.0 / 30, 10.0 / 20], [0.5, 0.5, 1.0, 1.0], [0.5, 0.5, 10.0 / 30, 0.5]])
+    assert torch.allclose(t[0]["boxes"], want) and torch.equal(t[0]["labels"], torch.tensor([1, 5, 2]))
+    assert t[1]["masks"].shape == (0, 32, 32) and t[1]["boxes"] is None
+    import pytest
+    with pytest.raises(ValueError):
+        prepare_targets(inst, (16, 16))
