@@ -120,3 +120,31 @@ def test_decoder_inputs_kernel_matches_torch(out_dtype):
     torch.autograd.backward([s_c, k_c], [g1, g2])
     torch.testing.assert_close(gb, base.grad, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(gl, le.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("switch", ["MPF_KV_BATCH", "MPF_COMPACT_MASK_GRAD", "MPF_NATIVE_LOSS_TAIL", "MPF_GN_FLATTEN", "MPF_HEADS_TALL"])
+def test_round2_switches_do_not_change_the_step(switch):
+    """Every scheduling change of the second half of round 2 (key / value projections per level, compact mask-loss gradient,
+    native criterion tail, GroupNorm into the flattened encoder input, tall-linear heads) against its plainer route
+    (`<switch>=0`): same losses, same gradients up to bf16 accumulation-order noise, on the AMP path with replayed draws."""
+    dev = torch.device("cuda:0")
+    z, cfg, pp, dp, feats, targets, replay = load_head_fixture("head_ragged")
+    h = _build(cfg, pp, dp, dev)
+    feats = {k: v.to(dev) for k, v in feats.items()}
+    targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+    l_on, g_on = _run(h, feats, targets, replay, cfg, fused=True)
+    os.environ[switch] = "0"
+    try:
+        l_off, g_off = _run(h, feats, targets, replay, cfg, fused=True)
+    finally:
+        os.environ.pop(switch, None)
+    for k in l_on:
+        assert abs(l_on[k] - l_off[k]) <= 2e-3 * max(1.0, abs(l_on[k])), (switch, k, l_on[k], l_off[k])
+    assert set(g_on) == set(g_off)
+    worst = ("", 0.0)
+    for n in g_on:
+        a, b = g_on[n].double().flatten(), g_off[n].double().flatten()
+        rel = (a - b).norm().item() / (a.norm().item() + 1e-12)
+        if rel > worst[1]:
+            worst = (n, rel)
+    assert worst[1] < 2e-2, (switch, worst)
