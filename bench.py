@@ -184,10 +184,15 @@ def main():
     if a.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     assert world == a.gpus, f"WORLD_SIZE {world} != --gpus {a.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test-only overrides (tests/test_bench_world2_gpu.py): every rank on cuda:0 and a gloo process group, so that the
+    # N > 1 code path of this file runs inside a one-GPU lease; never set by the driver
+    one_device = os.environ.get("MPF_DIST_ONE_DEVICE", "0") == "1"
+    backend = os.environ.get("MPF_DIST_BACKEND", "nccl")
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     from mp_former_amd import dist as mdist
-    mdist.init_from_env("nccl", dev)                     # nccl == RCCL on ROCm
+    mdist.init_from_env(backend, dev)                    # nccl == RCCL on ROCm
 
     from mp_former_amd import _lib, _miopen
     _lib.lib()   # fail loudly if the native library is missing
@@ -206,7 +211,7 @@ def main():
         model.on_head_backward_done = lambda: sync.launch(0)
         ddp = model
     else:
-        ddp = mdist.wrap_ddp(model, [local_rank])
+        ddp = mdist.wrap_ddp(model, [dev_index])
     opt = build_optimizer(model)
     params = [p for p in model.parameters() if p.requires_grad]
     batches = [synth_batch(a.batch, a.size, 80, 1000 * rank + i, dev) for i in range(4)]
@@ -280,6 +285,17 @@ def main():
         else:
             traffic_note = "PMC file is older than csrc/msda_block.hip: refused"
 
+    # test-only (MPF_CHECK_SYNC=1): the ranks' parameters must have stayed identical through the averaged updates
+    sync_spread = None
+    if mdist.distributed() and os.environ.get("MPF_CHECK_SYNC", "0") == "1":
+        ps_ = list(model.parameters())
+        cs = torch.stack([p.detach().double().sum() for p in ps_])                 # signed sum per parameter tensor
+        scale = torch.stack([p.detach().double().abs().sum() for p in ps_]) + 1e-30
+        allcs = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(allcs, cs)
+        allcs = torch.stack(allcs)
+        sync_spread = float(((allcs.max(0).values - allcs.min(0).values) / scale).max())
+
     if rank == 0:
         ips = a.batch * world * a.steps / dt
         achieved = by_b / (ms_b * 1e-3) / 1e9 if ms_b > 0 else 0.0
@@ -316,7 +332,7 @@ def main():
                                    % (a.size, a.size),
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "tokens_per_image_S": S_tok, "final_loss": round(final_loss, 4),
-                       "roofline_steps": P},
+                       "roofline_steps": P, "process_group": (dist.get_backend() if mdist.distributed() else None)},
             "roofline": {"kernel": "MSDA backward (msda_bwd_push_block_kernel + msda_bwd_pull_mfma_kernel, atomics-free)",
                          "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
@@ -340,6 +356,8 @@ def main():
                              gemm_entry("gemm3_nt_kernel<conv3x3>", n_gw, ms_gw, fl_gw)]},
             "cpu_baseline": None,
         }
+        if sync_spread is not None:
+            out["config"]["param_sync_spread"] = sync_spread
         out["config"]["miopen_find_db"] = "mismatch (MIOpen ignored the shipped db)" if _miopen.db_mismatch() else "shipped"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_size)

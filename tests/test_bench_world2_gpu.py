@@ -1,0 +1,54 @@
+"""bench.py's N > 1 code path inside a one-GPU lease: two ranks started by torch.distributed.run exactly as the driver
+starts them, both mapped to cuda:0 and talking over gloo (MPF_DIST_ONE_DEVICE / MPF_DIST_BACKEND, test-only switches:
+RCCL refuses two ranks on one device).  Everything else is the real thing — rank-dependent synthetic batches (different
+numbers of ground-truth masks per rank, hence different Qtot), the flat-bucket gradient exchange launched from the
+autograd hook while the backbone back-propagates, the device-side num_masks all-reduce, ClipAdamW on the bucket views,
+barrier + max-over-ranks timing, one JSON line from rank 0.  The ranks' parameters must still be identical after the
+averaged updates.  RCCL itself is covered at world size 1 by tests/test_rccl_gpu.py; no scaling number follows from this."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("grad_sync", ["flat", "ddp"])
+def test_bench_two_ranks_one_device(grad_sync):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MPF_FORCE_DIST"):
+        env.pop(k, None)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MPF_DIST_ONE_DEVICE="1", MPF_DIST_BACKEND="gloo", MPF_CHECK_SYNC="1",
+               MPF_GRAD_SYNC=grad_sync)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--profile-steps", "1", "--size", "512", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1400)
+    assert r.returncode == 0, f"bench.py --gpus 2 failed:\n{r.stdout[-2000:]}\n{r.stderr[-6000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line expected from rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["process_group"] == "gloo"
+    assert out["cpu_baseline"] is None                      # rank 0 at N = 1 only
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    loss = out["config"]["final_loss"]
+    assert loss == loss and abs(loss) < 1e6, loss
+    # identical parameters on both ranks after 4 averaged updates: per parameter tensor |sum_rank0 - sum_rank1| / sum|p|
+    # (a tensor left out of the exchange would differ by >= 1e-5 after four AdamW steps)
+    assert out["config"]["param_sync_spread"] <= 1e-7, out["config"]["param_sync_spread"]
+    assert out["roofline"]["launches"] > 0                  # the native MSDA backward ran on the profiled step
