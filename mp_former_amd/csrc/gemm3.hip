@@ -59,6 +59,8 @@ struct G3 {
 
 int g_ablate = 0;      // mpf_set_option("gemm3_ablate"): reserved for timing experiments
 int g_mixed = 1;       // mpf_set_option("gemm3_mixed_tiles"): 128 x 64 tiles for the last partial round
+int g_two_pass = 256;  // mpf_set_option("gemm3_two_pass"): N >= this and N % 256 == 0 -> 128 x 256 / 96 x 256 two-pass tiles (0 = off)
+int g_two_pass_rows = 0;   // mpf_set_option("gemm3_two_pass_rows"): 0 = pick 128 or 96 rows per tile by rounds, else force
 
 #ifdef G3_TIMING
 // phase timing (build with -DG3_TIMING; tools/bench_gemm3.py --phases): s_memtime deltas of wave 0 of every
@@ -291,14 +293,14 @@ struct Acc<4, true> {
 // 16-column group (bias + 4 row tiles x 3 operands) are requested together.
 __device__ float g3_const[8] = {0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, 1.f};
 
-template <int NJ>
-__device__ __forceinline__ void g3_epilogue(const G3& p, const Acc<NJ, false>& acc, int lane, int m_wave, int n_wave)
+template <int NJ, int NI = 4, typename AccT = Acc<NJ, false>>
+__device__ __forceinline__ void g3_epilogue(const G3& p, const AccT& acc, int lane, int m_wave, int n_wave)
 {
     const int r16 = lane & 15, g = lane >> 4;
-    int64_t mrow[4];
-    bool mok[4];
+    int64_t mrow[NI];
+    bool mok[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int m = m_wave + i * 16 + r16;
         mok[i] = m < p.M;
         mrow[i] = min(m, p.M - 1);
@@ -309,15 +311,15 @@ __device__ __forceinline__ void g3_epilogue(const G3& p, const Acc<NJ, false>& a
         const bool nok = n < p.N;                    // N % 4 == 0: a quad is inside or outside as a whole
         const int nc = min(n, p.N - 4);
         const float4 bz = *reinterpret_cast<const float4*>(p.bias + nc * p.bias_cm);
-        float4 ci[4], c2[4], gt[4];
+        float4 ci[NI], c2[NI], gt[NI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             ci[i] = *reinterpret_cast<const float4*>(p.cin + mrow[i] * p.ldcin + nc * p.cin_cm);
             c2[i] = *reinterpret_cast<const float4*>(p.cin2 + mrow[i] * p.ldcin2 + nc * p.cin2_cm);
             gt[i] = *reinterpret_cast<const float4*>(p.gate + mrow[i] * p.ldgate + nc * p.gate_cm);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             float4 o = make_float4(acc.v[i][j][0], acc.v[i][j][1], acc.v[i][j][2], acc.v[i][j][3]);
             // same order of additions as before: bias, addend 1, addend 2
             o = make_float4(o.x + bz.x, o.y + bz.y, o.z + bz.z, o.w + bz.w);
@@ -590,6 +592,188 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
     if (tile >= p.ntiles) return;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
     g3_tn_tile<BN, A2>(p, lds, tm * kBM, tn * BN);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 128 x 256 tile as TWO 128-column passes over ONE A image per K step (gemm3_tn2_kernel).
+// Measured on the 128 x 128 kernel: the part of a K step that does not depend on the tile width (staging A: loads, split,
+// LDS stores) is worth ~91 columns of MFMA time.  Here it is paid once per 256 columns inside the same 72 KB of LDS: B
+// stage 0 holds columns 0-127 of the K step, stage 1 columns 128-255; the A fragments are read once and stay in registers
+// for both passes; the stage a pass has released is refilled by DMA at once (three barriers per K step):
+//   barrier a | split + write A(k) | DMA half 1 of k -> stage 1 | wait half 0 of k | barrier b | A loads of k + 2 |
+//   pass 0 (stage 0) | wait half 1 | barrier c | DMA half 0 of k + 1 -> stage 0 | pass 1 (stage 1)
+// Same products in the same order per output element as the 128 x 128 tile: bit-identical results.
+template <int NI, int AKC>
+struct Acc2 {
+    f32x4 v[2][NI][4];
+    bf16x8 fa[3][NI];
+
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void load_a(const unsigned char* lds, int a_base, int lane)
+    {
+        const int r16 = lane & 15, g = lane >> 4;
+        const int a_frag = a_base + g * AKC + (r16 ^ (2 * g)) * 16;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fa[pl][i] = as_frag(*reinterpret_cast<const uint4*>(lds + a_frag + pl * 4 * AKC + i * 256));
+    }
+    template <int H>
+    __device__ __forceinline__ void pass(const unsigned char* lds, int b_base, int lane)
+    {
+        constexpr int BKC = 128 * 16;
+        const int r16 = lane & 15, g = lane >> 4;
+        const int b_frag = b_base + (r16 * 4 + (g ^ ((0 - (r16 >> 2)) & 3))) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x8 fb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fb[pl] = as_frag(*reinterpret_cast<const uint4*>(lds + b_frag + pl * 4 * BKC + j * 1024));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[H][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[2][i], v[H][i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[H][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[2], fa[0][i], v[H][i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[H][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[1][i], v[H][i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[H][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[1][i], v[H][i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[H][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1], fa[0][i], v[H][i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[H][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0], fa[0][i], v[H][i][j], 0, 0, 0);
+        }
+    }
+};
+
+// BM = 128, or 96: M = 43 008 is 336 row blocks of 128 for the chip's 512 workgroup slots, but 448 of 96 (the rows 64-95 of
+// the A tile are staged by the first two waves)
+template <int BM>
+__global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
+{
+    static_assert(BM == 128 || BM == 96, "row blocks of 128 or 96");
+    constexpr int BN = 128;
+    constexpr int NI = BM / 32;                      // 16-row MFMA tiles per wave
+    constexpr int kAKcT = BM * 16;                   // bytes per (plane, k-chunk) of the A image
+    constexpr int kBKc = BN * 16;
+    constexpr int kAbytes = 12 * kAKcT;
+    constexpr int kBstage = 12 * kBKc;
+    constexpr int kPW = kBstage / 1024 / 4;          // 6 DMA pieces per wave and stage
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kAbytes + 2 * kBstage];
+    const int per_xcd = (p.ntiles + 7) >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (tile >= p.ntiles) return;
+    const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int akc = tid & 3;
+    const int arow0 = tid >> 2, arow1 = 64 + (tid >> 2);
+    const int aslot0 = arow0 ^ (2 * akc), aslot1 = arow1 ^ (2 * akc);
+    const float* ap0 = p.a + (int64_t)min(m0 + arow0, p.M - 1) * p.lda + akc * 8;
+    const float* ap1 = p.a + (int64_t)min(m0 + arow1, p.M - 1) * p.lda + akc * 8;
+    const bool second = BM == 128 || wave < 2;       // (wave-uniform) this thread stages a second row
+    unsigned boff[kPW];
+    int bpiece[kPW];
+    {
+        const int nl = lane >> 2, kc = (lane & 3) ^ ((0 - (nl >> 2)) & 3);
+#pragma unroll
+        for (int i = 0; i < kPW; ++i) {
+            const int q = wave + 4 * i;
+            const int pl = q / (BN / 16), nb = (q % (BN / 16)) * 16;
+            boff[i] = (unsigned)(((int64_t)pl * p.plane + (int64_t)(n0 + nb + nl) * p.K + kc * 8) * 2);     // N % 256 == 0: in range
+            bpiece[i] = __builtin_amdgcn_readfirstlane(q * 1024);
+        }
+    }
+    const unsigned lds_b = (unsigned)(uintptr_t)(lds + kAbytes);
+    const unsigned short* bp1 = p.bp + (int64_t)128 * p.K;         // the second column half
+
+    // ONE register set for A, loaded one step ahead (a step is two passes long, i.e. as far ahead in time as the two-step
+    // distance of the 128 x 128 kernel): accumulators 128 + A fragments 48 + B fragments 12 leave no room for a second set
+    float4 ra[4];
+#define G3_LA2(k0)                                                                           \
+    {                                                                                        \
+        ra[0] = *reinterpret_cast<const float4*>(ap0 + (k0));                                \
+        ra[1] = *reinterpret_cast<const float4*>(ap0 + (k0) + 4);                            \
+        if (second) {                                                                        \
+            ra[2] = *reinterpret_cast<const float4*>(ap1 + (k0));                            \
+            ra[3] = *reinterpret_cast<const float4*>(ap1 + (k0) + 4);                        \
+        }                                                                                    \
+    }
+#define G3_DMA2(base, k0, stage)                                                             \
+    {                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < kPW; ++i_)                                   \
+            glds16((base) + (k0), boff[i_], lds_b + (stage) * kBstage + bpiece[i_]);         \
+    }
+#define G3_WRITE2()                                                                          \
+    {                                                                                        \
+        uint4 h, m, l;                                                                       \
+        split8(ra[0], ra[1], &h, &m, &l);                                                    \
+        *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKcT + aslot0 * 16) = h;            \
+        *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKcT + aslot0 * 16) = m;            \
+        *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKcT + aslot0 * 16) = l;            \
+        if (second) {                                                                        \
+            split8(ra[2], ra[3], &h, &m, &l);                                                \
+            *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKcT + aslot1 * 16) = h;        \
+            *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKcT + aslot1 * 16) = m;        \
+            *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKcT + aslot1 * 16) = l;        \
+        }                                                                                    \
+    }
+
+    Acc2<NI, kAKcT> acc;
+    acc.zero();
+    const int a_frag = wr * (BM / 2) * 16;
+    const int b_frag = kAbytes + wc * 64 * 64;
+    const int nk = p.K / kBK;
+    const int klast = (nk - 1) * kBK;
+    G3_LA2(0);
+    __builtin_amdgcn_sched_barrier(0);
+    G3_DMA2(p.bp, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // Vector-memory operations complete in order.  Issue order of a step: [DMA half 1 of k] [A loads of k + 1] [DMA half 0 of
+    // k + 1].  The compiler knows of the A loads only and waits for all of them (vmcnt(0)) before the split, which also
+    // covers half 0 of the step (issued one pass earlier); the wait for half 1 is explicit.
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                                   // a: the A image and stage 1 are free
+        G3_WRITE2();                                       // (waits for the A loads and, with them, for half 0 of this step)
+        __builtin_amdgcn_sched_barrier(0);
+        G3_DMA2(bp1, kt * kBK, 1);
+        __syncthreads();                                   // b
+        G3_LA2(min((kt + 1) * kBK, klast));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(G3_PRIO);
+        acc.load_a(lds, a_frag, lane);
+        acc.template pass<0>(lds, b_frag, lane);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // half 1 has landed (only the A loads are younger)
+        __syncthreads();                                   // c: stage 0 is free, half 1 visible to all
+        G3_DMA2(p.bp, min((kt + 1) * kBK, klast), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(G3_PRIO);
+        acc.template pass<1>(lds, b_frag + kBstage, lane);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef G3_LA2
+#undef G3_DMA2
+#undef G3_WRITE2
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        struct { f32x4 v[NI][4]; } out;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out.v[i][j] = acc.v[h][i][j];
+        g3_epilogue<4, NI>(p, out, lane, m0 + wr * (BM / 2), n0 + h * 128 + wc * 64);
+    }
 }
 
 // A in bf16 (g3_tn_tile<.., ABF>): activations that ARE bf16 (the backbone's feature maps under autocast, the bf16
@@ -949,6 +1133,8 @@ __global__ __launch_bounds__(256) void gemm3_split_grouped_kernel(const MpfSplit
 int mpf::set_gemm3_option(const char* key, int v)
 {
     if (!strcmp(key, "gemm3_mixed_tiles")) { g_mixed = v; return 0; }
+    if (!strcmp(key, "gemm3_two_pass")) { g_two_pass = v; return 0; }
+    if (!strcmp(key, "gemm3_two_pass_rows")) { g_two_pass_rows = v; return 0; }
     if (strcmp(key, "gemm3_ablate") != 0) return 1;
     g_ablate = v;
     return 0;
@@ -975,6 +1161,30 @@ extern "C" int mpf_gemm3_split_grouped(const MpfSplitItem* items_device, int n_i
     hipLaunchKernelGGL(gemm3_split_grouped_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_device,
                        n_items);
     return mpf::check(hipGetLastError(), "mpf_gemm3_split_grouped");
+}
+
+// 128 x 256 / 96 x 256 tiles (gemm3_tn2_kernel: two 128-column passes over one A image per K step) for fp32 A without the
+// addend rows and N a multiple of 256; row blocks of 96 when they need fewer (rounds x rows) on the chip's workgroup slots
+// (M = 43 008, N = 256: 448 tiles instead of 336 for 512 slots).  Starts the launch-log record itself; false = not taken.
+static bool g3_launch_two_pass(G3& p, hipStream_t st)
+{
+    if (g_two_pass <= 0 || p.N % 256 != 0 || p.N < g_two_pass) return false;
+    static int slots2 = 0;
+    if (!slots2) {
+        int dev = 0, cus = 0;
+        slots2 = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? 2 * cus : 512;
+    }
+    p.tiles_n = p.N / 256;
+    const int t128 = ((p.M + 127) / 128) * p.tiles_n, t96 = ((p.M + 95) / 96) * p.tiles_n;
+    const double c128 = (double)((t128 + slots2 - 1) / slots2) * 128.0, c96 = (double)((t96 + slots2 - 1) / slots2) * 96.0;
+    const bool use96r = g_two_pass_rows == 96 || (g_two_pass_rows == 0 && c96 < c128);
+    p.ntiles = use96r ? t96 : t128;
+    p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
+    mpf::prof_begin(st);
+    mpf::set_kernel(use96r ? "gemm3_tn_kernel<96x256>" : "gemm3_tn_kernel<128x256>");
+    if (use96r) hipLaunchKernelGGL(gemm3_tn2_kernel<96>, dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
+    else hipLaunchKernelGGL(gemm3_tn2_kernel<128>, dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
+    return true;
 }
 
 extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2_rows, const void* b_planes,
@@ -1014,6 +1224,10 @@ extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2
     p.tiles_n = use96 ? (N + 95) / 96 : (N + 127) / 128;
     p.ntiles = tiles_m * p.tiles_n;
     p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
+    if (!a2 && g3_launch_two_pass(p, st)) {
+        mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + 6.0 * (double)N * K, 2.0 * M * (double)N * K);
+        return mpf::check(hipGetLastError(), "mpf_gemm3_tn");
+    }
     // tail effect: when the last round of 128 x 128 tiles would fill at most half of the chip's workgroup slots, its row
     // blocks are cut into 128 x 64 tiles instead (gemm3_tn_mixed_kernel)
     if (!use96 && N % 64 == 0 && g_mixed) {
@@ -1090,6 +1304,10 @@ extern "C" int mpf_gemm3_tn_ex(const void* a, int a_dtype, int64_t lda, const vo
     const bool use96 = waste96 < waste128;
     p.tiles_n = use96 ? (N + 95) / 96 : (N + 127) / 128;
     p.ntiles = tiles_m * p.tiles_n;
+    if (a_dtype == MPF_F32 && g3_launch_two_pass(p, st)) {
+        mpf::prof_end(mpf_last_kernel(), st, 4.0 * (double)M * K + 2.0 * (double)M * N + 6.0 * (double)N * K, 2.0 * M * (double)N * K);
+        return mpf::check(hipGetLastError(), "mpf_gemm3_tn_ex");
+    }
     const dim3 grid(((p.ntiles + 7) / 8) * 8);
     mpf::prof_begin(st);
     if (a_dtype == MPF_BF16) {

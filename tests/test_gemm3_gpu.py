@@ -76,16 +76,52 @@ def test_gemm3_tn_mixed_tiles_bit_equal(N, K):
     b = torch.randn(N, device=dev)
     cin = torch.randn(M, N, device=dev)
     planes = split_weight(w)
-    got = gemm3(a, planes, b, cin=cin, relu=True)
-    assert _lib.last_kernel() == "gemm3_tn_kernel<128+64>", _lib.last_kernel()
-    _lib.set_option("gemm3_mixed_tiles", 0)
+    _lib.set_option("gemm3_two_pass", 0)          # (N % 256 == 0 takes the 128 x 256 tiles by default)
     try:
-        want = gemm3(a, planes, b, cin=cin, relu=True)
-        assert _lib.last_kernel() == "gemm3_tn_kernel<128>"
+        got = gemm3(a, planes, b, cin=cin, relu=True)
+        assert _lib.last_kernel() == "gemm3_tn_kernel<128+64>", _lib.last_kernel()
+        _lib.set_option("gemm3_mixed_tiles", 0)
+        try:
+            want = gemm3(a, planes, b, cin=cin, relu=True)
+            assert _lib.last_kernel() == "gemm3_tn_kernel<128>"
+        finally:
+            _lib.set_option("gemm3_mixed_tiles", 1)
     finally:
-        _lib.set_option("gemm3_mixed_tiles", 1)
+        _lib.set_option("gemm3_two_pass", 256)
     assert torch.equal(got, want)
     ref = (a.double() @ w.double().t() + b.double() + cin.double()).relu()
+    assert float((got.double() - ref).abs().max()) <= 4e-6 * (float(ref.abs().max()) + 1.0) * max(1.0, (K / 256) ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 64), (43008, 1024, 256), (4099, 512, 1024), (128, 256, 32)])
+def test_gemm3_tn_two_pass_tiles_bit_equal(M, N, K):
+    """The 128 x 256 tile (two 128-column passes over one A image per K step, gemm3_tn2_kernel) does the same products in
+    the same order per output element as the 128 x 128 tile: identical bits, with every epilogue operand and a ragged
+    last row block."""
+    from mp_former_amd import _lib
+    from mp_former_amd.gemm3 import gemm3, split_weight
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev)
+    cin = torch.randn(M, N, device=dev)
+    gate = torch.randn(M, N, device=dev)
+    planes = split_weight(w)
+    _lib.set_option("gemm3_two_pass", 0)
+    want = gemm3(a, planes, b, cin=cin, gate=gate, relu=True)
+    assert "x256" not in _lib.last_kernel()
+    _lib.set_option("gemm3_two_pass", 256)
+    try:
+        for rows in (128, 96):          # 96-row blocks: the first two waves stage rows 64-95 of the A tile
+            _lib.set_option("gemm3_two_pass_rows", rows)
+            got = gemm3(a, planes, b, cin=cin, gate=gate, relu=True)
+            assert _lib.last_kernel() == f"gemm3_tn_kernel<{rows}x256>", _lib.last_kernel()
+            assert torch.equal(got, want), rows
+    finally:
+        _lib.set_option("gemm3_two_pass_rows", 0)
+        _lib.set_option("gemm3_two_pass", 256)
+    ref = torch.where(gate > 0, (a.double() @ w.double().t() + b.double() + cin.double()).relu(), torch.zeros((), dtype=torch.float64, device=dev))
     assert float((got.double() - ref).abs().max()) <= 4e-6 * (float(ref.abs().max()) + 1.0) * max(1.0, (K / 256) ** 0.5)
 
 
@@ -121,7 +157,7 @@ def test_gemm3_tn_bf16_operand_and_result(M, N, K, adt, cdt):
     cin = torch.randn(M, N, device=dev)
     planes = split_weight(w)
     got = gemm3_ex(a, planes, b, cin=cin, relu=True, out_dtype=T[cdt])
-    assert _lib.last_kernel() == ("gemm3_tn_kernel<a16>" if adt == "bf16" else "gemm3_tn_kernel<c16>"), _lib.last_kernel()
+    assert _lib.last_kernel() in (("gemm3_tn_kernel<a16>",) if adt == "bf16" else ("gemm3_tn_kernel<c16>", "gemm3_tn_kernel<96x256>", "gemm3_tn_kernel<128x256>")), _lib.last_kernel()
     ref = (a.double() @ w.double().t() + b.double() + cin.double()).relu()
     full = gemm3(a.float(), planes, b, cin=cin, relu=True)          # the six-product kernel on the same values
     scale = float(ref.abs().max()) + 1.0
