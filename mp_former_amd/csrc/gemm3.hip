@@ -655,10 +655,13 @@ struct Acc2 {
 
 // BM = 128, or 96: M = 43 008 is 336 row blocks of 128 for the chip's 512 workgroup slots, but 448 of 96 (the rows 64-95 of
 // the A tile are staged by the first two waves)
-template <int BM>
+// CV: the 3x3 convolution mode of g3_tn_tile (K step kt belongs to tap kt / (Cin / 32); rows shifted by the tap, taps off
+// the image zeroed before the split)
+template <int BM, bool CV = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
 {
     static_assert(BM == 128 || BM == 96, "row blocks of 128 or 96");
+    static_assert(!CV || BM == 128, "convolution mode: 128-row blocks");
     constexpr int BN = 128;
     constexpr int NI = BM / 32;                      // 16-row MFMA tiles per wave
     constexpr int kAKcT = BM * 16;                   // bytes per (plane, k-chunk) of the A image
@@ -681,6 +684,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
     const float* ap0 = p.a + (int64_t)min(m0 + arow0, p.M - 1) * p.lda + akc * 8;
     const float* ap1 = p.a + (int64_t)min(m0 + arow1, p.M - 1) * p.lda + akc * 8;
     const bool second = BM == 128 || wave < 2;       // (wave-uniform) this thread stages a second row
+    int cy0 = 0, cx0 = 0, cy1 = 0, cx1 = 0, mr0 = 0, mr1 = 0, vm = 3;
+    if constexpr (CV) {
+        mr0 = min(m0 + arow0, p.M - 1); mr1 = min(m0 + arow1, p.M - 1);
+        cx0 = mr0 % p.cv_W; cy0 = (mr0 / p.cv_W) % p.cv_H;
+        cx1 = mr1 % p.cv_W; cy1 = (mr1 / p.cv_W) % p.cv_H;
+    }
+    (void)cy0; (void)cx0; (void)cy1; (void)cx1; (void)mr0; (void)mr1; (void)vm;
     unsigned boff[kPW];
     int bpiece[kPW];
     {
@@ -700,7 +710,20 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
     // distance of the 128 x 128 kernel): accumulators 128 + A fragments 48 + B fragments 12 leave no room for a second set
     float4 ra[4];
 #define G3_LA2(k0)                                                                           \
-    {                                                                                        \
+    if constexpr (CV) {                                                                      \
+        const int tap_ = (k0) / p.cv_cin, kk_ = (k0) - tap_ * p.cv_cin;                      \
+        const int dy_ = (tap_ / 3 - 1) * p.cv_sign, dx_ = (tap_ % 3 - 1) * p.cv_sign;        \
+        const int sh_ = dy_ * p.cv_W + dx_;                                                  \
+        const bool v0_ = (unsigned)(cy0 + dy_) < (unsigned)p.cv_H && (unsigned)(cx0 + dx_) < (unsigned)p.cv_W; \
+        const bool v1_ = (unsigned)(cy1 + dy_) < (unsigned)p.cv_H && (unsigned)(cx1 + dx_) < (unsigned)p.cv_W; \
+        const unsigned o0_ = (unsigned)(min(max(mr0 + sh_, 0), p.M - 1) * (int)p.lda + akc * 8 + kk_); \
+        const unsigned o1_ = (unsigned)(min(max(mr1 + sh_, 0), p.M - 1) * (int)p.lda + akc * 8 + kk_); \
+        ra[0] = *reinterpret_cast<const float4*>(p.a + o0_);                                 \
+        ra[1] = *reinterpret_cast<const float4*>(p.a + o0_ + 4);                             \
+        ra[2] = *reinterpret_cast<const float4*>(p.a + o1_);                                 \
+        ra[3] = *reinterpret_cast<const float4*>(p.a + o1_ + 4);                             \
+        vm = (v0_ ? 1 : 0) | (v1_ ? 2 : 0);                                                  \
+    } else {                                                                                 \
         ra[0] = *reinterpret_cast<const float4*>(ap0 + (k0));                                \
         ra[1] = *reinterpret_cast<const float4*>(ap0 + (k0) + 4);                            \
         if (second) {                                                                        \
@@ -716,12 +739,20 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
 #define G3_WRITE2()                                                                          \
     {                                                                                        \
         uint4 h, m, l;                                                                       \
-        split8(ra[0], ra[1], &h, &m, &l);                                                    \
+        float4 w0_ = ra[0], w1_ = ra[1], w2_ = ra[2], w3_ = ra[3];                           \
+        if constexpr (CV) {                                                                  \
+            const float s0_ = (vm & 1) ? 1.f : 0.f, s1_ = (vm & 2) ? 1.f : 0.f;              \
+            w0_ = make_float4(w0_.x * s0_, w0_.y * s0_, w0_.z * s0_, w0_.w * s0_);           \
+            w1_ = make_float4(w1_.x * s0_, w1_.y * s0_, w1_.z * s0_, w1_.w * s0_);           \
+            w2_ = make_float4(w2_.x * s1_, w2_.y * s1_, w2_.z * s1_, w2_.w * s1_);           \
+            w3_ = make_float4(w3_.x * s1_, w3_.y * s1_, w3_.z * s1_, w3_.w * s1_);           \
+        }                                                                                    \
+        split8(w0_, w1_, &h, &m, &l);                                                        \
         *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKcT + aslot0 * 16) = h;            \
         *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKcT + aslot0 * 16) = m;            \
         *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKcT + aslot0 * 16) = l;            \
         if (second) {                                                                        \
-            split8(ra[2], ra[3], &h, &m, &l);                                                \
+            split8(w2_, w3_, &h, &m, &l);                                                    \
             *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKcT + aslot1 * 16) = h;        \
             *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKcT + aslot1 * 16) = m;        \
             *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKcT + aslot1 * 16) = l;        \
@@ -1352,6 +1383,11 @@ extern "C" int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const flo
     p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
     mpf::prof_begin(st);
     mpf::set_kernel("gemm3_conv_kernel");
+    if (g_two_pass > 0 && Cout % 256 == 0) {       // 128 x 256 tiles, two passes over one A image per K step
+        p.tiles_n = Cout / 256;
+        p.ntiles = ((p.M + kBM - 1) / kBM) * p.tiles_n;
+        hipLaunchKernelGGL((gemm3_tn2_kernel<128, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
+    } else
     hipLaunchKernelGGL(gemm3_conv_kernel, dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
     mpf::prof_end("gemm3_conv_kernel", st, 4.0 * ((double)p.M * Cin + (double)p.M * Cout) + 6.0 * (double)Cout * p.K, 2.0 * p.M * (double)Cout * p.K);
     return mpf::check(hipGetLastError(), "mpf_gemm3_conv3x3");
