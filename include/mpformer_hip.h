@@ -120,6 +120,10 @@ int mpf_msda_backward_ws(const void* value, const int64_t* host_spatial_shapes,
  *   mpf_set_option("msda_fwd_variant", v): 0 = auto, 1 = generic kernel, 2 = tiled V4 (8 lanes x 16 B per row), 3 = tiled V1 (32 lanes x 4 B),
  *                                           4 = tiled V2 (16 lanes x 8 B)
  *   mpf_set_option("msda_bwd_variant", v): same numbering
+ *   mpf_set_option("gemm3_two_pass", n): mpf_gemm3_tn(_ex) / mpf_gemm3_conv3x3 use the 128 x 256 / 96 x 256 two-pass tile when the
+ *                                           output width is a multiple of 256 and >= n (default 256; 0 = the 128 x 128 tiles only;
+ *                                           same bits either way); "gemm3_two_pass_rows" 0 / 128 / 96 = rows per tile (0 = by rounds);
+ *                                           "gemm3_mixed_tiles" 1 / 0 = 128 x 64 tiles for the last partial round of the one-pass kernel
  * Returns 0, or MPF_E_SHAPE for an unknown key/value.
  */
 int mpf_set_option(const char* key, int value);
