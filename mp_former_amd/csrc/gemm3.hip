@@ -784,7 +784,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
         acc.load_a(lds, a_frag, lane);
         acc.template pass<0>(lds, b_frag, lane);
         __builtin_amdgcn_s_setprio(0);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // half 1 has landed (only the A loads are younger)
+        // half 1 has landed: only this step's A loads are younger (4 of them, 2 in the waves that stage one row of a 96-row tile)
+        if (second) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __syncthreads();                                   // c: stage 0 is free, half 1 visible to all
         G3_DMA2(p.bp, min((kt + 1) * kBK, klast), 0);
         __builtin_amdgcn_sched_barrier(0);
