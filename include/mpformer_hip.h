@@ -129,6 +129,16 @@ int mpf_msda_backward_ws(const void* value, const int64_t* host_spatial_shapes,
 int mpf_set_option(const char* key, int value);
 /* Name of the kernel the most recent native call in this process launched (any thread). */
 const char* mpf_last_kernel(void);
+/*
+ * Tests only: which route the spatially blocked MSDA kernels (mp_former_amd/csrc/msda_block.hip) took since
+ * mpf_set_option("msda_stats", 1) / the last reset.  Unlike every other entry point this one SYNCHRONISES the device.
+ *   out[0] forward: (workgroup, level) boxes staged in LDS     out[1] forward: L2-gather fallback (box > region)
+ *   out[2] push: boxes staged in LDS                           out[3] push: L2-gather fallback
+ *   out[4] push: workgroups on direct-mapped tile counters     out[5] push: workgroups on the LDS hash
+ *   out[6] spill: entries applied with atomics (run overflow)
+ *   out[7] pull: non-empty tiles split over several waves      out[8] pull: non-empty single-wave tiles
+ */
+int mpf_msda_stats(unsigned long long* out, int n, int reset);
 
 /*
  * Bilinear point sampling: out[i, p] = bilinear(src[rows[i]], coords[coord_rows[i], p]) with zero

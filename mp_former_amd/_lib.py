@@ -25,6 +25,7 @@ SIGNATURES = {
     "mpf_last_error": (ctypes.c_char_p, []),
     "mpf_last_kernel": (ctypes.c_char_p, []),
     "mpf_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
+    "mpf_msda_stats": (_c_int, [ctypes.POINTER(ctypes.c_ulonglong), _c_int, _c_int]),
     "mpf_profile_enable": (_c_int, [_c_int]),
     "mpf_profile_get_flops": (_c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]),
     "mpf_profile_get": (_c_int, [ctypes.c_char_p, ctypes.POINTER(_c_int), ctypes.POINTER(ctypes.c_double),
@@ -165,6 +166,14 @@ def check(code, what):
 
 def set_option(key, value):
     check(lib().mpf_set_option(key.encode(), int(value)), f"mpf_set_option({key})")
+
+
+def msda_stats(reset=True):
+    """Route counters of the blocked MSDA kernels (tests; enable with set_option("msda_stats", 1)) -> dict."""
+    out = (ctypes.c_ulonglong * 9)()
+    check(lib().mpf_msda_stats(out, 9, 1 if reset else 0), "mpf_msda_stats")
+    keys = ("fwd_lds", "fwd_gather", "push_lds", "push_gather", "push_direct", "push_hash", "spill_entries", "pull_split", "pull_single")
+    return dict(zip(keys, (int(v) for v in out)))
 
 
 def last_kernel():

@@ -257,7 +257,8 @@ template <int NL, bool RAW>
 __global__ __launch_bounds__(kT) void msda_fwd_block_kernel(const float* __restrict__ value, const float* loc_,
                                                             const float* attn_, float* __restrict__ out, GeomB g,
                                                             int nblocks, int region_cap, unsigned value_bytes,
-                                                            const float* __restrict__ raw, const float* __restrict__ ref)
+                                                            const float* __restrict__ raw, const float* __restrict__ ref,
+                                                            unsigned* __restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4* s_f = reinterpret_cast<float4*>(smem);
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(kT) void msda_fwd_block_kernel(const float* __restr
         const bool any = xmax >= xmin;
         const int rw = xmax - xmin + 1, rows = any ? rw * (ymax - ymin + 1) : 0;
         const bool lds_path = rows <= region_cap;     // wave-uniform (also when the level has no sample at all)
+        if (stats && tid == 0 && rows > 0) atomicAdd(&stats[lds_path ? 0 : 1], 1u);
         {
             const Dec& d = dec[l];
             const float hx = 1.f - d.lx, hy = 1.f - d.ly, a = d.in ? at[l] : 0.f;
@@ -449,7 +451,8 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
     const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
     const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
     float* __restrict__ grad_raw, int* __restrict__ tile_count, unsigned* __restrict__ entries,
-    int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB g, int nblocks, int region_cap, unsigned value_bytes, int ablate, unsigned long long* __restrict__ dbg)
+    int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB g, int nblocks, int region_cap, unsigned value_bytes, int ablate, unsigned long long* __restrict__ dbg,
+    unsigned* __restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* s_bb = reinterpret_cast<int*>(smem);
@@ -579,6 +582,7 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
         tof[l + 1] = tof[l] + (any ? tbw[l] * ((ymax >> 2) - tby[l] + 1) : 0);
     }
     const bool direct = tof[NL] <= kSlots;             // workgroup-uniform
+    if (stats && tid == 0) atomicAdd(&stats[direct ? 4 : 5], 1u);
     int* s_cnt1 = s_cnt;                               // [kSlots + 1]: the last one is the dummy
     if (direct) {
         int ret[NL][4];
@@ -665,6 +669,7 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
         int xmin, ymin, rw, rows;
         bool lds_path;
         box(l, xmin, ymin, rw, rows, lds_path);
+        if (stats && tid == 0 && rows > 0) atomicAdd(&stats[lds_path ? 2 : 3], 1u);
         if (l + 1 < NL) fetch(l + 1);                  // next box: in flight while this level is reduced
         const bool in = (in_mask >> l) & 1;
         const int H = g.H[l], W = g.W[l];
@@ -794,7 +799,7 @@ template <int NL>
 __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
     const int* __restrict__ tile_count, const unsigned* __restrict__ entries, float* __restrict__ grad_value, GeomB g, int nwg,
-    unsigned loc_bytes, unsigned go_bytes)
+    unsigned loc_bytes, unsigned go_bytes, unsigned* __restrict__ stats)
 {
     __shared__ float s_red[kWP - 1][8][64];            // partial accumulators of the waves with part > 0
     __shared__ float4 s_rec[kWP][64];                   // per wave: the 64 sample records of the current chunk
@@ -907,6 +912,7 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
             e_cur = e_nxt; e_nxt = e_nn; la = la_n;
         }
     }
+    if (stats && lane == 0 && live && part == 0 && n > 0) atomicAdd(&stats[wpt > 1 ? 7 : 8], 1u);
     if (wpt > 1) {
         // tiles of coarse levels are split over the waves of the workgroup: sum the partial tiles
         if (part > 0) {
@@ -939,11 +945,13 @@ __global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
 template <int NL>
 __global__ __launch_bounds__(kT) void msda_bwd_spill_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
                                                             const float* __restrict__ grad_out, const int* __restrict__ ovf_count,
-                                                            const uint2* __restrict__ ovf, float* __restrict__ grad_value, GeomB g)
+                                                            const uint2* __restrict__ ovf, float* __restrict__ grad_value, GeomB g,
+                                                            unsigned* __restrict__ stats)
 {
     constexpr int LP = NL * kP;
     const int n = *ovf_count;
     const int c = threadIdx.x & 31;
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[6], (unsigned)n);
     for (int i = blockIdx.x * (kT / 32) + (threadIdx.x >> 5); i < n; i += gridDim.x * (kT / 32)) {
         const uint2 o = ovf[i];
         const int key = (int)o.x, q = (int)(o.y >> 2), p = (int)(o.y & 3);
@@ -981,6 +989,14 @@ int g_block_disable = 0;
 int g_fuse_prep = 1;        // mpf_set_option("msda_fuse_prep"): softmax / location arithmetic inside the forward kernel
 unsigned long long* g_dbg = nullptr;   // benchmarking only: s_memtime phase stamps of the push kernel, [workgroup][16]
 int g_push_ablate = 0;       // benchmarking only: 1 = no tile entries, 2 = no reduction, 4 = no box staging
+// tests only (mpf_set_option("msda_stats", 1) / mpf_msda_stats): which route every (workgroup, level) took.
+//   [0] forward: boxes staged in LDS   [1] forward: L2-gather fallback (box larger than the region)
+//   [2] push: boxes staged in LDS      [3] push: L2-gather fallback
+//   [4] push: workgroups with the direct-mapped tile counters   [5] push: workgroups on the compare-and-swap hash
+//   [6] spill: entries applied with atomics (run overflow)
+//   [7] pull: non-empty tiles split over several waves (merged through LDS)   [8] pull: non-empty single-wave tiles
+constexpr int kNStats = 16;
+unsigned* g_stats = nullptr;
 
 bool build_geom(GeomB& g, const int64_t* hs, int N, int S, int M, int L, int Lq)
 {
@@ -1074,10 +1090,10 @@ hipError_t launch_fwd(const float* value, const float* loc, const float* attn, f
     const unsigned vb = (unsigned)((size_t)g.N * g.S * g.M * kD * 4);
     if (raw)
         hipLaunchKernelGGL((msda_fwd_block_kernel<NL, true>), dim3(grid), dim3(kT), lds, st, value, loc, attn, out, g, nblocks,
-                           g_region_rows, vb, raw, ref);
+                           g_region_rows, vb, raw, ref, g_stats);
     else
         hipLaunchKernelGGL((msda_fwd_block_kernel<NL, false>), dim3(grid), dim3(kT), lds, st, value, loc, attn, out, g, nblocks,
-                           g_region_rows, vb, raw, ref);
+                           g_region_rows, vb, raw, ref, g_stats);
     return hipGetLastError();
 }
 
@@ -1117,15 +1133,15 @@ hipError_t launch_bwd(const float* value, const float* loc, const float* attn, c
     const double esz = 4.0;
     mpf::prof_begin(st);
     hipLaunchKernelGGL(msda_bwd_push_block_kernel<NL>, dim3(grid), dim3(kT), lds, st, value, loc, attn, go, gl, ga, graw, tile_count,
-                       entries, ovf_count, ovf, g, nblocks, g_push_rows, (unsigned)((size_t)g.N * g.S * g.M * kD * 4), g_push_ablate, g_dbg);
+                       entries, ovf_count, ovf, g, nblocks, g_push_rows, (unsigned)((size_t)g.N * g.S * g.M * kD * 4), g_push_ablate, g_dbg, g_stats);
     mpf::prof_end("msda_bwd_push_block_kernel", st,
                   esz * ((double)g.N * g.S * g.M * kD + (double)g.N * g.Lq * g.M * LP * 6 + (double)g.N * g.Lq * g.M * kD));
     const int nwg = g.N * g.M * g.wg_per_bm;
     mpf::prof_begin(st);
     hipLaunchKernelGGL(msda_bwd_pull_mfma_kernel<NL>, dim3(((nwg + 7) / 8) * 8), dim3(kTP), 0, st, loc, attn, go, tile_count, entries,
-                       gv, g, nwg, (unsigned)((size_t)g.N * g.Lq * g.M * LP * 8), (unsigned)((size_t)g.N * g.Lq * g.M * kD * 4));
+                       gv, g, nwg, (unsigned)((size_t)g.N * g.Lq * g.M * LP * 8), (unsigned)((size_t)g.N * g.Lq * g.M * kD * 4), g_stats);
     mpf::prof_end("msda_bwd_pull_mfma_kernel", st, esz * ((double)g.N * g.Lq * g.M * kD + (double)g.N * g.S * g.M * kD));
-    hipLaunchKernelGGL(msda_bwd_spill_kernel<NL>, dim3(64), dim3(kT), 0, st, loc, attn, go, ovf_count, ovf, gv, g);
+    hipLaunchKernelGGL(msda_bwd_spill_kernel<NL>, dim3(64), dim3(kT), 0, st, loc, attn, go, ovf_count, ovf, gv, g, g_stats);
     return hipGetLastError();
 }
 
@@ -1134,6 +1150,21 @@ hipError_t launch_bwd(const float* value, const float* loc, const float* attn, c
 extern "C" int mpf_debug_set_buffer(void* p)
 {
     g_dbg = (unsigned long long*)p;
+    return 0;
+}
+
+// tests only: route counters of the blocked kernels (see g_stats).  Synchronises the device.
+extern "C" int mpf_msda_stats(unsigned long long* out, int n, int reset)
+{
+    if (!out || n < 1) return MPF_E_NULL;
+    for (int i = 0; i < n; ++i) out[i] = 0;
+    if (!g_stats) return mpf::fail(MPF_E_SHAPE, "mpf_msda_stats: enable with mpf_set_option(\"msda_stats\", 1) first");
+    unsigned h[kNStats];
+    hipError_t err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipMemcpy(h, g_stats, sizeof(h), hipMemcpyDeviceToHost);
+    if (err == hipSuccess && reset) err = hipMemset(g_stats, 0, sizeof(h));
+    if (err != hipSuccess) return mpf::check(err, "mpf_msda_stats");
+    for (int i = 0; i < n && i < kNStats; ++i) out[i] = h[i];
     return 0;
 }
 
@@ -1208,6 +1239,17 @@ int set_block_option(const char* key, int v)
     if (!strcmp(key, "msda_block_disable")) { g_block_disable = v; return 0; }
     if (!strcmp(key, "msda_fuse_prep")) { g_fuse_prep = v; return 0; }
     if (!strcmp(key, "msda_push_ablate2")) { g_push_ablate = v; return 0; }
+    if (!strcmp(key, "msda_stats")) {
+        if (v && !g_stats) {
+            if (hipMalloc((void**)&g_stats, kNStats * sizeof(unsigned)) != hipSuccess) { g_stats = nullptr; return MPF_E_SHAPE; }
+            (void)hipMemset(g_stats, 0, kNStats * sizeof(unsigned));
+        } else if (!v && g_stats) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(g_stats);
+            g_stats = nullptr;
+        }
+        return 0;
+    }
     return 1;
 }
 
