@@ -787,6 +787,40 @@ int mpf_upsample2x_cl_backward(const float* gy, int64_t gy_bs, int N, int Ht, in
                                void* stream);
 
 /*
+ * Fused mask product + point-sampled matching cost / loss planes (mp_former_amd/csrc/mask_fused.hip).
+ * Replaces   outputs_mask = einsum("bqc,bchw->bqhw", mask_embed, mask_features)   (mask2former_transformer_decoder.py:1865-1870)
+ * together with its only consumers on the training path: the matcher's point samples (matcher.py:95-147) and the
+ * criterion's per-pair planes (criterion.py:141-191).  The [N, Qtot, H/4, W/4] maps are never formed.
+ *   embed     bf16 mask embeddings, any row addressing: a row is 256 contiguous bf16 at `embed + offset`
+ *   features  bf16 channel-last mask features [N][h*w][256] (image stride feat_img_stride elements)
+ *
+ * mpf_match_cost_fused: cost[g][q][t] (fp32, [G][Q][Tmax]; entries t >= t_count[g] untouched) of matcher.py:105-147
+ *   (mask + dice part) for G groups = (decoder output, image): queries q = 0..Q-1 of group g are the rows
+ *   embed + embed_first[g] + q * embed_row_stride; coords [G][P][2] (x, y) in [0,1]; tsamp [tsamp_rows][P] = the
+ *   ground-truth masks sampled at the group's points, rows t_first[g] .. + t_count[g].  Tmax <= 128.  Deterministic.
+ * mpf_pair_planes_forward: out[slot][h*w] (bf16) = embed row of slot . features of its image, for the slots
+ *   slot_first[b] .. + slot_count[b] of image b; the row of a slot is embed + row_off[pair_of_slot ? pair_of_slot[slot] : slot].
+ *   All index arrays are DEVICE memory (row_off is written by the device assignment solver).  h*w % 4 == 0.
+ * mpf_pair_planes_backward: from grad_planes [total_slots][h*w] bf16:
+ *   d_features[b][px][c] = sum_slot grad[slot][px] * embed_row(slot)[c]  (bf16, fully written; may be NULL) and
+ *   d_embed (same row addressing as embed; dtype MPF_BF16 / MPF_F32; only paired rows are written; may be NULL)
+ *   = sum_px grad[slot][px] * features[b][px][:]  (pixel-range partial sums reduced in a fixed order).  h*w % 128 == 0.
+ */
+size_t mpf_match_cost_fused_workspace_bytes(int G, int Q, int Tmax, int P, int tsamp_rows);
+int mpf_match_cost_fused(const void* embed, const int64_t* embed_first, int64_t embed_row_stride, const void* features,
+                         int64_t feat_img_stride, const int32_t* group_image, int h, int w, int channels, const float* coords,
+                         const float* tsamp, int tsamp_rows, const int32_t* t_first, const int32_t* t_count, float* cost, int G,
+                         int Q, int Tmax, int P, float w_mask, float w_dice, void* workspace, size_t workspace_bytes, void* stream);
+int mpf_pair_planes_forward(const void* embed, const int64_t* row_off, const int32_t* pair_of_slot, const int32_t* slot_first,
+                            const int32_t* slot_count, const void* features, int64_t feat_img_stride, void* out, int N, int HW,
+                            int channels, void* stream);
+size_t mpf_pair_planes_backward_workspace_bytes(int N, int HW, int total_slots, int max_count);
+int mpf_pair_planes_backward(const void* grad_planes, const void* embed, const int64_t* row_off, const int32_t* pair_of_slot,
+                             const int32_t* slot_first, const int32_t* slot_count, const void* features, int64_t feat_img_stride,
+                             void* d_features, int64_t dfeat_img_stride, void* d_embed, int d_embed_dtype, int N, int HW, int channels,
+                             int total_slots, int max_count, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Launch profiler.  While enabled, every kernel launch of this library is bracketed by two HIP
  * events recorded on the launch stream (kernel only: memsets and host work are outside the
  * bracket).  mpf_profile_enable(on) clears the log.  mpf_profile_get() waits for the logged events

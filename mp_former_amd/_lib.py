@@ -25,6 +25,14 @@ SIGNATURES = {
     "mpf_last_error": (ctypes.c_char_p, []),
     "mpf_last_kernel": (ctypes.c_char_p, []),
     "mpf_set_option": (_c_int, [ctypes.c_char_p, _c_int]),
+    "mpf_match_cost_fused_workspace_bytes": (ctypes.c_size_t, [_c_int] * 5),
+    "mpf_match_cost_fused": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int,
+                                      _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, ctypes.c_float, ctypes.c_float, _c_vp,
+                                      ctypes.c_size_t, _c_vp]),
+    "mpf_pair_planes_forward": (_c_int, [_c_vp] * 6 + [ctypes.c_int64, _c_vp, _c_int, _c_int, _c_int, _c_vp]),
+    "mpf_pair_planes_backward_workspace_bytes": (ctypes.c_size_t, [_c_int] * 4),
+    "mpf_pair_planes_backward": (_c_int, [_c_vp] * 7 + [ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                          _c_int, _c_vp, ctypes.c_size_t, _c_vp]),
     "mpf_msda_stats": (_c_int, [ctypes.POINTER(ctypes.c_ulonglong), _c_int, _c_int]),
     "mpf_profile_enable": (_c_int, [_c_int]),
     "mpf_profile_get_flops": (_c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]),

@@ -27,7 +27,8 @@ from .dist import distributed, global_num_masks, global_num_masks_device
 from .matcher import GTMasks
 from ._h2d import upload
 from .lsa import MAX_DIM as LSA_MAX_DIM, lsa_assign
-from .point_sample import MapSet, MaskLossSums, MaskLossSumsCompact, sample_select_uncertain
+from .mask_fused import FactoredMasks, PairPlanes
+from .point_sample import MapSet, MaskLossSums, MaskLossSumsPlanes, sample_select_uncertain
 
 
 def strided_stack(ts):
@@ -174,32 +175,16 @@ class SetCriterion(nn.Module):
         return (nll * w).flatten(1).sum(1) / w.flatten(1).sum(1)
 
     @staticmethod
-    def _compact_layout(ms, bi, N):
-        """The maps are one batched product of (mask_embed, mask_features) (transformer_decoder.mask_product left the factors on
-        its result): lay the gradient planes of the pairs out back to back, image by image (each image's block padded to 16
-        rows), so that the loss backward can contract only those rows (point_sample.MaskLossSumsCompact).
-        -> (plane offsets of the pairs [n], (slots per image, rows per image, offset of the first row), (me, mf)) or None."""
-        if os.environ.get("MPF_COMPACT_MASK_GRAD", "1") != "1" or len(ms.bases) != 1:
-            return None
-        root = ms.bases[0]._base
-        fac = getattr(root, "_mpf_factors", None) if root is not None else None
-        if fac is None:
-            return None
-        me, mf = fac
-        base = ms.bases[0]
-        if not (me.dim() == 3 and mf.dim() == 4 and me.dtype == mf.dtype == ms.dtype and base.is_contiguous()
-                and tuple(base.shape) == (N, me.shape[1], mf.shape[2], mf.shape[3]) and (me.requires_grad or mf.requires_grad)):
-            return None
-        hw = ms.h * ms.w
+    def _slot_layout(bi, N):
+        """Planes of the step's pairs back to back, image by image: -> (slot of every pair, first slot / count per image)."""
         slot = np.zeros(len(bi), dtype=np.int64)
-        slots, first = [], 0
+        first, count, at = [], [], 0
         for b in range(N):
             idx = np.flatnonzero(bi == b)
-            slot[idx] = first + np.arange(len(idx))
-            npad = (len(idx) + 15) // 16 * 16
-            slots.append((first, len(idx), npad))
-            first += npad
-        return slot * hw, (slots, int(base.shape[1]), int(ms.t_off[0])), (me, mf)
+            slot[idx] = at + np.arange(len(idx))
+            first.append(at); count.append(len(idx))
+            at += len(idx)
+        return slot, np.asarray(first, dtype=np.int32), np.asarray(count, dtype=np.int32)
 
     def forward(self, outputs, targets):
         dn_out = outputs["dn_out"]
@@ -225,7 +210,15 @@ class SetCriterion(nn.Module):
         gt = GTMasks(targets)
         # every prediction-map tensor of the step in one address space: [main_0..main_{L-1}, dn_0..dn_{L-1}]
         map_tensors = [o["pred_masks"] for o in outs] + [o["pred_masks"] for o in dn_outs]
-        ms = MapSet(map_tensors)
+        # the decoder's training path hands the predictions over as their factors (mask_fused.FactoredMasks): matching cost
+        # and loss planes are then produced from (mask_embed, mask_features) directly and no [N, Q, h, w] map exists
+        fm = map_tensors[0] if isinstance(map_tensors[0], FactoredMasks) else None
+        if fm is not None and not (all(fm.same_factors(t) for t in map_tensors) and gt.tmax <= 128):
+            map_tensors = [t.materialize() if isinstance(t, FactoredMasks) else t for t in map_tensors]
+            for o, t in zip(outs + dn_outs, map_tensors):
+                o["pred_masks"] = t
+            fm = None
+        ms = MapSet(map_tensors) if fm is None else None
 
         # ---- stage 1: all matchings -----------------------------------------------------------------
         # device solver (csrc/lsa.hip): the matched query / target of every pair stays on the GPU and the
@@ -235,10 +228,10 @@ class SetCriterion(nn.Module):
         dev_lsa = (os.environ.get("MPF_DEVICE_LSA", "1") == "1" and max(Q, gt.tmax) <= LSA_MAX_DIM)
         firsts = gt.offsets
         if dev_lsa:
-            C = self.matcher.cost_matrices(outs, targets, gt=gt, tags=tags, mapset=ms, map_index=list(range(L)))
+            C = self.matcher.cost_matrices(outs, targets, gt=gt, tags=tags, mapset=ms, map_index=list(range(L)) if ms else None)
             indices = None
         else:
-            indices = self.matcher.match_many(outs, targets, gt=gt, tags=tags, mapset=ms, map_index=list(range(L)))
+            indices = self.matcher.match_many(outs, targets, gt=gt, tags=tags, mapset=ms, map_index=list(range(L)) if ms else None)
 
         # ---- pair lists (host): order = for each output: matched pairs, then MP pairs ----------------
         ti, bi, qi, gr, gid, over_parts, rand_parts = [], [], [], [], [], [], []
@@ -297,29 +290,45 @@ class SetCriterion(nn.Module):
 
         # ---- index arrays of the pairs -> device (one upload each); the solver fills the matched slots ----
         tc_main_d = torch.full((L, N, Q), K, dtype=torch.int64, device=dev) if dev_lsa else None
-        compact = None
+        planes = None
         if n_pairs:
-            g_offs = ms.grad_offsets(ti, bi, qi)
-            p_offs = ms.offsets(ti, bi, qi)
-            if not dev_lsa:
-                assert len(np.unique(g_offs)) == n_pairs, "a prediction plane is paired twice in one step"
-            compact = self._compact_layout(ms, bi, N)
-            if compact is not None:
-                g_offs = compact[0]             # plane i of the COMPACT gradient (pairs back to back, image by image)
+            gt_rows = upload(gr.astype(np.int32), dev)
+            if fm is not None:
+                # factors: pair i = embedding row p_offs[i] (elements from mask_embed's base) -> plane slot[i] of a compact
+                # [slots, h*w] tensor produced AFTER the assignment (mask_fused.pair_planes); the solver writes the row offsets
+                hw = fm.mf.shape[2] * fm.mf.shape[3]
+                q0s = np.array([t.q0 for t in map_tensors], dtype=np.int64)
+                p_offs = bi * fm.me.stride(0) + (q0s[ti] + qi) * fm.me.stride(1)
+                slot, s_first, s_count = self._slot_layout(bi, N)
+                g_offs = slot * hw
+                row_stride = np.full(n_pairs, fm.me.stride(1), dtype=np.int64)
+            else:
+                g_offs = ms.grad_offsets(ti, bi, qi)
+                p_offs = ms.offsets(ti, bi, qi)
+                row_stride = ms.s1[ms.base_of[ti]]
+                if not dev_lsa:
+                    assert len(np.unique(g_offs)) == n_pairs, "a prediction plane is paired twice in one step"
             up = upload(np.concatenate([p_offs, g_offs, gid]), dev)
             pred_offs, grad_offs, gid_d = up[:n_pairs], up[n_pairs:2 * n_pairs], up[2 * n_pairs:]
-            gt_rows = upload(gr.astype(np.int32), dev)
             if dev_lsa and problems:
                 # matched slots: the offsets of query 0 were uploaded; the solver writes base + q * stride,
                 # the ground-truth row, and the class target of the matched query
                 pr = np.asarray(problems, dtype=np.int64)
                 pos = pr[:, 4]
-                pr[:, 6], pr[:, 7] = p_offs[pos], ms.s1[ms.base_of[ti[pos]]]
-                pr[:, 8], pr[:, 9] = g_offs[pos], ms.h * ms.w
+                pr[:, 6], pr[:, 7] = p_offs[pos], row_stride[pos]
+                pr[:, 8], pr[:, 9] = g_offs[pos], (0 if fm is not None else ms.h * ms.w)
                 into = {"cols": gt_rows, "a": pred_offs}
-                if compact is None:
-                    into["b"] = grad_offs           # (the compact gradient's plane does not depend on the matched query)
+                if fm is None:
+                    into["b"] = grad_offs           # (a pair's slot in the compact planes does not depend on the matched query)
                 lsa_assign(C, pr, n_pairs, want_rows=False, scatter_dst=tc_main_d, scatter_src=labels_dev, into=into)
+            if fm is not None:
+                inv = np.zeros(n_pairs, dtype=np.int32)
+                inv[slot] = np.arange(n_pairs, dtype=np.int32)
+                i32 = upload(np.concatenate([inv, s_first, s_count]), dev)
+                planes = PairPlanes.apply(fm.me, fm.mf, pred_offs, i32[:n_pairs], i32[n_pairs:n_pairs + N], i32[n_pairs + N:],
+                                          n_pairs, int(s_count.max()))
+                ms = MapSet([planes.view(1, n_pairs, fm.mf.shape[2], fm.mf.shape[3])])
+                pred_offs = grad_offs               # from here on a pair is addressed by its plane
 
         # ---- stage 2: mask losses ----------------------------------------------------------------------
         if "masks" in self.losses:
@@ -329,8 +338,8 @@ class SetCriterion(nn.Module):
                     coords = sample_select_uncertain(ms, pred_offs, coords_over, num_uncertain, P)
                     if P - num_uncertain > 0:
                         coords[:, num_uncertain:] = _rng.rand_cat(rand_parts, dev)
-                if compact is not None:
-                    sums = MaskLossSumsCompact.apply(ms, pred_offs, grad_offs, gt, gt_rows, coords, compact[1], *compact[2])
+                if planes is not None:
+                    sums = MaskLossSumsPlanes.apply(ms, pred_offs, gt, gt_rows, coords, planes)
                 else:
                     sums = MaskLossSums.apply(ms, pred_offs, grad_offs, gt, gt_rows, coords, *ms.bases)
                 mult = [1.0] * L + ([float(scalar)] * L if use_dn else [])
@@ -358,7 +367,10 @@ class SetCriterion(nn.Module):
                 # no ground truth anywhere: sums over empty sets (still consume the draws for RNG parity)
                 _rng.rand_cat(over_parts, dev)
                 _rng.rand_cat(rand_parts, dev)
-                zero = sum(t.sum() * 0.0 for t in map_tensors).float()
+                if fm is not None:
+                    zero = (fm.me.sum() * 0.0 + fm.mf.sum() * 0.0).float()
+                else:
+                    zero = sum(t.sum() * 0.0 for t in map_tensors).float()
                 g_mask = g_dice = zero.expand(G)
             names_m = ["loss_mask" + s_ for s_ in suffixes] + (["loss_mask_dn" + s_ for s_ in suffixes] if use_dn else [])
             names_d = ["loss_dice" + s_ for s_ in suffixes] + (["loss_dice_dn" + s_ for s_ in suffixes] if use_dn else [])

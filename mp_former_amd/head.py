@@ -56,7 +56,7 @@ class MPFormerHead(nn.Module):
     NOISE_SCALE 0, DN_MODE points, ALL_LY_DN True, LB_NOISE_RATIO 0.2."""
 
     def __init__(self, num_classes=80, num_queries=100, enc_layers=6, dec_layers=9, num_points=12544,
-                 feature_shapes=None, scalar=1, noise_scale=0.0, label_noise_ratio=0.2, hidden_dim=256):
+                 feature_shapes=None, scalar=1, noise_scale=0.0, label_noise_ratio=0.2, hidden_dim=256, factored_masks=True):
         super().__init__()
         shapes = feature_shapes or R50_SHAPES
         self.pixel_decoder = MSDeformAttnPixelDecoder(
@@ -69,6 +69,8 @@ class MPFormerHead(nn.Module):
             dim_feedforward=2048, dec_layers=dec_layers, pre_norm=False, mask_dim=hidden_dim,
             enforce_input_project=False, dn_mode="points", head_dn=False, all_lys=True, dn_ratio=0.5,
             dn_label_noise_ratio=label_noise_ratio)
+        # predictor and criterion are both ours: the mask predictions travel between them as their factors (mask_fused.py)
+        self.predictor.factored_masks = bool(factored_masks)
         matcher = HungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=5.0, num_points=num_points)
         self.criterion = SetCriterion(num_classes, matcher=matcher, weight_dict=build_weight_dict(dec_layers + 1),
                                       eos_coef=0.1, losses=["labels", "masks"], num_points=num_points,

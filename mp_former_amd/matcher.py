@@ -21,6 +21,7 @@ from . import _rng
 from . import _lib
 from ._h2d import upload
 from ._targets import stacked_masks
+from .mask_fused import FactoredMasks, match_cost_fused
 from .point_sample import MapSet, match_cost, point_sample_offsets
 
 
@@ -83,35 +84,46 @@ class HungarianMatcher(nn.Module):
         coords = _rng.rand_cat([(tags[l], (1, P, 2)) for l in range(L) for _ in range(N)], dev)   # [L*N,P,2]
         if gt.tmax == 0:
             return None
-        if mapset is None:
-            mapset = MapSet([o["pred_masks"] for o in outs])
-            map_index = list(range(L))
         Tt, Tmax = gt.total, gt.tmax
-        # ---- index arrays (host) -> one upload ---------------------------------------------------
-        l_idx, b_idx, q_idx = np.meshgrid(np.arange(L), np.arange(N), np.arange(Q), indexing="ij")
-        l_idx, b_idx, q_idx = l_idx.reshape(-1), b_idx.reshape(-1), q_idx.reshape(-1)
-        pred_offs = mapset.offsets(np.asarray(map_index, dtype=np.int64)[l_idx], b_idx, q_idx)
-        gt_offs = np.tile(np.arange(Tt, dtype=np.int64) * (gt.H * gt.W), L)
-        i64 = upload(np.concatenate([pred_offs, gt_offs]), dev)
         counts = np.asarray(gt.counts, dtype=np.int64)
         firsts = np.asarray(gt.offsets[:-1], dtype=np.int64)
-        i32 = np.concatenate([
-            (l_idx * N + b_idx),                                        # coord row of every prediction row
-            (l_idx * Tt + firsts[b_idx]),                               # first tsamp row of its image
-            counts[b_idx],                                              # number of targets of its image
-            (np.repeat(np.arange(L), Tt) * N + np.tile(gt.image_of_row, L)),   # coord row of every GT sample row
-        ]).astype(np.int32)
-        i32 = upload(i32, dev)
-        n_rows = L * N * Q
-        pred_offs_d, gt_offs_d = i64[:n_rows], i64[n_rows:]
-        crow_d, tfirst_d, tcount_d, gcrow_d = i32[:n_rows], i32[n_rows:2 * n_rows], i32[2 * n_rows:3 * n_rows], i32[3 * n_rows:]
-        # ---- ground-truth samples [L*Tt, P], then mask + dice cost [L*N*Q, Tmax] ------------------
-        if gt.bits is not None:      # gt_offs are pixel offsets either way
-            tsamp = point_sample_offsets(gt.bits.data_ptr(), "bits", gt.H, gt.W, gt_offs_d, coords, gcrow_d, dev)
+        # ground-truth samples [L*Tt, P]: every mask at the point set of its (output, image)
+        gt_offs = np.tile(np.arange(Tt, dtype=np.int64) * (gt.H * gt.W), L)
+        gcrow = (np.repeat(np.arange(L), Tt) * N + np.tile(gt.image_of_row, L)).astype(np.int32)
+        masks = [o["pred_masks"] for o in outs]
+        factored = mapset is None and all(isinstance(m, FactoredMasks) and m.same_factors(masks[0]) for m in masks) and Tmax <= 128
+        if factored:
+            # the maps are kept as (mask_embed, mask_features): cost straight from the factors (csrc/mask_fused.hip)
+            gt_offs_d = upload(gt_offs, dev)
+            gcrow_d = upload(gcrow, dev)
+            tsamp = self._gt_samples(gt, gt_offs_d, coords, gcrow_d, dev)
+            l_idx, b_idx = np.meshgrid(np.arange(L), np.arange(N), indexing="ij")
+            l_idx, b_idx = l_idx.reshape(-1), b_idx.reshape(-1)
+            C = match_cost_fused(masks, coords, tsamp, l_idx * Tt + firsts[b_idx], counts[b_idx], l_idx, b_idx, Q, Tmax,
+                                 self.cost_mask, self.cost_dice).view(L, N, Q, Tmax)
         else:
-            tsamp = point_sample_offsets(gt.u8.data_ptr(), torch.uint8, gt.H, gt.W, gt_offs_d, coords, gcrow_d, dev)
-        C = match_cost(mapset, pred_offs_d, coords, crow_d, tsamp, tfirst_d, tcount_d, Tmax,
-                       self.cost_mask, self.cost_dice, rows_per_group=Q).view(L, N, Q, Tmax)   # rows are (l, b, q), q fastest
+            if mapset is None:
+                mapset = MapSet([m.materialize() if isinstance(m, FactoredMasks) else m for m in masks])
+                map_index = list(range(L))
+            # ---- index arrays (host) -> one upload ---------------------------------------------------
+            l_idx, b_idx, q_idx = np.meshgrid(np.arange(L), np.arange(N), np.arange(Q), indexing="ij")
+            l_idx, b_idx, q_idx = l_idx.reshape(-1), b_idx.reshape(-1), q_idx.reshape(-1)
+            pred_offs = mapset.offsets(np.asarray(map_index, dtype=np.int64)[l_idx], b_idx, q_idx)
+            i64 = upload(np.concatenate([pred_offs, gt_offs]), dev)
+            i32 = np.concatenate([
+                (l_idx * N + b_idx),                                        # coord row of every prediction row
+                (l_idx * Tt + firsts[b_idx]),                               # first tsamp row of its image
+                counts[b_idx],                                              # number of targets of its image
+                gcrow,                                                      # coord row of every GT sample row
+            ]).astype(np.int32)
+            i32 = upload(i32, dev)
+            n_rows = L * N * Q
+            pred_offs_d, gt_offs_d = i64[:n_rows], i64[n_rows:]
+            crow_d, tfirst_d, tcount_d, gcrow_d = i32[:n_rows], i32[n_rows:2 * n_rows], i32[2 * n_rows:3 * n_rows], i32[3 * n_rows:]
+            # ---- ground-truth samples [L*Tt, P], then mask + dice cost [L*N*Q, Tmax] ------------------
+            tsamp = self._gt_samples(gt, gt_offs_d, coords, gcrow_d, dev)
+            C = match_cost(mapset, pred_offs_d, coords, crow_d, tsamp, tfirst_d, tcount_d, Tmax,
+                           self.cost_mask, self.cost_dice, rows_per_group=Q).view(L, N, Q, Tmax)   # rows are (l, b, q), q fastest
         # ---- class cost: -softmax(logits)[:, labels]  (matcher.py:105-111) ------------------------
         logits = torch.stack([o["pred_logits"] for o in outs]).float()                  # [L,N,Q,K+1]
         labels = torch.zeros((N, Tmax), dtype=torch.int64, device=dev)
@@ -120,6 +132,12 @@ class HungarianMatcher(nn.Module):
                 labels[b, :gt.counts[b]] = t["labels"]
         prob = logits.softmax(-1)
         return (C - self.cost_class * torch.gather(prob, 3, labels[None, :, None, :].expand(L, N, Q, Tmax))).contiguous()
+
+    @staticmethod
+    def _gt_samples(gt, gt_offs_d, coords, gcrow_d, dev):
+        if gt.bits is not None:      # gt_offs are pixel offsets either way
+            return point_sample_offsets(gt.bits.data_ptr(), "bits", gt.H, gt.W, gt_offs_d, coords, gcrow_d, dev)
+        return point_sample_offsets(gt.u8.data_ptr(), torch.uint8, gt.H, gt.W, gt_offs_d, coords, gcrow_d, dev)
 
     @torch.no_grad()
     def match_many(self, outs, targets, gt=None, tags=None, mapset=None, map_index=None):

@@ -229,89 +229,32 @@ class MaskLossSums(Function):
         return (None, None, None, None, None, None, *grads)
 
 
-_split_k_ok = True
-
-
-def _long_k_product(a, b, chunk=2048):
-    """a [m, K] @ b [K, n] for a few hundred rows and K = h * w = 65 536: as ONE GEMM the library runs it on ceil(m/64) *
-    ceil(n/64) workgroups with no split over K (170 us for 8 GFLOP); as a batched GEMM over K chunks with fp32 partial
-    results + one sum it fills the chip.  Falls back to the plain product where the fp32-output batched GEMM is missing."""
-    global _split_k_ok
-    m, K = a.shape
-    if _split_k_ok and a.dtype == torch.bfloat16 and K % chunk == 0 and K // chunk > 1 and a.stride(1) == 1 and b.is_contiguous():
-        S = K // chunk
-        try:
-            part = torch.bmm(a.as_strided((S, m, chunk), (chunk, a.stride(0), 1)), b.view(S, chunk, b.shape[1]),
-                             out_dtype=torch.float32)
-            return part.sum(0).to(a.dtype)
-        except (RuntimeError, NotImplementedError, TypeError):
-            _split_k_ok = False
-    return torch.mm(a, b)
-
-
-class MaskLossSumsCompact(Function):
-    """MaskLossSums for maps that ARE a product: pred_masks = einsum("bqc,bchw->bqhw", mask_embed, mask_features)
-    (mask2former_transformer_decoder.py:1869), differentiated with respect to the FACTORS.
-
-    The loss touches ~1/4 of the N * 10 * Qtot rows of the batched prediction (matched + MP rows); the dense route
-    zero-fills a gradient of the whole [N, 10 Qtot, h, w] tensor and contracts all of it twice (d mask_embed over 65 536
-    pixels, d mask_features over all rows).  Here the scatter kernel writes the gradient planes of the n pairs back to back
-    (image by image), and both products run on those rows only:
-        d mask_features[b] = G_b^T . mask_embed[b, rows_b]          [hw, n_b] x [n_b, C]
-        d mask_embed[b, rows_b] = G_b . mask_features[b]            [n_b, hw] x [hw, C]
-    ``lay`` = (per-image (first slot, pairs, padded pairs) list, rows per image Qb, element offset of the maps' first row)."""
-
-    calls = 0          # (tests assert that this route, not the dense one, ran)
+class MaskLossSumsPlanes(Function):
+    """MaskLossSums over the compact planes of the step's pairs (mask_fused.pair_planes: [slots, h*w], one plane per
+    pair): the backward scatter writes every paired plane of a fresh gradient buffer exactly once (one workgroup per
+    (pair, band): LDS fixed-point accumulators, no atomics on memory), so there is no zero-fill; rows of padding slots
+    stay uninitialised and are never read (the products of pair_planes' backward run on the paired rows only)."""
 
     @staticmethod
-    def forward(ctx, ms, pred_offs, grad_offs, gt, gt_rows, coords, lay, me, mf):
-        MaskLossSumsCompact.calls += 1
-        sums = _mask_loss_sums_forward(ctx, ms, pred_offs, gt, gt_rows, coords)
-        ctx.save_for_backward(pred_offs, grad_offs, ctx.gt_u8, gt_rows, coords, me, mf)
-        ctx.lay = lay
+    def forward(ctx, ms, plane_offs, gt, gt_rows, coords, planes):
+        sums = _mask_loss_sums_forward(ctx, ms, plane_offs, gt, gt_rows, coords)
+        ctx.save_for_backward(plane_offs, ctx.gt_u8, gt_rows, coords, planes)
         return sums
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_sums):
         ms = ctx.ms
-        pred_offs, grad_offs, gt_u8, gt_rows, coords, me, mf = ctx.saved_tensors
-        slots, Qb, root_off = ctx.lay
+        plane_offs, gt_u8, gt_rows, coords, planes = ctx.saved_tensors
         n, P = coords.shape[0], coords.shape[1]
         H, W = ctx.gt_hw
-        hw = ms.h * ms.w
-        N, C = mf.shape[0], mf.shape[1]
-        total_slots = slots[-1][0] + slots[-1][2] if slots else 0
-        gcomp = torch.empty((total_slots, hw), dtype=ms.dtype, device=ms.device)
-        for first, nb, npad in slots:                       # the padding rows of an image's block enter the products as zeros
-            if npad > nb:
-                gcomp[first + nb:first + npad].zero_()
-        g = grad_sums.contiguous().float()
-        with torch.cuda.device(ms.device):
-            code = _lib.lib().mpf_mask_loss_backward_dense(
-                ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), ctx.gdt, H, W,
-                gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), gcomp.data_ptr(), _DT[ms.dtype], grad_offs.data_ptr(),
-                n, P, _stream(ms.device))
-        _lib.check(code, "mpf_mask_loss_backward_dense")
-        # row (b * Qb + q) of every pair, in slot order (grad_offs = slot * hw by construction)
-        row_of_pair = (pred_offs - root_off) // hw
-        slot_of_pair = grad_offs // hw
-        row_of_slot = torch.zeros(total_slots, dtype=torch.int64, device=ms.device)
-        row_of_slot[slot_of_pair] = row_of_pair
-        planes = mf.permute(0, 2, 3, 1).reshape(N, hw, C)                   # view of the channel-last features
-        d_me = torch.zeros_like(me) if ctx.needs_input_grad[7] else None
-        d_mf = torch.empty((N, hw, C), dtype=mf.dtype, device=mf.device) if ctx.needs_input_grad[8] else None
-        for b, (first, nb, npad) in enumerate(slots):
-            if npad == 0:
-                if d_mf is not None:
-                    d_mf[b].zero_()
-                continue
-            Gb = gcomp[first:first + npad]
-            q = row_of_slot[first:first + npad] - b * Qb                     # (padding slots: row 0 of the image, times zeros)
-            q = q.clamp_(0, Qb - 1)
-            if d_mf is not None:
-                torch.mm(Gb.t(), me[b].index_select(0, q), out=d_mf[b])
-            if d_me is not None:
-                d_me[b].index_copy_(0, q[:nb], _long_k_product(Gb, planes[b])[:nb])
-        g_mf = d_mf.view(N, ms.h, ms.w, C).permute(0, 3, 1, 2) if d_mf is not None else None
-        return (None, None, None, None, None, None, None, d_me, g_mf)
+        g_planes = torch.empty_like(planes)
+        if n:
+            g = grad_sums.contiguous().float()
+            with torch.cuda.device(ms.device):
+                code = _lib.lib().mpf_mask_loss_backward_dense(
+                    ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, plane_offs.data_ptr(), gt_u8.data_ptr(), ctx.gdt, H, W,
+                    gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), g_planes.data_ptr(), _DT[ms.dtype], plane_offs.data_ptr(),
+                    n, P, _stream(ms.device))
+            _lib.check(code, "mpf_mask_loss_backward_dense")
+        return None, None, None, None, None, g_planes

@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-from . import _lib, _rng
+from . import _lib, _rng, mask_fused
 from ._h2d import upload
 from ._targets import stacked_masks
 from .attention import attention_core
@@ -218,44 +218,15 @@ def _is_planes(x):
             and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
 
 
-class _MaskProductCL(torch.autograd.Function):
-    """einsum("bqc,bchw->bqhw") for channel-last features: the features enter the batched GEMM as its transposed operand
-    and their gradient leaves it as [N, H*W, C] planes again, so nothing between the last convolution of the pixel decoder
-    and the mask logits (forward or backward) changes layout."""
-
-    @staticmethod
-    def forward(ctx, me, mf):
-        N, C, H, W = mf.shape
-        ctx.save_for_backward(me, mf)
-        planes = mf.permute(0, 2, 3, 1).reshape(N, H * W, C)               # view
-        # [N, Q, H*W]; the caller reshapes: a view made in here would hide this node from the views taken of it later
-        # (their ._base would be the raw GEMM result, which point_sample.MapSet follows to address the maps)
-        return torch.bmm(me, planes.transpose(1, 2))
-
-    @staticmethod
-    def backward(ctx, g):
-        me, mf = ctx.saved_tensors
-        N, C, H, W = mf.shape
-        g_me = g_mf = None
-        if ctx.needs_input_grad[0]:
-            g_me = torch.bmm(g, mf.permute(0, 2, 3, 1).reshape(N, H * W, C))
-        if ctx.needs_input_grad[1]:
-            g_mf = torch.bmm(g.transpose(1, 2), me).view(N, H, W, C).permute(0, 3, 1, 2)
-        return g_me, g_mf
-
-
 def mask_product(me, mask_features):
-    """outputs_mask = einsum("bqc,bchw->bqhw", mask_embed, mask_features) (decoder :1869)."""
-    if _is_planes(mask_features) and not mask_features.is_contiguous() and me.dtype == mask_features.dtype and me.is_cuda:
+    """outputs_mask = einsum("bqc,bchw->bqhw", mask_embed, mask_features) (decoder :1869).  bf16 operands with channel-last
+    features (the AMP path) run on the native MFMA product (csrc/mask_fused.hip, forward and both gradients); anything else
+    is the library einsum."""
+    if me.is_cuda and me.dtype == mask_features.dtype and mask_fused.supported(me, mask_features):
         amp = torch.is_autocast_enabled()
         if not amp or me.dtype == torch.get_autocast_dtype("cuda"):      # operands already in the dtype autocast would pick
             with torch.autocast(device_type="cuda", enabled=False):
-                N, C, H, W = mask_features.shape
-                out = _MaskProductCL.apply(me, mask_features)
-                # the criterion's mask losses differentiate with respect to the factors on the rows they touch instead of
-                # through a dense gradient of this tensor (point_sample.MaskLossSumsCompact finds them here)
-                out._mpf_factors = (me, mask_features)
-                return out.view(N, me.shape[1], H, W)
+                return mask_fused.full_product(me, mask_features)
     return torch.einsum("bqc,bchw->bqhw", me, mask_features)
 
 
@@ -456,6 +427,9 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         self.label_enc = nn.Embedding(num_classes, hidden_dim)
         self.all_lys = all_lys
+        # True: in training mode "pred_masks" are mask_fused.FactoredMasks (for mp_former_amd's SetCriterion, which samples
+        # them from the factors); False (the reference interface): materialised [N, Q, H/4, W/4] tensors
+        self.factored_masks = False
 
     @classmethod
     def from_config(cls, cfg, in_channels, mask_classification):
@@ -625,8 +599,13 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         e = F.relu(lin(x, W["mask_embed.layers.0.weight"], W["mask_embed.layers.0.bias"]))
         e = F.relu(lin(e, W["mask_embed.layers.1.weight"], W["mask_embed.layers.1.bias"]))
         me = lin(e, W["mask_embed.layers.2.weight"], W["mask_embed.layers.2.bias"]).transpose(0, 1)   # [N, L*Qt, C]
-        pm = mask_product(me, mask_features)                                                 # [N, L*Qt, H, W]
         cls = cls.view(L, Qt, N, -1)
+        if self.factored_masks and self.training and mask_fused.supported(me, mask_features):
+            # training: the criterion samples the predictions from their factors (matching cost, loss planes of the pairs);
+            # the [N, L*Qt, H, W] maps are never formed (mask_fused.FactoredMasks)
+            pm = mask_fused.FactoredMasks(me, mask_features)
+        else:
+            pm = mask_product(me, mask_features)                                             # [N, L*Qt, H, W]
         return [cls[l].transpose(0, 1) for l in range(L)], [pm[:, l * Qt:(l + 1) * Qt] for l in range(L)]
 
     def _layer_by_ops(self, W, i, level, output, xb, kin, src, attn_mask, tgt_mask, post_norm):

@@ -192,7 +192,8 @@ def test_head_baseline_config_shapes_run(name, size, chans, classes, queries, n)
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
     assert not [k for k, p in h.named_parameters() if p.grad is None]
-    for kern in ("msda_fwd_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost", "mask_loss_fwd", "mask_head_bits", "pool_features"):
+    for kern in ("msda_fwd_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost_fused", "pair_planes_fwd", "pair_planes_dfeat",
+                 "pair_planes_dembed", "mask_loss_fwd", "mask_head_bits", "pool_features"):
         assert _lib.profile_get(kern)[0] > 0, kern
     _lib.profile_enable(False)
 
@@ -220,8 +221,6 @@ def test_head_amp_path_matches_reference_golden(name):
     use_dn = "dn_pred_logits" in z
     _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
     _lib.profile_enable(True)
-    from mp_former_amd.point_sample import MaskLossSumsCompact
-    compact_before = MaskLossSumsCompact.calls
     try:
         with torch.autocast("cuda", dtype=torch.bfloat16):
             losses, _ = h(feats, targets)            # weighted, like maskformer_model.py:226-231
@@ -229,8 +228,11 @@ def test_head_amp_path_matches_reference_golden(name):
         assert _rng.remaining() == 0
         total.backward()
         torch.cuda.synchronize()
-        # the mask losses differentiate w.r.t. (mask_embed, mask_features) on the paired rows only (no dense map gradient)
-        assert MaskLossSumsCompact.calls == compact_before + 1, "the compact mask-gradient route did not run"
+        # the mask predictions never exist as maps: matching cost from the factors, loss planes of the paired rows only, and
+        # their gradients w.r.t. (mask_embed, mask_features) from the native products (csrc/mask_fused.hip)
+        # (pair_planes_fwd also serves the next-layer attention mask where a level is too small for the fused mask head)
+        assert _lib.profile_get("match_cost_fused_kernel")[0] == 1 and _lib.profile_get("pair_planes_fwd_kernel")[0] >= 1
+        assert _lib.profile_get("pair_planes_dfeat_kernel")[0] == 1 and _lib.profile_get("pair_planes_dembed_kernel")[0] == 1
         for kern in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "small_gemm", "small_gemm_group_kernel", "lsa_kernel", "msda_fwd_block",
                      "msda_bwd_pull_mfma", "gemm3", "gn_cl_apply", "gn_cl_bwd_apply"):
             assert _lib.profile_get(kern)[0] > 0, f"{kern} did not run on the AMP path"
@@ -302,8 +304,8 @@ def test_head_full_size_configs_B_C(name, classes, n):
 
     _lib.profile_enable(True)
     l0 = run(11)
-    for kern in ("msda_fwd_block", "msda_bwd_push_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost",
-                 "mask_loss_fwd", "mask_head_bits", "pool_features", "lsa_kernel", "gemm3", "gemm3_conv_kernel",
+    for kern in ("msda_fwd_block", "msda_bwd_push_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost_fused",
+                 "pair_planes_fwd", "pair_planes_dfeat", "pair_planes_dembed", "mask_loss_fwd", "mask_head_bits", "pool_features", "lsa_kernel", "gemm3", "gemm3_conv_kernel",
                  "gemm3_nt_kernel<conv3x3>", "gemm3_tn_kernel<a16>", "gemm3_nt_kernel<b16>", "gn_cl_apply", "gn_cl_bwd_apply"):
         assert _lib.profile_get(kern)[0] > 0, kern
     _lib.profile_enable(False)

@@ -65,28 +65,31 @@ def test_stacked_masks_is_shared_within_a_step_and_follows_inplace_changes():
     assert stacked_masks([b, a]).shape == (5, 4, 4) and bool(stacked_masks([b, a])[:2].all())
 
 
-def test_compact_layout_orders_pairs_by_image():
-    """criterion._compact_layout: the gradient planes of the pairs back to back, image by image, each image padded to 16."""
+def test_slot_layout_orders_pairs_by_image():
+    """criterion._slot_layout: the logits planes of the step's pairs back to back, image by image (no padding)."""
     from mp_former_amd.criterion import SetCriterion
-
-    class FakeMS:
-        pass
-
-    N, Q, h, w, C = 2, 7, 4, 4, 8
-    me = torch.randn(N, Q, C, requires_grad=True)
-    mf = torch.randn(N, C, h, w)
-    root = torch.randn(N, Q, h * w)
-    root._mpf_factors = (me, mf)
-    ms = FakeMS()
-    ms.bases = [root.view(N, Q, h, w)]
-    ms.h, ms.w, ms.dtype, ms.t_off = h, w, torch.float32, np.array([0])
     bi = np.array([0, 1, 1, 0, 1, 0, 0])
-    offs, (slots, Qb, root_off), (me2, mf2) = SetCriterion._compact_layout(ms, bi, N)
-    assert me2 is me and mf2 is mf and Qb == Q and root_off == 0
-    assert slots == [(0, 4, 16), (16, 3, 16)]
-    assert list(offs // (h * w)) == [0, 16, 17, 1, 18, 2, 3]
-    del root._mpf_factors
-    assert SetCriterion._compact_layout(ms, bi, N) is None
+    slot, first, count = SetCriterion._slot_layout(bi, 3)
+    assert list(slot) == [0, 4, 5, 1, 6, 2, 3]
+    assert list(first) == [0, 4, 7] and list(count) == [4, 3, 0]
+
+
+def test_factored_masks_views_and_row_offsets():
+    """mask_fused.FactoredMasks: dim-1 slices stay factored (incl. the decoder's [:, :-nq] / [:, -nq:] split) and address
+    the embedding rows through the strides of the sequence-first tensor the heads produce."""
+    from mp_former_amd.mask_fused import FactoredMasks
+    L, Qt, N, C, H, W = 3, 7, 2, 256, 8, 16
+    me = torch.zeros(L * Qt, N, C).transpose(0, 1)              # [N, L*Qt, C] view of [L*Qt, N, C]
+    mf = torch.zeros(N, H, W, C).permute(0, 3, 1, 2)
+    root = FactoredMasks(me, mf)
+    assert root.shape == (N, L * Qt, H, W) and root.dim() == 4
+    layer1 = root[:, Qt:2 * Qt]
+    dn, main = layer1[:, :-5], layer1[:, -5:]
+    assert (dn.q0, dn.q1, main.q0, main.q1) == (7, 9, 9, 14) and main.shape == (N, 5, H, W)
+    assert main.same_factors(root) and not main.same_factors(FactoredMasks(me.clone(), mf))
+    offs = main.row_offsets(np.array([0, 1]), np.array([0, 4]))
+    assert list(offs) == [9 * N * C, C + 13 * N * C]
+    assert dn.detach().q0 == 7
 
 
 def test_prepare_targets_pads_masks_and_normalises_boxes():

@@ -96,22 +96,25 @@ def test_pool_features_channel_last_equals_nchw(dtype, N, h, w, size):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_mask_product_channel_last_matches_einsum(dtype):
-    """mask_product on channel-last features = einsum("bqc,bchw->bqhw"), values and both gradients; the feature
-    gradient comes back as channel-last planes."""
-    from mp_former_amd import transformer_decoder as TD
+    """mask_product on channel-last features = einsum("bqc,bchw->bqhw"), values and both gradients; bf16 operands run on
+    the native MFMA product (csrc/mask_fused.hip) and the feature gradient comes back as channel-last planes; fp32 is the
+    library einsum (not on the AMP training path)."""
+    from mp_former_amd import _lib, transformer_decoder as TD
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
-    N, Q, C, H, W = 2, 77, 256, 24, 40
+    N, Q, C, H, W = 2, 77, 256, 24, 48
     me = torch.randn(N, Q, C, device=dev).to(dtype).requires_grad_(True)
     mf = torch.randn(N, H, W, C, device=dev).to(dtype).permute(0, 3, 1, 2).requires_grad_(True)
     assert TD._is_planes(mf) and not mf.is_contiguous()
     out = TD.mask_product(me, mf)
+    if dtype == torch.bfloat16:
+        assert _lib.last_kernel() == "pair_planes_fwd_kernel"
     ref = torch.einsum("bqc,bchw->bqhw", me.double(), mf.double())
     tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
     torch.testing.assert_close(out.double(), ref, rtol=tol, atol=tol * 16)
     g = torch.randn_like(out)
     g_me, g_mf = torch.autograd.grad(out, [me, mf], g)
     r_me, r_mf = torch.autograd.grad(ref, [me, mf], g.double())
-    assert TD._is_planes(g_mf)
+    assert dtype != torch.bfloat16 or TD._is_planes(g_mf)
     torch.testing.assert_close(g_me.double(), r_me.double(), rtol=tol, atol=tol * float(r_me.abs().max()))
     torch.testing.assert_close(g_mf.double(), r_mf.double(), rtol=tol, atol=tol * float(r_mf.abs().max()))
