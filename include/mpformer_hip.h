@@ -735,6 +735,13 @@ int mpf_res_ln256_backward(const float* s, const float* mean, const float* rstd,
                            int rows, void* stream);
 /* The same with dgamma / dbeta reduced through per-workgroup partials in a fixed order (no float atomics: deterministic, and
  * the two vectors need no zero-initialisation).  workspace: mpf_res_ln256_backward_workspace_bytes(rows) bytes. */
+/* One-launch deterministic form (the workgroup that arrives last sums the per-workgroup partials in a fixed order):
+ * dgamma_dbeta [2][256] = (dgamma, dbeta), fully written.  The first 4 bytes of `workspace`
+ * (mpf_res_ln256_backward_det_workspace_bytes(rows) bytes) must be zero on entry and are zero again on exit. */
+size_t mpf_res_ln256_backward_det_workspace_bytes(int rows);
+int mpf_res_ln256_backward_det(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                               const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma_dbeta, int rows,
+                               void* workspace, size_t workspace_bytes, void* stream);
 size_t mpf_res_ln256_backward_workspace_bytes(int rows);
 int mpf_res_ln256_backward_ws(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
                               const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta, int rows,

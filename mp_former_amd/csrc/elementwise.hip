@@ -148,7 +148,10 @@ __global__ __launch_bounds__(256) void res_ln256_fwd_kernel(const float* __restr
 
 // PART: the block's dgamma / dbeta sums go to partial[block][2][256] (summed in a fixed order by ln_partial_reduce_kernel)
 // instead of float atomics into zero-initialised vectors: deterministic, no pre-zeroing, no contended atomics
-template <bool G32, bool G16, bool GP, bool PART = false>
+// PART == 2: the same partials, summed in block order by the workgroup that ARRIVES LAST (ticket from one integer atomic per
+// workgroup): one launch, no floating-point atomics, bit-reproducible.  dgamma = the workspace: [0] ticket counter (zero on
+// entry, reset to zero on exit), partials from byte 256; dbeta = the output pair [2][256] (dgamma row, dbeta row).
+template <bool G32, bool G16, bool GP, int PART = 0>
 __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restrict__ s, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ gy32, const __bf16* __restrict__ gy16,
@@ -193,9 +196,27 @@ __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restr
     const int col = threadIdx.x;
     const float sg = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
     const float sb = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
-    if constexpr (PART) {       // dgamma doubles as the partial buffer pointer
+    if constexpr (PART == 1) {       // dgamma doubles as the partial buffer pointer
         dgamma[(int64_t)blockIdx.x * 512 + col] = sg;
         dgamma[(int64_t)blockIdx.x * 512 + 256 + col] = sb;
+    } else if constexpr (PART == 2) {
+        float* part = dgamma + 64;
+        part[(int64_t)blockIdx.x * 512 + col] = sg;
+        part[(int64_t)blockIdx.x * 512 + 256 + col] = sb;
+        __threadfence();                                      // partials visible device-wide before the ticket
+        __shared__ int s_last;
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(reinterpret_cast<int*>(dgamma), 1) == (int)gridDim.x - 1;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            const volatile float* vp = part;
+            float tg = 0.f, tb = 0.f;
+            for (int b = 0; b < (int)gridDim.x; ++b) { tg += vp[(int64_t)b * 512 + col]; tb += vp[(int64_t)b * 512 + 256 + col]; }
+            dbeta[col] = tg;
+            dbeta[256 + col] = tb;
+            if (threadIdx.x == 0) *reinterpret_cast<int*>(dgamma) = 0;
+        }
     } else {
         atomicAdd(dgamma + col, sg);
         atomicAdd(dbeta + col, sb);
@@ -311,7 +332,7 @@ extern "C" int mpf_res_ln256_backward_ws(const float* s, const float* mean, cons
     float* part = (float*)workspace;
     mpf::set_kernel("res_ln256_bwd_kernel");
 #define RLN_BWDP(A, B, C)                                                                                                         \
-    hipLaunchKernelGGL((res_ln256_bwd_kernel<A, B, C, true>), grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16,    \
+    hipLaunchKernelGGL((res_ln256_bwd_kernel<A, B, C, 1>), grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16,    \
                        gy_plus, ds32, (__bf16*)ds16, part, part, rows, rpb)
     switch ((gy32 ? 4 : 0) | (gy16 ? 2 : 0) | (gy_plus ? 1 : 0)) {
         case 1: RLN_BWDP(false, false, true); break;
@@ -325,6 +346,43 @@ extern "C" int mpf_res_ln256_backward_ws(const float* s, const float* mean, cons
 #undef RLN_BWDP
     hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(2, 8), dim3(1024), 0, st, (const float*)part, (int)grid.x, dgamma, dbeta);
     return mpf::check(hipGetLastError(), "mpf_res_ln256_backward_ws");
+}
+
+// few rows (the decoder's query side): ONE launch, the workgroup that arrives last sums the partials in block order
+extern "C" size_t mpf_res_ln256_backward_det_workspace_bytes(int rows)
+{
+    return rows <= 0 ? 0 : 256 + mpf_res_ln256_backward_workspace_bytes(rows);
+}
+
+extern "C" int mpf_res_ln256_backward_det(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                                          const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma_dbeta, int rows,
+                                          void* workspace, size_t workspace_bytes, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) return 0;
+    if (!s || !mean || !rstd || !gamma || (!gy32 && !gy16 && !gy_plus) || (!ds32 && !ds16) || !dgamma_dbeta || !workspace)
+        return mpf::fail(MPF_E_NULL, "res_ln256_backward_det: NULL buffer");
+    if (rows < 0 || workspace_bytes < mpf_res_ln256_backward_det_workspace_bytes(rows))
+        return mpf::fail(MPF_E_SHAPE, "res_ln256_backward_det: bad rows / workspace too small");
+    int rpb = (rows + 1023) / 1024;
+    rpb = ((rpb + 3) / 4) * 4;
+    const dim3 grid((rows + rpb - 1) / rpb);
+    float* ws = (float*)workspace;
+    mpf::set_kernel("res_ln256_bwd_kernel");
+#define RLN_BWDD(A, B, C)                                                                                                         \
+    hipLaunchKernelGGL((res_ln256_bwd_kernel<A, B, C, 2>), grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16,       \
+                       gy_plus, ds32, (__bf16*)ds16, ws, dgamma_dbeta, rows, rpb)
+    switch ((gy32 ? 4 : 0) | (gy16 ? 2 : 0) | (gy_plus ? 1 : 0)) {
+        case 1: RLN_BWDD(false, false, true); break;
+        case 2: RLN_BWDD(false, true, false); break;
+        case 3: RLN_BWDD(false, true, true); break;
+        case 4: RLN_BWDD(true, false, false); break;
+        case 5: RLN_BWDD(true, false, true); break;
+        case 6: RLN_BWDD(true, true, false); break;
+        default: RLN_BWDD(true, true, true); break;
+    }
+#undef RLN_BWDD
+    return mpf::check(hipGetLastError(), "mpf_res_ln256_backward_det");
 }
 
 // ------------------------------------------------------------------------------------------------

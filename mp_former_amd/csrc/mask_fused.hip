@@ -358,15 +358,23 @@ __global__ void slot_valid_kernel(const int32_t* __restrict__ slot_first, const 
 // ====================================================================================================================
 // 5. matching cost from the factors
 // ====================================================================================================================
-// row sums of the pre-sampled ground-truth points: tsum[row] = sum_p tsamp[row][p]; one wave per row, fixed order
+// row sums of the pre-sampled ground-truth points: tsum[row] = sum_p tsamp[row][p]; one workgroup per row, fixed order
 __global__ __launch_bounds__(kT) void tsamp_rowsum_kernel(const float* __restrict__ tsamp, float* __restrict__ tsum, int rows, int P)
 {
-    const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
+    __shared__ float red[kT / 64];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float* src = tsamp + (int64_t)row * P;
     float v = 0.f;
-    for (int p = lane; p < P; p += 64) v += tsamp[(int64_t)row * P + p];
+    if ((P & 3) == 0) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int i = tid; i < (P >> 2); i += kT) { const float4 t = s4[i]; v += (t.x + t.y) + (t.z + t.w); }
+    } else {
+        for (int p = tid; p < P; p += kT) v += src[p];
+    }
     v = wave_sum64(v);
-    if (lane == 0) tsum[row] = v;
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) tsum[row] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 constexpr int kMP = 32;           // points per tile
@@ -607,7 +615,7 @@ extern "C" int mpf_match_cost_fused(const void* embed, const int64_t* embed_firs
     float* tsum = (float*)((char*)pq + align256((size_t)m.nwg * G * Q * 2 * 4));
     const __hip_bfloat16* e = (const __hip_bfloat16*)embed;
     const __hip_bfloat16* f = (const __hip_bfloat16*)features;
-    hipLaunchKernelGGL(tsamp_rowsum_kernel, dim3((tsamp_rows + 3) / 4), dim3(kT), 0, st, tsamp, tsum, tsamp_rows, P);
+    hipLaunchKernelGGL(tsamp_rowsum_kernel, dim3(tsamp_rows), dim3(kT), 0, st, tsamp, tsum, tsamp_rows, P);
     const dim3 grid(m.nwg, G, m.qgroups);
     const int need = (Tmax + 1) / 2;
     mpf::prof_begin(st);

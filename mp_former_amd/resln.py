@@ -46,18 +46,21 @@ class _ResLN(Function):
         want32 = need_x or (need_t and not t16) or not t16
         ds32 = torch.empty_like(s) if want32 else None
         ds16 = torch.empty_like(s, dtype=torch.bfloat16) if t16 else None
-        dgb = torch.zeros((2, 256), dtype=torch.float32, device=s.device)
+        dgb = torch.empty((2, 256), dtype=torch.float32, device=s.device)
         if g32 is not None:
             g32 = g32.contiguous()
         if g16 is not None:
             g16 = g16.contiguous()
+        lib = _lib.lib()
+        ws = _det_ws(s.device, lib.mpf_res_ln256_backward_det_workspace_bytes(ctx.rows))
         with torch.cuda.device(s.device):
-            code = _lib.lib().mpf_res_ln256_backward(
+            # parameter gradients: per-workgroup partials summed in a fixed order by the last workgroup (no float atomics)
+            code = lib.mpf_res_ln256_backward_det(
                 s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                 g32.data_ptr() if g32 is not None else None, g16.data_ptr() if g16 is not None else None, None,
                 ds32.data_ptr() if ds32 is not None else None, ds16.data_ptr() if ds16 is not None else None,
-                dgb[0].data_ptr(), dgb[1].data_ptr(), ctx.rows, _stream(s))
-        _lib.check(code, "mpf_res_ln256_backward")
+                dgb.data_ptr(), ctx.rows, ws.data_ptr(), ws.numel(), _stream(s))
+        _lib.check(code, "mpf_res_ln256_backward_det")
         dt = None
         if need_t:
             dt = ds16 if t16 else ds32
@@ -115,3 +118,15 @@ def ln256_backward(s, mean, rstd, gamma, gy, gy_plus=None):
 
 
 _ln_ws = {}
+_det_ws_cache = {}
+
+
+def _det_ws(dev, nbytes):
+    """workspace of mpf_res_ln256_backward_det per (device, stream): its ticket word is zero between calls (zero-initialised
+    here, reset by every launch), so it is shared by all LayerNorms that run on that stream"""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _det_ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(int(nbytes) + 4096, dtype=torch.uint8, device=dev)
+        _det_ws_cache[key] = ws
+    return ws

@@ -122,9 +122,9 @@ def test_decoder_inputs_kernel_matches_torch(out_dtype):
     torch.testing.assert_close(gl, le.grad, rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("switch", ["MPF_KV_BATCH", "MPF_COMPACT_MASK_GRAD", "MPF_NATIVE_LOSS_TAIL", "MPF_GN_FLATTEN", "MPF_HEADS_TALL"])
+@pytest.mark.parametrize("switch", ["MPF_KV_BATCH", "MPF_NATIVE_LOSS_TAIL", "MPF_GN_FLATTEN", "MPF_HEADS_TALL"])
 def test_round2_switches_do_not_change_the_step(switch):
-    """Every scheduling change of the second half of round 2 (key / value projections per level, compact mask-loss gradient,
+    """Every scheduling change of the second half of round 2 (key / value projections per level,
     native criterion tail, GroupNorm into the flattened encoder input, tall-linear heads) against its plainer route
     (`<switch>=0`): same losses, same gradients up to bf16 accumulation-order noise, on the AMP path with replayed draws."""
     dev = torch.device("cuda:0")
@@ -132,27 +132,21 @@ def test_round2_switches_do_not_change_the_step(switch):
     h = _build(cfg, pp, dp, dev)
     feats = {k: v.to(dev) for k, v in feats.items()}
     targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
-    # Two bf16 runs of the same step are not bit-identical (the library's split reductions are not run-to-run deterministic),
-    # and once in a few dozen runs that noise flips a Hungarian assignment of an aux layer, which moves that layer's losses
-    # by O(1).  A scheduling switch that really changed the step fails every attempt; the noise does not.
-    problems = []
-    for attempt in range(3):
-        l_on, g_on = _run(h, feats, targets, replay, cfg, fused=True)
-        os.environ[switch] = "0"
-        try:
-            l_off, g_off = _run(h, feats, targets, replay, cfg, fused=True)
-        finally:
-            os.environ.pop(switch, None)
-        assert set(g_on) == set(g_off) and set(l_on) == set(l_off)
-        bad = [(k, l_on[k], l_off[k]) for k in l_on if abs(l_on[k] - l_off[k]) > 2e-3 * max(1.0, abs(l_on[k]))]
-        worst = ("", 0.0)
-        for n in g_on:
-            a, b = g_on[n].double().flatten(), g_off[n].double().flatten()
-            rel = (a - b).norm().item() / (a.norm().item() + 1e-12)
-            if rel > worst[1]:
-                worst = (n, rel)
-        if not bad and worst[1] < 2e-2:
-            break
-        problems.append((attempt, bad[:3], worst))
-    else:
-        raise AssertionError((switch, problems))
+    # (the step is bit-reproducible run to run — no library split reductions or float atomics are left on the head's forward — so
+    # one comparison decides; a switch that moved a cost across a tie would fail every time, not now and then)
+    l_on, g_on = _run(h, feats, targets, replay, cfg, fused=True)
+    os.environ[switch] = "0"
+    try:
+        l_off, g_off = _run(h, feats, targets, replay, cfg, fused=True)
+    finally:
+        os.environ.pop(switch, None)
+    assert set(g_on) == set(g_off) and set(l_on) == set(l_off)
+    bad = [(k, l_on[k], l_off[k]) for k in l_on if abs(l_on[k] - l_off[k]) > 2e-3 * max(1.0, abs(l_on[k]))]
+    assert not bad, (switch, bad[:3])
+    worst = ("", 0.0)
+    for n in g_on:
+        a, b = g_on[n].double().flatten(), g_off[n].double().flatten()
+        rel = (a - b).norm().item() / (a.norm().item() + 1e-12)
+        if rel > worst[1]:
+            worst = (n, rel)
+    assert worst[1] < 2e-2, (switch, worst)

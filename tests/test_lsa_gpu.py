@@ -200,22 +200,14 @@ def test_criterion_device_assignment_edge_counts(counts):
         grads = torch.cat([p.grad.flatten().float() for p in h.parameters() if p.grad is not None])
         return {k: float(v.detach()) for k, v in losses.items()}, grads
 
-    # two bf16 runs are not bit-identical (the library's split reductions are not run-to-run deterministic); rarely that
-    # noise moves a cost across a tie and flips an assignment in BOTH routes' inputs differently.  A solver that disagrees
-    # with SciPy fails every attempt; the noise does not.
-    problems = []
-    for attempt in range(3):
-        l_host, g_host = run(False)
-        l_dev, g_dev = run(True)
-        assert set(l_host) == set(l_dev) and len(l_dev) == 6 * 3
-        assert torch.isfinite(g_dev).all()
-        bad = [(k, l_host[k], l_dev[k]) for k in l_host if abs(l_host[k] - l_dev[k]) > 2e-3 * max(1.0, abs(l_host[k]))]
-        rel = (g_host - g_dev).norm().item() / (g_host.norm().item() + 1e-9)
-        if not bad and rel <= 2e-2:
-            break
-        problems.append((attempt, bad[:3], rel))
-    else:
-        raise AssertionError(problems)
+    # the forward is bit-reproducible, so both routes see the same cost matrices: one comparison decides
+    l_host, g_host = run(False)
+    l_dev, g_dev = run(True)
+    assert set(l_host) == set(l_dev) and len(l_dev) == 6 * 3
+    assert torch.isfinite(g_dev).all()
+    bad = [(k, l_host[k], l_dev[k]) for k in l_host if abs(l_host[k] - l_dev[k]) > 2e-3 * max(1.0, abs(l_host[k]))]
+    rel = (g_host - g_dev).norm().item() / (g_host.norm().item() + 1e-9)
+    assert not bad and rel <= 2e-2, (bad[:3], rel)
 
 
 def test_infeasible_cost_matrix_is_reported_like_scipy():
