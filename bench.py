@@ -83,16 +83,29 @@ class TrainModel(torch.nn.Module):
         self.backbone = ResNet50()
         self.head = MPFormerHead(num_classes=num_classes, num_queries=num_queries)
 
-    on_head_backward_done = None      # callable: the gradients of every head parameter are final (FlatGradSync.launch)
+    # feature name -> callable, run when the backward pass reaches that feature map, i.e. when every parameter that was used
+    # AFTER it in the forward pass has its final gradient (FlatGradSync.launch): "res5" = the head is done (the head's nodes
+    # were created last, so autograd runs all of them before the first backbone node), "res3" = res5 and res4 are done too
+    grad_ready_hooks = None
 
     def forward(self, images, targets):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             feats = self.backbone(images.contiguous(memory_format=torch.channels_last))
-            if self.on_head_backward_done is not None and torch.is_grad_enabled():
-                fs = tuple(f for f in feats.values() if f.requires_grad)
-                cb = self.on_head_backward_done
-                torch.autograd.graph.register_multi_grad_hook(fs, lambda grads: cb(), mode="all")
+            if self.grad_ready_hooks and torch.is_grad_enabled():
+                for name, cb in self.grad_ready_hooks.items():
+                    if feats[name].requires_grad:
+                        feats[name].register_hook(lambda g, cb=cb: cb())     # (returns None: the gradient is unchanged)
             return self.head.total_loss(feats, targets)
+
+
+def grad_sync_groups(model):
+    """Three flat buckets in the order in which their gradients complete: the head (80 MB), the backbone's res5 + res4
+    (88 MB, 94 % of the backbone) and the rest (res3, res2, stem: 6 MB) — only the last one is exchanged after backward()."""
+    bb = model.backbone
+    late = list(bb.res5.parameters()) + list(bb.res4.parameters())
+    ids = {id(p) for p in late}
+    early = [p for p in bb.parameters() if id(p) not in ids]
+    return [list(model.head.parameters()), late, early]
 
 
 def build_optimizer(model):
@@ -184,15 +197,11 @@ def main():
     if a.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     assert world == a.gpus, f"WORLD_SIZE {world} != --gpus {a.gpus}"
-    # test-only overrides (tests/test_bench_world2_gpu.py): every rank on cuda:0 and a gloo process group, so that the
-    # N > 1 code path of this file runs inside a one-GPU lease; never set by the driver
-    one_device = os.environ.get("MPF_DIST_ONE_DEVICE", "0") == "1"
-    backend = os.environ.get("MPF_DIST_BACKEND", "nccl")
-    dev_index = 0 if one_device else local_rank
+    dev_index = local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     from mp_former_amd import dist as mdist
-    mdist.init_from_env(backend, dev)                    # nccl == RCCL on ROCm
+    mdist.init_from_env("nccl", dev)                     # nccl == RCCL on ROCm
 
     from mp_former_amd import _lib, _miopen
     _lib.lib()   # fail loudly if the native library is missing
@@ -203,12 +212,13 @@ def main():
         torch.backends.cudnn.benchmark = True
     model = TrainModel().to(dev).train()
     model.backbone.to(memory_format=torch.channels_last)
-    # gradient exchange: two flat buckets (head, backbone) launched from ONE autograd hook (mp_former_amd.dist.FlatGradSync);
-    # MPF_GRAD_SYNC=ddp selects torch's DistributedDataParallel (per-parameter hooks, 25 MB buckets)
+    # gradient exchange: three flat buckets (head | res5 + res4 | rest of the backbone), the first two launched from two
+    # tensor hooks while the backbone back-propagates (mp_former_amd.dist.FlatGradSync); MPF_GRAD_SYNC=ddp selects torch's
+    # DistributedDataParallel (per-parameter hooks, 25 MB buckets)
     sync = None
     if mdist.distributed() and os.environ.get("MPF_GRAD_SYNC", "flat") == "flat":
-        sync = mdist.FlatGradSync([list(model.head.parameters()), list(model.backbone.parameters())])
-        model.on_head_backward_done = lambda: sync.launch(0)
+        sync = mdist.FlatGradSync(grad_sync_groups(model))
+        model.grad_ready_hooks = {"res5": lambda: sync.launch(0), "res3": lambda: sync.launch(1)}
         ddp = model
     else:
         ddp = mdist.wrap_ddp(model, [dev_index])

@@ -103,6 +103,12 @@ class FlatGradSync:
     to overlap an exchange that xGMI finishes in about a millisecond.  Two flat buckets keep the overlap where it pays
     (behind the backbone's backward) and drop the per-parameter work.  Parameters are broadcast from rank 0 once, as DDP
     does.  A gradient that arrives for a group AFTER its launch would be lost: ``finish`` checks and raises.
+
+    Unused parameters: a parameter without a gradient on this rank contributes zeros and ends the step with the averaged
+    view as its ``.grad`` (another rank may have used it), so the optimizer steps it (weight decay, moment decay) where the
+    single-process run — whose ``.grad`` stays None — skips it.  DistributedDataParallel has the same semantics with
+    ``find_unused_parameters``; the shipped training step uses every parameter on every rank (asserted by
+    tests/test_head_gpu.py::test_head_config_A_runs_and_is_finite), so the two trajectories agree there.
     """
 
     def __init__(self, groups, broadcast=True):

@@ -1,8 +1,8 @@
 """bench.py's N > 1 code path inside a one-GPU lease: two ranks started by torch.distributed.run exactly as the driver
-starts them, both mapped to cuda:0 and talking over gloo (MPF_DIST_ONE_DEVICE / MPF_DIST_BACKEND, test-only switches:
-RCCL refuses two ranks on one device).  Everything else is the real thing — rank-dependent synthetic batches (different
-numbers of ground-truth masks per rank, hence different Qtot), the flat-bucket gradient exchange launched from the
-autograd hook while the backbone back-propagates, the device-side num_masks all-reduce, ClipAdamW on the bucket views,
+starts them, both mapped to cuda:0 and talking over gloo (tests/_bench_world2_child.py patches exactly those two things
+around an unchanged bench.py: RCCL refuses two ranks on one device).  Everything else is the real thing — rank-dependent synthetic batches (different
+numbers of ground-truth masks per rank, hence different Qtot), the three-bucket gradient exchange whose first two buckets
+are launched from tensor hooks while the backbone back-propagates (a gradient arriving after its bucket's launch raises), the device-side num_masks all-reduce, ClipAdamW on the bucket views,
 barrier + max-over-ranks timing, one JSON line from rank 0.  The ranks' parameters must still be identical after the
 averaged updates.  RCCL itself is covered at world size 1 by tests/test_rccl_gpu.py; no scaling number follows from this."""
 import json
@@ -31,10 +31,9 @@ def test_bench_two_ranks_one_device(grad_sync):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MPF_FORCE_DIST"):
         env.pop(k, None)
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MPF_DIST_ONE_DEVICE="1", MPF_DIST_BACKEND="gloo", MPF_CHECK_SYNC="1",
-               MPF_GRAD_SYNC=grad_sync)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MPF_CHECK_SYNC="1", MPF_GRAD_SYNC=grad_sync)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_bench_world2_child.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--profile-steps", "1", "--size", "512", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1400)
     assert r.returncode == 0, f"bench.py --gpus 2 failed:\n{r.stdout[-2000:]}\n{r.stderr[-6000:]}"

@@ -46,43 +46,56 @@ def _worker(rank, world, port, q):
         m2(torch.full((2, 8), float(rr + 1))).sum().backward()
         ref += m2[0].weight.grad / world
     out["grad_ref"] = ref.tolist()
-    # FlatGradSync: two flat buckets (a "head" launched early from an autograd hook, a "backbone" at finish), parameters
-    # that differ per rank before the broadcast, an unused parameter, a channels-last parameter
+    # FlatGradSync as bench.py drives it: THREE flat buckets — head | late backbone stage | early backbone stages — the first
+    # two launched from tensor hooks on the feature maps while the rest of the backbone back-propagates, the last at
+    # finish(); parameters that differ per rank before the broadcast, an unused parameter, channels-last parameters
     torch.manual_seed(10 + rank)                       # different initial weights per rank: the broadcast must fix that
-    backbone = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU()).to(memory_format=torch.channels_last)
-    head = torch.nn.ModuleDict({"a": torch.nn.Linear(4, 5), "unused": torch.nn.Linear(2, 2)})
-    sync = mdist.FlatGradSync([list(head.parameters()), list(backbone.parameters())])
-    out["w0_after_broadcast"] = backbone[0].weight.detach().flatten()[:4].tolist()
+
+    def make():
+        bb = torch.nn.ModuleDict({"stem": torch.nn.Conv2d(3, 4, 3, padding=1), "early": torch.nn.Conv2d(4, 4, 3, padding=1),
+                                  "late": torch.nn.Conv2d(4, 4, 3, padding=1)})
+        hd = torch.nn.ModuleDict({"a": torch.nn.Linear(4, 5), "b": torch.nn.Linear(4, 5), "unused": torch.nn.Linear(2, 2)})
+        return bb, hd
+
+    backbone, head = make()
+    backbone = backbone.to(memory_format=torch.channels_last)
+    names = lambda bb, hd: list(hd.named_parameters()) + list(bb.named_parameters())  # noqa: E731
+    sync = mdist.FlatGradSync([list(head.parameters()), list(backbone["late"].parameters()),
+                               list(backbone["stem"].parameters()) + list(backbone["early"].parameters())])
+    out["w0_after_broadcast"] = backbone["stem"].weight.detach().flatten()[:4].tolist()
     launched = []
 
-    def fwd(xin):
-        f = backbone(xin)
-        torch.autograd.graph.register_multi_grad_hook((f,), lambda grads: (launched.append(1), sync.launch(0)), mode="all")
-        return head["a"](f.mean((2, 3))).square().sum()
+    def net(bb, hd, xin, hooks):
+        f_early = torch.relu(bb["early"](torch.relu(bb["stem"](xin))))
+        f_late = torch.relu(bb["late"](f_early))
+        if hooks:   # the head's nodes are created last, so autograd runs them before the first backbone node
+            f_late.register_hook(lambda g: (launched.append(0), sync.launch(0))[2:] or None)
+            f_early.register_hook(lambda g: (launched.append(1), sync.launch(1))[2:] or None)
+        return (hd["a"](f_late.mean((2, 3))) + hd["b"](f_early.mean((2, 3)))).square().sum()
 
     xin = torch.full((2, 3, 6, 6), float(rank + 1)) + torch.arange(6.0).view(1, 1, 1, 6)
-    fwd(xin).backward()
+    net(backbone, head, xin, True).backward()
+    assert sync.groups[0]["launched"] and sync.groups[1]["launched"] and not sync.groups[2]["launched"]
     sync.finish()
-    out["flat_launched_early"] = len(launched)
-    out["flat_grads"] = {n: p.grad.flatten().tolist() for n, p in list(head.named_parameters()) + list(backbone.named_parameters())}
-    out["flat_strides_ok"] = all(p.grad.stride() == p.stride() for p in list(head.parameters()) + list(backbone.parameters()))
+    out["flat_launched_early"] = list(launched)
+    out["flat_grads"] = {n: p.grad.flatten().tolist() for n, p in names(backbone, head)}
+    out["flat_strides_ok"] = all(p.grad.stride() == p.stride() for _, p in names(backbone, head))
     refg = {}
     for rr in range(world):
-        b2 = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU())
-        h2 = torch.nn.ModuleDict({"a": torch.nn.Linear(4, 5), "unused": torch.nn.Linear(2, 2)})
+        b2, h2 = make()
         b2.load_state_dict(backbone.state_dict()); h2.load_state_dict(head.state_dict())
         xr = torch.full((2, 3, 6, 6), float(rr + 1)) + torch.arange(6.0).view(1, 1, 1, 6)
-        h2["a"](b2(xr).mean((2, 3))).square().sum().backward()
-        for n, p in list(h2.named_parameters()) + list(b2.named_parameters()):
+        net(b2, h2, xr, False).backward()
+        for n, p in names(b2, h2):
             g = p.grad if p.grad is not None else torch.zeros_like(p)
             refg[n] = refg.get(n, 0) + g.flatten() / world
     out["flat_ref"] = {n: v.tolist() for n, v in refg.items()}
     # a second step reuses the buckets (p.grad is the view now; zero_grad(set_to_none) as the bench does)
-    for p in list(head.parameters()) + list(backbone.parameters()):
+    for _, p in names(backbone, head):
         p.grad = None
-    fwd(xin).backward()
+    net(backbone, head, xin, True).backward()
     sync.finish()
-    out["flat_grads_step2"] = {n: p.grad.flatten().tolist() for n, p in list(head.named_parameters()) + list(backbone.named_parameters())}
+    out["flat_grads_step2"] = {n: p.grad.flatten().tolist() for n, p in names(backbone, head)}
     q.put((rank, out))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -109,7 +122,7 @@ def test_world2_gloo():
     torch.testing.assert_close(torch.tensor(res[0]["grad"]), torch.tensor(res[1]["grad"]))
     assert res[0]["w0_after_broadcast"] == res[1]["w0_after_broadcast"]
     for r in range(2):
-        assert res[r]["flat_launched_early"] == 1 and res[r]["flat_strides_ok"]
+        assert res[r]["flat_launched_early"] == [0, 1] and res[r]["flat_strides_ok"]     # the head bucket first, then the late stage
         assert set(res[r]["flat_grads"]) == set(res[r]["flat_ref"])
         for n in res[r]["flat_ref"]:
             torch.testing.assert_close(torch.tensor(res[r]["flat_grads"][n]), torch.tensor(res[r]["flat_ref"][n]), rtol=1e-5, atol=1e-6)
