@@ -23,6 +23,8 @@
 // swizzle permutes rows only inside aligned groups of 4, so both are bank-conflict free.  MFMA is issued as D^T = B.A^T so a lane
 // owns 4 consecutive output columns of one row (16-B stores, bias as float4).
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 
 #include "mpf_common.h"
@@ -293,6 +295,25 @@ struct Acc<4, true> {
 // 16-column group (bias + 4 row tiles x 3 operands) are requested together.
 __device__ float g3_const[8] = {0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, 1.f};
 
+// device address of g3_const ON THE CURRENT DEVICE: a __device__ variable has one instance per GPU, so the address is
+// cached per device ordinal (a process-wide cache would hand a second GPU a pointer into the first one's memory)
+int g3_consts(const float** out, const char* who)
+{
+    constexpr int kMaxDev = 64;
+    static std::atomic<const float*> cache[kMaxDev];
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return mpf::check(e, who);
+    const float* c = (dev >= 0 && dev < kMaxDev) ? cache[dev].load(std::memory_order_acquire) : nullptr;
+    if (!c) {
+        void* sym = nullptr;
+        if (hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g3_const)); e != hipSuccess) return mpf::check(e, who);
+        c = (const float*)sym;
+        if (dev >= 0 && dev < kMaxDev) cache[dev].store(c, std::memory_order_release);     // (racing threads store the same value)
+    }
+    *out = c;
+    return 0;
+}
+
 template <int NJ, int NI = 4, typename AccT = Acc<NJ, false>>
 __device__ __forceinline__ void g3_epilogue(const G3& p, const AccT& acc, int lane, int m_wave, int n_wave)
 {
@@ -353,7 +374,11 @@ __device__ __forceinline__ void g3_epilogue(const G3& p, const AccT& acc, int la
 // Address = scalar base (SGPR pair) + per-lane 32-bit byte offset: no 64-bit vector arithmetic per piece.
 __device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned lds_addr)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
+    // M0 is a reserved register for inline asm (a clobber on it is "undefined behaviour" to hipcc): the statement saves the
+    // compiler's M0 in an SGPR it allocates and restores it, so no clobber is declared and nothing is assumed about M0
+    unsigned saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
 
 // one output tile: 128 rows x BN columns starting at (m0, n0)
@@ -1238,12 +1263,8 @@ extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2
     p.lda = lda; p.ldc = ldc; p.ldcin = ldcin; p.plane = (int64_t)N * K;
     p.M = M; p.N = N; p.K = K; p.a2_rows = a2_rows; p.relu = relu; p.c16 = nullptr;
     {
-        static const float* consts = nullptr;
-        if (!consts) {
-            void* sym = nullptr;
-            if (hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g3_const)); e != hipSuccess) return mpf::check(e, "gemm3_tn: constants");
-            consts = (const float*)sym;
-        }
+        const float* consts = nullptr;
+        if (int rc = g3_consts(&consts, "gemm3_tn: constants")) return rc;
         p.bias_cm = bias ? 1 : 0; p.cin_cm = c_in ? 1 : 0; p.cin2_cm = c_in2 ? 1 : 0; p.gate_cm = gate ? 1 : 0;
         if (!bias) p.bias = consts;
         if (!c_in) { p.cin = consts; p.ldcin = 0; }
@@ -1316,12 +1337,8 @@ extern "C" int mpf_gemm3_tn_ex(const void* a, int a_dtype, int64_t lda, const vo
         return mpf::fail(MPF_E_SHAPE, "gemm3_tn_ex: K must be a multiple of 32, N / ldc of 4, 16-byte aligned A rows");
     if (a_dtype == MPF_F32 && c_dtype == MPF_F32)
         return mpf_gemm3_tn((const float*)a, lda, nullptr, 0, b_planes, bias, c_in, ldcin, nullptr, 0, nullptr, 0, (float*)c, ldc, M, N, K, relu, stream);
-    static const float* consts = nullptr;
-    if (!consts) {
-        void* sym = nullptr;
-        if (hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g3_const)); e != hipSuccess) return mpf::check(e, "gemm3_tn_ex: constants");
-        consts = (const float*)sym;
-    }
+    const float* consts = nullptr;
+    if (int rc = g3_consts(&consts, "gemm3_tn_ex: constants")) return rc;
     G3 p;
     p.a = (const float*)a; p.a2 = nullptr; p.bp = (const unsigned short*)b_planes;
     p.bias = bias ? bias : consts; p.bias_cm = bias ? 1 : 0;
@@ -1368,12 +1385,8 @@ extern "C" int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const flo
     const int64_t M64 = (int64_t)n_img * H * W;
     if (M64 >= (1ll << 31) / 4 || M64 * Cin >= (1ll << 40)) return mpf::fail(MPF_E_TOO_LARGE, "gemm3_conv3x3: image too large");
     G3 p;
-    static const float* consts = nullptr;
-    if (!consts) {
-        void* sym = nullptr;
-        if (hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(g3_const)); e != hipSuccess) return mpf::check(e, "gemm3_conv3x3: constants");
-        consts = (const float*)sym;
-    }
+    const float* consts = nullptr;
+    if (int rc = g3_consts(&consts, "gemm3_conv3x3: constants")) return rc;
     p.a = x; p.a2 = nullptr; p.bp = (const unsigned short*)w_planes; p.c = y;
     p.bias = bias ? bias : consts; p.bias_cm = bias ? 1 : 0;
     p.cin = consts; p.ldcin = 0; p.cin_cm = 0; p.cin2 = consts; p.ldcin2 = 0; p.cin2_cm = 0; p.gate = consts + 4; p.ldgate = 0; p.gate_cm = 0;
