@@ -7,9 +7,7 @@ native library is missing or if it is handed CPU tensors (the reference's op doe
 ``ops/src/ms_deform_attn.h:43``).
 """
 from . import _lib  # noqa: F401
-from ._miopen import use_shipped_find_db
-
-use_shipped_find_db()       # tuned MIOpen solver choice for the backbone / FPN convolutions (see _miopen.py)
+from ._miopen import use_shipped_find_db  # noqa: F401  (an explicit call: importing the package changes no environment variable)
 from .msda import (MSDeformAttn, MSDeformAttnFunction, ms_deform_attn_backward,  # noqa: F401
                    ms_deform_attn_forward)
 

@@ -70,9 +70,13 @@ __global__ __launch_bounds__(256) void class_loss_rows_kernel(ClsArgs a, float* 
         x[k] = c < a.C ? ldf<T>(row + min(c, a.C - 1)) : -INFINITY;
         mx = fmaxf(mx, x[k]);
     }
-    const int64_t t = a.target[(int64_t)l * a.tl + r];
+    // a label outside [0, C) (F.cross_entropy device-asserts on it): reads stay in range and the row's loss is NaN, so the
+    // step fails visibly instead of reading out of bounds
+    const int64_t t_raw = a.target[(int64_t)l * a.tl + r];
+    const bool t_ok = t_raw >= 0 && t_raw < a.C;
+    const int64_t t = t_ok ? t_raw : 0;
     const float xt = ldf<T>(row + t);
-    const float w = a.weight[t];
+    const float w = t_ok ? a.weight[t] : __builtin_nanf("");
     mx = wave_max(mx);
     float se = 0.f;
 #pragma unroll
@@ -113,9 +117,11 @@ __global__ __launch_bounds__(256) void class_loss_bwd_kernel(ClsArgs a, const fl
     const int l = (int)(gr / rows), r = (int)(gr - (int64_t)l * rows);
     const int n = r / a.Q, q = r - n * a.Q;
     const T* row = static_cast<const T*>(a.logits) + (int64_t)l * a.sl + (int64_t)n * a.sn + (int64_t)q * a.sq;
-    const int64_t t = a.target[(int64_t)l * a.tl + r];
+    const int64_t t_raw = a.target[(int64_t)l * a.tl + r];
+    const bool t_ok = t_raw >= 0 && t_raw < a.C;
+    const int64_t t = t_ok ? t_raw : 0;
     const float lse = a.lse[gr];
-    const float s = g[l] / a.wsum[l] * a.weight[t];
+    const float s = t_ok ? g[l] / a.wsum[l] * a.weight[t] : __builtin_nanf("");
     T* out = dlogits + gr * a.C;
 #pragma unroll
     for (int k = 0; k < kCls; ++k) {

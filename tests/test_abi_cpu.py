@@ -74,8 +74,9 @@ def test_missing_library_fails_loudly(built, monkeypatch):
 
 
 def test_shipped_miopen_find_db_is_wired(monkeypatch, tmp_path):
-    """the tuned MIOpen solver choice travels with the package: importing it points MIOPEN_USER_DB_PATH at the
-    shipped find-db unless the user already chose one (or switched it off)"""
+    """the tuned MIOpen solver choice travels with the package: use_shipped_find_db() (an explicit call — bench.py makes
+    it; importing the package leaves the environment alone) points MIOPEN_USER_DB_PATH at a private copy of the shipped
+    find-db unless the user already chose one (or switched it off)"""
     import glob
     import os
     from mp_former_amd import _miopen
@@ -84,6 +85,10 @@ def test_shipped_miopen_find_db_is_wired(monkeypatch, tmp_path):
     monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
     monkeypatch.delenv("MPF_MIOPEN_DB", raising=False)
     monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "cache"))
+    import importlib
+    import mp_former_amd
+    importlib.reload(mp_former_amd)
+    assert "MIOPEN_USER_DB_PATH" not in os.environ, "importing the package must not touch the environment"
     path = _miopen.use_shipped_find_db()
     assert path and os.path.isdir(path) and os.environ["MIOPEN_USER_DB_PATH"] == path
     # MIOpen appends to its user db: it must get a private copy, never the tracked directory

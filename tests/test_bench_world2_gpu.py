@@ -50,4 +50,6 @@ def test_bench_two_ranks_one_device(grad_sync):
     # identical parameters on both ranks after 4 averaged updates: per parameter tensor |sum_rank0 - sum_rank1| / sum|p|
     # (a tensor left out of the exchange would differ by >= 1e-5 after four AdamW steps)
     assert out["config"]["param_sync_spread"] <= 1e-7, out["config"]["param_sync_spread"]
-    assert out["roofline"]["launches"] > 0                  # the native MSDA backward ran on the profiled step
+    assert out["roofline"]["launches_per_step"] > 0         # the split-bf16 GEMMs ran on the profiled step ...
+    msda = [e for e in out["roofline"]["also"] if e["kernel"].startswith("MSDA backward")]
+    assert msda and msda[0]["launches"] > 0                 # ... and so did the native MSDA backward

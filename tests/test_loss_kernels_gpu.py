@@ -231,6 +231,23 @@ def test_class_loss_kernel_matches_cross_entropy():
         assert (got.double() - ref_in.grad).abs().max() <= tol * ref_in.grad.abs().max() + 1e-9
 
 
+def test_class_loss_out_of_range_label_is_loud_not_out_of_bounds():
+    """A label outside [0, C) (ignore_index-style -100, or a dataset with more classes than the head): F.cross_entropy
+    device-asserts; the native kernel reads nothing out of bounds and returns NaN for that output only."""
+    from mp_former_amd.criterion import _ClassLossFn
+    dev = torch.device("cuda:0")
+    L, N, Q, C = 3, 2, 9, 81
+    logits = torch.randn(L, N, Q, C, device=dev, requires_grad=True)
+    tgt = torch.randint(0, C, (L, N, Q), device=dev)
+    tgt[1, 0, 4] = C + 5
+    tgt[2, 1, 0] = -100
+    w = torch.ones(C, device=dev)
+    ce = _ClassLossFn.apply(logits, tgt, w)
+    assert bool(torch.isfinite(ce[0])) and bool(torch.isnan(ce[1])) and bool(torch.isnan(ce[2]))
+    ce[0].backward()
+    assert bool(torch.isfinite(logits.grad[0]).all())
+
+
 def test_mask_loss_finalize_kernel_matches_the_tensor_expression():
     from mp_former_amd.criterion import _MaskLossFinalizeFn
     dev = torch.device("cuda:0")

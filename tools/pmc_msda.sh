@@ -2,9 +2,14 @@
 # HBM traffic of the MSDA kernels at config B, N = 2 from rocprofv3 PMC counters (separate passes, as the guide
 # prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass), with FETCH_SIZE / WRITE_SIZE calibrated on kernels that
 # move a known byte count in the same access shapes (tools/ubench/fetch_calib.hip).  Run on the GPU box from the repo
-# root; writes gpurun_out/r02_msda_bwd_pmc_configB_N2.json (copy it to profiles/).
+# root; writes gpurun_out/${TAG}_msda_bwd_pmc_configB_N2.json (TAG defaults to r03; copy the file to profiles/).
+TAG=${1:-r03}
+export PMC_TAG=$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
+# the calibration binary is built here (it is not tracked): without it every factor would silently be 1.0 and the
+# "corrected" traffic off by ~2x
+/opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 tools/ubench/fetch_calib.hip -o tools/ubench/fetch_calib || { echo "pmc_msda: cannot build fetch_calib" >&2; exit 1; }
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   t=$(echo $c | tr ' ' '_')
   rm -rf /tmp/pmcm_$t /tmp/pmcc_$t
@@ -32,6 +37,10 @@ cal = load("pmcc", r"(calib_\w+)")
 msda = load("pmcm", r"(msda_\w+_kernel)")
 EXPECT = 512 * 1024 * 1024
 factors = {}
+need = {"calib_stream16": "FETCH_SIZE", "calib_rows16": "FETCH_SIZE", "calib_rows8": "FETCH_SIZE", "calib_write16": "WRITE_SIZE"}
+missing = [k for k, c in need.items() if k not in cal or c not in cal[k] or cal[k][c] <= 0]
+if missing:
+    raise SystemExit(f"pmc_msda: calibration kernels / counters missing ({missing}): refusing to write uncalibrated traffic")
 for k, v in cal.items():
     if k == "calib_write16":
         factors[k] = EXPECT / (v["WRITE_SIZE"] * 1024.0)
@@ -39,13 +48,15 @@ for k, v in cal.items():
         factors[k] = EXPECT / (v["FETCH_SIZE"] * 1024.0)
 # dominant read shape per kernel: 128-B rows fetched as 8 lanes x 16 B (forward, push) or 16 lanes x 8 B (pull)
 shape = {"msda_fwd_block_kernel": "calib_rows16", "msda_bwd_push_block_kernel": "calib_rows16", "msda_bwd_pull_mfma_kernel": "calib_rows8"}
+import os
 out = {"config": "B (1024x1024: S = 21504), N = 2, init-like offsets (tools/bench_msda_breakdown.py init)",
+       "calibration": "tools/ubench/fetch_calib.hip built and run in this call: kernels that move a known 512 MiB in the access shapes of the MSDA kernels",
        "source_sha256": hashlib.sha256(open("mp_former_amd/csrc/msda_block.hip", "rb").read()).hexdigest(),
        "calibration_bytes_per_counter_byte": factors, "kernels": {}}
 total = 0.0
 for k, v in msda.items():
-    f = factors.get(shape.get(k, "calib_rows16"), 1.0)
-    fw = factors.get("calib_write16", 1.0)
+    f = factors[shape.get(k, "calib_rows16")]
+    fw = factors["calib_write16"]
     rd = v.get("FETCH_SIZE", 0.0) * 1024.0 * f
     wr = v.get("WRITE_SIZE", 0.0) * 1024.0 * fw
     e = dict(v)
@@ -61,6 +72,6 @@ out["hbm_bytes_per_call"] = round(total)
 out["algorithmic_bytes_per_call"] = 1344 * 4 * 21504 * 2
 out["note"] = ("FETCH_SIZE x read_factor + WRITE_SIZE x write_factor of push + pull (+ spill); factors from tools/ubench/fetch_calib "
                "(known 512 MiB per launch in the kernels' access shapes)")
-json.dump(out, open("gpurun_out/r02_msda_bwd_pmc_configB_N2.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/%s_msda_bwd_pmc_configB_N2.json" % os.environ.get("PMC_TAG", "r03"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY

@@ -10,6 +10,5 @@ trace=$(find /tmp/prof_$tag -name 'bench_kernel_trace.csv' | head -1)
 python3 tools/prof_trace_stats.py "$trace" 3 gpurun_out/prof_$tag/steady_kernel_stats.csv
 python3 tools/prof_summary.py gpurun_out/prof_$tag/steady_kernel_stats.csv 6
 python3 tools/prof_gaps.py "$trace" 3 20 | head -3 | tee gpurun_out/prof_$tag/gaps.txt
-python3 tools/prof_segments.py "$trace" 3 22 | tee gpurun_out/prof_$tag/segments.txt
 python3 tools/prof_sequence.py "$trace" 3 2 gpurun_out/prof_$tag/sequence_step2.txt
 tail -1 gpurun_out/bench_prof_$tag.log | cut -c1-160
