@@ -26,8 +26,6 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
-#include <algorithm>
-
 #include "mpf_common.h"
 
 namespace {
@@ -641,340 +639,6 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const __hip_bfloat16
     else delta_block(dout, out, delta, Lq, N, H, b - n_tiles);
 }
 
-
-// ================================================================================================
-// Workgroup forms (the production path for H <= 8 heads).  The per-wave kernels above give every (32 queries, head,
-// key split) its own single-wave workgroup: the 8 heads and the 4 query tiles re-read the same K / V lines and the
-// same mask bytes from L2 from 32 different CUs (measured: ~300 MB of L2 traffic for the 37 MB a 16 384-key layer owns).
-// Here a WORKGROUP owns (image, key chunk, group of <= 128 queries) and its H waves are the heads:
-//   * the byte mask of the chunk [128 queries x KC keys] is staged ONCE in LDS (coalesced dword loads) and applied from
-//     there by all heads — attn_mask never comes from global memory inside the key loop;
-//   * a wave keeps ALL query tiles of its head in registers (Q fragments, O accumulators, running max / sum), so a K / V
-//     fragment is loaded once per workgroup and head and used for every query tile: K / V stream through the CU once;
-//   * one chunk covering all keys (self-attention, small levels) writes the normalised output directly — no partials,
-//     no combine launch; otherwise the partial (max, sum, O) go to the combine kernel as before.
-// ================================================================================================
-constexpr int kQT = 8;                  // 16-row query tiles per workgroup
-constexpr int kQG = 16 * kQT;           // queries per workgroup
-constexpr int kMaxKC = 256;             // keys per chunk (mask tile: 128 x (256 + 8) bytes of LDS)
-
-// mask tile [kQG][pitch] bytes, pitch = KC + 8 (rows 2 dwords off a multiple of 128 B: the dword reads of the 16 query rows
-// x 2 key groups of a half-wave hit 32 different banks); rows / keys beyond the problem read clamped (their scores are dead)
-template <bool AL>
-__device__ __forceinline__ void stage_mask_tile(unsigned char* tile, const uint8_t* mask_n, int q0, int Lq, int kb0, int Lk, int KC,
-                                                int pitch, int tid, int nthreads)
-{
-    const int dw_per_row = KC >> 2;
-    for (int idx = tid; idx < kQG * dw_per_row; idx += nthreads) {
-        const int row = idx / dw_per_row, dw = idx - row * dw_per_row;
-        const uint8_t* mrow = mask_n + (int64_t)min(q0 + row, Lq - 1) * Lk;
-        *reinterpret_cast<uint32_t*>(tile + row * pitch + dw * 4) = ld_mask4<AL>(mrow, kb0 + dw * 4, Lk);
-    }
-}
-
-template <bool AL, bool MK>
-__global__ __launch_bounds__(512) void attn_fwd_wg_kernel(AttnParams p, int KC, __hip_bfloat16* __restrict__ out, float* __restrict__ lse)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_mask[];
-    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, c16 = lane & 15, g = lane >> 4;
-    const int chunk = blockIdx.x, n = blockIdx.z;
-    const int q0 = blockIdx.y * kQG;
-    const int kb0 = chunk * KC, kb1 = min(p.Lk, kb0 + KC);
-    const int pitch = KC + 8;
-    if constexpr (MK) {
-        stage_mask_tile<AL>(s_mask, p.mask + (int64_t)n * p.mask_stride_n, q0, p.Lq, kb0, p.Lk, KC, pitch, tid, blockDim.x);
-        __syncthreads();
-    }
-    const int64_t rowE = (int64_t)p.N * p.E;
-    const __hip_bfloat16* qb = p.q + (int64_t)n * p.E + h * kHD;
-    const __hip_bfloat16* kb = p.k + (int64_t)n * p.k_img + h * kHD;
-    const __hip_bfloat16* vb = p.vt + ((int64_t)n * p.E + h * kHD) * p.Lk;
-    bf16x8 bq[kQT];
-    f32x4 o[kQT][2];
-    float m[kQT], l[kQT];
-#pragma unroll
-    for (int s = 0; s < kQT; ++s) {
-        bq[s] = ld8_rows(qb, q0 + 16 * s + c16, p.Lq, rowE, 8 * g);
-        o[s][0] = f32x4{0, 0, 0, 0}; o[s][1] = f32x4{0, 0, 0, 0};
-        m[s] = kNegInf; l[s] = 0.f;
-    }
-    const int ntile = min(kQT, (p.Lq - q0 + 15) >> 4);              // query tiles that exist (workgroup-uniform)
-    for (int kk = kb0; kk < kb1; kk += 32) {
-        bf16x8 ak[2], av[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) ak[t] = ld8_rows(kb, kk + 16 * t + c16, kb1, p.k_row, 8 * g);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const __hip_bfloat16* vr = vb + (int64_t)(16 * dt + c16) * p.Lk;
-            const bf16x4 lo = ld4_clamped<AL>(vr, kk + 4 * g, kb1), hi = ld4_clamped<AL>(vr, kk + 16 + 4 * g, kb1);
-            av[dt] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-#pragma unroll
-        for (int s = 0; s < kQT; ++s) {
-            if (s < ntile) {
-                float sc[8];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    f32x4 acc = {0, 0, 0, 0};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[t], bq[s], acc, 0, 0, 0);
-                    const int key0 = kk + 16 * t + 4 * g;
-                    uint32_t mw = 0;
-                    if constexpr (MK) mw = *reinterpret_cast<const uint32_t*>(s_mask + (16 * s + c16) * pitch + (key0 - kb0));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool dead = (key0 + r >= kb1) || ((mw >> (8 * r)) & 0xFFu);
-                        sc[4 * t + r] = dead ? kNegInf : acc[r] * p.scale;
-                    }
-                }
-                float mx = sc[0];
-#pragma unroll
-                for (int j = 1; j < 8; ++j) mx = fmaxf(mx, sc[j]);
-                mx = xmax(mx);
-                const float m_new = fmaxf(m[s], mx);
-                const float alpha = (m_new == kNegInf) ? 1.f : __expf(m[s] - m_new);
-                float ps = 0.f;
-                bf16x8 bp;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float e = (m_new == kNegInf) ? 0.f : __expf(sc[j] - m_new);
-                    ps += e;
-                    bp[j] = (__bf16)e;
-                }
-                l[s] = l[s] * alpha + ps;
-                m[s] = m_new;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    o[s][dt] *= alpha;
-                    o[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[dt], bp, o[s][dt], 0, 0, 0);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < kQT; ++s) {
-        const int qi = q0 + 16 * s + c16;
-        const float lt = xsum(l[s]);
-        if (s < ntile && qi < p.Lq) {
-            if (out) {
-                // the chunk was the whole key range: normalised output [q, n, h*32 + d] and log-sum-exp, no combine pass
-                const float inv = lt > 0.f ? 1.f / lt : 0.f;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x4 v = {(__bf16)(o[s][dt][0] * inv), (__bf16)(o[s][dt][1] * inv), (__bf16)(o[s][dt][2] * inv), (__bf16)(o[s][dt][3] * inv)};
-                    *reinterpret_cast<bf16x4*>(out + ((int64_t)qi * p.N + n) * p.E + h * kHD + 16 * dt + 4 * g) = v;
-                }
-                if (g == 0 && lse) lse[((int64_t)n * p.H + h) * p.Lq + qi] = lt > 0.f ? m[s] + __logf(lt) : kNegInf;
-            } else {
-                const int64_t row = (((int64_t)chunk * p.N + n) * p.H + h) * p.Lq + qi;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<f32x4*>(p.part_o + row * kHD + 16 * dt + 4 * g) = o[s][dt];
-                if (g == 0) { p.part_ml[row * 2] = m[s]; p.part_ml[row * 2 + 1] = lt; }
-            }
-        }
-    }
-}
-
-// dK / dV: the per-wave kernel's arithmetic with the H heads of one 32-key block in ONE workgroup and the block's mask
-// bytes [Lq x 32 keys] staged once in LDS, TRANSPOSED ([key][query]) so that a lane (= key) reads the four query rows of
-// its C-tile group as one dword (the per-wave form issued 16 single-byte global loads per lane and 32-query step)
-template <bool MK>
-__global__ __launch_bounds__(512) void attn_bwd_kv_wg_kernel(AttnBwdParams p, int LqT)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_maskT[];     // [32 keys][LqT] bytes, LqT = LqP + 4
-    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, c16 = lane & 15, g = lane >> 4;
-    const int kb = blockIdx.x * 32, n = blockIdx.z;
-    if constexpr (MK) {
-        const uint8_t* mn = p.mask + (int64_t)n * p.mask_stride_n;
-        // element (query, key): thread-strided over (query, key group of 4)
-        for (int idx = tid; idx < p.LqP * 8; idx += blockDim.x) {
-            const int qi = idx >> 3, kq = idx & 7;
-            uint32_t mw = 0x01010101u;                                  // padded query rows: dead
-            if (qi < p.Lq) {
-                const uint8_t* mrow = mn + (int64_t)qi * p.Lk;
-                mw = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mw |= (mrow[min(kb + 4 * kq + r, p.Lk - 1)] ? 1u : 0u) << (8 * r);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_maskT[(4 * kq + r) * LqT + qi] = (unsigned char)((mw >> (8 * r)) & 0xFFu);
-        }
-        __syncthreads();
-    }
-    const int64_t rowE = (int64_t)p.N * p.E;
-    const int64_t hoff = (int64_t)n * p.E + h * kHD;
-    const int64_t kvoff = (int64_t)n * p.kv_img + h * kHD, dkvoff = (int64_t)n * p.dkv_img + h * kHD;
-    bf16x8 bk[2], bv[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        const int key = kb + 16 * kt + c16;
-        bk[kt] = ld8_rows(p.k + kvoff, key, p.Lk, p.kv_row, 8 * g);
-        bv[kt] = ld8_rows(p.v + kvoff, key, p.Lk, p.kv_row, 8 * g);
-    }
-    f32x4 dkt[2][2], dvt[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) { dkt[a][b] = f32x4{0, 0, 0, 0}; dvt[a][b] = f32x4{0, 0, 0, 0}; }
-    const float* lse = p.lse + ((int64_t)n * p.H + h) * p.Lq;
-    const float* dl = p.delta + ((int64_t)n * p.H + h) * p.Lq;
-    const __hip_bfloat16* qTb = p.qT + ((int64_t)n * p.E + h * kHD) * p.LqP;
-    const __hip_bfloat16* doTb = p.doT + ((int64_t)n * p.E + h * kHD) * p.LqP;
-    for (int qq = 0; qq < p.Lq; qq += 32) {
-        bf16x8 aq[2], ado[2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            const int qi = qq + 16 * qt + c16;
-            aq[qt] = ld8_rows(p.q + hoff, qi, p.Lq, rowE, 8 * g);
-            ado[qt] = ld8_rows(p.dout + hoff, qi, p.Lq, rowE, 8 * g);
-        }
-        float ls[2][4], de[2][4];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qi = qq + 16 * qt + 4 * g + r;
-                const float lv = lse[min(qi, p.Lq - 1)], dv_ = dl[min(qi, p.Lq - 1)];
-                ls[qt][r] = qi < p.Lq ? lv : 0.f;
-                de[qt][r] = qi < p.Lq ? dv_ : 0.f;
-            }
-        bf16x8 adoT[2], aqT[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const int64_t ro = (int64_t)(16 * dt + c16) * p.LqP;
-            adoT[dt] = load4x2<true>(doTb + ro, qq + 4 * g, qq + 16 + 4 * g, p.LqP);
-            aqT[dt] = load4x2<true>(qTb + ro, qq + 4 * g, qq + 16 + 4 * g, p.LqP);
-        }
-        bf16x8 bp[2], bds[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const int key = kb + 16 * kt + c16;
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                f32x4 z = {0, 0, 0, 0};
-                const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[qt], bk[kt], z, 0, 0, 0);
-                const f32x4 dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado[qt], bv[kt], z, 0, 0, 0);
-                uint32_t mw = 0;
-                if constexpr (MK) mw = *reinterpret_cast<const uint32_t*>(s_maskT + (16 * kt + c16) * LqT + qq + 16 * qt + 4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qi = qq + 16 * qt + 4 * g + r;
-                    const bool dead = (qi >= p.Lq) || (key >= p.Lk) || (ls[qt][r] == kNegInf) || ((mw >> (8 * r)) & 0xFFu);
-                    const float pr = dead ? 0.f : __expf(sacc[r] * p.scale - ls[qt][r]);
-                    const float ds = pr * (dpacc[r] - de[qt][r]) * p.scale;
-                    bp[kt][4 * qt + r] = (__bf16)pr;
-                    bds[kt][4 * qt + r] = (__bf16)ds;
-                }
-            }
-        }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                dvt[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adoT[dt], bp[kt], dvt[kt][dt], 0, 0, 0);
-                dkt[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqT[dt], bds[kt], dkt[kt][dt], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        const int key = kb + 16 * kt + c16;
-        if (key < p.Lk) {
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const bf16x4 kk = {(__bf16)dkt[kt][dt][0], (__bf16)dkt[kt][dt][1], (__bf16)dkt[kt][dt][2], (__bf16)dkt[kt][dt][3]};
-                const bf16x4 vv = {(__bf16)dvt[kt][dt][0], (__bf16)dvt[kt][dt][1], (__bf16)dvt[kt][dt][2], (__bf16)dvt[kt][dt][3]};
-                *reinterpret_cast<bf16x4*>(p.dk + dkvoff + (int64_t)key * p.dkv_row + 16 * dt + 4 * g) = kk;
-                *reinterpret_cast<bf16x4*>(p.dv + dkvoff + (int64_t)key * p.dkv_row + 16 * dt + 4 * g) = vv;
-            }
-        }
-    }
-}
-
-// dQ: the forward's workgroup form (heads = waves, all query tiles of a head in one wave's registers, mask tile in LDS)
-template <bool AL, bool MK>
-__global__ __launch_bounds__(512) void attn_bwd_q_wg_kernel(AttnBwdParams p, int KC, __hip_bfloat16* __restrict__ dq_out)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_mask[];
-    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6, c16 = lane & 15, g = lane >> 4;
-    const int chunk = blockIdx.x, n = blockIdx.z;
-    const int q0 = blockIdx.y * kQG;
-    const int kb0 = chunk * KC, kb1 = min(p.Lk, kb0 + KC);
-    const int pitch = KC + 8;
-    if constexpr (MK) {
-        stage_mask_tile<AL>(s_mask, p.mask + (int64_t)n * p.mask_stride_n, q0, p.Lq, kb0, p.Lk, KC, pitch, tid, blockDim.x);
-        __syncthreads();
-    }
-    const int64_t rowE = (int64_t)p.N * p.E;
-    const int64_t hoff = (int64_t)n * p.E + h * kHD;
-    const int64_t kvoff = (int64_t)n * p.kv_img + h * kHD;
-    const __hip_bfloat16* kTb = p.kT + ((int64_t)n * p.E + h * kHD) * p.Lk;
-    bf16x8 bq[kQT], bdo[kQT];
-    float ls[kQT], de[kQT];
-    f32x4 dq[kQT][2];
-#pragma unroll
-    for (int s = 0; s < kQT; ++s) {
-        const int qi = q0 + 16 * s + c16;
-        bq[s] = ld8_rows(p.q + hoff, qi, p.Lq, rowE, 8 * g);
-        bdo[s] = ld8_rows(p.dout + hoff, qi, p.Lq, rowE, 8 * g);
-        const float lv = p.lse[((int64_t)n * p.H + h) * p.Lq + min(qi, p.Lq - 1)], dv_ = p.delta[((int64_t)n * p.H + h) * p.Lq + min(qi, p.Lq - 1)];
-        ls[s] = qi < p.Lq ? lv : kNegInf;
-        de[s] = qi < p.Lq ? dv_ : 0.f;
-        dq[s][0] = f32x4{0, 0, 0, 0}; dq[s][1] = f32x4{0, 0, 0, 0};
-    }
-    const int ntile = min(kQT, (p.Lq - q0 + 15) >> 4);
-    for (int kk = kb0; kk < kb1; kk += 32) {
-        bf16x8 ak[2], av[2], akT[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int key = kk + 16 * t + c16;
-            ak[t] = ld8_rows(p.k + kvoff, key, kb1, p.kv_row, 8 * g);
-            av[t] = ld8_rows(p.v + kvoff, key, kb1, p.kv_row, 8 * g);
-        }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) akT[dt] = load4x2<AL>(kTb + (int64_t)(16 * dt + c16) * p.Lk, kk + 4 * g, kk + 16 + 4 * g, kb1);
-#pragma unroll
-        for (int s = 0; s < kQT; ++s) {
-            if (s < ntile) {
-                bf16x8 bds;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    f32x4 z = {0, 0, 0, 0};
-                    const f32x4 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[t], bq[s], z, 0, 0, 0);
-                    const f32x4 dpacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[t], bdo[s], z, 0, 0, 0);
-                    const int key0 = kk + 16 * t + 4 * g;
-                    uint32_t mw = 0;
-                    if constexpr (MK) mw = *reinterpret_cast<const uint32_t*>(s_mask + (16 * s + c16) * pitch + (key0 - kb0));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool dead = (key0 + r >= kb1) || ((mw >> (8 * r)) & 0xFFu) || (ls[s] == kNegInf);
-                        const float pr = dead ? 0.f : __expf(sacc[r] * p.scale - ls[s]);
-                        bds[4 * t + r] = (__bf16)(pr * (dpacc[r] - de[s]) * p.scale);
-                    }
-                }
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) dq[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(akT[dt], bds, dq[s][dt], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < kQT; ++s) {
-        const int qi = q0 + 16 * s + c16;
-        if (s < ntile && qi < p.Lq) {
-            if (dq_out) {
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x4 v = {(__bf16)dq[s][dt][0], (__bf16)dq[s][dt][1], (__bf16)dq[s][dt][2], (__bf16)dq[s][dt][3]};
-                    *reinterpret_cast<bf16x4*>(dq_out + ((int64_t)qi * p.N + n) * p.E + h * kHD + 16 * dt + 4 * g) = v;
-                }
-            } else {
-                const int64_t row = (((int64_t)chunk * p.N + n) * p.H + h) * p.Lq + qi;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<f32x4*>(p.part_dq + row * kHD + 16 * dt + 4 * g) = dq[s][dt];
-            }
-        }
-    }
-}
-
 }  // namespace
 
 // Key splits of the forward / dQ kernels: one WAVE per (32 queries, head, image, split) and each wave
@@ -992,40 +656,10 @@ static int attn_splits(int Lq, int Lk, int N, int H)
     return splits < 1 ? 1 : splits;
 }
 
-// Workgroup forms: keys per chunk (a multiple of 32, at most kMaxKC) and number of chunks.  Key ranges of up to kMaxKC keys
-// are ONE chunk (direct output, no combine pass); longer ones are cut so that ~256 workgroups exist, in chunks of >= 128
-// keys (every chunk costs a partial (max, sum, O) of the whole query set).
-static int g_attn_wg = 1;          // mpf_set_option("attn_wg", 0): the per-wave kernels (tests compare the two)
-static void attn_wg_chunks(int Lq, int Lk, int N, int* KC, int* chunks)
-{
-    const int qgroups = (Lq + kQG - 1) / kQG;
-    int kc;
-    if (Lk <= kMaxKC) {
-        kc = (Lk + 31) & ~31;
-    } else {
-        const int want = std::max(1, 256 / std::max(1, N * qgroups));
-        kc = (((Lk + want - 1) / want) + 31) & ~31;
-        kc = std::min(std::max(kc, 128), kMaxKC);
-    }
-    *KC = kc;
-    *chunks = (Lk + kc - 1) / kc;
-}
-static bool attn_wg_ok(int H) { return g_attn_wg && H >= 1 && H <= 8; }     // one wave per head, <= 512 threads (256 VGPRs)
-
-namespace mpf {
-int set_attn_option(const char* key, int v)
-{
-    if (!strcmp(key, "attn_wg")) { g_attn_wg = v; return 0; }
-    return 1;
-}
-}  // namespace mpf
-
 extern "C" size_t mpf_attn_workspace_bytes(int Lq, int Lk, int N, int H)
 {
     if (Lq <= 0 || Lk <= 0 || N <= 0 || H <= 0) return 0;
-    int KC, chunks;
-    attn_wg_chunks(Lq, Lk, N, &KC, &chunks);
-    const int splits = std::max(attn_splits(Lq, Lk, N, H), chunks);
+    const int splits = attn_splits(Lq, Lk, N, H);
     return (size_t)splits * N * H * Lq * (kHD + 2) * sizeof(float);
 }
 
@@ -1059,31 +693,6 @@ extern "C" int mpf_attn_forward_kv(const void* q, const void* k, int64_t k_row_s
     p.splits = (Lk + p.keys_per_split - 1) / p.keys_per_split;          // (rounding up to 32 keys may need fewer)
     p.part_o = (float*)workspace;
     p.part_ml = p.part_o + (size_t)p.splits * N * H * Lq * kHD;
-    if (attn_wg_ok(H)) {
-        int KC, chunks;
-        attn_wg_chunks(Lq, Lk, N, &KC, &chunks);
-        p.splits = chunks; p.keys_per_split = KC;
-        p.part_o = (float*)workspace;
-        p.part_ml = p.part_o + (size_t)chunks * N * H * Lq * kHD;
-        const dim3 grid(chunks, (Lq + kQG - 1) / kQG, N), block(64 * H);
-        const size_t lds = mask ? (size_t)kQG * (KC + 8) : 0;
-        const bool al = (Lk & 3) == 0 && ((uintptr_t)p.vt & 7) == 0 && (!mask || ((uintptr_t)mask & 3) == 0);
-        __hip_bfloat16* direct = chunks == 1 ? (__hip_bfloat16*)out : nullptr;
-        mpf::prof_begin(st);
-        mpf::set_kernel("attn_fwd_wg_kernel");
-        if (al && mask) hipLaunchKernelGGL((attn_fwd_wg_kernel<true, true>), grid, block, lds, st, p, KC, direct, lse);
-        else if (al) hipLaunchKernelGGL((attn_fwd_wg_kernel<true, false>), grid, block, lds, st, p, KC, direct, lse);
-        else if (mask) hipLaunchKernelGGL((attn_fwd_wg_kernel<false, true>), grid, block, lds, st, p, KC, direct, lse);
-        else hipLaunchKernelGGL((attn_fwd_wg_kernel<false, false>), grid, block, lds, st, p, KC, direct, lse);
-        mpf::prof_end("attn_fwd_kernel<wg>", st, 2.0 * ((double)Lk * N * p.E * 2 + (double)Lq * N * p.E) + (mask ? (double)N * Lq * Lk : 0.0),
-                      4.0 * Lq * (double)Lk * p.E * N);      // QK^T + PV
-        if (chunks > 1) {
-            const int total = N * H * Lq * kHD;
-            hipLaunchKernelGGL(attn_combine_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p.part_o, p.part_ml,
-                               (__hip_bfloat16*)out, lse, Lq, N, H, p.E, chunks);
-        }
-        return mpf::check(hipGetLastError(), "mpf_attn_forward");
-    }
     constexpr int QS = 2;
     const int qtiles = (Lq + 16 * QS - 1) / (16 * QS);
     mpf::prof_begin(st);
@@ -1146,35 +755,6 @@ extern "C" int mpf_attn_backward_kv(const void* q, const void* k, const void* v,
     p.keys_per_split = (((Lk + p.splits - 1) / p.splits) + 31) & ~31;
     p.splits = (Lk + p.keys_per_split - 1) / p.keys_per_split;          // (rounding up to 32 keys may need fewer)
     const double bytes = 2.0 * (4.0 * Lk * N * p.E + 4.0 * Lq * N * p.E) + (mask ? 2.0 * N * Lq * Lk : 0.0);
-    if (attn_wg_ok(H)) {
-        const dim3 block(64 * H);
-        const int LqT = LqP + 4;
-        mpf::prof_begin(st);
-        mpf::set_kernel("attn_bwd_kv_wg_kernel");
-        if (mask) hipLaunchKernelGGL(attn_bwd_kv_wg_kernel<true>, dim3((Lk + 31) / 32, 1, N), block, (size_t)32 * LqT, st, p, LqT);
-        else hipLaunchKernelGGL(attn_bwd_kv_wg_kernel<false>, dim3((Lk + 31) / 32, 1, N), block, 0, st, p, LqT);
-        mpf::prof_end("attn_bwd_kv_kernel<wg>", st, bytes * 0.5, 8.0 * Lq * (double)Lk * p.E * N);   // S, dP, dV, dK
-        int KC, chunks;
-        attn_wg_chunks(Lq, Lk, N, &KC, &chunks);
-        p.splits = chunks; p.keys_per_split = KC;
-        const dim3 grid(chunks, (Lq + kQG - 1) / kQG, N);
-        const size_t lds = mask ? (size_t)kQG * (KC + 8) : 0;
-        const bool al = (Lk & 3) == 0 && ((uintptr_t)p.kT & 7) == 0 && (!mask || ((uintptr_t)mask & 3) == 0);
-        __hip_bfloat16* direct = chunks == 1 ? (__hip_bfloat16*)dq : nullptr;
-        mpf::prof_begin(st);
-        mpf::set_kernel("attn_bwd_q_wg_kernel");
-        if (al && mask) hipLaunchKernelGGL((attn_bwd_q_wg_kernel<true, true>), grid, block, lds, st, p, KC, direct);
-        else if (al) hipLaunchKernelGGL((attn_bwd_q_wg_kernel<true, false>), grid, block, lds, st, p, KC, direct);
-        else if (mask) hipLaunchKernelGGL((attn_bwd_q_wg_kernel<false, true>), grid, block, lds, st, p, KC, direct);
-        else hipLaunchKernelGGL((attn_bwd_q_wg_kernel<false, false>), grid, block, lds, st, p, KC, direct);
-        mpf::prof_end("attn_bwd_q_kernel<wg>", st, bytes * 0.5, 6.0 * Lq * (double)Lk * p.E * N);  // S, dP, dQ
-        if (chunks > 1) {
-            const int total = N * H * Lq * kHD;
-            hipLaunchKernelGGL(attn_sum_splits_kernel, dim3((total + 255) / 256), dim3(256), 0, st, p.part_dq, (__hip_bfloat16*)dq, Lq, N, H,
-                               p.E, chunks);
-        }
-        return mpf::check(hipGetLastError(), "mpf_attn_backward");
-    }
     mpf::prof_begin(st);
     mpf::set_kernel("attn_bwd_kv_kernel");
     if (mask) hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, dim3((Lk + 31) / 32, H, N), dim3(64), 0, st, p);

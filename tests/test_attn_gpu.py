@@ -44,27 +44,15 @@ def _problem(Lq, Lk, N, mask_kind, dev, seed):
 
 
 CASES = [(100, 1024, 2, "3d"), (117, 4096, 2, "3d"), (123, 16384, 1, "3d"), (100, 64, 2, "3d"),
-         (117, 117, 2, "2d"), (100, 100, 1, None), (37, 1000, 3, "3d"), (214, 214, 2, "2d"), (300, 2048, 1, "3d"), (130, 260, 2, "3d")]
-# (300 queries: three query groups of the workgroup kernels; 260 keys: two chunks, the second one of 4 keys)
-
-
-@pytest.fixture(params=["wg", "wave"])
-def form(request):
-    """wg: the workgroup kernels (heads = waves, mask tile in LDS; the production path); wave: the per-wave kernels"""
-    from mp_former_amd import _lib
-    _lib.set_option("attn_wg", 1 if request.param == "wg" else 0)
-    yield request.param
-    _lib.set_option("attn_wg", 1)
+         (117, 117, 2, "2d"), (100, 100, 1, None), (37, 1000, 3, "3d"), (214, 214, 2, "2d")]
 
 
 @pytest.mark.parametrize("Lq,Lk,N,mask_kind", CASES)
-def test_attention_forward_matches_fp32_reference(Lq, Lk, N, mask_kind, form):
-    from mp_former_amd import _lib
+def test_attention_forward_matches_fp32_reference(Lq, Lk, N, mask_kind):
     from mp_former_amd.attention import attention_core
     dev = torch.device("cuda:0")
     q, k, v, mask = _problem(Lq, Lk, N, mask_kind, dev, Lq * 7 + Lk)
     out = attention_core(q, k, v, mask, 8)
-    assert ("wg" in _lib.last_kernel()) == (form == "wg") or "combine" in _lib.last_kernel(), _lib.last_kernel()
     ref = _ref(q, k, v, mask, 8)
     err = (out.float() - ref).abs().max().item()
     assert err < 2e-2 * max(1.0, v.float().abs().max().item()), err
@@ -72,7 +60,7 @@ def test_attention_forward_matches_fp32_reference(Lq, Lk, N, mask_kind, form):
 
 
 @pytest.mark.parametrize("Lq,Lk,N,mask_kind", CASES)
-def test_attention_backward_matches_fp32_autograd(Lq, Lk, N, mask_kind, form):
+def test_attention_backward_matches_fp32_autograd(Lq, Lk, N, mask_kind):
     """dq, dk, dv of the native backward vs autograd through the fp32 reference on the same bf16
     inputs; tolerance 3 % of the gradient's max-abs (bf16 P / dS operands), measured ~1 %."""
     from mp_former_amd.attention import attention_core
