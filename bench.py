@@ -126,11 +126,9 @@ def build_optimizer(model):
                 wd = 0.0
             buckets.setdefault((lr, wd), []).append(p)   # 4 groups -> 4 fused multi-tensor launches
     groups = [{"params": ps, "lr": lr, "weight_decay": wd} for (lr, wd), ps in buckets.items()]
-    if os.environ.get("MPF_NATIVE_OPTIM", "1") == "1":
-        # full-model clip (CLIP_VALUE 0.01, train_net.py:316-320) + AdamW in three native launches
-        from mp_former_amd.optim import ClipAdamW
-        return ClipAdamW(groups, lr=1e-4, max_norm=0.01)
-    return torch.optim.AdamW(groups, lr=1e-4, fused=True)
+    # full-model clip (CLIP_VALUE 0.01, train_net.py:316-320) + AdamW in three native launches
+    from mp_former_amd.optim import ClipAdamW
+    return ClipAdamW(groups, lr=1e-4, max_norm=0.01)
 
 
 def _cpu_baseline_one(size, timed_steps, threads):
@@ -224,7 +222,6 @@ def main():
     else:
         ddp = mdist.wrap_ddp(model, [dev_index])
     opt = build_optimizer(model)
-    params = [p for p in model.parameters() if p.requires_grad]
     batches = [synth_batch(a.batch, a.size, 80, 1000 * rank + i, dev) for i in range(4)]
 
     def step(i):
@@ -234,8 +231,6 @@ def main():
         loss.backward()
         if sync is not None:
             sync.finish()
-        if not hasattr(opt, "max_norm"):      # stock AdamW: separate full-model clip (train_net.py:316-320)
-            torch.nn.utils.clip_grad_norm_(params, 0.01, foreach=True)
         opt.step()
         return loss
 

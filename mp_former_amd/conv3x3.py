@@ -2,8 +2,7 @@
 GEMM: forward and input gradient are ONE GEMM each with K = 9 * Cin over channel-last planes (``mpf_gemm3_conv3x3``:
 the A rows of a K step are read at the tap's (dy, dx) shift, taps off the image contribute zeros); the weight
 gradient stays MIOpen's (``aten.convolution_backward``), which is already at the rate the NT kernel would reach.
-``MPF_CONV3X3_GEMM3=0`` keeps the library convolution."""
-import os
+Shapes outside the kernel (channel counts, alignment) keep the library convolution."""
 
 import torch
 from torch.autograd import Function
@@ -14,7 +13,7 @@ from .groupnorm import is_cl_plane
 
 
 def enabled():
-    return os.environ.get("MPF_CONV3X3_GEMM3", "1") == "1"
+    return True
 
 
 def supported(x, weight):
@@ -64,7 +63,7 @@ class _Conv3x3Fn(Function):
                                                     torch.cuda.current_stream(x.device).cuda_stream)
             _lib.check(code, "mpf_gemm3_conv3x3")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            if W % 8 == 0 and Cin % 128 == 0 and os.environ.get("MPF_CONV3X3_WGRAD", "1") == "1":
+            if W % 8 == 0 and Cin % 128 == 0:
                 dw, db = _wgrad_native(gy, x, N, H, W, Cin, Cout, ctx.has_bias)
             else:
                 _, dw, db = torch.ops.aten.convolution_backward(
@@ -112,12 +111,10 @@ def _planes_any(x):
 
 
 def supported_1x1(x, weight):
-    if not (os.environ.get("MPF_CONV1X1_GEMM3", "1") == "1" and _planes_any(x) and weight.dtype == torch.float32 and weight.dim() == 4):
+    if not (_planes_any(x) and weight.dtype == torch.float32 and weight.dim() == 4):
         return False
     N, C, H, W = x.shape
     Cout, Cin, kh, kw = weight.shape
-    if x.dtype == torch.bfloat16 and os.environ.get("MPF_CONV1X1_BF16_IN", "1") != "1":
-        return False
     return kh == 1 and kw == 1 and Cin == C and C % 32 == 0 and Cout % 32 == 0
 
 

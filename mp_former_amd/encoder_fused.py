@@ -18,7 +18,6 @@ inactive; ``MPF_FUSED_ENCODER=0`` selects the layer-by-layer modules (same resul
 tests/test_encoder_fused_gpu.py).
 """
 import math
-import os
 
 import torch
 from torch.autograd import Function
@@ -60,13 +59,12 @@ def _balanced_rps(R, M, N, device, base=1 << 30):
     2 x CU workgroup slots (more rounds only if the output alone has more tiles than slots): with round 1's 512-row
     splits a 256 x 256 gradient at R = 43 008 was 336 workgroups (0.66 of a round) and a 256 x 1024 one 1 344 (2.6
     rounds, run as 3) with 84 partial results to sum; now 492 / 512 workgroups and 123 / 32 partials.  Same tiles, same
-    products — only the split boundaries move (``MPF_WGRAD_BASE=512`` restores the old choice)."""
+    products — only the split boundaries move."""
     slots = _slots.get(device)
     if slots is None:
         slots = 2 * torch.cuda.get_device_properties(device).multi_processor_count
         _slots[device] = slots
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    base = int(os.environ.get("MPF_WGRAD_BASE", base))
     rounds = max(1, -(-tiles * max(1, R // base) // slots))          # rounds that `base`-row splits would take
     ns = max(1, rounds * slots // tiles)
     rps = max(128, ((-(-R // ns)) + 31) // 32 * 32)
@@ -75,8 +73,7 @@ def _balanced_rps(R, M, N, device, base=1 << 30):
 
 def _wgrad(g2, x2, rps):
     """dW[out, in] = g2^T . x2 and the bias gradient colsum(g2), both from the split-K NT GEMM."""
-    if os.environ.get("MPF_WGRAD_BALANCE", "1") == "1":
-        rps = _balanced_rps(g2.shape[0], g2.shape[1], x2.shape[1], g2.device)
+    rps = _balanced_rps(g2.shape[0], g2.shape[1], x2.shape[1], g2.device)
     c, ca, _ = gemm3_nt(g2, x2, rps, want_csum_a=True)
     return nt_reduce(c, ca)
 

@@ -2,12 +2,11 @@
 
 Channel-last planes (what MIOpen's fp32 convolutions return) take csrc/groupnorm_cl.hip: chunked statistics
 with a Chan merge, ONE apply pass (optionally fused with the following ReLU or with the FPN top-down sum
-``+ upsample2x(top)``) and a native backward, all without leaving the layout (``MPF_GN_CL=0`` turns this off).
+``+ upsample2x(top)``) and a native backward, all without leaving the layout (shapes outside the kernels keep the library GroupNorm).
 Contiguous NCHW input takes round 1's path: ``mpf_group_stats`` (rows cut into chunks; torch's
 one-workgroup-per-row moments fill 64 of 256 CUs at batch 2), an element-wise apply, and aten's
 ``native_group_norm_backward``.  Same parameters and state-dict keys as ``nn.GroupNorm``; other devices /
 dtypes take the stock implementation."""
-import os
 
 import torch
 from torch import nn
@@ -57,8 +56,7 @@ def to_nchw(x):
     # encoder memory is such a view)
     if (x.dim() == 4 and x.dtype == torch.float32 and x.is_cuda and x.stride(1) == 1 and x.stride(3) == x.shape[1]
             and x.stride(2) == x.shape[3] * x.shape[1] and x.stride(0) % 4 == 0
-            and not x.is_contiguous() and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0
-            and os.environ.get("MPF_FAST_TRANSPOSE", "1") == "1"):
+            and not x.is_contiguous() and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0):
         return _ToNCHW.apply(x)
     return x.contiguous()
 
@@ -234,7 +232,7 @@ def group_norm_flatten(norms, xs):
 
 
 def cl_enabled():
-    return os.environ.get("MPF_GN_CL", "1") == "1"
+    return True
 
 
 class GroupNorm(nn.GroupNorm):

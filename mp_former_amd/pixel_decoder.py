@@ -353,7 +353,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                     out.append(self.output_convs[idx](lat.norm.forward_cl(z, top=out[-1])))
                     continue
             cur_fpn = self.lateral_convs[idx](x.float())
-            top = to_nchw(out[-1]) if os.environ.get("MPF_FPN_NCHW_TOP", "1") == "1" else out[-1]
+            top = to_nchw(out[-1])
             y = cur_fpn + F.interpolate(top, size=cur_fpn.shape[-2:], mode="bilinear", align_corners=False)
             out.append(self.output_convs[idx](y))
         multi_scale_features = out[:self.maskformer_num_feature_levels]

@@ -52,15 +52,20 @@ class _ResLN(Function):
         if g16 is not None:
             g16 = g16.contiguous()
         lib = _lib.lib()
-        ws = _det_ws(s.device, lib.mpf_res_ln256_backward_det_workspace_bytes(ctx.rows))
-        with torch.cuda.device(s.device):
-            # parameter gradients: per-workgroup partials summed in a fixed order by the last workgroup (no float atomics)
-            code = lib.mpf_res_ln256_backward_det(
-                s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+        args = (s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                 g32.data_ptr() if g32 is not None else None, g16.data_ptr() if g16 is not None else None, None,
-                ds32.data_ptr() if ds32 is not None else None, ds16.data_ptr() if ds16 is not None else None,
-                dgb.data_ptr(), ctx.rows, ws.data_ptr(), ws.numel(), _stream(s))
-        _lib.check(code, "mpf_res_ln256_backward_det")
+                ds32.data_ptr() if ds32 is not None else None, ds16.data_ptr() if ds16 is not None else None)
+        with torch.cuda.device(s.device):
+            # parameter gradients without float atomics (bit-reproducible): per-workgroup partials summed in a fixed order —
+            # by the workgroup that arrives last (one launch) for a few hundred rows, by a parallel second launch beyond
+            if ctx.rows <= 1024:
+                ws = _det_ws(s.device, lib.mpf_res_ln256_backward_det_workspace_bytes(ctx.rows))
+                code = lib.mpf_res_ln256_backward_det(*args, dgb.data_ptr(), ctx.rows, ws.data_ptr(), ws.numel(), _stream(s))
+            else:
+                ws = _det_ws(s.device, lib.mpf_res_ln256_backward_workspace_bytes(ctx.rows) + 256)
+                code = lib.mpf_res_ln256_backward_ws(*args, dgb[0].data_ptr(), dgb[1].data_ptr(), ctx.rows, ws.data_ptr() + 256,
+                                                     ws.numel() - 256, _stream(s))
+        _lib.check(code, "mpf_res_ln256_backward")
         dt = None
         if need_t:
             dt = ds16 if t16 else ds32

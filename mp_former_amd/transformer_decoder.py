@@ -261,9 +261,9 @@ def linear(x, w, b=None, relu=False):
     """relu?(F.linear(x, w, b)).  bf16 activations with a few hundred rows (the query side of the decoder
     under autocast) run on the small-row MFMA GEMM with the ReLU / its backward gate / the bias gradient
     fused (small_linear.py); everything else is the library GEMM."""
-    if _small_ok(x, w, b) and os.environ.get("MPF_SMALL_LINEAR", "1") == "1":
+    if _small_ok(x, w, b):
         return small_linear(x, w, b, relu)
-    if not relu and _tall_ok(x, w, b) and os.environ.get("MPF_TALL_LINEAR", "1") == "1":
+    if not relu and _tall_ok(x, w, b):
         return tall_linear(x, w, b)         # library forward / dX, native split-over-rows weight gradient
     y = F.linear(x, w, b)
     return F.relu(y) if relu else y
@@ -504,7 +504,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         parameters stay fp32 modules (autocast runs them in fp32 anyway)."""
         named = [(n, p) for n, p in self.named_parameters()
                  if not (".norm." in n or n.startswith("decoder_norm") or n.startswith(("query_feat", "level_embed", "label_enc")))]
-        if torch.is_autocast_enabled() and named and named[0][1].is_cuda and os.environ.get("MPF_GROUPED_CAST", "1") == "1":
+        if torch.is_autocast_enabled() and named and named[0][1].is_cuda:
             chunks = [3 if "in_proj" in n else 1 for n, _ in named]
             cast = _CastParams.apply(torch.get_autocast_dtype("cuda"), chunks, *[p for _, p in named])
             out, k = {}, 0
@@ -643,7 +643,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             Hi, Wi = size_list[-1]
             if (xi.is_cuda and xi.dtype == torch.float32 and xi.shape[1] % 8 == 0 and xi.stride(1) == 1 and xi.stride(2) == Wi * xi.stride(3)
                     and xi.stride(3) % 4 == 0 and xi.stride(0) % 4 == 0 and xi.data_ptr() % 16 == 0
-                    and (not amp or adt == torch.bfloat16) and os.environ.get("MPF_DEC_INPUTS", "1") == "1"):
+                    and (not amp or adt == torch.bfloat16)):
                 # the pixel decoder hands over channel-last views of the encoder memory: one native pass
                 key = (Hi, Wi, xi.device)
                 pos_t = self._pos_t.get(key)
@@ -686,7 +686,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         # fused mask head (AMP, 256 channels): the features resized ONCE per step to each level grid; the per-layer mask
         # is then a [Qtot x 256] x [256 x HW_l] MFMA product whose sign goes straight to the byte mask
         pooled = [None] * self.num_feature_levels
-        if (amp and adt == torch.bfloat16 and mask_features.shape[1] == 256 and os.environ.get("MPF_FUSED_MASK_HEAD", "1") == "1"
+        if (amp and adt == torch.bfloat16 and mask_features.shape[1] == 256
                 and all((hh * ww) % 16 == 0 for hh, ww in size_list)):
             with torch.no_grad():
                 done = {}
