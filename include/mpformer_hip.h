@@ -735,6 +735,13 @@ int mpf_res_ln256_backward(const float* s, const float* mean, const float* rstd,
                            int rows, void* stream);
 /* The same with dgamma / dbeta reduced through per-workgroup partials in a fixed order (no float atomics: deterministic, and
  * the two vectors need no zero-initialisation).  workspace: mpf_res_ln256_backward_workspace_bytes(rows) bytes. */
+/* The two halves of mpf_res_ln256_backward_ws as separate calls (several LayerNorm backwards, ONE reduce launch): `partials`
+ * of LayerNorm z at partials_base + z * stride_bytes, each mpf_res_ln256_backward_workspace_bytes(rows) bytes; out[z][2][256] =
+ * (dgamma, dbeta) of LayerNorm z, summed in a fixed order. */
+int mpf_res_ln256_backward_partial(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                                   const void* gy16, const float* gy_plus, float* ds32, void* ds16, int rows, void* partials,
+                                   size_t partials_bytes, void* stream);
+int mpf_ln_partial_reduce(const void* partials, size_t stride_bytes, int rows, int n_ln, float* out, void* stream);
 /* One-launch deterministic form (the workgroup that arrives last sums the per-workgroup partials in a fixed order):
  * dgamma_dbeta [2][256] = (dgamma, dbeta), fully written.  The first 4 bytes of `workspace`
  * (mpf_res_ln256_backward_det_workspace_bytes(rows) bytes) must be zero on entry and are zero again on exit. */

@@ -53,7 +53,7 @@ struct BwdScratch {
     // are issued together at the end of the layer (one grouped launch)
     void *dt3, *dt2, *dt1, *dxb, *dh, *dout, *dq, *dk_s, *dv_s, *dq_c, *qT, *doT;
     float *ds_a, *ds_b, *delta;
-    void* ln_ws;                 // ticket + partial sums of the LayerNorm parameter gradients (mpf_res_ln256_backward_det)
+    void* ln_ws;                 // per-workgroup partial sums of the three LayerNorms' parameter gradients, ln_ws_bytes each
     size_t ln_ws_bytes;
     size_t bytes;
 };
@@ -79,8 +79,8 @@ BwdScratch bwd_scratch(void* base, int Qt, int N, int H, int F)
     b.ds_a = c.take<float>(R * kE);
     b.ds_b = c.take<float>(R * kE);
     b.delta = c.take<float>((size_t)N * H * Qt);
-    b.ln_ws_bytes = mpf_res_ln256_backward_det_workspace_bytes((int)R);
-    b.ln_ws = c.take<char>(b.ln_ws_bytes);
+    b.ln_ws_bytes = (mpf_res_ln256_backward_workspace_bytes((int)R) + 255) & ~size_t(255);
+    b.ln_ws = c.take<char>(3 * b.ln_ws_bytes);
     b.bytes = c.used;
     return b;
 }
@@ -229,22 +229,23 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
     const BwdScratch b = bwd_scratch(L->scratch, Qt, N, H, F);
     const float scale = 0.17677669529663687f;
     float* dln = G->d_ln;
-    // (the LayerNorm parameter gradients are written, not accumulated: only the ticket word of their workspace is zeroed)
-    MPF_TRY(mpf::check(hipMemsetAsync(b.ln_ws, 0, 256, (hipStream_t)st), "decoder_layer_backward memset"));
+    // LayerNorm parameter gradients: the three backward launches leave per-workgroup partial sums, ONE launch at the end of the
+    // layer reduces them in a fixed order (no float atomics, nothing to zero)
+    char* ln_part = static_cast<char*>(b.ln_ws);
     // The weight gradients depend only on the dY buffers of the chain below (each kept in its own scratch buffer), so they
     // are collected here and issued as ONE grouped launch after the chain.
     MpfSmallGemmItem dw[kMaxDw];
     int ndw = 0;
     // FFN block: x3 = LN(x2 + W2 relu(W1 xb2))
-    MPF_TRY(mpf_res_ln256_backward_det(L->s3, L->mean3, L->rstd3, L->ff_gamma, G->g_x3, G->g_xb3, nullptr, b.ds_a, b.dt3, dln + 4 * kE, R,
-                                       b.ln_ws, b.ln_ws_bytes, st));
+    MPF_TRY(mpf_res_ln256_backward_partial(L->s3, L->mean3, L->rstd3, L->ff_gamma, G->g_x3, G->g_xb3, nullptr, b.ds_a, b.dt3, R,
+                                           ln_part + 2 * b.ln_ws_bytes, b.ln_ws_bytes, st));
     MPF_TRY(lin_dx(b.dt3, nullptr, L->ff_w2, nullptr, b.dh, R, kE, F, st));
     dw[ndw++] = dw_item(b.dt3, nullptr, L->h, G->d_ff_w2, G->d_ff_b2, R, kE, F);
     MPF_TRY(lin_dx(b.dh, L->h, L->ff_w1, nullptr, b.dxb, R, F, kE, st));
     dw[ndw++] = dw_item(b.dh, L->h, L->xb2, G->d_ff_w1, G->d_ff_b1, R, F, kE);
     // self-attention block: x2 = LN(x1 + Wo attn(Wq xb1, Wk xb1, Wv xb1))
-    MPF_TRY(mpf_res_ln256_backward_det(L->s2, L->mean2, L->rstd2, L->sa_gamma, b.ds_a, b.dxb, nullptr, b.ds_b, b.dt2, dln + 2 * kE, R,
-                                       b.ln_ws, b.ln_ws_bytes, st));
+    MPF_TRY(mpf_res_ln256_backward_partial(L->s2, L->mean2, L->rstd2, L->sa_gamma, b.ds_a, b.dxb, nullptr, b.ds_b, b.dt2, R,
+                                           ln_part + b.ln_ws_bytes, b.ln_ws_bytes, st));
     MPF_TRY(lin_dx(b.dt2, nullptr, L->sa_wo, nullptr, b.dout, R, kE, kE, st));
     dw[ndw++] = dw_item(b.dt2, nullptr, L->o_s, G->d_sa_wo, G->d_sa_bo, R, kE, kE);
     MPF_TRY(mpf_attn_bwd_prep(L->q_s, b.dout, L->o_s, b.qT, b.doT, b.delta, Qt, LqP, N, H, st));
@@ -271,8 +272,9 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
         dw[ndw++] = dw_item(b.dv_s, nullptr, L->xb1, G->d_sa_wv, G->d_sa_bv, R, kE, kE);
     }
     // cross-attention block: x1 = LN(x0 + Wo attn(Wq xb0, k_c, v_c))
-    MPF_TRY(mpf_res_ln256_backward_det(L->s1, L->mean1, L->rstd1, L->ca_gamma, b.ds_b, b.dxb, nullptr, G->d_x0, b.dt1, dln, R, b.ln_ws,
-                                       b.ln_ws_bytes, st));
+    MPF_TRY(mpf_res_ln256_backward_partial(L->s1, L->mean1, L->rstd1, L->ca_gamma, b.ds_b, b.dxb, nullptr, G->d_x0, b.dt1, R, ln_part,
+                                           b.ln_ws_bytes, st));
+    MPF_TRY(mpf_ln_partial_reduce(ln_part, b.ln_ws_bytes, R, 3, dln, st));      // dln = [ca | sa | ff] x (dgamma, dbeta)
     MPF_TRY(lin_dx(b.dt1, nullptr, L->ca_wo, nullptr, b.dout, R, kE, kE, st));
     dw[ndw++] = dw_item(b.dt1, nullptr, L->o_c, G->d_ca_wo, G->d_ca_bo, R, kE, kE);
     MPF_TRY(mpf_attn_bwd_prep(L->q_c, b.dout, L->o_c, b.qT, b.doT, b.delta, Qt, LqP, N, H, st));

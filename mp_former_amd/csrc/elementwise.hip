@@ -244,11 +244,15 @@ __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restr
 // out[which][col] = sum over blocks of partial[block][which][col] in a fixed order; grid = (2 "which", 8 groups of 32 columns),
 // 1024 threads = 32 columns x 32 block slices (a wave reads two 128-byte row pieces), slices merged through LDS.  (Two
 // workgroups walking all blocks were latency-bound: 245 dependent-ish reads per thread, 29 us for 2 MB.)
+// blockIdx.z = which LayerNorm of a group (partials `zstride` floats apart, outputs 512 floats apart: dgamma row, dbeta row)
 __global__ __launch_bounds__(1024) void ln_partial_reduce_kernel(const float* __restrict__ partial, int blocks, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta)
+                                                                 float* __restrict__ dbeta, int64_t zstride = 0)
 {
     __shared__ float red[32][33];
     const int which = blockIdx.x, c = threadIdx.x & 31, col = blockIdx.y * 32 + c, sl = threadIdx.x >> 5;
+    partial += (int64_t)blockIdx.z * zstride;
+    dgamma += (int64_t)blockIdx.z * 512;
+    dbeta += (int64_t)blockIdx.z * 512;
     const float* src = partial + which * 256 + col;
     float acc = 0.f;
     int b = sl;
@@ -364,6 +368,54 @@ extern "C" int mpf_res_ln256_backward_ws(const float* s, const float* mean, cons
 #undef RLN_BWDP
     hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(2, 8), dim3(1024), 0, st, (const float*)part, (int)grid.x, dgamma, dbeta);
     return mpf::check(hipGetLastError(), "mpf_res_ln256_backward_ws");
+}
+
+// The two halves of mpf_res_ln256_backward_ws as separate calls, for callers that run SEVERAL LayerNorm backwards and reduce
+// their parameter gradients together (a decoder layer: three LayerNorms, one reduce launch at the end of the layer):
+//   mpf_res_ln256_backward_partial: ds + the per-workgroup partial sums into `partials`
+//                                   (mpf_res_ln256_backward_workspace_bytes(rows) bytes);
+//   mpf_ln_partial_reduce: out[z][2][256] = fixed-order sums of the partials of LayerNorm z (z < n_ln, `stride_bytes` apart).
+extern "C" int mpf_res_ln256_backward_partial(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                                              const void* gy16, const float* gy_plus, float* ds32, void* ds16, int rows, void* partials,
+                                              size_t partials_bytes, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) return 0;
+    if (!s || !mean || !rstd || !gamma || (!gy32 && !gy16 && !gy_plus) || (!ds32 && !ds16) || !partials)
+        return mpf::fail(MPF_E_NULL, "res_ln256_backward_partial: NULL buffer");
+    if (rows < 0 || partials_bytes < mpf_res_ln256_backward_workspace_bytes(rows))
+        return mpf::fail(MPF_E_SHAPE, "res_ln256_backward_partial: bad rows / buffer too small");
+    int rpb = (rows + 1023) / 1024;
+    rpb = ((rpb + 3) / 4) * 4;
+    const dim3 grid((rows + rpb - 1) / rpb);
+    float* part = (float*)partials;
+    mpf::set_kernel("res_ln256_bwd_kernel");
+#define RLN_BWDQ(A, B, C)                                                                                                         \
+    hipLaunchKernelGGL((res_ln256_bwd_kernel<A, B, C, 1>), grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16,       \
+                       gy_plus, ds32, (__bf16*)ds16, part, part, rows, rpb)
+    switch ((gy32 ? 4 : 0) | (gy16 ? 2 : 0) | (gy_plus ? 1 : 0)) {
+        case 1: RLN_BWDQ(false, false, true); break;
+        case 2: RLN_BWDQ(false, true, false); break;
+        case 3: RLN_BWDQ(false, true, true); break;
+        case 4: RLN_BWDQ(true, false, false); break;
+        case 5: RLN_BWDQ(true, false, true); break;
+        case 6: RLN_BWDQ(true, true, false); break;
+        default: RLN_BWDQ(true, true, true); break;
+    }
+#undef RLN_BWDQ
+    return mpf::check(hipGetLastError(), "mpf_res_ln256_backward_partial");
+}
+
+extern "C" int mpf_ln_partial_reduce(const void* partials, size_t stride_bytes, int rows, int n_ln, float* out, void* stream)
+{
+    if (!partials || !out) return mpf::fail(MPF_E_NULL, "ln_partial_reduce: NULL buffer");
+    if (rows <= 0 || n_ln <= 0 || n_ln > 65535 || (stride_bytes & 3)) return mpf::fail(MPF_E_SHAPE, "ln_partial_reduce: bad sizes");
+    int rpb = (rows + 1023) / 1024;
+    rpb = ((rpb + 3) / 4) * 4;
+    const int blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(2, 8, n_ln), dim3(1024), 0, (hipStream_t)stream, (const float*)partials, blocks, out,
+                       out + 256, (int64_t)(stride_bytes / 4));
+    return mpf::check(hipGetLastError(), "mpf_ln_partial_reduce");
 }
 
 // few rows (the decoder's query side): ONE launch, the workgroup that arrives last sums the partials in block order
