@@ -64,7 +64,7 @@ def smooth_points(z, eps=1e-4):
 
 
 # ---- head fixtures (tests/golden/head_*.npz) ----------------------------------------------------
-HEAD_FIXTURES = ["head_small", "head_ragged", "head_nogt"]
+HEAD_FIXTURES = ["head_small", "head_ragged", "head_nogt", "head_deep"]
 
 
 def load_head_fixture(name):

@@ -153,6 +153,9 @@ HEAD_CFGS = {
     # no GT anywhere -> prepare_for_normal path, dn losses are zeros
     "nogt": dict(size=64, N=1, counts=[0], num_queries=5, num_classes=3, enc_layers=1, dec_layers=2,
                  num_points=32),
+    # the shipped depth and class count (6 encoder / 9 decoder layers, 80 classes; 10 outputs -> 60 losses) at 128 x 128
+    "deep": dict(size=128, N=2, counts=[4, 2], num_queries=50, num_classes=80, enc_layers=6, dec_layers=9,
+                 num_points=224, aux_step=11),
 }
 
 
@@ -191,9 +194,11 @@ def _sub(t, step):
     return t.detach().reshape(-1)[::step].clone().numpy()
 
 
-def gen_head():
+def gen_head(only=None):
     import det_params as DP
     for name, cfg in HEAD_CFGS.items():
+        if only and name not in only:
+            continue
         torch.manual_seed(1234)
         pix, d, crit, wd = build_reference_head(cfg)
         feats = DP.det_features(cfg["N"], cfg["size"])
@@ -233,7 +238,7 @@ def gen_head():
         out["pred_masks"] = dout["pred_masks"].detach().numpy()
         for i, a in enumerate(dout["aux_outputs"]):
             out[f"aux{i}_pred_logits"] = a["pred_logits"].detach().numpy()
-            out[f"aux{i}_pred_masks_s3"] = _sub(a["pred_masks"], 3)
+            out[f"aux{i}_pred_masks_s3"] = _sub(a["pred_masks"], cfg.get("aux_step", 3))
         if dout["dn_out"] is not None:
             out["dn_pred_logits"] = dout["dn_out"]["pred_logits"].detach().numpy()
             out["dn_pred_masks"] = dout["dn_out"]["pred_masks"].detach().numpy()
@@ -269,7 +274,10 @@ def main():
     torch.set_num_threads(4)
     for w in what:
         print(f"[{w}]")
-        globals()["gen_" + w]()
+        if w.startswith("head:"):          # e.g. head:deep — one head fixture only
+            gen_head(only=w.split(":", 1)[1].split(","))
+        else:
+            globals()["gen_" + w]()
 
 
 if __name__ == "__main__":
