@@ -448,8 +448,6 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         """prepare_for_dn_v5 (:968-1060) minus the prediction-head call.  Returns None when there is
         no ground truth in the batch (-> prepare_for_normal)."""
         targets, scalar, noise_scale = dn_args["tgt"], dn_args["scalar"], dn_args["noise_scale"]
-        if noise_scale != 0:
-            raise NotImplementedError("point-noise on MP masks (NOISE_SCALE > 0) is not in the shipped configuration")
         num = [len(t["boxes"]) for t in targets]
         max_num = max(num)
         if scalar >= 100:
@@ -479,15 +477,29 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         padding = torch.zeros(bs, pad, feats.shape[-1], device=device, dtype=feats.dtype)
         padding[(bid, slot)] = feats
         # GT rows per level, computed once per forward (the reference re-derives them every layer)
-        rows = []
+        rows, base = [], []
         gts = [t["masks"] for t in targets if len(t["masks"]) > 0]
         same = all(g.shape[1:] == gts[0].shape[1:] and g.dtype == gts[0].dtype for g in gts)
         all_masks = stacked_masks(gts) if same else None      # (shared with the matcher's copy: _targets.py)
         for size in size_list:
-            pm = torch.ones(bs, pad, size[0] * size[1], dtype=torch.bool, device=device)
             gt = gt_block_or(all_masks, size) if same else torch.cat([gt_block_or(g, size) for g in gts])
-            pm[(bid, slot)] = gt.repeat(scalar, 1)
-            rows.append(pm)
+            base.append(gt.repeat(scalar, 1))
+            if noise_scale == 0:
+                pm = torch.ones(bs, pad, size[0] * size[1], dtype=torch.bool, device=device)
+                pm[(bid, slot)] = base[-1]
+                rows.append(pm)
+
+        def noisy_rows(level):
+            """point noise (:991-998, :1606-1613): a fresh draw per call flips every position of a row with probability
+            (open area of the row) * noise_scale / (h w)"""
+            b = base[level]
+            ratio = (~b).sum(1) * (noise_scale / b.shape[1])
+            pm = torch.ones(bs, pad, b.shape[1], dtype=torch.bool, device=device)
+            pm[(bid, slot)] = torch.logical_xor(b, _rng.rand("mp_noise", tuple(b.shape), device) < ratio[:, None])
+            return pm
+
+        if noise_scale != 0:
+            rows = noisy_rows
         tgt_size = pad + self.num_queries
         tgt_mask = torch.zeros(tgt_size, tgt_size, dtype=torch.bool, device=device)
         tgt_mask[pad:, :pad] = True
@@ -678,7 +690,8 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
                 return None
             if i is not None and not (self.all_lys or i < 3):
                 return None
-            return mp["rows"][level]
+            r = mp["rows"]
+            return r(level) if callable(r) else r[level]           # (callable: point noise, a fresh draw per layer)
 
         H = self.num_heads
         output = output.float().contiguous()            # fp32 residual stream [Qtot, N, C]
@@ -733,6 +746,8 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
             streams.append(output)
             if i + 1 < self.num_layers:
                 attn_mask = self._next_attn_mask(W, output, mask_features, size_list[nxt], rows(nxt, i), pooled[nxt])
+            elif mp is not None and callable(mp["rows"]) and _rng.replaying() and (self.all_lys or i < 3):
+                rows(nxt, i)        # the reference draws the noise of the mask after the last layer too (unused): keep the FIFO aligned
         predictions_class, predictions_mask = self._heads_batched(W, streams, mask_features)
 
         nq = self.num_queries

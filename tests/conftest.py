@@ -64,7 +64,7 @@ def smooth_points(z, eps=1e-4):
 
 
 # ---- head fixtures (tests/golden/head_*.npz) ----------------------------------------------------
-HEAD_FIXTURES = ["head_small", "head_ragged", "head_nogt", "head_deep"]
+HEAD_FIXTURES = ["head_small", "head_ragged", "head_nogt", "head_deep", "head_noise"]
 
 
 def load_head_fixture(name):
@@ -98,9 +98,15 @@ def fifo_to_tags(replay, cfg, use_dn, label_noise=True):
     def put(tag):
         tags.setdefault(tag, []).append(q.pop(0))
 
+    noise = use_dn and cfg.get("noise_scale", 0.0) > 0
+    if noise:
+        put("mp_noise")                       # prepare_for_dn_v5: the first level's rows, before the label noise
     if use_dn and label_noise:
         put("label_prob")
         put("label_new")
+    if noise:
+        for _ in range(cfg["dec_layers"]):    # gen_mask_dn after every layer (the last one's mask is never used)
+            put("mp_noise")
     for suffix in [""] + [f"_{i}" for i in range(cfg["dec_layers"])]:
         for _ in range(cfg["N"]):
             put("match" + suffix)

@@ -154,6 +154,9 @@ HEAD_CFGS = {
     "nogt": dict(size=64, N=1, counts=[0], num_queries=5, num_classes=3, enc_layers=1, dec_layers=2,
                  num_points=32),
     # the shipped depth and class count (6 encoder / 9 decoder layers, 80 classes; 10 outputs -> 60 losses) at 128 x 128
+    # point noise on the mask-piloted rows (NOISE_SCALE 0.2: run_50ep_noise scripts of the reference)
+    "noise": dict(size=64, N=2, counts=[3, 2], num_queries=8, num_classes=5, enc_layers=1, dec_layers=3,
+                  num_points=64, noise_scale=0.2),
     "deep": dict(size=128, N=2, counts=[4, 2], num_queries=50, num_classes=80, enc_layers=6, dec_layers=9,
                  num_points=224, aux_step=11),
 }
@@ -220,7 +223,7 @@ def gen_head(only=None):
         captured_masks = []
         orig_heads = d.forward_prediction_heads
         with R.RandCapture() as cap:
-            dn_args = {"tgt": targets, "scalar": 1, "noise_scale": 0.0}
+            dn_args = {"tgt": targets, "scalar": 1, "noise_scale": cfg.get("noise_scale", 0.0)}
             dout = d(ms, mf, None, dn_args)
             n_dec_draws = len(cap.log)
             losses = crit(dout, targets)
@@ -229,7 +232,7 @@ def gen_head(only=None):
         keep = []
         for i, (fn, t) in enumerate(draws):
             is_mask_noise = (i < n_dec_draws and fn == "rand_like" and t.dim() == 2)
-            if not is_mask_noise:
+            if not is_mask_noise or cfg.get("noise_scale", 0.0) > 0:
                 keep.append((fn, t))
         for i, (fn, t) in enumerate(keep):
             out[f"rng_{i:03d}_{fn}"] = t.numpy()

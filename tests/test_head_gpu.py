@@ -19,7 +19,7 @@ def _sub(t, step):
 def _build(cfg, pp, dp, dev):
     from mp_former_amd.head import MPFormerHead
     h = MPFormerHead(num_classes=cfg["num_classes"], num_queries=cfg["num_queries"], enc_layers=cfg["enc_layers"],
-                     dec_layers=cfg["dec_layers"], num_points=cfg["num_points"])
+                     dec_layers=cfg["dec_layers"], num_points=cfg["num_points"], noise_scale=cfg.get("noise_scale", 0.0))
     h.pixel_decoder.load_state_dict(pp, strict=True)
     h.predictor.load_state_dict(dp, strict=True)
     return h.to(dev).train()
@@ -63,7 +63,7 @@ def test_head_matches_reference_golden_fp32(name, layout):
         np.testing.assert_allclose(_sub(mf, 5), z["mask_features_s5"], rtol=2e-3, atol=5e-4)
         for i, t in enumerate(ms):
             np.testing.assert_allclose(_sub(t, 3), z[f"multi_scale_{i}_s3"], rtol=2e-3, atol=5e-4)
-        out = h.predictor(ms, mf, None, {"tgt": targets, "scalar": 1, "noise_scale": 0.0})
+        out = h.predictor(ms, mf, None, {"tgt": targets, "scalar": 1, "noise_scale": cfg.get("noise_scale", 0.0)})
         np.testing.assert_allclose(out["pred_logits"].detach().cpu().numpy(), z["pred_logits"], rtol=5e-3, atol=2e-3)
         np.testing.assert_allclose(out["pred_masks"].detach().cpu().numpy(), z["pred_masks"], rtol=5e-3, atol=5e-3)
         for i, a in enumerate(out["aux_outputs"]):
@@ -208,7 +208,7 @@ def _rel_l2(got, want):
     return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
 
 
-@pytest.mark.parametrize("name", ["head_small", "head_ragged", "head_deep"])
+@pytest.mark.parametrize("name", ["head_small", "head_ragged", "head_deep", "head_noise"])
 def test_head_amp_path_matches_reference_golden(name):
     """The path bench.py times — bf16 autocast with every default switch (natively sequenced decoder layers, MFMA
     attention, small-row GEMMs, device-side assignment) — against the PINNED goldens of the imported reference (fp32),

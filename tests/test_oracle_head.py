@@ -30,7 +30,7 @@ def test_head_forward_backward_matches_reference(name):
         np.testing.assert_allclose(_sub(t, 3), z[f"multi_scale_{i}_s3"], rtol=1e-3, atol=2e-4)
 
     out = O.decoder_forward(dp, ms, mf, targets, num_queries=cfg["num_queries"], num_classes=cfg["num_classes"],
-                            dec_layers=cfg["dec_layers"], scalar=1, label_noise_ratio=0.2, rng=rng)
+                            dec_layers=cfg["dec_layers"], scalar=1, noise_scale=cfg.get("noise_scale", 0.0), label_noise_ratio=0.2, rng=rng)
     np.testing.assert_allclose(out["pred_logits"].detach().numpy(), z["pred_logits"], rtol=2e-3, atol=5e-4)
     np.testing.assert_allclose(out["pred_masks"].detach().numpy(), z["pred_masks"], rtol=2e-3, atol=2e-3)
     for i, a in enumerate(out["aux_outputs"]):
