@@ -431,20 +431,29 @@ __device__ __forceinline__ int hash_slot(unsigned* keys, unsigned key)
     return -1;
 }
 
-// LDS of the push kernel (rows padded to a pitch of 144 B):
-//   [0, 64)   bounding boxes   [128, 272) the zero row   [512, 9728) grad_out rows of the 64 queries
-//   [9728, 9728 + cap * 144)  staged value rows; the hash table (keys, counts) lives in the same bytes before the first
-//   box is written, the run bases after the last one is read.
+// LDS of the push kernel:
+//   [0, 64)   bounding boxes   [128, 272) the zero row   [512, 9728) grad_out rows of the 64 queries (pitch 144 B)
+//   [9728, 12864)  tile tables (hash keys, counters + dummy, run bases)
+//   [12864, 12864 + cap * 128)  value rows of the current level's box, filled by DMA (16-byte pieces XOR-swizzled, see swz16)
 // Thread = one sample per level, (query tid >> 2, point tid & 3): the thread that decodes a sample also reduces it — it
-// walks the 32 channels of its four corner rows and of its query's grad_out row with 16-byte LDS reads (8 per row, all
-// at immediate offsets), so grad_attn / grad_loc need no cross-lane reduction and no descriptor round trip through LDS.
-// Lanes of a 16-lane LDS service group read the SAME piece of DIFFERENT rows; with 128-B rows every second row would
-// sit on the same banks, the 144-B pitch (9 x 16 B, odd) makes rows collide only when their indices agree mod 16.
-// Boxes are staged through registers (global_load -> ds_write; the direct-to-LDS path cannot pad): the loads of level
-// l + 1 are issued before level l is reduced and written after it, so their latency hides behind the arithmetic; the
-// returning adds that reserve the entry runs are consumed at the very end for the same reason.
-constexpr int kPitch = 144, kPOffZero = 128, kPOffG = 512, kPOffReg = kPOffG + kQB * kPitch;
-constexpr int kPStage = 7;        // 16-byte pieces per thread and level: covers 7 * 256 / 8 = 224 rows
+// walks the 32 channels of its four corner rows and of its query's grad_out row with 16-byte LDS reads, so grad_attn /
+// grad_loc need no cross-lane reduction and no descriptor round trip through LDS.  Lanes of a 16-lane LDS service group
+// read the SAME piece of DIFFERENT rows: the grad_out rows sit at a 144-B pitch, the box rows (which arrive by DMA and
+// cannot be padded) have their pieces swizzled by the row index, so in both images rows collide only when their indices
+// agree mod 16.
+// Round 3: the boxes go global -> LDS by DMA (like the forward) instead of through 28 staging registers that were kept
+// alive across a level's reduction to overlap the next box's fetch: 155 -> 122 VGPRs and 40.8 -> 40.5 KB of LDS, i.e. FOUR
+// resident workgroups per CU instead of three.  The kernel is bound by the length of a workgroup's dependent chain at low
+// occupancy (tools/experiments/README.md: 102 of its 156 us remain with every byte and flop ablated), so the fourth
+// workgroup buys more than the now exposed round trip per level costs: 157 -> 142 us (N(0, 3 px) offsets: 284 -> 260).
+// The returning adds that reserve the entry runs are consumed at the very end so that their latency hides behind the levels.
+constexpr int kPitch = 144, kPOffZero = 128, kPOffG = 512, kPOffTab = kPOffG + kQB * kPitch;
+// tile tables (keys, counts + dummy, run bases) have their own 3 KB: the first box lands in LDS by DMA while they are in use
+constexpr int kPOffReg = kPOffTab + (3 * kSlots + 16) * 4;
+// value rows of a box: 128 B each (no padding — they arrive by DMA); the eight 16-byte pieces of LDS row r are stored at
+// slot (piece ^ ((r >> 1) & 7)): the swizzle is applied on the SOURCE side of the DMA (lane -> which global piece it fetches),
+// and the per-lane row reads of the reduction (same piece, different rows) collide only for rows equal mod 16
+__device__ __forceinline__ int swz16(int r) { return ((r >> 1) & 7) << 4; }
 
 template <int NL>
 __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
@@ -457,9 +466,9 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* s_bb = reinterpret_cast<int*>(smem);
     constexpr int LP = NL * kP;
-    unsigned* s_keys = reinterpret_cast<unsigned*>(smem + kPOffReg);                 // [kSlots]   (aliases the box)
-    int* s_cnt = reinterpret_cast<int*>(s_keys + kSlots);                            // [kSlots]
-    int* s_base = reinterpret_cast<int*>(smem + kPOffReg);                           // [kSlots]   (after the last level)
+    unsigned* s_keys = reinterpret_cast<unsigned*>(smem + kPOffTab);                 // [kSlots]
+    int* s_cnt = reinterpret_cast<int*>(s_keys + kSlots);                            // [kSlots + 1]: the last one is the dummy
+    int* s_base = s_cnt + kSlots + 8;                                                // [kSlots]
 
     const int blk = xcd_index(nblocks);
     if (blk >= nblocks) return;
@@ -528,8 +537,6 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(value), 0, value_bytes, 0x00020000);
-    // box of level l -> registers (piece idx = tid + 256 i: row idx >> 3, piece idx & 7); rows beyond the box read nothing
-    float4 stg[kPStage];
     auto box = [&](int l, int& xmin, int& ymin, int& rw, int& rows, bool& lds_path) {
         xmin = s_bb[l * 4 + 0]; ymin = s_bb[l * 4 + 1];
         const int xmax = s_bb[l * 4 + 2], ymax = s_bb[l * 4 + 3];
@@ -537,27 +544,27 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
         rows = xmax >= xmin ? rw * (ymax - ymin + 1) : 0;
         lds_path = rows <= region_cap;
     };
+    // box of level l -> LDS by DMA: a wave instruction moves 8 rows; lane (row, slot) fetches global piece slot ^ swizzle(row)
     auto fetch = [&](int l) {
         int xmin, ymin, rw, rows;
         bool lds_path;
         box(l, xmin, ymin, rw, rows, lds_path);
         if (!lds_path || (ablate & 4)) rows = 0;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const float inv_rw = 1.0f / (float)max(rw, 1);
-        const int lvl = ((c.b * g.S + g.start[l]) * g.M + c.m) * 128;
+        const int nchunk = (rows + 31) >> 5;
         const int W = g.W[l];
-#pragma unroll
-        for (int i = 0; i < kPStage; ++i) {
-            const int idx = tid + i * kT, r = idx >> 3;
+        const float* base = value + ((int64_t)(c.b * g.S + g.start[l]) * g.M + c.m) * kD;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int rr = ch * 32 + wave * 8 + (lane >> 3);             // LDS row of this lane
+            const int r = min(rr, rows - 1);
             const int ry = (int)(((float)r + 0.5f) * inv_rw), rx = r - ry * rw;
-            const int off = r < rows ? lvl + ((ymin + ry) * W + xmin + rx) * (g.M * 128) + (idx & 7) * 16 : kOobOff;
-            stg[i] = buf_row(vrs, off);
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < kPStage; ++i) {
-            const int idx = tid + i * kT, r = idx >> 3;
-            if (r < region_cap) *reinterpret_cast<float4*>(smem + kPOffReg + r * kPitch + (idx & 7) * 16) = stg[i];
+            const int piece = (lane & 7) ^ ((rr >> 1) & 7);
+            const float* src = base + (int64_t)((ymin + ry) * W + (xmin + rx)) * (g.M * kD) + piece * 4;
+            unsigned char* dst = smem + kPOffReg + (ch * 32 + wave * 8) * 128;
+            if (rr < region_cap)          // (the buffer holds region_cap rows, not whole 32-row passes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
     stamp();     // 3: decode + box reduction (waited for loc/attn/g)
@@ -657,8 +664,8 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
     }
     __syncthreads();
     stamp();     // 6: reservation issued
-    // the first box -> LDS
-    commit();
+    // the first box (requested before the tile counting) has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     stamp();     // 7: first box in LDS
 
@@ -670,23 +677,23 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
         bool lds_path;
         box(l, xmin, ymin, rw, rows, lds_path);
         if (stats && tid == 0 && rows > 0) atomicAdd(&stats[lds_path ? 2 : 3], 1u);
-        if (l + 1 < NL) fetch(l + 1);                  // next box: in flight while this level is reduced
         const bool in = (in_mask >> l) & 1;
         const int H = g.H[l], W = g.W[l];
         const bool y0v = in && y0[l] >= 0, y1v = in && y0[l] + 1 <= H - 1, x0v = in && x0[l] >= 0, x1v = in && x0[l] + 1 <= W - 1;
         f2v t0 = {0.f, 0.f}, t1 = {0.f, 0.f}, t2 = {0.f, 0.f}, t3 = {0.f, 0.f};
         if (ablate & 2) {
         } else if (lds_path) {
-            const int base = kPOffReg + ((y0[l] - ymin) * rw + (x0[l] - xmin)) * kPitch;
-            const int o0 = (y0v && x0v) ? base : kPOffZero, o1 = (y0v && x1v) ? base + kPitch : kPOffZero;
-            const int o2 = (y1v && x0v) ? base + rw * kPitch : kPOffZero, o3 = (y1v && x1v) ? base + rw * kPitch + kPitch : kPOffZero;
+            const int r0 = (y0[l] - ymin) * rw + (x0[l] - xmin);
+            const int o0 = (y0v && x0v) ? kPOffReg + r0 * 128 : kPOffZero, o1 = (y0v && x1v) ? kPOffReg + (r0 + 1) * 128 : kPOffZero;
+            const int o2 = (y1v && x0v) ? kPOffReg + (r0 + rw) * 128 : kPOffZero, o3 = (y1v && x1v) ? kPOffReg + (r0 + rw + 1) * 128 : kPOffZero;
+            const int s0 = swz16(r0), s1 = swz16(r0 + 1), s2 = swz16(r0 + rw), s3 = swz16(r0 + rw + 1);    // (zero row: any piece is zero)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const f4v gk = *reinterpret_cast<const f4v*>(smem + g_base + k * 16);
-                const f4v v0 = *reinterpret_cast<const f4v*>(smem + o0 + k * 16);
-                const f4v v1 = *reinterpret_cast<const f4v*>(smem + o1 + k * 16);
-                const f4v v2 = *reinterpret_cast<const f4v*>(smem + o2 + k * 16);
-                const f4v v3 = *reinterpret_cast<const f4v*>(smem + o3 + k * 16);
+                const f4v v0 = *reinterpret_cast<const f4v*>(smem + o0 + ((k * 16) ^ s0));
+                const f4v v1 = *reinterpret_cast<const f4v*>(smem + o1 + ((k * 16) ^ s1));
+                const f4v v2 = *reinterpret_cast<const f4v*>(smem + o2 + ((k * 16) ^ s2));
+                const f4v v3 = *reinterpret_cast<const f4v*>(smem + o3 + ((k * 16) ^ s3));
                 t0 = __builtin_elementwise_fma(gk.xy, v0.xy, t0); t0 = __builtin_elementwise_fma(gk.zw, v0.zw, t0);
                 t1 = __builtin_elementwise_fma(gk.xy, v1.xy, t1); t1 = __builtin_elementwise_fma(gk.zw, v1.zw, t1);
                 t2 = __builtin_elementwise_fma(gk.xy, v2.xy, t2); t2 = __builtin_elementwise_fma(gk.zw, v2.zw, t2);
@@ -724,7 +731,8 @@ __global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
         stamp();                                       // 8, 10, 12: level reduced
         __syncthreads();                               // every reader is done with this box
         if (l + 1 < NL) {
-            commit();
+            fetch(l + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
         stamp();                                       // 9, 11, 13: next box in LDS
@@ -984,7 +992,7 @@ __global__ __launch_bounds__(kT) void msda_bwd_spill_kernel(const float* __restr
 // host side
 // --------------------------------------------------------------------------------------------------
 int g_region_rows = 217;      // forward: usable rows of the staged box (the buffer is rounded up to whole 32-row stage passes)
-int g_push_rows = 216;        // push: rows of its box buffer (pitch 144 B): 9728 + 216 * 144 = 40832 B -> four workgroups per CU
+int g_push_rows = 216;        // push: rows of its box buffer (128 B each): 12864 + 216 * 128 = 40512 B -> four workgroups per CU
 int g_block_disable = 0;
 int g_fuse_prep = 1;        // mpf_set_option("msda_fuse_prep"): softmax / location arithmetic inside the forward kernel
 unsigned long long* g_dbg = nullptr;   // benchmarking only: s_memtime phase stamps of the push kernel, [workgroup][16]
@@ -1129,7 +1137,7 @@ hipError_t launch_bwd(const float* value, const float* loc, const float* attn, c
     const int nblocks = g.N * g.M * g.blocks_per_b;
     const int grid = ((nblocks + 7) / 8) * 8;
     constexpr int LP = NL * kP;
-    const size_t lds = kPOffReg + (size_t)g_push_rows * kPitch;
+    const size_t lds = kPOffReg + (size_t)g_push_rows * 128;
     const double esz = 4.0;
     mpf::prof_begin(st);
     hipLaunchKernelGGL(msda_bwd_push_block_kernel<NL>, dim3(grid), dim3(kT), lds, st, value, loc, attn, go, gl, ga, graw, tile_count,
@@ -1232,7 +1240,7 @@ int set_block_option(const char* key, int v)
         return 0;
     }
     if (!strcmp(key, "msda_push_rows")) {
-        if (v < 16 || v > kPStage * 32) return MPF_E_SHAPE;
+        if (v < 16 || v > 480) return MPF_E_SHAPE;
         g_push_rows = v;
         return 0;
     }
