@@ -113,16 +113,21 @@ __global__ __launch_bounds__(kT) void pool_features_cl_kernel(const T* __restric
 
 // ----------------------------------------------------------------------------------------------------------------
 // sign(mask_embed . pooled features) -> byte mask, MP rows, per-row open flags
-// grid (pixel blocks of 128, N); 4 waves; wave w owns query tiles w, w + 4, ... of the current 128-query group
+// grid (pixel blocks of PB, N); 4 waves; wave w owns query tiles w, w + 4 of the current 128-query group.
+// PB = 32 (round 3; was 128): a workgroup's critical path is PB / 16 dependent (8 loads -> 16 MFMAs -> LDS bytes) steps per wave
+// and a level has only HW / PB x N workgroups — with 128-pixel blocks every launch took ~20 us whatever the level (256 / 64 / 16
+// workgroups of one wave per SIMD walking 8 steps); 32-pixel blocks give 4x the workgroups and a quarter of the chain.
 // ----------------------------------------------------------------------------------------------------------------
+template <int PB>
 __global__ __launch_bounds__(kT) void mask_head_bits_kernel(const __hip_bfloat16* __restrict__ me, int64_t me_stride_n,
                                                             int64_t me_stride_q, const __hip_bfloat16* __restrict__ pooled,
                                                             const uint8_t* __restrict__ mp_rows, int pad, uint8_t* __restrict__ out,
                                                             int* __restrict__ flags, int Q, int HW)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[128][128 + 16];      // [query][pixel], rows 144 B apart
+    constexpr int NPT = PB / 16, NPC = PB / 16;                       // pixel tiles / 16-byte output pieces per row
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[128][PB + 16];       // [query][pixel]
     __shared__ int s_any[128];
-    const int n = blockIdx.y, p0 = blockIdx.x * 128;
+    const int n = blockIdx.y, p0 = blockIdx.x * PB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     const __hip_bfloat16* men = me + n * me_stride_n;
@@ -139,8 +144,8 @@ __global__ __launch_bounds__(kT) void mask_head_bits_kernel(const __hip_bfloat16
                 a[t][ks] = *reinterpret_cast<const bf16x8*>(men + q * me_stride_q + ks * 32 + kg * 8);
         }
         __syncthreads();
-#pragma unroll 2
-        for (int pt = 0; pt < 8; ++pt) {
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
             const int pos = min(p0 + pt * 16 + li, HW - 1);
             bf16x8 b[8];
 #pragma unroll
@@ -156,9 +161,9 @@ __global__ __launch_bounds__(kT) void mask_head_bits_kernel(const __hip_bfloat16
             }
         }
         __syncthreads();
-        // rows out: 128 queries x 8 pieces of 16 bytes; MP rows take their ground-truth bytes instead
-        for (int i = tid; i < 128 * 8; i += kT) {
-            const int ql = i >> 3, pc = i & 7, q = q0 + ql, p = p0 + pc * 16;
+        // rows out: 128 queries x NPC pieces of 16 bytes; MP rows take their ground-truth bytes instead
+        for (int i = tid; i < 128 * NPC; i += kT) {
+            const int ql = i / NPC, pc = i % NPC, q = q0 + ql, p = p0 + pc * 16;
             if (q >= Q || p >= HW) continue;
             uint4 v = *reinterpret_cast<const uint4*>(&s_out[ql][pc * 16]);
             if (q < pad) {
@@ -250,7 +255,8 @@ extern "C" int mpf_mask_head_bits(const void* mask_embed, int64_t stride_n, int6
     hipStream_t st = (hipStream_t)stream;
     mpf::prof_begin(st);
     mpf::set_kernel("mask_head_bits_kernel");
-    hipLaunchKernelGGL(mask_head_bits_kernel, dim3((HW + 127) / 128, N), dim3(kT), 0, st, (const __hip_bfloat16*)mask_embed, stride_n,
+    constexpr int kPB = 32;
+    hipLaunchKernelGGL(mask_head_bits_kernel<kPB>, dim3((HW + kPB - 1) / kPB, N), dim3(kT), 0, st, (const __hip_bfloat16*)mask_embed, stride_n,
                        stride_q, (const __hip_bfloat16*)pooled, mp_rows, pad, out, (int*)flags, Q, HW);
     mpf::prof_end("mask_head_bits_kernel", st, 2.0 * ((double)N * Q * kC + (double)N * HW * kC) + (double)N * Q * HW,
                   2.0 * N * (double)Q * HW * kC);
