@@ -850,6 +850,9 @@ __global__ __launch_bounds__(kMcThreads) void sample_select_kernel(
     if (tid == 0) { misc[0] = 0; misc[1] = k; }
     __syncthreads();
     unsigned key[PT];
+    // (The coordinate loads stay behind `if (p < M)`, one dependent round trip each: every unconditional form measured in round
+    // 3 — batches of 2..8 on clamped indices, buffer loads with the point stride as scalar offset, scheduling barriers between
+    // batches — made hipcc spill ~240 registers at the 128 VGPRs of a 1024-thread workgroup: 172 -> 280 us.)
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
         const int p = tid + j * kMcThreads;
@@ -870,15 +873,27 @@ __global__ __launch_bounds__(kMcThreads) void sample_select_kernel(
             if (tid + j * kMcThreads < M && (key[j] & mask) == prefix) atomicAdd(&hist[(key[j] >> shift) & 255u], 1);
         __syncthreads();
         const int krem = misc[1];
+        // exclusive prefix of the 256 digit counts: wave scan (threads 0..255 = 4 waves) + the sums of the lower waves
+        // (a per-thread loop `for d < tid` was up to 255 dependent LDS reads on the critical path of every pass)
         int below = 0, mine = 0;
         if (tid < 256) {
-            for (int d = 0; d < tid; ++d) below += hist[d];
             mine = hist[tid];
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) misc[4 + wave] = incl;
+            below = incl - mine;
         }
-        __syncthreads();                                               // everyone has read misc[1] / hist
-        if (tid < 256 && below < krem && krem <= below + mine) {       // exactly one digit holds the k-th key
-            misc[1] = krem - below;
-            misc[0] = (int)(prefix | ((unsigned)tid << shift));
+        __syncthreads();                                               // everyone has read misc[1] / hist; wave sums published
+        if (tid < 256) {
+            for (int wv = 0; wv < wave; ++wv) below += misc[4 + wv];
+            if (below < krem && krem <= below + mine) {                // exactly one digit holds the k-th key
+                misc[1] = krem - below;
+                misc[0] = (int)(prefix | ((unsigned)tid << shift));
+            }
         }
         mask |= 255u << shift;
         __syncthreads();
