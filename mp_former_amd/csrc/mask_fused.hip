@@ -559,7 +559,8 @@ McGeom mc_geom(int G, int Q, int P)
     McGeom m;
     m.ntiles = (P + kMP - 1) / kMP;
     m.qgroups = (Q + kMQ - 1) / kMQ;
-    const int want = std::max(1, 768 / std::max(1, G * m.qgroups));            // ~3 workgroups per CU
+    // two workgroups fit a CU (208 VGPRs): ONE full round of 512 (768 workgroups = 1.5 rounds measured 8 % slower)
+    const int want = std::max(1, 512 / std::max(1, G * m.qgroups));
     m.tiles_per_wg = (m.ntiles + want - 1) / want;
     m.nwg = (m.ntiles + m.tiles_per_wg - 1) / m.tiles_per_wg;
     return m;
