@@ -271,6 +271,7 @@ def main():
     n_gn, ms_gn, _, fl_gn = prof("gemm3_nt_kernel<1")          # fp32 (three-plane) weight gradients; "<128, bf16>" is one product
     n_gc, ms_gc, _, fl_gc = prof("gemm3_conv_kernel")          # 3x3 FPN convolution (forward + input gradient) as K = 9*Cin GEMMs
     n_gw, ms_gw, _, fl_gw = prof("gemm3_nt_kernel<conv3x3>")   # ... and its weight gradient
+    fused = {k: prof(k) for k in ("match_cost_fused_kernel", "pair_planes_fwd_kernel", "pair_planes_dfeat_kernel", "pair_planes_dembed_kernel")}
     _lib.profile_enable(False)
     S_tok = sum((a.size // s) ** 2 for s in (8, 16, 32))
     n_b = n_pull                                   # one push + one pull launch per MSDA backward call
@@ -335,7 +336,7 @@ def main():
         g_tf32 = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0          # fp32-equivalent: 2 M N K of the GEMM it replaces
 
         def fused_entry(name, unit_bytes_note):
-            n, ms, by, fl = prof(name)
+            n, ms, by, fl = fused[name]
             if not n or ms <= 0:
                 return {"kernel": name, "launches": 0}
             e = {"kernel": name, "launches_per_step": n / max(P, 1), "ms_per_step": round(ms / max(P, 1), 3),
