@@ -268,7 +268,13 @@ def main():
     n_f, ms_f, by_f, _ = prof("msda_fwd")
     attn = {k: prof(k) for k in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "attn_bwd_q_kernel")}
     n_g, ms_g, _, fl_g = prof("gemm3_tn_kernel")
-    n_gn, ms_gn, _, fl_gn = prof("gemm3_nt_kernel<1")          # fp32 (three-plane) weight gradients; "<128, bf16>" is one product
+    # fp32 (three-plane) weight gradients launched one problem at a time (the 288-wide one with its per-level sums, the 1x1
+    # convolutions); "<128, bf16>" (one product: the decoder's K / V projections) is not part of the family
+    n_gn, ms_gn, fl_gn = 0, 0.0, 0.0
+    for nm in ("gemm3_nt_kernel<128>", "gemm3_nt_kernel<96>", "gemm3_nt_kernel<a16>", "gemm3_nt_kernel<b16>"):
+        n_, ms_, _, fl_ = prof(nm)
+        n_gn, ms_gn, fl_gn = n_gn + n_, ms_gn + ms_, fl_gn + fl_
+    n_gg, ms_gg, _, fl_gg = prof("gemm3_nt_group_kernel")      # ... the four plain ones of an encoder layer as one launch
     n_gc, ms_gc, _, fl_gc = prof("gemm3_conv_kernel")          # 3x3 FPN convolution (forward + input gradient) as K = 9*Cin GEMMs
     n_gw, ms_gw, _, fl_gw = prof("gemm3_nt_kernel<conv3x3>")   # ... and its weight gradient
     fused = {k: prof(k) for k in ("match_cost_fused_kernel", "pair_planes_fwd_kernel", "pair_planes_dfeat_kernel", "pair_planes_dembed_kernel")}
@@ -328,8 +334,8 @@ def main():
                     "bf16_mfma_tflops": round(6.0 * tf, 1), "bf16_mfma_frac": round(6.0 * tf / MFMA_BF16_PEAK_TFLOPS, 4)}
 
         FP32_MFMA_PEAK_TFLOPS = 157.0            # native fp32 MFMA peak (MI355X_MICROARCH.md): what a true-fp32 GEMM could reach
-        gemm_parts = [("gemm3_tn_kernel", n_g, ms_g, fl_g), ("gemm3_nt_kernel", n_gn, ms_gn, fl_gn), ("gemm3_conv_kernel", n_gc, ms_gc, fl_gc),
-                      ("gemm3_nt_kernel<conv3x3>", n_gw, ms_gw, fl_gw)]
+        gemm_parts = [("gemm3_tn_kernel", n_g, ms_g, fl_g), ("gemm3_nt_kernel", n_gn, ms_gn, fl_gn), ("gemm3_nt_group_kernel", n_gg, ms_gg, fl_gg),
+                      ("gemm3_conv_kernel", n_gc, ms_gc, fl_gc), ("gemm3_nt_kernel<conv3x3>", n_gw, ms_gw, fl_gw)]
         g_ms = sum(x[2] for x in gemm_parts)
         g_fl = sum(x[3] for x in gemm_parts)
         g_n = sum(x[1] for x in gemm_parts)
@@ -374,6 +380,7 @@ def main():
                          "frac_of_native_fp32_mfma_peak_157": round(g_tf32 / FP32_MFMA_PEAK_TFLOPS, 3),
                          "also": [
                              gemm_entry("gemm3_tn_kernel", n_g, ms_g, fl_g), gemm_entry("gemm3_nt_kernel", n_gn, ms_gn, fl_gn),
+                             gemm_entry("gemm3_nt_group_kernel", n_gg, ms_gg, fl_gg),
                              gemm_entry("gemm3_conv_kernel", n_gc, ms_gc, fl_gc),
                              gemm_entry("gemm3_nt_kernel<conv3x3>", n_gw, ms_gw, fl_gw),
                              # the deformable-sampling kernels against the HBM roofline (north-star)

@@ -538,6 +538,27 @@ int mpf_grouped_scale_cast(const MpfScaleCastItem* items_device, int n_items, in
                            void* stream);
 
 /*
+ * Several weight gradients over the SAME rows in one launch (the four Linear layers of an encoder layer whose operands are
+ * alive at the end of the layer's backward, msdeformattn.py:103-131): item i is the problem of mpf_gemm3_nt without b2 /
+ * csum_b / transpose_out,
+ *   c_part_i[s * split_stride + m * Ndim_i + n] = sum_{r in split s} A_i[r, m] * B_i[r, n],   csum_a_i[s * split_stride + m],
+ * i.e. the partial results of one split of all items can be laid out back to back (split_stride = their total size) and
+ * summed over the splits by ONE mpf_gemm3_nt_reduce over split_stride elements.  Same tiles and the same order of products
+ * as mpf_gemm3_nt with the same rows_per_split: bit-identical partial results.  items: HOST array, 1..8 entries;
+ * csum_a may be NULL; Ndim % 4 == 0.
+ */
+typedef struct MpfNtItem {
+    const float* a;
+    int64_t lda;
+    const float* b;
+    int64_t ldb;
+    float* c_part;
+    float* csum_a;
+    int64_t Mdim, Ndim;
+} MpfNtItem;
+int mpf_gemm3_nt_grouped(const MpfNtItem* items, int n_items, int R, int rows_per_split, int64_t split_stride, void* stream);
+
+/*
  * 3x3 convolution (stride 1, zero padding 1, no groups / dilation) of channel-last fp32 images on the split-bf16 GEMM:
  * the FPN output convolution of the pixel decoder (msdeformattn.py:272-281 / :351), forward and input gradient.
  *   x [n_img][H][W][Cin] -> y [n_img][H][W][Cout] (+ bias[Cout]); one GEMM with K = 9*Cin whose A rows are read at the

@@ -902,6 +902,15 @@ struct G3N {
     int R, Mdim, Ndim, b2_rows, rows_per_split, nsplit, tiles_m, tiles_n, ntiles, transpose_out;
     unsigned a_bytes, b_bytes;      // sizes of the operands (for the buffer descriptors; both < 4 GiB)
     int cv_H, cv_W, cv_cin;         // CV: weight gradient of a 3x3 convolution (B = the input image, columns = (tap, channel))
+    int64_t c_ss, csa_ss, csb_ss;   // elements between the partial results of consecutive splits (c, csum_a, csum_b)
+};
+// a group of weight-gradient problems over the SAME rows in one launch (mpf_gemm3_nt_grouped): item i owns the tiles
+// [tile_end[i-1], tile_end[i])
+constexpr int kNtGroupMax = 8;
+struct G3NG {
+    G3N it[kNtGroupMax];
+    int tile_end[kNtGroupMax];
+    int n_items, ntiles;
 };
 
 // BF: the operands are bf16 matrices (p.a / p.b point to 2-byte elements): one plane, one product —
@@ -912,8 +921,8 @@ struct G3N {
 // W % 8 == 0 the 8 rows of a k-chunk lie in one image row, so a row's validity is wave-uniform as well.
 // A16 / B16 (BN = 128, fp32 result): that operand is a bf16 matrix (2-byte elements, its lda / ldb in elements): loaded with
 // 2-byte reads into plane 0 only, and the products with its planes 1, 2 are skipped (three instead of six).
-template <int BN, bool BF = false, bool CV = false, bool A16 = false, bool B16 = false>
-__global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
+template <int BN, bool BF, bool CV, bool A16, bool B16>
+__device__ __forceinline__ void gemm3_nt_tile(const G3N& p, const int tile)
 {
     static_assert(!((A16 || B16) && (BF || CV || BN != 128)), "mixed-precision operands: plain 128-column tiles only");
     constexpr int NJ = BN / 32;
@@ -922,9 +931,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
     constexpr int kBunits = 4 * BN;                          // (k-chunk, column) units of the B tile
     __shared__ __attribute__((aligned(16))) unsigned char lds[kAbytes + 12 * kBKc];
 
-    const int per_xcd = (p.ntiles + 7) >> 3;
-    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (tile >= p.ntiles) return;
     // order: column tiles fastest, then row tiles, then splits (neighbouring blocks share the rows)
     const int tn = tile % p.tiles_n, tm = (tile / p.tiles_n) % p.tiles_m, sp = tile / (p.tiles_n * p.tiles_m);
     const int m0 = tm * kBM, n0 = tn * BN;
@@ -1092,7 +1098,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
-    float* cp = p.c + (int64_t)sp * p.Mdim * p.Ndim;
+    float* cp = p.c + (int64_t)sp * p.c_ss;
     acc.quads(lane, [&](int mo, int no, float4 o) {
         const int m = m0 + wr * 64 + mo, n = n0 + wc * (BN / 2) + no;
         if (m >= p.Mdim) return;
@@ -1123,10 +1129,33 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
             if (b_ok[1]) atomicAdd(&red[kBM + bn_[1]], csb1);
         }
         __syncthreads();
-        if (want_csa && tid < kBM && m0 + tid < p.Mdim) p.csum_a[(int64_t)sp * p.Mdim + m0 + tid] = red[tid];
-        if (want_csb && tid < BN && n0 + tid < p.Ndim) p.csum_b[(int64_t)sp * p.Ndim + n0 + tid] = red[kBM + tid];
+        if (want_csa && tid < kBM && m0 + tid < p.Mdim) p.csum_a[(int64_t)sp * p.csa_ss + m0 + tid] = red[tid];
+        if (want_csb && tid < BN && n0 + tid < p.Ndim) p.csum_b[(int64_t)sp * p.csb_ss + n0 + tid] = red[kBM + tid];
     }
     (void)a_col_ok; (void)b_col_ok;
+}
+
+template <int BN, bool BF = false, bool CV = false, bool A16 = false, bool B16 = false>
+__global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
+{
+    const int per_xcd = (p.ntiles + 7) >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (tile >= p.ntiles) return;
+    gemm3_nt_tile<BN, BF, CV, A16, B16>(p, tile);
+}
+
+// several problems over the same rows: with the tiles of all of them in one launch a workgroup's split is n_items times
+// longer at the same number of workgroups (one round of the chip), so the pipeline fill / drain and the partial results
+// are paid once per (tile, long split) instead of once per (tile, short split)
+__global__ __launch_bounds__(kThreads, 2) void gemm3_nt_group_kernel(G3NG g)
+{
+    const int per_xcd = (g.ntiles + 7) >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (tile >= g.ntiles) return;
+    int i = 0;
+    while (i + 1 < g.n_items && tile >= g.tile_end[i]) ++i;
+    const int first = i ? g.tile_end[i - 1] : 0;
+    gemm3_nt_tile<128, false, false, false, false>(g.it[i], tile - first);
 }
 
 // W[R,C] fp32 -> planes[3][R][C] (transpose = 0) or planes[3][C][R] (transpose = 1), bf16 bits
@@ -1435,6 +1464,7 @@ extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t
     const bool use96 = waste96 < waste128;
     p.tiles_n = use96 ? (Ndim + 95) / 96 : (Ndim + 127) / 128;
     p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
+    p.c_ss = (int64_t)p.Mdim * p.Ndim; p.csa_ss = p.Mdim; p.csb_ss = p.Ndim;
     const int grid = ((p.ntiles + 7) / 8) * 8;
     mpf::prof_begin(st);
     if (use96) {
@@ -1447,6 +1477,51 @@ extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t
     mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)R * Mdim + (double)R * Ndim + (double)p.nsplit * Mdim * Ndim),
                   2.0 * R * (double)Mdim * Ndim);
     return mpf::check(hipGetLastError(), "mpf_gemm3_nt");
+}
+
+extern "C" int mpf_gemm3_nt_grouped(const MpfNtItem* items, int n_items, int R, int rows_per_split, int64_t split_stride,
+                                    void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!items) return mpf::fail(MPF_E_NULL, "gemm3_nt_grouped: NULL items");
+    if (n_items <= 0 || n_items > kNtGroupMax) return mpf::fail(MPF_E_SHAPE, "gemm3_nt_grouped: 1..8 items");
+    if (R <= 0 || rows_per_split <= 0 || rows_per_split % kBK != 0 || split_stride <= 0)
+        return mpf::fail(MPF_E_SHAPE, "gemm3_nt_grouped: bad sizes (rows_per_split must be a positive multiple of 32)");
+    G3NG g;
+    memset(&g, 0, sizeof(g));
+    const int nsplit = (R + rows_per_split - 1) / rows_per_split;
+    int tiles = 0;
+    double bytes = 0.0, flops = 0.0;
+    for (int i = 0; i < n_items; ++i) {
+        const MpfNtItem& it = items[i];
+        if (!it.a || !it.b || !it.c_part) return mpf::fail(MPF_E_NULL, "gemm3_nt_grouped: NULL buffer");
+        if (it.Mdim <= 0 || it.Ndim <= 0 || it.Ndim % 4 != 0 || it.Mdim > (1 << 20) || it.Ndim > (1 << 20))
+            return mpf::fail(MPF_E_SHAPE, "gemm3_nt_grouped: Ndim must be a positive multiple of 4");
+        G3N& p = g.it[i];
+        p.a = it.a; p.b = it.b; p.b2 = nullptr; p.c = it.c_part; p.csum_a = it.csum_a; p.csum_b = nullptr;
+        p.lda = it.lda; p.ldb = it.ldb; p.ldb2 = 0;
+        p.R = R; p.Mdim = (int)it.Mdim; p.Ndim = (int)it.Ndim; p.b2_rows = 0; p.rows_per_split = rows_per_split;
+        p.nsplit = nsplit;
+        p.transpose_out = 0;
+        const uint64_t ab = ((uint64_t)(R - 1) * it.lda + it.Mdim) * 4, bb = ((uint64_t)(R - 1) * it.ldb + it.Ndim) * 4;
+        if (ab >= (1ull << 32) || bb >= (1ull << 32) || it.lda * 4 >= (1ll << 31) || it.ldb * 4 >= (1ll << 31))
+            return mpf::fail(MPF_E_TOO_LARGE, "gemm3_nt_grouped: an operand spans 4 GiB or more");
+        p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+        p.tiles_m = (p.Mdim + kBM - 1) / kBM;
+        p.tiles_n = (p.Ndim + 127) / 128;
+        p.ntiles = p.tiles_m * p.tiles_n * nsplit;
+        p.c_ss = p.csa_ss = split_stride; p.csb_ss = 0;
+        tiles += p.ntiles;
+        g.tile_end[i] = tiles;
+        bytes += 4.0 * ((double)R * p.Mdim + (double)R * p.Ndim + (double)nsplit * p.Mdim * p.Ndim);
+        flops += 2.0 * R * (double)p.Mdim * p.Ndim;
+    }
+    g.n_items = n_items; g.ntiles = tiles;
+    mpf::prof_begin(st);
+    mpf::set_kernel("gemm3_nt_group_kernel");
+    hipLaunchKernelGGL(gemm3_nt_group_kernel, dim3(((tiles + 7) / 8) * 8), dim3(kThreads), 0, st, g);
+    mpf::prof_end(mpf_last_kernel(), st, bytes, flops);
+    return mpf::check(hipGetLastError(), "mpf_gemm3_nt_grouped");
 }
 
 namespace {
@@ -1521,6 +1596,7 @@ extern "C" int mpf_gemm3_nt_ex(const void* a, int a_dtype, int64_t lda, const vo
     p.tiles_m = (Mdim + kBM - 1) / kBM;
     p.tiles_n = Ndim / 128;
     p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
+    p.c_ss = (int64_t)p.Mdim * p.Ndim; p.csa_ss = p.Mdim; p.csb_ss = p.Ndim;
     const dim3 grid(((p.ntiles + 7) / 8) * 8);
     mpf::prof_begin(st);
     mpf::set_kernel(a16 ? "gemm3_nt_kernel<a16>" : "gemm3_nt_kernel<b16>");
@@ -1552,6 +1628,7 @@ extern "C" int mpf_gemm3_conv3x3_wgrad(const float* dy, const float* x, float* c
     p.tiles_m = (Cout + kBM - 1) / kBM;
     p.tiles_n = 9 * Cin / 128;
     p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
+    p.c_ss = (int64_t)p.Mdim * p.Ndim; p.csa_ss = p.Mdim; p.csb_ss = p.Ndim;
     mpf::prof_begin(st);
     mpf::set_kernel("gemm3_nt_kernel<conv3x3>");
     hipLaunchKernelGGL((gemm3_nt_kernel<128, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
@@ -1593,6 +1670,7 @@ extern "C" int mpf_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64
     p.tiles_m = (Mdim + kBM - 1) / kBM;
     p.tiles_n = (Ndim + 127) / 128;
     p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
+    p.c_ss = (int64_t)p.Mdim * p.Ndim; p.csa_ss = p.Mdim; p.csb_ss = p.Ndim;
     const int grid = ((p.ntiles + 7) / 8) * 8;
     mpf::prof_begin(st);
     mpf::set_kernel("gemm3_nt_kernel<128, bf16>");

@@ -22,7 +22,7 @@ import math
 import torch
 from torch.autograd import Function
 
-from .gemm3 import gemm3, gemm3_nt, nt_reduce, nt_reduce_levels, split_weights_grouped
+from .gemm3 import gemm3, gemm3_nt, gemm3_nt_grouped, nt_reduce_levels, split_weights_grouped
 from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
 from .resln import ln256_backward, ln256_forward
 
@@ -71,11 +71,19 @@ def _balanced_rps(R, M, N, device, base=1 << 30):
     return rps
 
 
-def _wgrad(g2, x2, rps):
-    """dW[out, in] = g2^T . x2 and the bias gradient colsum(g2), both from the split-K NT GEMM."""
-    rps = _balanced_rps(g2.shape[0], g2.shape[1], x2.shape[1], g2.device)
-    c, ca, _ = gemm3_nt(g2, x2, rps, want_csum_a=True)
-    return nt_reduce(c, ca)
+def _wgrad_group(pairs):
+    """[(dW_i, db_i)] of several Linear layers over the same rows: ONE split-K launch whose splits are as long as the tiles
+    of all problems together allow at one round of workgroups (R = 43 008: 40 tiles x 12 splits of 3 584 rows instead of
+    4 x (4 | 16 tiles x 123 | 31 splits of 352 | 1 376 rows)) and ONE reduction."""
+    R = pairs[0][0].shape[0]
+    dev = pairs[0][0].device
+    slots = _slots.get(dev)
+    if slots is None:
+        slots = _slots[dev] = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+    tiles = sum(((g.shape[1] + 127) // 128) * ((x.shape[1] + 127) // 128) for g, x in pairs)
+    ns = max(1, slots // tiles)
+    rps = max(128, ((-(-R // ns)) + 31) // 32 * 32)
+    return gemm3_nt_grouped(pairs, rps)
 
 
 class EncoderFn(Function):
@@ -159,13 +167,10 @@ class EncoderFn(Function):
             # norm2 <- ffn
             ds2, dp[14], dp[15] = ln256_backward(s2, mean2, rstd2, g2, g, gq)
             dh = gemm3(ds2, t2, gate=h)
-            dp[12], dp[13] = _wgrad(ds2, h, rps)
             dx1 = gemm3(dh, t1, cin=ds2)
-            dp[10], dp[11] = _wgrad(dh, x1, rps)
             # norm1 <- attention
             ds1, dp[8], dp[9] = ln256_backward(s1, mean1, rstd1, g1, dx1)
             dao = gemm3(ds1, to)
-            dp[6], dp[7] = _wgrad(ds1, ao, rps)
             # d(raw): the softmax / offset-normaliser backward is the epilogue of the push kernel
             gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C))
             dq = gemm3(draw, t288)
@@ -188,7 +193,8 @@ class EncoderFn(Function):
             # joins inside the previous layer's norm2 backward (layer 0: added here)
             g = gemm3(gv2, tv, cin=ds1, cin2=dq if i == 0 else None)
             gq = dq
-            dp[4], dp[5] = _wgrad(gv2, x, rps)
+            # the four plain weight gradients of the layer (their operands are all alive here) as one launch
+            (dp[12], dp[13]), (dp[10], dp[11]), (dp[6], dp[7]), (dp[4], dp[5]) = _wgrad_group([(ds2, h), (dh, x1), (ds1, ao), (gv2, x)])
             dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp
         # d level_embed = sum_i lvl_i . [W_offsets_i ; W_weights_i]: one stacked product for all layers
         w288_all = torch.cat([params[i * PARAMS_PER_LAYER + k] for i in range(nl) for k in (0, 2)]).view(nl, -1, C)

@@ -123,6 +123,39 @@ def gemm3_nt(a, b, rows_per_split, b2=None, want_csum_a=False, want_csum_b=False
     return c, ca, cb
 
 
+def gemm3_nt_grouped(pairs, rows_per_split):
+    """The weight gradients of several Linear layers over the same rows in ONE split-K launch + ONE reduction.
+    pairs: [(g_i [R, M_i], x_i [R, N_i])] (fp32, row strides free, at most 8); returns [(dW_i [M_i, N_i], db_i [M_i])] with
+    dW_i = g_i^T . x_i and db_i = colsum(g_i) — views of one buffer.  Same partial sums as ``gemm3_nt`` with the same
+    ``rows_per_split`` (bit-identical)."""
+    import numpy as np
+    R = pairs[0][0].shape[0]
+    dev = pairs[0][0].device
+    ns = (R + rows_per_split - 1) // rows_per_split
+    offs, tot = [], 0
+    for g, x in pairs:
+        assert g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.dim() == 2 and x.dim() == 2
+        assert g.stride(1) == 1 and x.stride(1) == 1 and g.shape[0] == R and x.shape[0] == R and x.shape[1] % 4 == 0
+        offs.append(tot)
+        tot += g.shape[1] * x.shape[1] + g.shape[1]
+    tot = (tot + 3) // 4 * 4          # (the alignment tail, if any, is summed too and never read)
+    part = torch.empty((ns, tot), dtype=torch.float32, device=dev)
+    base = part.data_ptr()
+    items = np.empty((len(pairs), 8), dtype=np.int64)
+    for i, ((g, x), o) in enumerate(zip(pairs, offs)):
+        M, N = g.shape[1], x.shape[1]
+        items[i] = (g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), base + 4 * o, base + 4 * (o + M * N), M, N)
+    with torch.cuda.device(dev):
+        code = _lib.lib().mpf_gemm3_nt_grouped(items.ctypes.data, len(pairs), R, rows_per_split, tot, _stream(part))
+    _lib.check(code, "mpf_gemm3_nt_grouped")
+    out, _ = nt_reduce(part)
+    res = []
+    for (g, x), o in zip(pairs, offs):
+        M, N = g.shape[1], x.shape[1]
+        res.append((out[o:o + M * N].view(M, N), out[o + M * N:o + M * N + M]))
+    return res
+
+
 def nt_reduce(c_part, s_part=None):
     """(sum over splits of c_part [ns, ...], of s_part [ns, n] or None) in ONE launch, fixed order."""
     ns = c_part.shape[0]

@@ -142,6 +142,35 @@ def test_gemm3_nt_weight_gradient_accuracy(R, M, N, rps):
     torch.testing.assert_close(db.double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("R,rps,strided", [(4096, 512, False), (3000, 352, True), (43008, 3584, False)])
+def test_gemm3_nt_grouped_bit_equal_to_single_problems(R, rps, strided):
+    """The four weight gradients of an encoder layer in one launch: same tiles, same split boundaries, same order of products and
+    of the split sum as four ``gemm3_nt`` + ``nt_reduce`` calls -> bit-identical; ragged sizes and row strides included."""
+    from mp_former_amd.gemm3 import gemm3_nt, gemm3_nt_grouped, nt_reduce
+    dev = torch.device("cuda:0")
+    torch.manual_seed(R)
+    shapes = [(256, 1024), (1024, 256), (256, 256), (100, 36)] if R < 10000 else [(256, 1024), (1024, 256), (256, 256), (256, 256)]
+    pairs = []
+    for (M, N) in shapes:
+        if strided:
+            g = torch.randn(R, M + 8, device=dev)[:, 4:4 + M]
+            x = torch.randn(R, N + 4, device=dev)[:, :N]
+        else:
+            g, x = torch.randn(R, M, device=dev), torch.randn(R, N, device=dev)
+        pairs.append((g, x))
+    got = gemm3_nt_grouped(pairs, rps)
+    for (g, x), (dw, db) in zip(pairs, got):
+        c, ca, _ = gemm3_nt(g, x, rps, want_csum_a=True)
+        N = x.shape[1]
+        same_tile = -N % 128 <= -N % 96           # the single-problem entry takes 96-column tiles (another MFMA shape) when they waste less
+        if same_tile and c[0].numel() % 4 == 0 and ca[0].numel() % 4 == 0:
+            wdw, wdb = nt_reduce(c, ca)
+            assert torch.equal(dw, wdw) and torch.equal(db, wdb), (g.shape, x.shape)
+        ref = g.double().t() @ x.double()
+        assert float((dw.double() - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1.0) * max(1.0, (R / 4096) ** 0.5)
+        torch.testing.assert_close(db.double(), g.double().sum(0), rtol=1e-5, atol=1e-4 * max(1.0, (R / 4096) ** 0.5))
+
+
 @pytest.mark.parametrize("M,N,K,adt,cdt", [(300, 288, 64, "bf16", "f32"), (4099, 256, 512, "bf16", "f32"), (1000, 256, 256, "f32", "bf16"),
                                             (129, 128, 2048, "bf16", "bf16"), (640, 96, 96, "bf16", "f32")])
 def test_gemm3_tn_bf16_operand_and_result(M, N, K, adt, cdt):
