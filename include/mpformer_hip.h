@@ -538,6 +538,41 @@ int mpf_grouped_scale_cast(const MpfScaleCastItem* items_device, int n_items, in
                            void* stream);
 
 /*
+ * The fp16 x 2 form of the same GEMMs ("_h2"): every fp32 operand x is scaled by a power of two s (chosen from the operand's
+ * largest magnitude so that s * amax lies in [2^14, 2^15)) and split into TWO fp16 pieces h = fp16(s x), l = fp16(s x - h),
+ * both rounded to nearest (|s x - h - l| <= 2^-23 |s x| while l is a normal fp16 number, i.e. for elements within 2^-18 of the
+ * operand's largest; smaller elements keep >= 11 bits and lose one bit per further binade), and a product is the three
+ * MFMA products l*h + h*l + h*h in the fp32 accumulator, rescaled by 1 / (s_a s_b) in the epilogue.  Half the matrix-core
+ * work of the three-piece bf16 form; measured error against fp64 at or below the library fp32 GEMM's
+ * (tests/test_gemm3_gpu.py).  The largest magnitudes live on the DEVICE in "amax slots" of MPF_AMAX_SLOT_FLOATS floats (16
+ * sub-slots on different cache lines, so that the one atomic max per producing workgroup does not serialise on one address;
+ * the value is the largest of the sub-slots): filled by mpf_amax_f32 or by the out_amax argument of the GEMM that produced
+ * the operand, into a slot the caller has zeroed; every kernel derives the same scale from the same slot.
+ *   mpf_amax_f32_grouped: item i (device table) = x_i[0 .. numel_i) -> *out_i, workgroups [first_block, + ceil(numel / 4096));
+ *   mpf_gemm3_split_grouped_h2: mpf_gemm3_split_grouped writing planes[2][..] of fp16 with the scale from *amax;
+ *   mpf_gemm3_tn_h2: mpf_gemm3_tn without the a2 rows, N % 256 == 0; out_amax (may be NULL) receives max |C|.
+ */
+#define MPF_AMAX_SLOT_FLOATS 512
+typedef struct MpfAmaxItem {
+    const float* src;
+    float* out;
+    int64_t numel, first_block;
+} MpfAmaxItem;
+typedef struct MpfSplitItemH2 {
+    const float* src;
+    void* dst;
+    const float* amax;
+    int64_t rows, cols, transpose, dst_ld, plane_stride, first_block;
+} MpfSplitItemH2;
+int mpf_amax_f32(const float* x, int64_t n, float* amax, void* stream);
+int mpf_amax_f32_grouped(const MpfAmaxItem* items_device, int n_items, int64_t total_blocks, void* stream);
+int mpf_gemm3_split_grouped_h2(const MpfSplitItemH2* items_device, int n_items, int64_t total_blocks, void* stream);
+int mpf_gemm3_tn_h2(const float* a, int64_t lda, const float* a_amax, const void* b_planes_h2, const float* b_amax,
+                    const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
+                    const float* gate, int64_t ldgate, float* c, int64_t ldc, float* out_amax, int M, int N, int K,
+                    int relu, void* stream);
+
+/*
  * Several weight gradients over the SAME rows in one launch (the four Linear layers of an encoder layer whose operands are
  * alive at the end of the layer's backward, msdeformattn.py:103-131): item i is the problem of mpf_gemm3_nt without b2 /
  * csum_b / transpose_out,

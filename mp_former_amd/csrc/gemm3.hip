@@ -24,6 +24,7 @@
 // owns 4 consecutive output columns of one row (16-B stores, bias as float4).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <stdint.h>
 
@@ -57,6 +58,11 @@ struct G3 {
     unsigned short* c16;                      // bf16 output instead of c (NULL: fp32)
     int cv_H, cv_W, cv_cin, cv_sign;          // 3x3 convolution mode (gemm3_conv_kernel): image size, channels per tap, +1 / -1
     int tm0, ntiles2, tiles_n2;      // mixed launch: row blocks >= tm0 are cut into ntiles2 tiles of 64 columns (tiles_n2 per row block)
+    // fp16 x 2 form (H2 kernels): largest magnitudes of A and of the matrix the B planes were split from (device floats), and
+    // an optional slot that receives max |C| (atomic max of the bit patterns: order-independent)
+    const float* a_amax;
+    const float* b_amax;
+    float* out_amax;
 };
 
 int g_ablate = 0;      // mpf_set_option("gemm3_ablate"): reserved for timing experiments
@@ -101,6 +107,80 @@ __device__ __forceinline__ void split8(const float4 u, const float4 v, uint4* h,
     *h = make_uint4(pack_hi16(hb[0], hb[1]), pack_hi16(hb[2], hb[3]), pack_hi16(hb[4], hb[5]), pack_hi16(hb[6], hb[7]));
     *m = make_uint4(pack_hi16(mb[0], mb[1]), pack_hi16(mb[2], mb[3]), pack_hi16(mb[4], mb[5]), pack_hi16(mb[6], mb[7]));
     *l = make_uint4(pack_hi16(lb[0], lb[1]), pack_hi16(lb[2], lb[3]), pack_hi16(lb[4], lb[5]), pack_hi16(lb[6], lb[7]));
+}
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// 8 floats -> two planes of 8 fp16 of (scale * x): h = fp16(s) and l = fp16(s - h), both rounded to nearest — 11 + 11 (+ 1
+// from the rounding of h) significand bits, |s - h - l| <= 2^-23 |s| while l stays a normal fp16 number.  scale is a power of
+// two chosen from the operand's largest magnitude (so that it lands in [2^14, 2^15)): exact, and undone in the epilogue.
+__device__ __forceinline__ void split8h(const float4 u, const float4 v, const float scale, uint4* h, uint4* l)
+{
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    unsigned hb[4], lb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 s = {x[2 * i] * scale, x[2 * i + 1] * scale};
+        const f16x2 hh = __builtin_convertvector(s, f16x2);
+        const f32x2 back = __builtin_convertvector(hh, f32x2);
+        const f32x2 r = {s[0] - back[0], s[1] - back[1]};
+        const f16x2 ll = __builtin_convertvector(r, f16x2);
+        union { f16x2 f; unsigned u; } ch, cl;
+        ch.f = hh; cl.f = ll;
+        hb[i] = ch.u; lb[i] = cl.u;
+    }
+    *h = make_uint4(hb[0], hb[1], hb[2], hb[3]);
+    *l = make_uint4(lb[0], lb[1], lb[2], lb[3]);
+}
+
+// An "amax slot" is kAmaxSub sub-slots kAmaxStride floats apart (different cache lines): producers max into the sub-slot
+// blockIdx.x % kAmaxSub with ONE atomic per workgroup (device-scope atomics on one address serialise at ~11 ns each: 8 192 of
+// them cost a 44 MB reduction 90 us), consumers take the largest of the 16.  Non-negative floats order like their bit
+// patterns and a NaN pattern is larger than inf, so the integer max is order-independent and keeps a NaN visible.
+constexpr int kAmaxSub = 16, kAmaxStride = 32;
+
+__device__ __forceinline__ unsigned amax_read(const float* slot)
+{
+    const unsigned* s = reinterpret_cast<const unsigned*>(slot);
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < kAmaxSub; ++i) m = max(m, s[i * kAmaxStride]);
+    return m;
+}
+
+// power-of-two scale that puts amax into [2^14, 2^15) (fp16 tops out at 65504) and its inverse, from the exponent field:
+// exact, and the same for every kernel that looks at the same amax.  amax below 2^-97 (incl. 0) counts as 2^-97; inf / nan
+// give a finite scale (the values themselves stay inf / nan and so does the result).
+__device__ __forceinline__ void h2_scale(const unsigned amax_bits, float* scale, float* inv)
+{
+    int e = (int)((amax_bits >> 23) & 0xffu);
+    e = max(e, 30);
+    *scale = __uint_as_float((unsigned)(268 - e) << 23);       // 2^(14 - (e - 127))
+    *inv = __uint_as_float((unsigned)(e - 14) << 23);          // 2^-(14 - (e - 127))
+}
+
+// running max |x| of the threads of a workgroup (256 threads) -> one atomic max; red: 4 floats of LDS nobody else is using
+// (called by all threads, contains a barrier)
+__device__ __forceinline__ void amax_commit(float* slot, float m, float* red)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(reinterpret_cast<unsigned*>(slot) + (blockIdx.x % kAmaxSub) * kAmaxStride, __float_as_uint(m));
+    }
+}
+
+__device__ __forceinline__ f16x8 as_fragh(const uint4 v)
+{
+    union { uint4 u; f16x8 f; } c;
+    c.u = v;
+    return c.f;
 }
 
 __device__ __forceinline__ float4 add4(float4 x, float4 y) { return make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); }
@@ -314,9 +394,12 @@ int g3_consts(const float** out, const char* who)
     return 0;
 }
 
-template <int NJ, int NI = 4, typename AccT = Acc<NJ, false>>
-__device__ __forceinline__ void g3_epilogue(const G3& p, const AccT& acc, int lane, int m_wave, int n_wave)
+// returns the largest |value| this thread stored (SCALED kernels; 0 otherwise)
+template <int NJ, int NI = 4, typename AccT = Acc<NJ, false>, bool SCALED = false>
+__device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int lane, int m_wave, int n_wave, const float inv_a = 1.f,
+                                            const float inv_b = 1.f)
 {
+    float amax = 0.f;
     const int r16 = lane & 15, g = lane >> 4;
     int64_t mrow[NI];
     bool mok[NI];
@@ -342,6 +425,8 @@ __device__ __forceinline__ void g3_epilogue(const G3& p, const AccT& acc, int la
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             float4 o = make_float4(acc.v[i][j][0], acc.v[i][j][1], acc.v[i][j][2], acc.v[i][j][3]);
+            if constexpr (SCALED)      // two factors: each is a representable power of two, their product need not be
+                o = make_float4(o.x * inv_a * inv_b, o.y * inv_a * inv_b, o.z * inv_a * inv_b, o.w * inv_a * inv_b);
             // same order of additions as before: bias, addend 1, addend 2
             o = make_float4(o.x + bz.x, o.y + bz.y, o.z + bz.z, o.w + bz.w);
             o = make_float4(o.x + ci[i].x, o.y + ci[i].y, o.z + ci[i].z, o.w + ci[i].w);
@@ -350,6 +435,7 @@ __device__ __forceinline__ void g3_epilogue(const G3& p, const AccT& acc, int la
             // ReLU backward: pass the gradient where the saved activation is > 0
             o = make_float4(gt[i].x > 0.f ? o.x : 0.f, gt[i].y > 0.f ? o.y : 0.f, gt[i].z > 0.f ? o.z : 0.f, gt[i].w > 0.f ? o.w : 0.f);
             if (mok[i] && nok) {
+                if constexpr (SCALED) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                 if (p.c16) {                 // (uniform; stores only) round to nearest even
                     unsigned w[4];
                     const float e[4] = {o.x, o.y, o.z, o.w};
@@ -366,6 +452,7 @@ __device__ __forceinline__ void g3_epilogue(const G3& p, const AccT& acc, int la
             }
         }
     }
+    return amax;
 }
 
 // one DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_addr, lds_addr + 1024) (M0 = LDS address
@@ -628,10 +715,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
 //   barrier a | split + write A(k) | DMA half 1 of k -> stage 1 | wait half 0 of k | barrier b | A loads of k + 2 |
 //   pass 0 (stage 0) | wait half 1 | barrier c | DMA half 0 of k + 1 -> stage 0 | pass 1 (stage 1)
 // Same products in the same order per output element as the 128 x 128 tile: bit-identical results.
-template <int NI, int AKC>
+template <int NI, int AKC, bool F16 = false>
 struct Acc2 {
     f32x4 v[2][NI][4];
-    bf16x8 fa[3][NI];
+    bf16x8 fa[F16 ? 1 : 3][NI];
+    f16x8 fh[F16 ? 2 : 1][NI];
 
     __device__ __forceinline__ void zero()
     {
@@ -646,6 +734,13 @@ struct Acc2 {
     {
         const int r16 = lane & 15, g = lane >> 4;
         const int a_frag = a_base + g * AKC + (r16 ^ (2 * g)) * 16;
+        if constexpr (F16) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fh[pl][i] = as_fragh(*reinterpret_cast<const uint4*>(lds + a_frag + pl * 4 * AKC + i * 256));
+            return;
+        }
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
@@ -657,6 +752,21 @@ struct Acc2 {
         constexpr int BKC = 128 * 16;
         const int r16 = lane & 15, g = lane >> 4;
         const int b_frag = b_base + (r16 * 4 + (g ^ ((0 - (r16 >> 2)) & 3))) * 16;
+        if constexpr (F16) {       // two fp16 pieces per operand: l*h + h*l + h*h, smallest first
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f16x8 fb[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) fb[pl] = as_fragh(*reinterpret_cast<const uint4*>(lds + b_frag + pl * 4 * BKC + j * 1024));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) v[H][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[1], fh[0][i], v[H][i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) v[H][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[0], fh[1][i], v[H][i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) v[H][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[0], fh[0][i], v[H][i][j], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bf16x8 fb[3];
@@ -682,7 +792,7 @@ struct Acc2 {
 // the A tile are staged by the first two waves)
 // CV: the 3x3 convolution mode of g3_tn_tile (K step kt belongs to tap kt / (Cin / 32); rows shifted by the tap, taps off
 // the image zeroed before the split)
-template <int BM, bool CV = false>
+template <int BM, bool CV = false, bool F16 = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
 {
     static_assert(BM == 128 || BM == 96, "row blocks of 128 or 96");
@@ -691,8 +801,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
     constexpr int NI = BM / 32;                      // 16-row MFMA tiles per wave
     constexpr int kAKcT = BM * 16;                   // bytes per (plane, k-chunk) of the A image
     constexpr int kBKc = BN * 16;
-    constexpr int kAbytes = 12 * kAKcT;
-    constexpr int kBstage = 12 * kBKc;
+    constexpr int kPl = F16 ? 2 : 3;                 // planes per operand
+    constexpr int kAbytes = kPl * 4 * kAKcT;
+    constexpr int kBstage = kPl * 4 * kBKc;
     constexpr int kPW = kBstage / 1024 / 4;          // 6 DMA pieces per wave and stage
     __shared__ __attribute__((aligned(16))) unsigned char lds[kAbytes + 2 * kBstage];
     const int per_xcd = (p.ntiles + 7) >> 3;
@@ -772,6 +883,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
             w2_ = make_float4(w2_.x * s1_, w2_.y * s1_, w2_.z * s1_, w2_.w * s1_);           \
             w3_ = make_float4(w3_.x * s1_, w3_.y * s1_, w3_.z * s1_, w3_.w * s1_);           \
         }                                                                                    \
+        if constexpr (F16) {                                                                 \
+            split8h(w0_, w1_, sc_a, &h, &l);                                                 \
+            *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKcT + aslot0 * 16) = h;        \
+            *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKcT + aslot0 * 16) = l;        \
+            if (second) {                                                                    \
+                split8h(w2_, w3_, sc_a, &h, &l);                                             \
+                *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKcT + aslot1 * 16) = h;    \
+                *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKcT + aslot1 * 16) = l;    \
+            }                                                                                \
+        } else {                                                                             \
         split8(w0_, w1_, &h, &m, &l);                                                        \
         *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKcT + aslot0 * 16) = h;            \
         *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKcT + aslot0 * 16) = m;            \
@@ -782,9 +903,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
             *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKcT + aslot1 * 16) = m;        \
             *reinterpret_cast<uint4*>(lds + (2 * 4 + akc) * kAKcT + aslot1 * 16) = l;        \
         }                                                                                    \
+        }                                                                                    \
     }
 
-    Acc2<NI, kAKcT> acc;
+    float sc_a = 1.f, inv_a = 1.f, inv_b = 1.f;
+    if constexpr (F16) {
+        float sc_b;
+        h2_scale(amax_read(p.a_amax), &sc_a, &inv_a);
+        h2_scale(amax_read(p.b_amax), &sc_b, &inv_b);
+    }
+    (void)sc_a;
+    Acc2<NI, kAKcT, F16> acc;
     acc.zero();
     const int a_frag = wr * (BM / 2) * 16;
     const int b_frag = kAbytes + wc * 64 * 64;
@@ -823,6 +952,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
 #undef G3_LA2
 #undef G3_DMA2
 #undef G3_WRITE2
+    float omax = 0.f;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         struct { f32x4 v[NI][4]; } out;
@@ -830,8 +960,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_tn2_kernel(G3 p)
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) out.v[i][j] = acc.v[h][i][j];
-        g3_epilogue<4, NI>(p, out, lane, m0 + wr * (BM / 2), n0 + h * 128 + wc * 64);
+        omax = fmaxf(omax, g3_epilogue<4, NI, decltype(out), F16>(p, out, lane, m0 + wr * (BM / 2), n0 + h * 128 + wc * 64, inv_a, inv_b));
     }
+    if constexpr (F16) {
+        if (p.out_amax) amax_commit(p.out_amax, omax, reinterpret_cast<float*>(lds));
+    }
+    (void)omax;
 }
 
 // A in bf16 (g3_tn_tile<.., ABF>): activations that ARE bf16 (the backbone's feature maps under autocast, the bf16
@@ -1215,7 +1349,124 @@ __global__ __launch_bounds__(256) void gemm3_split_grouped_kernel(const MpfSplit
     }
 }
 
+// ---- fp16 x 2 form: largest magnitudes and the weight planes -------------------------------------------------------------
+// items[i] (device table): x_i[0 .. n_i) -> atomic max of |x| into *out_i (several items may share a slot: one operand stacked
+// from two weights); item i owns workgroups [first_block, first_block + ceil(n_i / 4096))
+__global__ __launch_bounds__(256) void amax_grouped_kernel(const MpfAmaxItem* __restrict__ items, int n_items)
+{
+    int lo = 0, hi = n_items - 1;
+    const int64_t blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const MpfAmaxItem it = items[lo];
+    const int64_t base = (blk - it.first_block) * 4096;
+    float m = 0.f;
+    if (((uintptr_t)it.src & 15) == 0 && base + 4096 <= it.numel) {
+        const float4* __restrict__ s4 = reinterpret_cast<const float4*>(it.src + base);
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = s4[k * 256 + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+    } else {
+        for (int64_t i = base + threadIdx.x; i < min(base + 4096, it.numel); i += 256) m = fmaxf(m, fabsf(it.src[i]));
+    }
+    __shared__ float red[4];
+    amax_commit(it.out, m, red);
+}
+
+// one tensor, grid-stride (activations: tens of MB)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n4, int64_t n, float* __restrict__ out)
+{
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    float m = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = x4[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[k].x), fabsf(v[k].y))), fmaxf(fabsf(v[k].z), fabsf(v[k].w)));
+    }
+    for (; i < n4; i += stride) {
+        const float4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (int64_t j = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) m = fmaxf(m, fabsf(x[j]));
+    __shared__ float red[4];
+    amax_commit(out, m, red);
+}
+
+// the split of gemm3_split_grouped_kernel into TWO fp16 planes of (scale x w), scale from *amax (h2_scale)
+__global__ __launch_bounds__(256) void gemm3_split_grouped_h2_kernel(const MpfSplitItemH2* __restrict__ items, int n_items)
+{
+    int lo = 0, hi = n_items - 1;
+    const int64_t blk = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+    }
+    const MpfSplitItemH2 it = items[lo];
+    const float* __restrict__ w = it.src;
+    _Float16* __restrict__ out = static_cast<_Float16*>(it.dst);
+    float scale, inv;
+    h2_scale(amax_read(it.amax), &scale, &inv);
+    const int R = (int)it.rows, C = (int)it.cols;
+    const int64_t total = (int64_t)R * C, base = (blk - it.first_block) * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;       // index in the (possibly transposed) output matrix
+        if (i >= total) continue;
+        int r, c;
+        int64_t o;
+        if (it.transpose) { c = (int)(i / R); r = (int)(i - (int64_t)c * R); o = (int64_t)c * it.dst_ld + r; }
+        else { r = (int)(i / C); c = (int)(i - (int64_t)r * C); o = (int64_t)r * it.dst_ld + c; }
+        const float x = w[(int64_t)r * C + c] * scale;
+        const _Float16 h = (_Float16)x;
+        out[o] = h;
+        out[it.plane_stride + o] = (_Float16)(x - (float)h);
+    }
+}
+
 }  // namespace
+
+extern "C" int mpf_amax_f32(const float* x, int64_t n, float* amax, void* stream)
+{
+    if (!x || !amax) return mpf::fail(MPF_E_NULL, "amax_f32: NULL buffer");
+    if (n <= 0) return 0;
+    if ((uintptr_t)x & 15) return mpf::fail(MPF_E_SHAPE, "amax_f32: x must be 16-byte aligned");
+    const int64_t n4 = n / 4;
+    const int blocks = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n4 + 1023) / 1024));
+    mpf::prof_begin((hipStream_t)stream);
+    mpf::set_kernel("amax_kernel");
+    hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n4, n, amax);
+    mpf::prof_end("amax_kernel", (hipStream_t)stream, 4.0 * (double)n);
+    return mpf::check(hipGetLastError(), "mpf_amax_f32");
+}
+
+extern "C" int mpf_amax_f32_grouped(const MpfAmaxItem* items_device, int n_items, int64_t total_blocks, void* stream)
+{
+    if (n_items == 0 || total_blocks == 0) return 0;
+    if (!items_device) return mpf::fail(MPF_E_NULL, "amax_f32_grouped: NULL table");
+    if (n_items < 0 || total_blocks < 0 || total_blocks > 0x7fffffffLL) return mpf::fail(MPF_E_SHAPE, "amax_f32_grouped: bad sizes");
+    mpf::set_kernel("amax_grouped_kernel");
+    hipLaunchKernelGGL(amax_grouped_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_device, n_items);
+    return mpf::check(hipGetLastError(), "mpf_amax_f32_grouped");
+}
+
+extern "C" int mpf_gemm3_split_grouped_h2(const MpfSplitItemH2* items_device, int n_items, int64_t total_blocks, void* stream)
+{
+    if (n_items == 0 || total_blocks == 0) return 0;
+    if (!items_device) return mpf::fail(MPF_E_NULL, "gemm3_split_grouped_h2: NULL table");
+    if (n_items < 0 || total_blocks < 0 || total_blocks > 0x7fffffffLL) return mpf::fail(MPF_E_SHAPE, "gemm3_split_grouped_h2: bad sizes");
+    mpf::set_kernel("gemm3_split_grouped_h2_kernel");
+    hipLaunchKernelGGL(gemm3_split_grouped_h2_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_device,
+                       n_items);
+    return mpf::check(hipGetLastError(), "mpf_gemm3_split_grouped_h2");
+}
 
 int mpf::set_gemm3_option(const char* key, int v)
 {
@@ -1269,15 +1520,46 @@ static bool g3_launch_two_pass(G3& p, hipStream_t st)
     p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
     mpf::prof_begin(st);
     mpf::set_kernel(use96r ? "gemm3_tn_kernel<96x256>" : "gemm3_tn_kernel<128x256>");
+    if (p.a_amax) {
+        mpf::set_kernel(use96r ? "gemm3_tn_kernel<h2 96x256>" : "gemm3_tn_kernel<h2 128x256>");
+        if (use96r) hipLaunchKernelGGL((gemm3_tn2_kernel<96, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
+        else hipLaunchKernelGGL((gemm3_tn2_kernel<128, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
+        return true;
+    }
     if (use96r) hipLaunchKernelGGL(gemm3_tn2_kernel<96>, dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
     else hipLaunchKernelGGL(gemm3_tn2_kernel<128>, dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
     return true;
 }
 
+static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows, const void* b_planes,
+                      const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
+                      const float* gate, int64_t ldgate, float* c, int64_t ldc, int M, int N, int K,
+                      int relu, void* stream, const float* a_amax, const float* b_amax, float* out_amax);
+
 extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2_rows, const void* b_planes,
                             const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
                             const float* gate, int64_t ldgate, float* c, int64_t ldc, int M, int N, int K,
                             int relu, void* stream)
+{
+    return g3_tn_impl(a, lda, a2, a2_rows, b_planes, bias, c_in, ldcin, c_in2, ldcin2, gate, ldgate, c, ldc, M, N, K, relu, stream,
+                      nullptr, nullptr, nullptr);
+}
+
+extern "C" int mpf_gemm3_tn_h2(const float* a, int64_t lda, const float* a_amax, const void* b_planes_h2, const float* b_amax,
+                               const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
+                               const float* gate, int64_t ldgate, float* c, int64_t ldc, float* out_amax, int M, int N, int K,
+                               int relu, void* stream)
+{
+    if (!a_amax || !b_amax) return mpf::fail(MPF_E_NULL, "gemm3_tn_h2: NULL amax");
+    if (N % 256 != 0) return mpf::fail(MPF_E_SHAPE, "gemm3_tn_h2: N must be a multiple of 256");
+    return g3_tn_impl(a, lda, nullptr, 0, b_planes_h2, bias, c_in, ldcin, c_in2, ldcin2, gate, ldgate, c, ldc, M, N, K, relu, stream,
+                      a_amax, b_amax, out_amax);
+}
+
+static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows, const void* b_planes,
+                      const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
+                      const float* gate, int64_t ldgate, float* c, int64_t ldc, int M, int N, int K,
+                      int relu, void* stream, const float* a_amax, const float* b_amax, float* out_amax)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!a || !b_planes || !c) return mpf::fail(MPF_E_NULL, "gemm3_tn: NULL buffer");
@@ -1287,10 +1569,12 @@ extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2
         return mpf::fail(MPF_E_SHAPE, "gemm3_tn: K must be a multiple of 32; N, lda, ldc multiples of 4");
     if (a2 && a2_rows <= 0) return mpf::fail(MPF_E_SHAPE, "gemm3_tn: a2_rows must be positive");
     G3 p;
+    p.a_amax = nullptr; p.b_amax = nullptr; p.out_amax = nullptr;
     p.a = a; p.a2 = a2; p.bp = (const unsigned short*)b_planes; p.bias = bias; p.cin = c_in; p.c = c;
     p.cin2 = c_in2; p.gate = gate; p.ldcin2 = ldcin2; p.ldgate = ldgate;
     p.lda = lda; p.ldc = ldc; p.ldcin = ldcin; p.plane = (int64_t)N * K;
     p.M = M; p.N = N; p.K = K; p.a2_rows = a2_rows; p.relu = relu; p.c16 = nullptr;
+    p.a_amax = a_amax; p.b_amax = b_amax; p.out_amax = out_amax;
     {
         const float* consts = nullptr;
         if (int rc = g3_consts(&consts, "gemm3_tn: constants")) return rc;
@@ -1308,9 +1592,10 @@ extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2
     p.ntiles = tiles_m * p.tiles_n;
     p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
     if (!a2 && g3_launch_two_pass(p, st)) {
-        mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + 6.0 * (double)N * K, 2.0 * M * (double)N * K);
+        mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + (a_amax ? 4.0 : 6.0) * (double)N * K, 2.0 * M * (double)N * K);
         return mpf::check(hipGetLastError(), "mpf_gemm3_tn");
     }
+    if (a_amax) return mpf::fail(MPF_E_SHAPE, "gemm3_tn_h2: shape outside the two-pass tiles");
     // tail effect: when the last round of 128 x 128 tiles would fill at most half of the chip's workgroup slots, its row
     // blocks are cut into 128 x 64 tiles instead (gemm3_tn_mixed_kernel)
     if (!use96 && N % 64 == 0 && g_mixed) {
@@ -1369,6 +1654,7 @@ extern "C" int mpf_gemm3_tn_ex(const void* a, int a_dtype, int64_t lda, const vo
     const float* consts = nullptr;
     if (int rc = g3_consts(&consts, "gemm3_tn_ex: constants")) return rc;
     G3 p;
+    p.a_amax = nullptr; p.b_amax = nullptr; p.out_amax = nullptr;
     p.a = (const float*)a; p.a2 = nullptr; p.bp = (const unsigned short*)b_planes;
     p.bias = bias ? bias : consts; p.bias_cm = bias ? 1 : 0;
     p.cin = c_in ? c_in : consts; p.ldcin = c_in ? ldcin : 0; p.cin_cm = c_in ? 1 : 0;
@@ -1414,6 +1700,7 @@ extern "C" int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const flo
     const int64_t M64 = (int64_t)n_img * H * W;
     if (M64 >= (1ll << 31) / 4 || M64 * Cin >= (1ll << 40)) return mpf::fail(MPF_E_TOO_LARGE, "gemm3_conv3x3: image too large");
     G3 p;
+    p.a_amax = nullptr; p.b_amax = nullptr; p.out_amax = nullptr;
     const float* consts = nullptr;
     if (int rc = g3_consts(&consts, "gemm3_conv3x3: constants")) return rc;
     p.a = x; p.a2 = nullptr; p.bp = (const unsigned short*)w_planes; p.c = y;

@@ -22,7 +22,8 @@ import math
 import torch
 from torch.autograd import Function
 
-from .gemm3 import gemm3, gemm3_nt, gemm3_nt_grouped, nt_reduce_levels, split_weights_grouped
+from .gemm3 import (amax, amax_slots, gemm3, gemm3_h2, gemm3_nt, gemm3_nt_grouped, nt_reduce_levels, split_weights_grouped,
+                    split_weights_grouped_h2)
 from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
 from .resln import ln256_backward, ln256_forward
 
@@ -101,37 +102,46 @@ class EncoderFn(Function):
         saved = []
         no = M * L * P * 2
         q = None
-        # bf16 planes of every weight, both orientations (W for forward, W^T for the input gradients), in ONE
-        # launch; sampling_offsets | attention_weights are stacked into one 288-row operand on the way
-        groups = []
+        # fp16 x 2 planes (+ largest magnitude) of every weight whose GEMMs have N % 256 == 0, both orientations (W for the
+        # forward, W^T for the input gradients), and bf16 x 3 planes of the stacked 288-row sampling_offsets | attention_weights
+        # operand — three launches for all layers
+        g2, g3 = [], []
         for i in range(nl):
             (wso, _, waw, _, wv, _, wo, _, _, _, w1, _, w2, _, _, _) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            ws = ([wv], [wso, waw], [wo], [w1], [w2])
-            groups += [(w_, False) for w_ in ws] + [(w_, True) for w_ in ws]
-        planes = split_weights_grouped(groups)
+            ws = ([wv], [wo], [w1], [w2])
+            g2 += [(w_, False) for w_ in ws] + [(w_, True) for w_ in ws] + [([wso, waw], True)]
+            g3.append(([wso, waw], False))
+        planes2 = split_weights_grouped_h2(g2)
+        planes3 = split_weights_grouped(g3)
         # the 288-wide bias of every layer in one concatenation
         b288_all = torch.cat([params[i * PARAMS_PER_LAYER + k] for i in range(nl) for k in (1, 3)]).view(nl, -1)
+        am = amax_slots(4 * nl + 1, src.device)          # per layer: ao, x1, h, the next layer's x
+        x_am = amax(x, am[4 * nl])
         for i in range(nl):
-            (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            pv, p288, po, p1, p2 = planes[10 * i:10 * i + 5]
+            (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2_, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
+            (pv, pv_am), (po, po_am), (p1, p1_am), (p2, p2_am) = planes2[9 * i:9 * i + 4]
+            p288 = planes3[i]
             b288 = b288_all[i]
-            value = gemm3(x, pv, bv)
+            ao_am, x1_am, h_am, xn_am = am[4 * i], am[4 * i + 1], am[4 * i + 2], am[4 * i + 3]
+            value = gemm3_h2(x, x_am, pv, pv_am, bv)
             if q is None:       # layer 0; later layers get src + pos from the previous layer's norm2 pass
                 q = (x.view(N, S, C) + pos_full).view(R, C)
             raw = gemm3(q, p288, b288)
             # softmax over the 12 logits, loc = ref + offset / (W_l, H_l) happen inside the MSDA kernel
             ao, loc, attn = ms_deform_attn_forward_raw(value.view(N, S, M, C // M), shapes, lsi, raw, ref, host_shapes)
             ao = ao.view(R, C)
-            s1 = gemm3(ao, po, bo, cin=x)
+            s1 = gemm3_h2(ao, amax(ao, ao_am), po, po_am, bo, cin=x)
             x1, mean1, rstd1, _ = ln256_forward(s1, g1, b1, _EPS)
-            h = gemm3(x1, p1, bb1, relu=True)
-            s2 = gemm3(h, p2, bb2, cin=x1)
-            x2, mean2, rstd2, qn = ln256_forward(s2, g2, b2, _EPS, padd=pos_full if i + 1 < nl else None)
-            saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2]
+            h = gemm3_h2(x1, amax(x1, x1_am), p1, p1_am, bb1, relu=True, out_amax=h_am)
+            s2 = gemm3_h2(h, h_am, p2, p2_am, bb2, cin=x1)
+            x2, mean2, rstd2, qn = ln256_forward(s2, g2_, b2, _EPS, padd=pos_full if i + 1 < nl else None)
+            saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am]
             x, q = x2, qn
+            if i + 1 < nl:
+                x_am = amax(x, xn_am)
         ctx.save_for_backward(pos_full, level_embed, *params, *saved)
         ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
-        ctx.planes_t = [planes[10 * i + 5:10 * i + 10] for i in range(nl)]       # W^T planes for the backward
+        ctx.planes_t = [planes2[9 * i + 4:9 * i + 9] for i in range(nl)]       # (W^T planes, amax) for the backward
         return x.view(N, S, C)
 
     @staticmethod
@@ -157,23 +167,25 @@ class EncoderFn(Function):
                 split_level = meta["level_idx"][::rps].repeat(N)          # level of every split's rows
                 meta[key] = split_level
         dparams = [None] * (nl * PARAMS_PER_LAYER)
+        am = amax_slots(5 * nl, g.device)               # per layer: ds2, dh, ds1, draw, gv
         lvls = [None] * nl
         gq = None
         for i in reversed(range(nl)):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2) = saved[i * 14:(i + 1) * 14]
+            (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am) = saved[i * 18:(i + 1) * 18]
             dp = [None] * PARAMS_PER_LAYER
-            tv, t288, to, t1, t2 = ctx.planes_t[i]
+            (tv, tv_am), (to, to_am), (t1, t1_am), (t2, t2_am), (t288, t288_am) = ctx.planes_t[i]
+            ds2_am, dh_am, ds1_am, draw_am, gv_am = am[5 * i:5 * i + 5]
             # norm2 <- ffn
             ds2, dp[14], dp[15] = ln256_backward(s2, mean2, rstd2, g2, g, gq)
-            dh = gemm3(ds2, t2, gate=h)
-            dx1 = gemm3(dh, t1, cin=ds2)
+            dh = gemm3_h2(ds2, amax(ds2, ds2_am), t2, t2_am, gate=h, out_amax=dh_am)
+            dx1 = gemm3_h2(dh, dh_am, t1, t1_am, cin=ds2)
             # norm1 <- attention
             ds1, dp[8], dp[9] = ln256_backward(s1, mean1, rstd1, g1, dx1)
-            dao = gemm3(ds1, to)
+            dao = gemm3_h2(ds1, amax(ds1, ds1_am), to, to_am)
             # d(raw): the softmax / offset-normaliser backward is the epilogue of the push kernel
             gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C))
-            dq = gemm3(draw, t288)
+            dq = gemm3_h2(draw, amax(draw, draw_am), t288, t288_am)
             # dW288^T = q^T . draw (288 on the 96-wide tile side) + per-split column sums of draw: the
             # bias gradient and, summed per level, the level_embed gradient
             cpart, _, cs = gemm3_nt(q, draw, rps, want_csum_b=True, transpose_out=True)
@@ -191,7 +203,7 @@ class EncoderFn(Function):
             gv2 = gv.view(R, C)
             # grad wrt this layer's input: through value_proj + the residual; the (src + pos) path (dq)
             # joins inside the previous layer's norm2 backward (layer 0: added here)
-            g = gemm3(gv2, tv, cin=ds1, cin2=dq if i == 0 else None)
+            g = gemm3_h2(gv2, amax(gv2, gv_am), tv, tv_am, cin=ds1, cin2=dq if i == 0 else None)
             gq = dq
             # the four plain weight gradients of the layer (their operands are all alive here) as one launch
             (dp[12], dp[13]), (dp[10], dp[11]), (dp[6], dp[7]), (dp[4], dp[5]) = _wgrad_group([(ds2, h), (dh, x1), (ds1, ao), (gv2, x)])

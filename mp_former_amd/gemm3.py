@@ -56,6 +56,96 @@ def split_weights_grouped(groups):
     return outs
 
 
+AMAX_SLOT = 512       # floats per amax slot (include/mpformer_hip.h MPF_AMAX_SLOT_FLOATS): 16 sub-slots, one per cache line
+
+
+def amax_slots(n, device):
+    """n zeroed amax slots [n, AMAX_SLOT]; row i is the slot handed to a producer / consumer."""
+    return torch.zeros((n, AMAX_SLOT), dtype=torch.float32, device=device)
+
+
+def amax_value(slot):
+    """the largest magnitude recorded in a slot (0-dim tensor; tests / diagnostics)"""
+    return slot.view(-1)[::32][:16].max()
+
+
+def amax(t, out=None):
+    """max |t| of an fp32 tensor into an amax slot (``out``: an already zeroed or partly filled slot); returns the slot."""
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    if out is None:
+        out = torch.zeros(AMAX_SLOT, dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        code = _lib.lib().mpf_amax_f32(t.data_ptr(), t.numel(), out.data_ptr(), _stream(t))
+    _lib.check(code, "mpf_amax_f32")
+    return out
+
+
+def split_weights_grouped_h2(groups):
+    """``split_weights_grouped`` for the fp16 x 2 form: per group (planes [2, R, K] or [2, K, R] fp16, amax [1]) — two launches
+    for all groups (largest magnitudes, then the scaled split)."""
+    import numpy as np
+    from ._h2d import upload
+    dev = groups[0][0][0].device
+    sizes, tot = [], 0
+    for srcs, _ in groups:
+        n = sum(t.numel() for t in srcs)
+        sizes.append((tot, n))
+        tot += 2 * n
+    buf = torch.empty(tot, dtype=torch.float16, device=dev)
+    slots = amax_slots(len(groups), dev)
+    base, sbase = buf.data_ptr(), slots.data_ptr()
+    am_tab, sp_tab, ablk, sblk, outs = [], [], 0, 0, []
+    seen = {}
+    for gi, ((srcs, tr), (off, n)) in enumerate(zip(groups, sizes)):
+        K = srcs[0].shape[1]
+        R = sum(t.shape[0] for t in srcs)
+        key = tuple(t.data_ptr() for t in srcs)
+        slot = sbase + 4 * AMAX_SLOT * gi
+        if key in seen:             # the same weight in the other orientation: same amax, no second pass
+            slot_src = seen[key]
+        else:
+            seen[key] = gi
+            slot_src = gi
+            for t in srcs:
+                am_tab.append((t.data_ptr(), slot, t.numel(), ablk))
+                ablk += (t.numel() + 4095) // 4096
+        slot = sbase + 4 * AMAX_SLOT * slot_src
+        r0 = 0
+        for t in srcs:
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[1] == K
+            dst = base + 2 * (off + (r0 if tr else r0 * K))
+            sp_tab.append((t.data_ptr(), dst, slot, t.shape[0], K, 1 if tr else 0, R if tr else K, n, sblk))
+            sblk += (t.numel() + 1023) // 1024
+            r0 += t.shape[0]
+        outs.append((buf[off:off + 2 * n].view((2, K, R) if tr else (2, R, K)), slots[slot_src]))
+    both = upload(np.asarray([x for row in am_tab for x in row] + [x for row in sp_tab for x in row], dtype=np.int64), dev)
+    with torch.cuda.device(dev):
+        code = _lib.lib().mpf_amax_f32_grouped(both.data_ptr(), len(am_tab), ablk, _stream(buf))
+        _lib.check(code, "mpf_amax_f32_grouped")
+        code = _lib.lib().mpf_gemm3_split_grouped_h2(both.data_ptr() + 8 * 4 * len(am_tab), len(sp_tab), sblk, _stream(buf))
+    _lib.check(code, "mpf_gemm3_split_grouped_h2")
+    return outs
+
+
+def gemm3_h2(a, a_amax, planes, w_amax, bias=None, cin=None, cin2=None, gate=None, relu=False, out_amax=None):
+    """``gemm3`` in the fp16 x 2 form: planes / w_amax from ``split_weights_grouped_h2``, a_amax = max |a| (device, [1]);
+    out_amax (a zeroed [1] slot or None) receives max |C|.  N % 256 == 0."""
+    assert a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
+    assert planes.dtype == torch.float16 and planes.is_contiguous() and planes.shape[0] == 2
+    M, K = a.shape
+    N = planes.shape[1]
+    assert planes.shape[2] == K
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        code = _lib.lib().mpf_gemm3_tn_h2(
+            a.data_ptr(), a.stride(0), a_amax.data_ptr(), planes.data_ptr(), w_amax.data_ptr(), _p(bias),
+            _p(cin), _rows(cin, N) if cin is not None else 0, _p(cin2), _rows(cin2, N) if cin2 is not None else 0,
+            _p(gate), _rows(gate, N) if gate is not None else 0, c.data_ptr(), c.stride(0), _p(out_amax), M, N, K, 1 if relu else 0,
+            _stream(a))
+    _lib.check(code, "mpf_gemm3_tn_h2")
+    return c
+
+
 def _p(t):
     return t.data_ptr() if t is not None else None
 

@@ -197,7 +197,7 @@ def test_head_baseline_config_shapes_run(name, size, chans, classes, queries, n)
     assert torch.isfinite(loss)
     assert not [k for k, p in h.named_parameters() if p.grad is None]
     for kern in ("msda_fwd_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost_fused", "pair_planes_fwd", "pair_planes_dfeat",
-                 "pair_planes_dembed", "mask_loss_fwd", "mask_head_bits", "pool_features"):
+                 "pair_planes_dembed", "mask_loss_fwd", "mask_head_bits", "pool_features", "lsa_kernel"):
         assert _lib.profile_get(kern)[0] > 0, kern
     _lib.profile_enable(False)
 
@@ -223,9 +223,27 @@ def test_head_amp_path_matches_reference_golden(name):
     feats = {k: _planes_leaf(v, dev) for k, v in feats.items()}      # channel-last planes, as the bf16 backbone delivers them
     targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
     use_dn = "dn_pred_logits" in z
-    _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
-    _lib.profile_enable(True)
+    # The assignment is PINNED to the reference's: these toy models have near-duplicate queries whose matching costs tie to
+    # within bf16's rounding, and a flipped pair is an O(0.1) change of that output's losses that says nothing about a kernel
+    # (any last-bit change upstream can trigger it).  Pass 1: the fp32 path (golden-exact: test_head_matches_reference_golden_fp32)
+    # on the reference's own route — cost matrices to the host, SciPy — records the indices; pass 2 (autocast) gets them back
+    # from the matcher instead of solving its own noisy costs.  The device solver is pinned to SciPy by tests/test_lsa_gpu.py and
+    # asserted on the default route in test_head_baseline_config_shapes_run.
+    import os
+    matcher = h.criterion.matcher
+    solve = matcher.match_many
+    pinned = []
+    os.environ["MPF_DEVICE_LSA"] = "0"
     try:
+        _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
+        matcher.match_many = lambda *a, **k: pinned.append(solve(*a, **k)) or pinned[-1]
+        with torch.no_grad():
+            h(feats, targets)
+        assert len(pinned) == 1 and _rng.remaining() == 0
+        matcher.match_many = lambda *a, **k: pinned[0]
+        # (the matcher's own point draws are not consumed in pass 2)
+        _rng.install_replay({t: d for t, d in fifo_to_tags(replay, cfg, use_dn).items() if not t.startswith("match")})
+        _lib.profile_enable(True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             losses, _ = h(feats, targets)            # weighted, like maskformer_model.py:226-231
             total = sum(losses.values())
@@ -235,14 +253,17 @@ def test_head_amp_path_matches_reference_golden(name):
         # the mask predictions never exist as maps: matching cost from the factors, loss planes of the paired rows only, and
         # their gradients w.r.t. (mask_embed, mask_features) from the native products (csrc/mask_fused.hip)
         # (pair_planes_fwd also serves the next-layer attention mask where a level is too small for the fused mask head)
-        assert _lib.profile_get("match_cost_fused_kernel")[0] == 1 and _lib.profile_get("pair_planes_fwd_kernel")[0] >= 1
+        # (the fused matching cost ran in pass 1, before the launch log was switched on; asserted in test_head_baseline_config_shapes_run)
+        assert _lib.profile_get("pair_planes_fwd_kernel")[0] >= 1
         assert _lib.profile_get("pair_planes_dfeat_kernel")[0] == 1 and _lib.profile_get("pair_planes_dembed_kernel")[0] == 1
-        for kern in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "small_gemm", "small_gemm_group_kernel", "lsa_kernel", "msda_fwd_block",
+        for kern in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "small_gemm", "small_gemm_group_kernel", "msda_fwd_block",
                      "msda_bwd_pull_mfma", "gemm3", "gn_cl_apply", "gn_cl_bwd_apply"):
             assert _lib.profile_get(kern)[0] > 0, f"{kern} did not run on the AMP path"
     finally:
         _lib.profile_enable(False)
         _rng.install_replay(None)
+        matcher.match_many = solve
+        os.environ.pop("MPF_DEVICE_LSA", None)
     wd = h.criterion.weight_dict
     ref_keys = sorted(k[5:] for k in z if k.startswith("loss."))
     assert sorted(losses) == ref_keys
