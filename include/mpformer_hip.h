@@ -567,6 +567,25 @@ typedef struct MpfSplitItemH2 {
 int mpf_amax_f32(const float* x, int64_t n, float* amax, void* stream);
 int mpf_amax_f32_grouped(const MpfAmaxItem* items_device, int n_items, int64_t total_blocks, void* stream);
 int mpf_gemm3_split_grouped_h2(const MpfSplitItemH2* items_device, int n_items, int64_t total_blocks, void* stream);
+/* the weight-gradient forms (mpf_gemm3_nt without b2, mpf_gemm3_nt_grouped, mpf_gemm3_conv3x3_wgrad) with both operands split
+ * into fp16 pieces on the fly; column sums are taken from the unscaled values */
+typedef struct MpfNtItemH2 {
+    const float* a;
+    int64_t lda;
+    const float* a_amax;
+    const float* b;
+    int64_t ldb;
+    const float* b_amax;
+    float* c_part;
+    float* csum_a;
+    int64_t Mdim, Ndim;
+} MpfNtItemH2;
+int mpf_gemm3_nt_h2(const float* a, int64_t lda, const float* a_amax, const float* b, int64_t ldb, const float* b_amax,
+                    float* c_part, float* csum_a, float* csum_b, int R, int Mdim, int Ndim, int rows_per_split,
+                    int transpose_out, void* stream);
+int mpf_gemm3_nt_grouped_h2(const MpfNtItemH2* items, int n_items, int R, int rows_per_split, int64_t split_stride, void* stream);
+int mpf_gemm3_conv3x3_wgrad_h2(const float* dy, const float* dy_amax, const float* x, const float* x_amax, float* c_part,
+                               float* csum_dy, int n_img, int H, int W, int Cin, int Cout, int rows_per_split, void* stream);
 int mpf_gemm3_tn_h2(const float* a, int64_t lda, const float* a_amax, const void* b_planes_h2, const float* b_amax,
                     const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
                     const float* gate, int64_t ldgate, float* c, int64_t ldc, float* out_amax, int M, int N, int K,

@@ -286,6 +286,33 @@ struct Acc {
         }
     }
 
+    // two fp16 pieces per operand (planes 0, 1 of the images): l*h + h*l + h*h, smallest first
+    template <int AKC, int BKC, bool BROW = false>
+    __device__ __forceinline__ void step_h2(const unsigned char* lds, int a_base, int b_base, int lane)
+    {
+        const int r16 = lane & 15, g = lane >> 4;
+        constexpr int BJ = BROW ? 1024 : 256;
+        const int a_frag = a_base + g * AKC + (r16 ^ (2 * g)) * 16;
+        const int b_frag = BROW ? b_base + (r16 * 4 + (g ^ ((0 - (r16 >> 2)) & 3))) * 16 : b_base + g * BKC + (r16 ^ (2 * g)) * 16;
+        f16x8 fa[2][4];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[pl][i] = as_fragh(*reinterpret_cast<const uint4*>(lds + a_frag + pl * 4 * AKC + i * 256));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f16x8 fb[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fb[pl] = as_fragh(*reinterpret_cast<const uint4*>(lds + b_frag + pl * 4 * BKC + j * BJ));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[1], fa[0][i], v[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[0], fa[1][i], v[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[0], fa[0][i], v[i][j], 0, 0, 0);
+        }
+    }
+
     // f(row offset in the wave tile, column offset in the wave tile, the 4 values of that row at columns +0..3)
     template <typename F>
     __device__ __forceinline__ void quads(int lane, F f) const
@@ -349,6 +376,30 @@ struct Acc<4, true> {
     }
             G3_MMA32(0, 2) G3_MMA32(2, 0) G3_MMA32(1, 1) G3_MMA32(0, 1) G3_MMA32(1, 0) G3_MMA32(0, 0)
 #undef G3_MMA32
+        }
+    }
+
+    template <int AKC, int BKC>
+    __device__ __forceinline__ void step_h2(const unsigned char* lds, int a_base, int b_base, int lane)
+    {
+        const int r32 = lane & 31, gh = lane >> 5;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const int kc = 2 * kh + gh;
+            const int sw = (r32 ^ (2 * kc)) * 16;
+            f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[pl][t] = as_fragh(*reinterpret_cast<const uint4*>(lds + a_base + (pl * 4 + kc) * AKC + t * 512 + sw));
+                    fb[pl][t] = as_fragh(*reinterpret_cast<const uint4*>(lds + b_base + (pl * 4 + kc) * BKC + t * 512 + sw));
+                }
+#define G3_MMA32H(PB, PA)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int i = 0; i < 2; ++i)                   \
+        v[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[PB][j], fa[PA][i], v[i][j], 0, 0, 0);
+            G3_MMA32H(1, 0) G3_MMA32H(0, 1) G3_MMA32H(0, 0)
+#undef G3_MMA32H
         }
     }
 
@@ -1037,6 +1088,8 @@ struct G3N {
     unsigned a_bytes, b_bytes;      // sizes of the operands (for the buffer descriptors; both < 4 GiB)
     int cv_H, cv_W, cv_cin;         // CV: weight gradient of a 3x3 convolution (B = the input image, columns = (tap, channel))
     int64_t c_ss, csa_ss, csb_ss;   // elements between the partial results of consecutive splits (c, csum_a, csum_b)
+    const float* a_amax;            // H2 kernels: amax slots of the two operands
+    const float* b_amax;
 };
 // a group of weight-gradient problems over the SAME rows in one launch (mpf_gemm3_nt_grouped): item i owns the tiles
 // [tile_end[i-1], tile_end[i])
@@ -1055,15 +1108,23 @@ struct G3NG {
 // W % 8 == 0 the 8 rows of a k-chunk lie in one image row, so a row's validity is wave-uniform as well.
 // A16 / B16 (BN = 128, fp32 result): that operand is a bf16 matrix (2-byte elements, its lda / ldb in elements): loaded with
 // 2-byte reads into plane 0 only, and the products with its planes 1, 2 are skipped (three instead of six).
-template <int BN, bool BF, bool CV, bool A16, bool B16>
+template <int BN, bool BF, bool CV, bool A16, bool B16, bool H2 = false>
 __device__ __forceinline__ void gemm3_nt_tile(const G3N& p, const int tile)
 {
     static_assert(!((A16 || B16) && (BF || CV || BN != 128)), "mixed-precision operands: plain 128-column tiles only");
+    static_assert(!(H2 && (BF || A16 || B16)), "fp16 x 2 form: fp32 operands only");
     constexpr int NJ = BN / 32;
     constexpr int kBKc = BN * 16;
-    constexpr int kAbytes = 12 * kAKc;
+    constexpr int kPl = H2 ? 2 : 3;
+    constexpr int kAbytes = kPl * 4 * kAKc;
     constexpr int kBunits = 4 * BN;                          // (k-chunk, column) units of the B tile
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kAbytes + 12 * kBKc];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kAbytes + kPl * 4 * kBKc];
+    float sc_a = 1.f, sc_b = 1.f, inv_a = 1.f, inv_b = 1.f;
+    if constexpr (H2) {
+        h2_scale(amax_read(p.a_amax), &sc_a, &inv_a);
+        h2_scale(amax_read(p.b_amax), &sc_b, &inv_b);
+    }
+    (void)sc_a; (void)sc_b;
 
     // order: column tiles fastest, then row tiles, then splits (neighbouring blocks share the rows)
     const int tn = tile % p.tiles_n, tm = (tile / p.tiles_n) % p.tiles_m, sp = tile / (p.tiles_n * p.tiles_m);
@@ -1194,7 +1255,31 @@ __device__ __forceinline__ void gemm3_nt_tile(const G3N& p, const int tile)
     if (r_begin + kBK <= r_end) G3N_LOAD(r_begin, false) else G3N_LOAD(r_begin, true);
     for (int r0 = r_begin; r0 < r_end; r0 += kBK) {
         __syncthreads();
-        {
+        if constexpr (H2) {
+            uint4 h, l;
+            split8h(make_float4(xa0[0], xa0[1], xa0[2], xa0[3]), make_float4(xa0[4], xa0[5], xa0[6], xa0[7]), sc_a, &h, &l);
+            *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = h;
+            *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = l;
+            split8h(make_float4(xa1[0], xa1[1], xa1[2], xa1[3]), make_float4(xa1[4], xa1[5], xa1[6], xa1[7]), sc_a, &h, &l);
+            *reinterpret_cast<uint4*>(lds + (0 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = h;
+            *reinterpret_cast<uint4*>(lds + (1 * 4 + akc + 2) * kAKc + (am ^ (2 * akc + 4)) * 16) = l;
+            split8h(make_float4(xb0[0], xb0[1], xb0[2], xb0[3]), make_float4(xb0[4], xb0[5], xb0[6], xb0[7]), sc_b, &h, &l);
+            *reinterpret_cast<uint4*>(lds + kAbytes + (0 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = h;
+            *reinterpret_cast<uint4*>(lds + kAbytes + (1 * 4 + bkc_[0]) * kBKc + (bn_[0] ^ (2 * bkc_[0])) * 16) = l;
+            if (b_ok[1]) {
+                split8h(make_float4(xb1[0], xb1[1], xb1[2], xb1[3]), make_float4(xb1[4], xb1[5], xb1[6], xb1[7]), sc_b, &h, &l);
+                *reinterpret_cast<uint4*>(lds + kAbytes + (0 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = h;
+                *reinterpret_cast<uint4*>(lds + kAbytes + (1 * 4 + bkc_[1]) * kBKc + (bn_[1] ^ (2 * bkc_[1])) * 16) = l;
+            }
+            if (want_csa) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) csa += xa0[j] + xa1[j];
+            }
+            if (want_csb) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { csb0 += xb0[j]; csb1 += xb1[j]; }
+            }
+        } else {
             uint4 h, m, l;
             split8(make_float4(xa0[0], xa0[1], xa0[2], xa0[3]), make_float4(xa0[4], xa0[5], xa0[6], xa0[7]), &h, &m, &l);
             *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + (am ^ (2 * akc)) * 16) = h;
@@ -1226,7 +1311,8 @@ __device__ __forceinline__ void gemm3_nt_tile(const G3N& p, const int tile)
         __syncthreads();
         if (r0 + 2 * kBK <= r_end) G3N_LOAD(r0 + kBK, false) else if (r0 + kBK < r_end) G3N_LOAD(r0 + kBK, true);
         __builtin_amdgcn_s_setprio(G3_PRIO);        // the MFMA phase outranks the other workgroups' staging VALU on this SIMD
-        if constexpr (A16 || B16) acc.template step<kAKc, kBKc, false, A16, B16>(lds, a_frag, b_frag, lane);
+        if constexpr (H2) acc.template step_h2<kAKc, kBKc>(lds, a_frag, b_frag, lane);
+        else if constexpr (A16 || B16) acc.template step<kAKc, kBKc, false, A16, B16>(lds, a_frag, b_frag, lane);
         else acc.template step<kAKc, kBKc, BF>(lds, a_frag, b_frag, lane);
         __builtin_amdgcn_s_setprio(0);
     }
@@ -1236,6 +1322,7 @@ __device__ __forceinline__ void gemm3_nt_tile(const G3N& p, const int tile)
     acc.quads(lane, [&](int mo, int no, float4 o) {
         const int m = m0 + wr * 64 + mo, n = n0 + wc * (BN / 2) + no;
         if (m >= p.Mdim) return;
+        if constexpr (H2) o = make_float4(o.x * inv_a * inv_b, o.y * inv_a * inv_b, o.z * inv_a * inv_b, o.w * inv_a * inv_b);
         const float e4[4] = {o.x, o.y, o.z, o.w};
         if (!p.transpose_out) {
             if (n + 3 < p.Ndim) {
@@ -1269,18 +1356,19 @@ __device__ __forceinline__ void gemm3_nt_tile(const G3N& p, const int tile)
     (void)a_col_ok; (void)b_col_ok;
 }
 
-template <int BN, bool BF = false, bool CV = false, bool A16 = false, bool B16 = false>
+template <int BN, bool BF = false, bool CV = false, bool A16 = false, bool B16 = false, bool H2 = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_kernel(G3N p)
 {
     const int per_xcd = (p.ntiles + 7) >> 3;
     const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
-    gemm3_nt_tile<BN, BF, CV, A16, B16>(p, tile);
+    gemm3_nt_tile<BN, BF, CV, A16, B16, H2>(p, tile);
 }
 
 // several problems over the same rows: with the tiles of all of them in one launch a workgroup's split is n_items times
 // longer at the same number of workgroups (one round of the chip), so the pipeline fill / drain and the partial results
 // are paid once per (tile, long split) instead of once per (tile, short split)
+template <bool H2>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_group_kernel(G3NG g)
 {
     const int per_xcd = (g.ntiles + 7) >> 3;
@@ -1289,7 +1377,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_group_kernel(G3NG g)
     int i = 0;
     while (i + 1 < g.n_items && tile >= g.tile_end[i]) ++i;
     const int first = i ? g.tile_end[i - 1] : 0;
-    gemm3_nt_tile<128, false, false, false, false>(g.it[i], tile - first);
+    gemm3_nt_tile<128, false, false, false, false, H2>(g.it[i], tile - first);
 }
 
 // W[R,C] fp32 -> planes[3][R][C] (transpose = 0) or planes[3][C][R] (transpose = 1), bf16 bits
@@ -1724,9 +1812,30 @@ extern "C" int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const flo
     return mpf::check(hipGetLastError(), "mpf_gemm3_conv3x3");
 }
 
+static int g3_nt_impl(const float* a, int64_t lda, const float* b, int64_t ldb, const float* b2, int64_t ldb2, int b2_rows,
+                      float* c_part, float* csum_a, float* csum_b, int R, int Mdim, int Ndim, int rows_per_split,
+                      int transpose_out, void* stream, const float* a_amax, const float* b_amax);
+
 extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t ldb, const float* b2, int64_t ldb2, int b2_rows,
                             float* c_part, float* csum_a, float* csum_b, int R, int Mdim, int Ndim, int rows_per_split,
                             int transpose_out, void* stream)
+{
+    return g3_nt_impl(a, lda, b, ldb, b2, ldb2, b2_rows, c_part, csum_a, csum_b, R, Mdim, Ndim, rows_per_split, transpose_out, stream,
+                      nullptr, nullptr);
+}
+
+extern "C" int mpf_gemm3_nt_h2(const float* a, int64_t lda, const float* a_amax, const float* b, int64_t ldb, const float* b_amax,
+                               float* c_part, float* csum_a, float* csum_b, int R, int Mdim, int Ndim, int rows_per_split,
+                               int transpose_out, void* stream)
+{
+    if (!a_amax || !b_amax) return mpf::fail(MPF_E_NULL, "gemm3_nt_h2: NULL amax");
+    return g3_nt_impl(a, lda, b, ldb, nullptr, 0, 0, c_part, csum_a, csum_b, R, Mdim, Ndim, rows_per_split, transpose_out, stream,
+                      a_amax, b_amax);
+}
+
+static int g3_nt_impl(const float* a, int64_t lda, const float* b, int64_t ldb, const float* b2, int64_t ldb2, int b2_rows,
+                      float* c_part, float* csum_a, float* csum_b, int R, int Mdim, int Ndim, int rows_per_split,
+                      int transpose_out, void* stream, const float* a_amax, const float* b_amax)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!a || !b || !c_part) return mpf::fail(MPF_E_NULL, "gemm3_nt: NULL buffer");
@@ -1735,6 +1844,7 @@ extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t
     if (b2 && b2_rows <= 0) return mpf::fail(MPF_E_SHAPE, "gemm3_nt: b2_rows must be positive");
     if (!transpose_out && Ndim % 4 != 0) return mpf::fail(MPF_E_SHAPE, "gemm3_nt: Ndim must be a multiple of 4 unless transpose_out");
     G3N p;
+    p.a_amax = nullptr; p.b_amax = nullptr;
     p.a = a; p.b = b; p.b2 = b2; p.c = c_part; p.csum_a = csum_a; p.csum_b = csum_b;
     p.lda = lda; p.ldb = ldb; p.ldb2 = ldb2;
     p.R = R; p.Mdim = Mdim; p.Ndim = Ndim; p.b2_rows = b2_rows; p.rows_per_split = rows_per_split;
@@ -1753,8 +1863,17 @@ extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t
     p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
     p.c_ss = (int64_t)p.Mdim * p.Ndim; p.csa_ss = p.Mdim; p.csb_ss = p.Ndim;
     const int grid = ((p.ntiles + 7) / 8) * 8;
+    p.a_amax = a_amax; p.b_amax = b_amax;
     mpf::prof_begin(st);
-    if (use96) {
+    if (a_amax) {
+        if (use96) {
+            mpf::set_kernel("gemm3_nt_kernel<96>h2");
+            hipLaunchKernelGGL((gemm3_nt_kernel<96, false, false, false, false, true>), dim3(grid), dim3(kThreads), 0, st, p);
+        } else {
+            mpf::set_kernel("gemm3_nt_kernel<128>h2");
+            hipLaunchKernelGGL((gemm3_nt_kernel<128, false, false, false, false, true>), dim3(grid), dim3(kThreads), 0, st, p);
+        }
+    } else if (use96) {
         mpf::set_kernel("gemm3_nt_kernel<96>");
         hipLaunchKernelGGL(gemm3_nt_kernel<96>, dim3(grid), dim3(kThreads), 0, st, p);
     } else {
@@ -1766,8 +1885,23 @@ extern "C" int mpf_gemm3_nt(const float* a, int64_t lda, const float* b, int64_t
     return mpf::check(hipGetLastError(), "mpf_gemm3_nt");
 }
 
+template <typename Item, bool H2>
+static int g3_nt_grouped_impl(const Item* items, int n_items, int R, int rows_per_split, int64_t split_stride, void* stream);
+
 extern "C" int mpf_gemm3_nt_grouped(const MpfNtItem* items, int n_items, int R, int rows_per_split, int64_t split_stride,
                                     void* stream)
+{
+    return g3_nt_grouped_impl<MpfNtItem, false>(items, n_items, R, rows_per_split, split_stride, stream);
+}
+
+extern "C" int mpf_gemm3_nt_grouped_h2(const MpfNtItemH2* items, int n_items, int R, int rows_per_split, int64_t split_stride,
+                                       void* stream)
+{
+    return g3_nt_grouped_impl<MpfNtItemH2, true>(items, n_items, R, rows_per_split, split_stride, stream);
+}
+
+template <typename Item, bool H2>
+static int g3_nt_grouped_impl(const Item* items, int n_items, int R, int rows_per_split, int64_t split_stride, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!items) return mpf::fail(MPF_E_NULL, "gemm3_nt_grouped: NULL items");
@@ -1780,7 +1914,7 @@ extern "C" int mpf_gemm3_nt_grouped(const MpfNtItem* items, int n_items, int R, 
     int tiles = 0;
     double bytes = 0.0, flops = 0.0;
     for (int i = 0; i < n_items; ++i) {
-        const MpfNtItem& it = items[i];
+        const Item& it = items[i];
         if (!it.a || !it.b || !it.c_part) return mpf::fail(MPF_E_NULL, "gemm3_nt_grouped: NULL buffer");
         if (it.Mdim <= 0 || it.Ndim <= 0 || it.Ndim % 4 != 0 || it.Mdim > (1 << 20) || it.Ndim > (1 << 20))
             return mpf::fail(MPF_E_SHAPE, "gemm3_nt_grouped: Ndim must be a positive multiple of 4");
@@ -1798,6 +1932,11 @@ extern "C" int mpf_gemm3_nt_grouped(const MpfNtItem* items, int n_items, int R, 
         p.tiles_n = (p.Ndim + 127) / 128;
         p.ntiles = p.tiles_m * p.tiles_n * nsplit;
         p.c_ss = p.csa_ss = split_stride; p.csb_ss = 0;
+        p.a_amax = nullptr; p.b_amax = nullptr;
+        if constexpr (H2) {
+            if (!it.a_amax || !it.b_amax) return mpf::fail(MPF_E_NULL, "gemm3_nt_grouped_h2: NULL amax");
+            p.a_amax = it.a_amax; p.b_amax = it.b_amax;
+        }
         tiles += p.ntiles;
         g.tile_end[i] = tiles;
         bytes += 4.0 * ((double)R * p.Mdim + (double)R * p.Ndim + (double)nsplit * p.Mdim * p.Ndim);
@@ -1805,8 +1944,8 @@ extern "C" int mpf_gemm3_nt_grouped(const MpfNtItem* items, int n_items, int R, 
     }
     g.n_items = n_items; g.ntiles = tiles;
     mpf::prof_begin(st);
-    mpf::set_kernel("gemm3_nt_group_kernel");
-    hipLaunchKernelGGL(gemm3_nt_group_kernel, dim3(((tiles + 7) / 8) * 8), dim3(kThreads), 0, st, g);
+    mpf::set_kernel(H2 ? "gemm3_nt_group_kernel<h2>" : "gemm3_nt_group_kernel");
+    hipLaunchKernelGGL(gemm3_nt_group_kernel<H2>, dim3(((tiles + 7) / 8) * 8), dim3(kThreads), 0, st, g);
     mpf::prof_end(mpf_last_kernel(), st, bytes, flops);
     return mpf::check(hipGetLastError(), "mpf_gemm3_nt_grouped");
 }
@@ -1869,6 +2008,7 @@ extern "C" int mpf_gemm3_nt_ex(const void* a, int a_dtype, int64_t lda, const vo
     if (R <= 0 || Mdim <= 0 || Ndim <= 0 || Ndim % 128 != 0 || rows_per_split <= 0 || rows_per_split % kBK != 0)
         return mpf::fail(MPF_E_SHAPE, "gemm3_nt_ex: Ndim must be a multiple of 128, rows_per_split a positive multiple of 32");
     G3N p;
+    p.a_amax = nullptr; p.b_amax = nullptr;
     p.a = (const float*)a; p.b = (const float*)b; p.b2 = nullptr; p.c = c_part; p.csum_a = csum_a; p.csum_b = nullptr;
     p.lda = lda; p.ldb = ldb; p.ldb2 = 0;
     p.R = R; p.Mdim = Mdim; p.Ndim = Ndim; p.b2_rows = 0; p.rows_per_split = rows_per_split;
@@ -1894,8 +2034,24 @@ extern "C" int mpf_gemm3_nt_ex(const void* a, int a_dtype, int64_t lda, const vo
     return mpf::check(hipGetLastError(), "mpf_gemm3_nt_ex");
 }
 
+static int g3_conv_wgrad_impl(const float* dy, const float* x, float* c_part, float* csum_dy, int n_img, int H, int W, int Cin,
+                              int Cout, int rows_per_split, void* stream, const float* dy_amax, const float* x_amax);
+
 extern "C" int mpf_gemm3_conv3x3_wgrad(const float* dy, const float* x, float* c_part, float* csum_dy, int n_img, int H, int W, int Cin,
                                        int Cout, int rows_per_split, void* stream)
+{
+    return g3_conv_wgrad_impl(dy, x, c_part, csum_dy, n_img, H, W, Cin, Cout, rows_per_split, stream, nullptr, nullptr);
+}
+
+extern "C" int mpf_gemm3_conv3x3_wgrad_h2(const float* dy, const float* dy_amax, const float* x, const float* x_amax, float* c_part,
+                                          float* csum_dy, int n_img, int H, int W, int Cin, int Cout, int rows_per_split, void* stream)
+{
+    if (!dy_amax || !x_amax) return mpf::fail(MPF_E_NULL, "gemm3_conv3x3_wgrad_h2: NULL amax");
+    return g3_conv_wgrad_impl(dy, x, c_part, csum_dy, n_img, H, W, Cin, Cout, rows_per_split, stream, dy_amax, x_amax);
+}
+
+static int g3_conv_wgrad_impl(const float* dy, const float* x, float* c_part, float* csum_dy, int n_img, int H, int W, int Cin,
+                              int Cout, int rows_per_split, void* stream, const float* dy_amax, const float* x_amax)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!dy || !x || !c_part) return mpf::fail(MPF_E_NULL, "gemm3_conv3x3_wgrad: NULL buffer");
@@ -1905,6 +2061,7 @@ extern "C" int mpf_gemm3_conv3x3_wgrad(const float* dy, const float* x, float* c
     const int64_t R64 = (int64_t)n_img * H * W;
     if (R64 * (Cin > Cout ? Cin : Cout) * 4 >= (1ll << 32)) return mpf::fail(MPF_E_TOO_LARGE, "gemm3_conv3x3_wgrad: an operand spans 4 GiB or more");
     G3N p;
+    p.a_amax = nullptr; p.b_amax = nullptr;
     p.a = dy; p.b = x; p.b2 = nullptr; p.c = c_part; p.csum_a = csum_dy; p.csum_b = nullptr;
     p.lda = Cout; p.ldb = Cin; p.ldb2 = 0;
     p.R = (int)R64; p.Mdim = Cout; p.Ndim = 9 * Cin; p.b2_rows = 0; p.rows_per_split = rows_per_split;
@@ -1917,8 +2074,10 @@ extern "C" int mpf_gemm3_conv3x3_wgrad(const float* dy, const float* x, float* c
     p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
     p.c_ss = (int64_t)p.Mdim * p.Ndim; p.csa_ss = p.Mdim; p.csb_ss = p.Ndim;
     mpf::prof_begin(st);
+    p.a_amax = dy_amax; p.b_amax = x_amax;
     mpf::set_kernel("gemm3_nt_kernel<conv3x3>");
-    hipLaunchKernelGGL((gemm3_nt_kernel<128, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
+    if (dy_amax) hipLaunchKernelGGL((gemm3_nt_kernel<128, false, true, false, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
+    else hipLaunchKernelGGL((gemm3_nt_kernel<128, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
     mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)p.R * Cout + (double)p.R * Cin + (double)p.nsplit * Cout * 9 * Cin),
                   2.0 * p.R * (double)Cout * 9 * Cin);
     return mpf::check(hipGetLastError(), "mpf_gemm3_conv3x3_wgrad");
@@ -1941,6 +2100,7 @@ extern "C" int mpf_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64
     if (workspace_bytes < mpf_gemm_nt_bf16_workspace_bytes(R, Mdim, Ndim, rows_per_split))
         return mpf::fail(MPF_E_SHAPE, "gemm_nt_bf16: workspace too small");
     G3N p;
+    p.a_amax = nullptr; p.b_amax = nullptr;
     p.a = static_cast<const float*>(a); p.b = static_cast<const float*>(b); p.b2 = nullptr;
     p.nsplit = (R + rows_per_split - 1) / rows_per_split;
     p.c = static_cast<float*>(workspace);

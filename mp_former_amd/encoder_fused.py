@@ -72,7 +72,7 @@ def _balanced_rps(R, M, N, device, base=1 << 30):
     return rps
 
 
-def _wgrad_group(pairs):
+def _wgrad_group(pairs, amax_pairs=None):
     """[(dW_i, db_i)] of several Linear layers over the same rows: ONE split-K launch whose splits are as long as the tiles
     of all problems together allow at one round of workgroups (R = 43 008: 40 tiles x 12 splits of 3 584 rows instead of
     4 x (4 | 16 tiles x 123 | 31 splits of 352 | 1 376 rows)) and ONE reduction."""
@@ -84,7 +84,7 @@ def _wgrad_group(pairs):
     tiles = sum(((g.shape[1] + 127) // 128) * ((x.shape[1] + 127) // 128) for g, x in pairs)
     ns = max(1, slots // tiles)
     rps = max(128, ((-(-R // ns)) + 31) // 32 * 32)
-    return gemm3_nt_grouped(pairs, rps)
+    return gemm3_nt_grouped(pairs, rps, amax_pairs)
 
 
 class EncoderFn(Function):
@@ -115,18 +115,19 @@ class EncoderFn(Function):
         planes3 = split_weights_grouped(g3)
         # the 288-wide bias of every layer in one concatenation
         b288_all = torch.cat([params[i * PARAMS_PER_LAYER + k] for i in range(nl) for k in (1, 3)]).view(nl, -1)
-        am = amax_slots(4 * nl + 1, src.device)          # per layer: ao, x1, h, the next layer's x
-        x_am = amax(x, am[4 * nl])
+        am = amax_slots(5 * nl + 1, src.device)          # per layer: ao, x1, h, the next layer's x, q
+        x_am = amax(x, am[5 * nl])
         for i in range(nl):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2_, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             (pv, pv_am), (po, po_am), (p1, p1_am), (p2, p2_am) = planes2[9 * i:9 * i + 4]
             p288 = planes3[i]
             b288 = b288_all[i]
-            ao_am, x1_am, h_am, xn_am = am[4 * i], am[4 * i + 1], am[4 * i + 2], am[4 * i + 3]
+            ao_am, x1_am, h_am, xn_am, q_am = am[5 * i:5 * i + 5]
             value = gemm3_h2(x, x_am, pv, pv_am, bv)
             if q is None:       # layer 0; later layers get src + pos from the previous layer's norm2 pass
                 q = (x.view(N, S, C) + pos_full).view(R, C)
             raw = gemm3(q, p288, b288)
+            amax(q, q_am)                      # (for the weight gradient q^T . d raw of the backward)
             # softmax over the 12 logits, loc = ref + offset / (W_l, H_l) happen inside the MSDA kernel
             ao, loc, attn = ms_deform_attn_forward_raw(value.view(N, S, M, C // M), shapes, lsi, raw, ref, host_shapes)
             ao = ao.view(R, C)
@@ -135,7 +136,7 @@ class EncoderFn(Function):
             h = gemm3_h2(x1, amax(x1, x1_am), p1, p1_am, bb1, relu=True, out_amax=h_am)
             s2 = gemm3_h2(h, h_am, p2, p2_am, bb2, cin=x1)
             x2, mean2, rstd2, qn = ln256_forward(s2, g2_, b2, _EPS, padd=pos_full if i + 1 < nl else None)
-            saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am]
+            saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am]
             x, q = x2, qn
             if i + 1 < nl:
                 x_am = amax(x, xn_am)
@@ -172,7 +173,7 @@ class EncoderFn(Function):
         gq = None
         for i in reversed(range(nl)):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am) = saved[i * 18:(i + 1) * 18]
+            (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am) = saved[i * 19:(i + 1) * 19]
             dp = [None] * PARAMS_PER_LAYER
             (tv, tv_am), (to, to_am), (t1, t1_am), (t2, t2_am), (t288, t288_am) = ctx.planes_t[i]
             ds2_am, dh_am, ds1_am, draw_am, gv_am = am[5 * i:5 * i + 5]
@@ -188,7 +189,7 @@ class EncoderFn(Function):
             dq = gemm3_h2(draw, amax(draw, draw_am), t288, t288_am)
             # dW288^T = q^T . draw (288 on the 96-wide tile side) + per-split column sums of draw: the
             # bias gradient and, summed per level, the level_embed gradient
-            cpart, _, cs = gemm3_nt(q, draw, rps, want_csum_b=True, transpose_out=True)
+            cpart, _, cs = gemm3_nt(q, draw, rps, want_csum_b=True, transpose_out=True, amax_ab=(q_am, draw_am))
             if aligned and L <= 4 and cpart[0].numel() % 4 == 0:
                 dw288, lvl, db288 = nt_reduce_levels(cpart, cs, split_level, L)     # one launch, fixed order
             else:
@@ -206,7 +207,8 @@ class EncoderFn(Function):
             g = gemm3_h2(gv2, amax(gv2, gv_am), tv, tv_am, cin=ds1, cin2=dq if i == 0 else None)
             gq = dq
             # the four plain weight gradients of the layer (their operands are all alive here) as one launch
-            (dp[12], dp[13]), (dp[10], dp[11]), (dp[6], dp[7]), (dp[4], dp[5]) = _wgrad_group([(ds2, h), (dh, x1), (ds1, ao), (gv2, x)])
+            (dp[12], dp[13]), (dp[10], dp[11]), (dp[6], dp[7]), (dp[4], dp[5]) = _wgrad_group(
+                [(ds2, h), (dh, x1), (ds1, ao), (gv2, x)], [(ds2_am, h_am), (dh_am, x1_am), (ds1_am, ao_am), (gv_am, x_am)])
             dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp
         # d level_embed = sum_i lvl_i . [W_offsets_i ; W_weights_i]: one stacked product for all layers
         w288_all = torch.cat([params[i * PARAMS_PER_LAYER + k] for i in range(nl) for k in (0, 2)]).view(nl, -1, C)

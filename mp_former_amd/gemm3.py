@@ -191,9 +191,9 @@ def pick_rows_per_split(R, out_tiles, align=None):
     return rps
 
 
-def gemm3_nt(a, b, rows_per_split, b2=None, want_csum_a=False, want_csum_b=False, transpose_out=False):
+def gemm3_nt(a, b, rows_per_split, b2=None, want_csum_a=False, want_csum_b=False, transpose_out=False, amax_ab=None):
     """a [R, M], b [R, N] fp32 (row strides free) -> (c_part [nsplit, M, N] (or [nsplit, N, M]),
-    csum_a [nsplit, M] or None, csum_b [nsplit, N] or None)."""
+    csum_a [nsplit, M] or None, csum_b [nsplit, N] or None).  amax_ab = (amax slot of a, of b): the fp16 x 2 form (no b2)."""
     assert a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] == b.shape[0]
     R, M = a.shape
@@ -205,19 +205,25 @@ def gemm3_nt(a, b, rows_per_split, b2=None, want_csum_a=False, want_csum_b=False
     if b2 is not None:
         assert b2.dtype == torch.float32 and b2.dim() == 2 and b2.stride(1) == 1 and b2.shape[1] == N
     with torch.cuda.device(a.device):
-        code = _lib.lib().mpf_gemm3_nt(
-            a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(b2), b2.stride(0) if b2 is not None else 0,
-            b2.shape[0] if b2 is not None else 0, c.data_ptr(), _p(ca), _p(cb), R, M, N, rows_per_split,
-            1 if transpose_out else 0, _stream(a))
+        if amax_ab is not None:
+            assert b2 is None
+            code = _lib.lib().mpf_gemm3_nt_h2(
+                a.data_ptr(), a.stride(0), amax_ab[0].data_ptr(), b.data_ptr(), b.stride(0), amax_ab[1].data_ptr(), c.data_ptr(),
+                _p(ca), _p(cb), R, M, N, rows_per_split, 1 if transpose_out else 0, _stream(a))
+        else:
+            code = _lib.lib().mpf_gemm3_nt(
+                a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), _p(b2), b2.stride(0) if b2 is not None else 0,
+                b2.shape[0] if b2 is not None else 0, c.data_ptr(), _p(ca), _p(cb), R, M, N, rows_per_split,
+                1 if transpose_out else 0, _stream(a))
     _lib.check(code, "mpf_gemm3_nt")
     return c, ca, cb
 
 
-def gemm3_nt_grouped(pairs, rows_per_split):
+def gemm3_nt_grouped(pairs, rows_per_split, amax_pairs=None):
     """The weight gradients of several Linear layers over the same rows in ONE split-K launch + ONE reduction.
     pairs: [(g_i [R, M_i], x_i [R, N_i])] (fp32, row strides free, at most 8); returns [(dW_i [M_i, N_i], db_i [M_i])] with
     dW_i = g_i^T . x_i and db_i = colsum(g_i) — views of one buffer.  Same partial sums as ``gemm3_nt`` with the same
-    ``rows_per_split`` (bit-identical)."""
+    ``rows_per_split`` (bit-identical).  amax_pairs: [(amax slot of g_i, of x_i)] selects the fp16 x 2 form."""
     import numpy as np
     R = pairs[0][0].shape[0]
     dev = pairs[0][0].device
@@ -231,12 +237,17 @@ def gemm3_nt_grouped(pairs, rows_per_split):
     tot = (tot + 3) // 4 * 4          # (the alignment tail, if any, is summed too and never read)
     part = torch.empty((ns, tot), dtype=torch.float32, device=dev)
     base = part.data_ptr()
-    items = np.empty((len(pairs), 8), dtype=np.int64)
+    items = np.empty((len(pairs), 8 if amax_pairs is None else 10), dtype=np.int64)
     for i, ((g, x), o) in enumerate(zip(pairs, offs)):
         M, N = g.shape[1], x.shape[1]
-        items[i] = (g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), base + 4 * o, base + 4 * (o + M * N), M, N)
+        if amax_pairs is None:
+            items[i] = (g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), base + 4 * o, base + 4 * (o + M * N), M, N)
+        else:
+            items[i] = (g.data_ptr(), g.stride(0), amax_pairs[i][0].data_ptr(), x.data_ptr(), x.stride(0), amax_pairs[i][1].data_ptr(),
+                        base + 4 * o, base + 4 * (o + M * N), M, N)
     with torch.cuda.device(dev):
-        code = _lib.lib().mpf_gemm3_nt_grouped(items.ctypes.data, len(pairs), R, rows_per_split, tot, _stream(part))
+        fn = _lib.lib().mpf_gemm3_nt_grouped if amax_pairs is None else _lib.lib().mpf_gemm3_nt_grouped_h2
+        code = fn(items.ctypes.data, len(pairs), R, rows_per_split, tot, _stream(part))
     _lib.check(code, "mpf_gemm3_nt_grouped")
     out, _ = nt_reduce(part)
     res = []

@@ -217,3 +217,107 @@ def test_gemm3_nt_one_bf16_operand(R, M, N, rps, which):
     ref = g.double().t() @ x.double()
     assert float((dw.double() - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1.0)
     torch.testing.assert_close(db.double(), g.double().sum(0), rtol=1e-5, atol=1e-4)
+
+
+# ---- the fp16 x 2 form (two pieces per operand, three products, amax-scaled) --------------------------------------------------
+def _heavy(M, K, dev, small_rows=1.0):
+    """activations with a 10x spread of row scales, 30x outliers, and (optionally) half of the rows `small_rows` times smaller"""
+    a = torch.randn(M, K, device=dev) * (1 + 9 * torch.rand(M, 1, device=dev))
+    a[::7, ::13] *= 30
+    if small_rows != 1.0:
+        a[M // 2:] *= small_rows
+    return a
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 256), (2000, 1024, 256), (3000, 256, 1024), (700, 256, 288)])
+def test_gemm3_tn_h2_accuracy_not_worse_than_library_fp32(M, N, K):
+    """Error against fp64, relative to sum |a||b| per output element: the fp16 x 2 form is held to the library fp32 GEMM's
+    (max and mean), with bias / addends / ReLU gate in the epilogue and the recorded output amax exact."""
+    from mp_former_amd import _lib
+    from mp_former_amd.gemm3 import amax, amax_slots, amax_value, gemm3_h2, split_weights_grouped_h2
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + N + K)
+    a = _heavy(M, K, dev)
+    w = torch.randn(N, K, device=dev) / K ** 0.5
+    b, cin, gate = torch.randn(N, device=dev), torch.randn(M, N, device=dev), torch.randn(M, N, device=dev)
+    (pl, wam), = split_weights_grouped_h2([([w], False)])
+    assert float(amax_value(wam)) == float(w.abs().max())
+    am = amax(a)
+    assert float(amax_value(am)) == float(a.abs().max())
+    oam = amax_slots(1, dev)[0]
+    got = gemm3_h2(a, am, pl, wam, b, cin=cin, gate=gate, out_amax=oam)
+    assert "h2" in _lib.last_kernel()
+    assert float(amax_value(oam)) == float(got.abs().max())
+    ref = torch.where(gate > 0, a.double() @ w.double().t() + b.double() + cin.double(), torch.zeros((), dtype=torch.float64, device=dev))
+    lib = torch.where(gate > 0, torch.addmm(b, a, w.t()) + cin, torch.zeros((), device=dev))
+    den = a.double().abs() @ w.double().abs().t() + b.double().abs() + cin.double().abs()
+    e2, el = (got.double() - ref).abs() / den, (lib.double() - ref).abs() / den
+    assert float(e2.max()) <= 1.25 * float(el.max()) + 1e-9, (float(e2.max()), float(el.max()))
+    assert float(e2.mean()) <= 1.1 * float(el.mean()) + 1e-12, (float(e2.mean()), float(el.mean()))
+
+
+def test_gemm3_tn_h2_dynamic_range_and_special_values():
+    """Rows 2^-13 below the operand's largest magnitude keep the library's accuracy (the second piece stays a normal fp16
+    number down to 2^-18); rows 2^-20 below are still far better than one fp16 / bf16 piece; an all-zero operand gives
+    exactly the bias; a NaN in the operand reaches the output (and its amax slot)."""
+    from mp_former_amd.gemm3 import amax, amax_slots, amax_value, gemm3_h2, split_weights_grouped_h2
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    M, N, K = 2048, 256, 256
+    w = torch.randn(N, K, device=dev) / 16
+    b = torch.randn(N, device=dev)
+    (pl, wam), = split_weights_grouped_h2([([w], False)])
+    for small, bound in ((2.0 ** -13, 1.5e-6), (2.0 ** -20, 2e-5)):
+        a = torch.randn(M, K, device=dev)
+        a[M // 2:] *= small
+        got = gemm3_h2(a, amax(a), pl, wam)
+        ref = a.double() @ w.double().t()
+        den = a.double().abs() @ w.double().abs().t()
+        e = ((got.double() - ref).abs() / den)[M // 2:]
+        assert float(e.max()) <= bound, (small, float(e.max()))
+    z = torch.zeros(M, K, device=dev)
+    got = gemm3_h2(z, amax(z), pl, wam, b)
+    assert torch.equal(got, b.expand(M, N))
+    a = torch.randn(M, K, device=dev)
+    a[5, 7] = float("nan")
+    oam = amax_slots(1, dev)[0]
+    got = gemm3_h2(a, amax(a), pl, wam, b, out_amax=oam)
+    assert bool(torch.isnan(got[5]).all()) and not bool(torch.isnan(got[6]).any())
+
+
+@pytest.mark.parametrize("R,M,N,rps", [(4096, 256, 256, 512), (3000, 256, 1024, 512), (2048, 256, 288, 256), (1000, 100, 36, 128)])
+def test_gemm3_nt_h2_weight_gradient_accuracy(R, M, N, rps):
+    from mp_former_amd import _lib
+    from mp_former_amd.gemm3 import amax, gemm3_nt
+    dev = torch.device("cuda:0")
+    torch.manual_seed(R + M + N)
+    g = _heavy(R, M, dev) * 1e-4
+    x = _heavy(R, N, dev)
+    c, ca, cb = gemm3_nt(g, x, rps, want_csum_a=True, want_csum_b=True, amax_ab=(amax(g), amax(x)))
+    assert "h2" in _lib.last_kernel()
+    dw = c.sum(0)
+    ref = g.double().t() @ x.double()
+    lib = g.t() @ x
+    den = g.double().abs().t() @ x.double().abs()
+    e2, el = (dw.double() - ref).abs() / den, (lib.double() - ref).abs() / den
+    assert float(e2.max()) <= 1.25 * float(el.max()) + 1e-9, (float(e2.max()), float(el.max()))
+    assert float(e2.mean()) <= 1.1 * float(el.mean()) + 1e-12, (float(e2.mean()), float(el.mean()))
+    torch.testing.assert_close(ca.sum(0).double(), g.double().sum(0), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(cb.sum(0).double(), x.double().sum(0), rtol=1e-5, atol=1e-3)
+    # transposed output (the 288-wide gradient of the encoder)
+    ct, _, _ = gemm3_nt(g, x, rps, transpose_out=True, amax_ab=(amax(g), amax(x)))
+    assert torch.equal(ct.transpose(1, 2), c)
+
+
+def test_gemm3_nt_grouped_h2_bit_equal_to_single_problems():
+    from mp_former_amd.gemm3 import amax, gemm3_nt, gemm3_nt_grouped, nt_reduce
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    R, rps = 6000, 512
+    pairs = [(_heavy(R, M, dev) * 1e-3, _heavy(R, N, dev)) for (M, N) in [(256, 1024), (1024, 256), (256, 256), (256, 256)]]
+    ams = [(amax(g), amax(x)) for g, x in pairs]
+    got = gemm3_nt_grouped(pairs, rps, ams)
+    for (g, x), am, (dw, db) in zip(pairs, ams, got):
+        c, ca, _ = gemm3_nt(g, x, rps, want_csum_a=True, amax_ab=am)
+        wdw, wdb = nt_reduce(c, ca)
+        assert torch.equal(dw, wdw) and torch.equal(db, wdb)
