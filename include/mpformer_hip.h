@@ -568,7 +568,8 @@ int mpf_amax_f32(const float* x, int64_t n, float* amax, void* stream);
 int mpf_amax_f32_grouped(const MpfAmaxItem* items_device, int n_items, int64_t total_blocks, void* stream);
 int mpf_gemm3_split_grouped_h2(const MpfSplitItemH2* items_device, int n_items, int64_t total_blocks, void* stream);
 /* the weight-gradient forms (mpf_gemm3_nt without b2, mpf_gemm3_nt_grouped, mpf_gemm3_conv3x3_wgrad) with both operands split
- * into fp16 pieces on the fly; column sums are taken from the unscaled values */
+ * into fp16 pieces on the fly; column sums are taken from the unscaled values; mpf_gemm3_conv3x3_h2: mpf_gemm3_conv3x3 with
+ * Cout % 256 == 0 */
 typedef struct MpfNtItemH2 {
     const float* a;
     int64_t lda;
@@ -584,6 +585,8 @@ int mpf_gemm3_nt_h2(const float* a, int64_t lda, const float* a_amax, const floa
                     float* c_part, float* csum_a, float* csum_b, int R, int Mdim, int Ndim, int rows_per_split,
                     int transpose_out, void* stream);
 int mpf_gemm3_nt_grouped_h2(const MpfNtItemH2* items, int n_items, int R, int rows_per_split, int64_t split_stride, void* stream);
+int mpf_gemm3_conv3x3_h2(const float* x, const float* x_amax, const void* w_planes_h2, const float* w_amax, const float* bias,
+                         float* y, float* out_amax, int n_img, int H, int W, int Cin, int Cout, int transposed, void* stream);
 int mpf_gemm3_conv3x3_wgrad_h2(const float* dy, const float* dy_amax, const float* x, const float* x_amax, float* c_part,
                                float* csum_dy, int n_img, int H, int W, int Cin, int Cout, int rows_per_split, void* stream);
 int mpf_gemm3_tn_h2(const float* a, int64_t lda, const float* a_amax, const void* b_planes_h2, const float* b_amax,

@@ -75,6 +75,7 @@ SIGNATURES = {
     "mpf_gemm3_nt_h2": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp,
                               _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_gemm3_nt_grouped_h2": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_int64, _c_vp]),
+    "mpf_gemm3_conv3x3_h2": (_c_int, [_c_vp] * 7 + [_c_int] * 6 + [_c_vp]),
     "mpf_gemm3_conv3x3_wgrad_h2": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_gemm3_nt_grouped": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_int64, _c_vp]),
     "mpf_small_gemm_bf16": (_c_int, [_c_vp, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_vp,

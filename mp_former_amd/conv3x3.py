@@ -8,7 +8,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from .gemm3 import split_weights_grouped
+from .gemm3 import amax, split_weights_grouped, split_weights_grouped_h2
 from .groupnorm import is_cl_plane
 
 
@@ -38,33 +38,53 @@ class _Conv3x3Fn(Function):
         # W2[co][(ky*3+kx)*Cin + ci] for the forward, W2t[ci][(ky*3+kx)*Cout + co] for the input gradient: one split launch
         w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
         w2t = weight.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout)
-        pf, pb = split_weights_grouped([([w2.contiguous()], False), ([w2t.contiguous()], False)])
         y = _planes(N, Cout, H, W, x.device)
-        with torch.cuda.device(x.device):
-            code = _lib.lib().mpf_gemm3_conv3x3(x.data_ptr(), pf.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                                N, H, W, Cin, Cout, 0, torch.cuda.current_stream(x.device).cuda_stream)
-        _lib.check(code, "mpf_gemm3_conv3x3")
-        ctx.save_for_backward(x, weight, pb)
-        ctx.has_bias = bias is not None
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        h2 = Cout % 256 == 0 and Cin % 256 == 0          # the fp16 x 2 form (two-pass tiles both ways)
+        if h2:
+            (pf, pf_am), (pb, pb_am) = split_weights_grouped_h2([([w2.contiguous()], False), ([w2t.contiguous()], False)])
+            x_am = amax(x.permute(0, 2, 3, 1))           # (the planes are dense in this order)
+            with torch.cuda.device(x.device):
+                code = _lib.lib().mpf_gemm3_conv3x3_h2(x.data_ptr(), x_am.data_ptr(), pf.data_ptr(), pf_am.data_ptr(),
+                                                       bias.data_ptr() if bias is not None else None, y.data_ptr(), None,
+                                                       N, H, W, Cin, Cout, 0, st)
+            _lib.check(code, "mpf_gemm3_conv3x3_h2")
+            ctx.save_for_backward(x, weight, pb, pb_am, x_am)
+        else:
+            pf, pb = split_weights_grouped([([w2.contiguous()], False), ([w2t.contiguous()], False)])
+            with torch.cuda.device(x.device):
+                code = _lib.lib().mpf_gemm3_conv3x3(x.data_ptr(), pf.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                                    N, H, W, Cin, Cout, 0, st)
+            _lib.check(code, "mpf_gemm3_conv3x3")
+            ctx.save_for_backward(x, weight, pb)
+        ctx.has_bias, ctx.h2 = bias is not None, h2
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, pb = ctx.saved_tensors
+        if ctx.h2:
+            x, weight, pb, pb_am, x_am = ctx.saved_tensors
+        else:
+            x, weight, pb = ctx.saved_tensors
         N, Cin, H, W = x.shape
         Cout = weight.shape[0]
         if not (is_cl_plane(gy) and gy.stride(0) == H * W * Cout):
             gy = gy.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
         dx = dw = db = None
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        gy_am = amax(gy.permute(0, 2, 3, 1)) if ctx.h2 else None
         if ctx.needs_input_grad[0]:
             dx = _planes(N, Cin, H, W, x.device)
             with torch.cuda.device(x.device):
-                code = _lib.lib().mpf_gemm3_conv3x3(gy.data_ptr(), pb.data_ptr(), None, dx.data_ptr(), N, H, W, Cout, Cin, 1,
-                                                    torch.cuda.current_stream(x.device).cuda_stream)
+                if ctx.h2:
+                    code = _lib.lib().mpf_gemm3_conv3x3_h2(gy.data_ptr(), gy_am.data_ptr(), pb.data_ptr(), pb_am.data_ptr(), None,
+                                                           dx.data_ptr(), None, N, H, W, Cout, Cin, 1, st)
+                else:
+                    code = _lib.lib().mpf_gemm3_conv3x3(gy.data_ptr(), pb.data_ptr(), None, dx.data_ptr(), N, H, W, Cout, Cin, 1, st)
             _lib.check(code, "mpf_gemm3_conv3x3")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if W % 8 == 0 and Cin % 128 == 0:
-                dw, db = _wgrad_native(gy, x, N, H, W, Cin, Cout, ctx.has_bias)
+                dw, db = _wgrad_native(gy, x, N, H, W, Cin, Cout, ctx.has_bias, (gy_am, x_am) if ctx.h2 else None)
             else:
                 _, dw, db = torch.ops.aten.convolution_backward(
                     gy, x, weight, [Cout] if ctx.has_bias else None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
@@ -72,7 +92,7 @@ class _Conv3x3Fn(Function):
         return dx, dw, db
 
 
-def _wgrad_native(gy, x, N, H, W, Cin, Cout, has_bias):
+def _wgrad_native(gy, x, N, H, W, Cin, Cout, has_bias, amax_ab=None):
     """dW [Cout, Cin, 3, 3] (as a channels_last-strided view of [Cout, 3, 3, Cin]) and the bias gradient on the split-bf16 NT
     kernel's convolution mode: one launch over (output tile, row split) + the fixed-order sum of the splits."""
     from .gemm3 import nt_reduce
@@ -85,8 +105,13 @@ def _wgrad_native(gy, x, N, H, W, Cin, Cout, has_bias):
     c = torch.empty((ns, Cout, 9 * Cin), dtype=torch.float32, device=x.device)
     ca = torch.empty((ns, Cout), dtype=torch.float32, device=x.device) if has_bias else None
     with torch.cuda.device(x.device):
-        code = _lib.lib().mpf_gemm3_conv3x3_wgrad(gy.data_ptr(), x.data_ptr(), c.data_ptr(), ca.data_ptr() if has_bias else None, N, H, W,
-                                                  Cin, Cout, rps, torch.cuda.current_stream(x.device).cuda_stream)
+        if amax_ab is not None:
+            code = _lib.lib().mpf_gemm3_conv3x3_wgrad_h2(gy.data_ptr(), amax_ab[0].data_ptr(), x.data_ptr(), amax_ab[1].data_ptr(), c.data_ptr(),
+                                                         ca.data_ptr() if has_bias else None, N, H, W, Cin, Cout, rps,
+                                                         torch.cuda.current_stream(x.device).cuda_stream)
+        else:
+            code = _lib.lib().mpf_gemm3_conv3x3_wgrad(gy.data_ptr(), x.data_ptr(), c.data_ptr(), ca.data_ptr() if has_bias else None, N, H, W,
+                                                      Cin, Cout, rps, torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(code, "mpf_gemm3_conv3x3_wgrad")
     dw2, db = nt_reduce(c, ca)
     return dw2.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), db

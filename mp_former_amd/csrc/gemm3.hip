@@ -1778,8 +1778,25 @@ extern "C" int mpf_gemm3_tn_ex(const void* a, int a_dtype, int64_t lda, const vo
     return mpf::check(hipGetLastError(), "mpf_gemm3_tn_ex");
 }
 
+static int g3_conv_impl(const float* x, const void* w_planes, const float* bias, float* y, int n_img, int H, int W, int Cin,
+                        int Cout, int transposed, void* stream, const float* x_amax, const float* w_amax, float* out_amax);
+
 extern "C" int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const float* bias, float* y, int n_img, int H, int W, int Cin,
                                  int Cout, int transposed, void* stream)
+{
+    return g3_conv_impl(x, w_planes, bias, y, n_img, H, W, Cin, Cout, transposed, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int mpf_gemm3_conv3x3_h2(const float* x, const float* x_amax, const void* w_planes_h2, const float* w_amax, const float* bias,
+                                    float* y, float* out_amax, int n_img, int H, int W, int Cin, int Cout, int transposed, void* stream)
+{
+    if (!x_amax || !w_amax) return mpf::fail(MPF_E_NULL, "gemm3_conv3x3_h2: NULL amax");
+    if (Cout % 256 != 0) return mpf::fail(MPF_E_SHAPE, "gemm3_conv3x3_h2: Cout must be a multiple of 256");
+    return g3_conv_impl(x, w_planes_h2, bias, y, n_img, H, W, Cin, Cout, transposed, stream, x_amax, w_amax, out_amax);
+}
+
+static int g3_conv_impl(const float* x, const void* w_planes, const float* bias, float* y, int n_img, int H, int W, int Cin,
+                        int Cout, int transposed, void* stream, const float* x_amax, const float* w_amax, float* out_amax)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!x || !w_planes || !y) return mpf::fail(MPF_E_NULL, "gemm3_conv3x3: NULL buffer");
@@ -1802,7 +1819,12 @@ extern "C" int mpf_gemm3_conv3x3(const float* x, const void* w_planes, const flo
     p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
     mpf::prof_begin(st);
     mpf::set_kernel("gemm3_conv_kernel");
-    if (g_two_pass > 0 && Cout % 256 == 0) {       // 128 x 256 tiles, two passes over one A image per K step
+    p.a_amax = x_amax; p.b_amax = w_amax; p.out_amax = out_amax;
+    if (x_amax) {
+        p.tiles_n = Cout / 256;
+        p.ntiles = ((p.M + kBM - 1) / kBM) * p.tiles_n;
+        hipLaunchKernelGGL((gemm3_tn2_kernel<128, true, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
+    } else if (g_two_pass > 0 && Cout % 256 == 0) {       // 128 x 256 tiles, two passes over one A image per K step
         p.tiles_n = Cout / 256;
         p.ntiles = ((p.M + kBM - 1) / kBM) * p.tiles_n;
         hipLaunchKernelGGL((gemm3_tn2_kernel<128, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
