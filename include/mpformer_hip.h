@@ -553,6 +553,17 @@ int mpf_grouped_scale_cast(const MpfScaleCastItem* items_device, int n_items, in
  *   mpf_gemm3_tn_h2: mpf_gemm3_tn without the a2 rows, N % 256 == 0; out_amax (may be NULL) receives max |C|.
  */
 #define MPF_AMAX_SLOT_FLOATS 512
+/* producers of amax slots outside the GEMMs (encoder LayerNorms, msdeformattn.py:123-131):
+ *   mpf_res_ln256_forward_b: mpf_res_ln256_forward that also writes an UPPER BOUND of |y| into y_bound (16 max|gamma| +
+ *     max|beta|: a normalised row of 256 values cannot exceed sqrt(255)) and of |y + padd| into yplus_bound (that + the value of
+ *     the slot padd_amax) — no pass over the data; a bound a few binades above the true maximum costs the split nothing it needs;
+ *   mpf_res_ln256_backward_ws_amax: mpf_res_ln256_backward_ws that records max |ds| in ds_amax (one atomic per workgroup). */
+int mpf_res_ln256_forward_b(const float* x, const void* t, int t_dtype, const float* gamma, const float* beta, float* s_out, float* y32,
+                            void* y16, float* mean, float* rstd, int rows, float eps, const float* padd, int padd_rows, float* y_plus,
+                            float* y_bound, const float* padd_amax, float* yplus_bound, void* stream);
+int mpf_res_ln256_backward_ws_amax(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                                   const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta, int rows,
+                                   void* workspace, size_t workspace_bytes, float* ds_amax, void* stream);
 typedef struct MpfAmaxItem {
     const float* src;
     float* out;

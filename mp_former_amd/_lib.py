@@ -115,6 +115,9 @@ SIGNATURES = {
     "mpf_bias_act": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_res_ln256_forward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
                                        _c_vp, _c_int, _c_vp, _c_vp]),
+    "mpf_res_ln256_forward_b": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
+                                         _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "mpf_res_ln256_backward_ws_amax": (_c_int, [_c_vp] * 11 + [_c_int, _c_vp, ctypes.c_size_t, _c_vp, _c_vp]),
     "mpf_res_ln256_backward": (_c_int, [_c_vp] * 11 + [_c_int, _c_vp]),
     "mpf_mask_loss_backward_dense": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp,
                                               _c_vp, _c_int, _c_vp, _c_int, _c_int, _c_vp]),

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "mpf_common.h"
+#include "amax.h"
 
 namespace {
 
@@ -120,11 +121,28 @@ __global__ __launch_bounds__(256) void res_ln256_fwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ s_out, float* __restrict__ y32, __bf16* __restrict__ y16,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int rows, float eps,
-                                                            const float* __restrict__ padd, int padd_rows, float* __restrict__ y_plus)
+                                                            const float* __restrict__ padd, int padd_rows, float* __restrict__ y_plus,
+                                                            float* __restrict__ y_bound, const float* __restrict__ padd_amax,
+                                                            float* __restrict__ yplus_bound)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int c = (threadIdx.x & 63) * 4;
+    // amax slots of the outputs as an UPPER BOUND from the parameters (no pass over the data, no atomics): a normalised row of
+    // 256 values has |x^| <= sqrt(255) < 16, so |y| <= 16 max|gamma| + max|beta| (typically 4-5x the true maximum: two of the
+    // 18 binades the fp16 x 2 split carries at full precision), and |y + padd| <= that + max|padd|.  Wave 0 of block 0 writes.
+    if (y_bound && blockIdx.x == 0 && threadIdx.x < 64) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gamma + c), b4 = *reinterpret_cast<const float4*>(beta + c);
+        float gm = fmaxf(fmaxf(fabsf(g4.x), fabsf(g4.y)), fmaxf(fabsf(g4.z), fabsf(g4.w)));
+        float bm = fmaxf(fmaxf(fabsf(b4.x), fabsf(b4.y)), fmaxf(fabsf(b4.z), fabsf(b4.w)));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { gm = fmaxf(gm, __shfl_xor(gm, o)); bm = fmaxf(bm, __shfl_xor(bm, o)); }
+        if (threadIdx.x == 0) {
+            const float bound = 16.f * gm + bm;
+            y_bound[0] = bound;
+            if (yplus_bound) yplus_bound[0] = bound + __uint_as_float(amax_read(padd_amax));
+        }
+    }
     float4 v = *reinterpret_cast<const float4*>(x + (int64_t)row * 256 + c);
     float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (PLUS) pp = *reinterpret_cast<const float4*>(padd + (int64_t)(row % padd_rows) * 256 + c);
@@ -157,9 +175,11 @@ __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gy32, const __bf16* __restrict__ gy16,
                                                             const float* __restrict__ gy_plus,
                                                             float* __restrict__ ds32, __bf16* __restrict__ ds16,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int rows_per_block)
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int rows_per_block,
+                                                            float* __restrict__ ds_amax = nullptr)
 {
     __shared__ float red[2][4][256];
+    float omax = 0.f;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane * 4;
     const float4 g = *reinterpret_cast<const float4*>(gamma + c);
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -187,8 +207,13 @@ __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restr
                                      rs * (dg.w - s1 - xh.w * s2));
         if (ds32) *reinterpret_cast<float4*>(ds32 + (int64_t)row * 256 + c) = o;
         if (ds16) *reinterpret_cast<bf16x4v*>(ds16 + (int64_t)row * 256 + c) = bf16x4v{(__bf16)o.x, (__bf16)o.y, (__bf16)o.z, (__bf16)o.w};
+        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         ag = make_float4(ag.x + dy.x * xh.x, ag.y + dy.y * xh.y, ag.z + dy.z * xh.z, ag.w + dy.w * xh.w);
         ab = make_float4(ab.x + dy.x, ab.y + dy.y, ab.z + dy.z, ab.w + dy.w);
+    }
+    if (ds_amax) {      // (uniform) the largest |ds| of this block's rows -> one atomic max (amax.h)
+        __shared__ float ared[4];
+        amax_commit(ds_amax, omax, ared);
     }
     *reinterpret_cast<float4*>(&red[0][wave][c]) = ag;
     *reinterpret_cast<float4*>(&red[1][wave][c]) = ab;
@@ -276,9 +301,33 @@ __global__ __launch_bounds__(1024) void ln_partial_reduce_kernel(const float* __
 
 }  // namespace
 
+static int res_ln256_forward_impl(const float* x, const void* t, int t_dtype, const float* gamma, const float* beta,
+                                  float* s_out, float* y32, void* y16, float* mean, float* rstd, int rows, float eps,
+                                  const float* padd, int padd_rows, float* y_plus, void* stream, float* y_bound,
+                                  const float* padd_amax, float* yplus_bound);
+
 extern "C" int mpf_res_ln256_forward(const float* x, const void* t, int t_dtype, const float* gamma, const float* beta,
                                      float* s_out, float* y32, void* y16, float* mean, float* rstd, int rows, float eps,
                                      const float* padd, int padd_rows, float* y_plus, void* stream)
+{
+    return res_ln256_forward_impl(x, t, t_dtype, gamma, beta, s_out, y32, y16, mean, rstd, rows, eps, padd, padd_rows, y_plus, stream,
+                                  nullptr, nullptr, nullptr);
+}
+
+extern "C" int mpf_res_ln256_forward_b(const float* x, const void* t, int t_dtype, const float* gamma, const float* beta,
+                                       float* s_out, float* y32, void* y16, float* mean, float* rstd, int rows, float eps,
+                                       const float* padd, int padd_rows, float* y_plus, float* y_bound, const float* padd_amax,
+                                       float* yplus_bound, void* stream)
+{
+    if (!y_bound || (yplus_bound && (!padd_amax || !y_plus))) return mpf::fail(MPF_E_NULL, "res_ln256_forward_b: NULL amax slot");
+    return res_ln256_forward_impl(x, t, t_dtype, gamma, beta, s_out, y32, y16, mean, rstd, rows, eps, padd, padd_rows, y_plus, stream,
+                                  y_bound, padd_amax, yplus_bound);
+}
+
+static int res_ln256_forward_impl(const float* x, const void* t, int t_dtype, const float* gamma, const float* beta,
+                                  float* s_out, float* y32, void* y16, float* mean, float* rstd, int rows, float eps,
+                                  const float* padd, int padd_rows, float* y_plus, void* stream, float* y_bound,
+                                  const float* padd_amax, float* yplus_bound)
 {
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) return 0;
@@ -288,7 +337,7 @@ extern "C" int mpf_res_ln256_forward(const float* x, const void* t, int t_dtype,
     mpf::set_kernel("res_ln256_fwd_kernel");
 #define RLN_FWD(TT, HT, PL)                                                                                                        \
     hipLaunchKernelGGL((res_ln256_fwd_kernel<TT, HT, PL>), grid, dim3(256), 0, st, x, (const TT*)t, gamma, beta, s_out, y32, (__bf16*)y16, \
-                       mean, rstd, rows, eps, padd, padd_rows, y_plus)
+                       mean, rstd, rows, eps, padd, padd_rows, y_plus, y_bound, padd_amax, yplus_bound)
     const bool plus = y_plus != nullptr;
     if (t && t_dtype == MPF_BF16) { if (plus) RLN_FWD(__bf16, true, true); else RLN_FWD(__bf16, true, false); }
     else if (t && t_dtype == MPF_F32) { if (plus) RLN_FWD(float, true, true); else RLN_FWD(float, true, false); }
@@ -338,9 +387,31 @@ extern "C" size_t mpf_res_ln256_backward_workspace_bytes(int rows)
 }
 
 // the same backward with the parameter gradients reduced WITHOUT atomics (deterministic; dgamma / dbeta need no zeroing)
+static int res_ln256_backward_ws_impl(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                                      const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta,
+                                      int rows, void* workspace, size_t workspace_bytes, void* stream, float* ds_amax);
+
 extern "C" int mpf_res_ln256_backward_ws(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
                                          const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta,
                                          int rows, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return res_ln256_backward_ws_impl(s, mean, rstd, gamma, gy32, gy16, gy_plus, ds32, ds16, dgamma, dbeta, rows, workspace, workspace_bytes,
+                                      stream, nullptr);
+}
+
+// ... recording the largest |ds| in an amax slot (zeroed by the caller) for the fp16 x 2 GEMMs that consume ds
+extern "C" int mpf_res_ln256_backward_ws_amax(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                                              const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta,
+                                              int rows, void* workspace, size_t workspace_bytes, float* ds_amax, void* stream)
+{
+    if (!ds_amax) return mpf::fail(MPF_E_NULL, "res_ln256_backward_ws_amax: NULL amax slot");
+    return res_ln256_backward_ws_impl(s, mean, rstd, gamma, gy32, gy16, gy_plus, ds32, ds16, dgamma, dbeta, rows, workspace, workspace_bytes,
+                                      stream, ds_amax);
+}
+
+static int res_ln256_backward_ws_impl(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                                      const void* gy16, const float* gy_plus, float* ds32, void* ds16, float* dgamma, float* dbeta,
+                                      int rows, void* workspace, size_t workspace_bytes, void* stream, float* ds_amax)
 {
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) return 0;
@@ -355,7 +426,7 @@ extern "C" int mpf_res_ln256_backward_ws(const float* s, const float* mean, cons
     mpf::set_kernel("res_ln256_bwd_kernel");
 #define RLN_BWDP(A, B, C)                                                                                                         \
     hipLaunchKernelGGL((res_ln256_bwd_kernel<A, B, C, 1>), grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16,    \
-                       gy_plus, ds32, (__bf16*)ds16, part, part, rows, rpb)
+                       gy_plus, ds32, (__bf16*)ds16, part, part, rows, rpb, ds_amax)
     switch ((gy32 ? 4 : 0) | (gy16 ? 2 : 0) | (gy_plus ? 1 : 0)) {
         case 1: RLN_BWDP(false, false, true); break;
         case 2: RLN_BWDP(false, true, false); break;

@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "mpf_common.h"
+#include "amax.h"
 #ifndef G3_PRIO
 #define G3_PRIO 1
 #endif
@@ -135,21 +136,6 @@ __device__ __forceinline__ void split8h(const float4 u, const float4 v, const fl
     *l = make_uint4(lb[0], lb[1], lb[2], lb[3]);
 }
 
-// An "amax slot" is kAmaxSub sub-slots kAmaxStride floats apart (different cache lines): producers max into the sub-slot
-// blockIdx.x % kAmaxSub with ONE atomic per workgroup (device-scope atomics on one address serialise at ~11 ns each: 8 192 of
-// them cost a 44 MB reduction 90 us), consumers take the largest of the 16.  Non-negative floats order like their bit
-// patterns and a NaN pattern is larger than inf, so the integer max is order-independent and keeps a NaN visible.
-constexpr int kAmaxSub = 16, kAmaxStride = 32;
-
-__device__ __forceinline__ unsigned amax_read(const float* slot)
-{
-    const unsigned* s = reinterpret_cast<const unsigned*>(slot);
-    unsigned m = 0;
-#pragma unroll
-    for (int i = 0; i < kAmaxSub; ++i) m = max(m, s[i * kAmaxStride]);
-    return m;
-}
-
 // power-of-two scale that puts amax into [2^14, 2^15) (fp16 tops out at 65504) and its inverse, from the exponent field:
 // exact, and the same for every kernel that looks at the same amax.  amax below 2^-97 (incl. 0) counts as 2^-97; inf / nan
 // give a finite scale (the values themselves stay inf / nan and so does the result).
@@ -159,21 +145,6 @@ __device__ __forceinline__ void h2_scale(const unsigned amax_bits, float* scale,
     e = max(e, 30);
     *scale = __uint_as_float((unsigned)(268 - e) << 23);       // 2^(14 - (e - 127))
     *inv = __uint_as_float((unsigned)(e - 14) << 23);          // 2^-(14 - (e - 127))
-}
-
-// running max |x| of the threads of a workgroup (256 threads) -> one atomic max; red: 4 floats of LDS nobody else is using
-// (called by all threads, contains a barrier)
-__device__ __forceinline__ void amax_commit(float* slot, float m, float* red)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        atomicMax(reinterpret_cast<unsigned*>(slot) + (blockIdx.x % kAmaxSub) * kAmaxStride, __float_as_uint(m));
-    }
 }
 
 __device__ __forceinline__ f16x8 as_fragh(const uint4 v)

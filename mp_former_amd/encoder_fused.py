@@ -115,31 +115,34 @@ class EncoderFn(Function):
         planes3 = split_weights_grouped(g3)
         # the 288-wide bias of every layer in one concatenation
         b288_all = torch.cat([params[i * PARAMS_PER_LAYER + k] for i in range(nl) for k in (1, 3)]).view(nl, -1)
-        am = amax_slots(5 * nl + 1, src.device)          # per layer: ao, x1, h, the next layer's x, q
-        x_am = amax(x, am[5 * nl])
+        # amax slots (largest magnitude, or an upper bound of it) of every GEMM operand: x / q of layer 0 and the positional
+        # term by a pass over the data; the rest from their producers — LayerNorm outputs bounded from (gamma, beta), the
+        # attention output bounded by max |value| (a convex combination of value rows), the FFN hidden layer from its GEMM
+        am = amax_slots(5 * nl + 3, src.device)          # per layer: ao, x1, h, the next layer's x, the next layer's q
+        x_am, q_am, pos_am = amax(x, am[5 * nl]), am[5 * nl + 1], amax(pos_full, am[5 * nl + 2])
         for i in range(nl):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2_, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             (pv, pv_am), (po, po_am), (p1, p1_am), (p2, p2_am) = planes2[9 * i:9 * i + 4]
             p288 = planes3[i]
             b288 = b288_all[i]
-            ao_am, x1_am, h_am, xn_am, q_am = am[5 * i:5 * i + 5]
-            value = gemm3_h2(x, x_am, pv, pv_am, bv)
+            ao_am, x1_am, h_am, xn_am, qn_am = am[5 * i:5 * i + 5]
+            value = gemm3_h2(x, x_am, pv, pv_am, bv, out_amax=ao_am)
             if q is None:       # layer 0; later layers get src + pos from the previous layer's norm2 pass
                 q = (x.view(N, S, C) + pos_full).view(R, C)
+                amax(q, q_am)
             raw = gemm3(q, p288, b288)
-            amax(q, q_am)                      # (for the weight gradient q^T . d raw of the backward)
             # softmax over the 12 logits, loc = ref + offset / (W_l, H_l) happen inside the MSDA kernel
             ao, loc, attn = ms_deform_attn_forward_raw(value.view(N, S, M, C // M), shapes, lsi, raw, ref, host_shapes)
             ao = ao.view(R, C)
-            s1 = gemm3_h2(ao, amax(ao, ao_am), po, po_am, bo, cin=x)
-            x1, mean1, rstd1, _ = ln256_forward(s1, g1, b1, _EPS)
-            h = gemm3_h2(x1, amax(x1, x1_am), p1, p1_am, bb1, relu=True, out_amax=h_am)
+            s1 = gemm3_h2(ao, ao_am, po, po_am, bo, cin=x)
+            x1, mean1, rstd1, _ = ln256_forward(s1, g1, b1, _EPS, y_bound=x1_am)
+            h = gemm3_h2(x1, x1_am, p1, p1_am, bb1, relu=True, out_amax=h_am)
             s2 = gemm3_h2(h, h_am, p2, p2_am, bb2, cin=x1)
-            x2, mean2, rstd2, qn = ln256_forward(s2, g2_, b2, _EPS, padd=pos_full if i + 1 < nl else None)
+            last = i + 1 == nl
+            x2, mean2, rstd2, qn = ln256_forward(s2, g2_, b2, _EPS, padd=None if last else pos_full, y_bound=xn_am,
+                                                 padd_amax=None if last else pos_am, yplus_bound=None if last else qn_am)
             saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am]
-            x, q = x2, qn
-            if i + 1 < nl:
-                x_am = amax(x, xn_am)
+            x, q, x_am, q_am = x2, qn, xn_am, qn_am
         ctx.save_for_backward(pos_full, level_embed, *params, *saved)
         ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
         ctx.planes_t = [planes2[9 * i + 4:9 * i + 9] for i in range(nl)]       # (W^T planes, amax) for the backward
@@ -178,12 +181,12 @@ class EncoderFn(Function):
             (tv, tv_am), (to, to_am), (t1, t1_am), (t2, t2_am), (t288, t288_am) = ctx.planes_t[i]
             ds2_am, dh_am, ds1_am, draw_am, gv_am = am[5 * i:5 * i + 5]
             # norm2 <- ffn
-            ds2, dp[14], dp[15] = ln256_backward(s2, mean2, rstd2, g2, g, gq)
-            dh = gemm3_h2(ds2, amax(ds2, ds2_am), t2, t2_am, gate=h, out_amax=dh_am)
+            ds2, dp[14], dp[15] = ln256_backward(s2, mean2, rstd2, g2, g, gq, ds_amax=ds2_am)
+            dh = gemm3_h2(ds2, ds2_am, t2, t2_am, gate=h, out_amax=dh_am)
             dx1 = gemm3_h2(dh, dh_am, t1, t1_am, cin=ds2)
             # norm1 <- attention
-            ds1, dp[8], dp[9] = ln256_backward(s1, mean1, rstd1, g1, dx1)
-            dao = gemm3_h2(ds1, amax(ds1, ds1_am), to, to_am)
+            ds1, dp[8], dp[9] = ln256_backward(s1, mean1, rstd1, g1, dx1, ds_amax=ds1_am)
+            dao = gemm3_h2(ds1, ds1_am, to, to_am)
             # d(raw): the softmax / offset-normaliser backward is the epilogue of the push kernel
             gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C))
             dq = gemm3_h2(draw, amax(draw, draw_am), t288, t288_am)

@@ -86,24 +86,31 @@ def res_ln(norm, x, t=None, want32=True, want16=False):
     return (y if want32 else None), (y.to(torch.bfloat16) if want16 else None)
 
 
-def ln256_forward(x, gamma, beta, eps, padd=None):
-    """Raw forward for hand-scheduled callers (encoder_fused): x fp32 [rows, 256] -> (y, mean, rstd[, y + padd[row % len]])."""
+def ln256_forward(x, gamma, beta, eps, padd=None, y_bound=None, padd_amax=None, yplus_bound=None):
+    """Raw forward for hand-scheduled callers (encoder_fused): x fp32 [rows, 256] -> (y, mean, rstd[, y + padd[row % len]]).
+    y_bound / yplus_bound: zeroed amax slots that receive an upper bound of |y| / |y + padd| (padd_amax: the slot of padd)."""
     rows = x.shape[0]
     y = torch.empty_like(x)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     yp = torch.empty_like(x) if padd is not None else None
+    p_ = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
     with torch.cuda.device(x.device):
-        code = _lib.lib().mpf_res_ln256_forward(
-            x.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), None, y.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(),
-            rows, float(eps), padd.data_ptr() if padd is not None else None, padd.shape[0] if padd is not None else 0,
-            yp.data_ptr() if yp is not None else None, _stream(x))
+        if y_bound is not None:
+            code = _lib.lib().mpf_res_ln256_forward_b(
+                x.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), None, y.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(),
+                rows, float(eps), p_(padd), padd.shape[0] if padd is not None else 0, p_(yp), y_bound.data_ptr(), p_(padd_amax),
+                p_(yplus_bound) if yp is not None else None, _stream(x))
+        else:
+            code = _lib.lib().mpf_res_ln256_forward(
+                x.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), None, y.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(),
+                rows, float(eps), p_(padd), padd.shape[0] if padd is not None else 0, p_(yp), _stream(x))
     _lib.check(code, "mpf_res_ln256_forward")
     return y, mean, rstd, yp
 
 
-def ln256_backward(s, mean, rstd, gamma, gy, gy_plus=None):
-    """Raw backward: -> (ds fp32, dgamma, dbeta) with g = gy (+ gy_plus)."""
+def ln256_backward(s, mean, rstd, gamma, gy, gy_plus=None, ds_amax=None):
+    """Raw backward: -> (ds fp32, dgamma, dbeta) with g = gy (+ gy_plus); ds_amax: a zeroed amax slot that receives max |ds|."""
     ds = torch.empty_like(s)
     dgb = torch.empty((2, 256), dtype=torch.float32, device=s.device)
     lib = _lib.lib()
@@ -114,10 +121,13 @@ def ln256_backward(s, mean, rstd, gamma, gy, gy_plus=None):
         _ln_ws[s.device] = ws
     with torch.cuda.device(s.device):
         # parameter gradients through per-workgroup partials, fixed order (no atomics, no zero-fill)
-        code = lib.mpf_res_ln256_backward_ws(
-            s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), gy.data_ptr(), None,
-            gy_plus.data_ptr() if gy_plus is not None else None, ds.data_ptr(), None, dgb[0].data_ptr(), dgb[1].data_ptr(),
-            s.shape[0], ws.data_ptr(), ws.numel(), _stream(s))
+        args = (s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), gy.data_ptr(), None,
+                gy_plus.data_ptr() if gy_plus is not None else None, ds.data_ptr(), None, dgb[0].data_ptr(), dgb[1].data_ptr(),
+                s.shape[0], ws.data_ptr(), ws.numel())
+        if ds_amax is not None:
+            code = lib.mpf_res_ln256_backward_ws_amax(*args, ds_amax.data_ptr(), _stream(s))
+        else:
+            code = lib.mpf_res_ln256_backward_ws(*args, _stream(s))
     _lib.check(code, "mpf_res_ln256_backward_ws")
     return ds, dgb[0], dgb[1]
 

@@ -268,10 +268,13 @@ def test_head_amp_path_matches_reference_golden(name):
     ref_keys = sorted(k[5:] for k in z if k.startswith("loss."))
     assert sorted(losses) == ref_keys
     bad = {}
+    # 2 % per loss through 3-4 bf16 decoder layers; 3 % through the 9 of head_deep (the importance sampling of the mask losses
+    # picks its points by the bf16 logits' uncertainty, so a few of the 3 x 112 / 224 points per pair differ from the reference's)
+    rtol = 2e-2 if cfg["dec_layers"] <= 4 else 3e-2
     for k in ref_keys:
         want = float(z["loss." + k]) * wd[k]
         got = float(losses[k])
-        if abs(got - want) > 2e-2 * abs(want) + 2e-3:
+        if abs(got - want) > rtol * abs(want) + 2e-3:
             bad[k] = (got, want)
     assert not bad, f"AMP losses off the fp32 goldens: {bad}"
     np.testing.assert_allclose(float(total), float(z["total_loss"]), rtol=1e-2)
