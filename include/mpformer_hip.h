@@ -550,7 +550,7 @@ int mpf_grouped_scale_cast(const MpfScaleCastItem* items_device, int n_items, in
  * the operand, into a slot the caller has zeroed; every kernel derives the same scale from the same slot.
  *   mpf_amax_f32_grouped: item i (device table) = x_i[0 .. numel_i) -> *out_i, workgroups [first_block, + ceil(numel / 4096));
  *   mpf_gemm3_split_grouped_h2: mpf_gemm3_split_grouped writing planes[2][..] of fp16 with the scale from *amax;
- *   mpf_gemm3_tn_h2: mpf_gemm3_tn without the a2 rows, N % 256 == 0; out_amax (may be NULL) receives max |C|.
+ *   mpf_gemm3_tn_h2: mpf_gemm3_tn without the a2 rows; out_amax (may be NULL) receives max |C|.
  */
 #define MPF_AMAX_SLOT_FLOATS 512
 /* producers of amax slots outside the GEMMs (encoder LayerNorms, msdeformattn.py:123-131):

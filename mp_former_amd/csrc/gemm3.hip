@@ -496,20 +496,22 @@ __device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned
 // the image contribute zeros (the loads stay unconditional on clamped rows, the registers are zeroed before the split).
 // ABF: A is a bf16 matrix (p.a points at 2-byte elements, lda in elements): its rows go to plane 0 of the LDS image as they
 // are (one 16-byte load per row and k-chunk, no split) and a K step is three products instead of six.
-template <int BN, bool A2, bool CV = false, bool ABF = false>
+template <int BN, bool A2, bool CV = false, bool ABF = false, bool H2 = false>
 __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, const int m0, const int n0)
 {
     static_assert(!(ABF && (A2 || CV)), "bf16 A: no addend, no convolution mode");
+    static_assert(!(H2 && (ABF || A2)), "fp16 x 2 form: fp32 A, no addend rows");
     constexpr int NJ = BN / 32;                  // 16-column MFMA tiles per wave
     constexpr int kBKc = BN * 16;                // bytes per (plane, k-chunk) of the B image
-    constexpr int kAbytes = 12 * kAKc;
+    constexpr int kPl = H2 ? 2 : 3;              // planes per operand
+    constexpr int kAbytes = kPl * 4 * kAKc;
     constexpr int kBunits = 3 * BN * 4;          // 16-B units of a B stage
     constexpr int kBiter = (kBunits + kThreads - 1) / kThreads;
     // B (the pre-split weight planes, L2-resident) goes global -> LDS by DMA (global_load_lds, 64 lanes x 16 B = 1 KB per
     // wave instruction) into one of TWO stages, no registers and no ds_write: the 16-byte LDS stores were a quarter of this
     // kernel's time (a wave's ds_write_b128 occupies the VGPR -> LDS path for ~13 cycles; A + B were 12 per thread and K step)
-    constexpr int kBstage = 12 * kBKc;           // bytes of one B stage
-    constexpr int kPieces = kBstage / 1024;      // DMA pieces per stage (BN = 128: 24, 96: 18, 64: 12)
+    constexpr int kBstage = kPl * 4 * kBKc;      // bytes of one B stage
+    constexpr int kPieces = kBstage / 1024;      // DMA pieces per stage (BN = 128: 24, 96: 18, 64: 12; two planes: 16, 12, 8)
     constexpr int kPW = (kPieces + 3) / 4;       // per wave (BN = 96: 5, the two surplus pieces repeat the last one)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -623,6 +625,13 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         if constexpr (ABF) {                                                                 \
             *reinterpret_cast<float4*>(lds + (0 * 4 + akc) * kAKc + aslot0 * 16) = w0_;      \
             *reinterpret_cast<float4*>(lds + (0 * 4 + akc) * kAKc + aslot1 * 16) = w2_;      \
+        } else if constexpr (H2) {                                                           \
+            split8h(w0_, w1_, sc_a, &h, &l);                                                 \
+            *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + aslot0 * 16) = h;         \
+            *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + aslot0 * 16) = l;         \
+            split8h(w2_, w3_, sc_a, &h, &l);                                                 \
+            *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + aslot1 * 16) = h;         \
+            *reinterpret_cast<uint4*>(lds + (1 * 4 + akc) * kAKc + aslot1 * 16) = l;         \
         } else {                                                                             \
         split8(w0_, w1_, &h, &m, &l);                                                        \
         *reinterpret_cast<uint4*>(lds + (0 * 4 + akc) * kAKc + aslot0 * 16) = h;             \
@@ -637,6 +646,13 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    float sc_a = 1.f, inv_a = 1.f, inv_b = 1.f;
+    if constexpr (H2) {
+        float sc_b;
+        h2_scale(amax_read(p.a_amax), &sc_a, &inv_a);
+        h2_scale(amax_read(p.b_amax), &sc_b, &inv_b);
+    }
+    (void)sc_a;
     Acc<NJ> acc;
     acc.zero();
 
@@ -677,7 +693,8 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         __builtin_amdgcn_sched_barrier(0);
         G3_T(3);
         __builtin_amdgcn_s_setprio(G3_PRIO);
-        acc.template step<kAKc, kBKc, false, ABF, true>(lds, a_frag, b_frag, lane);
+        if constexpr (H2) acc.template step_h2<kAKc, kBKc, true>(lds, a_frag, b_frag, lane);
+        else acc.template step<kAKc, kBKc, false, ABF, true>(lds, a_frag, b_frag, lane);
         __builtin_amdgcn_s_setprio(0);
         G3_T(4);
         if (kt + 1 >= nk) break;
@@ -694,7 +711,8 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
         __builtin_amdgcn_sched_barrier(0);
         G3_T(3);
         __builtin_amdgcn_s_setprio(G3_PRIO);
-        acc.template step<kAKc, kBKc, false, ABF, true>(lds, a_frag, b_frag + kBstage, lane);
+        if constexpr (H2) acc.template step_h2<kAKc, kBKc, true>(lds, a_frag, b_frag + kBstage, lane);
+        else acc.template step<kAKc, kBKc, false, ABF, true>(lds, a_frag, b_frag + kBstage, lane);
         __builtin_amdgcn_s_setprio(0);
         G3_T(4);
     }
@@ -707,7 +725,11 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
     }
 #endif
 
-    g3_epilogue<NJ>(p, acc, lane, m0 + wr * 64, n0 + wc * (BN / 2));
+    const float omax = g3_epilogue<NJ, 4, Acc<NJ, false>, H2>(p, acc, lane, m0 + wr * 64, n0 + wc * (BN / 2), inv_a, inv_b);
+    if constexpr (H2) {
+        if (p.out_amax) amax_commit(p.out_amax, omax, reinterpret_cast<float*>(lds));
+    }
+    (void)omax;
 }
 #undef G3_LOAD_A
 #undef G3_LOAD_A_CV
@@ -715,17 +737,17 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
 #undef G3_LOAD_B
 #undef G3_WRITE
 
-template <int BN, bool A2>
+template <int BN, bool A2, bool H2 = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm3_tn_kernel(G3 p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[12 * kAKc + 2 * 12 * BN * 16];       // A image + two B stages
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(H2 ? 8 : 12) * (kAKc + 2 * BN * 16)];       // A image + two B stages
     // XCD-aware tile order: each XCD walks a contiguous run of tiles (column tiles of one row block
     // are neighbours, so the A rows they share stay in that XCD's L2)
     const int per_xcd = (p.ntiles + 7) >> 3;
     const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    g3_tn_tile<BN, A2>(p, lds, tm * kBM, tn * BN);
+    g3_tn_tile<BN, A2, false, false, H2>(p, lds, tm * kBM, tn * BN);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1610,7 +1632,6 @@ extern "C" int mpf_gemm3_tn_h2(const float* a, int64_t lda, const float* a_amax,
                                int relu, void* stream)
 {
     if (!a_amax || !b_amax) return mpf::fail(MPF_E_NULL, "gemm3_tn_h2: NULL amax");
-    if (N % 256 != 0) return mpf::fail(MPF_E_SHAPE, "gemm3_tn_h2: N must be a multiple of 256");
     return g3_tn_impl(a, lda, nullptr, 0, b_planes_h2, bias, c_in, ldcin, c_in2, ldcin2, gate, ldgate, c, ldc, M, N, K, relu, stream,
                       a_amax, b_amax, out_amax);
 }
@@ -1654,7 +1675,19 @@ static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows,
         mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + (a_amax ? 4.0 : 6.0) * (double)N * K, 2.0 * M * (double)N * K);
         return mpf::check(hipGetLastError(), "mpf_gemm3_tn");
     }
-    if (a_amax) return mpf::fail(MPF_E_SHAPE, "gemm3_tn_h2: shape outside the two-pass tiles");
+    if (a_amax) {       // N % 256 != 0: the one-pass 128- / 96-column tiles
+        const int grid_h = ((p.ntiles + 7) / 8) * 8;
+        mpf::prof_begin(st);
+        if (use96) {
+            mpf::set_kernel("gemm3_tn_kernel<h2 96>");
+            hipLaunchKernelGGL((gemm3_tn_kernel<96, false, true>), dim3(grid_h), dim3(kThreads), 0, st, p);
+        } else {
+            mpf::set_kernel("gemm3_tn_kernel<h2 128>");
+            hipLaunchKernelGGL((gemm3_tn_kernel<128, false, true>), dim3(grid_h), dim3(kThreads), 0, st, p);
+        }
+        mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + 4.0 * (double)N * K, 2.0 * M * (double)N * K);
+        return mpf::check(hipGetLastError(), "mpf_gemm3_tn_h2");
+    }
     // tail effect: when the last round of 128 x 128 tiles would fill at most half of the chip's workgroup slots, its row
     // blocks are cut into 128 x 64 tiles instead (gemm3_tn_mixed_kernel)
     if (!use96 && N % 64 == 0 && g_mixed) {

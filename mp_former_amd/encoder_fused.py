@@ -22,8 +22,7 @@ import math
 import torch
 from torch.autograd import Function
 
-from .gemm3 import (amax, amax_slots, gemm3, gemm3_h2, gemm3_nt, gemm3_nt_grouped, nt_reduce_levels, split_weights_grouped,
-                    split_weights_grouped_h2)
+from .gemm3 import amax, amax_slots, gemm3_h2, gemm3_nt, gemm3_nt_grouped, nt_reduce_levels, split_weights_grouped_h2
 from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
 from .resln import ln256_backward, ln256_forward
 
@@ -104,17 +103,14 @@ class EncoderFn(Function):
         saved = []
         no = M * L * P * 2
         q = None
-        # fp16 x 2 planes (+ largest magnitude) of every weight whose GEMMs have N % 256 == 0, both orientations (W for the
-        # forward, W^T for the input gradients), and bf16 x 3 planes of the stacked 288-row sampling_offsets | attention_weights
-        # operand — three launches for all layers
-        g2, g3 = [], []
+        # fp16 x 2 planes (+ largest magnitude) of every weight, both orientations (W for the forward, W^T for the input
+        # gradients; sampling_offsets | attention_weights stacked into one 288-row operand on the way): two launches for all layers
+        g2 = []
         for i in range(nl):
             (wso, _, waw, _, wv, _, wo, _, _, _, w1, _, w2, _, _, _) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            ws = ([wv], [wo], [w1], [w2])
-            g2 += [(w_, False) for w_ in ws] + [(w_, True) for w_ in ws] + [([wso, waw], True)]
-            g3.append(([wso, waw], False))
+            ws = ([wv], [wo], [w1], [w2], [wso, waw])
+            g2 += [(w_, False) for w_ in ws] + [(w_, True) for w_ in ws]
         planes2 = split_weights_grouped_h2(g2)
-        planes3 = split_weights_grouped(g3)
         # the 288-wide bias of every layer in one concatenation
         b288_all = torch.cat([params[i * PARAMS_PER_LAYER + k] for i in range(nl) for k in (1, 3)]).view(nl, -1)
         # amax slots (largest magnitude, or an upper bound of it) of every GEMM operand: x / q of layer 0 and the positional
@@ -124,15 +120,14 @@ class EncoderFn(Function):
         x_am, q_am, pos_am = amax(x, am[5 * nl]), am[5 * nl + 1], amax(pos_full, am[5 * nl + 2])
         for i in range(nl):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2_, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            (pv, pv_am), (po, po_am), (p1, p1_am), (p2, p2_am) = planes2[9 * i:9 * i + 4]
-            p288 = planes3[i]
+            (pv, pv_am), (po, po_am), (p1, p1_am), (p2, p2_am), (p288, p288_am) = planes2[10 * i:10 * i + 5]
             b288 = b288_all[i]
             ao_am, x1_am, h_am, xn_am, qn_am = am[5 * i:5 * i + 5]
             value = gemm3_h2(x, x_am, pv, pv_am, bv, out_amax=ao_am)
             if q is None:       # layer 0; later layers get src + pos from the previous layer's norm2 pass
                 q = (x.view(N, S, C) + pos_full).view(R, C)
                 amax(q, q_am)
-            raw = gemm3(q, p288, b288)
+            raw = gemm3_h2(q, q_am, p288, p288_am, b288)
             # softmax over the 12 logits, loc = ref + offset / (W_l, H_l) happen inside the MSDA kernel
             ao, loc, attn = ms_deform_attn_forward_raw(value.view(N, S, M, C // M), shapes, lsi, raw, ref, host_shapes)
             ao = ao.view(R, C)
@@ -147,7 +142,7 @@ class EncoderFn(Function):
             x, q, x_am, q_am = x2, qn, xn_am, qn_am
         ctx.save_for_backward(pos_full, level_embed, *params, *saved)
         ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
-        ctx.planes_t = [planes2[9 * i + 4:9 * i + 9] for i in range(nl)]       # (W^T planes, amax) for the backward
+        ctx.planes_t = [planes2[10 * i + 5:10 * i + 10] for i in range(nl)]       # (W^T planes, amax) for the backward
         return x.view(N, S, C)
 
     @staticmethod

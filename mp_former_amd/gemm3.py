@@ -129,7 +129,7 @@ def split_weights_grouped_h2(groups):
 
 def gemm3_h2(a, a_amax, planes, w_amax, bias=None, cin=None, cin2=None, gate=None, relu=False, out_amax=None):
     """``gemm3`` in the fp16 x 2 form: planes / w_amax from ``split_weights_grouped_h2``, a_amax = max |a| (device, [1]);
-    out_amax (a zeroed [1] slot or None) receives max |C|.  N % 256 == 0."""
+    out_amax (a zeroed slot or None) receives max |C|."""
     assert a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
     assert planes.dtype == torch.float16 and planes.is_contiguous() and planes.shape[0] == 2
     M, K = a.shape

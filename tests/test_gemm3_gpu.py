@@ -229,7 +229,8 @@ def _heavy(M, K, dev, small_rows=1.0):
     return a
 
 
-@pytest.mark.parametrize("M,N,K", [(4096, 256, 256), (2000, 1024, 256), (3000, 256, 1024), (700, 256, 288)])
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 256), (2000, 1024, 256), (3000, 256, 1024), (700, 256, 288), (1500, 288, 256), (333, 128, 64),
+                                   (257, 100, 96)])
 def test_gemm3_tn_h2_accuracy_not_worse_than_library_fp32(M, N, K):
     """Error against fp64, relative to sum |a||b| per output element: the fp16 x 2 form is held to the library fp32 GEMM's
     (max and mean), with bias / addends / ReLU gate in the epilogue and the recorded output amax exact."""
