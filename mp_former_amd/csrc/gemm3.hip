@@ -1824,6 +1824,7 @@ static int g3_conv_impl(const float* x, const void* w_planes, const float* bias,
     mpf::prof_begin(st);
     mpf::set_kernel("gemm3_conv_kernel");
     p.a_amax = x_amax; p.b_amax = w_amax; p.out_amax = out_amax;
+    if (x_amax) mpf::set_kernel("gemm3_conv_kernel<h2>");
     if (x_amax) {
         p.tiles_n = Cout / 256;
         p.ntiles = ((p.M + kBM - 1) / kBM) * p.tiles_n;
@@ -1834,7 +1835,8 @@ static int g3_conv_impl(const float* x, const void* w_planes, const float* bias,
         hipLaunchKernelGGL((gemm3_tn2_kernel<128, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
     } else
     hipLaunchKernelGGL(gemm3_conv_kernel, dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
-    mpf::prof_end("gemm3_conv_kernel", st, 4.0 * ((double)p.M * Cin + (double)p.M * Cout) + 6.0 * (double)Cout * p.K, 2.0 * p.M * (double)Cout * p.K);
+    mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)p.M * Cin + (double)p.M * Cout) + (x_amax ? 4.0 : 6.0) * (double)Cout * p.K,
+                  2.0 * p.M * (double)Cout * p.K);
     return mpf::check(hipGetLastError(), "mpf_gemm3_conv3x3");
 }
 
@@ -2101,7 +2103,7 @@ static int g3_conv_wgrad_impl(const float* dy, const float* x, float* c_part, fl
     p.c_ss = (int64_t)p.Mdim * p.Ndim; p.csa_ss = p.Mdim; p.csb_ss = p.Ndim;
     mpf::prof_begin(st);
     p.a_amax = dy_amax; p.b_amax = x_amax;
-    mpf::set_kernel("gemm3_nt_kernel<conv3x3>");
+    mpf::set_kernel(dy_amax ? "gemm3_nt_kernel<conv3x3 h2>" : "gemm3_nt_kernel<conv3x3>");
     if (dy_amax) hipLaunchKernelGGL((gemm3_nt_kernel<128, false, true, false, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
     else hipLaunchKernelGGL((gemm3_nt_kernel<128, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
     mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)p.R * Cout + (double)p.R * Cin + (double)p.nsplit * Cout * 9 * Cin),
