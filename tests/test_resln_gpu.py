@@ -72,3 +72,31 @@ def test_to_nchw_matches_contiguous(shape):
     g = torch.randn(shape, device="cuda:0")
     y.backward(g)
     assert torch.equal(x.grad, g)
+
+
+def test_ln256_amax_slots_bound_forward_exact_backward():
+    """The amax slots the fp16 x 2 GEMMs read (include/mpformer_hip.h): the forward writes an upper BOUND of |y| and |y + padd| from
+    (gamma, beta, slot of padd) — never below the true maximum, exactly 16 max|gamma| + max|beta| (+ max|padd|) — the backward the
+    exact max |ds|; results unchanged by the slot arguments."""
+    from mp_former_amd.gemm3 import amax, amax_slots, amax_value
+    from mp_former_amd.resln import ln256_backward, ln256_forward
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    rows = 5000
+    x = torch.randn(rows, 256, device=dev) * 3 + 1
+    g, b = torch.randn(256, device=dev), torch.randn(256, device=dev)
+    padd = torch.randn(100, 256, device=dev) * 2
+    sl = amax_slots(3, dev)
+    pa = amax(padd)
+    y0, m0, r0, yp0 = ln256_forward(x, g, b, 1e-5, padd=padd)
+    y, m, r, yp = ln256_forward(x, g, b, 1e-5, padd=padd, y_bound=sl[0], padd_amax=pa, yplus_bound=sl[1])
+    assert torch.equal(y, y0) and torch.equal(yp, yp0) and torch.equal(m, m0) and torch.equal(r, r0)
+    bound = 16.0 * float(g.abs().max()) + float(b.abs().max())
+    assert abs(float(amax_value(sl[0])) - bound) <= 1e-5 * bound and float(amax_value(sl[0])) >= float(y.abs().max())
+    bp = bound + float(padd.abs().max())
+    assert abs(float(amax_value(sl[1])) - bp) <= 1e-5 * bp and float(amax_value(sl[1])) >= float(yp.abs().max())
+    gy = torch.randn(rows, 256, device=dev) * 1e-3
+    ds0, dg0, db0 = ln256_backward(x, m, r, g, gy)
+    ds, dg, db = ln256_backward(x, m, r, g, gy, ds_amax=sl[2])
+    assert torch.equal(ds, ds0) and torch.equal(dg, dg0) and torch.equal(db, db0)
+    assert float(amax_value(sl[2])) == float(ds.abs().max())
