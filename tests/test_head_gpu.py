@@ -336,7 +336,7 @@ def test_head_full_size_configs_B_C(name, classes, n):
     l0 = run(11)
     for kern in ("msda_fwd_block", "msda_bwd_push_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost_fused",
                  "pair_planes_fwd", "pair_planes_dfeat", "pair_planes_dembed", "mask_loss_fwd", "mask_head_bits", "pool_features", "lsa_kernel", "gemm3", "gemm3_conv_kernel",
-                 "gemm3_nt_kernel<conv3x3>", "gemm3_tn_kernel<a16>", "gemm3_nt_kernel<b16>", "gn_cl_apply", "gn_cl_bwd_apply"):
+                 "gemm3_nt_kernel<conv3x3", "gemm3_tn_kernel<a16>", "gemm3_nt_kernel<b16>", "gn_cl_apply", "gn_cl_bwd_apply"):
         assert _lib.profile_get(kern)[0] > 0, kern
     _lib.profile_enable(False)
     assert len(l0) == 60 and all(np.isfinite(v) for v in l0.values()), l0
