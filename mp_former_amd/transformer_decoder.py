@@ -514,8 +514,19 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         working copies made by ONE grouped cast (_CastParams); the packed in-projections come back as
         (q, k, v) row-block tuples.  LayerNorm / embedding
         parameters stay fp32 modules (autocast runs them in fp32 anyway)."""
-        named = [(n, p) for n, p in self.named_parameters()
-                 if not (".norm." in n or n.startswith("decoder_norm") or n.startswith(("query_feat", "level_embed", "label_enc")))]
+        # (walking the module tree costs ~1 ms of launch-thread time per call: the (name, owner module, key) triples are kept and
+        # the parameters read from their owners each time, so a replaced parameter is still picked up)
+        where = self.__dict__.get("_gemm_param_slots")
+        if where is None:
+            where = []
+            for mname, m in self.named_modules():
+                for k in m._parameters:
+                    n = (mname + "." if mname else "") + k
+                    if m._parameters[k] is not None and not (".norm." in n or n.startswith("decoder_norm")
+                                                             or n.startswith(("query_feat", "level_embed", "label_enc"))):
+                        where.append((n, m, k))
+            self.__dict__["_gemm_param_slots"] = where
+        named = [(n, m._parameters[k]) for n, m, k in where]
         if torch.is_autocast_enabled() and named and named[0][1].is_cuda:
             chunks = [3 if "in_proj" in n else 1 for n, _ in named]
             cast = _CastParams.apply(torch.get_autocast_dtype("cuda"), chunks, *[p for _, p in named])
