@@ -81,8 +81,8 @@ def amax(t, out=None):
 
 
 def split_weights_grouped_h2(groups):
-    """``split_weights_grouped`` for the fp16 x 2 form: per group (planes [2, R, K] or [2, K, R] fp16, amax [1]) — two launches
-    for all groups (largest magnitudes, then the scaled split)."""
+    """``split_weights_grouped`` for the fp16 x 2 form: per group (planes [2, R, K] or [2, K, R] fp16, the operand's amax slot) —
+    two launches for all groups (largest magnitudes, then the scaled split); both orientations of a weight share one slot."""
     import numpy as np
     from ._h2d import upload
     dev = groups[0][0][0].device
@@ -128,8 +128,8 @@ def split_weights_grouped_h2(groups):
 
 
 def gemm3_h2(a, a_amax, planes, w_amax, bias=None, cin=None, cin2=None, gate=None, relu=False, out_amax=None):
-    """``gemm3`` in the fp16 x 2 form: planes / w_amax from ``split_weights_grouped_h2``, a_amax = max |a| (device, [1]);
-    out_amax (a zeroed slot or None) receives max |C|."""
+    """``gemm3`` in the fp16 x 2 form: planes / w_amax from ``split_weights_grouped_h2``, a_amax = the amax slot of ``a`` (the
+    largest |a|, or an upper bound within a few binades of it); out_amax (a zeroed slot or None) receives max |C|."""
     assert a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
     assert planes.dtype == torch.float16 and planes.is_contiguous() and planes.shape[0] == 2
     M, K = a.shape
