@@ -268,7 +268,7 @@ def test_gemm3_tn_h2_dynamic_range_and_special_values():
     w = torch.randn(N, K, device=dev) / 16
     b = torch.randn(N, device=dev)
     (pl, wam), = split_weights_grouped_h2([([w], False)])
-    for small, bound in ((2.0 ** -13, 1.5e-6), (2.0 ** -20, 2e-5)):
+    for small, bound in ((2.0 ** -13, 5e-7), (2.0 ** -20, 6e-6)):        # measured 1.6e-7 / 2.1e-6 (library fp32: 2.9e-7)
         a = torch.randn(M, K, device=dev)
         a[M // 2:] *= small
         got = gemm3_h2(a, amax(a), pl, wam)
