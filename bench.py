@@ -99,6 +99,15 @@ class TrainModel(torch.nn.Module):
             return self.head.total_loss(feats, targets)
 
 
+def _gemm3_traffic_ratios():
+    """{shape: HBM bytes from the PMC counters / algorithmic bytes} of the fp16 x 2 TN kernel (profiles/r03f_gemm3_traffic.json), or None"""
+    f = os.path.join(ROOT, "profiles", "r03f_gemm3_traffic.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    return {k: v["fp16x2"]["traffic_over_algorithmic"] for k, v in d.get("shapes", {}).items() if "fp16x2" in v}
+
+
 def grad_sync_groups(model):
     """Three flat buckets in the order in which their gradients complete: the head (80 MB), the backbone's res5 + res4
     (88 MB, 94 % of the backbone) and the rest (res3, res2, stem: 6 MB) — only the last one is exchanged after backward()."""
@@ -391,7 +400,10 @@ def main():
                          "peak": MFMA_BF16_PEAK_TFLOPS if g_mf >= g_hf else HBM_PEAK_GBPS,
                          "unit": "TFLOP/s" if g_mf >= g_hf else "GB/s",
                          "frac": round(max(g_mf, g_hf), 4), "traffic": None,
-                         "traffic_note": "algorithmic bytes = 4 (M K + M N) + 4 | 6 N K per launch (activations in, result out, weight planes); no PMC figure",
+                         "traffic_note": "algorithmic bytes = 4 (M K + M N) + 4 | 6 N K per launch (activations in, result out, weight planes); a family of "
+                                         "~90 launches of different shapes has no per-launch PMC figure — the calibrated FETCH_SIZE / WRITE_SIZE of its TN "
+                                         "kernel on the three encoder shapes (tools/pmc_gemm3_traffic.sh) is in tn_traffic_over_algorithmic",
+                         "tn_traffic_over_algorithmic": _gemm3_traffic_ratios(),
                          "launches_per_step": g_n / max(P, 1), "ms_per_step": round(g_ms / max(P, 1), 3),
                          "avg_us": round(g_ms * 1e3 / max(g_n, 1), 1),
                          "mfma_tflops_issued": round(g_issued / g_sec / 1e12, 1), "mfma_frac": round(g_mf, 4),

@@ -13,7 +13,10 @@ from tools.bench_gemm3 import timeit  # noqa: E402
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 M = 43008
-for (n, k) in ((256, 256), (1024, 256), (256, 1024)):
+SHAPES = ((256, 256), (1024, 256), (256, 1024))
+if os.environ.get("PROBE_SHAPE"):            # one shape only (tools/pmc_gemm3_traffic.sh)
+    SHAPES = (SHAPES[int(os.environ["PROBE_SHAPE"])],)
+for (n, k) in SHAPES:
     a = torch.randn(M, k, device=dev) * (1 + 9 * torch.rand(M, 1, device=dev))
     a[::7, ::13] *= 30
     w = torch.randn(n, k, device=dev) / k ** 0.5
