@@ -908,6 +908,8 @@ int mpf_upsample2x_cl_backward(const float* gy, int64_t gy_bs, int N, int Ht, in
  *   d_features[b][px][c] = sum_slot grad[slot][px] * embed_row(slot)[c]  (bf16, fully written; may be NULL) and
  *   d_embed (same row addressing as embed; dtype MPF_BF16 / MPF_F32; only paired rows are written; may be NULL)
  *   = sum_px grad[slot][px] * features[b][px][:]  (pixel-range partial sums reduced in a fixed order).  h*w % 128 == 0.
+ *   PRECONDITION: the embedding rows of the valid slots are distinct (a query is matched at most once per output:
+ *   matcher.py:149-156) — the d_embed row of a slot is WRITTEN, not accumulated; a row listed twice keeps the last write.
  */
 size_t mpf_match_cost_fused_workspace_bytes(int G, int Q, int Tmax, int P, int tsamp_rows);
 int mpf_match_cost_fused(const void* embed, const int64_t* embed_first, int64_t embed_row_stride, const void* features,

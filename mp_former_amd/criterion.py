@@ -302,6 +302,9 @@ class SetCriterion(nn.Module):
                 slot, s_first, s_count = self._slot_layout(bi, N)
                 g_offs = slot * hw
                 row_stride = np.full(n_pairs, fm.me.stride(1), dtype=np.int64)
+                if not dev_lsa:
+                    # mpf_pair_planes_backward WRITES the d_embed row of a slot (include/mpformer_hip.h): rows must be distinct
+                    assert len(np.unique(p_offs)) == n_pairs, "an embedding row is paired twice in one step"
             else:
                 g_offs = ms.grad_offsets(ti, bi, qi)
                 p_offs = ms.offsets(ti, bi, qi)

@@ -184,7 +184,6 @@ __global__ __launch_bounds__(256) void res_ln256_bwd_kernel(const float* __restr
     const float4 g = *reinterpret_cast<const float4*>(gamma + c);
     float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = make_float4(0.f, 0.f, 0.f, 0.f);
     const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-#pragma unroll 2
     for (int row = r0 + wave; row < r1; row += 4) {
         // all operands of the row requested together (G32 / G16 / GP compile-time: no load behind a branch)
         float4 dy = make_float4(0.f, 0.f, 0.f, 0.f);

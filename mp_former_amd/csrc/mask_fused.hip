@@ -315,8 +315,9 @@ __global__ __launch_bounds__(kT) void pair_planes_dembed_kernel(const __hip_bflo
 }
 
 // d E rows: fixed-order sum of the pixel-chunk partials, written (bf16 or fp32) to the embedding row of the slot's pair.
-// One workgroup per slot, thread = channel.  A row paired twice (never on the training path: a query is matched once
-// per output) would be overwritten, so `accumulate` adds into a zero-initialised gradient instead (identity row lists).
+// One workgroup per slot, thread = channel.  PRECONDITION (include/mpformer_hip.h, mpf_pair_planes_backward): the embedding
+// rows of the valid slots are DISTINCT — a query is matched at most once per output, so this holds by construction on the
+// training path and the python wrapper asserts it for host-built pair lists.  A row paired twice would be overwritten, not summed.
 template <typename OT>
 __global__ __launch_bounds__(kT) void pair_dembed_reduce_kernel(const float* __restrict__ part, int KS, int total_slots,
                                                                 const int64_t* __restrict__ row_off, const int32_t* __restrict__ pair_of_slot,
@@ -573,11 +574,12 @@ void launch_mc(dim3 grid, hipStream_t st, const __hip_bfloat16* embed, const int
                const int32_t* t_count, float* pqt, float* pq, int G, int Q, int Tmax, int P, int tpw)
 {
     const size_t lds = kOffTV + (size_t)kMP * 2 * TCH * 4;
-    static bool attr_set = false;          // > 64 KB of dynamic LDS needs the attribute (idempotent; benign race)
-    if (!attr_set && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&match_cost_fused_kernel<TCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    // > 64 KB of dynamic LDS needs the attribute; it is PER DEVICE, so it is set (and checked) on every launch like loss.hip does
+    if (lds > 48 * 1024 &&
+        mpf::check(hipFuncSetAttribute(reinterpret_cast<const void*>(&match_cost_fused_kernel<TCH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                   "match_cost_fused: hipFuncSetAttribute") != 0)
+        return;
     hipLaunchKernelGGL(match_cost_fused_kernel<TCH>, grid, dim3(kT), lds, st, embed, embed_first, ers, feat, feat_bs, gi, h, w, coords, tsamp,
                        t_first, t_count, pqt, pq, G, Q, Tmax, P, tpw);
 }

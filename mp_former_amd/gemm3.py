@@ -233,9 +233,11 @@ def gemm3_nt_grouped(pairs, rows_per_split, amax_pairs=None):
         assert g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.dim() == 2 and x.dim() == 2
         assert g.stride(1) == 1 and x.stride(1) == 1 and g.shape[0] == R and x.shape[0] == R and x.shape[1] % 4 == 0
         offs.append(tot)
-        tot += g.shape[1] * x.shape[1] + g.shape[1]
-    tot = (tot + 3) // 4 * 4          # (the alignment tail, if any, is summed too and never read)
-    part = torch.empty((ns, tot), dtype=torch.float32, device=dev)
+        # every item starts on a 16-byte boundary (float4 epilogue stores / float4 reduction); M_i % 4 != 0 leaves pad floats
+        tot += (g.shape[1] * x.shape[1] + g.shape[1] + 3) // 4 * 4
+    padded = any((g.shape[1] * x.shape[1] + g.shape[1]) % 4 for g, x in pairs)
+    # pad floats are summed by nt_reduce and never read back: zero them so that the reduction reads no uninitialised memory
+    part = (torch.zeros if padded else torch.empty)((ns, tot), dtype=torch.float32, device=dev)
     base = part.data_ptr()
     items = np.empty((len(pairs), 8 if amax_pairs is None else 10), dtype=np.int64)
     for i, ((g, x), o) in enumerate(zip(pairs, offs)):

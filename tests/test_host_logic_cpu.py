@@ -110,3 +110,25 @@ def test_prepare_targets_pads_masks_and_normalises_boxes():
     import pytest
     with pytest.raises(ValueError):
         prepare_targets(inst, (16, 16))
+
+
+def test_decoder_weight_cache_follows_the_module_tree():
+    """transformer_decoder._weights caches (name, owner, key) triples; a replaced parameter, a swapped submodule and a wrapped
+    submodule must all be picked up on the next call (the cache may not outlive the tree it was built from)."""
+    import torch.nn as nn
+    from mp_former_amd.transformer_decoder import MLP, MultiScaleMaskedTransformerDecoderMaskDN
+    dec = MultiScaleMaskedTransformerDecoderMaskDN(256, True, num_classes=5, hidden_dim=256, num_queries=4, nheads=8,
+                                                   dim_feedforward=64, dec_layers=2, pre_norm=False, mask_dim=256,
+                                                   enforce_input_project=False, dn_mode="points")
+    w0 = dec._weights()
+    assert w0["class_embed.weight"] is dec.class_embed.weight
+    assert "decoder_norm.weight" not in w0 and "query_feat.weight" not in w0
+    assert dec._weights()["mask_embed.layers.0.weight"] is dec.mask_embed.layers[0].weight          # cached path
+    dec.class_embed.weight = nn.Parameter(torch.zeros_like(dec.class_embed.weight))                 # replaced parameter
+    assert dec._weights()["class_embed.weight"] is dec.class_embed.weight
+    dec.mask_embed = MLP(256, 256, 256, 3)                                                          # swapped submodule
+    assert dec._weights()["mask_embed.layers.2.weight"] is dec.mask_embed.layers[2].weight
+    dec.transformer_ffn_layers[1].linear1 = nn.Linear(256, 64)                                      # swapped leaf, two levels down
+    assert dec._weights()["transformer_ffn_layers.1.linear1.weight"] is dec.transformer_ffn_layers[1].linear1.weight
+    dec.class_embed.register_parameter("extra", nn.Parameter(torch.zeros(3)))                       # added parameter
+    assert dec._weights()["class_embed.extra"] is dec.class_embed.extra

@@ -98,13 +98,19 @@ def test_pair_planes_forward_backward_on_gathered_rows(dev, N, R, H, W, counts):
     used = torch.zeros(N, R, dtype=torch.bool, device=dev)
     used[bi_t, rows_t] = True
     assert float(a.grad[~used].abs().max()) == 0.0
-    # deterministic: fixed-order reductions, no atomics
+    # deterministic: fixed-order reductions, no atomics — forward planes AND both gradients bit-equal run to run
+    g1a, g1b = a.grad.clone(), b.grad.clone()
     a.grad = None
     b.grad = None
     planes2 = mask_fused.PairPlanes.apply(a, b, row_off, i32[:n], i32[n:n + N], i32[n + N:], n, int(count.max()))
-    g1a, g1b = None, None
     planes2.backward(g)
     assert torch.equal(planes2, planes)
+    assert torch.equal(a.grad, g1a), "d_embed differs between two runs"
+    assert torch.equal(b.grad, g1b), "d_features differs between two runs"
+    # an image without pairs gets an exactly-zero feature gradient
+    for bimg in range(N):
+        if int(count[bimg]) == 0:
+            assert float(b.grad[bimg].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("L,N,Q,Qt,H,W,P,counts", [(2, 2, 10, 14, 16, 16, 112, (3, 5)), (3, 2, 100, 120, 64, 64, 1000, (17, 0)),
