@@ -64,7 +64,29 @@ def smooth_points(z, eps=1e-4):
 
 
 # ---- head fixtures (tests/golden/head_*.npz) ----------------------------------------------------
-HEAD_FIXTURES = ["head_small", "head_ragged", "head_nogt", "head_deep", "head_noise"]
+HEAD_FIXTURES = ["head_small", "head_ragged", "head_nogt", "head_deep", "head_noise", "head_cfgA"]
+
+
+def regenerate_draws(seed, spec):
+    """The reference's random draws of a fixture that stores a seed instead of the tensors (head_cfgA: ~40 MB of point
+    coordinates): torch's CPU generator is seeded and the same calls are made in the same order with the same shapes —
+    rand / rand_like are uniform_() on an empty tensor of that shape, randint_like(t, lo, hi) is random_(lo, hi).  The CPU
+    generator's stream is a function of (seed, call sequence) for a given torch build; the fixture's per-draw checksums
+    catch a build that draws differently."""
+    import torch
+    state = torch.get_rng_state()
+    try:
+        torch.manual_seed(int(seed))
+        out = []
+        for item in spec:
+            fn, shape, dtype = item[0], tuple(item[1]), getattr(torch, item[2])
+            if fn == "randint_like":
+                out.append(torch.empty(shape, dtype=dtype).random_(int(item[3]), int(item[4])))
+            else:
+                out.append(torch.empty(shape, dtype=dtype).uniform_())
+        return out
+    finally:
+        torch.set_rng_state(state)
 
 
 def load_head_fixture(name):
@@ -82,10 +104,24 @@ def load_head_fixture(name):
     feats = DP.det_features(cfg["N"], cfg["size"])
     targets = DP.det_targets(cfg["N"], cfg["size"], cfg["counts"], cfg["num_classes"])
     replay = []
-    for i in range(int(z["n_rng"])):
-        key = [k for k in z if k.startswith(f"rng_{i:03d}_")][0]
-        replay.append(torch.from_numpy(z[key]))
+    if "rng_spec" in z:
+        draws = regenerate_draws(cfg["draw_seed"], json.loads(str(z["rng_spec"])))
+        got = np.array([float(t.double().sum()) for t in draws])
+        np.testing.assert_allclose(got, z["rng_checksum"], rtol=0, atol=0,
+                                   err_msg="this torch build does not regenerate the fixture's random draws")
+        replay = [draws[i] for i in z["rng_kept"]]
+    else:
+        for i in range(int(z["n_rng"])):
+            key = [k for k in z if k.startswith(f"rng_{i:03d}_")][0]
+            replay.append(torch.from_numpy(z[key]))
     return z, cfg, pp, dp, feats, targets, replay
+
+
+def masks_view(t, cfg):
+    """pred_masks as the fixture stores them: whole, or every mask_step-th element (head_cfgA)"""
+    step = cfg.get("mask_step", 1)
+    a = t.detach().float().cpu()
+    return a.numpy() if step == 1 else a.reshape(-1)[::step].numpy()
 
 
 def fifo_to_tags(replay, cfg, use_dn, label_noise=True):

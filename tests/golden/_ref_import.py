@@ -230,6 +230,7 @@ class RandCapture:
 
     def __init__(self, replay=None):
         self.log = []
+        self.spec = []
         self.replay = list(replay) if replay is not None else None
         self._orig = {}
 
@@ -242,6 +243,13 @@ class RandCapture:
                 return t.clone()
             t = orig(*a, **k)
             self.log.append((name, t.detach().clone()))
+            # how to draw the same tensor again from the same generator state (conftest.regenerate_draws): rand / rand_like fill
+            # an empty tensor of that shape with uniform_(); randint_like(t, low, high) fills with random_(low, high)
+            if name == "randint_like":
+                lo, hi = (a[1], a[2]) if len(a) >= 3 else (k.get("low", 0), a[1] if len(a) >= 2 else k["high"])
+                self.spec.append([name, list(t.shape), str(t.dtype).split(".")[-1], int(lo), int(hi)])
+            else:
+                self.spec.append([name, list(t.shape), str(t.dtype).split(".")[-1]])
             return t
         return orig, f
 

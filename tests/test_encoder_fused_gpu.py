@@ -84,3 +84,104 @@ def test_fused_encoder_is_the_default_path():
         assert enc._fused_ok(srcs, [pe(s) for s in srcs])
     finally:
         os.environ.pop("MPF_FUSED_ENCODER", None)
+
+
+def _encoder_at_size(offset_weights):
+    """6-layer encoder at config B (levels 32^2 / 64^2 / 128^2, N = 2: R = 43 008 rows) with trained-like parameters: every
+    weight jittered away from its initial value, LayerNorm gamma x 8 on layer 2 (the amax slot of a LayerNorm output is an
+    upper bound from (gamma, beta): its slack costs the fp16 x 2 split mantissa bits exactly there)."""
+    from mp_former_amd import pixel_decoder as PD
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    enc = PD.MSDeformAttnTransformerEncoderOnly(d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024,
+                                                dropout=0.0, num_feature_levels=3).to(dev).train()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if "sampling_offsets.weight" in n:
+                p.normal_(0, 0.02) if offset_weights else p.zero_()
+            elif "sampling_offsets.bias" in n:
+                p.add_(torch.randn_like(p) * 0.5)
+            elif "attention_weights" in n:
+                p.normal_(0, 0.05)
+            elif "norm" in n:
+                p.add_(torch.randn_like(p) * 0.1)
+                if ".layers.2.norm" in n and n.endswith("weight"):
+                    p.mul_(8.0)
+            else:
+                p.add_(torch.randn_like(p) * 0.3 * float(p.std() if p.dim() > 1 else 0.02))
+    shapes, batch = ((32, 32), (64, 64), (128, 128)), 2
+    srcs = [torch.randn(batch, 256, h, w, device=dev) for h, w in shapes]
+    pe = PD.PositionEmbeddingSine(128, normalize=True)
+    pos = [pe(s) for s in srcs]
+    go = torch.randn(batch, sum(h * w for h, w in shapes), 256, device=dev)
+    return enc, srcs, pos, go
+
+
+def _run64(enc, srcs, pos, go):
+    import copy
+    enc64 = copy.deepcopy(enc).double()
+    enc64._shape_cache = {}
+    xs = [s.detach().double().requires_grad_(True) for s in srcs]
+    mem, _, _ = enc64(xs, [p.double() for p in pos])
+    mem.backward(go.double())
+    return mem.detach(), [x.grad for x in xs], {n: p.grad for n, p in enc64.named_parameters()}
+
+
+def _errs(a, ref):
+    a = a.double()
+    return float((a - ref).norm() / (ref.norm() + 1e-300)), float((a - ref).abs().max() / (ref.abs().max() + 1e-300))
+
+
+def test_fp16x2_encoder_at_config_B_size_against_library_fp32_and_fp64():
+    """the fp16 x 2 form of every encoder GEMM (forward, input gradients, weight gradients) on REAL
+    activation / gradient tensors at config-B size against the library-fp32 run of the layer-by-layer modules on the same
+    inputs, with an fp64 run of those modules as the referee.  The sampling geometry is pinned (sampling_offsets.weight = 0:
+    the offsets are the jittered biases, bit-identical in both fp32 pipelines), so no sample changes its bilinear cell
+    between them and the comparison measures GEMM arithmetic only; every other parameter is trained-like (jittered,
+    gamma x 8 on one layer).  Bars: every gradient tensor and the memory: relative L2 <= 2e-6, largest deviation <= 1e-5 of
+    the tensor's largest magnitude (fp16 x 2 vs library fp32); the memory (continuous in the sampling locations, so the
+    fp64 run referees it) no further from fp64 than 2 x the library pipeline + 2e-7."""
+    enc, srcs, pos, go = _encoder_at_size(offset_weights=False)
+    mL, gxL, gpL = _run(enc, srcs, pos, go, fused=False)
+    mH, gxH, gpH = _run(enc, srcs, pos, go, fused=True)
+    rows = {"memory": _errs(mH, mL.double())}
+    for i in range(len(srcs)):
+        rows[f"grad src[{i}]"] = _errs(gxH[i], gxL[i].double())
+    for n in gpL:
+        rows["grad " + n] = _errs(gpH[n], gpL[n].double())
+    worst = max(rows.items(), key=lambda kv: kv[1][0])
+    print(f"\nfp16x2 vs library fp32 at config B: worst rel-L2 {worst[1][0]:.2e} ({worst[0]}), "
+          f"median {sorted(v[0] for v in rows.values())[len(rows) // 2]:.2e}, worst relmax {max(v[1] for v in rows.values()):.2e}")
+    bad = {k: v for k, v in rows.items() if not (v[0] <= 2e-6 and v[1] <= 1e-5)}
+    assert not bad, f"fp16 x 2 encoder vs the library-fp32 modules (relL2, relmax): {bad}"
+    m64, gx64, gp64 = _run64(enc, srcs, pos, go)
+    eH, eL = _errs(mH, m64)[0], _errs(mL, m64)[0]
+    print(f"memory vs fp64: fp16x2 {eH:.2e}, library fp32 {eL:.2e}")
+    assert eH <= 2 * eL + 2e-7, (eH, eL)
+    # referee for the gradients as well — informative (a sample within 1e-8 of a pixel edge takes the other bilinear cell in
+    # fp64): the medians over the tensors must agree to a factor 2
+    med = lambda xs: sorted(xs)[len(xs) // 2]  # noqa: E731
+    mh = med([_errs(gpH[n], gp64[n])[0] for n in gp64])
+    ml = med([_errs(gpL[n], gp64[n])[0] for n in gp64])
+    print(f"parameter gradients vs fp64, median rel-L2: fp16x2 {mh:.2e}, library fp32 {ml:.2e}")
+    assert mh <= 2 * ml + 2e-7, (mh, ml)
+
+
+def test_fp16x2_encoder_at_config_B_size_with_learned_offsets():
+    """Same problem with non-zero sampling_offsets weights: now a sampling point within round-off of a pixel edge may take
+    the neighbouring bilinear cell in one pipeline (the value is continuous there, its location gradient is not), so single
+    contributions flip in ANY two fp32 pipelines; the bar is the library-fp32 pipeline's own distance from fp64."""
+    enc, srcs, pos, go = _encoder_at_size(offset_weights=True)
+    m64, gx64, gp64 = _run64(enc, srcs, pos, go)
+    mL, gxL, gpL = _run(enc, srcs, pos, go, fused=False)
+    mH, gxH, gpH = _run(enc, srcs, pos, go, fused=True)
+    assert _errs(mH, m64)[0] <= 2e-6, _errs(mH, m64)
+    rows = {}
+    for i in range(len(srcs)):
+        rows[f"grad src[{i}]"] = (_errs(gxH[i], gx64[i])[0], _errs(gxL[i], gx64[i])[0])
+    for n in gp64:
+        rows["grad " + n] = (_errs(gpH[n], gp64[n])[0], _errs(gpL[n], gp64[n])[0])
+    print("\nlearned offsets, rel-L2 vs fp64 (h2 | library): worst h2 %.2e, worst library %.2e" %
+          (max(v[0] for v in rows.values()), max(v[1] for v in rows.values())))
+    bad = {k: v for k, v in rows.items() if not v[0] <= 3 * v[1] + 2e-6}
+    assert not bad, f"fp16 x 2 encoder further from fp64 than 3 x the library-fp32 pipeline: {bad}"

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import HEAD_FIXTURES, fifo_to_tags, load_head_fixture
+from conftest import HEAD_FIXTURES, fifo_to_tags, load_head_fixture, masks_view
 
 pytestmark = pytest.mark.gpu
 
@@ -65,7 +65,7 @@ def test_head_matches_reference_golden_fp32(name, layout):
             np.testing.assert_allclose(_sub(t, 3), z[f"multi_scale_{i}_s3"], rtol=2e-3, atol=5e-4)
         out = h.predictor(ms, mf, None, {"tgt": targets, "scalar": 1, "noise_scale": cfg.get("noise_scale", 0.0)})
         np.testing.assert_allclose(out["pred_logits"].detach().cpu().numpy(), z["pred_logits"], rtol=5e-3, atol=2e-3)
-        np.testing.assert_allclose(out["pred_masks"].detach().cpu().numpy(), z["pred_masks"], rtol=5e-3, atol=5e-3)
+        np.testing.assert_allclose(masks_view(out["pred_masks"], cfg), z["pred_masks"], rtol=5e-3, atol=5e-3)
         for i, a in enumerate(out["aux_outputs"]):
             np.testing.assert_allclose(a["pred_logits"].detach().cpu().numpy(), z[f"aux{i}_pred_logits"], rtol=5e-3, atol=2e-3)
             np.testing.assert_allclose(_sub(a["pred_masks"], cfg.get("aux_step", 3)), z[f"aux{i}_pred_masks_s3"], rtol=5e-3, atol=5e-3)
@@ -208,7 +208,7 @@ def _rel_l2(got, want):
     return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
 
 
-@pytest.mark.parametrize("name", ["head_small", "head_ragged", "head_deep", "head_noise"])
+@pytest.mark.parametrize("name", ["head_small", "head_ragged", "head_deep", "head_noise", "head_cfgA"])
 def test_head_amp_path_matches_reference_golden(name):
     """The path bench.py times — bf16 autocast with every default switch (natively sequenced decoder layers, MFMA
     attention, small-row GEMMs, device-side assignment) — against the PINNED goldens of the imported reference (fp32),

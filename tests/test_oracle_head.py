@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import HEAD_FIXTURES, load_head_fixture
+from conftest import HEAD_FIXTURES, load_head_fixture, masks_view
 from oracle import head_ref as O
 
 
@@ -32,7 +32,7 @@ def test_head_forward_backward_matches_reference(name):
     out = O.decoder_forward(dp, ms, mf, targets, num_queries=cfg["num_queries"], num_classes=cfg["num_classes"],
                             dec_layers=cfg["dec_layers"], scalar=1, noise_scale=cfg.get("noise_scale", 0.0), label_noise_ratio=0.2, rng=rng)
     np.testing.assert_allclose(out["pred_logits"].detach().numpy(), z["pred_logits"], rtol=2e-3, atol=5e-4)
-    np.testing.assert_allclose(out["pred_masks"].detach().numpy(), z["pred_masks"], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(masks_view(out["pred_masks"], cfg), z["pred_masks"], rtol=2e-3, atol=2e-3)
     for i, a in enumerate(out["aux_outputs"]):
         np.testing.assert_allclose(a["pred_logits"].detach().numpy(), z[f"aux{i}_pred_logits"], rtol=2e-3, atol=5e-4)
         np.testing.assert_allclose(_sub(a["pred_masks"], cfg.get("aux_step", 3)), z[f"aux{i}_pred_masks_s3"], rtol=2e-3, atol=2e-3)
