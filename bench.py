@@ -195,6 +195,11 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=2, help="images per GPU")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra steps after the timed region with the launch log on (roofline block)")
+    ap.add_argument("--msda-offsets", choices=["init", "trained"], default="init",
+                    help="sampling_offsets of the six encoder layers: the module's initial pattern (ms_deform_attn.py:66-74), or "
+                         "'trained' = that pattern + N(0, 3 px) noise written into the biases and N(0, 0.02) weights (per-query scatter), "
+                         "the regime of a mid-training step")
+    ap.add_argument("--trained-steps", type=int, default=10, help="timed steps of the trained-offsets second number (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=1024)
     a = ap.parse_args()
@@ -220,6 +225,21 @@ def main():
         torch.backends.cudnn.benchmark = True
     model = TrainModel().to(dev).train()
     model.backbone.to(memory_format=torch.channels_last)
+
+    def trained_like_offsets():
+        """sampling offsets of a mid-training model: per-query scatter of sigma ~ 3 px (weights N(0, 0.18) on the O(1) query
+        features) around the initial pattern moved by N(0, 1 px) (biases).  A freshly built MSDeformAttn has zero offset weights,
+        i.e. every query of a head looks the same way: the regime in which bounding-box designs are at their best."""
+        g_ = torch.Generator(device="cpu").manual_seed(1234)          # the same on every rank: replicas stay identical
+        with torch.no_grad():
+            for n_, p_ in model.head.pixel_decoder.named_parameters():
+                if n_.endswith("sampling_offsets.bias"):
+                    p_.add_(torch.randn(p_.shape, generator=g_).to(dev))
+                elif n_.endswith("sampling_offsets.weight"):
+                    p_.copy_((torch.randn(p_.shape, generator=g_) * 0.18).to(dev))
+
+    if a.msda_offsets == "trained":
+        trained_like_offsets()
     # gradient exchange: three flat buckets (head | res5 + res4 | rest of the backbone), the first two launched from two
     # tensor hooks while the backbone back-propagates (mp_former_amd.dist.FlatGradSync); MPF_GRAD_SYNC=ddp selects torch's
     # DistributedDataParallel (per-parameter hooks, 25 MB buckets)
@@ -272,8 +292,8 @@ def main():
         n, ms, by = _lib.profile_get(name)
         return n, ms, by, _lib.profile_get_flops(name)
 
-    n_push, ms_push, _, _ = prof("msda_bwd_push")
-    n_pull, ms_pull, _, _ = prof("msda_bwd_pull")
+    n_push, ms_push, _, _ = prof("msda_bwd_bin")      # round 4: destination-side backward = bin + tile launches per call
+    n_pull, ms_pull, _, _ = prof("msda_bwd_tile")
     n_f, ms_f, by_f, _ = prof("msda_fwd")
     attn = {k: prof(k) for k in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "attn_bwd_q_kernel")}
     # gemm3 family: per group (launches, ms, fp32-equivalent flops 2 M N K, MFMA flops actually issued, algorithmic bytes).  An
@@ -298,7 +318,7 @@ def main():
     fused = {k: prof(k) for k in ("match_cost_fused_kernel", "pair_planes_fwd_kernel", "pair_planes_dfeat_kernel", "pair_planes_dembed_kernel")}
     _lib.profile_enable(False)
     S_tok = sum((a.size // s) ** 2 for s in (8, 16, 32))
-    n_b = n_pull                                   # one push + one pull launch per MSDA backward call
+    n_b = n_pull                                   # one bin + one tile launch per MSDA backward call
     ms_b = ms_push + ms_pull
     by_b = 1344.0 * 4 * S_tok * a.batch * n_b      # algorithmic bytes: SURVEY.md §8(d), fp32, per call
     # HBM traffic per call from rocprofv3 PMC passes (tools/pmc_msda.sh: FETCH_SIZE + WRITE_SIZE in separate passes, KiB
@@ -306,7 +326,7 @@ def main():
     # inside the process, so the file carries the hash of the kernel source it was measured on and is REFUSED (traffic =
     # null) when the kernels have changed since
     traffic, traffic_note = None, "no PMC file for this shape"
-    pmc_file = os.path.join(ROOT, "profiles", "r03_msda_bwd_pmc_configB_N2.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r04_msda_bwd_pmc_configB_N2.json")
     if a.size == 1024 and a.batch == 2 and os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
         src = os.path.join(ROOT, "mp_former_amd", "csrc", "msda_block.hip")
@@ -315,6 +335,20 @@ def main():
             traffic_note = pmc.get("note", "")
         else:
             traffic_note = "PMC file is older than csrc/msda_block.hip: refused"
+
+    # second number: the same step with trained-like sampling offsets (the headline above is iteration 0 of a
+    # freshly initialised model); 3 warm-up + 10 timed steps, launch log off
+    trained_ms = None
+    if a.msda_offsets == "init" and a.trained_steps > 0:
+        trained_like_offsets()
+        for i in range(3):
+            step(i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(a.trained_steps):
+            step(3 + i)
+        barrier()
+        trained_ms = mdist.max_over_ranks(time.perf_counter() - t1, dev) / a.trained_steps * 1e3
 
     # test-only (MPF_CHECK_SYNC=1): the ranks' parameters must have stayed identical through the averaged updates
     sync_spread = None
@@ -327,6 +361,12 @@ def main():
         allcs = torch.stack(allcs)
         sync_spread = float(((allcs.max(0).values - allcs.min(0).values) / scale).max())
 
+    # what the process group actually was (a SCALE line then proves RCCL saw N ranks): backend, ranks, RCCL's version
+    pg_info = None
+    if mdist.distributed():
+        pg_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "grad_sync": os.environ.get("MPF_GRAD_SYNC", "flat")}
+        if pg_info["backend"] == "nccl":
+            pg_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
     if rank == 0:
         ips = a.batch * world * a.steps / dt
         achieved = by_b / (ms_b * 1e-3) / 1e9 if ms_b > 0 else 0.0
@@ -388,7 +428,8 @@ def main():
                                    % (a.size, a.size),
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "tokens_per_image_S": S_tok, "final_loss": round(final_loss, 4),
-                       "roofline_steps": P, "process_group": (dist.get_backend() if mdist.distributed() else None)},
+                       "roofline_steps": P, "msda_offsets": a.msda_offsets,
+                       "process_group": pg_info},
             # the time-dominant native kernel family: the fp32 GEMMs of the pixel decoder as SIX bf16 MFMA products per fp32
             # product (three 8-bit-mantissa planes per operand, terms >= 2^-16 kept).  achieved = bf16 MFMA flops actually
             # issued per second; peak = the dense bf16 MFMA peak
@@ -416,11 +457,11 @@ def main():
                              gemm_entry("gemm3_nt_group_kernel", g_ng), gemm_entry("gemm3_conv_kernel", g_cv),
                              gemm_entry("gemm3_nt_kernel<conv3x3>", g_cw),
                              # the deformable-sampling kernels against the HBM roofline (north-star)
-                             {"kernel": "MSDA backward (msda_bwd_push_block_kernel + msda_bwd_pull_mfma_kernel, atomics-free)",
+                             {"kernel": "MSDA backward (msda_bwd_bin_kernel + msda_bwd_tile_kernel: destination-side, atomics-free, no bounding boxes)",
                               "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                               "launches": n_b, "avg_us": round(ms_b * 1e3 / max(n_b, 1), 1),
-                              "avg_us_push": round(ms_push * 1e3 / max(n_push, 1), 1), "avg_us_pull": round(ms_pull * 1e3 / max(n_pull, 1), 1),
+                              "avg_us_bin": round(ms_push * 1e3 / max(n_push, 1), 1), "avg_us_tile": round(ms_pull * 1e3 / max(n_pull, 1), 1),
                               "algorithmic_bytes_per_launch": round(by_b / max(n_b, 1))},
                              {"kernel": "msda_fwd_block_kernel", "launches": n_f, "avg_us": round(ms_f * 1e3 / max(n_f, 1), 1),
                               "bound": "hbm", "achieved": round(fwd_alg / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0, 1), "unit": "GB/s",
@@ -439,6 +480,10 @@ def main():
                              fused_entry("pair_planes_dembed_kernel", "features + gradient planes read")]},
             "cpu_baseline": None,
         }
+        if trained_ms is not None:
+            out["config"]["trained_like_offsets"] = {"ms_per_step": round(trained_ms, 2), "images_per_sec": round(a.batch * world / trained_ms * 1e3, 2),
+                                                     "steps": a.trained_steps,
+                                                     "what": "same step, sampling offsets scattered per query (sigma ~ 3 px): offset weights N(0, 0.18), biases + N(0, 1 px)"}
         if sync_spread is not None:
             out["config"]["param_sync_spread"] = sync_spread
         out["config"]["fp32_gemm"] = ("fp16 x 2 split: two pieces per operand, three MFMA products, power-of-two scale from the operand's "

@@ -989,6 +989,605 @@ __global__ __launch_bounds__(kT) void msda_bwd_spill_kernel(const float* __restr
 }
 
 // --------------------------------------------------------------------------------------------------
+// backward, third generation: "bin" + "tile"  (round 4)
+// --------------------------------------------------------------------------------------------------
+// The push kernel above is a QUERY-centric pass: per 8x8 query block and level it stages the bounding box of the block's
+// samples (halo re-reads: 246 MB for 137 algorithmic), reduces every sample against its four corner rows, and emits the
+// tile entries; the pull kernel then gathers loc / attn / grad_out per entry a second time.  With scattered (trained)
+// offsets the boxes no longer fit and push falls back to L2 gathers (146 -> 262 us).  Here the whole arithmetic moves to
+// the DESTINATION side, where it is independent of how far the queries look:
+//
+//   bin   (query blocks, no value / no reduction): decode every sample, count it into its <= 4 destination tiles
+//         (direct-mapped LDS counters, one global add per (workgroup, tile)), write the 4-byte entries; samples outside
+//         the map get their zero gradients here.  Raw form: delta[q, m] = <grad_out[q, m, :], out[q, m, :]> — the
+//         softmax-backward sum  sum_j a_j dA_j  of a (query, head) equals it, because out = sum_j a_j val_j — so the
+//         per-sample gradients need nothing from the other samples of their query.
+//   tile  (one wave per (4x4 tile, part), as pull): per chunk of 64 entries the grad_out rows of the chunk's queries are
+//         copied global -> LDS by DMA ONCE and serve both roles: (a) the hat-function MFMA product that produces
+//         grad_value (as pull), (b) for the samples the tile OWNS (top-left corner inside the tile; every sample has
+//         exactly one owner) the four corner dot products against the tile's 5x5 value neighbourhood (also in LDS),
+//         i.e. grad_attn / grad_loc (or their raw-projection form) — lane = sample walks the 32 channels, no cross-lane
+//         reduction.  Value rows are read 25/16 x, nothing depends on a bounding box.
+// per-wave LDS of the tile kernel: 64 grad_out rows | 25 value rows | per sample {a * hat_x(4 pixel columns), hat_y(4 pixel rows)}:
+// 4 waves x 13 440 B = 53 760 B = 42 LDS granules of 1 280 B -> exactly three workgroups in a CU's 160 KB
+constexpr int kTG = 8192, kTV = 3200, kTR = 2048;
+constexpr int kTWave = kTG + kTV + kTR;
+constexpr int kBDummy = 64;                              // lane-private dummy counters of the bin kernel
+
+template <int NL, bool RAW>
+__global__ __launch_bounds__(kT) void msda_bwd_bin_kernel(
+    const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out, const float* __restrict__ fwd_out,
+    float* __restrict__ grad_loc, float* __restrict__ grad_attn, float* __restrict__ grad_raw, float* __restrict__ delta,
+    int* __restrict__ tile_count, unsigned* __restrict__ entries, int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB g,
+    int nblocks, unsigned* __restrict__ stats)
+{
+    __shared__ int s_bb[kMaxL * 4];
+    __shared__ unsigned s_keys[kSlots];
+    __shared__ int s_cnt[kSlots + kBDummy];
+    __shared__ int s_base[kSlots];
+    constexpr int LP = NL * kP;
+    const int blk = xcd_index(nblocks);
+    if (blk >= nblocks) return;
+    BlockCtx c;
+    block_of(g, blk, c);
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < kMaxL * 4) s_bb[tid] = (tid & 2) ? INT_MIN : INT_MAX;
+    s_keys[tid] = kEmpty; s_cnt[tid] = 0;                      // kSlots == kT
+    if (tid < kBDummy) s_cnt[kSlots + tid] = 0;
+    const int qi_d = tid >> 2, p_d = tid & 3;
+    const int q_d = query_of(g, c, qi_d);
+    const int64_t gi0 = ((int64_t)(c.b * g.Lq + max(q_d, 0)) * g.M + c.m) * LP + p_d;
+    float2 xy[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) xy[l] = reinterpret_cast<const float2*>(loc)[gi0 + l * kP];
+    float dl = 0.f;
+    if (RAW) {
+        // delta of (query, head): the four lanes of a query take 8 channels each
+        const int64_t ro = ((int64_t)(c.b * g.Lq + max(q_d, 0)) * g.M + c.m) * kD + p_d * 8;
+        const f4v g0 = *reinterpret_cast<const f4v*>(grad_out + ro), g1 = *reinterpret_cast<const f4v*>(grad_out + ro + 4);
+        const f4v o0 = *reinterpret_cast<const f4v*>(fwd_out + ro), o1 = *reinterpret_cast<const f4v*>(fwd_out + ro + 4);
+        dl = g0.x * o0.x + g0.y * o0.y + g0.z * o0.z + g0.w * o0.w + g1.x * o1.x + g1.y * o1.y + g1.z * o1.z + g1.w * o1.w;
+        dl = quad_sum(dl);
+        if (p_d == 0 && q_d >= 0) delta[(int64_t)(c.b * g.Lq + q_d) * g.M + c.m] = dl;
+    }
+    __syncthreads();
+    const int bm = c.b * g.M + c.m;
+    int x0[NL], y0[NL];
+    unsigned in_mask = 0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const Dec d = decode(xy[l], g.H[l], g.W[l], q_d >= 0);
+        x0[l] = d.x0; y0[l] = d.y0;
+        in_mask |= d.in ? (1u << l) : 0u;
+        const int H = g.H[l], W = g.W[l];
+        const int xa = d.in ? max(d.x0, 0) : INT_MAX, ya = d.in ? max(d.y0, 0) : INT_MAX;
+        const int xb = d.in ? min(d.x0 + 1, W - 1) : INT_MIN, yb = d.in ? min(d.y0 + 1, H - 1) : INT_MIN;
+        const int x_lo = wave_min(xa), y_lo = wave_min(ya), x_hi = wave_max(xb), y_hi = wave_max(yb);
+        if (lane == 0) {
+            atomicMin(&s_bb[l * 4 + 0], x_lo); atomicMin(&s_bb[l * 4 + 1], y_lo);
+            atomicMax(&s_bb[l * 4 + 2], x_hi); atomicMax(&s_bb[l * 4 + 3], y_hi);
+        }
+    }
+    __syncthreads();
+    // destination tiles: as in the push kernel (direct-mapped counters over the tile grid under the block's boxes, the
+    // compare-and-swap hash when that grid has more than kSlots tiles); inactive adds go to a LANE-PRIVATE dummy counter
+    // (one shared dummy made ~60 % of a workgroup's 3 072 adds hit the same LDS address)
+    int tpk[NL][4];
+    int tbx[NL], tby[NL], tbw[NL], tof[NL + 1];
+    tof[0] = 0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int xmin = s_bb[l * 4 + 0], ymin = s_bb[l * 4 + 1], xmax = s_bb[l * 4 + 2], ymax = s_bb[l * 4 + 3];
+        const bool any = xmax >= xmin;
+        tbx[l] = xmin >> 2; tby[l] = ymin >> 2;
+        tbw[l] = any ? (xmax >> 2) - tbx[l] + 1 : 0;
+        tof[l + 1] = tof[l] + (any ? tbw[l] * ((ymax >> 2) - tby[l] + 1) : 0);
+    }
+    const bool direct = tof[NL] <= kSlots;             // workgroup-uniform
+    if (stats && tid == 0) atomicAdd(&stats[direct ? 4 : 5], 1u);
+    const int dummy = kSlots + (tid & (kBDummy - 1));
+    if (direct) {
+        int ret[NL][4];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const bool in = (in_mask >> l) & 1;
+            const int H = g.H[l], W = g.W[l];
+            const int txa = max(x0[l], 0) >> 2, txb = min(x0[l] + 1, W - 1) >> 2, tya = max(y0[l], 0) >> 2, tyb = min(y0[l] + 1, H - 1) >> 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ty = (e >> 1) ? tyb : tya, tx = (e & 1) ? txb : txa;
+                const bool act = in && !((e & 1) && txb == txa) && !((e >> 1) && tyb == tya);
+                const int slot = act ? tof[l] + (ty - tby[l]) * tbw[l] + (tx - tbx[l]) : dummy;
+                tpk[l][e] = act ? slot : -1;
+                ret[l][e] = atomicAdd(&s_cnt[slot], act ? 1 : 0);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tpk[l][e] = tpk[l][e] >= 0 ? ((tpk[l][e] << 16) | ret[l][e]) : -1;
+    } else {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const bool in = (in_mask >> l) & 1;
+            const int H = g.H[l], W = g.W[l];
+            const int txa = max(x0[l], 0) >> 2, txb = min(x0[l] + 1, W - 1) >> 2, tya = max(y0[l], 0) >> 2, tyb = min(y0[l] + 1, H - 1) >> 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ty = (e >> 1) ? tyb : tya, tx = (e & 1) ? txb : txa;
+                const bool act = in && !((e & 1) && txb == txa) && !((e >> 1) && tyb == tya);
+                tpk[l][e] = -1;
+                if (act) {
+                    const int key = bm * g.tiles_per_bm + g.tile_base[l] + ty * g.ntx[l] + tx;
+                    const int slot = hash_slot(s_keys, (unsigned)key);
+                    if (slot >= 0) {
+                        tpk[l][e] = (slot << 16) | atomicAdd(&s_cnt[slot], 1);
+                    } else {
+                        const int pos = atomicAdd(&tile_count[key], 1);
+                        const unsigned ent = ((unsigned)q_d << 2) | (unsigned)p_d;
+                        if (pos < g.cap[l]) {
+                            entries[(int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)(ty * g.ntx[l] + tx) * g.cap[l] + pos] = ent;
+                        } else {
+                            const int k = atomicAdd(ovf_count, 1);
+                            ovf[k] = make_uint2((unsigned)key, ent);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {   // one returning add per touched tile reserves the workgroup's run
+        int my_base = 0;
+        unsigned key = s_keys[tid];
+        if (direct) {
+            int l = 0;
+#pragma unroll
+            for (int k = 1; k < NL; ++k) l = tid >= tof[k] ? k : l;
+            int bx_ = tbx[0], by_ = tby[0], bw_ = tbw[0], of_ = 0, tb_ = g.tile_base[0], nt_ = g.ntx[0];
+#pragma unroll
+            for (int k = 1; k < NL; ++k)
+                if (l == k) { bx_ = tbx[k]; by_ = tby[k]; bw_ = tbw[k]; of_ = tof[k]; tb_ = g.tile_base[k]; nt_ = g.ntx[k]; }
+            const int rel = tid - of_, ry = rel / max(bw_, 1), rx = rel - ry * bw_;
+            key = tid < tof[NL] && s_cnt[tid] > 0 ? (unsigned)(bm * g.tiles_per_bm + tb_ + (by_ + ry) * nt_ + bx_ + rx) : kEmpty;
+        }
+        if (key != kEmpty) my_base = atomicAdd(&tile_count[key], s_cnt[tid]);
+        s_base[tid] = my_base;
+    }
+    __syncthreads();
+    if (q_d < 0) return;
+    const unsigned ent = ((unsigned)q_d << 2) | (unsigned)p_d;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const int txa = max(x0[l], 0) >> 2, txb = min(x0[l] + 1, g.W[l] - 1) >> 2;
+        const int tya = max(y0[l], 0) >> 2, tyb = min(y0[l] + 1, g.H[l] - 1) >> 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (tpk[l][e] < 0) continue;
+            const int local = ((e >> 1) ? tyb : tya) * g.ntx[l] + ((e & 1) ? txb : txa);
+            const int pos = s_base[tpk[l][e] >> 16] + (tpk[l][e] & 0xFFFF);
+            if (pos < g.cap[l]) {
+                entries[(int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)local * g.cap[l] + pos] = ent;
+            } else {
+                const int k = atomicAdd(ovf_count, 1);
+                ovf[k] = make_uint2((unsigned)(bm * g.tiles_per_bm + g.tile_base[l] + local), ent);
+            }
+        }
+        // a sample outside the map has no owner tile: its gradients (zero; raw form: the softmax term -a delta) are written here
+        if (!((in_mask >> l) & 1)) {
+            if (RAW) {
+                const int no = g.M * LP * 2, nr = g.M * LP * 3, lp = l * kP + p_d;
+                float* row = grad_raw + (int64_t)(c.b * g.Lq + q_d) * nr;
+                reinterpret_cast<float2*>(row + c.m * LP * 2)[lp] = make_float2(0.f, 0.f);
+                row[no + c.m * LP + lp] = -attn[gi0 + l * kP] * dl;
+            } else {
+                grad_attn[gi0 + l * kP] = 0.f;
+                reinterpret_cast<float2*>(grad_loc)[gi0 + l * kP] = make_float2(0.f, 0.f);
+            }
+        }
+    }
+}
+
+template <int NL, bool RAW, bool DBG>
+__global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
+    const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
+    const float* __restrict__ delta, const int* __restrict__ tile_count, const unsigned* __restrict__ entries,
+    float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn, float* __restrict__ grad_raw, GeomB g,
+    int nwg, unsigned loc_bytes, unsigned* __restrict__ stats, int ablate_, unsigned long long* __restrict__ dbg_)
+{
+    // DBG (benchmarking: mpf_set_option("msda_push_ablate2") / mpf_debug_set_buffer): the ablation switches and phase stamps
+    // exist only in that instantiation; the production kernel carries neither their branches nor their registers
+    const int ablate = DBG ? ablate_ : 0;
+    unsigned long long* const dbg = DBG ? dbg_ : nullptr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wg = xcd_index(nwg);
+    if (wg >= nwg) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // benchmarking only (mpf_debug_set_buffer): per wave [start, loop entry, sum wait, sum dots, sum operands, sum next-chunk, sum mfma, chunks]
+    unsigned long long t_prev = 0, t_acc[5] = {0, 0, 0, 0, 0}, t_start = 0, t_loop = 0;
+    int t_chunks = 0;
+    auto stamp = [&](int k) {
+        if (dbg) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (k >= 0) t_acc[k] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    if (dbg) { t_start = __builtin_amdgcn_s_memtime(); }
+    unsigned char* s_g = smem + wave * kTWave;            // [64 rows][128 B], 16-byte pieces XOR-swizzled by swz16(row)
+    unsigned char* s_v = s_g + kTG;                        // [25 rows][128 B]: the 5 x 5 value neighbourhood, same swizzle
+    float* s_w = reinterpret_cast<float*>(s_v + kTV);     // [64][8]: a * hat(column 0..3 of the tile), hat(row 0..3)
+    const int bm = wg / g.wg_per_bm;
+    const int r = wg - bm * g.wg_per_bm;
+    int slot, slot_base;
+    {
+        const int nslot = g.nband * NL;
+        const int base_k = g.band_wg_base[min(lane, nslot - 1)];
+        const unsigned long long ge = __ballot(lane < nslot && r >= base_k);
+        slot = __builtin_amdgcn_readfirstlane(__popcll(ge) - 1);
+        slot_base = __builtin_amdgcn_readlane(base_k, slot);
+    }
+    const int band = slot / NL, l = slot - band * NL;
+    const int wpt = sel(g.wpt, l);
+    const int W = sel(g.W, l), H = sel(g.H, l);
+    const int nty = (H + 3) >> 2, ntx = sel(g.ntx, l);
+    const int tile_base = sel(g.tile_base, l), cap = sel(g.cap, l), ent_base = sel(g.ent_base, l), start = sel(g.start, l);
+    const int row0 = band * nty / g.nband, row1 = (band + 1) * nty / g.nband;
+    const int unit = (r - slot_base) * kWP + wave;
+    const int part = unit % wpt, tb = unit / wpt;
+    const bool live = tb < (row1 - row0) * ntx;
+    const int ty = row0 + tb / ntx, tx = tb - (tb / ntx) * ntx;
+    const int local = live ? ty * ntx + tx : 0;
+    const int b = bm / g.M, m = bm - b * g.M;
+    constexpr int LP = NL * kP;
+    const int MLP = g.M * LP;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int kgrp = lane >> 4, j = lane & 15;
+    const unsigned* ent = entries + (int64_t)bm * g.ent_per_bm + ent_base + (int64_t)local * cap;   // this tile's run
+    // the first 64 slots of the run (cap >= 64) are requested together with the tile's count (one round trip instead of two);
+    // slots at or past the count hold stale entries and are replaced by the run's last entry once the count is known
+    unsigned e_first = ent[part * 64 + lane < cap ? part * 64 + lane : 0];
+    unsigned e_second = ent[(part + wpt) * 64 + lane < cap ? (part + wpt) * 64 + lane : 0];
+    int n = min(tile_count[bm * g.tiles_per_bm + tile_base + local], cap);
+    if (!live) n = 0;
+    const int nchunks = (n + 63) >> 6;
+    if (part < nchunks) {
+        // value neighbourhood: rows (4 ty + dy, 4 tx + dx), dy, dx = 0..4 (clamped to the image: a clamped row is only ever read
+        // for a corner that is masked out), LDS row = dy * 5 + dx; DMA, 8 rows per wave instruction, source-side swizzle
+        {
+            const float* vbase = value + ((int64_t)(b * g.S + start) * g.M + m) * kD;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = min(i * 8 + (lane >> 3), 24);
+                const int dy = rr / 5, dx = rr - dy * 5;
+                const int yy = min(ty * 4 + dy, H - 1), xx = min(tx * 4 + dx, W - 1);
+                const int piece = (lane & 7) ^ (((i * 8 + (lane >> 3)) >> 1) & 7);
+                const float* src = vbase + (int64_t)(yy * W + xx) * (g.M * kD) + piece * 4;
+                if (i < 3 || (lane >> 3) == 0)          // 25 rows: of the fourth piece only row 24 (masked lanes copy nothing)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(s_v + i * 1024), 16, 0, 0);
+            }
+        }
+        const float fx0 = (float)(tx * 4), fy0 = (float)(ty * 4);
+        const float fW = (float)W, fH = (float)H;
+        const __amdgpu_buffer_rsrc_t rs_loc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(loc), 0, loc_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_att = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(attn), 0, loc_bytes >> 1, 0x00020000);
+        const int gi_base = (b * g.Lq * g.M + m) * LP + l * kP;              // sample index of (q = 0, p = 0)
+        const float* w_x = s_w + kgrp * 8 + (j & 3);          // MFMA role: this lane's column / row weight of sample (4 s + kgrp)
+        const float* w_y = s_w + kgrp * 8 + 4 + (j >> 2);
+        const unsigned char* g_l = s_g + kgrp * 128 + (j & 1) * 8;
+        const int so_loc = gi_base * 8, so_att = gi_base * 4;
+        const float* go_base = grad_out + (int64_t)(b * g.Lq * g.M + m) * kD;
+        const int MD = g.M * kD;
+        // entries past the run's end repeat its last entry (with weight 0): every lane always has a real row to fetch
+        auto load_entry = [&](int c) { return ent[min(c * 64 + lane, n - 1)]; };
+        struct LA { float x, y, a, d; };
+        auto gather_la = [&](unsigned e) {
+            const int si = (int)(e >> 2) * MLP + (int)(e & 3);
+            const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(rs_loc, si * 8, so_loc, 0);
+            LA t;
+            t.x = __int_as_float(v2[0]); t.y = __int_as_float(v2[1]);
+            t.a = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_att, si * 4, so_att, 0));
+            t.d = RAW ? delta[(int64_t)(b * g.Lq + (int)(e >> 2)) * g.M + m] : 0.f;
+            return t;
+        };
+        auto synth_la = [&](unsigned e) {          // benchmarking (ablate & 8): no gathers, a location inside the tile
+            LA t;
+            t.x = ((float)(tx * 4) + 1.3f + (float)(e & 3) * 0.5f) / fW; t.y = ((float)(ty * 4) + 1.6f) / fH; t.a = 0.08f; t.d = 0.f;
+            return t;
+        };
+        // grad_out rows of a chunk -> LDS by DMA (row = entry index in the chunk; lane (row, slot) fetches piece slot ^ swizzle)
+        // Lane (r8 = lane >> 3) fetches a piece of rows r8, 8 + r8, ..., 56 + r8: the eight query indices it needs are passed
+        // through the row buffer itself (free at this point), transposed, so that they come back as two 16-byte reads.
+        auto dma_rows = [&](unsigned e, int cnt) {                                  // cnt = entries in the chunk (1..64)
+            int* s_q = reinterpret_cast<int*>(s_g);
+            s_q[(lane & 7) * 8 + (lane >> 3)] = (int)(e >> 2) * MD;                // entry (i * 8 + r8) -> slot r8 * 8 + i
+            const int4 qa = *reinterpret_cast<const int4*>(s_q + (lane >> 3) * 8), qb = *reinterpret_cast<const int4*>(s_q + (lane >> 3) * 8 + 4);
+            int qo[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            // BOTH reads must have returned before the first piece is requested: piece 0 lands on the scratch slots, and the
+            // compiler only waits for the operand it is about to use (lgkmcnt(3) with the second read still queued: measured
+            // as a memory fault once the LDS queue was busy enough)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (DBG && dbg) {       // debugging: row offsets outside grad_out are counted (slot after the per-wave records) and clamped
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if ((unsigned)qo[i] > (unsigned)((g.Lq - 1) * MD) || (qo[i] % MD) != 0) {
+                        atomicAdd(dbg + (size_t)nwg * kWP * 8, 1ull);
+                        dbg[(size_t)nwg * kWP * 8 + 1] = ((unsigned long long)(unsigned)qo[i] << 32) | (unsigned)cnt;
+                        dbg[(size_t)nwg * kWP * 8 + 2] = ((unsigned long long)(unsigned)e << 32) | (unsigned)(i * 64 + lane);
+                        qo[i] = 0;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rr = i * 8 + (lane >> 3);
+                const int piece = (lane & 7) ^ ((rr >> 1) & 7);
+                const float* src = go_base + qo[i] + piece * 4;
+                // piece i = rows 8 i .. 8 i + 7 — skipped when the run ends before it (its rows carry weight 0 and whatever
+                // finite data the buffer holds; operand groups past the end are skipped as well): two pieces at a time
+                if ((i & ~1) * 8 < cnt)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(s_g + i * 1024), 16, 0, 0);
+            }
+        };
+        // sample role (lane = entry): footprint, ownership, and the hat weights of the tile's four pixel columns / rows
+        // (zero outside the 2 x 2 footprint and for padding lanes) -> s_w
+        struct SR { int x0, y0; float lx, ly, a, d; unsigned e; bool owned; };
+        auto sample_role = [&](int c, unsigned e, const LA& t) {
+            SR s;
+            const bool valid = c * 64 + lane < n;
+            const float px = pix(t.x, W), py = pix(t.y, H);
+            const float xf = floorf(px), yf = floorf(py);
+            s.x0 = (int)xf; s.y0 = (int)yf; s.lx = px - xf; s.ly = py - yf; s.a = t.a; s.d = t.d; s.e = e;
+            s.owned = valid && ((max(s.x0, 0) >> 2) == tx) && ((max(s.y0, 0) >> 2) == ty);
+            const float av = valid ? t.a : 0.f;
+            const float dxp = fx0 - px, dyp = fy0 - py;
+            f4v wxa, wyv;
+            wxa.x = av * fmaxf(0.f, 1.f - fabsf(dxp)); wxa.y = av * fmaxf(0.f, 1.f - fabsf(dxp + 1.f));
+            wxa.z = av * fmaxf(0.f, 1.f - fabsf(dxp + 2.f)); wxa.w = av * fmaxf(0.f, 1.f - fabsf(dxp + 3.f));
+            wyv.x = fmaxf(0.f, 1.f - fabsf(dyp)); wyv.y = fmaxf(0.f, 1.f - fabsf(dyp + 1.f));
+            wyv.z = fmaxf(0.f, 1.f - fabsf(dyp + 2.f)); wyv.w = fmaxf(0.f, 1.f - fabsf(dyp + 3.f));
+            *reinterpret_cast<f4v*>(s_w + lane * 8) = wxa;
+            *reinterpret_cast<f4v*>(s_w + lane * 8 + 4) = wyv;
+            return s;
+        };
+        int c = part;
+        unsigned e_cur;
+        {   // padding slots of the speculative load -> the run's last entry (it is inside this wave's first 64 slots or later)
+            const int last = n - 1 - part * 64;                              // >= 0: part < nchunks
+            const unsigned e_last = __builtin_amdgcn_readlane(e_first, min(last, 63));
+            e_cur = lane <= last ? e_first : e_last;
+        }
+        unsigned e_nxt;
+        {   // same for the second chunk's slots (all of them padding when the run ends before it)
+            const int last = n - 1 - (part + wpt) * 64;
+            const unsigned e_last2 = last >= 0 ? __builtin_amdgcn_readlane(e_second, min(max(last, 0), 63))
+                                               : __builtin_amdgcn_readlane(e_cur, 63);
+            e_nxt = lane <= last ? e_second : e_last2;
+        }
+        LA la = (ablate & 8) ? synth_la(e_cur) : gather_la(e_cur);
+        if (!(ablate & 4)) dma_rows(e_cur, n - c * 64);
+        SR sr = sample_role(c, e_cur, la);
+        LA la_n = (ablate & 8) ? synth_la(e_nxt) : gather_la(e_nxt);
+        unsigned e_nn = load_entry(c + 2 * wpt);
+        if (dbg) { t_loop = __builtin_amdgcn_s_memtime(); t_prev = t_loop; }
+#pragma unroll 1
+        for (; c < nchunks; c += wpt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this chunk's rows (and the value neighbourhood) have landed
+            __builtin_amdgcn_wave_barrier();
+            stamp(0);
+            ++t_chunks;
+            if (sr.owned && !(ablate & 1)) {
+                const int x0 = sr.x0, y0 = sr.y0;
+                const bool x0v = x0 >= 0, x1v = x0 + 1 <= W - 1, y0v = y0 >= 0, y1v = y0 + 1 <= H - 1;
+                const int dx = x0 - tx * 4, dy = y0 - ty * 4;            // -1 .. 3
+                const int r0 = max(dy, 0) * 5 + max(dx, 0), r1 = max(dy, 0) * 5 + dx + 1, r2 = (dy + 1) * 5 + max(dx, 0), r3 = (dy + 1) * 5 + dx + 1;
+                const unsigned char* pg = s_g + lane * 128;
+                const unsigned char *p0 = s_v + r0 * 128, *p1 = s_v + r1 * 128, *p2 = s_v + r2 * 128, *p3 = s_v + r3 * 128;
+                const int sg = swz16(lane), s0 = swz16(r0), s1 = swz16(r1), s2 = swz16(r2), s3 = swz16(r3);
+                f2v t0 = {0.f, 0.f}, t1 = {0.f, 0.f}, t2 = {0.f, 0.f}, t3 = {0.f, 0.f};
+                // the five 16-byte pieces of channel octet k + 1 are requested before the FMAs of octet k (two register sets):
+                // a lane's waits for the LDS overlap its arithmetic instead of following each other
+                f4v gA, vA[4], gB, vB[4];
+                auto fetch1 = [&](int k, f4v& gg, f4v (&vv)[4]) {
+                    gg = *reinterpret_cast<const f4v*>(pg + ((k * 16) ^ sg));
+                    vv[0] = *reinterpret_cast<const f4v*>(p0 + ((k * 16) ^ s0));
+                    vv[1] = *reinterpret_cast<const f4v*>(p1 + ((k * 16) ^ s1));
+                    vv[2] = *reinterpret_cast<const f4v*>(p2 + ((k * 16) ^ s2));
+                    vv[3] = *reinterpret_cast<const f4v*>(p3 + ((k * 16) ^ s3));
+                };
+                auto fma1 = [&](const f4v& gg, const f4v (&vv)[4]) {
+                    t0 = __builtin_elementwise_fma(gg.xy, vv[0].xy, t0); t0 = __builtin_elementwise_fma(gg.zw, vv[0].zw, t0);
+                    t1 = __builtin_elementwise_fma(gg.xy, vv[1].xy, t1); t1 = __builtin_elementwise_fma(gg.zw, vv[1].zw, t1);
+                    t2 = __builtin_elementwise_fma(gg.xy, vv[2].xy, t2); t2 = __builtin_elementwise_fma(gg.zw, vv[2].zw, t2);
+                    t3 = __builtin_elementwise_fma(gg.xy, vv[3].xy, t3); t3 = __builtin_elementwise_fma(gg.zw, vv[3].zw, t3);
+                };
+                fetch1(0, gA, vA);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    fetch1(k + 1, gB, vB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fma1(gA, vA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 2 < 8) fetch1(k + 2, gA, vA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fma1(gB, vB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float s0f = (y0v && x0v) ? t0.x + t0.y : 0.f, s1f = (y0v && x1v) ? t1.x + t1.y : 0.f;
+                const float s2f = (y1v && x0v) ? t2.x + t2.y : 0.f, s3f = (y1v && x1v) ? t3.x + t3.y : 0.f;
+                const float lx = sr.lx, ly = sr.ly, hx = 1.f - lx, hy = 1.f - ly, a = sr.a;
+                const float ra = hy * (hx * s0f + lx * s1f) + ly * (hx * s2f + lx * s3f);
+                const float rx = fW * a * (hy * (s1f - s0f) + ly * (s3f - s2f));
+                const float ry = fH * a * (hx * (s2f - s0f) + lx * (s3f - s1f));
+                const int q = (int)(sr.e >> 2), p = (int)(sr.e & 3);
+                if (RAW) {
+                    const int no = g.M * LP * 2, nr = g.M * LP * 3, lp = l * kP + p;
+                    float* row = grad_raw + (int64_t)(b * g.Lq + q) * nr;
+                    reinterpret_cast<float2*>(row + m * LP * 2)[lp] = make_float2(rx / fW, ry / fH);
+                    row[no + m * LP + lp] = a * (ra - sr.d);
+                } else {
+                    const int64_t gi = ((int64_t)(b * g.Lq + q) * g.M + m) * LP + l * kP + p;
+                    grad_attn[gi] = ra;
+                    reinterpret_cast<float2*>(grad_loc)[gi] = make_float2(rx, ry);
+                }
+            }
+            // MFMA role, part 1: lane = (pixel j, sample kgrp of the step) takes the chunk's weights and its 8 bytes of every
+            // row into REGISTERS (steps in groups of four; a group past the run's end is skipped, steps past it inside a group
+            // carry weight 0) ...
+            stamp(1);
+            const int nst = (ablate & 2) ? 0 : min(16, (n - c * 64 + 3) >> 2);
+            float wv[16];
+            float2 gq[16];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (s4 * 4 < nst) {
+                    float wa[4], wb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int st = s4 * 4 + u;                       // rows 4 st + kgrp
+                        wa[u] = w_x[st * 32];
+                        wb[u] = w_y[st * 32];
+                        gq[st] = *reinterpret_cast<const float2*>(g_l + st * 512 + (((j >> 1) << 4) ^ swz16(st * 4 + kgrp)));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wv[s4 * 4 + u] = wa[u] * wb[u];
+                }
+            }
+            // ... so that the row buffer and the weight table are free for the NEXT chunk: its rows are requested and its sample
+            // role runs before this chunk's 32 MFMAs, which then cover the copy's round trip
+            if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(2); }
+            if (c + wpt < nchunks) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every LDS read of this chunk has returned
+                __builtin_amdgcn_wave_barrier();
+                // (sample role BEFORE the copy is requested: hipcc waits vmcnt(0) in front of any LDS access that follows an
+                // LDS-DMA, which would expose the copy's round trip right here instead of under the MFMAs)
+                sr = sample_role(c + wpt, e_nxt, la_n);
+                if (!(ablate & 4)) dma_rows(e_nxt, n - (c + wpt) * 64);
+                e_cur = e_nxt; e_nxt = e_nn;
+                la_n = (ablate & 8) ? synth_la(e_nxt) : gather_la(e_nxt);
+                e_nn = load_entry(c + 3 * wpt);
+            }
+            stamp(3);
+            // MFMA role, part 2
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (s4 * 4 < nst) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s4 * 4 + u], gq[s4 * 4 + u].x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s4 * 4 + u], gq[s4 * 4 + u].y, acc1, 0, 0, 0);
+                    }
+                }
+            }
+            if (dbg) { asm volatile("s_nop 0" :: "v"(acc0), "v"(acc1)); stamp(4); }
+        }
+    }
+    if (dbg && lane == 0) {
+        unsigned long long* o = dbg + (size_t)(wg * kWP + wave) * 8;
+        o[0] = t_start; o[1] = t_loop; o[2] = t_acc[0]; o[3] = t_acc[1]; o[4] = t_acc[2]; o[5] = t_acc[3]; o[6] = t_acc[4]; o[7] = (unsigned long long)t_chunks;
+    }
+    if (stats && lane == 0 && live && part == 0 && n > 0) atomicAdd(&stats[wpt > 1 ? 7 : 8], 1u);
+    if (wpt > 1) {
+        // tiles of coarse levels are split over the waves of the workgroup: partial tiles go through the wave's own row buffer
+        float* red = reinterpret_cast<float*>(s_g);
+        if (part > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { red[q * 64 + lane] = acc0[q]; red[(4 + q) * 64 + lane] = acc1[q]; }
+        }
+        __syncthreads();
+        if (part == 0) {
+            for (int k = 1; k < wpt; ++k) {
+                const float* o = reinterpret_cast<const float*>(smem + (wave + k) * kTWave);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc0[q] += o[q * 64 + lane]; acc1[q] += o[(4 + q) * 64 + lane]; }
+            }
+        }
+    }
+    if (!live || part != 0) return;
+    const int py_ = ty * 4 + kgrp;
+    if (py_ < H) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int px_ = tx * 4 + q;
+            if (px_ < W)
+                *reinterpret_cast<float2*>(grad_value + ((int64_t)(b * g.S + start + py_ * W + px_) * g.M + m) * kD + j * 2) =
+                    make_float2(acc0[q], acc1[q]);
+        }
+    }
+}
+
+// spill entries of the third generation: as msda_bwd_spill_kernel, plus the per-sample gradients of the entries whose tile OWNS
+// the sample (the tile kernel never saw them).  32 lanes per entry (lane = channel); correctness path.
+template <int NL, bool RAW>
+__global__ __launch_bounds__(kT) void msda_bwd_spill3_kernel(const float* __restrict__ value, const float* __restrict__ loc,
+                                                             const float* __restrict__ attn, const float* __restrict__ grad_out,
+                                                             const float* __restrict__ delta, const int* __restrict__ ovf_count,
+                                                             const uint2* __restrict__ ovf, float* __restrict__ grad_value,
+                                                             float* __restrict__ grad_loc, float* __restrict__ grad_attn,
+                                                             float* __restrict__ grad_raw, GeomB g, unsigned* __restrict__ stats)
+{
+    constexpr int LP = NL * kP;
+    const int n = *ovf_count;
+    const int c = threadIdx.x & 31;
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[6], (unsigned)n);
+    for (int i = blockIdx.x * (kT / 32) + (threadIdx.x >> 5); i < n; i += gridDim.x * (kT / 32)) {
+        const uint2 o = ovf[i];
+        const int key = (int)o.x, q = (int)(o.y >> 2), p = (int)(o.y & 3);
+        const int bm = key / g.tiles_per_bm;
+        int r = key - bm * g.tiles_per_bm, l = 0;
+#pragma unroll
+        for (int k = 1; k < NL; ++k) if (r >= g.tile_base[k]) l = k;
+        r -= g.tile_base[l];
+        const int ty = r / g.ntx[l], tx = r - ty * g.ntx[l];
+        const int b = bm / g.M, m = bm - b * g.M;
+        const int W = g.W[l], H = g.H[l];
+        const int64_t gi = ((int64_t)(b * g.Lq + q) * g.M + m) * LP + l * kP + p;
+        const float2 xy = reinterpret_cast<const float2*>(loc)[gi];
+        const float a = attn[gi];
+        const float x = pix(xy.x, W), y = pix(xy.y, H);
+        if (!(y > -1.f && x > -1.f && y < (float)H && x < (float)W)) continue;
+        const float gq = grad_out[((int64_t)(b * g.Lq + q) * g.M + m) * kD + c];
+        const float xf = floorf(x), yf = floorf(y);
+        const int x0 = (int)xf, y0 = (int)yf;
+        const bool owned = ((max(x0, 0) >> 2) == tx) && ((max(y0, 0) >> 2) == ty);
+        float sc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int px = x0 + (k & 1), py = y0 + (k >> 1);
+            const bool inimg = px >= 0 && py >= 0 && px <= W - 1 && py <= H - 1;
+            const int64_t vo = ((int64_t)(b * g.S + g.start[l] + (inimg ? py * W + px : 0)) * g.M + m) * kD + c;
+            float d = (owned && inimg) ? gq * value[vo] : 0.f;
+#pragma unroll
+            for (int s = 16; s >= 1; s >>= 1) d += __shfl_xor(d, s, 32);
+            sc[k] = d;
+            if (!inimg || px < tx * 4 || px > tx * 4 + 3 || py < ty * 4 || py > ty * 4 + 3) continue;
+            const float wgt = fmaxf(0.f, 1.f - fabsf((float)px - x)) * fmaxf(0.f, 1.f - fabsf((float)py - y)) * a;
+            atomicAdd(grad_value + vo, wgt * gq);
+        }
+        if (owned && c == 0) {
+            const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
+            const float ra = hy * (hx * sc[0] + lx * sc[1]) + ly * (hx * sc[2] + lx * sc[3]);
+            const float rx = (float)W * a * (hy * (sc[1] - sc[0]) + ly * (sc[3] - sc[2]));
+            const float ry = (float)H * a * (hx * (sc[2] - sc[0]) + lx * (sc[3] - sc[1]));
+            if (RAW) {
+                const int no = g.M * LP * 2, nr = g.M * LP * 3, lp = l * kP + p;
+                float* row = grad_raw + (int64_t)(b * g.Lq + q) * nr;
+                reinterpret_cast<float2*>(row + m * LP * 2)[lp] = make_float2(rx / (float)W, ry / (float)H);
+                row[no + m * LP + lp] = a * (ra - delta[(int64_t)(b * g.Lq + q) * g.M + m]);
+            } else {
+                grad_attn[gi] = ra;
+                reinterpret_cast<float2*>(grad_loc)[gi] = make_float2(rx, ry);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------------
 int g_region_rows = 217;      // forward: usable rows of the staged box (the buffer is rounded up to whole 32-row stage passes)
@@ -997,6 +1596,7 @@ int g_block_disable = 0;
 int g_fuse_prep = 1;        // mpf_set_option("msda_fuse_prep"): softmax / location arithmetic inside the forward kernel
 unsigned long long* g_dbg = nullptr;   // benchmarking only: s_memtime phase stamps of the push kernel, [workgroup][16]
 int g_push_ablate = 0;       // benchmarking only: 1 = no tile entries, 2 = no reduction, 4 = no box staging
+int g_bwd_gen = 3;           // mpf_set_option("msda_bwd_gen"): 3 = bin + tile kernels (round 4), 2 = push + pull (rounds 2-3)
 // tests only (mpf_set_option("msda_stats", 1) / mpf_msda_stats): which route every (workgroup, level) took.
 //   [0] forward: boxes staged in LDS   [1] forward: L2-gather fallback (box larger than the region)
 //   [2] push: boxes staged in LDS      [3] push: L2-gather fallback
@@ -1106,7 +1706,7 @@ hipError_t launch_fwd(const float* value, const float* loc, const float* attn, f
 }
 
 struct WsLayout {
-    size_t off_count, off_ovf_count, off_entries, off_ovf, total;
+    size_t off_count, off_ovf_count, off_entries, off_ovf, off_delta, total;
     int ntiles;
 };
 
@@ -1118,7 +1718,8 @@ WsLayout ws_layout(const GeomB& g)
     w.off_ovf_count = (size_t)w.ntiles * 4;
     w.off_entries = align256(w.off_ovf_count + 4);
     w.off_ovf = align256(w.off_entries + (size_t)g.N * g.M * g.ent_per_bm * 4);
-    w.total = w.off_ovf + (size_t)g.N * g.Lq * g.M * g.L * kP * 4 * 8;
+    w.off_delta = align256(w.off_ovf + (size_t)g.N * g.Lq * g.M * g.L * kP * 4 * 8);
+    w.total = w.off_delta + (size_t)g.N * g.Lq * g.M * 4;          // delta[q, m] of the raw form (third generation)
     return w;
 }
 
@@ -1150,6 +1751,60 @@ hipError_t launch_bwd(const float* value, const float* loc, const float* attn, c
                        gv, g, nwg, (unsigned)((size_t)g.N * g.Lq * g.M * LP * 8), (unsigned)((size_t)g.N * g.Lq * g.M * kD * 4), g_stats);
     mpf::prof_end("msda_bwd_pull_mfma_kernel", st, esz * ((double)g.N * g.Lq * g.M * kD + (double)g.N * g.S * g.M * kD));
     hipLaunchKernelGGL(msda_bwd_spill_kernel<NL>, dim3(64), dim3(kT), 0, st, loc, attn, go, ovf_count, ovf, gv, g, g_stats);
+    return hipGetLastError();
+}
+
+// third generation: memset -> bin -> tile -> spill3.  fwd_out (the forward result, [N, Lq, M * 32]) is needed by the raw form only.
+template <int NL>
+hipError_t launch_bwd3(const float* value, const float* loc, const float* attn, const float* go, const float* fwd_out, float* gv,
+                       float* gl, float* ga, float* graw, const GeomB& g, void* workspace, hipStream_t st)
+{
+    const WsLayout w = ws_layout(g);
+    char* ws = (char*)workspace;
+    int* tile_count = (int*)(ws + w.off_count);
+    int* ovf_count = (int*)(ws + w.off_ovf_count);
+    unsigned* entries = (unsigned*)(ws + w.off_entries);
+    uint2* ovf = (uint2*)(ws + w.off_ovf);
+    float* delta = (float*)(ws + w.off_delta);
+    hipError_t err = hipMemsetAsync(ws, 0, w.off_ovf_count + 4, st);
+    if (err != hipSuccess) return err;
+    const int nblocks = g.N * g.M * g.blocks_per_b;
+    const int grid = ((nblocks + 7) / 8) * 8;
+    constexpr int LP = NL * kP;
+    const double esz = 4.0;
+    const double n_samp = (double)g.N * g.Lq * g.M * LP, n_row = (double)g.N * g.Lq * g.M * kD;
+    mpf::prof_begin(st);
+    if (graw)
+        hipLaunchKernelGGL((msda_bwd_bin_kernel<NL, true>), dim3(grid), dim3(kT), 0, st, loc, attn, go, fwd_out, gl, ga, graw, delta, tile_count,
+                           entries, ovf_count, ovf, g, nblocks, g_stats);
+    else
+        hipLaunchKernelGGL((msda_bwd_bin_kernel<NL, false>), dim3(grid), dim3(kT), 0, st, loc, attn, go, fwd_out, gl, ga, graw, delta, tile_count,
+                           entries, ovf_count, ovf, g, nblocks, g_stats);
+    // algorithmic bytes of the pair (1344 e S N) are split as: bin = loc in; tile = the rest
+    mpf::prof_end("msda_bwd_bin_kernel", st, esz * n_samp * 2);
+    const int nwg = g.N * g.M * g.wg_per_bm;
+    const size_t lds = (size_t)kWP * kTWave;
+    const unsigned loc_bytes = (unsigned)((size_t)g.N * g.Lq * g.M * LP * 8);
+    mpf::prof_begin(st);
+    const dim3 tgrid(((nwg + 7) / 8) * 8);
+    if (g_push_ablate || g_dbg) {
+        if (graw)
+            hipLaunchKernelGGL((msda_bwd_tile_kernel<NL, true, true>), tgrid, dim3(kTP), lds, st, value, loc, attn, go, delta, tile_count,
+                               entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, g_push_ablate, g_dbg);
+        else
+            hipLaunchKernelGGL((msda_bwd_tile_kernel<NL, false, true>), tgrid, dim3(kTP), lds, st, value, loc, attn, go, delta, tile_count,
+                               entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, g_push_ablate, g_dbg);
+    } else if (graw)
+        hipLaunchKernelGGL((msda_bwd_tile_kernel<NL, true, false>), tgrid, dim3(kTP), lds, st, value, loc, attn, go, delta, tile_count,
+                           entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, 0, nullptr);
+    else
+        hipLaunchKernelGGL((msda_bwd_tile_kernel<NL, false, false>), tgrid, dim3(kTP), lds, st, value, loc, attn, go, delta, tile_count,
+                           entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, 0, nullptr);
+    mpf::prof_end("msda_bwd_tile_kernel", st, esz * ((double)g.N * g.S * g.M * kD * 2 + n_row + n_samp * 4));
+    if (graw)
+        hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, true>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, delta, ovf_count, ovf, gv, gl, ga, graw, g, g_stats);
+    else
+        hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, false>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, delta, ovf_count, ovf, gv, gl, ga, graw, g, g_stats);
     return hipGetLastError();
 }
 
@@ -1215,12 +1870,24 @@ size_t msda_block_workspace_bytes(const int64_t* host_shapes, int N, int M, int 
 
 int msda_block_backward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, const void* go, void* gv,
                         void* gl, void* ga, void* graw, int N, int S, int M, int D, int L, int Lq, int P, int dtype, void* workspace,
-                        size_t workspace_bytes, hipStream_t st)
+                        size_t workspace_bytes, hipStream_t st, const void* fwd_out)
 {
     if (!host_shapes || !block_ok(N, S, M, D, L, Lq, P, dtype)) return -1000;
     GeomB g;
     if (!build_geom(g, host_shapes, N, S, M, L, Lq)) return -1000;
     if (workspace_bytes < ws_layout(g).total) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: workspace too small");
+    if (g_bwd_gen == 3 && (!graw || fwd_out)) {
+        mpf::set_kernel("msda_bwd_block(bin+tile)");
+        hipError_t e3;
+        const float *v_ = (const float*)value, *l_ = (const float*)loc, *a_ = (const float*)attn, *g_ = (const float*)go, *o_ = (const float*)fwd_out;
+        switch (L) {
+            case 1: e3 = launch_bwd3<1>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
+            case 2: e3 = launch_bwd3<2>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
+            case 3: e3 = launch_bwd3<3>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
+            default: e3 = launch_bwd3<4>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
+        }
+        return mpf::check(e3, "msda_bwd_block(bin+tile)");
+    }
     mpf::set_kernel("msda_bwd_block(push+pull)");
     hipError_t err;
     switch (L) {
@@ -1247,6 +1914,11 @@ int set_block_option(const char* key, int v)
     if (!strcmp(key, "msda_block_disable")) { g_block_disable = v; return 0; }
     if (!strcmp(key, "msda_fuse_prep")) { g_fuse_prep = v; return 0; }
     if (!strcmp(key, "msda_push_ablate2")) { g_push_ablate = v; return 0; }
+    if (!strcmp(key, "msda_bwd_gen")) {
+        if (v != 2 && v != 3) return MPF_E_SHAPE;
+        g_bwd_gen = v;
+        return 0;
+    }
     if (!strcmp(key, "msda_stats")) {
         if (v && !g_stats) {
             if (hipMalloc((void**)&g_stats, kNStats * sizeof(unsigned)) != hipSuccess) { g_stats = nullptr; return MPF_E_SHAPE; }

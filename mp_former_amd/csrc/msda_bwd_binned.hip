@@ -581,7 +581,7 @@ static int backward_ws_impl(const void* value, const int64_t* host_spatial_shape
                             void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, void* grad_raw,
                             int batch, int spatial_size, int num_heads, int channels,
                             int num_levels, int num_query, int num_point, int dtype,
-                            void* workspace, size_t workspace_bytes, void* stream)
+                            void* workspace, size_t workspace_bytes, void* stream, const void* fwd_out = nullptr)
 {
     const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query, P = num_point;
     if (!value || !host_spatial_shapes || !sampling_loc || !attn_weight || !grad_output || !grad_value ||
@@ -592,7 +592,7 @@ static int backward_ws_impl(const void* value, const int64_t* host_spatial_shape
     {   // production path: spatially blocked push + MFMA pull (msda_block.hip); -1000 = not its shapes
         const int r = mpf::msda_block_backward(value, host_spatial_shapes, sampling_loc, attn_weight, grad_output, grad_value,
                                                grad_sampling_loc, grad_attn_weight, grad_raw, N, S, M, D, L, Lq, P, dtype, workspace,
-                                               workspace_bytes, (hipStream_t)stream);
+                                               workspace_bytes, (hipStream_t)stream, fwd_out);
         if (r != -1000) return r;
     }
     Geom g;
@@ -668,6 +668,21 @@ extern "C" int mpf_msda_backward_ws_raw(const void* value, const int64_t* host_s
     return backward_ws_impl(value, host_spatial_shapes, sampling_loc, attn_weight, grad_output, grad_value, nullptr, nullptr,
                             grad_raw, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, dtype,
                             workspace, workspace_bytes, stream);
+}
+
+// raw form with the forward result at hand (the module keeps it): the softmax-backward sum of a (query, head) is
+// <grad_output, output> of that (query, head), so the destination-side kernels (bin + tile, msda_block.hip) apply
+extern "C" int mpf_msda_backward_ws_raw_o(const void* value, const int64_t* host_spatial_shapes,
+                                          const void* sampling_loc, const void* attn_weight, const void* grad_output,
+                                          const void* output, void* grad_value, void* grad_raw,
+                                          int batch, int spatial_size, int num_heads, int channels,
+                                          int num_levels, int num_query, int num_point, int dtype,
+                                          void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!grad_raw || !output) return mpf::fail(MPF_E_NULL, "msda_backward_ws_raw_o: NULL grad_raw / output");
+    return backward_ws_impl(value, host_spatial_shapes, sampling_loc, attn_weight, grad_output, grad_value, nullptr, nullptr,
+                            grad_raw, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, dtype,
+                            workspace, workspace_bytes, stream, output);
 }
 
 namespace mpf {

@@ -185,7 +185,7 @@ class EncoderFn(Function):
             ds1, dp[8], dp[9] = ln256_backward(s1, mean1, rstd1, g1, dx1, ds_amax=ds1_am)
             dao = gemm3_h2(ds1, ds1_am, to, to_am)
             # d(raw): the softmax / offset-normaliser backward is the epilogue of the push kernel
-            gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C))
+            gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C), ao.view(N, S, C))
             dq = gemm3_h2(draw, amax(draw, draw_am), t288, t288_am)
             # dW288^T = q^T . draw (288 on the 96-wide tile side) + per-split column sums of draw: the
             # bias gradient and, summed per level, the level_embed gradient

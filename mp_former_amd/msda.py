@@ -208,8 +208,9 @@ def ms_deform_attn_forward_raw(value, spatial_shapes, level_start_index, raw, re
     return out, loc, attn
 
 
-def ms_deform_attn_backward_raw(value, host_shapes, sampling_loc, attn_weight, grad_output):
-    """-> (grad_value, grad_raw [N*Lq, M*L*P*3]) with the atomics-free kernels (mpf_msda_backward_ws_raw)."""
+def ms_deform_attn_backward_raw(value, host_shapes, sampling_loc, attn_weight, grad_output, output=None):
+    """-> (grad_value, grad_raw [N*Lq, M*L*P*3]) with the atomics-free kernels (mpf_msda_backward_ws_raw; with the forward
+    result ``output`` [N, Lq, M*32]: mpf_msda_backward_ws_raw_o, the destination-side bin + tile kernels)."""
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = sampling_loc.shape
     gv = torch.empty_like(value)
@@ -220,10 +221,17 @@ def ms_deform_attn_backward_raw(value, host_shapes, sampling_loc, attn_weight, g
         raise RuntimeError("mpf_msda_backward_workspace_bytes rejected the level geometry")
     ws = _workspace(value.device, need)
     with torch.cuda.device(value.device):
-        code = lib.mpf_msda_backward_ws_raw(
-            value.data_ptr(), host_shapes.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
-            grad_output.data_ptr(), gv.data_ptr(), graw.data_ptr(),
-            N, S, M, D, L, Lq, P, _DTYPES[value.dtype], ws.data_ptr(), ws.numel(), _stream(value))
+        if output is not None:
+            assert output.is_contiguous() and output.numel() == N * Lq * M * D and output.dtype == value.dtype
+            code = lib.mpf_msda_backward_ws_raw_o(
+                value.data_ptr(), host_shapes.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                grad_output.data_ptr(), output.data_ptr(), gv.data_ptr(), graw.data_ptr(),
+                N, S, M, D, L, Lq, P, _DTYPES[value.dtype], ws.data_ptr(), ws.numel(), _stream(value))
+        else:
+            code = lib.mpf_msda_backward_ws_raw(
+                value.data_ptr(), host_shapes.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+                grad_output.data_ptr(), gv.data_ptr(), graw.data_ptr(),
+                N, S, M, D, L, Lq, P, _DTYPES[value.dtype], ws.data_ptr(), ws.numel(), _stream(value))
     _lib.check(code, "mpf_msda_backward_ws_raw")
     return gv, graw
 

@@ -25,24 +25,48 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(1500)
-@pytest.mark.parametrize("grad_sync", ["flat", "ddp"])
-def test_bench_two_ranks_one_device(grad_sync):
+def _run_two_ranks(grad_sync, **extra_env):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MPF_FORCE_DIST"):
         env.pop(k, None)
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MPF_CHECK_SYNC="1", MPF_GRAD_SYNC=grad_sync)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MPF_CHECK_SYNC="1", MPF_GRAD_SYNC=grad_sync, **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_bench_world2_child.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--profile-steps", "1", "--size", "512", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1400)
+           "--profile-steps", "1", "--trained-steps", "1", "--size", "512", "--no-cpu-baseline"]
+    return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1400)
+
+
+@pytest.mark.timeout(1500)
+def test_late_gradient_after_an_early_launch_raises():
+    """the three-bucket route under MPF_CHECK_SYNC with a gradient injected after the head bucket's launch (from the res5
+    hook): FlatGradSync.finish must raise — a dropped gradient would otherwise only show as slowly diverging replicas"""
+    r = _run_two_ranks("flat", MPF_TEST_LATE_GRAD="1")
+    assert r.returncode != 0, "a late gradient went unnoticed"
+    assert "arrived after its all-reduce was launched" in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.timeout(1500)
+def test_missing_res3_hook_is_caught_up_by_finish():
+    """the second early launch never happens: finish() exchanges that bucket itself; replicas identical afterwards"""
+    r = _run_two_ranks("flat", MPF_TEST_NO_RES3_HOOK="1")
+    assert r.returncode == 0, f"bench.py --gpus 2 failed:\n{r.stdout[-2000:]}\n{r.stderr[-6000:]}"
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["config"]["param_sync_spread"] <= 1e-7, out["config"]["param_sync_spread"]
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("grad_sync", ["flat", "ddp"])
+def test_bench_two_ranks_one_device(grad_sync):
+    r = _run_two_ranks(grad_sync)
     assert r.returncode == 0, f"bench.py --gpus 2 failed:\n{r.stdout[-2000:]}\n{r.stderr[-6000:]}"
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, f"exactly one JSON line expected from rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
-    assert out["config"]["process_group"] == "gloo"
+    pg = out["config"]["process_group"]           # proves what the process group saw: backend, ranks, (RCCL version when nccl)
+    assert pg["backend"] == "gloo" and pg["world_size"] == 2 and pg["grad_sync"] == grad_sync and "rccl_version" not in pg
+    assert out["config"]["trained_like_offsets"]["ms_per_step"] > 0
     assert out["cpu_baseline"] is None                      # rank 0 at N = 1 only
     assert out["value"] > 0 and out["ms_per_step"] > 0
     loss = out["config"]["final_loss"]

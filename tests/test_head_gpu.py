@@ -85,7 +85,7 @@ def test_head_matches_reference_golden_fp32(name, layout):
         np.testing.assert_allclose(float(total), float(z["total_loss"]), rtol=5e-4)
         _lib.profile_enable(True)
         total.backward()
-        assert _lib.profile_get("msda_bwd_pull_mfma")[0] >= 1 and _lib.profile_get("gemm3_nt")[0] >= 1, _lib.last_kernel()
+        assert _lib.profile_get("msda_bwd_tile")[0] >= 1 and _lib.profile_get("gemm3_nt")[0] >= 1, _lib.last_kernel()
         _lib.profile_enable(False)
         for k, v in feats.items():
             n = float(z[f"grad_feat_{k}_norm"])
@@ -202,7 +202,7 @@ def test_head_baseline_config_shapes_run(name, size, chans, classes, queries, n)
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
     assert not [k for k, p in h.named_parameters() if p.grad is None]
-    for kern in ("msda_fwd_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost_fused", "pair_planes_fwd", "pair_planes_dfeat",
+    for kern in ("msda_fwd_block", "msda_bwd_tile", "attn_fwd_kernel", "attn_bwd_kv", "match_cost_fused", "pair_planes_fwd", "pair_planes_dfeat",
                  "pair_planes_dembed", "mask_loss_fwd", "mask_head_bits", "pool_features", "lsa_kernel"):
         assert _lib.profile_get(kern)[0] > 0, kern
     _lib.profile_enable(False)
@@ -263,7 +263,7 @@ def test_head_amp_path_matches_reference_golden(name):
         assert _lib.profile_get("pair_planes_fwd_kernel")[0] >= 1
         assert _lib.profile_get("pair_planes_dfeat_kernel")[0] == 1 and _lib.profile_get("pair_planes_dembed_kernel")[0] == 1
         for kern in ("attn_fwd_kernel", "attn_bwd_kv_kernel", "small_gemm", "small_gemm_group_kernel", "msda_fwd_block",
-                     "msda_bwd_pull_mfma", "gemm3", "gn_cl_apply", "gn_cl_bwd_apply"):
+                     "msda_bwd_tile", "gemm3", "gn_cl_apply", "gn_cl_bwd_apply"):
             assert _lib.profile_get(kern)[0] > 0, f"{kern} did not run on the AMP path"
     finally:
         _lib.profile_enable(False)
@@ -340,7 +340,7 @@ def test_head_full_size_configs_B_C(name, classes, n):
 
     _lib.profile_enable(True)
     l0 = run(11)
-    for kern in ("msda_fwd_block", "msda_bwd_push_block", "msda_bwd_pull_mfma", "attn_fwd_kernel", "attn_bwd_kv", "match_cost_fused",
+    for kern in ("msda_fwd_block", "msda_bwd_bin", "msda_bwd_tile", "attn_fwd_kernel", "attn_bwd_kv", "match_cost_fused",
                  "pair_planes_fwd", "pair_planes_dfeat", "pair_planes_dembed", "mask_loss_fwd", "mask_head_bits", "pool_features", "lsa_kernel", "gemm3", "gemm3_conv_kernel",
                  "gemm3_nt_kernel<conv3x3", "gemm3_tn_kernel<a16>", "gemm3_nt_kernel<b16>", "gn_cl_apply", "gn_cl_bwd_apply"):
         assert _lib.profile_get(kern)[0] > 0, kern

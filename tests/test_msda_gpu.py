@@ -33,6 +33,7 @@ def _reset_variants():
     _lib.set_option("msda_fwd_variant", 0)
     _lib.set_option("msda_bwd_variant", 0)
     _lib.set_option("msda_block_disable", 0)
+    _lib.set_option("msda_bwd_gen", 3)
     msda.BWD_MODE = "auto"
 
 
@@ -231,15 +232,19 @@ def _decoder_like_problem(lv, N, Lq=None, mode="near", spread=3.0, seed=0, M=8, 
                 attn=attn.numpy(), grad_out=go.numpy())
 
 
-def _run_with_stats(z, dev):
+def _run_with_stats(z, dev, gen=3):
+    """gen: backward generation of the blocked kernels — 3 = bin + tile (destination-side, round 4), 2 = push + pull"""
     from mp_former_amd import _lib
     _lib.set_option("msda_stats", 1)
+    _lib.set_option("msda_bwd_gen", gen)
     try:
         _lib.msda_stats(reset=True)
         res, kern = _run(z, torch.float32, dev)
         st = _lib.msda_stats(reset=True)
     finally:
         _lib.set_option("msda_stats", 0)
+        _lib.set_option("msda_bwd_gen", 3)
+    assert ("bin+tile" in kern[1]) == (gen == 3) or "block" not in kern[1], kern
     return res, kern, st
 
 
@@ -274,30 +279,32 @@ _ROUTE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("gen", [3, 2])
 @pytest.mark.parametrize("case", _ROUTE_CASES, ids=[c[0] for c in _ROUTE_CASES])
-def test_blocked_routes_vs_oracle(dev, oracle_msda, case):
+def test_blocked_routes_vs_oracle(dev, oracle_msda, case, gen):
     """The production kernels on every problem class they branch on (LDS-staged boxes vs L2 gathers, direct-mapped vs
     hashed tile counters, 1..4 levels, odd level sizes, queries that are not the pixels) against the C oracle, with the
     route counters proving which branch ran."""
     name, lv, N, Lq, mode, spread = case
     z = _decoder_like_problem(lv, N, Lq, mode, spread, seed=len(name))
-    res, (kf, kb), st = _run_with_stats(z, dev)
+    res, (kf, kb), st = _run_with_stats(z, dev, gen)
     assert "block" in kf and "block" in kb, (kf, kb)
     _assert_matches_oracle(z, res, oracle_msda)
     assert st["spill_entries"] == 0, st
     assert st["pull_split"] + st["pull_single"] > 0, st
     if mode == "near":
         # decoder-like offsets: the fine-query blocks fit the LDS region in both kernels
-        assert st["fwd_lds"] > 0 and st["push_lds"] > 0 and st["push_direct"] > 0, st
+        assert st["fwd_lds"] > 0 and st["push_direct"] > 0 and (gen == 3 or st["push_lds"] > 0), st
     if name == "queries_not_pixels_300":
-        assert st["fwd_gather"] > 0 and st["push_gather"] > 0, st      # 64 consecutive queries scattered over the maps
+        assert st["fwd_gather"] > 0 and (gen == 3 or st["push_gather"] > 0), st      # 64 consecutive queries scattered over the maps
 
 
-def test_blocked_spill_route_vs_oracle(dev, oracle_msda):
+@pytest.mark.parametrize("gen", [3, 2])
+def test_blocked_spill_route_vs_oracle(dev, oracle_msda, gen):
     """Every sample of the problem on one spot: the fixed-capacity runs of the four tiles around it overflow and the
     spill kernel applies the rest with atomics (ms_deform_im2col_cuda.cuh:92-164 semantics for any multiplicity)."""
     z = _decoder_like_problem([(8, 8), (16, 16), (32, 32)], 1, None, "point", seed=11)
-    res, (kf, kb), st = _run_with_stats(z, dev)
+    res, (kf, kb), st = _run_with_stats(z, dev, gen)
     assert "block" in kb, kb
     assert st["spill_entries"] > 0, st
     out, gv, gl, ga = res
@@ -305,6 +312,8 @@ def test_blocked_spill_route_vs_oracle(dev, oracle_msda):
     rgv, rgl, rga = oracle_msda.msda_backward(z["value"], z["shapes"], z["level_start"], z["loc"], z["attn"], z["grad_out"])
     np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(ga, rga, rtol=1e-4, atol=1e-4)
+    ok = smooth_points(z)
+    np.testing.assert_allclose(gl[ok], rgl[ok], rtol=1e-3, atol=5e-3)      # (gen 3: the spill kernel owns the overflowed samples' gradients)
     # 16 128 samples summed into four pixels per level: fp32 sums in a different order
     np.testing.assert_allclose(gv, rgv, rtol=2e-3, atol=2e-3 * float(np.abs(rgv).max()))
 
@@ -312,7 +321,8 @@ def test_blocked_spill_route_vs_oracle(dev, oracle_msda):
 @pytest.mark.parametrize("cfg,lv,N,mode,spread", [("B_init", [(32, 32), (64, 64), (128, 128)], 2, "init", 0.5),
                                                   ("B_spread3", [(32, 32), (64, 64), (128, 128)], 1, "near", 3.0),
                                                   ("E_init", [(32, 64), (64, 128), (128, 256)], 1, "init", 0.5)])
-def test_production_route_full_size_vs_oracle(dev, oracle_msda, cfg, lv, N, mode, spread):
+@pytest.mark.parametrize("gen", [3, 2])
+def test_production_route_full_size_vs_oracle(dev, oracle_msda, cfg, lv, N, mode, spread, gen):
     """BASELINE configs B (1024^2, N = 2) and E (1024x2048) with pixel-decoder-like offsets — the route the training
     step takes: boxes staged in LDS by DMA, inter-block halos, multi-band pull with split tiles — against the C oracle
     (grad_value in full, the per-query results on every 5th query to bound the oracle's run time).  "init" = the
@@ -320,15 +330,19 @@ def test_production_route_full_size_vs_oracle(dev, oracle_msda, cfg, lv, N, mode
     coarse queries looking into finer maps); N(0, 3 px) offsets make most boxes overflow it (L2 gathers), so both
     routes meet the oracle at size."""
     z = _decoder_like_problem(lv, N, None, mode, spread, seed=7)
-    res, (kf, kb), st = _run_with_stats(z, dev)
+    res, (kf, kb), st = _run_with_stats(z, dev, gen)
     assert "block" in kf and "block" in kb, (kf, kb)
     nblk = sum(((h + 7) // 8) * ((w + 7) // 8) for h, w in lv) * N * 8
-    assert st["fwd_lds"] + st["fwd_gather"] == 3 * nblk and st["push_lds"] + st["push_gather"] == 3 * nblk, (st, nblk)
-    if mode == "init":
-        assert st["fwd_lds"] > 0.8 * 3 * nblk and st["push_lds"] > 0.8 * 3 * nblk, (st, nblk)
+    assert st["fwd_lds"] + st["fwd_gather"] == 3 * nblk, (st, nblk)
+    if gen == 2:
+        assert st["push_lds"] + st["push_gather"] == 3 * nblk, (st, nblk)
     else:
-        assert st["fwd_lds"] > 0 and st["push_lds"] > 0 and st["fwd_gather"] > 0.5 * 3 * nblk, (st, nblk)
-    assert st["fwd_gather"] > 0 and st["push_gather"] > 0, st            # coarse queries looking into the finest map
+        assert st["push_lds"] + st["push_gather"] == 0, st               # the destination-side backward stages no boxes
+    if mode == "init":
+        assert st["fwd_lds"] > 0.8 * 3 * nblk and (gen == 3 or st["push_lds"] > 0.8 * 3 * nblk), (st, nblk)
+    else:
+        assert st["fwd_lds"] > 0 and (gen == 3 or st["push_lds"] > 0) and st["fwd_gather"] > 0.5 * 3 * nblk, (st, nblk)
+    assert st["fwd_gather"] > 0 and (gen == 3 or st["push_gather"] > 0), st            # coarse queries looking into the finest map
     assert st["push_direct"] > 0 and st["pull_split"] > 0 and st["pull_single"] > 0, st
     assert st["spill_entries"] == 0, st
     out, gv, gl, ga = res
@@ -336,7 +350,7 @@ def test_production_route_full_size_vs_oracle(dev, oracle_msda, cfg, lv, N, mode
     np.testing.assert_allclose(gv, rgv, rtol=1e-3, atol=1e-3)
     _assert_matches_oracle(z, res, oracle_msda, sub=slice(0, None, 5))
     # bit-reproducible: exclusive tile ownership, no atomics on this route
-    res2, _, _ = _run_with_stats(z, dev)
+    res2, _, _ = _run_with_stats(z, dev, gen)
     for a, b in zip(res, res2):
         if a is gv:
             continue                                                      # entry order inside a tile's run is not fixed
@@ -476,11 +490,15 @@ def test_raw_forms_match_softmax_plus_op(shapes, N, fuse_prep):
     torch.testing.assert_close(loc, l_ref.detach(), rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(out, o_ref.detach(), rtol=1e-4, atol=1e-4)
     o_ref.backward(go)
-    gv, graw = msda.ms_deform_attn_backward_raw(value, ss._mpf_host, loc, attn, go)
-    torch.testing.assert_close(gv, v.grad, rtol=1e-4, atol=1e-4)
     pts = ((loc.detach() * normalizer[None, None, None, :, None, :] - 0.5) % 1.0)
     smooth = ((pts > 1e-3) & (pts < 1 - 1e-3)).all(-1)                           # away from bilinear cell edges
-    g_off = graw[:, :no].view(N, S, M, L, P, 2)
     r_off = r.grad[:, :no].view(N, S, M, L, P, 2)
-    torch.testing.assert_close(g_off[smooth], r_off[smooth], rtol=2e-3, atol=2e-3)
-    torch.testing.assert_close(graw[:, no:], r.grad[:, no:], rtol=2e-3, atol=2e-3)
+    # without the forward result: push + pull (the softmax backward inside the push kernel); with it: bin + tile, where
+    # sum_j a_j dA_j of a (query, head) is <grad_out, out> (mpf_msda_backward_ws_raw_o)
+    for fwd_out in (None, out):
+        gv, graw = msda.ms_deform_attn_backward_raw(value, ss._mpf_host, loc, attn, go, fwd_out)
+        assert ("bin+tile" in _lib.last_kernel()) == (fwd_out is not None), _lib.last_kernel()
+        torch.testing.assert_close(gv, v.grad, rtol=1e-4, atol=1e-4)
+        g_off = graw[:, :no].view(N, S, M, L, P, 2)
+        torch.testing.assert_close(g_off[smooth], r_off[smooth], rtol=2e-3, atol=2e-3)
+        torch.testing.assert_close(graw[:, no:], r.grad[:, no:], rtol=2e-3, atol=2e-3)

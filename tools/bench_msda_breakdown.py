@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel breakdown of the MSDA forward + backward at config B, N=2 (in-library HIP-event profiler).
-usage: bench_msda_breakdown.py [init|trained|uniform] [cfg] [N]"""
+usage: bench_msda_breakdown.py [init|trained|uniform] [cfg] [N] [backward generation 2|3]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +10,8 @@ dev = torch.device("cuda:0")
 mode = sys.argv[1] if len(sys.argv) > 1 else "init"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "B"
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+if len(sys.argv) > 4:
+    _lib.set_option("msda_bwd_gen", int(sys.argv[4]))       # 3 = bin + tile (default), 2 = push + pull
 value, shapes, lsi, loc, attn, go, S = problem(cfg, N, dev, mode)
 ss = msda.attach_host_shapes(shapes, shapes.tolist(), lsi)
 for _ in range(3):
@@ -21,7 +23,7 @@ for _ in range(10):
     ms_deform_attn_forward(value, ss, lsi, loc, attn, 128)
     ms_deform_attn_backward(value, ss, lsi, loc, attn, go, 128)
 torch.cuda.synchronize()
-for k in ("msda_fwd", "msda_bwd_push", "msda_bwd_fill", "msda_bwd_pull"):
+for k in ("msda_fwd", "msda_bwd_push", "msda_bwd_fill", "msda_bwd_pull", "msda_bwd_bin", "msda_bwd_tile"):
     n, ms, by = _lib.profile_get(k)
     if n:
         print(f"{k:14s} launches={n} avg={ms / n * 1e3:8.1f} us")

@@ -2,8 +2,8 @@
 # HBM traffic of the MSDA kernels at config B, N = 2 from rocprofv3 PMC counters (separate passes, as the guide
 # prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass), with FETCH_SIZE / WRITE_SIZE calibrated on kernels that
 # move a known byte count in the same access shapes (tools/ubench/fetch_calib.hip).  Run on the GPU box from the repo
-# root; writes gpurun_out/${TAG}_msda_bwd_pmc_configB_N2.json (TAG defaults to r03; copy the file to profiles/).
-TAG=${1:-r03}
+# root; writes gpurun_out/${TAG}_msda_bwd_pmc_configB_N2.json (TAG defaults to r04; copy the file to profiles/).
+TAG=${1:-r04}
 export PMC_TAG=$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -47,7 +47,8 @@ for k, v in cal.items():
     else:
         factors[k] = EXPECT / (v["FETCH_SIZE"] * 1024.0)
 # dominant read shape per kernel: 128-B rows fetched as 8 lanes x 16 B (forward, push) or 16 lanes x 8 B (pull)
-shape = {"msda_fwd_block_kernel": "calib_rows16", "msda_bwd_push_block_kernel": "calib_rows16", "msda_bwd_pull_mfma_kernel": "calib_rows8"}
+shape = {"msda_fwd_block_kernel": "calib_rows16", "msda_bwd_push_block_kernel": "calib_rows16", "msda_bwd_pull_mfma_kernel": "calib_rows8",
+         "msda_bwd_bin_kernel": "calib_stream16", "msda_bwd_tile_kernel": "calib_rows16"}
 import os
 out = {"config": "B (1024x1024: S = 21504), N = 2, init-like offsets (tools/bench_msda_breakdown.py init)",
        "calibration": "tools/ubench/fetch_calib.hip built and run in this call: kernels that move a known 512 MiB in the access shapes of the MSDA kernels",
@@ -70,8 +71,8 @@ for k, v in msda.items():
         total += rd + wr
 out["hbm_bytes_per_call"] = round(total)
 out["algorithmic_bytes_per_call"] = 1344 * 4 * 21504 * 2
-out["note"] = ("FETCH_SIZE x read_factor + WRITE_SIZE x write_factor of push + pull (+ spill); factors from tools/ubench/fetch_calib "
+out["note"] = ("FETCH_SIZE x read_factor + WRITE_SIZE x write_factor of the backward kernels (bin + tile + spill3; push + pull before round 4); factors from tools/ubench/fetch_calib "
                "(known 512 MiB per launch in the kernels' access shapes)")
-json.dump(out, open("gpurun_out/%s_msda_bwd_pmc_configB_N2.json" % os.environ.get("PMC_TAG", "r03"), "w"), indent=1)
+json.dump(out, open("gpurun_out/%s_msda_bwd_pmc_configB_N2.json" % os.environ.get("PMC_TAG", "r04"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
