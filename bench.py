@@ -89,14 +89,21 @@ class TrainModel(torch.nn.Module):
     # were created last, so autograd runs all of them before the first backbone node), "res3" = res5 and res4 are done too
     grad_ready_hooks = None
 
+    # mp_former_amd.graphs.GraphedTrunk (backbone + pixel decoder as HIP graphs) or None = every launch issued eagerly
+    trunk = None
+
     def forward(self, images, targets):
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            feats = self.backbone(images.contiguous(memory_format=torch.channels_last))
+            pd_out = None
+            if self.trunk is not None and torch.is_grad_enabled():
+                feats, pd_out = self.trunk(images)
+            else:
+                feats = self.backbone(images.contiguous(memory_format=torch.channels_last))
             if self.grad_ready_hooks and torch.is_grad_enabled():
                 for name, cb in self.grad_ready_hooks.items():
                     if feats[name].requires_grad:
                         feats[name].register_hook(lambda g, cb=cb: cb())     # (returns None: the gradient is unchanged)
-            return self.head.total_loss(feats, targets)
+            return self.head.total_loss(feats, targets, pd_out)
 
 
 def _gemm3_traffic_ratios():
@@ -200,6 +207,11 @@ def main():
                          "'trained' = that pattern + N(0, 3 px) noise written into the biases and N(0, 0.02) weights (per-query scatter), "
                          "the regime of a mid-training step")
     ap.add_argument("--trained-steps", type=int, default=10, help="timed steps of the trained-offsets second number (0 = skip)")
+    ap.add_argument("--graphs", type=int, default=int(os.environ.get("MPF_GRAPHS", "0")),
+                    help="1: backbone + pixel decoder (fixed shapes) replayed as HIP graphs (mp_former_amd/graphs.py); 0 (default): every "
+                         "launch eager.  Measured on MI355X / ROCm 7.2 (round 4): the replays take the launch thread from 21.6 to ~8 ms per "
+                         "step but cost the GPU 4-7 us per graph node (dependent dispatches inside a replay) = +2.5 ms over the ~850 "
+                         "captured launches: 23.8 -> 26.3 ms/step while the eager step is GPU-bound")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=1024)
     a = ap.parse_args()
@@ -252,6 +264,21 @@ def main():
         ddp = mdist.wrap_ddp(model, [dev_index])
     opt = build_optimizer(model)
     batches = [synth_batch(a.batch, a.size, 80, 1000 * rank + i, dev) for i in range(4)]
+    # the static part of the step (backbone + pixel decoder: fixed shapes at the fixed crop) as HIP graphs: three replays
+    # forward, three backward per step instead of ~850 launches.  Captured in-process before the warm-up; a failed capture
+    # falls back to the eager path and says so in the JSON line.
+    graphs_note = "off (--graphs 0: measured slower on ROCm 7.2 — 4-7 us of GPU time per replayed node; DESIGN.md section 5)"
+    trunk = None
+    if a.graphs:
+        try:
+            from mp_former_amd.graphs import GraphedTrunk
+            trunk = GraphedTrunk(model.backbone, model.head.pixel_decoder, batches[0][0], pieces=os.environ.get("MPF_GRAPH_PIECES", "abc"))
+            graphs_note = "backbone (2 pieces) + pixel decoder: forward and backward replayed (torch.cuda.make_graphed_callables)"
+        except Exception as e:                                  # noqa: BLE001 — any capture failure: run eagerly, report it
+            graphs_note = f"capture failed, eager: {type(e).__name__}: {str(e)[:200]}"
+            trunk = None
+            torch.cuda.synchronize()
+    model.trunk = trunk
 
     def step(i):
         images, targets = batches[i % len(batches)]
@@ -283,10 +310,12 @@ def main():
     # ---- roofline block: a few MORE steps with the in-library launch log on (HIP events recorded on the launch stream
     # around every native kernel; outside the timed region, so the headline does not pay for the event records) --------
     P = a.profile_steps
+    model.trunk = None                       # the launch log records nothing inside a graph replay: these steps run eagerly
     _lib.profile_enable(True)
     for i in range(P):
         step(a.warmup + a.steps + i)
     barrier()
+    model.trunk = trunk
 
     def prof(name):
         n, ms, by = _lib.profile_get(name)
@@ -428,7 +457,7 @@ def main():
                                    % (a.size, a.size),
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "tokens_per_image_S": S_tok, "final_loss": round(final_loss, 4),
-                       "roofline_steps": P, "msda_offsets": a.msda_offsets,
+                       "roofline_steps": P, "msda_offsets": a.msda_offsets, "hip_graphs": graphs_note,
                        "process_group": pg_info},
             # the time-dominant native kernel family: the fp32 GEMMs of the pixel decoder as SIX bf16 MFMA products per fp32
             # product (three 8-bit-mantissa planes per operand, terms >= 2^-16 kept).  achieved = bf16 MFMA flops actually

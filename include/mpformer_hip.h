@@ -816,6 +816,14 @@ int mpf_bias_act(const void* x, const float* bias, const void* res, void* y, int
                  int relu, void* stream);
 
 /*
+ * Small host -> device table (item lists of the grouped launches) through the kernel-argument segment: `nbytes` (multiple
+ * of 4) from host memory to device memory on `stream`, 3 968 bytes per launch, no staging buffer — capturable in a HIP
+ * graph (the node carries the bytes), and cheaper for the launch thread than a pinned-memory copy.  (No reference
+ * counterpart: the reference builds such tensors with torch.tensor(..., device=...), a synchronising copy.)
+ */
+int mpf_upload_small(const void* host_src, void* device_dst, int64_t nbytes, void* stream);
+
+/*
  * Post-norm residual block of the decoder layers (mask2former_transformer_decoder.py:42-52, :100-112,
  * :165-169: tgt = LayerNorm(tgt + tgt2)) for 256 channels, one pass:
  *   s = x + t;  y = (s - mean) * rstd * gamma + beta      x fp32 [rows,256]; t fp32/bf16 or NULL

@@ -10,6 +10,12 @@ import numpy as np
 import torch
 
 
+# tables up to this size travel as kernel arguments (mpf_upload_small: <= 3 968 bytes per launch): no staging memory, one
+# launch per 3.9 KB, and a HIP graph that captures the launch carries the bytes (the item tables of the grouped launches
+# in the backbone / pixel decoder are functions of pointers that are fixed inside a graph's memory pool)
+SMALL_BYTES = 2 * 3968
+
+
 def upload(data, device, dtype=None):
     """numpy array / python list / CPU tensor -> device tensor, asynchronously."""
     t = torch.from_numpy(data) if isinstance(data, np.ndarray) else torch.as_tensor(data)
@@ -17,6 +23,16 @@ def upload(data, device, dtype=None):
         t = t.to(dtype)
     if t.device.type != "cpu":
         return t.to(device)
-    if torch.device(device).type != "cuda":
+    device = torch.device(device)
+    if device.type != "cuda":
         return t.to(device)
+    nbytes = t.numel() * t.element_size()
+    if 0 < nbytes <= SMALL_BYTES and nbytes % 4 == 0:
+        from . import _lib
+        t = t.contiguous()
+        out = torch.empty(t.shape, dtype=t.dtype, device=device)
+        with torch.cuda.device(device):
+            code = _lib.lib().mpf_upload_small(t.data_ptr(), out.data_ptr(), nbytes, torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(code, "mpf_upload_small")
+        return out
     return t.pin_memory().to(device, non_blocking=True)

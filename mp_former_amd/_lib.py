@@ -113,6 +113,7 @@ SIGNATURES = {
     "mpf_mask_loss_finalize": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),
     "mpf_mask_loss_finalize_backward": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),
     "mpf_bias_act": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
+    "mpf_upload_small": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_vp]),
     "mpf_res_ln256_forward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
                                        _c_vp, _c_int, _c_vp, _c_vp]),
     "mpf_res_ln256_forward_b": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,
@@ -224,3 +225,29 @@ def profile_get(name_substr):
     check(lib().mpf_profile_get(name_substr.encode(), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)),
           "mpf_profile_get")
     return n.value, ms.value, by.value
+
+
+# ---- workspace scopes -------------------------------------------------------------------------------------------------------
+# The python mirrors keep grow-on-demand scratch buffers per device (MSDA entry runs, GroupNorm / LayerNorm partials, decoder
+# scratch).  A HIP graph bakes the address of the buffer it was captured with: if eager code later asks the same cache for more
+# bytes, the old buffer is freed and every replay writes through a dangling pointer (measured: memory fault in the first
+# step after capturing the pixel decoder).  Code that is being captured therefore runs inside ``workspace_scope(name)``, which
+# is part of every cache key: buffers baked into a graph are private to it and never resized by anyone else.
+_WS_SCOPE = [""]
+
+
+def ws_scope():
+    return _WS_SCOPE[-1]
+
+
+class workspace_scope:
+    def __init__(self, name):
+        self.name = str(name)
+
+    def __enter__(self):
+        _WS_SCOPE.append(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        _WS_SCOPE.pop()
+        return False

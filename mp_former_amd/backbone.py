@@ -203,7 +203,8 @@ class ResNet50(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
-    def _fold_group(self, pairs, dtype):
+    @staticmethod
+    def _fold_group(pairs, dtype):
         """Fold + cast the conv weights of one stage in grouped launches.  One group per stage (not one for
         the whole network) so that, in backward, the stage's weight gradients become ready as soon as
         the stage has been back-propagated and DDP can start all-reducing them under the earlier stages."""
@@ -213,18 +214,29 @@ class ResNet50(nn.Module):
         return [(w, b_) for w, (_, b_) in zip(ws, sb)]
 
     def forward(self, x):
-        dtype = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled() and x.is_cuda) else None
-        stem = self._fold_group([(self.stem_conv, self.stem_norm)], dtype)
-        x = conv_bn(self.stem_conv, self.stem_norm, x, stem[0])
+        return self.forward_stages(x, self.stage_names, stem=True)
+
+    def forward_stages(self, x, names, stem=False):
+        """The stem (optional) and the named consecutive stages: {name: feature map}.  forward() is the whole chain; the
+        HIP-graph trunk (mp_former_amd/graphs.py) captures it in two pieces so that the gradient exchange can start between them."""
+        return run_stages(x, [(n, getattr(self, n)) for n in names], (self.stem_conv, self.stem_norm) if stem else None)
+
+
+def run_stages(x, stages, stem=None):
+    """stem = (conv, norm) or None; stages = [(name, nn.Sequential of Bottlenecks)] -> {name: feature map}"""
+    dtype = torch.get_autocast_dtype("cuda") if (torch.is_autocast_enabled() and x.is_cuda) else None
+    if stem is not None:
+        st = ResNet50._fold_group([stem], dtype)
+        x = conv_bn(stem[0], stem[1], x, st[0])
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
-        out = {}
-        for name in self.stage_names:
-            blocks = list(getattr(self, name))
-            folded = self._fold_group([p for b in blocks for p in b.pairs()], dtype)
-            k = 0
-            for b in blocks:
-                n = len(b.pairs())
-                x = b(x, folded[k:k + n])
-                k += n
-            out[name] = x
-        return out
+    out = {}
+    for name, stage in stages:
+        blocks = list(stage)
+        folded = ResNet50._fold_group([p for b in blocks for p in b.pairs()], dtype)
+        k = 0
+        for b in blocks:
+            n = len(b.pairs())
+            x = b(x, folded[k:k + n])
+            k += n
+        out[name] = x
+    return out

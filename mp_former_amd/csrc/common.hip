@@ -98,6 +98,36 @@ extern "C" int mpf_profile_get_flops(const char* name_substr, double* total_flop
     return 0;
 }
 
+// ---- small host -> device tables through the KERNEL ARGUMENT segment ------------------------------------------
+// The grouped launches take device tables of (pointer, size, ...) items.  Uploading one through pinned staging memory
+// costs the launch thread an allocator round trip + an asynchronous copy and cannot be captured in a HIP graph (the
+// staging block is recycled).  Here the bytes travel BY VALUE as a kernel argument (<= kUpPayload per launch) and a
+// one-workgroup kernel stores them: one launch, no staging memory, and a captured graph node carries the table itself.
+namespace {
+constexpr int kUpPayload = 3968;          // bytes per launch (the kernel argument segment is 4 KB)
+struct UpPayload { uint32_t w[kUpPayload / 4]; };
+__global__ __launch_bounds__(256) void upload_small_kernel(UpPayload p, uint32_t* __restrict__ dst, int nwords)
+{
+    for (int i = threadIdx.x; i < nwords; i += 256) dst[i] = p.w[i];
+}
+}  // namespace
+
+extern "C" int mpf_upload_small(const void* host_src, void* device_dst, int64_t nbytes, void* stream)
+{
+    if (nbytes == 0) return 0;
+    if (!host_src || !device_dst) return mpf::fail(MPF_E_NULL, "upload_small: NULL buffer");
+    if (nbytes < 0 || (nbytes & 3) || ((uintptr_t)device_dst & 3)) return mpf::fail(MPF_E_SHAPE, "upload_small: size / destination must be multiples of 4 bytes");
+    const unsigned char* src = static_cast<const unsigned char*>(host_src);
+    unsigned char* dst = static_cast<unsigned char*>(device_dst);
+    for (int64_t off = 0; off < nbytes; off += kUpPayload) {
+        const int n = (int)((nbytes - off) < kUpPayload ? (nbytes - off) : kUpPayload);
+        UpPayload p;
+        memcpy(p.w, src + off, (size_t)n);
+        hipLaunchKernelGGL(upload_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p, reinterpret_cast<uint32_t*>(dst + off), n / 4);
+    }
+    return mpf::check(hipGetLastError(), "mpf_upload_small");
+}
+
 extern "C" int mpf_abi_version(void) { return 1; }
 extern "C" const char* mpf_last_error(void) { return t_err; }
 extern "C" const char* mpf_last_kernel(void) { return g_kernel.load(std::memory_order_relaxed); }

@@ -1705,6 +1705,21 @@ hipError_t launch_fwd(const float* value, const float* loc, const float* attn, f
     return hipGetLastError();
 }
 
+// zero-fill of the tile counters as a KERNEL (not hipMemsetAsync): a captured HIP graph replays a kernel node faithfully; the
+// runtime's memset node of this odd byte count did not (replays of the captured pixel-decoder backward ran the bin / tile /
+// spill kernels on stale counters: memory faults) — and the launch is cheaper for the launch thread than the memset call
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, int nwords)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nwords) p[i] = 0u;
+}
+inline hipError_t zero_counters(void* ws, size_t bytes, hipStream_t st)
+{
+    const int nwords = (int)((bytes + 3) / 4);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((nwords + 255) / 256), dim3(256), 0, st, (unsigned*)ws, nwords);
+    return hipGetLastError();
+}
+
 struct WsLayout {
     size_t off_count, off_ovf_count, off_entries, off_ovf, off_delta, total;
     int ntiles;
@@ -1733,7 +1748,7 @@ hipError_t launch_bwd(const float* value, const float* loc, const float* attn, c
     int* ovf_count = (int*)(ws + w.off_ovf_count);
     unsigned* entries = (unsigned*)(ws + w.off_entries);
     uint2* ovf = (uint2*)(ws + w.off_ovf);
-    hipError_t err = hipMemsetAsync(ws, 0, w.off_ovf_count + 4, st);
+    hipError_t err = zero_counters(ws, w.off_ovf_count + 4, st);
     if (err != hipSuccess) return err;
     const int nblocks = g.N * g.M * g.blocks_per_b;
     const int grid = ((nblocks + 7) / 8) * 8;
@@ -1766,7 +1781,7 @@ hipError_t launch_bwd3(const float* value, const float* loc, const float* attn, 
     unsigned* entries = (unsigned*)(ws + w.off_entries);
     uint2* ovf = (uint2*)(ws + w.off_ovf);
     float* delta = (float*)(ws + w.off_delta);
-    hipError_t err = hipMemsetAsync(ws, 0, w.off_ovf_count + 4, st);
+    hipError_t err = zero_counters(ws, w.off_ovf_count + 4, st);
     if (err != hipSuccess) return err;
     const int nblocks = g.N * g.M * g.blocks_per_b;
     const int grid = ((nblocks + 7) / 8) * 8;

@@ -57,10 +57,11 @@ def _lib_checked():
 
 
 def _scratch_buf(device, nbytes):
-    w = _scratch.get(device)
+    key = (device, _lib.ws_scope())
+    w = _scratch.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
-        _scratch[device] = w
+        _scratch[key] = w
     return w
 
 

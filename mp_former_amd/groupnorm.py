@@ -18,10 +18,11 @@ _ws = {}
 
 
 def _workspace(device, nbytes):
-    w = _ws.get(device)
+    key = (device, _lib.ws_scope())          # (a graph capture has its own buffers: _lib.workspace_scope)
+    w = _ws.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(int(nbytes) + 1024, dtype=torch.uint8, device=device)
-        _ws[device] = w
+        _ws[key] = w
     return w
 
 

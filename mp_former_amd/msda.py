@@ -135,10 +135,11 @@ def _host_shapes(spatial_shapes, level_start_index):
 
 
 def _workspace(device, nbytes):
-    ws = _workspaces.get(device)
+    key = (device, _lib.ws_scope())          # (a graph capture has its own buffers: _lib.workspace_scope)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
+        _workspaces[key] = ws
     return ws
 
 

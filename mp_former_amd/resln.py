@@ -115,10 +115,11 @@ def ln256_backward(s, mean, rstd, gamma, gy, gy_plus=None, ds_amax=None):
     dgb = torch.empty((2, 256), dtype=torch.float32, device=s.device)
     lib = _lib.lib()
     nbytes = lib.mpf_res_ln256_backward_workspace_bytes(s.shape[0])
-    ws = _ln_ws.get(s.device)
+    wkey = (s.device, _lib.ws_scope())          # (a graph capture has its own buffers: _lib.workspace_scope)
+    ws = _ln_ws.get(wkey)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes) + 1024, dtype=torch.uint8, device=s.device)
-        _ln_ws[s.device] = ws
+        _ln_ws[wkey] = ws
     with torch.cuda.device(s.device):
         # parameter gradients through per-workgroup partials, fixed order (no atomics, no zero-fill)
         args = (s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), gy.data_ptr(), None,
@@ -139,7 +140,7 @@ _det_ws_cache = {}
 def _det_ws(dev, nbytes):
     """workspace of mpf_res_ln256_backward_det per (device, stream): its ticket word is zero between calls (zero-initialised
     here, reset by every launch), so it is shared by all LayerNorms that run on that stream"""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, _lib.ws_scope())
     ws = _det_ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros(int(nbytes) + 4096, dtype=torch.uint8, device=dev)
