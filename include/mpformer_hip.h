@@ -740,6 +740,12 @@ int mpf_gemm3_nt_reduce_levels(const float* c_part, int64_t c_numel, const float
  * rows like mpf_gemm3_nt (same kernel, one bf16 product instead of six), partials summed in a fixed
  * order by a second launch.  workspace: mpf_gemm_nt_bf16_workspace_bytes(...) bytes.
  */
+/* Forward / input-gradient GEMM of the same layers (and of the batched prediction heads, :1859-1870): c[M, N] (bf16, row
+ * stride ldc) = a[M, K] . b[N, K]^T (+ bias[N]), all bf16, fp32 accumulation, one rounding (the library's rounding points);
+ * both operands contraction-contiguous (the input gradient passes the transposed weight).  K % 32 == 0; lda, ldb % 8 == 0,
+ * ldc % 4 == 0; a, b 16-byte aligned, c 8-byte aligned; M, N arbitrary. */
+int mpf_tall_gemm_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const void* bias, void* c, int64_t ldc, int M, int N,
+                       int K, void* stream);
 size_t mpf_gemm_nt_bf16_workspace_bytes(int R, int Mdim, int Ndim, int rows_per_split);
 int mpf_gemm_nt_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* c_out, void* csum_out, int R, int Mdim,
                      int Ndim, int rows_per_split, void* workspace, size_t workspace_bytes, void* stream);

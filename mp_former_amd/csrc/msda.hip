@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_tiled_f32(
         const float* vbase = value + j * V;
         float* gvbase = grad_value + j * V;
         const int it0 = g * LP;
-#pragma unroll 2
+// (no unroll request: the trip count is data-dependent and hipcc rejects the hint)
         for (int lp = 0; lp < LP; ++lp) {
             const int4 off = s_off[it0 + lp];
             const float4 f = s_f[it0 + lp];

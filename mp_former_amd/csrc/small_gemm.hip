@@ -383,3 +383,115 @@ extern "C" int mpf_small_gemm_bf16_group(const MpfSmallGemmItem* items, int n_it
     mpf::prof_end("small_gemm_group_kernel", st, bytes);
     return mpf::check(hipGetLastError(), "small_gemm_group launch");
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 Linear with MANY rows: the key / value in-projections of the cross-attention (nn.MultiheadAttention in_proj of
+// mask2former_transformer_decoder.py:100-112; rows = S_l * N = 2 048 .. 32 768 per level, the three layers of a level side
+// by side: 768 outputs) and their input gradients, the batched prediction heads (:1859-1870, ~2 400 rows).  Round 4: these
+// were the last library GEMMs of the head (hipBLASLt Cijk_* / CK batched_gemm_xdl: 0.3 ms/step in 21 launches).
+//   C[m][n] = sum_k A[m][k] * B[n][k] (+ bias[n]),   A [M, K] bf16 (row stride lda), B [N, K] bf16 (row stride ldb),
+//   C [M, N] bf16 (row stride ldc), fp32 accumulation, one rounding of the result — the library's rounding points.
+// Both operands are contraction-contiguous, i.e. ARE v_mfma_f32_16x16x32_bf16 fragments as they lie in memory (a lane's 16
+// bytes = 8 consecutive k of one row): no LDS, no staging — the weights (<= 400 KB) stay in L2, an A row block is read by
+// the two waves that share it.  The product is formed transposed (D = B-tile x A-tile^T) so that a lane ends up with FOUR
+// CONSECUTIVE output columns of one row: 8-byte stores.  Workgroup = 4 waves = 128 rows x 128 columns, wave = 64 x 64
+// (4 x 4 MFMA tiles), fragments of K step k + 1 requested before the 16 MFMAs of step k.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+typedef __attribute__((ext_vector_type(8))) __bf16 tg_bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 tg_bf16x4;
+typedef float tg_f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool BIAS>
+__global__ __launch_bounds__(256) void tall_gemm_bf16_kernel(const __bf16* __restrict__ A, int64_t lda, const __bf16* __restrict__ B,
+                                                             int64_t ldb, const __bf16* __restrict__ bias, __bf16* __restrict__ C,
+                                                             int64_t ldc, int M, int N, int K)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.y * 128 + (wave >> 1) * 64, col0 = blockIdx.x * 128 + (wave & 1) * 64;
+    if (row0 >= M || col0 >= N) return;
+    const int li = lane & 15, kb = (lane >> 4) * 8;
+    // clamped rows / columns: out-of-range tiles compute on the last row / column and are not stored
+    const __bf16* ap[4];
+    const __bf16* bp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ap[t] = A + (int64_t)min(row0 + t * 16 + li, M - 1) * lda + kb;
+        bp[t] = B + (int64_t)min(col0 + t * 16 + li, N - 1) * ldb + kb;
+    }
+    tg_f32x4 acc[4][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[n][m] = tg_f32x4{0.f, 0.f, 0.f, 0.f};
+    tg_bf16x8 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { a0[t] = *reinterpret_cast<const tg_bf16x8*>(ap[t]); b0[t] = *reinterpret_cast<const tg_bf16x8*>(bp[t]); }
+    const int nk = K >> 5;
+    for (int ks = 0; ks < nk; ks += 2) {
+        const int k1 = min(ks + 1, nk - 1) * 32, k2 = min(ks + 2, nk - 1) * 32;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { a1[t] = *reinterpret_cast<const tg_bf16x8*>(ap[t] + k1); b1[t] = *reinterpret_cast<const tg_bf16x8*>(bp[t] + k1); }
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[n], a0[m], acc[n][m], 0, 0, 0);
+        if (ks + 1 < nk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { a0[t] = *reinterpret_cast<const tg_bf16x8*>(ap[t] + k2); b0[t] = *reinterpret_cast<const tg_bf16x8*>(bp[t] + k2); }
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[n], a1[m], acc[n][m], 0, 0, 0);
+        }
+    }
+    // D[n-tile][m-tile]: lane holds output columns col0 + n * 16 + 4 * (lane >> 4) + r (r = 0..3) of row row0 + m * 16 + (lane & 15)
+    const int cq = (lane >> 4) * 4;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int col = col0 + n * 16 + cq;
+        float bz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (BIAS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bz[r] = (float)bias[min(col + r, N - 1)];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = row0 + m * 16 + li;
+            if (row >= M || col >= N) continue;
+            __bf16* dst = C + (int64_t)row * ldc + col;
+            const tg_bf16x4 v = {(__bf16)(acc[n][m][0] + bz[0]), (__bf16)(acc[n][m][1] + bz[1]), (__bf16)(acc[n][m][2] + bz[2]),
+                                 (__bf16)(acc[n][m][3] + bz[3])};
+            if (col + 3 < N) {
+                *reinterpret_cast<tg_bf16x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (col + r < N) dst[r] = v[r];
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mpf_tall_gemm_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const void* bias, void* c, int64_t ldc, int M,
+                                  int N, int K, void* stream)
+{
+    if (M == 0 || N == 0) return 0;
+    if (!a || !b || !c) return mpf::fail(MPF_E_NULL, "tall_gemm_bf16: NULL buffer");
+    if (M < 0 || N < 0 || K <= 0 || (K & 31)) return mpf::fail(MPF_E_SHAPE, "tall_gemm_bf16: K must be a positive multiple of 32");
+    if ((lda & 7) || (ldb & 7) || (ldc & 3) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)c & 7))
+        return mpf::fail(MPF_E_SHAPE, "tall_gemm_bf16: 16-byte aligned operand rows, 8-byte aligned result rows");
+    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
+    if (grid.y > 65535u) return mpf::fail(MPF_E_TOO_LARGE, "tall_gemm_bf16: more than 65 535 row tiles");
+    hipStream_t st = (hipStream_t)stream;
+    mpf::prof_begin(st);
+    mpf::set_kernel("tall_gemm_bf16_kernel");
+    if (bias)
+        hipLaunchKernelGGL((tall_gemm_bf16_kernel<true>), grid, dim3(256), 0, st, (const __bf16*)a, lda, (const __bf16*)b, ldb,
+                           (const __bf16*)bias, (__bf16*)c, ldc, M, N, K);
+    else
+        hipLaunchKernelGGL((tall_gemm_bf16_kernel<false>), grid, dim3(256), 0, st, (const __bf16*)a, lda, (const __bf16*)b, ldb,
+                           (const __bf16*)bias, (__bf16*)c, ldc, M, N, K);
+    mpf::prof_end("tall_gemm_bf16_kernel", st, 2.0 * ((double)M * K + (double)N * K + (double)M * N), 2.0 * M * (double)N * K);
+    return mpf::check(hipGetLastError(), "mpf_tall_gemm_bf16");
+}

@@ -114,10 +114,11 @@ def small_linear(x, w, b=None, relu=False):
 
 
 # ---------------------------------------------------------------------------------------------------
-# bf16 Linear with MANY rows (the key / value projections of the cross-attention): forward and input
-# gradient stay library GEMMs; the weight gradient dW = dY^T x — a 256x256 output contracted over
-# thousands of rows, 57-66 us in the library plus a separate bias reduction — runs on the split-over-rows
-# MFMA kernel of gemm3.hip in its one-product bf16 form (mpf_gemm_nt_bf16), bias gradient included.
+# bf16 Linear with MANY rows (the key / value projections of the cross-attention, the batched prediction heads): forward
+# and input gradient on the native tall GEMM (mpf_tall_gemm_bf16; the library only for shapes it does not take); the weight
+# gradient dW = dY^T x — a 256x256 output contracted over thousands of rows, 57-66 us in the library plus a separate bias
+# reduction — on the split-over-rows MFMA kernel of gemm3.hip in its one-product bf16 form (mpf_gemm_nt_bf16), bias gradient
+# included.
 _nt_ws = {}
 
 
@@ -152,11 +153,33 @@ def tall_usable(x, w, b=None):
             and x.numel() // max(K, 1) > MAX_ROWS and K % 4 == 0 and w.shape[0] % 4 == 0)
 
 
+def tall_gemm(a, b, bias=None):
+    """a [M, K] . b [N, K]^T (+ bias [N]) -> [M, N], all bf16 (unit column strides), on mpf_tall_gemm_bf16
+    (csrc/small_gemm.hip: operands straight from memory as MFMA fragments)."""
+    M, K = a.shape
+    N = b.shape[0]
+    c = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    with torch.cuda.device(a.device):
+        code = _lib.lib().mpf_tall_gemm_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
+                                             bias.data_ptr() if bias is not None else None, c.data_ptr(), N, M, N, K, _stream(a))
+    _lib.check(code, "mpf_tall_gemm_bf16")
+    return c
+
+
+def _tall_native_ok(a, b):
+    """operand pair the native tall GEMM takes as it lies in memory: contraction-contiguous, 16-byte aligned rows, K % 32 == 0"""
+    return (a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[1] % 32 == 0 and a.stride(0) % 8 == 0
+            and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and b.shape[0] % 4 == 0)
+
+
 class _TallLinear(Function):
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        x2 = x.reshape(-1, x.shape[-1])
+        if _tall_native_ok(x2, w) and (b is None or b.is_contiguous()):
+            return tall_gemm(x2, w, b).view(*x.shape[:-1], w.shape[0])
         return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
@@ -171,7 +194,13 @@ class _TallLinear(Function):
             x2 = x2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.matmul(g2, w).view(x.shape)
+            # dX[m, k] = sum_n dY[m, n] W[n, k]: the native kernel contracts along contiguous memory, so it gets W^T (a
+            # <= 400 KB copy; the weights of a level's three layers side by side)
+            wt = w.t().contiguous() if N % 32 == 0 else None
+            if wt is not None and _tall_native_ok(g2, wt):
+                dx = tall_gemm(g2, wt).view(x.shape)
+            else:
+                dx = torch.matmul(g2, w).view(x.shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = gemm_nt_bf16(g2, x2, want_csum=ctx.has_bias)
         return dx, dw, db

@@ -269,6 +269,21 @@ def linear(x, w, b=None, relu=False):
     return F.relu(y) if relu else y
 
 
+def _class_linear(x, w, b):
+    """class_embed over the batched residual streams (mask2former_transformer_decoder.py:1862): K + 1 = 81 outputs is not a
+    multiple of the native GEMM's 4-column / 32-deep granules, so weight and bias are zero-padded to 96 rows — forward, input
+    gradient (contraction over the 96 padded outputs, whose gradient is zero) and weight gradient then run on the native tall
+    kernels like every other Linear of the heads; the pad rows are sliced off again (autograd pads / slices the gradients)."""
+    n, K = w.shape
+    rows = x.numel() // max(K, 1)
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and b is not None and b.dtype == torch.bfloat16
+            and n % 32 and K % 32 == 0 and rows > 1024):
+        return F.linear(x, w, b)
+    pad = (-n) % 32
+    # (contiguous: the criterion's class-loss kernels address the logits as dense [rows, K + 1])
+    return tall_linear(x, F.pad(w, (0, 0, 0, pad)), F.pad(b, (0, pad)))[..., :n].contiguous()
+
+
 def masked_mha_w(q_in, k_in, v_in, w, b, wo, bo, nheads, mask: Optional[Tensor]):
     """Multi-head attention with in-projection (w, b) and out-projection (wo, bo), seq-first.
     q_in [Lq,N,E]; k_in, v_in [Lk,N,E]; mask bool, True = masked: [N,Lq,Lk] (shared by heads) or
@@ -627,7 +642,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         X = torch.stack(outputs, 0).view(L * Qt, N, C)
         d32, d16 = res_ln(self.decoder_norm, X, None, want32=not amp, want16=amp)
         x = d16 if amp else d32
-        cls = F.linear(x, W["class_embed.weight"], W["class_embed.bias"])                    # [L*Qt, N, K+1]
+        cls = _class_linear(x, W["class_embed.weight"], W["class_embed.bias"])              # [L*Qt, N, K+1]
         # (2 000+ rows: `linear` takes the library forward / dX and the native split-over-rows weight + bias gradient — the
         # library's dW for a [256, 2 280] x [2 280, 256] product is 4 workgroups walking the whole contraction)
         lin = linear if os.environ.get("MPF_HEADS_TALL", "1") == "1" else F.linear
