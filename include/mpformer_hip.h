@@ -322,13 +322,16 @@ int mpf_msda_backward_ws_raw(const void* value, const int64_t* host_spatial_shap
                              void* workspace, size_t workspace_bytes, void* stream);
 /* the same with `output` = the forward result [N, Lq, M*32] of these inputs (MSDeformAttn keeps it for output_proj's
  * backward, ops/modules/ms_deform_attn.py:117-124): sum_j attn_j * d attn_j of a (query, head) equals
- * <grad_output, output>, which lets every sample's gradient be formed where its value rows are (msda_block.hip, "bin + tile") */
+ * <grad_output, output>, which lets every sample's gradient be formed where its value rows are (msda_block.hip, "bin + tile").
+ * grad_raw_amax / grad_value_amax (NULL or amax slots, MPF_AMAX_SLOT_FLOATS floats, zeroed by the caller): the largest
+ * magnitudes of the two results, recorded by the kernels that write them (one atomic max per workgroup) for the fp16 x 2 GEMMs
+ * that consume them — the separate amax passes over the two tensors are not needed */
 int mpf_msda_backward_ws_raw_o(const void* value, const int64_t* host_spatial_shapes,
                                const void* sampling_loc, const void* attn_weight, const void* grad_output,
                                const void* output, void* grad_value, void* grad_raw,
                                int batch, int spatial_size, int num_heads, int channels,
                                int num_levels, int num_query, int num_point, int dtype,
-                               void* workspace, size_t workspace_bytes, void* stream);
+                               void* workspace, size_t workspace_bytes, float* grad_raw_amax, float* grad_value_amax, void* stream);
 
 /*
  * fp32 GEMM of the pixel-decoder encoder's Linear layers (reference: nn.Linear inside

@@ -150,7 +150,7 @@ SIGNATURES = {
     "mpf_msda_forward_raw_hs": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_forward_raw": (_c_int, [_c_vp] * 8 + [_c_int] * 8 + [_c_vp]),
     "mpf_msda_backward_ws_raw": (_c_int, [_c_vp] * 7 + [_c_int] * 8 + [_c_vp, ctypes.c_size_t, _c_vp]),
-    "mpf_msda_backward_ws_raw_o": (_c_int, [_c_vp] * 8 + [_c_int] * 8 + [_c_vp, ctypes.c_size_t, _c_vp]),
+    "mpf_msda_backward_ws_raw_o": (_c_int, [_c_vp] * 8 + [_c_int] * 8 + [_c_vp, ctypes.c_size_t, _c_vp, _c_vp, _c_vp]),
     "mpf_msda_backward_workspace_bytes": (ctypes.c_size_t, [_c_int] * 5 + [_c_vp]),
     "mpf_msda_backward_ws": (_c_int, [_c_vp] * 8 + [_c_int] * 8 + [_c_vp, ctypes.c_size_t, _c_vp]),
 }

@@ -27,5 +27,6 @@ int msda_block_forward(const void* value, const int64_t* host_shapes, const void
 size_t msda_block_workspace_bytes(const int64_t* host_shapes, int N, int M, int L, int Lq, int P);
 int msda_block_backward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, const void* go, void* gv,
                         void* gl, void* ga, void* graw, int N, int S, int M, int D, int L, int Lq, int P, int dtype, void* workspace,
-                        size_t workspace_bytes, hipStream_t st, const void* fwd_out = nullptr);
+                        size_t workspace_bytes, hipStream_t st, const void* fwd_out = nullptr, float* graw_amax = nullptr,
+                        float* gv_amax = nullptr);
 }  // namespace mpf

@@ -40,6 +40,7 @@
 #include <algorithm>
 #include <stdint.h>
 
+#include "amax.h"
 #include "mpf_common.h"
 
 namespace {
@@ -1019,7 +1020,7 @@ __global__ __launch_bounds__(kT) void msda_bwd_bin_kernel(
     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out, const float* __restrict__ fwd_out,
     float* __restrict__ grad_loc, float* __restrict__ grad_attn, float* __restrict__ grad_raw, float* __restrict__ delta,
     int* __restrict__ tile_count, unsigned* __restrict__ entries, int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB g,
-    int nblocks, unsigned* __restrict__ stats)
+    int nblocks, unsigned* __restrict__ stats, float* __restrict__ graw_amax)
 {
     __shared__ int s_bb[kMaxL * 4];
     __shared__ unsigned s_keys[kSlots];
@@ -1155,8 +1156,9 @@ __global__ __launch_bounds__(kT) void msda_bwd_bin_kernel(
         s_base[tid] = my_base;
     }
     __syncthreads();
-    if (q_d < 0) return;
-    const unsigned ent = ((unsigned)q_d << 2) | (unsigned)p_d;
+    float wmax = 0.f;            // raw form: largest magnitude this thread writes into grad_raw (amax slot of the GEMMs that read it)
+    const unsigned ent = ((unsigned)max(q_d, 0) << 2) | (unsigned)p_d;
+    if (q_d >= 0) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
         const int txa = max(x0[l], 0) >> 2, txb = min(x0[l] + 1, g.W[l] - 1) >> 2;
@@ -1179,12 +1181,19 @@ __global__ __launch_bounds__(kT) void msda_bwd_bin_kernel(
                 const int no = g.M * LP * 2, nr = g.M * LP * 3, lp = l * kP + p_d;
                 float* row = grad_raw + (int64_t)(c.b * g.Lq + q_d) * nr;
                 reinterpret_cast<float2*>(row + c.m * LP * 2)[lp] = make_float2(0.f, 0.f);
-                row[no + c.m * LP + lp] = -attn[gi0 + l * kP] * dl;
+                const float dlg = -attn[gi0 + l * kP] * dl;
+                row[no + c.m * LP + lp] = dlg;
+                wmax = fmaxf(wmax, fabsf(dlg));
             } else {
                 grad_attn[gi0 + l * kP] = 0.f;
                 reinterpret_cast<float2*>(grad_loc)[gi0 + l * kP] = make_float2(0.f, 0.f);
             }
         }
+    }
+    }
+    if (RAW && graw_amax) {      // (uniform) one atomic max per workgroup
+        __shared__ float ared[4];
+        amax_commit(graw_amax, wmax, ared);
     }
 }
 
@@ -1193,7 +1202,8 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
     const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
     const float* __restrict__ delta, const int* __restrict__ tile_count, const unsigned* __restrict__ entries,
     float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn, float* __restrict__ grad_raw, GeomB g,
-    int nwg, unsigned loc_bytes, unsigned* __restrict__ stats, int ablate_, unsigned long long* __restrict__ dbg_)
+    int nwg, unsigned loc_bytes, unsigned* __restrict__ stats, int ablate_, unsigned long long* __restrict__ dbg_,
+    float* __restrict__ graw_amax, float* __restrict__ gv_amax)
 {
     // DBG (benchmarking: mpf_set_option("msda_push_ablate2") / mpf_debug_set_buffer): the ablation switches and phase stamps
     // exist only in that instantiation; the production kernel carries neither their branches nor their registers
@@ -1242,6 +1252,7 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
     constexpr int LP = NL * kP;
     const int MLP = g.M * LP;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float wmax_r = 0.f;          // largest magnitude this lane writes into grad_raw (the amax slot of the GEMMs that read it)
     const int kgrp = lane >> 4, j = lane & 15;
     const unsigned* ent = entries + (int64_t)bm * g.ent_per_bm + ent_base + (int64_t)local * cap;   // this tile's run
     // the first 64 slots of the run (cap >= 64) are requested together with the tile's count (one round trip instead of two);
@@ -1427,8 +1438,10 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
                 if (RAW) {
                     const int no = g.M * LP * 2, nr = g.M * LP * 3, lp = l * kP + p;
                     float* row = grad_raw + (int64_t)(b * g.Lq + q) * nr;
-                    reinterpret_cast<float2*>(row + m * LP * 2)[lp] = make_float2(rx / fW, ry / fH);
-                    row[no + m * LP + lp] = a * (ra - sr.d);
+                    const float ox = rx / fW, oy = ry / fH, dlg = a * (ra - sr.d);
+                    reinterpret_cast<float2*>(row + m * LP * 2)[lp] = make_float2(ox, oy);
+                    row[no + m * LP + lp] = dlg;
+                    wmax_r = fmaxf(wmax_r, fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(dlg)));
                 } else {
                     const int64_t gi = ((int64_t)(b * g.Lq + q) * g.M + m) * LP + l * kP + p;
                     grad_attn[gi] = ra;
@@ -1508,16 +1521,28 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
             }
         }
     }
-    if (!live || part != 0) return;
-    const int py_ = ty * 4 + kgrp;
-    if (py_ < H) {
+    float wmax_v = 0.f;
+    if (live && part == 0) {
+        const int py_ = ty * 4 + kgrp;
+        if (py_ < H) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int px_ = tx * 4 + q;
-            if (px_ < W)
-                *reinterpret_cast<float2*>(grad_value + ((int64_t)(b * g.S + start + py_ * W + px_) * g.M + m) * kD + j * 2) =
-                    make_float2(acc0[q], acc1[q]);
+            for (int q = 0; q < 4; ++q) {
+                const int px_ = tx * 4 + q;
+                if (px_ < W) {
+                    *reinterpret_cast<float2*>(grad_value + ((int64_t)(b * g.S + start + py_ * W + px_) * g.M + m) * kD + j * 2) =
+                        make_float2(acc0[q], acc1[q]);
+                    wmax_v = fmaxf(wmax_v, fmaxf(fabsf(acc0[q]), fabsf(acc1[q])));
+                }
+            }
         }
+    }
+    // amax slots of the two outputs (the fp16 x 2 GEMMs that consume grad_value / grad_raw scale by them): the workgroup's
+    // largest magnitudes -> one atomic max each, instead of a pass over the tensors afterwards
+    if (gv_amax || (RAW && graw_amax)) {           // (uniform)
+        float* red = reinterpret_cast<float*>(smem);   // (one buffer for the workgroup: wave 0's rows)
+        __syncthreads();                            // every wave is done with its buffers
+        if (gv_amax) amax_commit(gv_amax, wmax_v, red);
+        if (RAW && graw_amax) amax_commit(graw_amax, wmax_r, red);
     }
 }
 
@@ -1529,7 +1554,8 @@ __global__ __launch_bounds__(kT) void msda_bwd_spill3_kernel(const float* __rest
                                                              const float* __restrict__ delta, const int* __restrict__ ovf_count,
                                                              const uint2* __restrict__ ovf, float* __restrict__ grad_value,
                                                              float* __restrict__ grad_loc, float* __restrict__ grad_attn,
-                                                             float* __restrict__ grad_raw, GeomB g, unsigned* __restrict__ stats)
+                                                             float* __restrict__ grad_raw, GeomB g, unsigned* __restrict__ stats,
+                                                             float* __restrict__ graw_amax)
 {
     constexpr int LP = NL * kP;
     const int n = *ovf_count;
@@ -1577,8 +1603,12 @@ __global__ __launch_bounds__(kT) void msda_bwd_spill3_kernel(const float* __rest
             if (RAW) {
                 const int no = g.M * LP * 2, nr = g.M * LP * 3, lp = l * kP + p;
                 float* row = grad_raw + (int64_t)(b * g.Lq + q) * nr;
-                reinterpret_cast<float2*>(row + m * LP * 2)[lp] = make_float2(rx / (float)W, ry / (float)H);
-                row[no + m * LP + lp] = a * (ra - delta[(int64_t)(b * g.Lq + q) * g.M + m]);
+                const float ox = rx / (float)W, oy = ry / (float)H, dlg = a * (ra - delta[(int64_t)(b * g.Lq + q) * g.M + m]);
+                reinterpret_cast<float2*>(row + m * LP * 2)[lp] = make_float2(ox, oy);
+                row[no + m * LP + lp] = dlg;
+                if (graw_amax)
+                    atomicMax(reinterpret_cast<unsigned*>(graw_amax) + (blockIdx.x % kAmaxSub) * kAmaxStride,
+                              __float_as_uint(fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(dlg))));
             } else {
                 grad_attn[gi] = ra;
                 reinterpret_cast<float2*>(grad_loc)[gi] = make_float2(rx, ry);
@@ -1772,7 +1802,8 @@ hipError_t launch_bwd(const float* value, const float* loc, const float* attn, c
 // third generation: memset -> bin -> tile -> spill3.  fwd_out (the forward result, [N, Lq, M * 32]) is needed by the raw form only.
 template <int NL>
 hipError_t launch_bwd3(const float* value, const float* loc, const float* attn, const float* go, const float* fwd_out, float* gv,
-                       float* gl, float* ga, float* graw, const GeomB& g, void* workspace, hipStream_t st)
+                       float* gl, float* ga, float* graw, const GeomB& g, void* workspace, hipStream_t st, float* graw_amax,
+                       float* gv_amax)
 {
     const WsLayout w = ws_layout(g);
     char* ws = (char*)workspace;
@@ -1791,10 +1822,10 @@ hipError_t launch_bwd3(const float* value, const float* loc, const float* attn, 
     mpf::prof_begin(st);
     if (graw)
         hipLaunchKernelGGL((msda_bwd_bin_kernel<NL, true>), dim3(grid), dim3(kT), 0, st, loc, attn, go, fwd_out, gl, ga, graw, delta, tile_count,
-                           entries, ovf_count, ovf, g, nblocks, g_stats);
+                           entries, ovf_count, ovf, g, nblocks, g_stats, graw_amax);
     else
         hipLaunchKernelGGL((msda_bwd_bin_kernel<NL, false>), dim3(grid), dim3(kT), 0, st, loc, attn, go, fwd_out, gl, ga, graw, delta, tile_count,
-                           entries, ovf_count, ovf, g, nblocks, g_stats);
+                           entries, ovf_count, ovf, g, nblocks, g_stats, graw_amax);
     // algorithmic bytes of the pair (1344 e S N) are split as: bin = loc in; tile = the rest
     mpf::prof_end("msda_bwd_bin_kernel", st, esz * n_samp * 2);
     const int nwg = g.N * g.M * g.wg_per_bm;
@@ -1805,21 +1836,21 @@ hipError_t launch_bwd3(const float* value, const float* loc, const float* attn, 
     if (g_push_ablate || g_dbg) {
         if (graw)
             hipLaunchKernelGGL((msda_bwd_tile_kernel<NL, true, true>), tgrid, dim3(kTP), lds, st, value, loc, attn, go, delta, tile_count,
-                               entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, g_push_ablate, g_dbg);
+                               entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, g_push_ablate, g_dbg, graw_amax, gv_amax);
         else
             hipLaunchKernelGGL((msda_bwd_tile_kernel<NL, false, true>), tgrid, dim3(kTP), lds, st, value, loc, attn, go, delta, tile_count,
-                               entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, g_push_ablate, g_dbg);
+                               entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, g_push_ablate, g_dbg, graw_amax, gv_amax);
     } else if (graw)
         hipLaunchKernelGGL((msda_bwd_tile_kernel<NL, true, false>), tgrid, dim3(kTP), lds, st, value, loc, attn, go, delta, tile_count,
-                           entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, 0, nullptr);
+                           entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, 0, nullptr, graw_amax, gv_amax);
     else
         hipLaunchKernelGGL((msda_bwd_tile_kernel<NL, false, false>), tgrid, dim3(kTP), lds, st, value, loc, attn, go, delta, tile_count,
-                           entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, 0, nullptr);
+                           entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, 0, nullptr, graw_amax, gv_amax);
     mpf::prof_end("msda_bwd_tile_kernel", st, esz * ((double)g.N * g.S * g.M * kD * 2 + n_row + n_samp * 4));
     if (graw)
-        hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, true>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, delta, ovf_count, ovf, gv, gl, ga, graw, g, g_stats);
+        hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, true>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, delta, ovf_count, ovf, gv, gl, ga, graw, g, g_stats, graw_amax);
     else
-        hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, false>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, delta, ovf_count, ovf, gv, gl, ga, graw, g, g_stats);
+        hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, false>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, delta, ovf_count, ovf, gv, gl, ga, graw, g, g_stats, graw_amax);
     return hipGetLastError();
 }
 
@@ -1885,21 +1916,23 @@ size_t msda_block_workspace_bytes(const int64_t* host_shapes, int N, int M, int 
 
 int msda_block_backward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, const void* go, void* gv,
                         void* gl, void* ga, void* graw, int N, int S, int M, int D, int L, int Lq, int P, int dtype, void* workspace,
-                        size_t workspace_bytes, hipStream_t st, const void* fwd_out)
+                        size_t workspace_bytes, hipStream_t st, const void* fwd_out, float* graw_amax, float* gv_amax)
 {
     if (!host_shapes || !block_ok(N, S, M, D, L, Lq, P, dtype)) return -1000;
     GeomB g;
     if (!build_geom(g, host_shapes, N, S, M, L, Lq)) return -1000;
     if (workspace_bytes < ws_layout(g).total) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: workspace too small");
+    if ((graw_amax || gv_amax) && !(g_bwd_gen == 3 && graw && fwd_out))
+        return mpf::fail(MPF_E_SHAPE, "msda_backward: the amax outputs belong to the raw form of the bin + tile kernels");
     if (g_bwd_gen == 3 && (!graw || fwd_out)) {
         mpf::set_kernel("msda_bwd_block(bin+tile)");
         hipError_t e3;
         const float *v_ = (const float*)value, *l_ = (const float*)loc, *a_ = (const float*)attn, *g_ = (const float*)go, *o_ = (const float*)fwd_out;
         switch (L) {
-            case 1: e3 = launch_bwd3<1>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
-            case 2: e3 = launch_bwd3<2>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
-            case 3: e3 = launch_bwd3<3>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
-            default: e3 = launch_bwd3<4>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
+            case 1: e3 = launch_bwd3<1>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
+            case 2: e3 = launch_bwd3<2>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
+            case 3: e3 = launch_bwd3<3>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
+            default: e3 = launch_bwd3<4>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
         }
         return mpf::check(e3, "msda_bwd_block(bin+tile)");
     }

@@ -581,7 +581,8 @@ static int backward_ws_impl(const void* value, const int64_t* host_spatial_shape
                             void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, void* grad_raw,
                             int batch, int spatial_size, int num_heads, int channels,
                             int num_levels, int num_query, int num_point, int dtype,
-                            void* workspace, size_t workspace_bytes, void* stream, const void* fwd_out = nullptr)
+                            void* workspace, size_t workspace_bytes, void* stream, const void* fwd_out = nullptr,
+                            float* graw_amax = nullptr, float* gv_amax = nullptr)
 {
     const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query, P = num_point;
     if (!value || !host_spatial_shapes || !sampling_loc || !attn_weight || !grad_output || !grad_value ||
@@ -592,8 +593,9 @@ static int backward_ws_impl(const void* value, const int64_t* host_spatial_shape
     {   // production path: spatially blocked push + MFMA pull (msda_block.hip); -1000 = not its shapes
         const int r = mpf::msda_block_backward(value, host_spatial_shapes, sampling_loc, attn_weight, grad_output, grad_value,
                                                grad_sampling_loc, grad_attn_weight, grad_raw, N, S, M, D, L, Lq, P, dtype, workspace,
-                                               workspace_bytes, (hipStream_t)stream, fwd_out);
+                                               workspace_bytes, (hipStream_t)stream, fwd_out, graw_amax, gv_amax);
         if (r != -1000) return r;
+        if (graw_amax || gv_amax) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws_raw_o: amax outputs need the blocked kernels' shapes");
     }
     Geom g;
     if (!build_geom(g, host_spatial_shapes, N, S, M, L, Lq, P))
@@ -677,12 +679,13 @@ extern "C" int mpf_msda_backward_ws_raw_o(const void* value, const int64_t* host
                                           const void* output, void* grad_value, void* grad_raw,
                                           int batch, int spatial_size, int num_heads, int channels,
                                           int num_levels, int num_query, int num_point, int dtype,
-                                          void* workspace, size_t workspace_bytes, void* stream)
+                                          void* workspace, size_t workspace_bytes, float* grad_raw_amax, float* grad_value_amax,
+                                          void* stream)
 {
     if (!grad_raw || !output) return mpf::fail(MPF_E_NULL, "msda_backward_ws_raw_o: NULL grad_raw / output");
     return backward_ws_impl(value, host_spatial_shapes, sampling_loc, attn_weight, grad_output, grad_value, nullptr, nullptr,
                             grad_raw, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, dtype,
-                            workspace, workspace_bytes, stream, output);
+                            workspace, workspace_bytes, stream, output, grad_raw_amax, grad_value_amax);
 }
 
 namespace mpf {

@@ -185,8 +185,10 @@ class EncoderFn(Function):
             ds1, dp[8], dp[9] = ln256_backward(s1, mean1, rstd1, g1, dx1, ds_amax=ds1_am)
             dao = gemm3_h2(ds1, ds1_am, to, to_am)
             # d(raw): the softmax / offset-normaliser backward is the epilogue of the push kernel
-            gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C), ao.view(N, S, C))
-            dq = gemm3_h2(draw, amax(draw, draw_am), t288, t288_am)
+            # (the bin + tile kernels record the largest magnitudes of gv / draw themselves: no amax pass over the two tensors)
+            gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C), ao.view(N, S, C),
+                                                   draw_am, gv_am)
+            dq = gemm3_h2(draw, draw_am, t288, t288_am)
             # dW288^T = q^T . draw (288 on the 96-wide tile side) + per-split column sums of draw: the
             # bias gradient and, summed per level, the level_embed gradient
             cpart, _, cs = gemm3_nt(q, draw, rps, want_csum_b=True, transpose_out=True, amax_ab=(q_am, draw_am))
@@ -204,7 +206,7 @@ class EncoderFn(Function):
             gv2 = gv.view(R, C)
             # grad wrt this layer's input: through value_proj + the residual; the (src + pos) path (dq)
             # joins inside the previous layer's norm2 backward (layer 0: added here)
-            g = gemm3_h2(gv2, amax(gv2, gv_am), tv, tv_am, cin=ds1, cin2=dq if i == 0 else None)
+            g = gemm3_h2(gv2, gv_am, tv, tv_am, cin=ds1, cin2=dq if i == 0 else None)
             gq = dq
             # the four plain weight gradients of the layer (their operands are all alive here) as one launch
             (dp[12], dp[13]), (dp[10], dp[11]), (dp[6], dp[7]), (dp[4], dp[5]) = _wgrad_group(

@@ -209,9 +209,10 @@ def ms_deform_attn_forward_raw(value, spatial_shapes, level_start_index, raw, re
     return out, loc, attn
 
 
-def ms_deform_attn_backward_raw(value, host_shapes, sampling_loc, attn_weight, grad_output, output=None):
+def ms_deform_attn_backward_raw(value, host_shapes, sampling_loc, attn_weight, grad_output, output=None, graw_amax=None, gv_amax=None):
     """-> (grad_value, grad_raw [N*Lq, M*L*P*3]) with the atomics-free kernels (mpf_msda_backward_ws_raw; with the forward
-    result ``output`` [N, Lq, M*32]: mpf_msda_backward_ws_raw_o, the destination-side bin + tile kernels)."""
+    result ``output`` [N, Lq, M*32]: mpf_msda_backward_ws_raw_o, the destination-side bin + tile kernels, which can also record
+    the largest magnitudes of both results in amax slots ``graw_amax`` / ``gv_amax`` — zeroed by the caller)."""
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = sampling_loc.shape
     gv = torch.empty_like(value)
@@ -227,7 +228,9 @@ def ms_deform_attn_backward_raw(value, host_shapes, sampling_loc, attn_weight, g
             code = lib.mpf_msda_backward_ws_raw_o(
                 value.data_ptr(), host_shapes.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
                 grad_output.data_ptr(), output.data_ptr(), gv.data_ptr(), graw.data_ptr(),
-                N, S, M, D, L, Lq, P, _DTYPES[value.dtype], ws.data_ptr(), ws.numel(), _stream(value))
+                N, S, M, D, L, Lq, P, _DTYPES[value.dtype], ws.data_ptr(), ws.numel(),
+                graw_amax.data_ptr() if graw_amax is not None else None, gv_amax.data_ptr() if gv_amax is not None else None,
+                _stream(value))
         else:
             code = lib.mpf_msda_backward_ws_raw(
                 value.data_ptr(), host_shapes.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),

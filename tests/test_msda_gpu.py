@@ -495,9 +495,14 @@ def test_raw_forms_match_softmax_plus_op(shapes, N, fuse_prep):
     r_off = r.grad[:, :no].view(N, S, M, L, P, 2)
     # without the forward result: push + pull (the softmax backward inside the push kernel); with it: bin + tile, where
     # sum_j a_j dA_j of a (query, head) is <grad_out, out> (mpf_msda_backward_ws_raw_o)
+    from mp_former_amd.gemm3 import amax_slots, amax_value
     for fwd_out in (None, out):
-        gv, graw = msda.ms_deform_attn_backward_raw(value, ss._mpf_host, loc, attn, go, fwd_out)
+        slots = amax_slots(2, dev) if fwd_out is not None else (None, None)
+        gv, graw = msda.ms_deform_attn_backward_raw(value, ss._mpf_host, loc, attn, go, fwd_out, slots[0], slots[1])
         assert ("bin+tile" in _lib.last_kernel()) == (fwd_out is not None), _lib.last_kernel()
+        if fwd_out is not None:      # the kernels' own amax records == the largest magnitudes of what they wrote
+            assert float(amax_value(slots[0])) == float(graw.abs().max()), (float(amax_value(slots[0])), float(graw.abs().max()))
+            assert float(amax_value(slots[1])) == float(gv.abs().max()), (float(amax_value(slots[1])), float(gv.abs().max()))
         torch.testing.assert_close(gv, v.grad, rtol=1e-4, atol=1e-4)
         g_off = graw[:, :no].view(N, S, M, L, P, 2)
         torch.testing.assert_close(g_off[smooth], r_off[smooth], rtol=2e-3, atol=2e-3)
