@@ -1281,6 +1281,7 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
         }
         const float fx0 = (float)(tx * 4), fy0 = (float)(ty * 4);
         const float fW = (float)W, fH = (float)H;
+        const float rW = 1.0f / fW, rH = 1.0f / fH;
         const __amdgpu_buffer_rsrc_t rs_loc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(loc), 0, loc_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_att = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(attn), 0, loc_bytes >> 1, 0x00020000);
         const int gi_base = (b * g.Lq * g.M + m) * LP + l * kP;              // sample index of (q = 0, p = 0)
@@ -1438,7 +1439,9 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
                 if (RAW) {
                     const int no = g.M * LP * 2, nr = g.M * LP * 3, lp = l * kP + p;
                     float* row = grad_raw + (int64_t)(b * g.Lq + q) * nr;
-                    const float ox = rx / fW, oy = ry / fH, dlg = a * (ra - sr.d);
+                    // d offset = d loc / (W, H): the reciprocals are formed once per wave (exact for power-of-two maps, else
+                    // within an ulp of the division the push kernel did)
+                    const float ox = rx * rW, oy = ry * rH, dlg = a * (ra - sr.d);
                     reinterpret_cast<float2*>(row + m * LP * 2)[lp] = make_float2(ox, oy);
                     row[no + m * LP + lp] = dlg;
                     wmax_r = fmaxf(wmax_r, fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(dlg)));
@@ -1448,31 +1451,49 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
                     reinterpret_cast<float2*>(grad_loc)[gi] = make_float2(rx, ry);
                 }
             }
-            // MFMA role, part 1: lane = (pixel j, sample kgrp of the step) takes the chunk's weights and its 8 bytes of every
-            // row into REGISTERS (steps in groups of four; a group past the run's end is skipped, steps past it inside a group
-            // carry weight 0) ...
+            // MFMA role: lane = (pixel j, sample kgrp of the step).  The chunk's weights and the lane's 8 bytes of every row go to
+            // REGISTERS in two halves of eight steps (groups of four; a group past the run's end is skipped, steps past it inside
+            // a group carry weight 0): half A's MFMAs run first, then half B's operands are taken, which frees the row buffer and
+            // the weight table for the NEXT chunk — its sample role runs and its rows are requested before half B's 16 MFMAs,
+            // which then cover part of the copy's round trip.  (All 16 steps in registers at once cost 24 more registers across
+            // the next-chunk preparation: the raw form spilled, i.e. paid scratch round trips per chunk.)
             stamp(1);
             const int nst = (ablate & 2) ? 0 : min(16, (n - c * 64 + 3) >> 2);
-            float wv[16];
-            float2 gq[16];
+            float wv[8];
+            float2 gq[8];
+            auto take = [&](int half) {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                if (s4 * 4 < nst) {
-                    float wa[4], wb[4];
+                for (int s4 = 0; s4 < 2; ++s4) {
+                    if ((half * 2 + s4) * 4 < nst) {
+                        float wa[4], wb[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int st = s4 * 4 + u;                       // rows 4 st + kgrp
-                        wa[u] = w_x[st * 32];
-                        wb[u] = w_y[st * 32];
-                        gq[st] = *reinterpret_cast<const float2*>(g_l + st * 512 + (((j >> 1) << 4) ^ swz16(st * 4 + kgrp)));
+                        for (int u = 0; u < 4; ++u) {
+                            const int st = (half * 2 + s4) * 4 + u;                       // rows 4 st + kgrp
+                            wa[u] = w_x[st * 32];
+                            wb[u] = w_y[st * 32];
+                            gq[s4 * 4 + u] = *reinterpret_cast<const float2*>(g_l + st * 512 + (((j >> 1) << 4) ^ swz16(st * 4 + kgrp)));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) wv[s4 * 4 + u] = wa[u] * wb[u];
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) wv[s4 * 4 + u] = wa[u] * wb[u];
                 }
-            }
-            // ... so that the row buffer and the weight table are free for the NEXT chunk: its rows are requested and its sample
-            // role runs before this chunk's 32 MFMAs, which then cover the copy's round trip
+            };
+            auto mfmas = [&](int half) {
+#pragma unroll
+                for (int s4 = 0; s4 < 2; ++s4) {
+                    if ((half * 2 + s4) * 4 < nst) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s4 * 4 + u], gq[s4 * 4 + u].x, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s4 * 4 + u], gq[s4 * 4 + u].y, acc1, 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            take(0);
+            mfmas(0);
+            take(1);
             if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(2); }
             if (c + wpt < nchunks) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every LDS read of this chunk has returned
@@ -1486,17 +1507,7 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
                 e_nn = load_entry(c + 3 * wpt);
             }
             stamp(3);
-            // MFMA role, part 2
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                if (s4 * 4 < nst) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s4 * 4 + u], gq[s4 * 4 + u].x, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s4 * 4 + u], gq[s4 * 4 + u].y, acc1, 0, 0, 0);
-                    }
-                }
-            }
+            mfmas(1);
             if (dbg) { asm volatile("s_nop 0" :: "v"(acc0), "v"(acc1)); stamp(4); }
         }
     }
@@ -1540,9 +1551,16 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
     // largest magnitudes -> one atomic max each, instead of a pass over the tensors afterwards
     if (gv_amax || (RAW && graw_amax)) {           // (uniform)
         float* red = reinterpret_cast<float*>(smem);   // (one buffer for the workgroup: wave 0's rows)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { wmax_v = fmaxf(wmax_v, __shfl_xor(wmax_v, o)); wmax_r = fmaxf(wmax_r, __shfl_xor(wmax_r, o)); }
         __syncthreads();                            // every wave is done with its buffers
-        if (gv_amax) amax_commit(gv_amax, wmax_v, red);
-        if (RAW && graw_amax) amax_commit(graw_amax, wmax_r, red);
+        if (lane == 0) { red[wave * 2] = wmax_v; red[wave * 2 + 1] = wmax_r; }
+        __syncthreads();
+        if (tid < 2) {                              // thread 0: grad_value, thread 1: grad_raw — one atomic max each per workgroup
+            const float mx = fmaxf(fmaxf(red[tid], red[2 + tid]), fmaxf(red[4 + tid], red[6 + tid]));
+            float* slot = tid == 0 ? gv_amax : (RAW ? graw_amax : nullptr);
+            if (slot) atomicMax(reinterpret_cast<unsigned*>(slot) + (blockIdx.x % kAmaxSub) * kAmaxStride, __float_as_uint(mx));
+        }
     }
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel breakdown of the MSDA forward + backward at config B, N=2 (in-library HIP-event profiler).
-usage: bench_msda_breakdown.py [init|trained|uniform] [cfg] [N] [backward generation 2|3]"""
+usage: bench_msda_breakdown.py [init|trained|uniform] [cfg] [N] [backward generation 2|3] [raw]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,14 +14,27 @@ if len(sys.argv) > 4:
     _lib.set_option("msda_bwd_gen", int(sys.argv[4]))       # 3 = bin + tile (default), 2 = push + pull
 value, shapes, lsi, loc, attn, go, S = problem(cfg, N, dev, mode)
 ss = msda.attach_host_shapes(shapes, shapes.tolist(), lsi)
-for _ in range(3):
+raw = len(sys.argv) > 5 and sys.argv[5] == "raw"          # the module-level (raw) form the encoder runs: grad_raw + amax slots
+if raw:
+    from mp_former_amd.gemm3 import amax_slots
+    out = ms_deform_attn_forward(value, ss, lsi, loc, attn, 128)
+
+
+def once():
     ms_deform_attn_forward(value, ss, lsi, loc, attn, 128)
-    ms_deform_attn_backward(value, ss, lsi, loc, attn, go, 128)
+    if raw:
+        sl = amax_slots(2, dev) if os.environ.get("NO_AMAX") != "1" else (None, None)
+        msda.ms_deform_attn_backward_raw(value, ss._mpf_host, loc, attn, go, out, sl[0], sl[1])
+    else:
+        ms_deform_attn_backward(value, ss, lsi, loc, attn, go, 128)
+
+
+for _ in range(3):
+    once()
 torch.cuda.synchronize()
 _lib.profile_enable(True)
 for _ in range(10):
-    ms_deform_attn_forward(value, ss, lsi, loc, attn, 128)
-    ms_deform_attn_backward(value, ss, lsi, loc, attn, go, 128)
+    once()
 torch.cuda.synchronize()
 for k in ("msda_fwd", "msda_bwd_push", "msda_bwd_fill", "msda_bwd_pull", "msda_bwd_bin", "msda_bwd_tile"):
     n, ms, by = _lib.profile_get(k)
