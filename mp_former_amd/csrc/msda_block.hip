@@ -71,6 +71,9 @@ struct GeomB {
     // pull launch geometry: waves per tile; workgroups (16 waves) per (image, head) ordered band-major, level-minor
     int wpt[kMaxL], nband, wg_per_bm;
     int band_wg_base[kMaxBand * kMaxL];
+    // every band has the same number of tile rows of every level (level heights multiples of 4 * nband: the power-of-two maps
+    // of the 1024^2 / 512 x 1024 configs): workgroup -> (band, level) is arithmetic, no table lookup in the kernel prologue
+    int band_uniform, wg_per_band, lvl_wg_base[kMaxL];
 };
 
 // a[i] for a run-time i without a run-time kernarg offset: every element is read at its constant offset (hipcc batches
@@ -1229,15 +1232,23 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
     float* s_w = reinterpret_cast<float*>(s_v + kTV);     // [64][8]: a * hat(column 0..3 of the tile), hat(row 0..3)
     const int bm = wg / g.wg_per_bm;
     const int r = wg - bm * g.wg_per_bm;
-    int slot, slot_base;
-    {
+    int band, l, slot_base;
+    if (g.band_uniform) {
+        // (arithmetic: one dependent memory round trip less before the wave can ask for its tile's count and entries)
+        band = r / g.wg_per_band;
+        const int rr_ = r - band * g.wg_per_band;
+        l = 0;
+#pragma unroll
+        for (int k = 1; k < NL; ++k) l = rr_ >= g.lvl_wg_base[k] ? k : l;
+        slot_base = band * g.wg_per_band + sel(g.lvl_wg_base, l);
+    } else {
         const int nslot = g.nband * NL;
         const int base_k = g.band_wg_base[min(lane, nslot - 1)];
         const unsigned long long ge = __ballot(lane < nslot && r >= base_k);
-        slot = __builtin_amdgcn_readfirstlane(__popcll(ge) - 1);
+        const int slot = __builtin_amdgcn_readfirstlane(__popcll(ge) - 1);
         slot_base = __builtin_amdgcn_readlane(base_k, slot);
+        band = slot / NL; l = slot - band * NL;
     }
-    const int band = slot / NL, l = slot - band * NL;
     const int wpt = sel(g.wpt, l);
     const int W = sel(g.W, l), H = sel(g.H, l);
     const int nty = (H + 3) >> 2, ntx = sel(g.ntx, l);
@@ -1699,6 +1710,10 @@ bool build_geom(GeomB& g, const int64_t* hs, int N, int S, int M, int L, int Lq)
                 base += (rows * g.ntx[l] * g.wpt[l] + kWP - 1) / kWP;
             }
         g.wg_per_bm = base;
+        g.band_uniform = 1;
+        for (int l = 0; l < L; ++l) if (((g.H[l] + 3) / 4) % nband != 0) g.band_uniform = 0;
+        g.wg_per_band = g.band_uniform ? base / nband : 0;
+        for (int l = 0; l < kMaxL; ++l) g.lvl_wg_base[l] = (g.band_uniform && l < L) ? g.band_wg_base[l] : (1 << 30);
     }
     g.tiles_per_bm = tbase; g.ent_per_bm = ebase;
     if ((int64_t)N * M * tbase >= (1ll << 31)) return false;
