@@ -289,6 +289,23 @@ int mpf_attn_backward_kv(const void* q, const void* k, const void* v, int64_t kv
                          const float* lse, const float* delta, void* dq, void* dk, void* dv, int64_t dkv_row_stride,
                          int64_t dkv_img_stride, int Lq, int LqP, int Lk, int N, int H, int head_dim, float scale, void* workspace,
                          size_t workspace_bytes, void* stream);
+/*
+ * The dK / dV kernel of the backward (keys on the lane axis) reads the mask TRANSPOSED ([N or 1, Lk, LqP] bytes) and
+ * (lse, delta) as pairs padded to LqP — its "aux" operands, mpf_attn_bwd_aux_bytes(Lq, Lk, N, H, mask_images) bytes
+ * (mask_images = N for a per-image mask, 1 for a shared one, 0 without mask).  mpf_attn_bwd_prep_aux makes them in
+ * the launch that also makes qT / doT / delta (mpf_attn_bwd_prep below); mpf_attn_backward_kv_aux consumes them.  The
+ * entry points without aux make them themselves (one more launch) in the workspace, which mpf_attn_workspace_bytes
+ * sizes for that.
+ */
+size_t mpf_attn_bwd_aux_bytes(int Lq, int Lk, int N, int H, int mask_images);
+int mpf_attn_bwd_prep_aux(const void* q, const void* dout, const void* out, const float* lse, const uint8_t* mask, int mask_per_image,
+                          int Lk, void* qT, void* doT, float* delta, void* aux, size_t aux_bytes, int Lq, int LqP, int N, int H,
+                          void* stream);
+int mpf_attn_backward_kv_aux(const void* q, const void* k, const void* v, int64_t kv_row_stride, int64_t kv_img_stride, const void* kT,
+                             const void* qT, const void* dout, const void* doutT, const uint8_t* mask, int mask_per_image,
+                             const float* lse, const float* delta, void* dq, void* dk, void* dv, int64_t dkv_row_stride,
+                             int64_t dkv_img_stride, int Lq, int LqP, int Lk, int N, int H, int head_dim, float scale, void* workspace,
+                             size_t workspace_bytes, const void* aux, void* stream);
 int mpf_attn_delta(const void* dout, const void* out, float* delta, int Lq, int N, int H, void* stream);
 /* mpf_attn_transpose2(q, dout -> qT, doT; E = 32 * H) and mpf_attn_delta(dout, out) in ONE launch: everything the attention
  * backward derives from the query side (nn.MultiheadAttention backward, mask2former_transformer_decoder.py:42-52, :100-112) */

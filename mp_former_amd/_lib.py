@@ -60,6 +60,10 @@ SIGNATURES = {
                                      _c_int, _c_int, _c_int, ctypes.c_float, _c_vp, ctypes.c_size_t, _c_vp]),
     "mpf_attn_backward_kv": (_c_int, [_c_vp] * 3 + [ctypes.c_int64] * 2 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 5 + [ctypes.c_int64] * 2
                              + [_c_int] * 6 + [ctypes.c_float, _c_vp, ctypes.c_size_t, _c_vp]),
+    "mpf_attn_backward_kv_aux": (_c_int, [_c_vp] * 3 + [ctypes.c_int64] * 2 + [_c_vp] * 5 + [_c_int] + [_c_vp] * 5 + [ctypes.c_int64] * 2
+                                 + [_c_int] * 6 + [ctypes.c_float, _c_vp, ctypes.c_size_t, _c_vp, _c_vp]),
+    "mpf_attn_bwd_aux_bytes": (ctypes.c_size_t, [_c_int] * 5),
+    "mpf_attn_bwd_prep_aux": (_c_int, [_c_vp] * 5 + [_c_int] * 2 + [_c_vp] * 4 + [ctypes.c_size_t] + [_c_int] * 4 + [_c_vp]),
     "mpf_attn_delta": (_c_int, [_c_vp] * 3 + [_c_int] * 3 + [_c_vp]),
     "mpf_attn_bwd_prep": (_c_int, [_c_vp] * 6 + [_c_int] * 4 + [_c_vp]),
     "mpf_gemm3_split": (_c_int, [_c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp]),

@@ -53,12 +53,14 @@ struct BwdScratch {
     // are issued together at the end of the layer (one grouped launch)
     void *dt3, *dt2, *dt1, *dxb, *dh, *dout, *dq, *dk_s, *dv_s, *dq_c, *qT, *doT;
     float *ds_a, *ds_b, *delta;
+    void* aux;                   // aux operands of the attention dK / dV kernel (mpf_attn_bwd_aux_bytes: the larger of the two attentions)
+    size_t aux_bytes;
     void* ln_ws;                 // per-workgroup partial sums of the three LayerNorms' parameter gradients, ln_ws_bytes each
     size_t ln_ws_bytes;
     size_t bytes;
 };
 
-BwdScratch bwd_scratch(void* base, int Qt, int N, int H, int F)
+BwdScratch bwd_scratch(void* base, int Qt, int N, int H, int F, int S)
 {
     Carve c(base);
     BwdScratch b;
@@ -79,6 +81,11 @@ BwdScratch bwd_scratch(void* base, int Qt, int N, int H, int F)
     b.ds_a = c.take<float>(R * kE);
     b.ds_b = c.take<float>(R * kE);
     b.delta = c.take<float>((size_t)N * H * Qt);
+    {
+        const size_t ca = mpf_attn_bwd_aux_bytes(Qt, S, N, H, N), sa = mpf_attn_bwd_aux_bytes(Qt, Qt, N, H, 1);
+        b.aux_bytes = ca > sa ? ca : sa;
+        b.aux = c.take<char>(b.aux_bytes);
+    }
     b.ln_ws_bytes = (mpf_res_ln256_backward_workspace_bytes((int)R) + 255) & ~size_t(255);
     b.ln_ws = c.take<char>(3 * b.ln_ws_bytes);
     b.bytes = c.used;
@@ -168,7 +175,7 @@ extern "C" uint64_t mpf_decoder_layer_struct_bytes(int which)
 extern "C" uint64_t mpf_decoder_layer_scratch_bytes(int Qt, int N, int H, int S, int ffn_dim, int backward)
 {
     if (Qt <= 0 || N <= 0 || H <= 0 || S <= 0 || ffn_dim <= 0) return 0;
-    return backward ? bwd_scratch(nullptr, Qt, N, H, ffn_dim).bytes : fwd_scratch(nullptr, Qt, N, S).bytes;
+    return backward ? bwd_scratch(nullptr, Qt, N, H, ffn_dim, S).bytes : fwd_scratch(nullptr, Qt, N, S).bytes;
 }
 
 extern "C" int mpf_decoder_layer_forward(const MpfDecoderLayer* L, void* st)
@@ -224,9 +231,9 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
         if (!q) return mpf::fail(MPF_E_NULL, "decoder_layer_backward: NULL buffer in MpfDecoderLayerGrad");
     const int Qt = L->Qt, N = L->N, H = L->H, S = L->S, F = L->ffn_dim, R = Qt * N;
     const int LqP = (Qt + 31) / 32 * 32;
-    if (L->scratch_bytes < bwd_scratch(nullptr, Qt, N, H, F).bytes)
+    if (L->scratch_bytes < bwd_scratch(nullptr, Qt, N, H, F, S).bytes)
         return mpf::fail(MPF_E_SHAPE, "decoder_layer_backward: scratch too small");
-    const BwdScratch b = bwd_scratch(L->scratch, Qt, N, H, F);
+    const BwdScratch b = bwd_scratch(L->scratch, Qt, N, H, F, S);
     const float scale = 0.17677669529663687f;
     float* dln = G->d_ln;
     // LayerNorm parameter gradients: the three backward launches leave per-workgroup partial sums, ONE launch at the end of the
@@ -248,9 +255,10 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
                                            ln_part + b.ln_ws_bytes, b.ln_ws_bytes, st));
     MPF_TRY(lin_dx(b.dt2, nullptr, L->sa_wo, nullptr, b.dout, R, kE, kE, st));
     dw[ndw++] = dw_item(b.dt2, nullptr, L->o_s, G->d_sa_wo, G->d_sa_bo, R, kE, kE);
-    MPF_TRY(mpf_attn_bwd_prep(L->q_s, b.dout, L->o_s, b.qT, b.doT, b.delta, Qt, LqP, N, H, st));
-    MPF_TRY(mpf_attn_backward(L->q_s, L->k_s, L->v_s, L->kT_s, b.qT, b.dout, b.doT, L->mask_s, 0, L->lse_s, b.delta, b.dq, b.dk_s,
-                              b.dv_s, Qt, LqP, Qt, N, H, 32, scale, L->attn_ws, L->attn_ws_bytes, st));
+    MPF_TRY(mpf_attn_bwd_prep_aux(L->q_s, b.dout, L->o_s, L->lse_s, L->mask_s, 0, Qt, b.qT, b.doT, b.delta, b.aux, b.aux_bytes, Qt, LqP,
+                                  N, H, st));
+    MPF_TRY(mpf_attn_backward_kv_aux(L->q_s, L->k_s, L->v_s, 0, 0, L->kT_s, b.qT, b.dout, b.doT, L->mask_s, 0, L->lse_s, b.delta, b.dq,
+                                     b.dk_s, b.dv_s, 0, 0, Qt, LqP, Qt, N, H, 32, scale, L->attn_ws, L->attn_ws_bytes, b.aux, st));
     const size_t act = (size_t)R * kE * 2, wsz = (size_t)kE * kE * 2, bsz = (size_t)kE * 2;
     const bool grads_packed = b.dk_s == at(b.dq, act) && b.dv_s == at(b.dq, 2 * act);
     if (packed_weights(L) && grads_packed) {
@@ -277,10 +285,11 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
     MPF_TRY(mpf_ln_partial_reduce(ln_part, b.ln_ws_bytes, R, 3, dln, st));      // dln = [ca | sa | ff] x (dgamma, dbeta)
     MPF_TRY(lin_dx(b.dt1, nullptr, L->ca_wo, nullptr, b.dout, R, kE, kE, st));
     dw[ndw++] = dw_item(b.dt1, nullptr, L->o_c, G->d_ca_wo, G->d_ca_bo, R, kE, kE);
-    MPF_TRY(mpf_attn_bwd_prep(L->q_c, b.dout, L->o_c, b.qT, b.doT, b.delta, Qt, LqP, N, H, st));
-    MPF_TRY(mpf_attn_backward_kv(L->q_c, L->k_c, L->v_c, L->kv_row_stride, L->kv_img_stride, L->kT_c, b.qT, b.dout, b.doT, L->mask_c, 1,
-                                 L->lse_c, b.delta, b.dq_c, G->d_k_c, G->d_v_c, G->dkv_row_stride, G->dkv_img_stride, Qt, LqP, S, N, H,
-                                 32, scale, L->attn_ws, L->attn_ws_bytes, st));
+    MPF_TRY(mpf_attn_bwd_prep_aux(L->q_c, b.dout, L->o_c, L->lse_c, L->mask_c, 1, S, b.qT, b.doT, b.delta, b.aux, b.aux_bytes, Qt, LqP, N,
+                                  H, st));
+    MPF_TRY(mpf_attn_backward_kv_aux(L->q_c, L->k_c, L->v_c, L->kv_row_stride, L->kv_img_stride, L->kT_c, b.qT, b.dout, b.doT, L->mask_c,
+                                     1, L->lse_c, b.delta, b.dq_c, G->d_k_c, G->d_v_c, G->dkv_row_stride, G->dkv_img_stride, Qt, LqP, S,
+                                     N, H, 32, scale, L->attn_ws, L->attn_ws_bytes, b.aux, st));
     MPF_TRY(lin_dx(b.dq_c, nullptr, L->ca_wq, nullptr, G->d_xb0, R, kE, kE, st));
     dw[ndw++] = dw_item(b.dq_c, nullptr, L->xb0, G->d_ca_wq, G->d_ca_bq, R, kE, kE);
     if (g_dw_group) {

@@ -98,6 +98,67 @@ def test_bwd_prep_equals_transpose_plus_delta():
         assert torch.equal(a[2][:, :, :Lq], q.permute(1, 2, 0)) and (a[2][:, :, Lq:] == 0).all()
 
 
+def test_bwd_prep_aux_and_backward_with_aux():
+    """mpf_attn_bwd_prep_aux = mpf_attn_bwd_prep + the aux operands of the dK / dV kernel ((lse, delta) pairs padded to LqP, the mask
+    transposed to [Lk, LqP]) in one launch; mpf_attn_backward_kv_aux on them == mpf_attn_backward (which builds the aux operands
+    itself), bit for bit; per-image, shared and absent masks, key counts with and without 16-byte rows."""
+    from mp_former_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    H, E, hd = 8, 256, 32
+    for Lq, Lk, N, kind in [(115, 1024, 2, "image"), (230, 200, 1, "image"), (118, 118, 2, "shared"), (33, 77, 3, "none"), (64, 4096, 2, "image")]:
+        LqP = (Lq + 31) // 32 * 32
+        st = torch.cuda.current_stream(dev).cuda_stream
+        q, do = (torch.randn(Lq, N, E, device=dev).bfloat16() for _ in range(2))
+        k, v = (torch.randn(Lk, N, E, device=dev).bfloat16() for _ in range(2))
+        mask = None
+        if kind != "none":
+            mask = torch.rand((N, Lq, Lk) if kind == "image" else (Lq, Lk), device=dev) < 0.4
+            mask[..., 0] = False
+        mp, per = (mask.data_ptr() if mask is not None else None), (1 if kind == "image" else 0)
+        ws = torch.empty(lib.mpf_attn_workspace_bytes(Lq, Lk, N, H) + 1024, dtype=torch.uint8, device=dev)
+        kt, vt = (torch.empty(N, E, Lk, dtype=torch.bfloat16, device=dev) for _ in range(2))
+        _lib.check(lib.mpf_attn_transpose2(k.data_ptr(), v.data_ptr(), kt.data_ptr(), vt.data_ptr(), Lk, Lk, N, E, st), "t")
+        out = torch.empty(Lq, N, E, dtype=torch.bfloat16, device=dev)
+        lse = torch.empty(N, H, Lq, dtype=torch.float32, device=dev)
+        _lib.check(lib.mpf_attn_forward(q.data_ptr(), k.data_ptr(), vt.data_ptr(), mp, per, out.data_ptr(), lse.data_ptr(), Lq, Lk, N, H, hd,
+                                        hd ** -0.5, ws.data_ptr(), ws.numel(), st), "f")
+        T = [torch.full((N, E, LqP), 7.0, dtype=torch.bfloat16, device=dev) for _ in range(4)]
+        d = [torch.full((N, H, Lq), 7.0, dtype=torch.float32, device=dev) for _ in range(2)]
+        _lib.check(lib.mpf_attn_bwd_prep(q.data_ptr(), do.data_ptr(), out.data_ptr(), T[0].data_ptr(), T[1].data_ptr(), d[0].data_ptr(),
+                                         Lq, LqP, N, H, st), "p")
+        mimgs = 0 if mask is None else (N if per else 1)
+        nb = lib.mpf_attn_bwd_aux_bytes(Lq, Lk, N, H, mimgs)
+        aux = torch.full((nb,), 9, dtype=torch.uint8, device=dev)
+        _lib.check(lib.mpf_attn_bwd_prep_aux(q.data_ptr(), do.data_ptr(), out.data_ptr(), lse.data_ptr(), mp, per, Lk, T[2].data_ptr(),
+                                             T[3].data_ptr(), d[1].data_ptr(), aux.data_ptr(), aux.numel(), Lq, LqP, N, H, st), "pa")
+        assert torch.equal(T[0], T[2]) and torch.equal(T[1], T[3]) and torch.equal(d[0], d[1])
+        ld_bytes = (N * H * LqP * 8 + 255) // 256 * 256
+        ld2 = aux[:N * H * LqP * 8].view(torch.float32).view(N, H, LqP, 2)
+        assert torch.equal(ld2[:, :, :Lq, 0], lse) and torch.equal(ld2[:, :, :Lq, 1], d[0])
+        if mask is not None:
+            mT = aux[ld_bytes:ld_bytes + mimgs * Lk * LqP].view(mimgs, Lk, LqP)
+            assert torch.equal(mT[:, :, :Lq] != 0, mask.reshape(mimgs, Lq, Lk).transpose(1, 2))
+            assert (mT[:, :, Lq:] != 0).all()              # queries past Lq are masked
+        res = []
+        for use_aux in (False, True):
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            if use_aux:
+                code = lib.mpf_attn_backward_kv_aux(q.data_ptr(), k.data_ptr(), v.data_ptr(), 0, 0, kt.data_ptr(), T[0].data_ptr(),
+                                                    do.data_ptr(), T[1].data_ptr(), mp, per, lse.data_ptr(), d[0].data_ptr(), dq.data_ptr(),
+                                                    dk.data_ptr(), dv.data_ptr(), 0, 0, Lq, LqP, Lk, N, H, hd, hd ** -0.5, ws.data_ptr(),
+                                                    ws.numel(), aux.data_ptr(), st)
+            else:
+                code = lib.mpf_attn_backward(q.data_ptr(), k.data_ptr(), v.data_ptr(), kt.data_ptr(), T[0].data_ptr(), do.data_ptr(),
+                                             T[1].data_ptr(), mp, per, lse.data_ptr(), d[0].data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                             dv.data_ptr(), Lq, LqP, Lk, N, H, hd, hd ** -0.5, ws.data_ptr(), ws.numel(), st)
+            _lib.check(code, "b")
+            res.append((dq, dk, dv))
+        for x, y in zip(*res):
+            assert torch.equal(x, y) and torch.isfinite(x.float()).all()
+
+
 def test_strided_kv_entry_points_equal_the_dense_ones():
     """mpf_attn_{transpose2_strided, forward_kv, backward_kv}: K / V (dK / dV) as 256-column blocks of a packed
     [Lk, N, 768] projection give bit-identical results to dense [Lk, N, 256] copies of the same blocks."""

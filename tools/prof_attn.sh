@@ -10,7 +10,7 @@ f = glob.glob("/tmp/pa/**/b_kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "attn_" in r["Kernel_Name"]]
 agg = collections.OrderedDict()
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    name = r["Kernel_Name"].split("((")[0].split("(float")[0].split("(__hip")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
     key = (name, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], r["Workgroup_Size_X"])
     agg.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = 0
