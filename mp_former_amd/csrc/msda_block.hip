@@ -1023,15 +1023,17 @@ __global__ __launch_bounds__(kT) void msda_bwd_bin_kernel(
     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out, const float* __restrict__ fwd_out,
     float* __restrict__ grad_loc, float* __restrict__ grad_attn, float* __restrict__ grad_raw, float* __restrict__ delta,
     int* __restrict__ tile_count, unsigned* __restrict__ entries, int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB g,
-    int nblocks, unsigned* __restrict__ stats, float* __restrict__ graw_amax)
+    int nblocks, unsigned* __restrict__ stats, float* __restrict__ graw_amax, int reverse)
 {
     __shared__ int s_bb[kMaxL * 4];
     __shared__ unsigned s_keys[kSlots];
     __shared__ int s_cnt[kSlots + kBDummy];
     __shared__ int s_base[kSlots];
     constexpr int LP = NL * kP;
-    const int blk = xcd_index(nblocks);
-    if (blk >= nblocks) return;
+    // (reverse: tests only — the query blocks in the opposite order, i.e. another arrival order of the entries in their runs)
+    const int blk0 = xcd_index(nblocks);
+    if (blk0 >= nblocks) return;
+    const int blk = reverse ? nblocks - 1 - blk0 : blk0;
     BlockCtx c;
     block_of(g, blk, c);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1655,6 +1657,8 @@ int g_block_disable = 0;
 int g_fuse_prep = 1;        // mpf_set_option("msda_fuse_prep"): softmax / location arithmetic inside the forward kernel
 unsigned long long* g_dbg = nullptr;   // benchmarking only: s_memtime phase stamps of the push kernel, [workgroup][16]
 int g_push_ablate = 0;       // benchmarking only: 1 = no tile entries, 2 = no reduction, 4 = no box staging
+int g_bwd_sorted = 0;        // mpf_set_option("msda_bwd_sorted"): sort every tile run before the tile kernel (bit-reproducible grad_value)
+int g_bin_reverse = 0;       // tests: bin kernel walks the query blocks backwards (another arrival order)
 int g_bwd_gen = 3;           // mpf_set_option("msda_bwd_gen"): 3 = bin + tile kernels (round 4), 2 = push + pull (rounds 2-3)
 // tests only (mpf_set_option("msda_stats", 1) / mpf_msda_stats): which route every (workgroup, level) took.
 //   [0] forward: boxes staged in LDS   [1] forward: L2-gather fallback (box larger than the region)
@@ -1771,6 +1775,42 @@ hipError_t launch_fwd(const float* value, const float* loc, const float* attn, f
 // zero-fill of the tile counters as a KERNEL (not hipMemsetAsync): a captured HIP graph replays a kernel node faithfully; the
 // runtime's memset node of this odd byte count did not (replays of the captured pixel-decoder backward ran the bin / tile /
 // spill kernels on stale counters: memory faults) — and the launch is cheaper for the launch thread than the memset call
+// Deterministic mode (mpf_set_option("msda_bwd_sorted", 1)): the entries of a tile's run arrive in the order in which the bin
+// kernel's workgroups won their atomic adds, and grad_value sums them in that order — fp32 reassociation from run to run.
+// Sorting every run (entries are distinct (query, point) codes) fixes the order: one workgroup per tile, bitonic sort in LDS.
+// Runs that overflowed their capacity keep a spill part whose atomics stay unordered (msda_bwd_spill3_kernel).
+// Cost at config B, N = 2: ~300 us for this plain kernel (off by default).  Side finding: on sorted runs the tile kernel is
+// 9-14 % FASTER (190 -> 171 us init offsets, 215 -> 186 us scattered), and sorting inside the 64-entry chunks alone gives most
+// of it (175 / 196) while a point-major order is slower than arrival order (215 / 230): what counts is that the four points
+// of a query sit next to each other in a chunk (their grad_out row, delta and loc / attn words coalesce in the gathers).
+__global__ __launch_bounds__(256) void msda_sort_runs_kernel(const int* __restrict__ tile_count, unsigned* __restrict__ entries, GeomB g)
+{
+    extern __shared__ unsigned s_sort[];
+    const int key = (int)blockIdx.x;
+    const int bm = key / g.tiles_per_bm, r = key - bm * g.tiles_per_bm;
+    int l = 0;
+    for (int k = 1; k < g.L; ++k) l = r >= g.tile_base[k] ? k : l;
+    const int cap = g.cap[l], local = r - g.tile_base[l];
+    const int n = min(tile_count[key], cap);
+    if (n < 2) return;
+    unsigned* run = entries + (int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)local * cap;
+    int n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    for (int i = threadIdx.x; i < n2; i += 256) s_sort[i] = i < n ? run[i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n2 >> 1); t += 256) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;         // comparator (i, i + j)
+                const unsigned a = s_sort[i], b = s_sort[p];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { s_sort[i] = b; s_sort[p] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += 256) run[i] = s_sort[i];
+}
+
 __global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, int nwords)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1855,12 +1895,25 @@ hipError_t launch_bwd3(const float* value, const float* loc, const float* attn, 
     mpf::prof_begin(st);
     if (graw)
         hipLaunchKernelGGL((msda_bwd_bin_kernel<NL, true>), dim3(grid), dim3(kT), 0, st, loc, attn, go, fwd_out, gl, ga, graw, delta, tile_count,
-                           entries, ovf_count, ovf, g, nblocks, g_stats, graw_amax);
+                           entries, ovf_count, ovf, g, nblocks, g_stats, graw_amax, g_bin_reverse);
     else
         hipLaunchKernelGGL((msda_bwd_bin_kernel<NL, false>), dim3(grid), dim3(kT), 0, st, loc, attn, go, fwd_out, gl, ga, graw, delta, tile_count,
-                           entries, ovf_count, ovf, g, nblocks, g_stats, graw_amax);
+                           entries, ovf_count, ovf, g, nblocks, g_stats, graw_amax, g_bin_reverse);
     // algorithmic bytes of the pair (1344 e S N) are split as: bin = loc in; tile = the rest
     mpf::prof_end("msda_bwd_bin_kernel", st, esz * n_samp * 2);
+    if (g_bwd_sorted) {
+        int cap_max = 2;
+        for (int l = 0; l < g.L; ++l) cap_max = std::max(cap_max, g.cap[l]);
+        int n2 = 2;
+        while (n2 < cap_max) n2 <<= 1;
+        const size_t sort_lds = (size_t)n2 * sizeof(unsigned);
+        if (sort_lds > 160 * 1024 - 1024) return hipErrorInvalidValue;          // (a run of > 40 k entries: not a shape this path sees)
+        hipError_t ea = hipFuncSetAttribute((const void*)msda_sort_runs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds);
+        if (ea != hipSuccess) return ea;
+        mpf::prof_begin(st);
+        hipLaunchKernelGGL(msda_sort_runs_kernel, dim3(g.N * g.M * g.tiles_per_bm), dim3(256), sort_lds, st, tile_count, entries, g);
+        mpf::prof_end("msda_sort_runs_kernel", st, esz * n_samp * 1.5625 * 2);
+    }
     const int nwg = g.N * g.M * g.wg_per_bm;
     const size_t lds = (size_t)kWP * kTWave;
     const unsigned loc_bytes = (unsigned)((size_t)g.N * g.Lq * g.M * LP * 8);
@@ -1995,6 +2048,8 @@ int set_block_option(const char* key, int v)
     if (!strcmp(key, "msda_block_disable")) { g_block_disable = v; return 0; }
     if (!strcmp(key, "msda_fuse_prep")) { g_fuse_prep = v; return 0; }
     if (!strcmp(key, "msda_push_ablate2")) { g_push_ablate = v; return 0; }
+    if (!strcmp(key, "msda_bwd_sorted")) { g_bwd_sorted = v != 0; return 0; }
+    if (!strcmp(key, "msda_bin_reverse")) { g_bin_reverse = v != 0; return 0; }
     if (!strcmp(key, "msda_bwd_gen")) {
         if (v != 2 && v != 3) return MPF_E_SHAPE;
         g_bwd_gen = v;

@@ -357,6 +357,33 @@ def test_production_route_full_size_vs_oracle(dev, oracle_msda, cfg, lv, N, mode
         assert np.array_equal(a, b)
 
 
+def test_sorted_runs_make_grad_value_independent_of_the_entry_order(dev):
+    """mpf_set_option("msda_bwd_sorted", 1): every tile run is sorted before the tile kernel, so grad_value no longer depends on
+    the order in which the bin kernel's workgroups appended their entries.  The arrival order is changed on purpose
+    (msda_bin_reverse: query blocks walked backwards): unsorted, grad_value moves in its last bits (fp32 reassociation);
+    sorted, it is bit-identical.  grad_loc / grad_attn are per-sample quantities and never depend on the order."""
+    from mp_former_amd import _lib
+    z = _decoder_like_problem([(32, 32), (16, 16), (8, 8)], 2, mode="near", spread=3.0, seed=4)
+    res = {}
+    try:
+        for srt in (0, 1):
+            for rev in (0, 1):
+                _lib.set_option("msda_bwd_sorted", srt)
+                _lib.set_option("msda_bin_reverse", rev)
+                r, kern, st = _run_with_stats(z, dev)
+                assert "bin+tile" in kern[1] and st["spill_entries"] == 0, (kern, st)
+                res[srt, rev] = r
+    finally:
+        _lib.set_option("msda_bwd_sorted", 0)
+        _lib.set_option("msda_bin_reverse", 0)
+    base = res[0, 0]
+    for key, r in res.items():
+        assert np.array_equal(r[2], base[2]) and np.array_equal(r[3], base[3]), key          # grad_loc, grad_attn
+        np.testing.assert_allclose(r[1], base[1], rtol=2e-5, atol=2e-5 * np.abs(base[1]).max())
+    assert np.array_equal(res[1, 0][1], res[1, 1][1])                    # sorted: the arrival order does not matter
+    assert not np.array_equal(res[0, 0][1], res[0, 1][1])                # (unsorted it does: the switch really changed the order)
+
+
 @pytest.mark.parametrize("channels", [30, 32, 64, 71])
 def test_gradcheck_like_reference(dev, channels):
     """torch.autograd.gradcheck in fp64 on the reference's test problem (test.py:66-81)."""

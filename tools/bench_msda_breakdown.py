@@ -36,7 +36,7 @@ _lib.profile_enable(True)
 for _ in range(10):
     once()
 torch.cuda.synchronize()
-for k in ("msda_fwd", "msda_bwd_push", "msda_bwd_fill", "msda_bwd_pull", "msda_bwd_bin", "msda_bwd_tile"):
+for k in ("msda_fwd", "msda_bwd_push", "msda_bwd_fill", "msda_bwd_pull", "msda_bwd_bin", "msda_sort_runs", "msda_bwd_tile"):
     n, ms, by = _lib.profile_get(k)
     if n:
         print(f"{k:14s} launches={n} avg={ms / n * 1e3:8.1f} us")
