@@ -147,5 +147,7 @@ extern "C" int mpf_set_option(const char* key, int value)
     if (r <= 0) return r;
     r = mpf::set_attn_option(key, value);
     if (r <= 0) return r;
+    r = mpf::set_small_gemm_option(key, value);
+    if (r <= 0) return r;
     return mpf::fail(MPF_E_SHAPE, "mpf_set_option: unknown key");
 }

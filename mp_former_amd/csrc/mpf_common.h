@@ -21,6 +21,7 @@ int set_gemm3_option(const char* key, int v);
 int set_block_option(const char* key, int v);
 int set_decoder_option(const char* key, int v);
 int set_attn_option(const char* key, int v);
+int set_small_gemm_option(const char* key, int v);
 // spatially blocked MSDA (msda_block.hip); return -1000 when the problem is outside their shapes
 // raw != NULL: loc / attn are outputs computed from the raw projection + reference points (msda_prep fused in)
 int msda_block_forward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, void* out, int N, int S, int M,

@@ -19,6 +19,7 @@
 // MFMA is issued as D^T = B . A^T so a lane owns 4 consecutive output columns (8-B bf16 stores).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "mpf_common.h"
 
@@ -471,7 +472,166 @@ __global__ __launch_bounds__(256) void tall_gemm_bf16_kernel(const __bf16* __res
         }
     }
 }
+
+// Weight-stationary form for K = 256 / 768 (the key / value projections of the decoder and their input gradients): what bounded
+// the kernel above was L1 <- L2 traffic of fragments that every wave fetched for itself (A six times per column tile and twice
+// per workgroup, W once per row tile: ~400 MB for a 67 MB problem).  Here a wave keeps the W fragments of its 16 NB columns over
+// the WHOLE contraction in registers (16 NB KS dwords) for the lifetime of the workgroup, which walks row tiles; a row tile of X
+// (16 MB rows x K) comes global -> LDS by DMA once per workgroup in full 128-byte lines and is read as ds_read_b128 fragments by
+// the four waves.  LDS image = rows of K elements, 16-byte slot XOR-swizzled by (row & 15) on the SOURCE side of the DMA (the
+// destination of a DMA piece is lane-linear): the 16-lane service groups of ds_read_b128 then touch 16 different slots.  One LDS
+// buffer: the copy of tile t + 1 is requested after the barrier that ends the reads of tile t and lands under tile t's epilogue
+// stores; several workgroups per CU cover the rest.
+// one DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_addr, lds_addr + 1024).  Inline asm, not
+// __builtin_amdgcn_global_load_lds: hipcc puts s_waitcnt vmcnt(0) in front of the next LDS access after the builtin, which
+// would wait for the tile that has just been requested (M0 saved / restored: see gemm3.hip glds16).
+__device__ __forceinline__ void tall_glds16(const void* gaddr, unsigned lds_addr)
+{
+    unsigned saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(saved) : "v"(gaddr), "s"(lds_addr) : "memory");
+}
+
+template <int KS, int NB, int MB, int NBUF, bool BIAS>
+__global__ __launch_bounds__(256) void tall_ws_bf16_kernel(const __bf16* __restrict__ A, int64_t lda, const __bf16* __restrict__ B,
+                                                           int64_t ldb, const __bf16* __restrict__ bias, __bf16* __restrict__ C,
+                                                           int64_t ldc, int M, int N, int ntiles)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
+    constexpr int CPR = KS * 4;                   // 16-byte chunks per row
+    constexpr int ROWS = MB * 16;
+    constexpr int PIECES = ROWS * CPR / 64;       // DMA pieces (1 KB) per tile
+    static_assert(CPR % 16 == 0 && PIECES % 4 == 0, "tile shape");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 15, cg = lane >> 4;
+    const int col0 = blockIdx.x * (64 * NB) + wave * (16 * NB);
+    // W fragments of this wave's columns: the A operand of D = W . X^T (clamped rows: columns past N are computed and not stored)
+    tg_bf16x8 wf[NB][KS];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const __bf16* wr = B + (int64_t)min(col0 + n * 16 + li, N - 1) * ldb + cg * 8;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) wf[n][j] = *reinterpret_cast<const tg_bf16x8*>(wr + j * 32);
+    }
+    float bz[NB][4];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bz[n][r] = BIAS ? (float)bias[min(col0 + n * 16 + cg * 4 + r, N - 1)] : 0.f;
+    constexpr int TILE_BYTES = ROWS * CPR * 16;
+    const unsigned lds0 = (unsigned)(uintptr_t)ws_lds;          // (LDS byte address of the dynamic segment)
+    auto request = [&](int t, int buf) {
+        const int row0 = t * ROWS;
+#pragma unroll
+        for (int i = 0; i < PIECES / 4; ++i) {
+            const int piece = wave * (PIECES / 4) + i;
+            const int slot = piece * 64 + lane, row = slot / CPR, pos = slot - row * CPR;
+            const __bf16* src = A + (int64_t)min(row0 + row, M - 1) * lda + (pos ^ (row & 15)) * 8;
+            tall_glds16(src, lds0 + buf * TILE_BYTES + piece * 1024);
+        }
+    };
+    // NBUF buffers, tiles requested D = NBUF - 1 ahead (X streams from HBM: one tile of arithmetic does not cover that round
+    // trip), ONE barrier per tile.  At the top of tile t the wave needs ITS pieces of tile t; everything it issued after them
+    // may stay in flight: the pieces of the D - 1 later tiles and the result stores of the D tiles before — vmcnt of that
+    // count while it is exact (full tiles, full column slices, all later tiles requested), vmcnt(0) otherwise.  The barrier
+    // then says every wave's pieces have landed AND every wave is done with tile t - 1, whose buffer receives tile t + D.
+    constexpr int D = NBUF - 1, P = PIECES / 4, S = NB * MB;
+    static_assert((D - 1) * P + D * S <= 63, "vmcnt range");
+    const bool exact = (N % (64 * NB)) == 0;
+    const int g = gridDim.y;
+    int t = blockIdx.y, it = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (t + d * g < ntiles) request(t + d * g, d);
+    for (; t < ntiles; t += g, ++it) {
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (it >= D) {
+            if (exact && t + (D - 1) * g < ntiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * P + D * S) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }                                                       // (0 < it < D: those tiles landed with the first wait)
+        __syncthreads();
+        if (t + D * g < ntiles) request(t + D * g, (it + D) % NBUF);
+        const unsigned char* tile = ws_lds + (it % NBUF) * TILE_BYTES;
+        tg_f32x4 acc[NB][MB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[n][m] = tg_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            tg_bf16x8 xf[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const int row = m * 16 + li;
+                xf[m] = *reinterpret_cast<const tg_bf16x8*>(tile + (row * CPR + ((4 * j + cg) ^ li)) * 16);
+            }
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n][j], xf[m], acc[n][m], 0, 0, 0);
+        }
+        // D[n][m]: lane holds columns col0 + 16 n + 4 cg + r (r = 0..3) of row t ROWS + 16 m + li
+        const int row0 = t * ROWS;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int col = col0 + n * 16 + cg * 4;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const int row = row0 + m * 16 + li;
+                if (row >= M || col >= N) continue;
+                __bf16* dst = C + (int64_t)row * ldc + col;
+                const tg_bf16x4 v = {(__bf16)(acc[n][m][0] + bz[n][0]), (__bf16)(acc[n][m][1] + bz[n][1]),
+                                     (__bf16)(acc[n][m][2] + bz[n][2]), (__bf16)(acc[n][m][3] + bz[n][3])};
+                if (col + 3 < N) {
+                    *reinterpret_cast<tg_bf16x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (col + r < N) dst[r] = v[r];
+                }
+            }
+        }
+    }
+}
+
+int g_tall_ws_wgs = 0;      // mpf_set_option("tall_ws_wgs"): workgroups of the weight-stationary kernel (0 = one residency)
+
+template <int KS, int NB, int MB, int NBUF>
+int launch_tall_ws(const void* a, int64_t lda, const void* b, int64_t ldb, const void* bias, void* c, int64_t ldc, int M, int N,
+                   hipStream_t st)
+{
+    const int ntiles = (M + MB * 16 - 1) / (MB * 16);
+    const unsigned gx = (unsigned)((N + 64 * NB - 1) / (64 * NB));
+    const size_t lds = (size_t)MB * 16 * KS * 64 * NBUF;
+    // the grid is exactly one residency (LDS: 160 KB per CU; registers: two workgroups), so that no workgroup starts after the
+    // others have walked their tiles
+    const unsigned per_cu = lds > 80 * 1024 ? 1u : 2u;
+    unsigned gy = (unsigned)(g_tall_ws_wgs ? g_tall_ws_wgs : 256 * per_cu) / gx;
+    gy = gy < 1u ? 1u : (gy > (unsigned)ntiles ? (unsigned)ntiles : gy);
+    {
+        const void* fn = bias ? (const void*)tall_ws_bf16_kernel<KS, NB, MB, NBUF, true> : (const void*)tall_ws_bf16_kernel<KS, NB, MB, NBUF, false>;
+        if (int e = mpf::check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
+    }
+    if (bias)
+        hipLaunchKernelGGL((tall_ws_bf16_kernel<KS, NB, MB, NBUF, true>), dim3(gx, gy), dim3(256), lds, st, (const __bf16*)a, lda,
+                           (const __bf16*)b, ldb, (const __bf16*)bias, (__bf16*)c, ldc, M, N, ntiles);
+    else
+        hipLaunchKernelGGL((tall_ws_bf16_kernel<KS, NB, MB, NBUF, false>), dim3(gx, gy), dim3(256), lds, st, (const __bf16*)a, lda,
+                           (const __bf16*)b, ldb, (const __bf16*)bias, (__bf16*)c, ldc, M, N, ntiles);
+    return 0;
+}
+
+int g_tall_ws = 1;          // mpf_set_option("tall_ws", 0): the fragment-per-wave kernel for every shape (A/B)
 }  // namespace
+
+namespace mpf {
+int set_small_gemm_option(const char* key, int v)
+{
+    if (!strcmp(key, "tall_ws")) { g_tall_ws = v != 0; return 0; }
+    if (!strcmp(key, "tall_ws_wgs")) { g_tall_ws_wgs = v; return 0; }
+
+    return 1;
+}
+}  // namespace mpf
 
 extern "C" int mpf_tall_gemm_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const void* bias, void* c, int64_t ldc, int M,
                                   int N, int K, void* stream)
@@ -484,6 +644,19 @@ extern "C" int mpf_tall_gemm_bf16(const void* a, int64_t lda, const void* b, int
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128));
     if (grid.y > 65535u) return mpf::fail(MPF_E_TOO_LARGE, "tall_gemm_bf16: more than 65 535 row tiles");
     hipStream_t st = (hipStream_t)stream;
+    if (g_tall_ws && M >= 1024 && (K == 256 || K == 768)) {
+        mpf::prof_begin(st);
+        mpf::set_kernel("tall_ws_bf16_kernel");
+        int e;
+        // (measured at 32 768 rows: 64-row tiles x 2 buffers, 32-row tiles x 3 or 4 buffers all give 29-30 us for K = 256 and
+        // 35-38 us for K = 768: the copies are not what the kernel waits for — ablations: result stores 9 us of HBM write time,
+        // copies 3-8, MFMA phase 3 (K = 256) / 15 (K = 768: one 16-column block per wave reads the whole X tile from LDS))
+        if (K == 256) e = launch_tall_ws<8, 2, 4, 2>(a, lda, b, ldb, bias, c, ldc, M, N, st);
+        else e = launch_tall_ws<24, 1, 2, 2>(a, lda, b, ldb, bias, c, ldc, M, N, st);
+        if (e) return e;
+        mpf::prof_end("tall_gemm_bf16_kernel", st, 2.0 * ((double)M * K + (double)N * K + (double)M * N), 2.0 * M * (double)N * K);
+        return mpf::check(hipGetLastError(), "mpf_tall_gemm_bf16");
+    }
     mpf::prof_begin(st);
     mpf::set_kernel("tall_gemm_bf16_kernel");
     if (bias)

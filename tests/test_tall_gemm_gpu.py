@@ -8,9 +8,13 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("ws", [1, 0])
 @pytest.mark.parametrize("M,N,K,bias", [(2048, 768, 256, True), (32768, 768, 256, True), (8192, 256, 768, False), (2400, 256, 256, True),
-                                        (2280, 96, 256, True), (130, 100, 64, False), (1, 4, 32, True), (257, 260, 96, False)])
-def test_tall_gemm_matches_fp32_reference(M, N, K, bias):
+                                        (2280, 96, 256, True), (1090, 260, 768, True), (130, 100, 64, False), (1, 4, 32, True),
+                                        (257, 260, 96, False)])
+def test_tall_gemm_matches_fp32_reference(M, N, K, bias, ws):
+    """both kernels behind mpf_tall_gemm_bf16: the weight-stationary one (K = 256 / 768, >= 1024 rows: W fragments in registers, X
+    row tiles through LDS) and the fragment-per-wave one (every other shape; all shapes with mpf_set_option("tall_ws", 0))"""
     from mp_former_amd import _lib
     from mp_former_amd.small_linear import tall_gemm
     dev = torch.device("cuda:0")
@@ -18,8 +22,13 @@ def test_tall_gemm_matches_fp32_reference(M, N, K, bias):
     a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
     b = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).to(dev)
     bz = (torch.randn(N, generator=g) * 0.2).to(torch.bfloat16).to(dev) if bias else None
-    c = tall_gemm(a, b, bz)
-    assert _lib.last_kernel() == "tall_gemm_bf16_kernel"
+    _lib.set_option("tall_ws", ws)
+    try:
+        c = tall_gemm(a, b, bz)
+        want = "tall_ws_bf16_kernel" if (ws and M >= 1024 and K in (256, 768)) else "tall_gemm_bf16_kernel"
+        assert _lib.last_kernel() == want
+    finally:
+        _lib.set_option("tall_ws", 1)
     ref = a.float() @ b.float().t() + (bz.float() if bias else 0.0)
     # one bf16 rounding of an fp32-accumulated result: half an ulp = 2^-9 relative
     torch.testing.assert_close(c.float(), ref, rtol=4e-3, atol=4e-3 * float(ref.abs().max()) / 64)
