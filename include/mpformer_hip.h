@@ -840,6 +840,10 @@ int mpf_small_gemm_bf16_group(const MpfSmallGemmItem* items, int n_items, void* 
  */
 int mpf_bias_act(const void* x, const float* bias, const void* res, void* y, int64_t numel, int C, int dtype,
                  int relu, void* stream);
+/* Backward of the block-output ReLU of a residual block (detectron2 BottleneckBlock: out = relu(conv3 + shortcut)) with the sum
+ * of the two gradients that reach the block's output folded in: out = y > 0 ? round_bf16(ga + gb) : 0 (gb may be NULL) — aten's
+ * add + threshold_backward in one pass.  bf16, numel % 8 == 0, 16-byte aligned, same (dense) layout for all four tensors. */
+int mpf_relu_bwd_add(const void* ga, const void* gb, const void* y, void* out, int64_t numel, int dtype, void* stream);
 
 /*
  * Small host -> device table (item lists of the grouped launches) through the kernel-argument segment: `nbytes` (multiple

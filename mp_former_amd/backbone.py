@@ -66,13 +66,59 @@ class _BiasAct(torch.autograd.Function):
         return g, None, (g if ctx.has_res else None), None
 
 
+def _relu_bwd_add(ga, gb, y):
+    """y > 0 ? ga + gb : 0 in one native pass (csrc/elementwise.hip: aten's add + threshold_backward, same rounding points);
+    gb may be None.  Falls back to the two aten ops for layouts / dtypes the kernel does not take."""
+    same = (ga.dtype == torch.bfloat16 and y.dtype == torch.bfloat16 and ga.shape == y.shape and ga.stride() == y.stride() and _dense(y)
+            and ga.numel() % 8 == 0 and (gb is None or (gb.dtype == ga.dtype and gb.shape == ga.shape and gb.stride() == ga.stride())))
+    if not (ga.is_cuda and same):
+        return torch.ops.aten.threshold_backward(ga if gb is None else ga + gb, y, 0)
+    out = torch.empty_like(y)
+    with torch.cuda.device(y.device):
+        code = _lib.lib().mpf_relu_bwd_add(ga.data_ptr(), gb.data_ptr() if gb is not None else None, y.data_ptr(), out.data_ptr(),
+                                           y.numel(), _lib.MPF_BF16, torch.cuda.current_stream(y.device).cuda_stream)
+    _lib.check(code, "mpf_relu_bwd_add")
+    return out
+
+
+class _BiasActFork(torch.autograd.Function):
+    """relu(x + shift[c] + res) returned TWICE (two aliases of one tensor): the output of a residual block has two consumers in
+    the next block (conv1 / shortcut convolution, and the identity skip or the other of the two), whose gradients autograd would
+    add with a kernel of its own before the ReLU backward — as separate outputs they arrive separately and are summed inside
+    the ReLU-backward pass.  A third consumer (the pixel decoder on a stage's last block) adds into the first alias as usual."""
+
+    @staticmethod
+    def forward(ctx, x, shift, res):
+        y = torch.empty_like(x)
+        code = _lib.lib().mpf_bias_act(x.data_ptr(), shift.data_ptr(), res.data_ptr(), y.data_ptr(), x.numel(), x.shape[1],
+                                       _lib.MPF_BF16 if x.dtype == torch.bfloat16 else _lib.MPF_F32, 1,
+                                       torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(code, "mpf_bias_act")
+        ctx.save_for_backward(y)
+        ctx.set_materialize_grads(False)
+        return y, y.view(y.shape)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        (y,) = ctx.saved_tensors
+        if ga is None and gb is None:
+            return None, None, None
+        if ga is None:
+            ga, gb = gb, None
+        g = _relu_bwd_add(ga, gb, y)
+        return g, None, g
+
+
+def _bias_act_ok(x, res):
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and (res is None or (res.dtype == x.dtype and res.shape == x.shape
+                                 and res.is_contiguous(memory_format=torch.channels_last))))
+
+
 def bias_act(x, shift, res=None, relu=True):
     """FrozenBN shift (+ residual) (+ ReLU) after a bias-free folded convolution."""
-    ok = (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and x.shape[1] % 8 == 0
-          and x.is_contiguous(memory_format=torch.channels_last)
-          and (res is None or (res.dtype == x.dtype and res.shape == x.shape
-                               and res.is_contiguous(memory_format=torch.channels_last))))
-    if ok:
+    if _bias_act_ok(x, res):
         return _BiasAct.apply(x, shift, res, relu)
     y = x + shift.to(x.dtype).view(1, -1, 1, 1)
     if res is not None:
@@ -80,7 +126,15 @@ def bias_act(x, shift, res=None, relu=True):
     return F.relu(y) if relu else y
 
 
-def conv_bn(conv, bn, x, folded=None, res=None, relu=True):
+def bias_act_fork(x, shift, res):
+    """relu(x + shift + res) as two aliases (see _BiasActFork); (y, y) on the paths the native kernel does not take"""
+    if _bias_act_ok(x, res) and x.dtype == torch.bfloat16:
+        return _BiasActFork.apply(x, shift, res)
+    y = bias_act(x, shift, res, True)
+    return y, y
+
+
+def conv_bn(conv, bn, x, folded=None, res=None, relu=True, fork=False):
     """relu?(FrozenBN(conv(x)) + res) with the fixed per-channel scale folded into the convolution
     weight (w' = w * scale: same function, same gradient wrt w) and shift / residual / ReLU as ONE
     element-wise pass over the activation instead of MIOpen's bias kernel + add + ReLU."""
@@ -89,7 +143,8 @@ def conv_bn(conv, bn, x, folded=None, res=None, relu=True):
     else:
         scale, shift = bn.scale_bias()
         w = conv.weight * scale.view(-1, 1, 1, 1)
-    return bias_act(F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups), shift, res, relu)
+    y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return bias_act_fork(y, shift, res) if fork else bias_act(y, shift, res, relu)
 
 
 def _dense(t):
@@ -177,11 +232,18 @@ class Bottleneck(nn.Module):
         return p
 
     def forward(self, x, fw=None):
+        return self.forward_fork((x, x), fw)[0]
+
+    def forward_fork(self, xs, fw=None):
+        """xs = two aliases of the block input (the previous block's forward_fork result, or (x, x)): conv1 reads the first, the
+        shortcut convolution / identity skip the second, so their gradients reach the previous block's ReLU backward as two
+        arguments (summed there) instead of through an add kernel.  Returns the output as two aliases."""
         f = fw if fw is not None else [None] * 4
-        out = conv_bn(self.conv1, self.norm1, x, f[0])
+        x_main, x_skip = xs
+        out = conv_bn(self.conv1, self.norm1, x_main, f[0])
         out = conv_bn(self.conv2, self.norm2, out, f[1])
-        sc = x if self.shortcut is None else conv_bn(self.shortcut, self.shortcut_norm, x, f[3], relu=False)
-        return conv_bn(self.conv3, self.norm3, out, f[2], res=sc)
+        sc = x_skip if self.shortcut is None else conv_bn(self.shortcut, self.shortcut_norm, x_skip, f[3], relu=False)
+        return conv_bn(self.conv3, self.norm3, out, f[2], res=sc, fork=True)
 
 
 class ResNet50(nn.Module):
@@ -234,9 +296,11 @@ def run_stages(x, stages, stem=None):
         blocks = list(stage)
         folded = ResNet50._fold_group([p for b in blocks for p in b.pairs()], dtype)
         k = 0
+        xs = x if isinstance(x, tuple) else (x, x)
         for b in blocks:
             n = len(b.pairs())
-            x = b(x, folded[k:k + n])
+            xs = b.forward_fork(xs, folded[k:k + n])
             k += n
-        out[name] = x
+        x = xs
+        out[name] = xs[0]
     return out

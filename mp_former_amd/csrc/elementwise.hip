@@ -54,7 +54,47 @@ __global__ __launch_bounds__(256) void bias_act_f32_kernel(const float4* __restr
     }
 }
 
+// backward of the block-output ReLU of a residual block with the sum of the two gradients that reach it (next block's
+// conv1 / shortcut input gradient and its identity-skip gradient) folded in: out = y > 0 ? bf16(ga + gb) : 0 — the rounding
+// points of aten's add followed by threshold_backward, one pass instead of two
+template <bool ADD>
+__global__ __launch_bounds__(256) void relu_bwd_add_bf16_kernel(const bf16x8* __restrict__ ga, const bf16x8* __restrict__ gb,
+                                                                const bf16x8* __restrict__ y, bf16x8* __restrict__ out, int64_t n8)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const bf16x8 a = ga[i], yy = y[i];
+        bf16x8 b = {0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (ADD) b = gb[i];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 sum = ADD ? (__bf16)((float)a[j] + (float)b[j]) : a[j];
+            o[j] = (float)yy[j] > 0.f ? sum : (__bf16)0.f;
+        }
+        out[i] = o;
+    }
+}
+
 }  // namespace
+
+extern "C" int mpf_relu_bwd_add(const void* ga, const void* gb, const void* y, void* out, int64_t numel, int dtype, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!ga || !y || !out) return mpf::fail(MPF_E_NULL, "relu_bwd_add: NULL buffer");
+    if (numel <= 0 || numel % 8 != 0) return mpf::fail(MPF_E_SHAPE, "relu_bwd_add: numel must be a positive multiple of 8");
+    if (dtype != MPF_BF16) return mpf::fail(MPF_E_DTYPE, "relu_bwd_add: dtype must be MPF_BF16");
+    if (((uintptr_t)ga | (uintptr_t)gb | (uintptr_t)y | (uintptr_t)out) & 15) return mpf::fail(MPF_E_SHAPE, "relu_bwd_add: 16-byte aligned buffers");
+    const int64_t n8 = numel / 8;
+    const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    mpf::set_kernel("relu_bwd_add_bf16_kernel");
+    if (gb)
+        hipLaunchKernelGGL(relu_bwd_add_bf16_kernel<true>, dim3(blocks), dim3(256), 0, st, (const bf16x8*)ga, (const bf16x8*)gb,
+                           (const bf16x8*)y, (bf16x8*)out, n8);
+    else
+        hipLaunchKernelGGL(relu_bwd_add_bf16_kernel<false>, dim3(blocks), dim3(256), 0, st, (const bf16x8*)ga, (const bf16x8*)gb,
+                           (const bf16x8*)y, (bf16x8*)out, n8);
+    return mpf::check(hipGetLastError(), "mpf_relu_bwd_add");
+}
 
 extern "C" int mpf_bias_act(const void* x, const float* bias, const void* res, void* y, int64_t numel, int C, int dtype,
                             int relu, void* stream)

@@ -87,3 +87,44 @@ def test_grouped_fold_cast_matches_foreach(channels_last, dtype):
         assert o.dtype == (dtype or torch.float32) and o.shape == w.shape and o.stride() == w.stride()
         assert torch.equal(o, ref)
         assert torch.equal(w.grad, g.float() * sc.view(-1, 1, 1, 1))
+
+
+def test_forked_block_outputs_equal_the_unfused_graph_bitwise():
+    """A stage of bottlenecks under bf16 autocast with the block outputs as two aliases (their gradients summed inside the
+    ReLU-backward pass, csrc/elementwise.hip relu_bwd_add) against the same stage with one output per block (autograd's add
+    kernel + threshold_backward): bit-identical outputs, input gradient and weight gradients; plus the kernel alone."""
+    import mp_former_amd.backbone as bb
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    stage = torch.nn.Sequential(bb.Bottleneck(64, 32, 128, 2), bb.Bottleneck(128, 32, 128, 1), bb.Bottleneck(128, 32, 128, 1)).to(dev)
+    stage.to(memory_format=torch.channels_last)
+    for m in stage.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 2.0); m.running_mean.normal_(); m.weight.uniform_(0.5, 1.5); m.bias.normal_()
+    x0 = torch.randn(2, 64, 24, 20, device=dev).contiguous(memory_format=torch.channels_last)
+    extra = torch.randn(2, 128, 12, 10, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+
+    def run():
+        x = x0.clone().requires_grad_(True)
+        for p in stage.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = bb.run_stages(x.bfloat16(), [("s", stage)])["s"]
+        # two consumers of the stage output, as in the model (next stage + pixel decoder)
+        ((y.float() * y.float()).sum() + (y * extra).float().sum()).backward()
+        return y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in stage.named_parameters()}
+
+    fused = run()
+    orig = bb.bias_act_fork
+    bb.bias_act_fork = lambda x, shift, res: (lambda y: (y, y))(bb.bias_act(x, shift, res, True))
+    try:
+        plain = run()
+    finally:
+        bb.bias_act_fork = orig
+    assert torch.equal(fused[0], plain[0]) and torch.equal(fused[1], plain[1])
+    for n in fused[2]:
+        assert torch.equal(fused[2][n], plain[2][n]), n
+    ga, gb = (torch.randn(2, 128, 12, 10, device=dev).bfloat16().contiguous(memory_format=torch.channels_last) for _ in range(2))
+    y = fused[0]
+    assert torch.equal(bb._relu_bwd_add(ga, gb, y), torch.ops.aten.threshold_backward(ga + gb, y, 0))
+    assert torch.equal(bb._relu_bwd_add(ga, None, y), torch.ops.aten.threshold_backward(ga, y, 0))
