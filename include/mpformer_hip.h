@@ -844,6 +844,11 @@ int mpf_bias_act(const void* x, const float* bias, const void* res, void* y, int
  * of the two gradients that reach the block's output folded in: out = y > 0 ? round_bf16(ga + gb) : 0 (gb may be NULL) — aten's
  * add + threshold_backward in one pass.  bf16, numel % 8 == 0, 16-byte aligned, same (dense) layout for all four tensors. */
 int mpf_relu_bwd_add(const void* ga, const void* gb, const void* y, void* out, int64_t numel, int dtype, void* stream);
+/* 3 x 3 / stride 2 / padding 1 max pooling of the ResNet stem (detectron2 BasicStem) on a channel-last bf16 activation x [N, H, W, C]
+ * -> y [N, OH, OW, C] (OH = (H - 1) / 2 + 1) with torch.nn.functional.max_pool2d's tie rule (first maximum in window scan order);
+ * code [N, OH, OW, C] bytes = the winner's window position, consumed by the backward (a gather: gx fully written). */
+int mpf_maxpool3x3s2_forward(const void* x, void* y, void* code, int N, int H, int W, int C, void* stream);
+int mpf_maxpool3x3s2_backward(const void* gy, const void* code, void* gx, int N, int H, int W, int C, void* stream);
 
 /*
  * Small host -> device table (item lists of the grouped launches) through the kernel-argument segment: `nbytes` (multiple

@@ -118,6 +118,8 @@ SIGNATURES = {
     "mpf_mask_loss_finalize_backward": (_c_int, [_c_vp, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),
     "mpf_bias_act": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_relu_bwd_add": (_c_int, [_c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp]),
+    "mpf_maxpool3x3s2_forward": (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
+    "mpf_maxpool3x3s2_backward": (_c_int, [_c_vp] * 3 + [_c_int] * 4 + [_c_vp]),
     "mpf_upload_small": (_c_int, [_c_vp, _c_vp, ctypes.c_int64, _c_vp]),
     "mpf_tall_gemm_bf16": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_res_ln256_forward": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, _c_int, ctypes.c_float,

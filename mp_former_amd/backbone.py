@@ -134,6 +134,46 @@ def bias_act_fork(x, shift, res):
     return y, y
 
 
+class _MaxPool3x3s2(torch.autograd.Function):
+    """F.max_pool2d(x, 3, 2, 1) of the stem on a channel-last bf16 activation in native passes (csrc/elementwise.hip): the forward
+    keeps one byte per output element (the winner's window position, aten's tie rule), the backward is a gather over the <= 4
+    windows of an input pixel — aten's nhwc backward at this size is 112 us for a 17 + 67 MB pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        code = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().mpf_maxpool3x3s2_forward(x.data_ptr(), y.data_ptr(), code.data_ptr(), N, H, W, C,
+                                                     torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(rc, "mpf_maxpool3x3s2_forward")
+        ctx.save_for_backward(code)
+        ctx.in_shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (code,) = ctx.saved_tensors
+        N, C, H, W = ctx.in_shape
+        if gy.dtype != torch.bfloat16 or not gy.is_contiguous(memory_format=torch.channels_last):
+            gy = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gx = torch.empty((N, C, H, W), dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
+        with torch.cuda.device(gy.device):
+            rc = _lib.lib().mpf_maxpool3x3s2_backward(gy.data_ptr(), code.data_ptr(), gx.data_ptr(), N, H, W, C,
+                                                      torch.cuda.current_stream(gy.device).cuda_stream)
+        _lib.check(rc, "mpf_maxpool3x3s2_backward")
+        return gx
+
+
+def max_pool_3x3_s2(x):
+    if (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and 256 % (x.shape[1] // 8) == 0
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        return _MaxPool3x3s2.apply(x)
+    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+
 def conv_bn(conv, bn, x, folded=None, res=None, relu=True, fork=False):
     """relu?(FrozenBN(conv(x)) + res) with the fixed per-channel scale folded into the convolution
     weight (w' = w * scale: same function, same gradient wrt w) and shift / residual / ReLU as ONE
@@ -290,7 +330,7 @@ def run_stages(x, stages, stem=None):
     if stem is not None:
         st = ResNet50._fold_group([stem], dtype)
         x = conv_bn(stem[0], stem[1], x, st[0])
-        x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+        x = max_pool_3x3_s2(x)
     out = {}
     for name, stage in stages:
         blocks = list(stage)

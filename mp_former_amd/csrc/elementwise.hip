@@ -77,6 +77,123 @@ __global__ __launch_bounds__(256) void relu_bwd_add_bf16_kernel(const bf16x8* __
 
 }  // namespace
 
+namespace {
+// 3 x 3 / stride 2 / padding 1 max pooling of the ResNet stem on a channel-last bf16 activation (torch.nn.functional.max_pool2d's
+// semantics: the FIRST maximum of the window in (kh, kw) scan order wins, NaN propagates).  The forward keeps the winner's
+// window position (0..8) as one byte per output element; the backward is a gather over the <= 4 windows that contain an input
+// pixel (no atomics, fp32 sum in aten's (oh, ow) order).  8 channels (16 B) per thread.
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ y,
+                                                               uint2* __restrict__ code, int N, int H, int W, int C8, int OH, int OW)
+{
+    // block = (32 * 8 / C8... ) output pixels of one output row: thread -> (pixel, 8-channel group), no 64-bit divisions
+    const int per = 256 / C8;                      // output pixels per block (C8 divides 256: checked by the caller)
+    const int c = threadIdx.x % C8, ow = blockIdx.x * per + threadIdx.x / C8;
+    const int oh = blockIdx.y, n = blockIdx.z;
+    if (ow < OW) {
+        const int64_t i = (((int64_t)n * OH + oh) * OW + ow) * C8 + c;
+        // aten: maxval = -inf, maxidx = the window's first in-range position, then `val > maxval || isnan(val)` in scan order.
+        // All nine loads are issued unconditionally on clamped coordinates (a load behind a branch is waited for on its own)
+        // and positions outside the image are masked out of the update.
+        float best[8];
+        unsigned arg[8];
+        const unsigned first = (unsigned)((oh == 0 ? 3 : 0) + (ow == 0 ? 1 : 0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; arg[j] = first; }
+        bf16x8 v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int h = min(max(2 * oh - 1 + k / 3, 0), H - 1), w = min(max(2 * ow - 1 + k % 3, 0), W - 1);
+            v[k] = x[(((int64_t)n * H + h) * W + w) * C8 + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int h = 2 * oh - 1 + k / 3, w = 2 * ow - 1 + k % 3;
+            const bool valid = h >= 0 && h < H && w >= 0 && w < W;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = (float)v[k][j];
+                const bool upd = valid && (f > best[j] || f != f);
+                best[j] = upd ? f : best[j];
+                arg[j] = upd ? (unsigned)k : arg[j];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)best[j];
+        y[i] = o;
+        code[i] = make_uint2(arg[0] | (arg[1] << 8) | (arg[2] << 16) | ((unsigned)arg[3] << 24),
+                             arg[4] | (arg[5] << 8) | (arg[6] << 16) | ((unsigned)arg[7] << 24));
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16x8* __restrict__ gy, const uint2* __restrict__ code,
+                                                               bf16x8* __restrict__ gx, int N, int H, int W, int C8, int OH, int OW)
+{
+    const int per = 256 / C8;
+    const int c = threadIdx.x % C8, w = blockIdx.x * per + threadIdx.x / C8;
+    const int h = blockIdx.y, n = blockIdx.z;
+    if (w < W) {
+        const int64_t i = (((int64_t)n * H + h) * W + w) * C8 + c;
+        // windows oh with 2 oh - 1 <= h <= 2 oh + 1 (and likewise ow): h / 2 and, for odd h, (h + 1) / 2 — requested together
+        // on clamped indices, the absent ones masked (aten's accumulation order: oh outer, ow inner, fp32)
+        const int ohs[2] = {h >> 1, min((h + 1) >> 1, OH - 1)}, ows[2] = {w >> 1, min((w + 1) >> 1, OW - 1)};
+        const bool vh[2] = {(h >> 1) < OH, (h & 1) && ((h + 1) >> 1) < OH}, vw[2] = {(w >> 1) < OW, (w & 1) && ((w + 1) >> 1) < OW};
+        uint2 cd[4];
+        bf16x8 g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t o = (((int64_t)n * OH + min(ohs[k >> 1], OH - 1)) * OW + min(ows[k & 1], OW - 1)) * C8 + c;
+            cd[k] = code[o];
+            g[k] = gy[o];
+        }
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oh = ohs[k >> 1], ow = ows[k & 1];
+            const bool valid = vh[k >> 1] && vw[k & 1];
+            const unsigned me = (unsigned)((h - (2 * oh - 1)) * 3 + (w - (2 * ow - 1)));      // this pixel's position in that window
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned a = ((j < 4 ? cd[k].x : cd[k].y) >> (8 * (j & 3))) & 0xFFu;
+                if (valid && a == me) acc[j] += (float)g[k][j];
+            }
+        }
+        bf16x8 o8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = (__bf16)acc[j];
+        gx[i] = o8;
+    }
+}
+}  // namespace
+
+extern "C" int mpf_maxpool3x3s2_forward(const void* x, void* y, void* code, int N, int H, int W, int C, void* stream)
+{
+    if (!x || !y || !code) return mpf::fail(MPF_E_NULL, "maxpool3x3s2_forward: NULL buffer");
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return mpf::fail(MPF_E_SHAPE, "maxpool3x3s2_forward: C must be a positive multiple of 8");
+    if (((uintptr_t)x | (uintptr_t)y) & 15 || ((uintptr_t)code & 7)) return mpf::fail(MPF_E_SHAPE, "maxpool3x3s2_forward: 16-byte aligned buffers");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    if (256 % (C / 8) || OH > 65535 || N > 65535) return mpf::fail(MPF_E_SHAPE, "maxpool3x3s2_forward: C / 8 must divide 256; OH, N <= 65535");
+    const int per = 256 / (C / 8);
+    mpf::set_kernel("maxpool3x3s2_fwd_kernel");
+    hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3((OW + per - 1) / per, OH, N), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)x, (bf16x8*)y, (uint2*)code,
+                       N, H, W, C / 8, OH, OW);
+    return mpf::check(hipGetLastError(), "mpf_maxpool3x3s2_forward");
+}
+
+extern "C" int mpf_maxpool3x3s2_backward(const void* gy, const void* code, void* gx, int N, int H, int W, int C, void* stream)
+{
+    if (!gy || !gx || !code) return mpf::fail(MPF_E_NULL, "maxpool3x3s2_backward: NULL buffer");
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return mpf::fail(MPF_E_SHAPE, "maxpool3x3s2_backward: C must be a positive multiple of 8");
+    if (((uintptr_t)gx | (uintptr_t)gy) & 15 || ((uintptr_t)code & 7)) return mpf::fail(MPF_E_SHAPE, "maxpool3x3s2_backward: 16-byte aligned buffers");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    if (256 % (C / 8) || H > 65535 || N > 65535) return mpf::fail(MPF_E_SHAPE, "maxpool3x3s2_backward: C / 8 must divide 256; H, N <= 65535");
+    const int per = 256 / (C / 8);
+    mpf::set_kernel("maxpool3x3s2_bwd_kernel");
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((W + per - 1) / per, H, N), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)gy, (const uint2*)code,
+                       (bf16x8*)gx, N, H, W, C / 8, OH, OW);
+    return mpf::check(hipGetLastError(), "mpf_maxpool3x3s2_backward");
+}
+
 extern "C" int mpf_relu_bwd_add(const void* ga, const void* gb, const void* y, void* out, int64_t numel, int dtype, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;

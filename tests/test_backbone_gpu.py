@@ -92,7 +92,8 @@ def test_grouped_fold_cast_matches_foreach(channels_last, dtype):
 def test_forked_block_outputs_equal_the_unfused_graph_bitwise():
     """A stage of bottlenecks under bf16 autocast with the block outputs as two aliases (their gradients summed inside the
     ReLU-backward pass, csrc/elementwise.hip relu_bwd_add) against the same stage with one output per block (autograd's add
-    kernel + threshold_backward): bit-identical outputs, input gradient and weight gradients; plus the kernel alone."""
+    kernel + threshold_backward): bit-identical outputs and input gradient, weight gradients to MIOpen's own run-to-run noise;
+    plus the kernel alone."""
     import mp_former_amd.backbone as bb
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
@@ -122,9 +123,29 @@ def test_forked_block_outputs_equal_the_unfused_graph_bitwise():
     finally:
         bb.bias_act_fork = orig
     assert torch.equal(fused[0], plain[0]) and torch.equal(fused[1], plain[1])
-    for n in fused[2]:
-        assert torch.equal(fused[2][n], plain[2][n]), n
+    for n in fused[2]:      # (MIOpen's split-K weight-gradient kernels add with atomics: not bit-reproducible run to run)
+        torch.testing.assert_close(fused[2][n], plain[2][n], rtol=2e-3, atol=2e-3 * float(plain[2][n].abs().max()))
     ga, gb = (torch.randn(2, 128, 12, 10, device=dev).bfloat16().contiguous(memory_format=torch.channels_last) for _ in range(2))
     y = fused[0]
     assert torch.equal(bb._relu_bwd_add(ga, gb, y), torch.ops.aten.threshold_backward(ga + gb, y, 0))
     assert torch.equal(bb._relu_bwd_add(ga, None, y), torch.ops.aten.threshold_backward(ga, y, 0))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 48), (1, 8, 7, 9), (2, 16, 5, 5), (1, 64, 33, 32)])
+def test_native_maxpool_equals_aten_bitwise(shape):
+    """max_pool_3x3_s2 (csrc/elementwise.hip) == F.max_pool2d(x, 3, 2, 1) on channel-last bf16, forward and backward, including
+    the tie rule: post-ReLU inputs (runs of equal zeros) and a NaN"""
+    from mp_former_amd.backbone import max_pool_3x3_s2
+    dev = torch.device("cuda:0")
+    torch.manual_seed(sum(shape))
+    x = torch.relu(torch.randn(shape, device=dev)).bfloat16().contiguous(memory_format=torch.channels_last)
+    x[0, 0, 1, 1] = float("nan")
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    ya, yb = max_pool_3x3_s2(a), F.max_pool2d(b, 3, 2, 1)
+    assert ya.shape == yb.shape and ya.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(torch.nan_to_num(ya.float(), nan=-7.0), torch.nan_to_num(yb.float(), nan=-7.0))
+    g = torch.randn_like(yb)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.equal(a.grad, b.grad)
