@@ -959,9 +959,8 @@ extern "C" int mpf_attn_forward_kv(const void* q, const void* k, int64_t k_row_s
     {
         const dim3 grid(qtiles * p.splits, H, N), block(64 * p.nw);
         const bool al = (Lk & 7) == 0 && ((uintptr_t)p.vt & 15) == 0 && (!mask || ((uintptr_t)mask & 7) == 0);
+        static_assert(kMaxNW * kMergeWave * sizeof(float) <= 64 * 1024, "the merge buffer fits the default dynamic-LDS limit");
         auto launch = [&](auto kfn) -> int {
-            if (int e = mpf::check(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                                   "hipFuncSetAttribute")) return e;
             hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
             return 0;
         };
@@ -1067,9 +1066,8 @@ extern "C" int mpf_attn_backward_kv_aux(const void* q, const void* k, const void
         const dim3 grid(qtiles * p.splits, H, N), block(64 * p.nw);
         const size_t lds = (size_t)p.nw * 32 * kMergePitch * sizeof(float);
         const bool al = (Lk & 7) == 0 && ((uintptr_t)p.kT & 15) == 0 && (!mask || ((uintptr_t)mask & 7) == 0);
+        static_assert(kMaxNW * kMergeWave * sizeof(float) <= 64 * 1024, "the merge buffer fits the default dynamic-LDS limit");
         auto launch = [&](auto kfn) -> int {
-            if (int e = mpf::check(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                                   "hipFuncSetAttribute")) return e;
             hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
             return 0;
         };

@@ -14,6 +14,20 @@ void set_kernel(const char* name);
 // launch profiler (mpf_profile_enable): events on the launch stream around the kernel only
 void prof_begin(hipStream_t st);
 void prof_end(const char* name, hipStream_t st, double algorithmic_bytes, double flops = 0.0);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) and size class instead of before every launch: the
+// call takes a runtime lock (~10-30 us of launch-thread time each, 55 per training step when issued per launch).  The attribute
+// is per device, so the high-water mark is kept per device ordinal; `slots` is the call site's own static array.
+constexpr int kMaxDevices = 32;
+struct LdsAttr { int bytes[kMaxDevices] = {}; };
+inline int ensure_dynamic_lds(const void* fn, size_t bytes, LdsAttr& slots)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
+    if (dev >= 0 && slots.bytes[dev] >= (int)bytes) return 0;
+    if (int e = check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), "hipFuncSetAttribute")) return e;
+    if (dev >= 0) slots.bytes[dev] = (int)bytes;
+    return 0;
+}
 // per-subsystem option hooks: return 0 if handled, 1 if the key is not theirs, <0 on bad value
 int set_msda_option(const char* key, int v);
 int set_binned_option(const char* key, int v);

@@ -609,7 +609,8 @@ int launch_tall_ws(const void* a, int64_t lda, const void* b, int64_t ldb, const
     gy = gy < 1u ? 1u : (gy > (unsigned)ntiles ? (unsigned)ntiles : gy);
     {
         const void* fn = bias ? (const void*)tall_ws_bf16_kernel<KS, NB, MB, NBUF, true> : (const void*)tall_ws_bf16_kernel<KS, NB, MB, NBUF, false>;
-        if (int e = mpf::check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute")) return e;
+        static mpf::LdsAttr attr[2];       // (per instantiation of this launcher: with / without bias)
+        if (int e = mpf::ensure_dynamic_lds(fn, lds, attr[bias ? 1 : 0])) return e;
     }
     if (bias)
         hipLaunchKernelGGL((tall_ws_bf16_kernel<KS, NB, MB, NBUF, true>), dim3(gx, gy), dim3(256), lds, st, (const __bf16*)a, lda,
