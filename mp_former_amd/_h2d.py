@@ -31,8 +31,8 @@ def upload(data, device, dtype=None):
         from . import _lib
         t = t.contiguous()
         out = torch.empty(t.shape, dtype=t.dtype, device=device)
-        with torch.cuda.device(device):
-            code = _lib.lib().mpf_upload_small(t.data_ptr(), out.data_ptr(), nbytes, torch.cuda.current_stream(device).cuda_stream)
+        with _lib.device_guard(device):
+            code = _lib.lib().mpf_upload_small(t.data_ptr(), out.data_ptr(), nbytes, _lib.stream_ptr(device))
         _lib.check(code, "mpf_upload_small")
         return out
     return t.pin_memory().to(device, non_blocking=True)

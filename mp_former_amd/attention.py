@@ -39,10 +39,10 @@ class _AttnCore(Function):
             raise RuntimeError("native attention supports head_dim 32 (NHEADS 8 x HIDDEN_DIM 256)")
         qb, kb, vb = (t.to(torch.bfloat16).contiguous() for t in (q, k, v))
         lib = _lib.lib()
-        stream = torch.cuda.current_stream(q.device).cuda_stream
+        stream = _lib.stream_ptr(q.device)
         kt = torch.empty((N, E, Lk), dtype=torch.bfloat16, device=q.device)      # K^T is for the backward
         vt = torch.empty((N, E, Lk), dtype=torch.bfloat16, device=q.device)
-        with torch.cuda.device(q.device):
+        with _lib.device_guard(q.device):
             _lib.check(lib.mpf_attn_transpose2(kb.data_ptr(), vb.data_ptr(), kt.data_ptr(), vt.data_ptr(), Lk, Lk, N, E, stream),
                        "mpf_attn_transpose2")
         m = None
@@ -52,7 +52,7 @@ class _AttnCore(Function):
         out = torch.empty((Lq, N, E), dtype=torch.bfloat16, device=q.device)
         lse = torch.empty((N, nheads, Lq), dtype=torch.float32, device=q.device)
         ws = _workspace(q.device, lib.mpf_attn_workspace_bytes(Lq, Lk, N, nheads))
-        with torch.cuda.device(q.device):
+        with _lib.device_guard(q.device):
             code = lib.mpf_attn_forward(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), m.data_ptr() if m is not None else None,
                                         1 if (m is not None and m.dim() == 3) else 0, out.data_ptr(), lse.data_ptr(),
                                         Lq, Lk, N, nheads, hd, 1.0 / math.sqrt(hd), ws.data_ptr(), ws.numel(), stream)
@@ -72,7 +72,7 @@ class _AttnCore(Function):
         dev = qb.device
         gob = go.to(torch.bfloat16).contiguous()
         lib = _lib.lib()
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         LqP = (Lq + 31) // 32 * 32
         delta = torch.empty((N, H, Lq), dtype=torch.float32, device=dev)
         qT = torch.empty((N, E, LqP), dtype=torch.bfloat16, device=dev)
@@ -81,7 +81,7 @@ class _AttnCore(Function):
         dk = torch.empty_like(kb)
         dv = torch.empty_like(vb)
         ws = _workspace(dev, lib.mpf_attn_workspace_bytes(Lq, Lk, N, H))
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             _lib.check(lib.mpf_attn_bwd_prep(qb.data_ptr(), gob.data_ptr(), out.data_ptr(), qT.data_ptr(), doT.data_ptr(),
                                              delta.data_ptr(), Lq, LqP, N, H, stream), "mpf_attn_bwd_prep")      # Q^T, dO^T, delta
             code = lib.mpf_attn_backward(qb.data_ptr(), kb.data_ptr(), vb.data_ptr(), kT.data_ptr(), qT.data_ptr(),

@@ -51,7 +51,7 @@ class _BiasAct(torch.autograd.Function):
         C = x.shape[1]
         code = _lib.lib().mpf_bias_act(x.data_ptr(), shift.data_ptr(), res.data_ptr() if res is not None else None,
                                        y.data_ptr(), x.numel(), C, _lib.MPF_BF16 if x.dtype == torch.bfloat16 else _lib.MPF_F32,
-                                       1 if relu else 0, torch.cuda.current_stream(x.device).cuda_stream)
+                                       1 if relu else 0, _lib.stream_ptr(x.device))
         _lib.check(code, "mpf_bias_act")
         ctx.relu, ctx.has_res = relu, res is not None
         if relu:
@@ -74,9 +74,9 @@ def _relu_bwd_add(ga, gb, y):
     if not (ga.is_cuda and same):
         return torch.ops.aten.threshold_backward(ga if gb is None else ga + gb, y, 0)
     out = torch.empty_like(y)
-    with torch.cuda.device(y.device):
+    with _lib.device_guard(y.device):
         code = _lib.lib().mpf_relu_bwd_add(ga.data_ptr(), gb.data_ptr() if gb is not None else None, y.data_ptr(), out.data_ptr(),
-                                           y.numel(), _lib.MPF_BF16, torch.cuda.current_stream(y.device).cuda_stream)
+                                           y.numel(), _lib.MPF_BF16, _lib.stream_ptr(y.device))
     _lib.check(code, "mpf_relu_bwd_add")
     return out
 
@@ -92,7 +92,7 @@ class _BiasActFork(torch.autograd.Function):
         y = torch.empty_like(x)
         code = _lib.lib().mpf_bias_act(x.data_ptr(), shift.data_ptr(), res.data_ptr(), y.data_ptr(), x.numel(), x.shape[1],
                                        _lib.MPF_BF16 if x.dtype == torch.bfloat16 else _lib.MPF_F32, 1,
-                                       torch.cuda.current_stream(x.device).cuda_stream)
+                                       _lib.stream_ptr(x.device))
         _lib.check(code, "mpf_bias_act")
         ctx.save_for_backward(y)
         ctx.set_materialize_grads(False)
@@ -145,9 +145,9 @@ class _MaxPool3x3s2(torch.autograd.Function):
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         y = torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         code = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             rc = _lib.lib().mpf_maxpool3x3s2_forward(x.data_ptr(), y.data_ptr(), code.data_ptr(), N, H, W, C,
-                                                     torch.cuda.current_stream(x.device).cuda_stream)
+                                                     _lib.stream_ptr(x.device))
         _lib.check(rc, "mpf_maxpool3x3s2_forward")
         ctx.save_for_backward(code)
         ctx.in_shape = (N, C, H, W)
@@ -160,9 +160,9 @@ class _MaxPool3x3s2(torch.autograd.Function):
         if gy.dtype != torch.bfloat16 or not gy.is_contiguous(memory_format=torch.channels_last):
             gy = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         gx = torch.empty((N, C, H, W), dtype=gy.dtype, device=gy.device, memory_format=torch.channels_last)
-        with torch.cuda.device(gy.device):
+        with _lib.device_guard(gy.device):
             rc = _lib.lib().mpf_maxpool3x3s2_backward(gy.data_ptr(), code.data_ptr(), gx.data_ptr(), N, H, W, C,
-                                                      torch.cuda.current_stream(gy.device).cuda_stream)
+                                                      _lib.stream_ptr(gy.device))
         _lib.check(rc, "mpf_maxpool3x3s2_backward")
         return gx
 
@@ -212,9 +212,9 @@ def _grouped_scale_cast(srcs, scales, out_dtype):
         blk += (numels[i] + 2047) // 2048
     items = upload(table.reshape(-1), dev)
     dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         code = _lib.lib().mpf_grouped_scale_cast(items.data_ptr(), len(srcs), blk, dt[srcs[0].dtype], dt[out_dtype],
-                                                 torch.cuda.current_stream(dev).cuda_stream)
+                                                 _lib.stream_ptr(dev))
     _lib.check(code, "mpf_grouped_scale_cast")
     return [out[o:o + n].as_strided(t.shape, t.stride()) for o, n, t in zip(offs, numels, srcs)]
 

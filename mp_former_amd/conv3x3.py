@@ -39,12 +39,12 @@ class _Conv3x3Fn(Function):
         w2 = weight.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
         w2t = weight.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout)
         y = _planes(N, Cout, H, W, x.device)
-        st = torch.cuda.current_stream(x.device).cuda_stream
+        st = _lib.stream_ptr(x.device)
         h2 = Cout % 256 == 0 and Cin % 256 == 0          # the fp16 x 2 form (two-pass tiles both ways)
         if h2:
             (pf, pf_am), (pb, pb_am) = split_weights_grouped_h2([([w2.contiguous()], False), ([w2t.contiguous()], False)])
             x_am = amax(x.permute(0, 2, 3, 1))           # (the planes are dense in this order)
-            with torch.cuda.device(x.device):
+            with _lib.device_guard(x.device):
                 code = _lib.lib().mpf_gemm3_conv3x3_h2(x.data_ptr(), x_am.data_ptr(), pf.data_ptr(), pf_am.data_ptr(),
                                                        bias.data_ptr() if bias is not None else None, y.data_ptr(), None,
                                                        N, H, W, Cin, Cout, 0, st)
@@ -52,7 +52,7 @@ class _Conv3x3Fn(Function):
             ctx.save_for_backward(x, weight, pb, pb_am, x_am)
         else:
             pf, pb = split_weights_grouped([([w2.contiguous()], False), ([w2t.contiguous()], False)])
-            with torch.cuda.device(x.device):
+            with _lib.device_guard(x.device):
                 code = _lib.lib().mpf_gemm3_conv3x3(x.data_ptr(), pf.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                                     N, H, W, Cin, Cout, 0, st)
             _lib.check(code, "mpf_gemm3_conv3x3")
@@ -71,11 +71,11 @@ class _Conv3x3Fn(Function):
         if not (is_cl_plane(gy) and gy.stride(0) == H * W * Cout):
             gy = gy.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
         dx = dw = db = None
-        st = torch.cuda.current_stream(x.device).cuda_stream
+        st = _lib.stream_ptr(x.device)
         gy_am = amax(gy.permute(0, 2, 3, 1)) if ctx.h2 else None
         if ctx.needs_input_grad[0]:
             dx = _planes(N, Cin, H, W, x.device)
-            with torch.cuda.device(x.device):
+            with _lib.device_guard(x.device):
                 if ctx.h2:
                     code = _lib.lib().mpf_gemm3_conv3x3_h2(gy.data_ptr(), gy_am.data_ptr(), pb.data_ptr(), pb_am.data_ptr(), None,
                                                            dx.data_ptr(), None, N, H, W, Cout, Cin, 1, st)
@@ -104,14 +104,14 @@ def _wgrad_native(gy, x, N, H, W, Cin, Cout, has_bias, amax_ab=None):
     ns = -(-R // rps)
     c = torch.empty((ns, Cout, 9 * Cin), dtype=torch.float32, device=x.device)
     ca = torch.empty((ns, Cout), dtype=torch.float32, device=x.device) if has_bias else None
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         if amax_ab is not None:
             code = _lib.lib().mpf_gemm3_conv3x3_wgrad_h2(gy.data_ptr(), amax_ab[0].data_ptr(), x.data_ptr(), amax_ab[1].data_ptr(), c.data_ptr(),
                                                          ca.data_ptr() if has_bias else None, N, H, W, Cin, Cout, rps,
-                                                         torch.cuda.current_stream(x.device).cuda_stream)
+                                                         _lib.stream_ptr(x.device))
         else:
             code = _lib.lib().mpf_gemm3_conv3x3_wgrad(gy.data_ptr(), x.data_ptr(), c.data_ptr(), ca.data_ptr() if has_bias else None, N, H, W,
-                                                      Cin, Cout, rps, torch.cuda.current_stream(x.device).cuda_stream)
+                                                      Cin, Cout, rps, _lib.stream_ptr(x.device))
     _lib.check(code, "mpf_gemm3_conv3x3_wgrad")
     dw2, db = nt_reduce(c, ca)
     return dw2.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), db

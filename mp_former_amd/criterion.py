@@ -74,11 +74,11 @@ class _ClassLossFn(torch.autograd.Function):
         weight = weight.float().contiguous()
         lse = torch.empty((3, L, N * Q), dtype=torch.float32, device=dev)    # log-sum-exp of the rows + the kernel's row scratch
         out = torch.empty((2, L), dtype=torch.float32, device=dev)           # ce, wsum
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             code = _lib.lib().mpf_class_loss_forward(
                 logits.data_ptr(), _DT[logits.dtype], logits.stride(0), logits.stride(1), logits.stride(2), target.data_ptr(),
                 per_output, weight.data_ptr(), L, N, Q, C, lse.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
-                torch.cuda.current_stream(dev).cuda_stream)
+                _lib.stream_ptr(dev))
         _lib.check(code, "mpf_class_loss_forward")
         ctx.save_for_backward(logits, target, weight, lse, out)
         ctx.per_output = per_output
@@ -91,11 +91,11 @@ class _ClassLossFn(torch.autograd.Function):
         dev = logits.device
         g = g.float().contiguous()
         d = torch.empty((L, N, Q, C), dtype=logits.dtype, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             code = _lib.lib().mpf_class_loss_backward(
                 logits.data_ptr(), _DT[logits.dtype], logits.stride(0), logits.stride(1), logits.stride(2), target.data_ptr(),
                 ctx.per_output, weight.data_ptr(), L, N, Q, C, lse.data_ptr(), out[1].data_ptr(), g.data_ptr(), d.data_ptr(),
-                torch.cuda.current_stream(dev).cuda_stream)
+                _lib.stream_ptr(dev))
         _lib.check(code, "mpf_class_loss_backward")
         return d, None, None
 
@@ -109,9 +109,9 @@ class _MaskLossFinalizeFn(torch.autograd.Function):
         n, G = sums.shape[0], norm.shape[0]
         sums = sums.contiguous()
         out = torch.empty((2, G), dtype=torch.float32, device=sums.device)
-        with torch.cuda.device(sums.device):
+        with _lib.device_guard(sums.device):
             code = _lib.lib().mpf_mask_loss_finalize(sums.data_ptr(), runs.data_ptr(), norm.data_ptr(), n, G, points, out.data_ptr(),
-                                                     torch.cuda.current_stream(sums.device).cuda_stream)
+                                                     _lib.stream_ptr(sums.device))
         _lib.check(code, "mpf_mask_loss_finalize")
         ctx.save_for_backward(sums, runs, norm)
         ctx.points = points
@@ -123,10 +123,10 @@ class _MaskLossFinalizeFn(torch.autograd.Function):
         n, G = sums.shape[0], norm.shape[0]
         g = g.float().contiguous()
         d = torch.empty_like(sums)
-        with torch.cuda.device(sums.device):
+        with _lib.device_guard(sums.device):
             code = _lib.lib().mpf_mask_loss_finalize_backward(sums.data_ptr(), runs.data_ptr(), norm.data_ptr(), n, G, ctx.points,
                                                               g.data_ptr(), d.data_ptr(),
-                                                              torch.cuda.current_stream(sums.device).cuda_stream)
+                                                              _lib.stream_ptr(sums.device))
         _lib.check(code, "mpf_mask_loss_finalize_backward")
         return d, None, None, None
 

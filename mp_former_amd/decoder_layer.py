@@ -165,8 +165,8 @@ class DecoderLayerFn(Function):
                                    lib.mpf_decoder_layer_scratch_bytes(Qt, N, nheads, S, F_, 1)))
         ws = _attn_workspace(dev, max(lib.mpf_attn_workspace_bytes(Qt, S, N, nheads), lib.mpf_attn_workspace_bytes(Qt, Qt, N, nheads)))
         L.scratch, L.scratch_bytes, L.attn_ws, L.attn_ws_bytes = sc.data_ptr(), sc.numel(), ws.data_ptr(), ws.numel()
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        stream = _lib.stream_ptr(dev)
+        with _lib.device_guard(dev):
             code = lib.mpf_decoder_layer_forward(ctypes.byref(L), stream)
         _lib.check(code, "mpf_decoder_layer_forward")
         ctx.save_for_backward(xb0, k_c, v_c, mask_c, mask_s, arena, *params)
@@ -221,8 +221,8 @@ class DecoderLayerFn(Function):
         sc = _scratch_buf(dev, lib.mpf_decoder_layer_scratch_bytes(Qt, N, H, S, F_, 1))
         ws = _attn_workspace(dev, max(lib.mpf_attn_workspace_bytes(Qt, S, N, H), lib.mpf_attn_workspace_bytes(Qt, Qt, N, H)))
         L.scratch, L.scratch_bytes, L.attn_ws, L.attn_ws_bytes = sc.data_ptr(), sc.numel(), ws.data_ptr(), ws.numel()
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        stream = _lib.stream_ptr(dev)
+        with _lib.device_guard(dev):
             code = lib.mpf_decoder_layer_backward(ctypes.byref(L), ctypes.byref(G), stream)
         _lib.check(code, "mpf_decoder_layer_backward")
         grads, wi, li = [], 0, 0

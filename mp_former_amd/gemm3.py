@@ -10,7 +10,7 @@ from . import _lib
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _lib.stream_ptr(t.device)
 
 
 def split_weight(w, transpose=False):
@@ -50,7 +50,7 @@ def split_weights_grouped(groups):
             r0 += t.shape[0]
         outs.append(buf[off:off + 3 * n].view((3, K, R) if tr else (3, R, K)))
     items = upload(np.asarray(rows_tab, dtype=np.int64).reshape(-1), dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         code = _lib.lib().mpf_gemm3_split_grouped(items.data_ptr(), len(rows_tab), blk, _stream(buf))
     _lib.check(code, "mpf_gemm3_split_grouped")
     return outs
@@ -74,7 +74,7 @@ def amax(t, out=None):
     assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
     if out is None:
         out = torch.zeros(AMAX_SLOT, dtype=torch.float32, device=t.device)
-    with torch.cuda.device(t.device):
+    with _lib.device_guard(t.device):
         code = _lib.lib().mpf_amax_f32(t.data_ptr(), t.numel(), out.data_ptr(), _stream(t))
     _lib.check(code, "mpf_amax_f32")
     return out
@@ -119,7 +119,7 @@ def split_weights_grouped_h2(groups):
             r0 += t.shape[0]
         outs.append((buf[off:off + 2 * n].view((2, K, R) if tr else (2, R, K)), slots[slot_src]))
     both = upload(np.asarray([x for row in am_tab for x in row] + [x for row in sp_tab for x in row], dtype=np.int64), dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         code = _lib.lib().mpf_amax_f32_grouped(both.data_ptr(), len(am_tab), ablk, _stream(buf))
         _lib.check(code, "mpf_amax_f32_grouped")
         code = _lib.lib().mpf_gemm3_split_grouped_h2(both.data_ptr() + 8 * 4 * len(am_tab), len(sp_tab), sblk, _stream(buf))
@@ -136,7 +136,7 @@ def gemm3_h2(a, a_amax, planes, w_amax, bias=None, cin=None, cin2=None, gate=Non
     N = planes.shape[1]
     assert planes.shape[2] == K
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with _lib.device_guard(a.device):
         code = _lib.lib().mpf_gemm3_tn_h2(
             a.data_ptr(), a.stride(0), a_amax.data_ptr(), planes.data_ptr(), w_amax.data_ptr(), _p(bias),
             _p(cin), _rows(cin, N) if cin is not None else 0, _p(cin2), _rows(cin2, N) if cin2 is not None else 0,
@@ -167,7 +167,7 @@ def gemm3(a, planes, bias=None, a2=None, cin=None, cin2=None, gate=None, relu=Fa
         assert a2.dtype == torch.float32 and a2.dim() == 2 and a2.is_contiguous() and a2.shape[1] == K
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
-    with torch.cuda.device(a.device):
+    with _lib.device_guard(a.device):
         code = _lib.lib().mpf_gemm3_tn(
             a.data_ptr(), a.stride(0), _p(a2), a2.shape[0] if a2 is not None else 0, planes.data_ptr(), _p(bias),
             _p(cin), _rows(cin, N) if cin is not None else 0, _p(cin2), _rows(cin2, N) if cin2 is not None else 0,
@@ -204,7 +204,7 @@ def gemm3_nt(a, b, rows_per_split, b2=None, want_csum_a=False, want_csum_b=False
     cb = torch.empty((ns, N), dtype=torch.float32, device=a.device) if want_csum_b else None
     if b2 is not None:
         assert b2.dtype == torch.float32 and b2.dim() == 2 and b2.stride(1) == 1 and b2.shape[1] == N
-    with torch.cuda.device(a.device):
+    with _lib.device_guard(a.device):
         if amax_ab is not None:
             assert b2 is None
             code = _lib.lib().mpf_gemm3_nt_h2(
@@ -247,7 +247,7 @@ def gemm3_nt_grouped(pairs, rows_per_split, amax_pairs=None):
         else:
             items[i] = (g.data_ptr(), g.stride(0), amax_pairs[i][0].data_ptr(), x.data_ptr(), x.stride(0), amax_pairs[i][1].data_ptr(),
                         base + 4 * o, base + 4 * (o + M * N), M, N)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         fn = _lib.lib().mpf_gemm3_nt_grouped if amax_pairs is None else _lib.lib().mpf_gemm3_nt_grouped_h2
         code = fn(items.ctypes.data, len(pairs), R, rows_per_split, tot, _stream(part))
     _lib.check(code, "mpf_gemm3_nt_grouped")
@@ -266,7 +266,7 @@ def nt_reduce(c_part, s_part=None):
     s = torch.empty(s_part.shape[1:], dtype=torch.float32, device=c_part.device) if s_part is not None else None
     if c.numel() % 4 or (s is not None and s.numel() % 4):
         return c_part.sum(0), (s_part.sum(0) if s_part is not None else None)
-    with torch.cuda.device(c_part.device):
+    with _lib.device_guard(c_part.device):
         code = _lib.lib().mpf_gemm3_nt_reduce(c_part.data_ptr(), c.numel(), _p(s_part), s.numel() if s is not None else 0, ns,
                                               c.data_ptr(), _p(s), _stream(c_part))
     _lib.check(code, "mpf_gemm3_nt_reduce")
@@ -282,7 +282,7 @@ def nt_reduce_levels(c_part, s_part, level_of_split, n_levels):
     lvl = torch.empty((n_levels, n), dtype=torch.float32, device=c_part.device)
     s = torch.empty((n,), dtype=torch.float32, device=c_part.device)
     assert level_of_split.dtype == torch.int64 and level_of_split.numel() == ns and c.numel() % 4 == 0 and n % 4 == 0 and n_levels <= 4
-    with torch.cuda.device(c_part.device):
+    with _lib.device_guard(c_part.device):
         code = _lib.lib().mpf_gemm3_nt_reduce_levels(c_part.data_ptr(), c.numel(), s_part.data_ptr(), n, ns, level_of_split.data_ptr(),
                                                      n_levels, c.data_ptr(), lvl.data_ptr(), s.data_ptr(), _stream(c_part))
     _lib.check(code, "mpf_gemm3_nt_reduce_levels")
@@ -298,7 +298,7 @@ def gemm3_ex(a, planes, bias=None, cin=None, relu=False, out_dtype=torch.float32
     assert planes.shape[2] == K and planes.dtype == torch.bfloat16 and planes.is_contiguous()
     c = torch.empty((M, N), dtype=out_dtype, device=a.device)
     dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}
-    with torch.cuda.device(a.device):
+    with _lib.device_guard(a.device):
         code = _lib.lib().mpf_gemm3_tn_ex(a.data_ptr(), dt[a.dtype], a.stride(0), planes.data_ptr(), _p(bias), _p(cin),
                                           _rows(cin, N) if cin is not None else 0, c.data_ptr(), dt[out_dtype], N, M, N, K,
                                           1 if relu else 0, _stream(a))
@@ -316,7 +316,7 @@ def gemm3_nt_ex(a, b, rows_per_split, want_csum_a=False):
     c = torch.empty((ns, M, N), dtype=torch.float32, device=a.device)
     ca = torch.empty((ns, M), dtype=torch.float32, device=a.device) if want_csum_a else None
     dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}
-    with torch.cuda.device(a.device):
+    with _lib.device_guard(a.device):
         code = _lib.lib().mpf_gemm3_nt_ex(a.data_ptr(), dt[a.dtype], a.stride(0), b.data_ptr(), dt[b.dtype], b.stride(0), c.data_ptr(),
                                           _p(ca), R, M, N, rows_per_split, _stream(a))
     _lib.check(code, "mpf_gemm3_nt_ex")

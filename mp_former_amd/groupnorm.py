@@ -28,9 +28,9 @@ def _workspace(device, nbytes):
 
 def _transpose(src, B, R, C, in_bs=None):
     out = torch.empty(B * R * C, dtype=torch.float32, device=src.device)
-    with torch.cuda.device(src.device):
+    with _lib.device_guard(src.device):
         code = _lib.lib().mpf_transpose_f32(src.data_ptr(), R * C if in_bs is None else in_bs, out.data_ptr(), R * C, B, R, C,
-                                            torch.cuda.current_stream(src.device).cuda_stream)
+                                            _lib.stream_ptr(src.device))
     _lib.check(code, "mpf_transpose_f32")
     return out
 
@@ -72,9 +72,9 @@ class _GroupNormFn(Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         lib = _lib.lib()
         ws = _workspace(x.device, lib.mpf_group_stats_workspace_bytes(rows, row_len))
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             code = lib.mpf_group_stats(x.data_ptr(), rows, row_len, float(eps), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(),
-                                       ws.numel(), torch.cuda.current_stream(x.device).cuda_stream)
+                                       ws.numel(), _lib.stream_ptr(x.device))
         _lib.check(code, "mpf_group_stats")
         # y = x * a + b with a[n, c] = rstd[n, g] * gamma[c], b[n, c] = beta[c] - mean[n, g] * a[n, c]
         a = (rstd.view(N, groups, 1) * weight.view(1, groups, C // groups)).view(N, C)
@@ -119,11 +119,11 @@ class _GroupNormCLFn(Function):
         rstd = torch.empty(N * groups, dtype=torch.float32, device=x.device)
         y = _cl_empty(N, C, H, W, x.device)
         ws = _workspace(x.device, lib.mpf_gn_cl_workspace_bytes(N, H * W, C, groups))
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             code = lib.mpf_gn_cl_forward(x.data_ptr(), x.stride(0), weight.data_ptr(), bias.data_ptr(), N, H * W, C, groups, float(eps),
                                          1 if relu else 0, top.data_ptr() if top is not None else None,
                                          top.stride(0) if top is not None else 0, W, y.data_ptr(), y.stride(0), mean.data_ptr(),
-                                         rstd.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(x.device).cuda_stream)
+                                         rstd.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device))
         _lib.check(code, "mpf_gn_cl_forward")
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         ctx.groups, ctx.relu, ctx.has_top = groups, bool(relu), top is not None
@@ -142,9 +142,9 @@ class _GroupNormCLFn(Function):
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _workspace(x.device, lib.mpf_gn_cl_workspace_bytes(N, H * W, C, ctx.groups))
-        stream = torch.cuda.current_stream(x.device).cuda_stream
+        stream = _lib.stream_ptr(x.device)
         dtop = None
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             code = lib.mpf_gn_cl_backward(gy.data_ptr(), gy.stride(0), x.data_ptr(), x.stride(0), weight.data_ptr(), bias.data_ptr(),
                                           mean.data_ptr(), rstd.data_ptr(), N, H * W, C, ctx.groups, 1 if ctx.relu else 0,
                                           dx.data_ptr(), dx.stride(0), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), stream)
@@ -172,9 +172,9 @@ class _GroupNormFlattenFn(Function):
         lib = _lib.lib()
         out = torch.empty((N, S, C), dtype=torch.float32, device=dev)
         stats = []
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         off = 0
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             for x, w, b, hw in zip(xs, ws, bs, sizes):
                 mean = torch.empty(N * groups, dtype=torch.float32, device=dev)
                 rstd = torch.empty(N * groups, dtype=torch.float32, device=dev)
@@ -198,10 +198,10 @@ class _GroupNormFlattenFn(Function):
         N, S, C = g.shape
         dev = g.device
         lib = _lib.lib()
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        stream = _lib.stream_ptr(dev)
         grads = []
         off = 0
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             for l, (x, w, b, hw) in enumerate(zip(xs, ws, bs, ctx.sizes)):
                 H, W = int(x.shape[2]), int(x.shape[3])
                 dx = _cl_empty(N, C, H, W, dev)

@@ -76,11 +76,11 @@ def lsa_assign(cost, problems, n_slots, want_rows=True, want_cols=True, want_a=F
     st = _status_of(dev)
     pd = upload(problems.reshape(-1), dev)
     p = lambda k: out[k].data_ptr() if k in out else None  # noqa: E731
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         code = _lib.lib().mpf_lsa_assign_status(cost.data_ptr(), pd.data_ptr(), n, max_dim, max_entries, p("rows"), p("cols"), p("a"),
                                                 p("b"), scatter_dst.data_ptr() if scatter_dst is not None else None,
                                                 scatter_src.data_ptr() if scatter_src is not None else None,
-                                                st["dev"].data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+                                                st["dev"].data_ptr(), _lib.stream_ptr(dev))
     _lib.check(code, "mpf_lsa_assign_status")
     if st["event"] is None:                 # one read-back in flight at a time (16 bytes, pinned, behind the kernel)
         st["host"].copy_(st["dev"], non_blocking=True)

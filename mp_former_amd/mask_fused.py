@@ -21,7 +21,7 @@ from ._h2d import upload
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.stream_ptr(dev)
 
 
 def _is_planes(x):
@@ -52,7 +52,7 @@ class PairPlanes(Function):
         dev = me.device
         out = torch.empty((total_slots, HW), dtype=torch.bfloat16, device=dev)
         if total_slots and max_count:
-            with torch.cuda.device(dev):
+            with _lib.device_guard(dev):
                 code = _lib.lib().mpf_pair_planes_forward(me.data_ptr(), row_off.data_ptr(),
                                                           pair_of_slot.data_ptr() if pair_of_slot is not None else None,
                                                           slot_first.data_ptr(), slot_count.data_ptr(), mf.data_ptr(), mf.stride(0),
@@ -83,7 +83,7 @@ class PairPlanes(Function):
             g = g.contiguous()
             lib = _lib.lib()
             ws = torch.empty(lib.mpf_pair_planes_backward_workspace_bytes(N, HW, total_slots, max_count), dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
+            with _lib.device_guard(dev):
                 code = lib.mpf_pair_planes_backward(
                     g.data_ptr(), me.data_ptr(), row_off.data_ptr(), pair_of_slot.data_ptr() if pair_of_slot is not None else None,
                     slot_first.data_ptr(), slot_count.data_ptr(), mf.data_ptr(), mf.stride(0),
@@ -188,7 +188,7 @@ def match_cost_fused(views, coords, tsamp, t_first, t_count, group_view, group_i
     cost = torch.zeros((G, Q, Tmax), dtype=torch.float32, device=dev)
     lib = _lib.lib()
     ws = torch.empty(lib.mpf_match_cost_fused_workspace_bytes(G, Q, Tmax, P, tsamp.shape[0]), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         code = lib.mpf_match_cost_fused(me.data_ptr(), first_d.data_ptr(), me.stride(1), mf.data_ptr(), mf.stride(0), i32[:G].data_ptr(),
                                         H, W, mf.shape[1], coords.data_ptr(), tsamp.data_ptr(), tsamp.shape[0], i32[G:2 * G].data_ptr(),
                                         i32[2 * G:].data_ptr(), cost.data_ptr(), G, Q, Tmax, P, float(w_mask), float(w_dice),

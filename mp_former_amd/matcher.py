@@ -54,9 +54,9 @@ class GTMasks:
         self.bits = None
         if self.total and (self.H * self.W) % 32 == 0:
             self.bits = torch.empty((self.total, self.H * self.W // 32), dtype=torch.int32, device=dev)
-            with torch.cuda.device(dev):
+            with _lib.device_guard(dev):
                 _lib.check(_lib.lib().mpf_pack_mask_bits(self.u8.data_ptr(), self.bits.data_ptr(), self.u8.numel(),
-                                                         torch.cuda.current_stream(dev).cuda_stream), "mpf_pack_mask_bits")
+                                                         _lib.stream_ptr(dev)), "mpf_pack_mask_bits")
         self.image_of_row = np.concatenate([np.full(c, b, dtype=np.int64) for b, c in enumerate(self.counts)]) \
             if self.total else np.zeros(0, dtype=np.int64)
         self.device = dev

@@ -59,7 +59,7 @@ def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, i
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _lib.stream_ptr(t.device)
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
@@ -74,7 +74,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     hs = host_shapes if host_shapes is not None else _attached_host_shapes(spatial_shapes, level_start_index)
-    with torch.cuda.device(value.device):
+    with _lib.device_guard(value.device):
         code = _lib.lib().mpf_msda_forward_hs(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             hs.data_ptr() if hs is not None else None,
@@ -170,14 +170,14 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         if need == 0:
             raise RuntimeError("mpf_msda_backward_workspace_bytes rejected the level geometry")
         ws = _workspace(value.device, need)
-        with torch.cuda.device(value.device):
+        with _lib.device_guard(value.device):
             code = lib.mpf_msda_backward_ws(
                 value.data_ptr(), hs.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
                 grad_output.data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
                 N, S, M, D, L, Lq, P, _DTYPES[value.dtype], ws.data_ptr(), ws.numel(), _stream(value))
         _lib.check(code, "mpf_msda_backward_ws")
         return [gv, gl, ga]
-    with torch.cuda.device(value.device):
+    with _lib.device_guard(value.device):
         code = _lib.lib().mpf_msda_backward(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
@@ -199,7 +199,7 @@ def ms_deform_attn_forward_raw(value, spatial_shapes, level_start_index, raw, re
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     loc = torch.empty((N, Lq, M, L, P, 2), dtype=value.dtype, device=value.device)
     attn = torch.empty((N, Lq, M, L, P), dtype=value.dtype, device=value.device)
-    with torch.cuda.device(value.device):
+    with _lib.device_guard(value.device):
         code = _lib.lib().mpf_msda_forward_raw_hs(
             value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
             host_shapes.data_ptr() if host_shapes is not None else None, raw.data_ptr(), ref_points.data_ptr(),
@@ -222,7 +222,7 @@ def ms_deform_attn_backward_raw(value, host_shapes, sampling_loc, attn_weight, g
     if need == 0:
         raise RuntimeError("mpf_msda_backward_workspace_bytes rejected the level geometry")
     ws = _workspace(value.device, need)
-    with torch.cuda.device(value.device):
+    with _lib.device_guard(value.device):
         if output is not None:
             assert output.is_contiguous() and output.numel() == N * Lq * M * D and output.dtype == value.dtype
             code = lib.mpf_msda_backward_ws_raw_o(

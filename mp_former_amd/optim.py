@@ -79,10 +79,10 @@ class ClipAdamW(torch.optim.Optimizer):
         if self._scratch is None or self._scratch.numel() < blk or self._scratch.device != dev:
             self._scratch = torch.empty(blk, dtype=torch.float32, device=dev)
         self.norm_clip = torch.empty(2, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             code = _lib.lib().mpf_clip_adamw_step(items.data_ptr(), len(plist), blk, self.max_norm, self._beta1, self._beta2,
                                                   self.param_groups[0]["eps"], self._scratch.data_ptr(),
-                                                  self.norm_clip.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+                                                  self.norm_clip.data_ptr(), _lib.stream_ptr(dev))
         _lib.check(code, "mpf_clip_adamw_step")
         return loss
 

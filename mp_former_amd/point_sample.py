@@ -23,7 +23,7 @@ _CHUNKS = 8
 
 
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    return _lib.stream_ptr(dev)
 
 
 def _row_slice_of(t):
@@ -121,7 +121,7 @@ def point_sample_offsets(base_ptr, dtype, h, w, offs, coords, coord_rows, device
     out = torch.empty((n, P), dtype=torch.float32, device=device)
     if n == 0:
         return out
-    with torch.cuda.device(device):
+    with _lib.device_guard(device):
         code = _lib.lib().mpf_point_sample(base_ptr, _DT[dtype], h, w, offs.data_ptr(), coords.data_ptr(),
                                            coord_rows.data_ptr() if coord_rows is not None else None,
                                            out.data_ptr(), n, P, _stream(device))
@@ -134,7 +134,7 @@ def select_uncertain(vals, coords_in, k, P_out):
     n, M = vals.shape
     out = torch.empty((n, P_out, 2), dtype=torch.float32, device=vals.device)
     if n and k:
-        with torch.cuda.device(vals.device):
+        with _lib.device_guard(vals.device):
             code = _lib.lib().mpf_select_uncertain(vals.data_ptr(), coords_in.data_ptr(), out.data_ptr(), n, M, k, P_out,
                                                    _stream(vals.device))
         _lib.check(code, "mpf_select_uncertain")
@@ -148,7 +148,7 @@ def sample_select_uncertain(ms, offs, coords_in, k, P_out):
     n, M = coords_in.shape[0], coords_in.shape[1]
     if ms.dtype == torch.bfloat16 and ms.h * ms.w * 2 <= 128 * 1024 and (ms.h * ms.w * 2) % 16 == 0 and M <= 40960 and n and k:
         out = torch.empty((n, P_out, 2), dtype=torch.float32, device=coords_in.device)
-        with torch.cuda.device(ms.device):
+        with _lib.device_guard(ms.device):
             code = _lib.lib().mpf_sample_select_uncertain(ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, offs.data_ptr(), coords_in.data_ptr(),
                                                           out.data_ptr(), n, M, k, P_out, _stream(ms.device))
         _lib.check(code, "mpf_sample_select_uncertain")
@@ -162,7 +162,7 @@ def match_cost(ms, offs, coords, coord_rows, tsamp, t_first, t_count, Tmax, w_ma
     P = coords.shape[-2]
     cost = torch.zeros((n, Tmax), dtype=torch.float32, device=ms.device)
     if n:
-        with torch.cuda.device(ms.device):
+        with _lib.device_guard(ms.device):
             code = _lib.lib().mpf_match_cost(ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, offs.data_ptr(), coords.data_ptr(),
                                              coord_rows.data_ptr(), tsamp.data_ptr(), t_first.data_ptr(),
                                              t_count.data_ptr(), cost.data_ptr(), n, Tmax, P, float(w_mask),
@@ -181,7 +181,7 @@ def _mask_loss_sums_forward(ctx, ms, pred_offs, gt, gt_rows, coords):
     ctx.gt_hw, ctx.gdt, ctx.gt_u8 = (H, W), gdt, gt_u8
     partial = torch.empty((n, _CHUNKS, 4), dtype=torch.float32, device=ms.device)
     if n:
-        with torch.cuda.device(ms.device):
+        with _lib.device_guard(ms.device):
             code = _lib.lib().mpf_mask_loss_forward(
                 ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), gdt, H, W,
                 gt_rows.data_ptr(), coords.data_ptr(), partial.data_ptr(), n, P, _CHUNKS, _stream(ms.device))
@@ -216,7 +216,7 @@ class MaskLossSums(Function):
         gbuf = torch.zeros(ms.g_total, dtype=ms.dtype, device=ms.device)
         if n:
             g = grad_sums.contiguous().float()
-            with torch.cuda.device(ms.device):
+            with _lib.device_guard(ms.device):
                 code = _lib.lib().mpf_mask_loss_backward_dense(
                     ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, pred_offs.data_ptr(), gt_u8.data_ptr(), ctx.gdt, H, W,
                     gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), gbuf.data_ptr(), _DT[ms.dtype], grad_offs.data_ptr(),
@@ -251,7 +251,7 @@ class MaskLossSumsPlanes(Function):
         g_planes = torch.empty_like(planes)
         if n:
             g = grad_sums.contiguous().float()
-            with torch.cuda.device(ms.device):
+            with _lib.device_guard(ms.device):
                 code = _lib.lib().mpf_mask_loss_backward_dense(
                     ms.base_ptr, _DT[ms.dtype], ms.h, ms.w, plane_offs.data_ptr(), gt_u8.data_ptr(), ctx.gdt, H, W,
                     gt_rows.data_ptr(), coords.data_ptr(), g.data_ptr(), g_planes.data_ptr(), _DT[ms.dtype], plane_offs.data_ptr(),

@@ -14,7 +14,7 @@ _DT = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _lib.stream_ptr(t.device)
 
 
 class _ResLN(Function):
@@ -26,7 +26,7 @@ class _ResLN(Function):
         y16 = torch.empty_like(x, dtype=torch.bfloat16) if want16 else None
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             code = _lib.lib().mpf_res_ln256_forward(
                 x.data_ptr(), t.data_ptr() if t is not None else None, _DT[t.dtype] if t is not None else 0,
                 gamma.data_ptr(), beta.data_ptr(), s.data_ptr() if t is not None else None,
@@ -55,7 +55,7 @@ class _ResLN(Function):
         args = (s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                 g32.data_ptr() if g32 is not None else None, g16.data_ptr() if g16 is not None else None, None,
                 ds32.data_ptr() if ds32 is not None else None, ds16.data_ptr() if ds16 is not None else None)
-        with torch.cuda.device(s.device):
+        with _lib.device_guard(s.device):
             # parameter gradients without float atomics (bit-reproducible): per-workgroup partials summed in a fixed order —
             # by the workgroup that arrives last (one launch) for a few hundred rows, by a parallel second launch beyond
             if ctx.rows <= 1024:
@@ -95,7 +95,7 @@ def ln256_forward(x, gamma, beta, eps, padd=None, y_bound=None, padd_amax=None, 
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     yp = torch.empty_like(x) if padd is not None else None
     p_ = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
-    with torch.cuda.device(x.device):
+    with _lib.device_guard(x.device):
         if y_bound is not None:
             code = _lib.lib().mpf_res_ln256_forward_b(
                 x.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), None, y.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(),
@@ -120,7 +120,7 @@ def ln256_backward(s, mean, rstd, gamma, gy, gy_plus=None, ds_amax=None):
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes) + 1024, dtype=torch.uint8, device=s.device)
         _ln_ws[wkey] = ws
-    with torch.cuda.device(s.device):
+    with _lib.device_guard(s.device):
         # parameter gradients through per-workgroup partials, fixed order (no atomics, no zero-fill)
         args = (s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), gy.data_ptr(), None,
                 gy_plus.data_ptr() if gy_plus is not None else None, ds.data_ptr(), None, dgb[0].data_ptr(), dgb[1].data_ptr(),
@@ -140,7 +140,7 @@ _det_ws_cache = {}
 def _det_ws(dev, nbytes):
     """workspace of mpf_res_ln256_backward_det per (device, stream): its ticket word is zero between calls (zero-initialised
     here, reset by every launch), so it is shared by all LayerNorms that run on that stream"""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream, _lib.ws_scope())
+    key = (dev, _lib.stream_ptr(dev), _lib.ws_scope())
     ws = _det_ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros(int(nbytes) + 4096, dtype=torch.uint8, device=dev)

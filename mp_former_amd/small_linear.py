@@ -17,14 +17,14 @@ MAX_ROWS = 1024     # above this the library GEMMs have enough tiles to fill the
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _lib.stream_ptr(t.device)
 
 
 def small_gemm(a, a_rs, a_ks, b, b_rs, b_ks, I, J, Kc, bias=None, gate=None, relu=False, rowsum=False, cin=None):
     """C[I, J] = sum_k A(i,k) B(j,k) (+bias) (ReLU) with explicit element strides; returns (C, rowsum_a or None)."""
     c = torch.empty((I, J), dtype=torch.bfloat16, device=a.device)
     rs = torch.empty((I,), dtype=torch.bfloat16, device=a.device) if rowsum else None
-    with torch.cuda.device(a.device):
+    with _lib.device_guard(a.device):
         code = _lib.lib().mpf_small_gemm_bf16(
             a.data_ptr(), a_rs, a_ks, gate.data_ptr() if gate is not None else None, b.data_ptr(), b_rs, b_ks,
             bias.data_ptr() if bias is not None else None, cin.data_ptr() if cin is not None else None,
@@ -58,7 +58,7 @@ def weight_grads_grouped(problems):
         it.a_blk, it.I, it.J, it.Kc = 0, J, K, R
         outs.append((dw, db))
     dev = problems[0][0].device
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         code = _lib.lib().mpf_small_gemm_bf16_group(items, len(problems), _stream(problems[0][0]))
     _lib.check(code, "mpf_small_gemm_bf16_group")
     return outs
@@ -140,7 +140,7 @@ def gemm_nt_bf16(a, b, want_csum=True):
     ws = _nt_workspace(a.device, lib.mpf_gemm_nt_bf16_workspace_bytes(R, M, N, rps))
     c = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     cs = torch.empty((M,), dtype=torch.bfloat16, device=a.device) if want_csum else None
-    with torch.cuda.device(a.device):
+    with _lib.device_guard(a.device):
         code = lib.mpf_gemm_nt_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(),
                                     cs.data_ptr() if want_csum else None, R, M, N, rps, ws.data_ptr(), ws.numel(), _stream(a))
     _lib.check(code, "mpf_gemm_nt_bf16")
@@ -159,7 +159,7 @@ def tall_gemm(a, b, bias=None):
     M, K = a.shape
     N = b.shape[0]
     c = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-    with torch.cuda.device(a.device):
+    with _lib.device_guard(a.device):
         code = _lib.lib().mpf_tall_gemm_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0),
                                              bias.data_ptr() if bias is not None else None, c.data_ptr(), N, M, N, K, _stream(a))
     _lib.check(code, "mpf_tall_gemm_bf16")

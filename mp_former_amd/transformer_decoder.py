@@ -132,10 +132,10 @@ class _DecoderInputs(torch.autograd.Function):
         src = torch.empty((S, N, C), dtype=out_dtype, device=x.device)
         kin = torch.empty((S, N, C), dtype=out_dtype, device=x.device)
         dt = _lib.MPF_BF16 if out_dtype == torch.bfloat16 else _lib.MPF_F32
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             code = _lib.lib().mpf_decoder_inputs_forward(x.data_ptr(), x.stride(0), x.stride(3), level_row.data_ptr(), pos_t.data_ptr(),
                                                          src.data_ptr(), kin.data_ptr(), dt, S, N, C,
-                                                         torch.cuda.current_stream(x.device).cuda_stream)
+                                                         _lib.stream_ptr(x.device))
         _lib.check(code, "mpf_decoder_inputs_forward")
         ctx.dims = (N, C, H, W)
         return src, kin
@@ -156,10 +156,10 @@ class _DecoderInputs(torch.autograd.Function):
         g_kin = g_kin.contiguous() if g_kin is not None else None
         mem = torch.empty((N, S, C), dtype=torch.float32, device=g.device)       # channel-last, like the input view
         dt = _lib.MPF_BF16 if g.dtype == torch.bfloat16 else _lib.MPF_F32
-        with torch.cuda.device(g.device):
+        with _lib.device_guard(g.device):
             code = _lib.lib().mpf_decoder_inputs_backward(g_src.data_ptr() if g_src is not None else None,
                                                           g_kin.data_ptr() if g_kin is not None else None, dt, mem.data_ptr(),
-                                                          S * C, C, S, N, C, torch.cuda.current_stream(g.device).cuda_stream)
+                                                          S * C, C, S, N, C, _lib.stream_ptr(g.device))
         _lib.check(code, "mpf_decoder_inputs_backward")
         dx = mem.permute(0, 2, 1).view(N, C, H, W)
         d_level = mem.sum((0, 1)) if ctx.needs_input_grad[1] else None
@@ -183,10 +183,10 @@ def native_attn_mask(masks, size, mp_rows=None):
     if pad:
         mp_rows = mp_rows.contiguous()
     out = torch.empty((N, Q, hl * wl), dtype=torch.bool, device=masks.device)
-    with torch.cuda.device(masks.device):
+    with _lib.device_guard(masks.device):
         code = _lib.lib().mpf_attn_mask(masks.data_ptr(), dt, masks.stride(0), masks.stride(1), h, w,
                                         mp_rows.data_ptr() if pad else None, pad, out.data_ptr(), N, Q, hl, wl,
-                                        torch.cuda.current_stream(masks.device).cuda_stream)
+                                        _lib.stream_ptr(masks.device))
     _lib.check(code, "mpf_attn_mask")
     return out
 
@@ -198,8 +198,8 @@ def pool_features(mask_features, size):
     hl, wl = size
     dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}[mask_features.dtype]
     out = torch.empty((N, hl * wl, C), dtype=torch.bfloat16, device=mask_features.device)
-    stream = torch.cuda.current_stream(mask_features.device).cuda_stream
-    with torch.cuda.device(mask_features.device):
+    stream = _lib.stream_ptr(mask_features.device)
+    with _lib.device_guard(mask_features.device):
         if _is_planes(mask_features) and not mask_features.is_contiguous():
             # channel-last features (the pixel decoder's layout): no transpose needed
             code = _lib.lib().mpf_pool_features_cl(mask_features.data_ptr(), mask_features.stride(0), dt, out.data_ptr(), N, C, h, w,
@@ -249,10 +249,10 @@ def mask_head_bits(mask_embed, pooled, mp_rows=None):
         flags = torch.zeros(N * Q, dtype=torch.int32, device=dev)          # zero on entry, zeroed again by the kernel
         _mask_flags[(dev, N * Q)] = flags
     out = torch.empty((N, Q, HW), dtype=torch.bool, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         code = _lib.lib().mpf_mask_head_bits(mask_embed.data_ptr(), mask_embed.stride(1), mask_embed.stride(0), pooled.data_ptr(),
                                              mp_rows.data_ptr() if pad else None, pad, out.data_ptr(), flags.data_ptr(), N, Q, HW,
-                                             torch.cuda.current_stream(dev).cuda_stream)
+                                             _lib.stream_ptr(dev))
     _lib.check(code, "mpf_mask_head_bits")
     return out
 
@@ -382,9 +382,9 @@ def gt_block_or(masks: Tensor, size):
         raise RuntimeError("mp_former_amd decoder runs on the GPU only (no CPU fallback)")
     m = m.contiguous()
     out = torch.empty((T, h * w), dtype=torch.bool, device=m.device)
-    with torch.cuda.device(m.device):
+    with _lib.device_guard(m.device):
         code = _lib.lib().mpf_mask_block_empty(m.data_ptr(), out.data_ptr(), T, H, W, h, w,
-                                               torch.cuda.current_stream(m.device).cuda_stream)
+                                               _lib.stream_ptr(m.device))
     _lib.check(code, "mpf_mask_block_empty")
     return out
 
