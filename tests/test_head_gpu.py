@@ -360,3 +360,61 @@ def test_head_full_size_configs_B_C(name, classes, n):
     # the same 60 losses BIT FOR BIT (and therefore the same assignments)
     l1 = run(11)
     assert l1 == l0, [(k, l0[k], l1[k]) for k in l0 if l0[k] != l1[k]][:5]
+
+
+@pytest.mark.parametrize("name", ["head_deep", "head_cfgA"])
+def test_amp_path_own_matching_against_the_fp32_matching(name):
+    """The AMP path's OWN Hungarian matching (the other AMP tests pin the assignment to the fp32 pass): cost matrices of the bf16
+    autocast forward against those of the fp32 forward (= the reference's, golden-exact) on the same replayed draws.  Reported and
+    bounded: the share of (output, image, target) assignments that agree, and the REGRET of the AMP assignment — its cost under
+    the fp32 cost matrix relative to the fp32 optimum.  A flipped pair is a near-tie (small regret), never a different matching
+    regime; the reference under fp16 autocast has the same property (its matcher also reads autocast logits, matcher.py:105-147)."""
+    from scipy.optimize import linear_sum_assignment
+    from mp_former_amd import _rng
+    from mp_former_amd.matcher import GTMasks
+    dev = torch.device("cuda:0")
+    z, cfg, pp, dp, feats, targets, replay = load_head_fixture(name)
+    h = _build(cfg, pp, dp, dev)
+    feats = {k: _planes_leaf(v, dev) for k, v in feats.items()}
+    targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+    use_dn = "dn_pred_logits" in z
+    matcher = h.criterion.matcher
+    orig = matcher.cost_matrices
+    got = []
+    import os
+    os.environ["MPF_DEVICE_LSA"] = "0"
+    try:
+        matcher.cost_matrices = lambda *a, **k: got.append(orig(*a, **k)) or got[-1]
+        for amp in (False, True):
+            _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                h(feats, targets)
+    finally:
+        matcher.cost_matrices = orig
+        _rng.install_replay(None)
+        os.environ.pop("MPF_DEVICE_LSA", None)
+    assert len(got) == 2 and got[0] is not None
+    c32, camp = (c.float().cpu().numpy() for c in got)
+    counts = GTMasks(targets).counts
+    agree, total, regrets = 0, 0, []
+    for l in range(c32.shape[0]):
+        for b, t in enumerate(counts):
+            if t == 0:
+                continue
+            a32, aamp = c32[l, b, :, :t], camp[l, b, :, :t]
+            i1, j1 = linear_sum_assignment(a32)
+            i2, j2 = linear_sum_assignment(aamp)
+            q1, q2 = np.empty(t, np.int64), np.empty(t, np.int64)
+            q1[j1], q2[j2] = i1, i2
+            agree += int((q1 == q2).sum())
+            total += t
+            best = a32[i1, j1].sum()
+            regrets.append(float((a32[i2, j2].sum() - best) / max(abs(best), 1e-6)))
+    share = agree / max(total, 1)
+    print(f"{name}: AMP matching agrees with the fp32 matching on {agree}/{total} targets ({share:.3f}); regret max {max(regrets):.4f} "
+          f"mean {np.mean(regrets):.5f}")
+    # measured (round 4): head_deep 54 / 60 targets agree, regret max 3.9e-2, mean 3.7e-3; head_cfgA (100 random-init queries, near
+    # duplicates of each other) 45 / 70 agree with regret max 8e-3, mean 1.7e-3 — the disagreements are ties at bf16 resolution,
+    # so the bound is on the regret, the agreement share is only required not to collapse
+    assert share >= 0.5, (share, regrets)
+    assert max(regrets) <= 6e-2 and np.mean(regrets) <= 8e-3, regrets
