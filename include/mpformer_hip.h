@@ -830,6 +830,18 @@ typedef struct {
     int a_blk, I, J, Kc;
 } MpfSmallGemmItem;
 int mpf_small_gemm_bf16_group(const MpfSmallGemmItem* items, int n_items, void* stream);
+/* Transposed, zero-padded bf16 copies of up to 16 matrices in one launch: src [R, C] (row stride ld elements) -> dst [C, Rp]
+ * (Rp >= R, Rp % 8 == 0; the padding is zero); with `gate` (same addressing as src) elements whose gate is <= 0 become zero.
+ * What turns the weight-gradient problems of mpf_small_gemm_bf16_group (contraction over the ROWS of dY and x) into its
+ * contraction-contiguous form (a_ks == b_ks == 1, row strides Rp, Kc = Rp): 16-byte fragment loads instead of 2-byte ones. */
+typedef struct MpfTransposeItem {
+    const void* src;
+    const void* gate;
+    void* dst;
+    int64_t ld;
+    int R, C;
+} MpfTransposeItem;
+int mpf_transpose_group_bf16(const MpfTransposeItem* items, int n_items, int Rp, void* stream);
 
 /*
  * y = relu?(x + bias[c] + res) over a dense channel-last activation (channel = fastest dimension,

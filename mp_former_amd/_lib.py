@@ -112,6 +112,7 @@ SIGNATURES = {
                                              ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_int, ctypes.c_int64,
                                              _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_small_gemm_bf16_group": (_c_int, [_c_vp, _c_int, _c_vp]),
+    "mpf_transpose_group_bf16": (_c_int, [_c_vp, _c_int, _c_int, _c_vp]),
     "mpf_class_loss_forward": (_c_int, [_c_vp, _c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_int, _c_vp, _c_int, _c_int,
                                         _c_int, _c_int, _c_vp, _c_vp, _c_vp, _c_vp]),
     "mpf_class_loss_backward": (_c_int, [_c_vp, _c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _c_vp, _c_int, _c_vp, _c_int, _c_int,

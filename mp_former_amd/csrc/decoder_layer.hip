@@ -55,6 +55,7 @@ struct BwdScratch {
     float *ds_a, *ds_b, *delta;
     void* aux;                   // aux operands of the attention dK / dV kernel (mpf_attn_bwd_aux_bytes: the larger of the two attentions)
     size_t aux_bytes;
+    uint16_t* tbuf;              // transposed [C, Rp] copies of the weight-gradient operands (2 F + 13 * 256 columns)
     void* ln_ws;                 // per-workgroup partial sums of the three LayerNorms' parameter gradients, ln_ws_bytes each
     size_t ln_ws_bytes;
     size_t bytes;
@@ -86,6 +87,7 @@ BwdScratch bwd_scratch(void* base, int Qt, int N, int H, int F, int S)
         b.aux_bytes = ca > sa ? ca : sa;
         b.aux = c.take<char>(b.aux_bytes);
     }
+    b.tbuf = c.take<uint16_t>((size_t)(2 * F + 13 * kE) * ((R + 31) / 32 * 32));
     b.ln_ws_bytes = (mpf_res_ln256_backward_workspace_bytes((int)R) + 255) & ~size_t(255);
     b.ln_ws = c.take<char>(3 * b.ln_ws_bytes);
     b.bytes = c.used;
@@ -149,14 +151,15 @@ bool packed_weights(const MpfDecoderLayer* L)
 }  // namespace
 
 namespace {
-// A/B switches (mpf_set_option): decoder_dw_group = 0 issues the weight gradients as separate launches (round-1 form)
-int g_dw_group = 1;
+// A/B switches (mpf_set_option): decoder_dw_group = 0 issues the weight gradients as separate launches (round-1 form), 1 = one grouped
+// launch on the row-contiguous operands (round 2), 2 = grouped transposes + one grouped launch on contraction-contiguous copies
+int g_dw_group = 2;
 }  // namespace
 
 namespace mpf {
 int set_decoder_option(const char* key, int v)
 {
-    if (!strcmp(key, "decoder_dw_group")) { g_dw_group = v != 0; return 0; }
+    if (!strcmp(key, "decoder_dw_group")) { if (v < 0 || v > 2) return -1; g_dw_group = v; return 0; }
     return 1;
 }
 }  // namespace mpf
@@ -292,7 +295,60 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
                                      N, H, 32, scale, L->attn_ws, L->attn_ws_bytes, b.aux, st));
     MPF_TRY(lin_dx(b.dq_c, nullptr, L->ca_wq, nullptr, G->d_xb0, R, kE, kE, st));
     dw[ndw++] = dw_item(b.dq_c, nullptr, L->xb0, G->d_ca_wq, G->d_ca_bq, R, kE, kE);
-    if (g_dw_group) {
+    if (g_dw_group == 2) {
+        // the weight gradients contract over the ROWS of dY and x: on transposed [C, Rp] copies (one grouped launch) both operands
+        // are contraction-contiguous, i.e. 16-byte fragment loads instead of eight 2-byte ones per fragment; same 32-row
+        // contraction steps on the same waves, zero padding: bit-identical to the row-contiguous form
+        const int Rp = (R + 31) / 32 * 32;
+        uint16_t* tp = b.tbuf;
+        MpfTransposeItem tr[16];
+        int ntr = 0;
+        auto tcopy = [&](const void* src, const void* gate, int C) {
+            uint16_t* dst = tp;
+            tr[ntr].src = src; tr[ntr].gate = gate; tr[ntr].dst = dst; tr[ntr].ld = C; tr[ntr].R = R; tr[ntr].C = C;
+            ++ntr;
+            tp += (size_t)C * Rp;
+            return dst;
+        };
+        const uint16_t* dt3T = tcopy(b.dt3, nullptr, kE);
+        const uint16_t* hT = tcopy(L->h, nullptr, F);
+        const uint16_t* dhT = tcopy(b.dh, L->h, F);
+        const uint16_t* xb2T = tcopy(L->xb2, nullptr, kE);
+        const uint16_t* dt2T = tcopy(b.dt2, nullptr, kE);
+        const uint16_t* osT = tcopy(L->o_s, nullptr, kE);
+        const uint16_t* dqT = tcopy(b.dq, nullptr, kE);          // dq | dk | dv: three consecutive [256, Rp] blocks = one [768, Rp]
+        tcopy(b.dk_s, nullptr, kE);
+        tcopy(b.dv_s, nullptr, kE);
+        const uint16_t* xb1T = tcopy(L->xb1, nullptr, kE);
+        const uint16_t* dt1T = tcopy(b.dt1, nullptr, kE);
+        const uint16_t* ocT = tcopy(L->o_c, nullptr, kE);
+        const uint16_t* dqcT = tcopy(b.dq_c, nullptr, kE);
+        const uint16_t* xb0T = tcopy(L->xb0, nullptr, kE);
+        MPF_TRY(mpf_transpose_group_bf16(tr, ntr, Rp, st));
+        auto titem = [&](const uint16_t* aT, const uint16_t* bT, void* dwp, void* dbp, int J, int Kin) {
+            MpfSmallGemmItem m;
+            m.a = aT; m.gate = nullptr; m.b = bT; m.c = dwp; m.rowsum_a = dbp;
+            m.a_rs = Rp; m.a_ks = 1; m.a_bs = 0; m.b_rs = Rp; m.b_ks = 1; m.ldc = Kin;
+            m.a_blk = 0; m.I = J; m.J = Kin; m.Kc = Rp;
+            return m;
+        };
+        MpfSmallGemmItem tw[kMaxDw];
+        int nt = 0;
+        tw[nt++] = titem(dt3T, hT, G->d_ff_w2, G->d_ff_b2, kE, F);
+        tw[nt++] = titem(dhT, xb2T, G->d_ff_w1, G->d_ff_b1, F, kE);
+        tw[nt++] = titem(dt2T, osT, G->d_sa_wo, G->d_sa_bo, kE, kE);
+        if (G->d_sa_wk == at(G->d_sa_wq, wsz) && G->d_sa_wv == at(G->d_sa_wq, 2 * wsz) && G->d_sa_bk == at(G->d_sa_bq, bsz) &&
+            G->d_sa_bv == at(G->d_sa_bq, 2 * bsz)) {
+            tw[nt++] = titem(dqT, xb1T, G->d_sa_wq, G->d_sa_bq, 3 * kE, kE);
+        } else {
+            tw[nt++] = titem(dqT, xb1T, G->d_sa_wq, G->d_sa_bq, kE, kE);
+            tw[nt++] = titem(dqT + (size_t)kE * Rp, xb1T, G->d_sa_wk, G->d_sa_bk, kE, kE);
+            tw[nt++] = titem(dqT + (size_t)2 * kE * Rp, xb1T, G->d_sa_wv, G->d_sa_bv, kE, kE);
+        }
+        tw[nt++] = titem(dt1T, ocT, G->d_ca_wo, G->d_ca_bo, kE, kE);
+        tw[nt++] = titem(dqcT, xb0T, G->d_ca_wq, G->d_ca_bq, kE, kE);
+        MPF_TRY(mpf_small_gemm_bf16_group(tw, nt, st));
+    } else if (g_dw_group) {
         MPF_TRY(mpf_small_gemm_bf16_group(dw, ndw, st));
     } else {
         for (int t = 0; t < ndw; ++t)

@@ -219,7 +219,10 @@ struct SGGroup {
     int n;
 };
 
-template <bool MASK>
+// CT: every problem's operands are contraction-contiguous (transposed copies made by mpf_transpose_group_bf16: 16-byte fragment
+// loads instead of eight 2-byte ones — the row-contiguous form of a decoder layer's six weight gradients was 30 us of mostly
+// vector-memory instruction issue)
+template <bool MASK, bool CT>
 __global__ __launch_bounds__(256) void small_gemm_group_kernel(const SGGroup g)
 {
     __shared__ float4 red[3 * 4 * 64];
@@ -232,11 +235,66 @@ __global__ __launch_bounds__(256) void small_gemm_group_kernel(const SGGroup g)
     const int block = (int)blockIdx.x - g.first[k];
     const bool gate = p.gate != nullptr;
     const int nj = g.nj[k];
-#define SG_CASE(NJ_, G_) sg_tile<NJ_, false, false, G_, MASK>(p, block, reinterpret_cast<float4(*)[NJ_][64]>(red), red_rs)
+#define SG_CASE(NJ_, G_) sg_tile<NJ_, CT, CT, G_, MASK>(p, block, reinterpret_cast<float4(*)[NJ_][64]>(red), red_rs)
     if (nj == 4) { if (gate) SG_CASE(4, true); else SG_CASE(4, false); }
     else if (nj == 2) { if (gate) SG_CASE(2, true); else SG_CASE(2, false); }
     else { if (gate) SG_CASE(1, true); else SG_CASE(1, false); }
 #undef SG_CASE
+}
+
+// Transposed, zero-padded copies of several bf16 matrices in one launch: src [R, C] (row stride ld) -> dst [C, Rp] (Rp >= R, a
+// multiple of 8; rows R .. Rp - 1 of the source read as zero), optionally gated: elements whose `gate` element (same addressing)
+// is <= 0 become zero (the ReLU backward of the FFN's hidden gradient).  64 x 64 tiles through LDS, 16-byte loads and stores.
+constexpr int kTrMax = 16;
+struct TrItem {
+    const u16* src;
+    const u16* gate;
+    u16* dst;
+    int64_t ld;
+    int R, C, first;             // first block of this item
+};
+struct TrGroup {
+    TrItem it[kTrMax];
+    int n, Rp, tiles_r;
+};
+
+__global__ __launch_bounds__(256) void transpose_group_kernel(const TrGroup g)
+{
+    __shared__ __attribute__((aligned(16))) u16 tl[64][72];       // [column][row], 144-byte rows
+    int k = 0;
+#pragma unroll
+    for (int t = 1; t < kTrMax; ++t)
+        if (t < g.n && (int)blockIdx.x >= g.it[t].first) k = t;
+    const TrItem& p = g.it[k];
+    const int b = (int)blockIdx.x - p.first;
+    const int tr = b % g.tiles_r, tc = b / g.tiles_r;
+    const int r0 = tr * 64, c0 = tc * 64;
+#pragma unroll
+    for (int itx = 0; itx < 2; ++itx) {
+        const int u = threadIdx.x + itx * 256;
+        const int r = u >> 3, cg = u & 7;
+        const int row = r0 + r, col = c0 + cg * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u), gt = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        if (row < p.R && col < p.C) {
+            v = *reinterpret_cast<const uint4*>(p.src + (int64_t)row * p.ld + col);
+            if (p.gate) gt = *reinterpret_cast<const uint4*>(p.gate + (int64_t)row * p.ld + col);
+        }
+        const unsigned w[4] = {gate_word(v.x, gt.x), gate_word(v.y, gt.y), gate_word(v.z, gt.z), gate_word(v.w, gt.w)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tl[cg * 8 + 2 * q][r] = (u16)(w[q] & 0xffffu);
+            tl[cg * 8 + 2 * q + 1][r] = (u16)(w[q] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int itx = 0; itx < 2; ++itx) {
+        const int u = threadIdx.x + itx * 256;
+        const int cc = u >> 3, lg = u & 7;
+        const int col = c0 + cc, row = r0 + lg * 8;
+        if (col < p.C && row < g.Rp)
+            *reinterpret_cast<uint4*>(p.dst + (int64_t)col * g.Rp + row) = *reinterpret_cast<const uint4*>(&tl[cc][lg * 8]);
+    }
 }
 
 template <int NJ, bool AC, bool BC>
@@ -356,12 +414,16 @@ extern "C" int mpf_small_gemm_bf16_group(const MpfSmallGemmItem* items, int n_it
     SGGroup g;
     g.n = 0;
     g.first[0] = 0;
-    bool mask = false;
+    bool mask = false, contig = false;
     double bytes = 0.0;
     for (int t = 0; t < n_items; ++t) {
         const MpfSmallGemmItem& m = items[t];
-        if (m.a_rs != 1 || m.b_rs != 1)
-            return mpf::fail(MPF_E_SHAPE, "small_gemm_group: row-contiguous operands only (the weight-gradient form)");
+        const bool ct_item = m.a_ks == 1 && m.b_ks == 1;
+        if (!ct_item && (m.a_rs != 1 || m.b_rs != 1))
+            return mpf::fail(MPF_E_SHAPE, "small_gemm_group: both operands row-contiguous (the weight-gradient form) or both contraction-contiguous");
+        if (t > 0 && ct_item != contig) return mpf::fail(MPF_E_SHAPE, "small_gemm_group: one operand form per group");
+        contig = ct_item;
+        if (ct_item && m.gate) return mpf::fail(MPF_E_SHAPE, "small_gemm_group: the gate belongs into the transposed copy (mpf_transpose_group_bf16)");
         int nj = 1, err = 0;
         const int empty = sg_fill(g.it[g.n], &nj, m.a, m.a_rs, m.a_ks, m.a_blk, m.a_bs, m.gate, m.b, m.b_rs, m.b_ks, nullptr, nullptr, 0,
                                   m.c, m.ldc, 0, 0, m.rowsum_a, m.I, m.J, m.Kc, 0, &err);
@@ -378,11 +440,41 @@ extern "C" int mpf_small_gemm_bf16_group(const MpfSmallGemmItem* items, int n_it
     for (int t = g.n; t < kGroupMax; ++t) { g.first[t + 1] = g.first[g.n]; g.nj[t] = 1; g.it[t] = g.it[0]; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     mpf::prof_begin(st);
-    if (mask) small_gemm_group_kernel<true><<<g.first[g.n], 256, 0, st>>>(g);
-    else small_gemm_group_kernel<false><<<g.first[g.n], 256, 0, st>>>(g);
+    if (contig) {
+        if (mask) small_gemm_group_kernel<true, true><<<g.first[g.n], 256, 0, st>>>(g);
+        else small_gemm_group_kernel<false, true><<<g.first[g.n], 256, 0, st>>>(g);
+    } else {
+        if (mask) small_gemm_group_kernel<true, false><<<g.first[g.n], 256, 0, st>>>(g);
+        else small_gemm_group_kernel<false, false><<<g.first[g.n], 256, 0, st>>>(g);
+    }
     mpf::set_kernel("small_gemm_group_kernel");
     mpf::prof_end("small_gemm_group_kernel", st, bytes);
     return mpf::check(hipGetLastError(), "small_gemm_group launch");
+}
+
+extern "C" int mpf_transpose_group_bf16(const MpfTransposeItem* items, int n_items, int Rp, void* stream)
+{
+    if (n_items < 0 || n_items > kTrMax) return mpf::fail(MPF_E_SHAPE, "transpose_group: at most 16 matrices per launch");
+    if (n_items == 0) return 0;
+    if (!items) return mpf::fail(MPF_E_NULL, "transpose_group: NULL items");
+    if (Rp <= 0 || Rp % 8) return mpf::fail(MPF_E_SHAPE, "transpose_group: Rp must be a positive multiple of 8");
+    TrGroup g;
+    g.n = n_items; g.Rp = Rp; g.tiles_r = (Rp + 63) / 64;
+    int blocks = 0;
+    for (int t = 0; t < n_items; ++t) {
+        const MpfTransposeItem& m = items[t];
+        if (!m.src || !m.dst) return mpf::fail(MPF_E_NULL, "transpose_group: NULL matrix");
+        if (m.R <= 0 || m.R > Rp || m.C <= 0 || m.C % 8 || m.ld % 8 || ((uintptr_t)m.src & 15) || ((uintptr_t)m.dst & 15) ||
+            (m.gate && ((uintptr_t)m.gate & 15)))
+            return mpf::fail(MPF_E_SHAPE, "transpose_group: 0 < R <= Rp, C % 8 == 0, 16-byte aligned rows");
+        g.it[t].src = static_cast<const u16*>(m.src); g.it[t].gate = static_cast<const u16*>(m.gate); g.it[t].dst = static_cast<u16*>(m.dst);
+        g.it[t].ld = m.ld; g.it[t].R = m.R; g.it[t].C = m.C; g.it[t].first = blocks;
+        blocks += g.tiles_r * ((m.C + 63) / 64);
+    }
+    for (int t = n_items; t < kTrMax; ++t) { g.it[t] = g.it[0]; g.it[t].first = blocks; }
+    mpf::set_kernel("transpose_group_kernel");
+    transpose_group_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(g);
+    return mpf::check(hipGetLastError(), "transpose_group launch");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
