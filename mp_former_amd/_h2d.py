@@ -16,8 +16,24 @@ import torch
 SMALL_BYTES = 2 * 3968
 
 
+_NP2T = {np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32,
+         np.dtype(np.uint8): torch.uint8, np.dtype(np.float64): torch.float64}
+
+
 def upload(data, device, dtype=None):
     """numpy array / python list / CPU tensor -> device tensor, asynchronously."""
+    if dtype is None and isinstance(data, np.ndarray) and data.dtype in _NP2T and isinstance(device, torch.device) \
+            and device.type == "cuda":
+        # the common case (item tables of the grouped launches): straight from the numpy buffer, no tensor wrappers
+        nbytes = data.nbytes
+        if 0 < nbytes <= SMALL_BYTES and nbytes % 4 == 0:
+            from . import _lib
+            a = data if data.flags.c_contiguous else np.ascontiguousarray(data)
+            out = torch.empty(a.shape, dtype=_NP2T[a.dtype], device=device)
+            with _lib.device_guard(device):
+                code = _lib.lib().mpf_upload_small(a.__array_interface__["data"][0], out.data_ptr(), nbytes, _lib.stream_ptr(device))
+            _lib.check(code, "mpf_upload_small")
+            return out
     t = torch.from_numpy(data) if isinstance(data, np.ndarray) else torch.as_tensor(data)
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)

@@ -45,22 +45,25 @@ class ClipAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        plist, glist = [], []
+        # (one pass over the parameters: this loop runs ~350 times per step on the launch thread)
+        plist, grads = [], []
         for group in self.param_groups:
             for p in group["params"]:
-                if p.grad is not None and p.numel():
+                g = p.grad
+                if g is not None and p.numel():
                     plist.append((p, group))
+                    grads.append(g)
         if not plist:
             return loss
-        key = tuple(id(p) for p, _ in plist)
+        key = tuple(map(id, [p for p, _ in plist]))
         if key != self._key:
             self._build(plist, key)
-        keep = []
-        for p, _ in plist:
-            g = p.grad
-            if g.is_sparse:
-                raise RuntimeError("ClipAdamW does not support sparse gradients")
-            if g.dtype != torch.float32 or g.device != p.device:
+        keep, glist = [], []
+        f32 = torch.float32
+        for (p, _), g in zip(plist, grads):
+            if g.dtype is not f32 or g.is_sparse or g.device != p.device:
+                if g.is_sparse:
+                    raise RuntimeError("ClipAdamW does not support sparse gradients")
                 raise RuntimeError("mp_former_amd ClipAdamW: fp32 gradients on the parameter's device only")
             if g.stride() != p.stride():          # the update is element-wise over raw memory: same layout needed
                 g = torch.empty_like(p).copy_(g)
@@ -85,6 +88,15 @@ class ClipAdamW(torch.optim.Optimizer):
                                                   self.norm_clip.data_ptr(), _lib.stream_ptr(dev))
         _lib.check(code, "mpf_clip_adamw_step")
         return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        """torch.optim.Optimizer.zero_grad without its per-call bookkeeping (profiler scope, foreach grouping): 0.4 -> 0.1 ms of
+        launch-thread time for ~350 parameters"""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:
+            for p in group["params"]:
+                p.grad = None
 
     def _build(self, plist, key):
         """static part of the launch table (parameter / moment pointers, sizes, lr, weight decay) for this set of
