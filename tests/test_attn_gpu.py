@@ -43,8 +43,11 @@ def _problem(Lq, Lk, N, mask_kind, dev, seed):
     return q, k, v, mask
 
 
+# (the split policy of csrc/attn.hip per case: waves of 64 / 128 / 256 / 512 keys, one workgroup or several per query tile,
+#  the merge of <= 8 and of > 8 workgroup partials, aligned and element-wise load paths)
 CASES = [(100, 1024, 2, "3d"), (117, 4096, 2, "3d"), (123, 16384, 1, "3d"), (100, 64, 2, "3d"),
-         (117, 117, 2, "2d"), (100, 100, 1, None), (37, 1000, 3, "3d"), (214, 214, 2, "2d")]
+         (117, 117, 2, "2d"), (100, 100, 1, None), (37, 1000, 3, "3d"), (214, 214, 2, "2d"),
+         (230, 32768, 1, "3d"), (300, 16384, 3, "3d"), (64, 200, 2, "3d"), (33, 8, 1, None), (40, 2040, 2, "3d")]
 
 
 @pytest.mark.parametrize("Lq,Lk,N,mask_kind", CASES)
