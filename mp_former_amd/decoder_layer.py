@@ -43,6 +43,39 @@ class MpfDecoderLayerGrad(ctypes.Structure):
 
 _checked = False
 _scratch = {}
+_PARAM_DTYPES = tuple(torch.float32 if n in _LN else torch.bfloat16 for n in PARAM_NAMES)
+_layouts = {}
+
+
+def _arena_layout(R, E, N, S, Qt, H, F_):
+    """byte offsets of the saved tensors (_SAVED order) inside a layer's arena, and its size"""
+    key = (R, E, N, S, Qt, H, F_)
+    hit = _layouts.get(key)
+    if hit is None:
+        sizes = {"q_c": R * E * 2, "kT_c": N * E * S * 2, "o_c": R * E * 2, "lse_c": N * H * Qt * 4,
+                 "s1": R * E * 4, "mean1": R * 4, "rstd1": R * 4, "xb1": R * E * 2,
+                 "q_s": R * E * 2, "k_s": R * E * 2, "v_s": R * E * 2, "kT_s": N * E * Qt * 2, "o_s": R * E * 2,
+                 "lse_s": N * H * Qt * 4, "s2": R * E * 4, "mean2": R * 4, "rstd2": R * 4, "xb2": R * E * 2,
+                 "h": R * F_ * 2, "s3": R * E * 4, "mean3": R * 4, "rstd3": R * 4}
+        offs, tot = [], 0
+        for n in _SAVED:
+            offs.append(tot)
+            tot += _al(sizes[n])
+        hit = _layouts[key] = (tuple(offs), tot)
+    return hit
+
+
+_scratch_sizes = {}
+
+
+def _scratch_bytes(lib, Qt, N, H, S, F_):
+    key = (Qt, N, H, S, F_)
+    hit = _scratch_sizes.get(key)
+    if hit is None:
+        hit = _scratch_sizes[key] = (max(lib.mpf_decoder_layer_scratch_bytes(Qt, N, H, S, F_, 0),
+                                         lib.mpf_decoder_layer_scratch_bytes(Qt, N, H, S, F_, 1)),
+                                     max(lib.mpf_attn_workspace_bytes(Qt, S, N, H), lib.mpf_attn_workspace_bytes(Qt, Qt, N, H)))
+    return hit
 
 
 def _lib_checked():
@@ -115,6 +148,34 @@ def split_cols(y, n):
     return [(v, (pack, j)) for j, v in enumerate(views)]
 
 
+_IS_LN = tuple(n in _LN for n in PARAM_NAMES)
+_WNAMES = tuple(n for n in PARAM_NAMES if n not in _LN)
+_wgrad_layouts = {}
+
+
+def _wgrad_layout(wshapes):
+    """element offsets of the weight / bias gradients inside a layer's gradient arena: the q / k / v weight gradients side by side,
+    then their bias gradients (the native layer then produces them with one GEMM), the rest in parameter order"""
+    hit = _wgrad_layouts.get(wshapes)
+    if hit is None:
+        order = sorted(range(len(_WNAMES)), key=lambda i: ({"sa_wq": 0, "sa_wk": 1, "sa_wv": 2, "sa_bq": 3, "sa_bk": 4, "sa_bv": 5}
+                                                            .get(_WNAMES[i], 6 + i)))
+        offs, tot = [0] * len(_WNAMES), 0
+        for i in order:
+            offs[i] = tot
+            tot += (wshapes[i].numel() + 127) & ~127
+        hit = _wgrad_layouts[wshapes] = (tuple(offs), tot)
+    return hit
+
+
+def _contig_strides(shape):
+    st, acc = [], 1
+    for d in reversed(shape):
+        st.append(acc)
+        acc *= d
+    return tuple(reversed(st))
+
+
 class DecoderLayerFn(Function):
     @staticmethod
     def forward(ctx, x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, kv_pack, *params):
@@ -134,26 +195,30 @@ class DecoderLayerFn(Function):
         if mask_s is not None:
             assert mask_s.dtype == torch.bool and mask_s.shape == (Qt, Qt)
             mask_s = mask_s.contiguous()
-        params = tuple(p if p.is_contiguous() else p.contiguous() for p in params)
-        for n, p in zip(PARAM_NAMES, params):
-            assert p.dtype == (torch.float32 if n in _LN else torch.bfloat16), n
-        # one arena for everything the backward reads
-        sizes = {"q_c": R * E * 2, "kT_c": N * E * S * 2, "o_c": R * E * 2, "lse_c": N * nheads * Qt * 4,
-                 "s1": R * E * 4, "mean1": R * 4, "rstd1": R * 4, "xb1": R * E * 2,
-                 "q_s": R * E * 2, "k_s": R * E * 2, "v_s": R * E * 2, "kT_s": N * E * Qt * 2, "o_s": R * E * 2,
-                 "lse_s": N * nheads * Qt * 4, "s2": R * E * 4, "mean2": R * 4, "rstd2": R * 4, "xb2": R * E * 2,
-                 "h": R * F_ * 2, "s3": R * E * 4, "mean3": R * 4, "rstd3": R * 4}
-        total = sum(_al(v) for v in sizes.values())
+        # (this function runs 9 times per step on the launch thread: one pass over the parameters, shape-derived tables cached)
+        ptrs = []
+        fixed = None
+        for i, p in enumerate(params):
+            if p.dtype is not _PARAM_DTYPES[i]:
+                raise AssertionError(PARAM_NAMES[i])
+            if not p.is_contiguous():
+                if fixed is None:
+                    fixed = list(params)
+                fixed[i] = p = p.contiguous()
+            ptrs.append(p.data_ptr())
+        if fixed is not None:
+            params = tuple(fixed)
+        # one arena for everything the backward reads (offsets per shape cached)
+        offs, total = _arena_layout(R, E, N, S, Qt, nheads, F_)
         arena = torch.empty(total, dtype=torch.uint8, device=dev)
         x3 = torch.empty_like(x0)
         xb3 = torch.empty_like(xb0)
         L = MpfDecoderLayer()
         base = arena.data_ptr()
-        for n in _SAVED:
-            setattr(L, n, base)
-            base += _al(sizes[n])
-        for n, p in zip(PARAM_NAMES, params):
-            setattr(L, n, p.data_ptr())
+        for n, o in zip(_SAVED, offs):
+            setattr(L, n, base + o)
+        for n, v in zip(PARAM_NAMES, ptrs):
+            setattr(L, n, v)
         L.x0, L.xb0, L.k_c, L.v_c = x0.data_ptr(), xb0.data_ptr(), k_c.data_ptr(), v_c.data_ptr()
         L.mask_c = mask_c.data_ptr()
         L.mask_s = mask_s.data_ptr() if mask_s is not None else None
@@ -161,9 +226,9 @@ class DecoderLayerFn(Function):
         L.Qt, L.N, L.H, L.S, L.ffn_dim, L.eps = Qt, N, nheads, S, F_, float(eps)
         if not k_c.is_contiguous():
             L.kv_row_stride, L.kv_img_stride = k_c.stride(0), k_c.stride(1)
-        sc = _scratch_buf(dev, max(lib.mpf_decoder_layer_scratch_bytes(Qt, N, nheads, S, F_, 0),
-                                   lib.mpf_decoder_layer_scratch_bytes(Qt, N, nheads, S, F_, 1)))
-        ws = _attn_workspace(dev, max(lib.mpf_attn_workspace_bytes(Qt, S, N, nheads), lib.mpf_attn_workspace_bytes(Qt, Qt, N, nheads)))
+        sc_bytes, ws_bytes = _scratch_bytes(lib, Qt, N, nheads, S, F_)
+        sc = _scratch_buf(dev, sc_bytes)
+        ws = _attn_workspace(dev, ws_bytes)
         L.scratch, L.scratch_bytes, L.attn_ws, L.attn_ws_bytes = sc.data_ptr(), sc.numel(), ws.data_ptr(), ws.numel()
         stream = _lib.stream_ptr(dev)
         with _lib.device_guard(dev):
@@ -199,16 +264,8 @@ class DecoderLayerFn(Function):
         else:
             d_kv = torch.empty((2,) + tuple(k_c.shape), dtype=torch.bfloat16, device=dev)
             d_k, d_v = d_kv[0], d_kv[1]
-        wnames = [n for n in PARAM_NAMES if n not in _LN]
-        wshapes = [p.shape for n, p in zip(PARAM_NAMES, params) if n not in _LN]
-        # arena order: the q / k / v weight gradients side by side, then their bias gradients (the native layer then
-        # produces them with one GEMM), the rest in parameter order
-        order = sorted(range(len(wnames)), key=lambda i: ({"sa_wq": 0, "sa_wk": 1, "sa_wv": 2, "sa_bq": 3, "sa_bk": 4, "sa_bv": 5}
-                                                           .get(wnames[i], 6 + i)))
-        offs, tot = [0] * len(wnames), 0
-        for i in order:
-            offs[i] = tot
-            tot += (wshapes[i].numel() + 127) & ~127
+        wshapes = [p.shape for p, ln in zip(params, _IS_LN) if not ln]
+        offs, tot = _wgrad_layout(tuple(wshapes))
         wg = torch.empty(tot, dtype=torch.bfloat16, device=dev)
         d_ln = torch.empty((6, 256), dtype=torch.float32, device=dev)
         G.g_x3 = g_x3.data_ptr() if g_x3 is not None else None
@@ -218,21 +275,23 @@ class DecoderLayerFn(Function):
         for n, o in zip(_WGRADS, offs):
             setattr(G, n, wbase + 2 * o)
         G.d_ln = d_ln.data_ptr()
-        sc = _scratch_buf(dev, lib.mpf_decoder_layer_scratch_bytes(Qt, N, H, S, F_, 1))
-        ws = _attn_workspace(dev, max(lib.mpf_attn_workspace_bytes(Qt, S, N, H), lib.mpf_attn_workspace_bytes(Qt, Qt, N, H)))
+        sc_bytes, ws_bytes = _scratch_bytes(lib, Qt, N, H, S, F_)
+        sc = _scratch_buf(dev, sc_bytes)
+        ws = _attn_workspace(dev, ws_bytes)
         L.scratch, L.scratch_bytes, L.attn_ws, L.attn_ws_bytes = sc.data_ptr(), sc.numel(), ws.data_ptr(), ws.numel()
         stream = _lib.stream_ptr(dev)
         with _lib.device_guard(dev):
             code = lib.mpf_decoder_layer_backward(ctypes.byref(L), ctypes.byref(G), stream)
         _lib.check(code, "mpf_decoder_layer_backward")
         grads, wi, li = [], 0, 0
-        for n in PARAM_NAMES:
-            if n in _LN:
-                grads.append(d_ln[li])
+        lns = d_ln.unbind(0)
+        for ln in _IS_LN:
+            if ln:
+                grads.append(lns[li])
                 li += 1
             else:
                 s_ = wshapes[wi]
-                grads.append(wg[offs[wi]:offs[wi] + s_.numel()].view(s_))
+                grads.append(wg.as_strided(s_, _contig_strides(s_), offs[wi]))      # (one view op instead of slice + view)
                 wi += 1
         return (d_x0, d_xb0, d_k, d_v, None, None, None, None, None, *grads)
 
