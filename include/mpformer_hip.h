@@ -894,6 +894,9 @@ int mpf_res_ln256_backward(const float* s, const float* mean, const float* rstd,
 int mpf_res_ln256_backward_partial(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
                                    const void* gy16, const float* gy_plus, float* ds32, void* ds16, int rows, void* partials,
                                    size_t partials_bytes, void* stream);
+int mpf_res_ln256_backward_partial_amax(const float* s, const float* mean, const float* rstd, const float* gamma, const float* gy32,
+                                        const void* gy16, const float* gy_plus, float* ds32, void* ds16, int rows, void* partials,
+                                        size_t partials_bytes, float* ds_amax, void* stream);
 int mpf_ln_partial_reduce(const void* partials, size_t stride_bytes, int rows, int n_ln, float* out, void* stream);
 /* One-launch deterministic form (the workgroup that arrives last sums the per-workgroup partials in a fixed order):
  * dgamma_dbeta [2][256] = (dgamma, dbeta), fully written.  The first 4 bytes of `workspace`

@@ -148,6 +148,7 @@ SIGNATURES = {
     "mpf_gemm3_nt_ex": (_c_int, [_c_vp, _c_int, ctypes.c_int64, _c_vp, _c_int, ctypes.c_int64, _c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_res_ln256_backward_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "mpf_res_ln256_backward_partial": (_c_int, [_c_vp] * 9 + [_c_int, _c_vp, ctypes.c_size_t, _c_vp]),
+    "mpf_res_ln256_backward_partial_amax": (_c_int, [_c_vp] * 9 + [_c_int, _c_vp, ctypes.c_size_t, _c_vp, _c_vp]),
     "mpf_ln_partial_reduce": (_c_int, [_c_vp, ctypes.c_size_t, _c_int, _c_int, _c_vp, _c_vp]),
     "mpf_res_ln256_backward_det_workspace_bytes": (ctypes.c_size_t, [_c_int]),
     "mpf_res_ln256_backward_det": (_c_int, [_c_vp] * 10 + [_c_int, _c_vp, ctypes.c_size_t, _c_vp]),

@@ -606,6 +606,15 @@ extern "C" int mpf_res_ln256_backward_partial(const float* s, const float* mean,
                                               const void* gy16, const float* gy_plus, float* ds32, void* ds16, int rows, void* partials,
                                               size_t partials_bytes, void* stream)
 {
+    return mpf_res_ln256_backward_partial_amax(s, mean, rstd, gamma, gy32, gy16, gy_plus, ds32, ds16, rows, partials, partials_bytes, nullptr,
+                                               stream);
+}
+
+// ... recording the largest |ds| in an amax slot (zeroed by the caller; may be NULL)
+extern "C" int mpf_res_ln256_backward_partial_amax(const float* s, const float* mean, const float* rstd, const float* gamma,
+                                                   const float* gy32, const void* gy16, const float* gy_plus, float* ds32, void* ds16,
+                                                   int rows, void* partials, size_t partials_bytes, float* ds_amax, void* stream)
+{
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) return 0;
     if (!s || !mean || !rstd || !gamma || (!gy32 && !gy16 && !gy_plus) || (!ds32 && !ds16) || !partials)
@@ -619,7 +628,7 @@ extern "C" int mpf_res_ln256_backward_partial(const float* s, const float* mean,
     mpf::set_kernel("res_ln256_bwd_kernel");
 #define RLN_BWDQ(A, B, C)                                                                                                         \
     hipLaunchKernelGGL((res_ln256_bwd_kernel<A, B, C, 1>), grid, dim3(256), 0, st, s, mean, rstd, gamma, gy32, (const __bf16*)gy16,       \
-                       gy_plus, ds32, (__bf16*)ds16, part, part, rows, rpb)
+                       gy_plus, ds32, (__bf16*)ds16, part, part, rows, rpb, ds_amax)
     switch ((gy32 ? 4 : 0) | (gy16 ? 2 : 0) | (gy_plus ? 1 : 0)) {
         case 1: RLN_BWDQ(false, false, true); break;
         case 2: RLN_BWDQ(false, true, false); break;

@@ -24,7 +24,7 @@ from torch.autograd import Function
 
 from .gemm3 import amax, amax_slots, gemm3_h2, gemm3_nt, gemm3_nt_grouped, nt_reduce_levels, split_weights_grouped_h2
 from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
-from .resln import ln256_backward, ln256_forward
+from .resln import LnGradGroup, ln256_forward
 
 PARAMS_PER_LAYER = 16
 _EPS = 1e-5
@@ -171,6 +171,7 @@ class EncoderFn(Function):
         am = amax_slots(5 * nl, g.device)               # per layer: ds2, dh, ds1, draw, gv
         lvls = [None] * nl
         gq = None
+        lng = LnGradGroup(2 * nl, R, g.device)           # the 2 nl LayerNorm parameter gradients: one reduce launch at the end
         for i in reversed(range(nl)):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am) = saved[i * 19:(i + 1) * 19]
@@ -178,11 +179,11 @@ class EncoderFn(Function):
             (tv, tv_am), (to, to_am), (t1, t1_am), (t2, t2_am), (t288, t288_am) = ctx.planes_t[i]
             ds2_am, dh_am, ds1_am, draw_am, gv_am = am[5 * i:5 * i + 5]
             # norm2 <- ffn
-            ds2, dp[14], dp[15] = ln256_backward(s2, mean2, rstd2, g2, g, gq, ds_amax=ds2_am)
+            ds2 = lng.backward(s2, mean2, rstd2, g2, g, gq, ds_amax=ds2_am)
             dh = gemm3_h2(ds2, ds2_am, t2, t2_am, gate=h, out_amax=dh_am)
             dx1 = gemm3_h2(dh, dh_am, t1, t1_am, cin=ds2)
             # norm1 <- attention
-            ds1, dp[8], dp[9] = ln256_backward(s1, mean1, rstd1, g1, dx1, ds_amax=ds1_am)
+            ds1 = lng.backward(s1, mean1, rstd1, g1, dx1, ds_amax=ds1_am)
             dao = gemm3_h2(ds1, ds1_am, to, to_am)
             # d(raw): the softmax / offset-normaliser backward is the epilogue of the push kernel
             # (the bin + tile kernels record the largest magnitudes of gv / draw themselves: no amax pass over the two tensors)
@@ -212,6 +213,11 @@ class EncoderFn(Function):
             (dp[12], dp[13]), (dp[10], dp[11]), (dp[6], dp[7]), (dp[4], dp[5]) = _wgrad_group(
                 [(ds2, h), (dh, x1), (ds1, ao), (gv2, x)], [(ds2_am, h_am), (dh_am, x1_am), (ds1_am, ao_am), (gv_am, x_am)])
             dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp
+        dgb = lng.finish()                                 # [2 nl, 2, 256] in call order: (norm2, norm1) of layers nl - 1 .. 0
+        for z, i in enumerate(reversed(range(nl))):
+            base = i * PARAMS_PER_LAYER
+            dparams[base + 14], dparams[base + 15] = dgb[2 * z, 0], dgb[2 * z, 1]
+            dparams[base + 8], dparams[base + 9] = dgb[2 * z + 1, 0], dgb[2 * z + 1, 1]
         # d level_embed = sum_i lvl_i . [W_offsets_i ; W_weights_i]: one stacked product for all layers
         w288_all = torch.cat([params[i * PARAMS_PER_LAYER + k] for i in range(nl) for k in (0, 2)]).view(nl, -1, C)
         # [nl, L, 288] x [nl, 288, C] summed over the layers: 1.3 M multiply-adds — as a broadcast product + one reduction

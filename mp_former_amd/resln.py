@@ -133,6 +133,38 @@ def ln256_backward(s, mean, rstd, gamma, gy, gy_plus=None, ds_amax=None):
     return ds, dgb[0], dgb[1]
 
 
+class LnGradGroup:
+    """Parameter gradients of SEVERAL 256-channel LayerNorm backwards over the same number of rows with ONE reduce launch: every
+    backward leaves its per-workgroup partial sums in its own slot (`backward`), `finish()` sums all slots in a fixed order ->
+    [n, 2, 256] (dgamma, dbeta) per LayerNorm, in the order of the `backward` calls."""
+
+    def __init__(self, n, rows, device):
+        lib = _lib.lib()
+        self.n, self.rows, self.used = n, rows, 0
+        self.stride = (int(lib.mpf_res_ln256_backward_workspace_bytes(rows)) + 255) & ~255
+        self.parts = torch.empty(n * self.stride, dtype=torch.uint8, device=device)
+
+    def backward(self, s, mean, rstd, gamma, gy, gy_plus=None, ds_amax=None):
+        """-> ds fp32 (the parameter gradients come from finish())"""
+        assert self.used < self.n and s.shape[0] == self.rows
+        ds = torch.empty_like(s)
+        with _lib.device_guard(s.device):
+            code = _lib.lib().mpf_res_ln256_backward_partial_amax(
+                s.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), gy.data_ptr(), None,
+                gy_plus.data_ptr() if gy_plus is not None else None, ds.data_ptr(), None, self.rows,
+                self.parts.data_ptr() + self.used * self.stride, self.stride, ds_amax.data_ptr() if ds_amax is not None else None, _stream(s))
+        _lib.check(code, "mpf_res_ln256_backward_partial_amax")
+        self.used += 1
+        return ds
+
+    def finish(self):
+        out = torch.empty((self.used, 2, 256), dtype=torch.float32, device=self.parts.device)
+        with _lib.device_guard(out.device):
+            code = _lib.lib().mpf_ln_partial_reduce(self.parts.data_ptr(), self.stride, self.rows, self.used, out.data_ptr(), _stream(out))
+        _lib.check(code, "mpf_ln_partial_reduce")
+        return out
+
+
 _ln_ws = {}
 _det_ws_cache = {}
 

@@ -100,3 +100,30 @@ def test_ln256_amax_slots_bound_forward_exact_backward():
     ds, dg, db = ln256_backward(x, m, r, g, gy, ds_amax=sl[2])
     assert torch.equal(ds, ds0) and torch.equal(dg, dg0) and torch.equal(db, db0)
     assert float(amax_value(sl[2])) == float(ds.abs().max())
+
+
+def test_ln_grad_group_equals_single_backwards():
+    """LnGradGroup (several LayerNorm backwards, ONE parameter-gradient reduce launch: the encoder's twelve) == ln256_backward per
+    LayerNorm, bit for bit (same per-workgroup partials, same fixed-order sums), with and without the second gradient operand and
+    the amax slot."""
+    from mp_former_amd.gemm3 import amax_slots, amax_value
+    from mp_former_amd.resln import LnGradGroup, ln256_backward, ln256_forward
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    rows = 4300
+    grp = LnGradGroup(3, rows, dev)
+    want, got = [], []
+    sl = amax_slots(3, dev)
+    for z in range(3):
+        x = torch.randn(rows, 256, device=dev) * (z + 1)
+        g, b = torch.randn(256, device=dev), torch.randn(256, device=dev)
+        _, m, r, _ = ln256_forward(x, g, b, 1e-5)
+        gy = torch.randn(rows, 256, device=dev) * 1e-2
+        gp = torch.randn(rows, 256, device=dev) * 1e-2 if z == 1 else None
+        want.append(ln256_backward(x, m, r, g, gy, gp))
+        got.append(grp.backward(x, m, r, g, gy, gp, ds_amax=sl[z] if z != 2 else None))
+    dgb = grp.finish()
+    for z in range(3):
+        assert torch.equal(got[z], want[z][0])
+        assert torch.equal(dgb[z, 0], want[z][1]) and torch.equal(dgb[z, 1], want[z][2])
+    assert float(amax_value(sl[0])) == float(got[0].abs().max()) and float(amax_value(sl[1])) == float(got[1].abs().max())
