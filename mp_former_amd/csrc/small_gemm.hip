@@ -622,25 +622,21 @@ __global__ __launch_bounds__(256) void tall_ws_bf16_kernel(const __bf16* __restr
             tall_glds16(src, lds0 + buf * TILE_BYTES + piece * 1024);
         }
     };
-    // NBUF buffers, tiles requested D = NBUF - 1 ahead (X streams from HBM: one tile of arithmetic does not cover that round
-    // trip), ONE barrier per tile.  At the top of tile t the wave needs ITS pieces of tile t; everything it issued after them
-    // may stay in flight: the pieces of the D - 1 later tiles and the result stores of the D tiles before — vmcnt of that
-    // count while it is exact (full tiles, full column slices, all later tiles requested), vmcnt(0) otherwise.  The barrier
-    // then says every wave's pieces have landed AND every wave is done with tile t - 1, whose buffer receives tile t + D.
-    constexpr int D = NBUF - 1, P = PIECES / 4, S = NB * MB;
-    static_assert((D - 1) * P + D * S <= 63, "vmcnt range");
-    const bool exact = (N % (64 * NB)) == 0;
+    // NBUF buffers, tiles requested D = NBUF - 1 ahead, ONE barrier per tile.  At the top of tile t the wave waits for
+    // everything it has in flight — its pieces of tile t AND the result stores of the tile before.  (A count that lets those
+    // stores stay in flight — vmcnt(#stores) — is NOT safe: the counter is shared by loads and stores, which complete in order
+    // only among themselves, so a satisfied count does not prove that the older DMA pieces have landed.  That form shipped for a
+    // few hours in round 4 and showed as a rare 0.3 % deviation of a whole forward pass in one of three full test runs.)
+    // The barrier then says every wave's pieces have landed AND every wave is done with tile t - 1, whose buffer receives
+    // tile t + D.
+    constexpr int D = NBUF - 1;
     const int g = gridDim.y;
     int t = blockIdx.y, it = 0;
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (t + d * g < ntiles) request(t + d * g, d);
     for (; t < ntiles; t += g, ++it) {
-        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (it >= D) {
-            if (exact && t + (D - 1) * g < ntiles) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((D - 1) * P + D * S) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }                                                       // (0 < it < D: those tiles landed with the first wait)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + D * g < ntiles) request(t + D * g, (it + D) % NBUF);
         const unsigned char* tile = ws_lds + (it % NBUF) * TILE_BYTES;

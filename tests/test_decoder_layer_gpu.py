@@ -160,6 +160,7 @@ def test_round2_switches_do_not_change_the_step(switch):
     finally:
         os.environ.pop(switch, None)
     assert set(g_on) == set(g_off) and set(l_on) == set(l_off)
+    print(f"{switch}: max relative loss difference {max(abs(l_on[k] - l_off[k]) / max(1.0, abs(l_on[k])) for k in l_on):.2e}")
     bad = [(k, l_on[k], l_off[k]) for k in l_on if abs(l_on[k] - l_off[k]) > 2e-3 * max(1.0, abs(l_on[k]))]
     assert not bad, (switch, bad[:3])
     worst = ("", 0.0)

@@ -418,3 +418,49 @@ def test_amp_path_own_matching_against_the_fp32_matching(name):
     # so the bound is on the regret, the agreement share is only required not to collapse
     assert share >= 0.5, (share, regrets)
     assert max(regrets) <= 6e-2 and np.mean(regrets) <= 8e-3, regrets
+
+
+def test_amp_forward_is_bit_reproducible_run_to_run():
+    """The AMP head forward (pixel decoder outputs and all 6 x (1 + #aux) losses) twice in one process, draws replayed and the
+    assignment pinned, with unrelated allocations in between: bit-identical.  (Until the end of round 4 the NCHW route fell back
+    to the library's fp32 3x3 convolution, whose result moved run to run — 2e-5 relative on the losses, rarely 3e-3.)"""
+    from mp_former_amd import _rng
+    dev = torch.device("cuda:0")
+    z, cfg, pp, dp, feats, targets, replay = load_head_fixture("head_ragged")
+    h = _build(cfg, pp, dp, dev)
+    feats = {k: v.to(dev) for k, v in feats.items()}                  # NCHW maps: the route that used the library convolution
+    targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+    matcher = h.criterion.matcher
+    solve = matcher.match_many
+    pin = []
+    import os
+    os.environ["MPF_DEVICE_LSA"] = "0"
+
+    def run(first):
+        tags = fifo_to_tags(replay, cfg, "dn_pred_logits" in z)
+        if first:
+            matcher.match_many = lambda *a, **k: pin.append(solve(*a, **k)) or pin[-1]
+        else:
+            matcher.match_many = lambda *a, **k: pin[0]
+            tags = {t: d for t, d in tags.items() if not t.startswith("match")}
+        _rng.install_replay(tags)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            pdo = h.pixel_decoder.forward_features(feats)
+            losses, _ = h(feats, targets)
+        out = {"mask_features": pdo[0].float().clone()}
+        out.update({f"ms{i}": t.float().clone() for i, t in enumerate(pdo[2])})
+        out.update({k: v.float().clone() for k, v in losses.items()})
+        return out
+
+    try:
+        ref = run(True)
+        for it in range(3):
+            junk = [torch.full((1 << 20,), 1e3 * (it + 1), device=dev) for _ in range(8)]
+            del junk
+            cur = run(False)
+            diff = [k for k in ref if not torch.equal(ref[k], cur[k])]
+            assert not diff, (it, diff[:5])
+    finally:
+        matcher.match_many = solve
+        _rng.install_replay(None)
+        os.environ.pop("MPF_DEVICE_LSA", None)
