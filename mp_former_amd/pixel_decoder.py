@@ -208,8 +208,15 @@ def _conv(m, x, out_dtype=torch.float32):
     the GEMM forms take (3x3 / stride 1 / pad 1, or 1x1), else the library convolution.  x may be a bf16 feature map (1x1
     only; anything else gets the ``.float()`` of msdeformattn.py:320); out_dtype = bf16 asks the 1x1 form for a bf16 result."""
     if m.groups == 1 and m.dilation == (1, 1) and m.stride == (1, 1):
-        if m.kernel_size == (1, 1) and m.padding == (0, 0) and conv3x3.supported_1x1(x, m.weight):
-            return conv3x3.conv1x1(x, m.weight, m.bias, out_dtype)
+        if m.kernel_size == (1, 1) and m.padding == (0, 0):
+            if not conv3x3.supported_1x1(x, m.weight) and x.is_cuda and x.dim() == 4:
+                # an NCHW map: one relayout to channel-last planes, then the native GEMM (the library's convolution is not run-to-run
+                # reproducible for every solver MIOpen may pick — see the 3x3 case below)
+                xp = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+                if conv3x3.supported_1x1(xp, m.weight):
+                    x = xp
+            if conv3x3.supported_1x1(x, m.weight):
+                return conv3x3.conv1x1(x, m.weight, m.bias, out_dtype)
         x = x.float()
         if m.kernel_size == (3, 3) and m.padding == (1, 1):
             if not conv3x3.supported(x, m.weight) and x.is_cuda and x.dim() == 4:
