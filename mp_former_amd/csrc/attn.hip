@@ -18,12 +18,15 @@
 //   * the transposed product puts the queries on the lane axis (C layout: col = lane&15 = query), so a
 //     lane owns ONE query row of P: the online-softmax scale factors are per-lane scalars and the row
 //     max needs two cross-lane steps (xor 16, 32) per 32 keys;
-//   * O^T = V^T P^T: the 8 probabilities a lane holds after two 16-key tiles ARE its B fragment once
-//     the 32 keys of the block are relabelled (k = 8g+j <-> key 4g+j / 16+4g+j-4; sums do not care),
-//     and V is consumed as V^T [N, 256, Lk] (what the 1x1 projection of the NCHW feature map produces
-//     anyway), so the A fragment is two 8-byte loads per lane;
-//   * the byte attention mask [N, Lq, Lk] (one copy for all heads) is read as one dword per lane per
-//     16-key tile.
+//   * O^T = V^T P^T: the rows of the two S^T tiles of a step are taken in the order key_of_row (tile t,
+//     row i = key 8 (i >> 2) + 4 t + (i & 3)), so the 8 probabilities a lane holds after the two tiles
+//     belong to 8 CONSECUTIVE keys and ARE its B fragment in natural key order; V is consumed as V^T
+//     [N, 256, Lk] (what the 1x1 projection of the NCHW feature map produces anyway): the A fragment is
+//     one 16-byte load per lane;
+//   * the byte attention mask [N, Lq, Lk] (one copy for all heads) is read as one 8-byte word per lane
+//     and query sub-tile; the dK / dV kernel (keys on the lane axis) reads it transposed (attn_bwd_aux);
+//   * every key loop is software-pipelined by hand (next step requested before the current step's
+//     arithmetic, scheduling barriers between the phases): hipcc otherwise sinks each load to its use.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
@@ -46,27 +49,6 @@ __device__ __forceinline__ bf16x8 ld8_rows(const __hip_bfloat16* base, int row, 
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     return row < limit ? v : z;
 }
-// 4 consecutive elements of a row starting at i (zero past `limit`); AL: i and limit multiples of 4.  AL is a
-// COMPILE-TIME switch: as a run-time flag it put every one of these loads behind a branch, i.e. exactly the serialised
-// round trips the comment above is about (9 per 32-key step in the forward kernel).
-template <bool AL>
-__device__ __forceinline__ bf16x4 ld4_clamped(const __hip_bfloat16* row, int i, int limit)
-{
-    const bf16x4 z = {0, 0, 0, 0};
-    if constexpr (AL) {
-        const bf16x4 v = *reinterpret_cast<const bf16x4*>(row + max(min(i, limit - 4), 0));
-        return i < limit ? v : z;
-    } else {
-        bf16x4 r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const __bf16 e = *reinterpret_cast<const __bf16*>(row + min(i + j, limit - 1));
-            r[j] = i + j < limit ? e : (__bf16)0.f;
-        }
-        return r;
-    }
-}
-
 // The same loads WITHOUT the zeroing select, for the software-pipelined key loops: a select on the loaded value inside the
 // request phase makes the wave wait for the request it has just issued.  Keys at or past the range's end are dead in the
 // score (probability exactly 0), so the finite stand-in data of the clamped address never reaches a result.
@@ -74,19 +56,6 @@ __device__ __forceinline__ bf16x8 ld8_rows_raw(const __hip_bfloat16* base, int r
 {
     return *reinterpret_cast<const bf16x8*>(base + (int64_t)min(row, limit - 1) * row_stride + col);
 }
-template <bool AL>
-__device__ __forceinline__ bf16x4 ld4_raw(const __hip_bfloat16* row, int i, int limit)
-{
-    if constexpr (AL) {
-        return *reinterpret_cast<const bf16x4*>(row + max(min(i, limit - 4), 0));
-    } else {
-        bf16x4 r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = *reinterpret_cast<const __bf16*>(row + min(i + j, limit - 1));
-        return r;
-    }
-}
-
 // 8 consecutive elements of a row starting at i; AL: i and limit multiples of 8, 16-byte aligned rows
 template <bool AL>
 __device__ __forceinline__ bf16x8 ld8_raw(const __hip_bfloat16* row, int i, int limit)
@@ -121,20 +90,6 @@ __device__ __forceinline__ uint2 ld_mask8(const uint8_t* mrow, int key0, int lim
 // B fragment of the P V product in natural key order.  V^T / K^T fragments are then ONE 16-byte load per lane and the mask
 // bytes of a query row one 8-byte load (was two 8-byte + two 4-byte loads on 32-byte pieces of twice as many cache lines).
 __device__ __forceinline__ int key_of_row(int t, int i) { return ((i >> 2) << 3) + 4 * t + (i & 3); }
-
-// the 4 mask bytes of keys key0 .. key0 + 3 of one query row as a word (nonzero byte = masked), clamped reads
-template <bool AL>
-__device__ __forceinline__ uint32_t ld_mask4(const uint8_t* mrow, int key0, int limit)
-{
-    if constexpr (AL) {
-        return *reinterpret_cast<const uint32_t*>(mrow + max(min(key0, limit - 4), 0));
-    } else {
-        uint32_t mw = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mw |= (mrow[min(key0 + r, limit - 1)] ? 0xFFu : 0u) << (8 * r);
-        return mw;
-    }
-}
 
 constexpr int kHD = 32;          // head dim
 constexpr float kNegInf = -INFINITY;
@@ -405,17 +360,6 @@ struct AttnBwdParams {
     int64_t kv_row, kv_img;        // element strides of k, v between sequence positions / images (N*E, E when dense)
     int64_t dkv_row, dkv_img;      // ... and of dk, dv
 };
-
-__device__ __forceinline__ bf16x8 load8(const __hip_bfloat16* p) { return *reinterpret_cast<const bf16x8*>(p); }
-__device__ __forceinline__ bf16x8 zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
-
-// two 8-byte pieces (4 + 4 consecutive elements) of a row -> one MFMA fragment
-template <bool AL>
-__device__ __forceinline__ bf16x8 load4x2(const __hip_bfloat16* row, int i0, int i1, int limit)
-{
-    const bf16x4 lo = ld4_clamped<AL>(row, i0, limit), hi = ld4_clamped<AL>(row, i1, limit);
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
 
 // dK / dV.  Keys live on the lane axis (C layout of S = Q K^T: col = key, rows = queries), so per (key, query) the kernel needs
 // the mask byte, lse and delta with the QUERY index running inside a lane: they come from the aux buffers of
