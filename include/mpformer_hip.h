@@ -633,6 +633,16 @@ int mpf_gemm3_tn_h2(const float* a, int64_t lda, const float* a_amax, const void
                     const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
                     const float* gate, int64_t ldgate, float* c, int64_t ldc, float* out_amax, int M, int N, int K,
                     int relu, void* stream);
+/* mpf_gemm3_tn_h2 with the ReLU-backward gate as a BIT mask instead of the saved activation (linear1 / linear2 of an encoder
+ * layer, msdeformattn.py:123-127: the backward of `activation(linear1(x))` needs the sign of 4 bytes per element only):
+ *   gate_bits (may be NULL): [M][ldgbits bytes], bit (n & 7) of byte n / 8 of row m set <=> C[m][n] passes; otherwise 0;
+ *   gate_bits_out (may be NULL): receives the mask of (C[m][n] > 0) of this product in the same layout (with relu = 1: the
+ *     gate of its own backward).  N % 128 == 0, mask rows >= N / 8 bytes, 8-byte aligned.  Same arithmetic as
+ *     mpf_gemm3_tn_h2 with gate = the activation (bit-identical C). */
+int mpf_gemm3_tn_h2_bits(const float* a, int64_t lda, const float* a_amax, const void* b_planes_h2, const float* b_amax,
+                         const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
+                         const unsigned char* gate_bits, int64_t ldgbits, float* c, int64_t ldc, float* out_amax,
+                         unsigned char* gate_bits_out, int64_t ldgbits_out, int M, int N, int K, int relu, void* stream);
 
 /*
  * Several weight gradients over the SAME rows in one launch (the four Linear layers of an encoder layer whose operands are

@@ -78,6 +78,9 @@ SIGNATURES = {
     "mpf_gemm3_split_grouped_h2": (_c_int, [_c_vp, _c_int, ctypes.c_int64, _c_vp]),
     "mpf_gemm3_tn_h2": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64,
                               _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
+    "mpf_gemm3_tn_h2_bits": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64,
+                                   _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64,
+                                   _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_gemm3_nt_h2": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp,
                               _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_gemm3_nt_grouped_h2": (_c_int, [_c_vp, _c_int, _c_int, _c_int, ctypes.c_int64, _c_vp]),

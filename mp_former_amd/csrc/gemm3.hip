@@ -64,6 +64,13 @@ struct G3 {
     const float* a_amax;
     const float* b_amax;
     float* out_amax;
+    // ReLU gate as a BIT mask (fp16 x 2 entry mpf_gemm3_tn_h2_bits, N % 128 == 0): row m, bit n of [M][ldgbits bytes] = the
+    // gate of C[m][n]; an absent mask points at 8 bytes of ones (g3_const) with leading dimension / column multiplier 0.
+    // gbits_out (may be NULL): receives the mask of (C > 0) in the same layout.
+    const unsigned char* gbits;
+    unsigned char* gbits_out;
+    int64_t ldgbits, ldgbits_out;
+    int gbits_cm;
 };
 
 int g_ablate = 0;      // mpf_set_option("gemm3_ablate"): reserved for timing experiments
@@ -395,7 +402,9 @@ struct Acc<4, true> {
 // store is predicated).  With `if (p.cin) load` per quad hipcc branched around each load and waited for it on its own:
 // up to 64 dependent memory round trips per wave in the epilogue of a kernel whose main loop takes 8.  Loads of one
 // 16-column group (bias + 4 row tiles x 3 operands) are requested together.
-__device__ float g3_const[8] = {0.f, 0.f, 0.f, 0.f, 1.f, 1.f, 1.f, 1.f};
+// (bit patterns: four zeros, four ones (1.0f), 16 bytes of 0xFF = the absent bit-mask gate)
+__device__ __attribute__((aligned(16))) unsigned g3_const[12] = {0u, 0u, 0u, 0u, 0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u,
+                                    0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
 
 // device address of g3_const ON THE CURRENT DEVICE: a __device__ variable has one instance per GPU, so the address is
 // cached per device ordinal (a process-wide cache would hand a second GPU a pointer into the first one's memory)
@@ -416,6 +425,11 @@ int g3_consts(const float** out, const char* who)
     return 0;
 }
 
+inline void g3_no_bits(G3& p, const float* consts)
+{
+    p.gbits = reinterpret_cast<const unsigned char*>(consts + 8); p.ldgbits = 0; p.gbits_cm = 0; p.gbits_out = nullptr; p.ldgbits_out = 0;
+}
+
 // returns the largest |value| this thread stored (SCALED kernels; 0 otherwise)
 template <int NJ, int NI = 4, typename AccT = Acc<NJ, false>, bool SCALED = false>
 __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int lane, int m_wave, int n_wave, const float inv_a = 1.f,
@@ -425,11 +439,15 @@ __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int l
     const int r16 = lane & 15, g = lane >> 4;
     int64_t mrow[NI];
     bool mok[NI];
+    uint2 gb[NI];                // the wave tile's 64 gate bits of every row (all ones when there is no bit mask)
+    unsigned wb[NI][2];          // (C > 0) of the same 64 columns, this lane's nibbles
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int m = m_wave + i * 16 + r16;
         mok[i] = m < p.M;
         mrow[i] = min(m, p.M - 1);
+        gb[i] = *reinterpret_cast<const uint2*>(p.gbits + mrow[i] * p.ldgbits + (n_wave >> 3) * p.gbits_cm);
+        wb[i][0] = wb[i][1] = 0u;
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -456,6 +474,12 @@ __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int l
             if (p.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
             // ReLU backward: pass the gradient where the saved activation is > 0
             o = make_float4(gt[i].x > 0.f ? o.x : 0.f, gt[i].y > 0.f ? o.y : 0.f, gt[i].z > 0.f ? o.z : 0.f, gt[i].w > 0.f ? o.w : 0.f);
+            {   // the same gate as a bit mask: column n_wave + 16 j + 4 g + t = bit (16 (j & 1) + 4 g + t) of word j >> 1
+                const unsigned nib = ((j & 2) ? gb[i].y : gb[i].x) >> ((j & 1) * 16 + g * 4);
+                o = make_float4((nib & 1u) ? o.x : 0.f, (nib & 2u) ? o.y : 0.f, (nib & 4u) ? o.z : 0.f, (nib & 8u) ? o.w : 0.f);
+                const unsigned pos = (o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u);
+                wb[i][(j >> 1) & 1] |= pos << ((j & 1) * 16 + g * 4);
+            }
             if (mok[i] && nok) {
                 if constexpr (SCALED) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                 if (p.c16) {                 // (uniform; stores only) round to nearest even
@@ -472,6 +496,16 @@ __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int l
                     *reinterpret_cast<float4*>(p.c + mrow[i] * p.ldc + n) = o;
                 }
             }
+        }
+    }
+    if (p.gbits_out) {           // (uniform) the four lane groups of a row hold disjoint nibbles: OR them, group 0 stores 8 bytes
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            unsigned lo = wb[i][0], hi = wb[i][1];
+            lo |= __shfl_xor(lo, 16); hi |= __shfl_xor(hi, 16);
+            lo |= __shfl_xor(lo, 32); hi |= __shfl_xor(hi, 32);
+            if (g == 0 && mok[i] && n_wave < p.N)
+                *reinterpret_cast<uint2*>(p.gbits_out + mrow[i] * p.ldgbits_out + (n_wave >> 3)) = make_uint2(lo, hi);
         }
     }
     return amax;
@@ -1615,7 +1649,9 @@ static bool g3_launch_two_pass(G3& p, hipStream_t st)
 static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows, const void* b_planes,
                       const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
                       const float* gate, int64_t ldgate, float* c, int64_t ldc, int M, int N, int K,
-                      int relu, void* stream, const float* a_amax, const float* b_amax, float* out_amax);
+                      int relu, void* stream, const float* a_amax, const float* b_amax, float* out_amax,
+                      const unsigned char* gbits = nullptr, int64_t ldgbits = 0, unsigned char* gbits_out = nullptr,
+                      int64_t ldgbits_out = 0);
 
 extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2_rows, const void* b_planes,
                             const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
@@ -1636,10 +1672,24 @@ extern "C" int mpf_gemm3_tn_h2(const float* a, int64_t lda, const float* a_amax,
                       a_amax, b_amax, out_amax);
 }
 
+extern "C" int mpf_gemm3_tn_h2_bits(const float* a, int64_t lda, const float* a_amax, const void* b_planes_h2, const float* b_amax,
+                                    const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
+                                    const unsigned char* gate_bits, int64_t ldgbits, float* c, int64_t ldc, float* out_amax,
+                                    unsigned char* gate_bits_out, int64_t ldgbits_out, int M, int N, int K, int relu, void* stream)
+{
+    if (!a_amax || !b_amax) return mpf::fail(MPF_E_NULL, "gemm3_tn_h2_bits: NULL amax");
+    if (N % 128 != 0 || (gate_bits && (ldgbits < N / 8 || ldgbits % 8 != 0 || ((uintptr_t)gate_bits & 7))) ||
+        (gate_bits_out && (ldgbits_out < N / 8 || ldgbits_out % 8 != 0 || ((uintptr_t)gate_bits_out & 7))))
+        return mpf::fail(MPF_E_SHAPE, "gemm3_tn_h2_bits: N must be a multiple of 128; mask rows of >= N / 8 bytes, 8-byte aligned");
+    return g3_tn_impl(a, lda, nullptr, 0, b_planes_h2, bias, c_in, ldcin, c_in2, ldcin2, nullptr, 0, c, ldc, M, N, K, relu, stream,
+                      a_amax, b_amax, out_amax, gate_bits, ldgbits, gate_bits_out, ldgbits_out);
+}
+
 static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows, const void* b_planes,
                       const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
                       const float* gate, int64_t ldgate, float* c, int64_t ldc, int M, int N, int K,
-                      int relu, void* stream, const float* a_amax, const float* b_amax, float* out_amax)
+                      int relu, void* stream, const float* a_amax, const float* b_amax, float* out_amax,
+                      const unsigned char* gbits, int64_t ldgbits, unsigned char* gbits_out, int64_t ldgbits_out)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!a || !b_planes || !c) return mpf::fail(MPF_E_NULL, "gemm3_tn: NULL buffer");
@@ -1663,6 +1713,9 @@ static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows,
         if (!c_in) { p.cin = consts; p.ldcin = 0; }
         if (!c_in2) { p.cin2 = consts; p.ldcin2 = 0; }
         if (!gate) { p.gate = consts + 4; p.ldgate = 0; }
+        g3_no_bits(p, consts);
+        if (gbits) { p.gbits = gbits; p.ldgbits = ldgbits; p.gbits_cm = 1; }
+        p.gbits_out = gbits_out; p.ldgbits_out = ldgbits_out;
     }
     const int tiles_m = (M + kBM - 1) / kBM;
     // 96-wide column tiles when they waste fewer columns (e.g. N = 288 = 3 x 96)
@@ -1751,6 +1804,7 @@ extern "C" int mpf_gemm3_tn_ex(const void* a, int a_dtype, int64_t lda, const vo
     p.bias = bias ? bias : consts; p.bias_cm = bias ? 1 : 0;
     p.cin = c_in ? c_in : consts; p.ldcin = c_in ? ldcin : 0; p.cin_cm = c_in ? 1 : 0;
     p.cin2 = consts; p.ldcin2 = 0; p.cin2_cm = 0; p.gate = consts + 4; p.ldgate = 0; p.gate_cm = 0;
+    g3_no_bits(p, consts);
     p.c = c_dtype == MPF_F32 ? (float*)c : nullptr; p.c16 = c_dtype == MPF_BF16 ? (unsigned short*)c : nullptr;
     p.lda = lda; p.ldc = ldc; p.plane = (int64_t)N * K;
     p.M = M; p.N = N; p.K = K; p.a2_rows = 0; p.relu = relu;
@@ -1815,6 +1869,7 @@ static int g3_conv_impl(const float* x, const void* w_planes, const float* bias,
     p.a = x; p.a2 = nullptr; p.bp = (const unsigned short*)w_planes; p.c = y;
     p.bias = bias ? bias : consts; p.bias_cm = bias ? 1 : 0;
     p.cin = consts; p.ldcin = 0; p.cin_cm = 0; p.cin2 = consts; p.ldcin2 = 0; p.cin2_cm = 0; p.gate = consts + 4; p.ldgate = 0; p.gate_cm = 0;
+    g3_no_bits(p, consts);
     p.M = (int)M64; p.N = Cout; p.K = 9 * Cin; p.lda = Cin; p.ldc = Cout; p.plane = (int64_t)Cout * p.K;
     p.a2_rows = 0; p.relu = 0; p.c16 = nullptr;
     p.cv_H = H; p.cv_W = W; p.cv_cin = Cin; p.cv_sign = transposed ? -1 : 1;

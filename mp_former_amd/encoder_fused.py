@@ -22,7 +22,7 @@ import math
 import torch
 from torch.autograd import Function
 
-from .gemm3 import amax, amax_slots, gemm3_h2, gemm3_nt, gemm3_nt_grouped, nt_reduce_levels, split_weights_grouped_h2
+from .gemm3 import amax, amax_slots, gemm3_h2, gemm3_h2_bits, gemm3_nt, gemm3_nt_grouped, nt_reduce_levels, split_weights_grouped_h2
 from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
 from .resln import LnGradGroup, ln256_forward
 
@@ -133,12 +133,16 @@ class EncoderFn(Function):
             ao = ao.view(R, C)
             s1 = gemm3_h2(ao, ao_am, po, po_am, bo, cin=x)
             x1, mean1, rstd1, _ = ln256_forward(s1, g1, b1, _EPS, y_bound=x1_am)
-            h = gemm3_h2(x1, x1_am, p1, p1_am, bb1, relu=True, out_amax=h_am)
+            # (the ReLU's gate leaves the product as a bit mask: the backward then reads 1 bit instead of 4 bytes per element of h)
+            if p1.shape[1] % 128 == 0:
+                h, hbits = gemm3_h2_bits(x1, x1_am, p1, p1_am, bb1, relu=True, out_amax=h_am, want_bits=True)
+            else:
+                h, hbits = gemm3_h2(x1, x1_am, p1, p1_am, bb1, relu=True, out_amax=h_am), None
             s2 = gemm3_h2(h, h_am, p2, p2_am, bb2, cin=x1)
             last = i + 1 == nl
             x2, mean2, rstd2, qn = ln256_forward(s2, g2_, b2, _EPS, padd=None if last else pos_full, y_bound=xn_am,
                                                  padd_amax=None if last else pos_am, yplus_bound=None if last else qn_am)
-            saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am]
+            saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am, hbits]
             x, q, x_am, q_am = x2, qn, xn_am, qn_am
         ctx.save_for_backward(pos_full, level_embed, *params, *saved)
         ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
@@ -174,13 +178,16 @@ class EncoderFn(Function):
         lng = LnGradGroup(2 * nl, R, g.device)           # the 2 nl LayerNorm parameter gradients: one reduce launch at the end
         for i in reversed(range(nl)):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
-            (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am) = saved[i * 19:(i + 1) * 19]
+            (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am, hbits) = saved[i * 20:(i + 1) * 20]
             dp = [None] * PARAMS_PER_LAYER
             (tv, tv_am), (to, to_am), (t1, t1_am), (t2, t2_am), (t288, t288_am) = ctx.planes_t[i]
             ds2_am, dh_am, ds1_am, draw_am, gv_am = am[5 * i:5 * i + 5]
             # norm2 <- ffn
             ds2 = lng.backward(s2, mean2, rstd2, g2, g, gq, ds_amax=ds2_am)
-            dh = gemm3_h2(ds2, ds2_am, t2, t2_am, gate=h, out_amax=dh_am)
+            if hbits is not None:
+                dh = gemm3_h2_bits(ds2, ds2_am, t2, t2_am, gate_bits=hbits, out_amax=dh_am)
+            else:
+                dh = gemm3_h2(ds2, ds2_am, t2, t2_am, gate=h, out_amax=dh_am)
             dx1 = gemm3_h2(dh, dh_am, t1, t1_am, cin=ds2)
             # norm1 <- attention
             ds1 = lng.backward(s1, mean1, rstd1, g1, dx1, ds_amax=ds1_am)

@@ -146,6 +146,29 @@ def gemm3_h2(a, a_amax, planes, w_amax, bias=None, cin=None, cin2=None, gate=Non
     return c
 
 
+def gemm3_h2_bits(a, a_amax, planes, w_amax, bias=None, cin=None, cin2=None, gate_bits=None, relu=False, out_amax=None,
+                  want_bits=False):
+    """``gemm3_h2`` with the ReLU-backward gate as a bit mask (``mpf_gemm3_tn_h2_bits``; N % 128 == 0): gate_bits [M, N / 8]
+    uint8 — bit n & 7 of byte n // 8 — instead of the saved activation; want_bits: also return the mask of (C > 0), i.e. with
+    ``relu`` the gate of this product's own backward.  Returns C, or (C, bits)."""
+    assert a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1
+    assert planes.dtype == torch.float16 and planes.is_contiguous() and planes.shape[0] == 2
+    M, K = a.shape
+    N = planes.shape[1]
+    assert planes.shape[2] == K and N % 128 == 0
+    if gate_bits is not None:
+        assert gate_bits.dtype == torch.uint8 and gate_bits.shape == (M, N // 8) and gate_bits.is_contiguous()
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    bits = torch.empty((M, N // 8), dtype=torch.uint8, device=a.device) if want_bits else None
+    with _lib.device_guard(a.device):
+        code = _lib.lib().mpf_gemm3_tn_h2_bits(
+            a.data_ptr(), a.stride(0), a_amax.data_ptr(), planes.data_ptr(), w_amax.data_ptr(), _p(bias),
+            _p(cin), _rows(cin, N) if cin is not None else 0, _p(cin2), _rows(cin2, N) if cin2 is not None else 0,
+            _p(gate_bits), N // 8, c.data_ptr(), c.stride(0), _p(out_amax), _p(bits), N // 8, M, N, K, 1 if relu else 0, _stream(a))
+    _lib.check(code, "mpf_gemm3_tn_h2_bits")
+    return (c, bits) if want_bits else c
+
+
 def _p(t):
     return t.data_ptr() if t is not None else None
 

@@ -286,6 +286,38 @@ def test_gemm3_tn_h2_dynamic_range_and_special_values():
     assert bool(torch.isnan(got[5]).all()) and not bool(torch.isnan(got[6]).any())
 
 
+@pytest.mark.parametrize("M,F,C", [(3000, 1024, 256), (1000, 128, 256), (43008, 1024, 256), (130, 384, 64)])
+def test_gemm3_tn_h2_bit_mask_gate_is_the_activation_gate(M, F, C):
+    """``mpf_gemm3_tn_h2_bits`` (the encoder's linear1 -> ReLU -> linear2 backward, msdeformattn.py:123-127): the product with
+    ReLU also returns the mask of (C > 0), one bit per element in numpy's little bit order; the input-gradient product gated by
+    that mask is bit-identical to the one gated by the saved activation (two-pass and one-pass tiles, ragged last row tile)."""
+    import numpy as np
+    from mp_former_amd.gemm3 import amax, amax_slots, gemm3_h2, gemm3_h2_bits, split_weights_grouped_h2
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + F)
+    w1 = torch.randn(F, C, device=dev) / 16
+    b1 = torch.randn(F, device=dev) * 0.1
+    x = torch.randn(M, C, device=dev)
+    g = torch.randn(M, C, device=dev)
+    add = torch.randn(M, F, device=dev)
+    (p1, a1), (p1t, a1t) = split_weights_grouped_h2([([w1], False), ([w1], True)])       # linear1; and W1 as the operand of g . W1
+    h_ref = gemm3_h2(x, amax(x), p1, a1, b1, relu=True)
+    oam = amax_slots(2, dev)
+    h, bits = gemm3_h2_bits(x, amax(x), p1, a1, b1, relu=True, out_amax=oam[0], want_bits=True)
+    assert torch.equal(h, h_ref)
+    assert bits.shape == (M, F // 8) and bits.dtype == torch.uint8
+    want = np.packbits((h_ref > 0).cpu().numpy(), axis=1, bitorder="little")
+    assert np.array_equal(bits.cpu().numpy(), want)
+    assert 0.2 < float((h_ref > 0).float().mean()) < 0.8
+    # dh = (g . W1^T ... here: any product with N = F) gated: activation gate against bit gate, with an addend in the epilogue
+    (p2t, a2t), = split_weights_grouped_h2([([torch.randn(C, F, device=dev) / 16], True)])  # [F, C] planes: g [M, C] -> [M, F]
+    d_ref = gemm3_h2(g, amax(g), p2t, a2t, cin=add, gate=h_ref, out_amax=oam[1])
+    d_bits = gemm3_h2_bits(g, amax(g), p2t, a2t, cin=add, gate_bits=bits)
+    assert torch.equal(d_bits, d_ref)
+    assert bool(((d_ref == 0) == (h_ref <= 0)).all())
+    del p1t, a1t
+
+
 @pytest.mark.parametrize("R,M,N,rps", [(4096, 256, 256, 512), (3000, 256, 1024, 512), (2048, 256, 288, 256), (1000, 100, 36, 128)])
 def test_gemm3_nt_h2_weight_gradient_accuracy(R, M, N, rps):
     from mp_former_amd import _lib
