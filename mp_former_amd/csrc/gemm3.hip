@@ -474,9 +474,13 @@ __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int l
             if (p.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
             // ReLU backward: pass the gradient where the saved activation is > 0
             o = make_float4(gt[i].x > 0.f ? o.x : 0.f, gt[i].y > 0.f ? o.y : 0.f, gt[i].z > 0.f ? o.z : 0.f, gt[i].w > 0.f ? o.w : 0.f);
-            {   // the same gate as a bit mask: column n_wave + 16 j + 4 g + t = bit (16 (j & 1) + 4 g + t) of word j >> 1
+            // the same gate as a bit mask: column n_wave + 16 j + 4 g + t = bit (16 (j & 1) + 4 g + t) of word j >> 1
+            // (uniform branches around register arithmetic only: the launches without masks do not pay for it)
+            if (p.gbits_cm) {
                 const unsigned nib = ((j & 2) ? gb[i].y : gb[i].x) >> ((j & 1) * 16 + g * 4);
                 o = make_float4((nib & 1u) ? o.x : 0.f, (nib & 2u) ? o.y : 0.f, (nib & 4u) ? o.z : 0.f, (nib & 8u) ? o.w : 0.f);
+            }
+            if (p.gbits_out) {
                 const unsigned pos = (o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u);
                 wb[i][(j >> 1) & 1] |= pos << ((j & 1) * 16 + g * 4);
             }
