@@ -16,6 +16,8 @@ torch.manual_seed(0)
 from mp_former_amd import _lib, _miopen  # noqa: E402
 _lib.lib()
 _miopen.use_shipped_find_db(check_version=True)
+if os.environ.get("MPF_CONV_FIND", "0") == "1":          # (experiment: the non-immediate MIOpen path with its per-process algorithm cache)
+    torch.backends.cudnn.benchmark = True
 model = bench.TrainModel().to(dev).train()
 model.backbone.to(memory_format=torch.channels_last)
 opt = bench.build_optimizer(model)
