@@ -232,6 +232,10 @@ def main():
     _lib.lib()   # fail loudly if the native library is missing
     _miopen.use_shipped_find_db(check_version=True)      # tuned MIOpen solver choice (private copy; logs a version mismatch)
 
+    from mp_former_amd import dropin
+    one_thread = os.environ.get("MPF_AUTOGRAD_ONE_THREAD", "1") == "1"
+    dropin.configure_training_process(single_thread_autograd=one_thread)    # backward on the launch thread (A/B switch: 0)
+
     torch.manual_seed(rank)
     if os.environ.get("MPF_CONV_FIND", "0") == "1":      # let MIOpen time its solvers per conv shape (slow warm-up)
         torch.backends.cudnn.benchmark = True
@@ -458,6 +462,7 @@ def main():
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "tokens_per_image_S": S_tok, "final_loss": round(final_loss, 4),
                        "roofline_steps": P, "msda_offsets": a.msda_offsets, "hip_graphs": graphs_note,
+                       "autograd_threads": "backward on the launch thread" if one_thread else "engine device thread (torch default)",
                        "process_group": pg_info},
             # the time-dominant native kernel family: the fp32 GEMMs of the pixel decoder as SIX bf16 MFMA products per fp32
             # product (three 8-bit-mantissa planes per operand, terms >= 2^-16 kept).  achieved = bf16 MFMA flops actually

@@ -132,3 +132,31 @@ def test_decoder_weight_cache_follows_the_module_tree():
     assert dec._weights()["transformer_ffn_layers.1.linear1.weight"] is dec.transformer_ffn_layers[1].linear1.weight
     dec.class_embed.register_parameter("extra", nn.Parameter(torch.zeros(3)))                       # added parameter
     assert dec._weights()["class_embed.extra"] is dec.class_embed.extra
+
+
+def test_configure_training_process_moves_backward_to_the_calling_thread():
+    """dropin.configure_training_process: backward() runs on the calling thread afterwards (a python autograd node sees the
+    caller's thread id), gradients unchanged; the previous setting is returned so a caller can restore it."""
+    import threading
+    from mp_former_amd import dropin
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(threading.get_ident())
+            return g * 2
+
+    prev = dropin.configure_training_process(single_thread_autograd=True)
+    try:
+        assert not torch.autograd.is_multithreading_enabled()
+        x = torch.ones(3, requires_grad=True)
+        Probe.apply(x).sum().backward()
+        assert seen == [threading.get_ident()] and torch.equal(x.grad, torch.full((3,), 2.0))
+    finally:
+        torch.autograd.set_multithreading_enabled(prev)
+    assert dropin.configure_training_process(single_thread_autograd=False) == prev
