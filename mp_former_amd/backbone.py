@@ -24,17 +24,21 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
 
     def scale_bias(self):
-        """(scale, shift) of the fixed affine; cached — the statistics are buffers that only change
-        through load_state_dict / .to(), which bump the tensors' version counters or replace them."""
-        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
-               self.weight.data_ptr(), self.running_var.data_ptr(), self.weight.device)
-        c = getattr(self, "_sb_cache", None)
-        if c is None or c[0] != key:
+        """(scale, shift) of the fixed affine; cached — the statistics are buffers that only change through load_state_dict
+        (in place: the version counters move) or .to() (the tensor objects are replaced).  The check reads the buffer dict
+        directly (identity + version of the four tensors): ``self.weight`` on a Module goes through ``__getattr__``, and this
+        runs once per convolution and step."""
+        b = self._buffers
+        w, bb, rm, rv = b["weight"], b["bias"], b["running_mean"], b["running_var"]
+        c = self.__dict__.get("_sb_cache")
+        if (c is None or c[0] is not w or c[1] is not bb or c[2] is not rm or c[3] is not rv
+                or c[4] != (w._version, bb._version, rm._version, rv._version)):
             with torch.no_grad():
-                scale = self.weight * (self.running_var + self.eps).rsqrt()
-                c = (key, scale, (self.bias - self.running_mean * scale).float().contiguous())
-            self._sb_cache = c
-        return c[1], c[2]
+                scale = w * (rv + self.eps).rsqrt()
+                c = (w, bb, rm, rv, (w._version, bb._version, rm._version, rv._version), scale,
+                     (bb - rm * scale).float().contiguous())
+            self.__dict__["_sb_cache"] = c
+        return c[5], c[6]
 
     def forward(self, x):
         scale, bias = self.scale_bias()
@@ -192,31 +196,44 @@ def _dense(t):
     return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
 
+_gsc_layouts = {}
+
+
 def _grouped_scale_cast(srcs, scales, out_dtype):
     """[cast(src_i * scale_i[c])] for a list of [C, ...] tensors (dense, dim 0 outermost) in ONE native
-    launch (csrc/elementwise.hip); the results are views of one buffer with the sources' strides."""
+    launch (csrc/elementwise.hip); the results are views of one buffer with the sources' strides.
+    The layout of a group (sizes, offsets, strides, scale pointers: functions of the shapes and of the frozen scales) is
+    computed once per group; per call only the source pointers and the new buffer's base enter the table."""
     dev = srcs[0].device
-    numels = [t.numel() for t in srcs]
-    offs, tot = [], 0
-    for n in numels:
-        offs.append(tot)
-        tot += (n + 63) & ~63
+    key = tuple([(t.shape, t.stride()) for t in srcs] + [id(sc) for sc in scales] + [out_dtype])
+    lay = _gsc_layouts.get(key)
+    if lay is None:
+        numels = [t.numel() for t in srcs]
+        offs, tot, blk = [], 0, 0
+        table = np.zeros((len(srcs), 6), dtype=np.int64)
+        for i, (t, sc) in enumerate(zip(srcs, scales)):
+            assert _dense(t) and sc.dtype == torch.float32 and sc.is_contiguous() and sc.numel() == t.shape[0]
+            offs.append(tot)
+            table[i, 2:] = (sc.data_ptr(), numels[i], numels[i] // t.shape[0], blk)
+            tot += (numels[i] + 63) & ~63
+            blk += (numels[i] + 2047) // 2048
+        esz = torch.empty(0, dtype=out_dtype).element_size()
+        lay = (table, np.asarray(offs, dtype=np.int64) * esz, tot, blk, [(o, n, t.shape, t.stride()) for o, n, t in zip(offs, numels, srcs)],
+               list(scales))                       # (the scales are kept referenced: their ids are part of the key)
+        if len(_gsc_layouts) > 64:
+            _gsc_layouts.clear()
+        _gsc_layouts[key] = lay
+    table, offs_b, tot, blk, views, _ = lay
     out = torch.empty(tot, dtype=out_dtype, device=dev)
-    esz = out.element_size()
-    table = np.empty((len(srcs), 6), dtype=np.int64)
-    blk = 0
-    base = out.data_ptr()
-    for i, (t, sc) in enumerate(zip(srcs, scales)):
-        assert _dense(t) and sc.dtype == torch.float32 and sc.is_contiguous() and sc.numel() == t.shape[0]
-        table[i] = (t.data_ptr(), base + offs[i] * esz, sc.data_ptr(), numels[i], numels[i] // t.shape[0], blk)
-        blk += (numels[i] + 2047) // 2048
+    table[:, 0] = [t.data_ptr() for t in srcs]
+    table[:, 1] = offs_b + out.data_ptr()
     items = upload(table.reshape(-1), dev)
     dt = {torch.float32: _lib.MPF_F32, torch.bfloat16: _lib.MPF_BF16}
     with _lib.device_guard(dev):
         code = _lib.lib().mpf_grouped_scale_cast(items.data_ptr(), len(srcs), blk, dt[srcs[0].dtype], dt[out_dtype],
                                                  _lib.stream_ptr(dev))
     _lib.check(code, "mpf_grouped_scale_cast")
-    return [out[o:o + n].as_strided(t.shape, t.stride()) for o, n, t in zip(offs, numels, srcs)]
+    return [out[o:o + n].as_strided(shp, std) for o, n, shp, std in views]
 
 
 class _FoldCast(torch.autograd.Function):
@@ -266,9 +283,14 @@ class Bottleneck(nn.Module):
         self.norm3 = FrozenBatchNorm2d(cout)
 
     def pairs(self):
-        p = [(self.conv1, self.norm1), (self.conv2, self.norm2), (self.conv3, self.norm3)]
-        if self.shortcut is not None:
-            p.append((self.shortcut, self.shortcut_norm))
+        """[(conv, norm)]: conv1, conv2, conv3 (, shortcut) — built once per instance (submodules are not replaced after
+        construction; ``self.conv1`` on a Module is a ``__getattr__`` round trip, ~430 of them per step came from here)"""
+        p = self.__dict__.get("_pairs")
+        if p is None:
+            p = [(self.conv1, self.norm1), (self.conv2, self.norm2), (self.conv3, self.norm3)]
+            if self.shortcut is not None:
+                p.append((self.shortcut, self.shortcut_norm))
+            self.__dict__["_pairs"] = p
         return p
 
     def forward(self, x, fw=None):
@@ -280,10 +302,11 @@ class Bottleneck(nn.Module):
         arguments (summed there) instead of through an add kernel.  Returns the output as two aliases."""
         f = fw if fw is not None else [None] * 4
         x_main, x_skip = xs
-        out = conv_bn(self.conv1, self.norm1, x_main, f[0])
-        out = conv_bn(self.conv2, self.norm2, out, f[1])
-        sc = x_skip if self.shortcut is None else conv_bn(self.shortcut, self.shortcut_norm, x_skip, f[3], relu=False)
-        return conv_bn(self.conv3, self.norm3, out, f[2], res=sc, fork=True)
+        p = self.pairs()
+        out = conv_bn(p[0][0], p[0][1], x_main, f[0])
+        out = conv_bn(p[1][0], p[1][1], out, f[1])
+        sc = x_skip if len(p) == 3 else conv_bn(p[3][0], p[3][1], x_skip, f[3], relu=False)
+        return conv_bn(p[2][0], p[2][1], out, f[2], res=sc, fork=True)
 
 
 class ResNet50(nn.Module):

@@ -32,12 +32,28 @@ _GATE_BITS = os.environ.get("MPF_ENC_GATE_BITS", "1") != "0"      # (A/B switch:
 _EPS = 1e-5
 
 
+_PARAM_SLOTS = (("self_attn", "sampling_offsets"), ("self_attn", "attention_weights"), ("self_attn", "value_proj"),
+                ("self_attn", "output_proj"), ("norm1",), ("linear1",), ("linear2",), ("norm2",))
+
+
 def layer_params(layer):
-    a = layer.self_attn
-    return [a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,
-            a.value_proj.weight, a.value_proj.bias, a.output_proj.weight, a.output_proj.bias,
-            layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,
-            layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias]
+    """The 16 parameters of an encoder layer in EncoderFn's order.  The owning ``_parameters`` dicts are looked up once per
+    layer object (submodules are not replaced after construction); per call only 16 dict reads — a parameter that was
+    re-assigned is picked up, and no ``Module.__getattr__`` chain runs (it was ~200 of them per step)."""
+    owners = layer.__dict__.get("_mpf_param_owners")
+    if owners is None:
+        owners = []
+        for path in _PARAM_SLOTS:
+            m = layer
+            for name in path:
+                m = getattr(m, name)
+            owners.append(m._parameters)
+        layer.__dict__["_mpf_param_owners"] = owners
+    out = []
+    for d in owners:
+        out.append(d["weight"])
+        out.append(d["bias"])
+    return out
 
 
 def rows_per_split(sizes):

@@ -53,3 +53,11 @@ tot = sum(v[2] for v in st.stats.values())
 print(f"python-visible time per step: {tot / N * 1e3:.2f} ms (profiler overhead included)")
 for (fn, line, name), (cc, nc, tt, ct, _) in rows[:TOP]:
     print(f"{tt / N * 1e3:7.3f} ms own {ct / N * 1e3:7.3f} ms cum  x{nc / N:7.1f}  {os.path.basename(fn)}:{line} {name}")
+if os.environ.get("MPF_CALLERS"):
+    import io
+    for pat in os.environ["MPF_CALLERS"].split(","):
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("tottime").print_callers(pat)
+        lines = [ln for ln in buf.getvalue().splitlines() if ln.strip()]
+        print(f"---- callers of {pat} (counts over {N} steps)")
+        print("\n".join(lines[:40]))
