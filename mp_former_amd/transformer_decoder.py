@@ -48,34 +48,53 @@ class _CastParams(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, chunks, *params):
-        srcs, dsts, outs = [], [], []
-        for p, c in zip(params, chunks):
-            d = p.detach()
-            full = torch.empty_like(d, dtype=dtype if dtype is not None else d.dtype)
-            srcs.append(d)
+        # ONE buffer for all copies (256-byte slots; layout cached per list of shapes) and one view per parameter: ~230
+        # allocations per direction were 0.5 ms of launch-thread time each way, at the two places of the step where the GPU
+        # has caught up with the host (end of the pixel decoder forward / end of the decoder backward)
+        dev = params[0].device
+        dt = dtype if dtype is not None else params[0].dtype
+        offs, tot, strides = _flat_layout(tuple(p.shape for p in params))
+        if dtype is None and any(p.dtype != dt for p in params):
+            raise RuntimeError("_CastParams without a target dtype needs parameters of one dtype")
+        flat = torch.empty(tot, dtype=dt, device=dev)
+        dsts, outs = [], []
+        for p, c, o, st in zip(params, chunks, offs, strides):
+            full = flat.as_strided(p.shape, st, o)
             dsts.append(full)
             # row blocks of ONE buffer: the blocks of a packed in-projection stay side by side in memory (the native
             # decoder layer then runs q | k | v as one GEMM)
             outs += [full] if c == 1 else list(full.chunk(c, 0))
-        torch._foreach_copy_(dsts, srcs)
+        torch._foreach_copy_(dsts, list(params))
         ctx.chunks = chunks
-        ctx.shapes = [p.shape for p in params]
+        ctx.shapes = tuple(p.shape for p in params)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         res, dsts, srcs = [], [], []
+        dev = next((g for g in grads if g is not None), None)
+        if dev is None:
+            return (None, None) + (None,) * len(ctx.shapes)
+        offs, tot, strides = _flat_layout(ctx.shapes)
+        flat = torch.empty(tot, dtype=torch.float32, device=dev.device)
         k = 0
-        for shape, c in zip(ctx.shapes, ctx.chunks):
+        for shape, c, o, st in zip(ctx.shapes, ctx.chunks, offs, strides):
             gs = grads[k:k + c]
             k += c
+            if c == 1:
+                if gs[0] is None:
+                    res.append(None)
+                    continue
+                full = flat.as_strided(shape, st, o)
+                dsts.append(full)
+                srcs.append(gs[0])
+                res.append(full)
+                continue
             if all(g is None for g in gs):
                 res.append(None)
                 continue
-            dev = next(g for g in gs if g is not None).device
-            full = torch.empty(shape, dtype=torch.float32, device=dev)
-            parts = [full] if c == 1 else list(full.chunk(c, 0))
-            for part, g in zip(parts, gs):
+            full = flat.as_strided(shape, st, o)
+            for part, g in zip(full.chunk(c, 0), gs):
                 if g is None:
                     part.zero_()
                 else:
@@ -85,6 +104,28 @@ class _CastParams(torch.autograd.Function):
         if dsts:
             torch._foreach_copy_(dsts, srcs)
         return (None, None, *res)
+
+
+_flat_layouts = {}
+
+
+def _flat_layout(shapes):
+    """(element offsets in 64-element slots, total, contiguous strides) of tensors of the given shapes inside one flat buffer"""
+    hit = _flat_layouts.get(shapes)
+    if hit is None:
+        offs, strides, tot = [], [], 0
+        for s_ in shapes:
+            offs.append(tot)
+            tot += (s_.numel() + 63) & ~63
+            st, acc = [], 1
+            for d in reversed(s_):
+                st.append(acc)
+                acc *= d
+            strides.append(tuple(reversed(st)))
+        if len(_flat_layouts) > 16:
+            _flat_layouts.clear()
+        hit = _flat_layouts[shapes] = (tuple(offs), tot, tuple(strides))
+    return hit
 
 
 class _GatherRows(torch.autograd.Function):
