@@ -31,6 +31,8 @@ def main():
     from mp_former_amd import _lib, _miopen
     _lib.lib()
     _miopen.use_shipped_find_db(check_version=True)
+    from mp_former_amd import dropin
+    dropin.configure_training_process()             # as bench.py: backward on the launch thread
     torch.manual_seed(0)
     model = bench.TrainModel().to(dev).train()
     model.backbone.to(memory_format=torch.channels_last)
