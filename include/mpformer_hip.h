@@ -546,6 +546,36 @@ typedef struct MpfDecoderLayerGrad {
 uint64_t mpf_decoder_layer_struct_bytes(int which); /* 0: sizeof(MpfDecoderLayer), 1: sizeof(MpfDecoderLayerGrad) */
 uint64_t mpf_decoder_layer_scratch_bytes(int Qt, int N, int H, int S, int ffn_dim, int backward);
 int mpf_decoder_layer_forward(const MpfDecoderLayer* layer, void* stream);
+/*
+ * The attention mask the NEXT decoder layer needs, from this layer's residual stream — the detached part of
+ * forward_prediction_heads (mask2former_transformer_decoder.py:1859-1875): decoder_norm -> mask_embed MLP -> (product with
+ * mask_features resized to the level grid).sigmoid() < 0.5, MP rows (:1814-1816) and the all-masked-row rule (:1780) — as ONE call
+ * (mpf_res_ln256_forward, 3 x mpf_small_gemm_bf16, mpf_mask_head_bits issued back to back).  x: fp32 [Q, N, 256] (sequence-first);
+ * weights bf16 [256, 256] row-major, biases bf16 [256]; pooled: bf16 [N, HW, 256] (mpf_pool_features); mp_rows: [N, pad, HW] bytes
+ * or NULL (pad = 0); out: bool bytes [N, Q, HW]; flags: int32 [N * Q], zero on entry (zeroed again by the kernel); scratch of
+ * mpf_next_attn_mask_scratch_bytes(N, Q) bytes, 256-byte aligned.
+ */
+typedef struct MpfNextMask {
+    const float* x;
+    const float* ln_gamma;
+    const float* ln_beta;
+    const void* w0;
+    const void* b0;
+    const void* w1;
+    const void* b1;
+    const void* w2;
+    const void* b2;
+    const void* pooled;
+    const uint8_t* mp_rows;
+    uint8_t* out;
+    int32_t* flags;
+    void* scratch;
+    size_t scratch_bytes;
+    int N, Q, HW, pad;
+    float eps;
+} MpfNextMask;
+size_t mpf_next_attn_mask_scratch_bytes(int N, int Q);
+int mpf_next_attn_mask(const MpfNextMask* m, void* stream);
 int mpf_decoder_layer_backward(const MpfDecoderLayer* layer, const MpfDecoderLayerGrad* grad, void* stream);
 
 /*

@@ -92,6 +92,8 @@ SIGNATURES = {
     "mpf_decoder_layer_struct_bytes": (ctypes.c_uint64, [_c_int]),
     "mpf_decoder_layer_scratch_bytes": (ctypes.c_uint64, [_c_int] * 6),
     "mpf_decoder_layer_forward": (_c_int, [_c_vp, _c_vp]),
+    "mpf_next_attn_mask_scratch_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
+    "mpf_next_attn_mask": (_c_int, [_c_vp, _c_vp]),
     "mpf_decoder_layer_backward": (_c_int, [_c_vp, _c_vp, _c_vp]),
     "mpf_pool_features": (_c_int, [_c_vp, _c_int, _c_vp] + [_c_int] * 6 + [_c_vp]),
     "mpf_pool_features_cl": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),

@@ -358,3 +358,38 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
     }
     return 0;
 }
+
+// The attention mask of the NEXT layer from this layer's residual stream (mask2former_transformer_decoder.py:1869-1875 with the
+// prediction-head part of :1859-1866, detached as the reference detaches it): decoder_norm -> mask_embed MLP (ReLU after the first
+// two layers) -> sign of the product with the features pooled to the level grid, MP rows and the all-masked-row rule applied by
+// the mask-head kernel.  Five launches issued from one call: the python glue around them (five autograd-free ops, ten times per
+// step) was 0.5 ms of launch-thread time at the one place of the step where the device waits for every launch.
+extern "C" size_t mpf_next_attn_mask_scratch_bytes(int N, int Q)
+{
+    if (N <= 0 || Q <= 0) return 0;
+    const size_t rows = (size_t)N * Q;
+    return 3 * ((rows * kE * 2 + 255) & ~(size_t)255) + 2 * ((rows * 4 + 255) & ~(size_t)255);
+}
+
+extern "C" int mpf_next_attn_mask(const MpfNextMask* m, void* st)
+{
+    if (!m || !m->x || !m->ln_gamma || !m->ln_beta || !m->w0 || !m->w1 || !m->w2 || !m->pooled || !m->out || !m->flags || !m->scratch)
+        return mpf::fail(MPF_E_NULL, "next_attn_mask: NULL buffer");
+    if (m->N <= 0 || m->Q <= 0 || m->HW <= 0 || m->pad < 0) return mpf::fail(MPF_E_SHAPE, "next_attn_mask: bad sizes");
+    if (m->scratch_bytes < mpf_next_attn_mask_scratch_bytes(m->N, m->Q)) return mpf::fail(MPF_E_SHAPE, "next_attn_mask: scratch too small");
+    const int rows = m->N * m->Q;
+    const size_t act = ((size_t)rows * kE * 2 + 255) & ~(size_t)255, vec = ((size_t)rows * 4 + 255) & ~(size_t)255;
+    char* sc = static_cast<char*>(m->scratch);
+    void* d16 = sc;                 // decoder_norm(x) in bf16; reused for the third layer's result
+    void* e1 = sc + act;
+    void* e2 = sc + 2 * act;
+    float* mean = reinterpret_cast<float*>(sc + 3 * act);
+    float* rstd = reinterpret_cast<float*>(sc + 3 * act + vec);
+    MPF_TRY(mpf_res_ln256_forward(m->x, nullptr, 0, m->ln_gamma, m->ln_beta, nullptr, nullptr, d16, mean, rstd, rows, m->eps, nullptr, 0,
+                                  nullptr, st));
+    MPF_TRY(mpf_small_gemm_bf16(d16, kE, 1, nullptr, m->w0, kE, 1, m->b0, nullptr, 0, e1, kE, nullptr, rows, kE, kE, 1, st));
+    MPF_TRY(mpf_small_gemm_bf16(e1, kE, 1, nullptr, m->w1, kE, 1, m->b1, nullptr, 0, e2, kE, nullptr, rows, kE, kE, 1, st));
+    MPF_TRY(mpf_small_gemm_bf16(e2, kE, 1, nullptr, m->w2, kE, 1, m->b2, nullptr, 0, d16, kE, nullptr, rows, kE, kE, 0, st));
+    // mask_embed is sequence-first [Q, N, 256]: image stride 256, query stride N * 256
+    return mpf_mask_head_bits(d16, kE, (int64_t)m->N * kE, m->pooled, m->mp_rows, m->pad, m->out, m->flags, m->N, m->Q, m->HW, st);
+}

@@ -18,6 +18,7 @@ Differences that do not change results:
 Only dn_mode "points" with NOISE_SCALE 0 (the shipped run script) is implemented; other modes raise.
 """
 import math
+import ctypes
 import os
 from typing import Optional
 
@@ -33,6 +34,9 @@ from .resln import res_ln
 from .small_linear import small_linear, tall_linear, tall_usable as _tall_ok, usable as _small_ok
 from .decoder_layer import decoder_layer, split_cols
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
+
+
+_NEXT_MASK_NATIVE = os.environ.get("MPF_NEXT_MASK_NATIVE", "1") != "0"     # (A/B switch: 0 = five python-level ops)
 
 
 class _CastParams(torch.autograd.Function):
@@ -272,6 +276,50 @@ def mask_product(me, mask_features):
 
 
 _mask_flags = {}
+
+
+class MpfNextMask(ctypes.Structure):
+    """include/mpformer_hip.h MpfNextMask"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "ln_gamma", "ln_beta", "w0", "b0", "w1", "b1", "w2", "b2", "pooled", "mp_rows",
+                                                "out", "flags", "scratch")] + \
+               [("scratch_bytes", ctypes.c_size_t), ("N", ctypes.c_int), ("Q", ctypes.c_int), ("HW", ctypes.c_int),
+                ("pad", ctypes.c_int), ("eps", ctypes.c_float)]
+
+
+_next_mask_scratch = {}
+
+
+def next_attn_mask_native(x, norm, mlp, pooled, mp_rows=None):
+    """bool [N, Q, HW] attention mask of the next layer from the residual stream x fp32 [Q, N, 256]: decoder_norm, the
+    three mask_embed layers (``mlp`` = [(w, b)] x 3, bf16) and the fused mask head as ONE native call
+    (``mpf_next_attn_mask``; same five launches as res_ln + 3 x linear + mask_head_bits, bit-identical)."""
+    Q, N, C = x.shape
+    HW = pooled.shape[1]
+    dev = x.device
+    pad = 0 if mp_rows is None else mp_rows.shape[1]
+    if pad:
+        mp_rows = mp_rows.contiguous()
+    flags = _mask_flags.get((dev, N * Q))
+    if flags is None:
+        flags = torch.zeros(N * Q, dtype=torch.int32, device=dev)          # zero on entry, zeroed again by the kernel
+        _mask_flags[(dev, N * Q)] = flags
+    lib = _lib.lib()
+    key = (dev, N, Q)
+    sc = _next_mask_scratch.get(key)
+    if sc is None:
+        sc = _next_mask_scratch[key] = torch.empty(lib.mpf_next_attn_mask_scratch_bytes(N, Q), dtype=torch.uint8, device=dev)
+    out = torch.empty((N, Q, HW), dtype=torch.bool, device=dev)
+    m = MpfNextMask()
+    m.x, m.ln_gamma, m.ln_beta, m.eps = x.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps)
+    (w0, b0), (w1, b1), (w2, b2) = mlp
+    m.w0, m.b0, m.w1, m.b1, m.w2, m.b2 = w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    m.pooled, m.mp_rows, m.out, m.flags = pooled.data_ptr(), (mp_rows.data_ptr() if pad else None), out.data_ptr(), flags.data_ptr()
+    m.scratch, m.scratch_bytes = sc.data_ptr(), sc.numel()
+    m.N, m.Q, m.HW, m.pad = N, Q, HW, pad
+    with _lib.device_guard(dev):
+        code = lib.mpf_next_attn_mask(ctypes.byref(m), _lib.stream_ptr(dev))
+    _lib.check(code, "mpf_next_attn_mask")
+    return out
 
 
 def mask_head_bits(mask_embed, pooled, mp_rows=None):
@@ -658,6 +706,14 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         layers are produced together by ``_heads_batched`` after the last layer."""
         with torch.no_grad():
             amp = W["class_embed.weight"].dtype == torch.bfloat16
+            if (pooled is not None and amp and output.dtype == torch.float32 and output.is_contiguous() and output.shape[-1] == 256
+                    and output.shape[0] * output.shape[1] <= 1024 and _NEXT_MASK_NATIVE):
+                n_ = self.decoder_norm
+                mlp = [(W[f"mask_embed.layers.{k}.weight"], W[f"mask_embed.layers.{k}.bias"]) for k in range(3)]
+                if (n_.elementwise_affine and n_.bias is not None
+                        and all(w_.dtype == torch.bfloat16 and w_.shape == (256, 256) and w_.is_contiguous() and b_.is_contiguous()
+                                for w_, b_ in mlp)):
+                    return next_attn_mask_native(output, n_, mlp, pooled, mp_rows)
             d32, d16 = res_ln(self.decoder_norm, output.detach(), None, want32=not amp, want16=amp)
             x = d16 if amp else d32
             e = linear(x, W["mask_embed.layers.0.weight"].detach(), W["mask_embed.layers.0.bias"].detach(), relu=True)

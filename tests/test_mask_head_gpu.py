@@ -118,3 +118,36 @@ def test_mask_product_channel_last_matches_einsum(dtype):
     assert dtype != torch.bfloat16 or TD._is_planes(g_mf)
     torch.testing.assert_close(g_me.double(), r_me.double(), rtol=tol, atol=tol * float(r_me.abs().max()))
     torch.testing.assert_close(g_mf.double(), r_mf.double(), rtol=tol, atol=tol * float(r_mf.abs().max()))
+
+
+@pytest.mark.parametrize("N,Q,HW,pad", [(2, 120, 1024, 20), (1, 100, 4096, 0), (2, 300, 256, 37), (3, 17, 16384, 5)])
+def test_next_attn_mask_as_one_native_call_equals_the_five_ops(N, Q, HW, pad):
+    """``mpf_next_attn_mask`` (decoder_norm -> mask_embed MLP -> fused mask head, mask2former_transformer_decoder.py:1859-1875
+    detached) issues the same five launches as res_ln + 3 x linear + mask_head_bits: the boolean masks must be identical, incl.
+    the MP rows and the all-masked-row rule, and a second call must see clean flags."""
+    from mp_former_amd.resln import res_ln
+    from mp_former_amd.transformer_decoder import linear, mask_head_bits, next_attn_mask_native
+    dev = torch.device("cuda:0")
+    torch.manual_seed(N * 1000 + Q)
+    x = torch.randn(Q, N, 256, device=dev) * 2
+    norm = torch.nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        norm.weight.add_(torch.randn(256, device=dev) * 0.2)
+        norm.bias.add_(torch.randn(256, device=dev) * 0.2)
+    mlp = [((torch.randn(256, 256, device=dev) / 16).to(torch.bfloat16), (torch.randn(256, device=dev) * 0.1).to(torch.bfloat16))
+           for _ in range(3)]
+    pooled = torch.randn(N, HW, 256, device=dev).to(torch.bfloat16)
+    mp_rows = (torch.rand(N, pad, HW, device=dev) < 0.5) if pad else None
+    if pad:
+        mp_rows[:, 0] = True                 # an MP row that masks everything: the all-masked-row rule clears it
+    with torch.no_grad():
+        _, d16 = res_ln(norm, x, None, want32=False, want16=True)
+        e = linear(d16, mlp[0][0], mlp[0][1], relu=True)
+        e = linear(e, mlp[1][0], mlp[1][1], relu=True)
+        me = linear(e, mlp[2][0], mlp[2][1])
+        want = mask_head_bits(me, pooled, mp_rows)
+        for _ in range(2):
+            got = next_attn_mask_native(x, norm, mlp, pooled, mp_rows)
+            assert got.dtype == torch.bool and got.shape == (N, Q, HW)
+            assert torch.equal(got, want)
+    assert 0.05 < float(want.float().mean()) < 0.95
