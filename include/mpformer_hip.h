@@ -541,6 +541,10 @@ typedef struct MpfDecoderLayerGrad {
     void *d_ff_w1, *d_ff_b1, *d_ff_w2, *d_ff_b2;
     float* d_ln;
     int64_t dkv_row_stride, dkv_img_stride;   /* strides of d_k_c / d_v_c as above (0, 0 = dense) */
+    /* a second upstream gradient of x3 (may be NULL; needs g_x3): x3 has two consumers — the next layer and the prediction
+       heads (mask2former_transformer_decoder.py:1797-1800) — and their gradients are summed by the layer's first LayerNorm
+       backward pass instead of by a separate add */
+    const float* g_x3_plus;
 } MpfDecoderLayerGrad;
 
 uint64_t mpf_decoder_layer_struct_bytes(int which); /* 0: sizeof(MpfDecoderLayer), 1: sizeof(MpfDecoderLayerGrad) */

@@ -247,7 +247,8 @@ extern "C" int mpf_decoder_layer_backward(const MpfDecoderLayer* L, const MpfDec
     MpfSmallGemmItem dw[kMaxDw];
     int ndw = 0;
     // FFN block: x3 = LN(x2 + W2 relu(W1 xb2))
-    MPF_TRY(mpf_res_ln256_backward_partial(L->s3, L->mean3, L->rstd3, L->ff_gamma, G->g_x3, G->g_xb3, nullptr, b.ds_a, b.dt3, R,
+    if (G->g_x3_plus && !G->g_x3) return mpf::fail(MPF_E_NULL, "decoder_layer_backward: g_x3_plus without g_x3");
+    MPF_TRY(mpf_res_ln256_backward_partial(L->s3, L->mean3, L->rstd3, L->ff_gamma, G->g_x3, G->g_xb3, G->g_x3_plus, b.ds_a, b.dt3, R,
                                            ln_part + 2 * b.ln_ws_bytes, b.ln_ws_bytes, st));
     MPF_TRY(lin_dx(b.dt3, nullptr, L->ff_w2, nullptr, b.dh, R, kE, F, st));
     dw[ndw++] = dw_item(b.dt3, nullptr, L->h, G->d_ff_w2, G->d_ff_b2, R, kE, F);

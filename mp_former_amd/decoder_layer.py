@@ -38,7 +38,7 @@ _WGRADS = tuple("d_" + n for n in PARAM_NAMES if n not in _LN)
 
 class MpfDecoderLayerGrad(ctypes.Structure):
     _fields_ = ([(n, _vp) for n in ("g_x3", "g_xb3", "d_x0", "d_xb0", "d_k_c", "d_v_c")] + [(n, _vp) for n in _WGRADS]
-                + [("d_ln", _vp), ("dkv_row_stride", ctypes.c_int64), ("dkv_img_stride", ctypes.c_int64)])
+                + [("d_ln", _vp), ("dkv_row_stride", ctypes.c_int64), ("dkv_img_stride", ctypes.c_int64), ("g_x3_plus", _vp)])
 
 
 _checked = False
@@ -238,10 +238,18 @@ class DecoderLayerFn(Function):
         ctx.layer = L
         ctx.kv_pack = kv_pack
         ctx.dims = (Qt, N, E, S, F_, nheads)
-        return x3, xb3
+        # x3 leaves twice (two aliases of one tensor): the next layer and the prediction heads both consume it, and their
+        # gradients then arrive as two arguments — summed by the first LayerNorm backward pass of the native call (its third
+        # gradient operand) instead of by an add kernel and an accumulation step of the autograd engine per layer
+        ctx.set_materialize_grads(False)
+        return x3, xb3, x3.view(x3.shape)
 
     @staticmethod
-    def backward(ctx, g_x3, g_xb3):
+    def backward(ctx, g_x3, g_xb3, g_x3h=None):
+        if g_x3 is None:
+            g_x3, g_x3h = g_x3h, None
+        if g_x3 is None and g_xb3 is None:
+            return (None,) * (9 + len(PARAM_NAMES))
         lib = _lib_checked()
         saved = ctx.saved_tensors
         xb0, k_c = saved[0], saved[1]
@@ -253,6 +261,8 @@ class DecoderLayerFn(Function):
             g_x3 = g_x3.to(torch.float32).contiguous()
         if g_xb3 is not None:
             g_xb3 = g_xb3.to(torch.bfloat16).contiguous()
+        if g_x3h is not None:
+            g_x3h = g_x3h.to(torch.float32).contiguous()
         d_x0 = torch.empty((Qt, N, E), dtype=torch.float32, device=dev)
         d_xb0 = torch.empty((Qt, N, E), dtype=torch.bfloat16, device=dev)
         G = MpfDecoderLayerGrad()
@@ -270,6 +280,7 @@ class DecoderLayerFn(Function):
         d_ln = torch.empty((6, 256), dtype=torch.float32, device=dev)
         G.g_x3 = g_x3.data_ptr() if g_x3 is not None else None
         G.g_xb3 = g_xb3.data_ptr() if g_xb3 is not None else None
+        G.g_x3_plus = g_x3h.data_ptr() if g_x3h is not None else None
         G.d_x0, G.d_xb0, G.d_k_c, G.d_v_c = d_x0.data_ptr(), d_xb0.data_ptr(), d_k.data_ptr(), d_v.data_ptr()
         wbase = wg.data_ptr()
         for n, o in zip(_WGRADS, offs):
@@ -297,7 +308,8 @@ class DecoderLayerFn(Function):
 
 
 def decoder_layer(x0, xb0, k_c, v_c, mask_c, mask_s, nheads, eps, params, kv_pack=None):
-    """(x3 fp32, xb3 bf16) = one decoder layer; ``params``: the 22 tensors of PARAM_NAMES.  ``kv_pack`` = the
+    """(x3 fp32, xb3 bf16, x3 again) = one decoder layer; ``params``: the 22 tensors of PARAM_NAMES.  The third result is an
+    alias of the first for a second consumer (see DecoderLayerFn.forward).  ``kv_pack`` = the
     ``split_cols`` handles of k_c and v_c when they are column blocks of a level's packed projection."""
     if not x0.is_cuda:
         raise RuntimeError("mp_former_amd decoder layer runs on the GPU only (no CPU fallback)")

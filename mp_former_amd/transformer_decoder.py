@@ -36,6 +36,7 @@ from .decoder_layer import decoder_layer, split_cols
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
 
 
+_DEC_ALIAS = os.environ.get("MPF_DEC_ALIAS", "1") != "0"
 _NEXT_MASK_NATIVE = os.environ.get("MPF_NEXT_MASK_NATIVE", "1") != "0"     # (A/B switch: 0 = five python-level ops)
 
 
@@ -869,7 +870,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
                     k_c, v_c, kv_pack = linear(kin[level], cw[1], cb[1]), linear(src[level], cw[2], cb[2]), None
                 n1, n2, n3 = (self.transformer_cross_attention_layers[i].norm, self.transformer_self_attention_layers[i].norm,
                               self.transformer_ffn_layers[i].norm)
-                output, xb = decoder_layer(
+                output, xb, out_heads = decoder_layer(
                     output, xb, k_c, v_c, attn_mask, tgt_mask, H, n1.eps,
                     (cw[0], cb[0], W[ca + "out_proj.weight"], W[ca + "out_proj.bias"], n1.weight, n1.bias,
                      sw[0], sb[0], sw[1], sb[1], sw[2], sb[2], W[sa + "out_proj.weight"], W[sa + "out_proj.bias"], n2.weight, n2.bias,
@@ -877,8 +878,10 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
                      n3.weight, n3.bias), kv_pack)
             else:
                 output, xb = self._layer_by_ops(W, i, level, output, xb, kin, src, attn_mask, tgt_mask, post_norm)
+                out_heads = output
             nxt = (i + 1) % self.num_feature_levels
-            streams.append(output)
+            # (the fused layer's second alias of its output, decoder_layer.DecoderLayerFn; MPF_DEC_ALIAS=0: the output itself)
+            streams.append(out_heads if _DEC_ALIAS else output)
             if i + 1 < self.num_layers:
                 attn_mask = self._next_attn_mask(W, output, mask_features, size_list[nxt], rows(nxt, i), pooled[nxt])
             elif mp is not None and callable(mp["rows"]) and _rng.replaying() and (self.all_lys or i < 3):
