@@ -268,6 +268,9 @@ class _FoldCast(torch.autograd.Function):
         return (None, None, *g32)
 
 
+_PAIR_NAMES = (("conv1", "norm1"), ("conv2", "norm2"), ("conv3", "norm3"), ("shortcut", "shortcut_norm"))
+
+
 class Bottleneck(nn.Module):
     def __init__(self, cin, cmid, cout, stride):
         super().__init__()
@@ -285,7 +288,12 @@ class Bottleneck(nn.Module):
     def pairs(self):
         """[(conv, norm)]: conv1, conv2, conv3 (, shortcut) — built once per instance (submodules are not replaced after
         construction; ``self.conv1`` on a Module is a ``__getattr__`` round trip, ~430 of them per step came from here)"""
+        m = self._modules
         p = self.__dict__.get("_pairs")
+        if p is not None:          # still the children this module holds (a swapped submodule rebuilds the list)
+            names = _PAIR_NAMES if len(p) == 4 else _PAIR_NAMES[:3]
+            if (m.get("shortcut") is None) != (len(p) == 3) or any(c is not m.get(cn) or n is not m.get(nn_) for (c, n), (cn, nn_) in zip(p, names)):
+                p = None
         if p is None:
             p = [(self.conv1, self.norm1), (self.conv2, self.norm2), (self.conv3, self.norm3)]
             if self.shortcut is not None:

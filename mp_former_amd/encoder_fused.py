@@ -37,20 +37,32 @@ _PARAM_SLOTS = (("self_attn", "sampling_offsets"), ("self_attn", "attention_weig
 
 
 def layer_params(layer):
-    """The 16 parameters of an encoder layer in EncoderFn's order.  The owning ``_parameters`` dicts are looked up once per
-    layer object (submodules are not replaced after construction); per call only 16 dict reads — a parameter that was
-    re-assigned is picked up, and no ``Module.__getattr__`` chain runs (it was ~200 of them per step)."""
+    """The 16 parameters of an encoder layer in EncoderFn's order.  The owning modules are looked up once per layer object and
+    re-validated per call against the module tree (identity of every child along the path: a swapped submodule rebuilds the
+    list); then 16 dict reads — a re-assigned parameter is picked up, and no ``Module.__getattr__`` chain runs (it was ~200 of
+    them per step)."""
     owners = layer.__dict__.get("_mpf_param_owners")
+    if owners is not None:
+        for path, m in owners:
+            cur = layer
+            for name in path:
+                cur = cur._modules.get(name)
+                if cur is None:
+                    break
+            if cur is not m:
+                owners = None
+                break
     if owners is None:
         owners = []
         for path in _PARAM_SLOTS:
             m = layer
             for name in path:
                 m = getattr(m, name)
-            owners.append(m._parameters)
+            owners.append((path, m))
         layer.__dict__["_mpf_param_owners"] = owners
     out = []
-    for d in owners:
+    for _, m in owners:
+        d = m._parameters
         out.append(d["weight"])
         out.append(d["bias"])
     return out

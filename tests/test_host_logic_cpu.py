@@ -160,3 +160,39 @@ def test_configure_training_process_moves_backward_to_the_calling_thread():
     finally:
         torch.autograd.set_multithreading_enabled(prev)
     assert dropin.configure_training_process(single_thread_autograd=False) == prev
+
+
+def test_cached_module_lookups_follow_the_module_tree():
+    """The per-step lookups that bypass Module.__getattr__ (backbone.Bottleneck.pairs, encoder_fused.layer_params,
+    FrozenBatchNorm2d.scale_bias) are caches over the module tree: a swapped submodule, a re-assigned parameter, an in-place
+    change or a replacement of a frozen statistic must all be picked up."""
+    from torch import nn
+    from mp_former_amd import encoder_fused as EF, pixel_decoder as PD
+    from mp_former_amd.backbone import Bottleneck, FrozenBatchNorm2d
+    b = Bottleneck(64, 64, 256, 1)
+    p1 = b.pairs()
+    assert b.pairs() is p1 and len(p1) == 4 and p1[3][0] is b.shortcut
+    b.conv1 = nn.Conv2d(64, 64, 1, bias=False)
+    assert b.pairs() is not p1 and b.pairs()[0][0] is b.conv1
+    assert len(Bottleneck(256, 64, 256, 1).pairs()) == 3
+    enc = PD.MSDeformAttnTransformerEncoderOnly(d_model=256, nhead=8, num_encoder_layers=1, dim_feedforward=1024, dropout=0.0,
+                                                num_feature_levels=3)
+    layer = enc.encoder.layers[0]
+    q1 = EF.layer_params(layer)
+    a = layer.self_attn
+    want = [a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,
+            a.value_proj.weight, a.value_proj.bias, a.output_proj.weight, a.output_proj.bias, layer.norm1.weight, layer.norm1.bias,
+            layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias]
+    assert len(q1) == 16 and all(x is y for x, y in zip(q1, want))
+    layer.linear1 = nn.Linear(256, 1024)
+    assert EF.layer_params(layer)[10] is layer.linear1.weight
+    layer.norm1.weight = nn.Parameter(torch.ones(256))
+    assert EF.layer_params(layer)[8] is layer.norm1.weight
+    bn = FrozenBatchNorm2d(8)
+    bn.running_var.fill_(4.0)
+    s1, _ = bn.scale_bias()
+    assert bn.scale_bias()[0] is s1 and torch.allclose(s1, torch.full((8,), 0.5))
+    bn.weight.mul_(2.0)                                        # in place: the version counter moves
+    assert torch.allclose(bn.scale_bias()[0], torch.ones(8))
+    bn = bn.double()                                           # .to(): the buffers are replaced
+    assert bn.scale_bias()[0].dtype == torch.float64
