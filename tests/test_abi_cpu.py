@@ -50,6 +50,20 @@ def test_abi_version_and_argument_errors(built):
     assert lib.mpf_msda_forward(None, one, one, one, one, one, 1, 1, 1, 1, 1, 1, 1, 0, None) == -3
     assert lib.mpf_msda_backward(one, one, one, one, one, one, one, one, None, 1, 1, 1, 1, 1, 1, 1, 0, None) == -3
     assert lib.mpf_set_option(b"no_such_key", 1) == -2
+    # round-4 entry points: the bit-mask gate needs N % 128 == 0 and 8-byte aligned mask rows; the next-mask call its buffers
+    args = [one, 256, one, one, one, None, None, 0, None, 0, one, 16, one, 128, None, None, 16]
+    assert lib.mpf_gemm3_tn_h2_bits(*args, 128, 96, 256, 0, None) == -2
+    assert lib.mpf_gemm3_tn_h2_bits(*(args[:11] + [12] + args[12:]), 128, 128, 256, 0, None) == -2           # ldgbits % 8
+    assert lib.mpf_gemm3_tn_h2_bits(*(args[:2] + [None] + args[3:]), 128, 128, 256, 0, None) == -3             # no amax slot
+    from mp_former_amd.transformer_decoder import MpfNextMask
+    m = MpfNextMask()
+    assert lib.mpf_next_attn_mask(ctypes.byref(m), None) == -3
+    for f in ("x", "ln_gamma", "ln_beta", "w0", "w1", "w2", "pooled", "out", "flags", "scratch"):
+        setattr(m, f, 16)
+    m.N, m.Q, m.HW, m.pad, m.scratch_bytes = 2, 100, 1024, 0, 16
+    assert lib.mpf_next_attn_mask(ctypes.byref(m), None) == -2 and b"scratch" in lib.mpf_last_error()
+    assert lib.mpf_next_attn_mask_scratch_bytes(2, 100) >= 3 * 200 * 256 * 2 + 2 * 200 * 4
+    assert lib.mpf_next_attn_mask_scratch_bytes(0, 100) == 0
 
 
 def test_python_mirror_rejects_cpu_tensors(built):
