@@ -31,6 +31,9 @@ import time
 # ROCr reads its flags when HIP initialises (the first torch.cuda call): the dmabuf-only IPC mode RCCL needs on this
 # driver has to be in the environment BEFORE that, i.e. before anything below touches the GPU
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# kernel arguments in device memory (this runtime's default; spelled out because the step is ~1 200 launches of mostly 3-10 us
+# kernels: with HIP_FORCE_DEV_KERNARG=0 the same step takes 24.6 instead of 22.7 ms — tools/experiments/README.md)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import torch
 import torch.distributed as dist
