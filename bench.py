@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — training images/sec of the MP-Former COCO-instance R50 step at 1024x1024 on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -197,6 +197,32 @@ def _sha256(path):
         return hashlib.sha256(f.read()).hexdigest()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start one FRESH process per GPU the way the reference's driver does
+    (train_net.py:399-412 -> detectron2 `launch(main, num_gpus, ...)`), here as a `torch.distributed.run` child of this process
+    with the same arguments, relay its output (rank 0's single JSON line) and return its exit status.  Called before
+    anything in this process has initialised HIP — the parent never touches the GPU and never replaces itself (no exec).
+    MPF_BENCH_LAUNCH_SCRIPT (tests only): the script the ranks run instead of this file (tests/_bench_world2_child.py maps
+    both ranks to the one GPU of the test box)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.environ.get("MPF_BENCH_LAUNCH_SCRIPT", os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + sys.argv[1:]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:                      # (stderr is inherited; stdout relayed line by line)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,8 +248,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))            # (nothing has touched the GPU yet: children are fresh processes)
     assert world == a.gpus, f"WORLD_SIZE {world} != --gpus {a.gpus}"
     dev_index = local_rank
     torch.cuda.set_device(dev_index)

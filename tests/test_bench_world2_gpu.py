@@ -77,3 +77,25 @@ def test_bench_two_ranks_one_device(grad_sync):
     assert out["roofline"]["launches_per_step"] > 0         # the split-bf16 GEMMs ran on the profiled step ...
     msda = [e for e in out["roofline"]["also"] if e["kernel"].startswith("MSDA backward")]
     assert msda and msda[0]["launches"] > 0                 # ... and so did the native MSDA backward
+
+
+@pytest.mark.timeout(1500)
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (the reference's train_net.py:399-412 starts its own
+    process per GPU): bench.py spawns torch.distributed.run itself before touching the GPU, relays rank 0's single JSON line and
+    returns the children's status.  MPF_BENCH_LAUNCH_SCRIPT points the ranks at the one-GPU child wrapper (both ranks on cuda:0,
+    gloo), everything else is the product's launch path."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MPF_FORCE_DIST"):
+        env.pop(k, None)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MPF_CHECK_SYNC="1", MPF_GRAD_SYNC="flat",
+               MPF_BENCH_LAUNCH_SCRIPT=os.path.join(ROOT, "tests", "_bench_world2_child.py"))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--profile-steps", "1",
+           "--trained-steps", "0", "--size", "512", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1400)
+    assert r.returncode == 0, f"self-launched bench.py --gpus 2 failed:\n{r.stdout[-2000:]}\n{r.stderr[-6000:]}"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["process_group"]["world_size"] == 2
+    assert out["config"]["param_sync_spread"] <= 1e-7

@@ -196,3 +196,35 @@ def test_cached_module_lookups_follow_the_module_tree():
     assert torch.allclose(bn.scale_bias()[0], torch.ones(8))
     bn = bn.double()                                           # .to(): the buffers are replaced
     assert bn.scale_bias()[0].dtype == torch.float64
+
+
+def test_bench_self_launch_starts_one_fresh_process_per_rank(tmp_path):
+    """bench.py --gpus N without a launcher (train_net.py:399-412 starts its own ranks): the parent spawns torch.distributed.run
+    with the same arguments before anything touches the GPU, relays the ranks' stdout and returns their status.  The ranks here
+    are a stub script (MPF_BENCH_LAUNCH_SCRIPT) that reports what the launcher gave it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = tmp_path / "rank.py"
+    stub.write_text("import json, os, sys\n"
+                    "if os.environ['RANK'] == '0':\n"
+                    "    print(json.dumps({'world': os.environ['WORLD_SIZE'], 'addr': os.environ['MASTER_ADDR'], 'argv': sys.argv[1:]}), flush=True)\n"
+                    "sys.exit(3 if '--fail' in sys.argv else 0)\n")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MPF_BENCH_LAUNCH_SCRIPT"] = str(stub)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    got = json.loads(lines[0])
+    assert got == {"world": "2", "addr": "127.0.0.1", "argv": ["--gpus", "2", "--steps", "3", "--warmup", "1"]}
+    # a failing rank's status reaches the caller
+    env["MPF_BENCH_LAUNCH_SCRIPT"] = str(stub)
+    stub.write_text(stub.read_text().replace("if '--fail' in sys.argv", "if True"))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
