@@ -209,8 +209,18 @@ def check(code, what):
         raise RuntimeError(f"{what} failed with code {code}: {msg}")
 
 
+_option_gen = 0
+
+
+def option_generation():
+    """advanced by every set_option: caches of option-dependent sizes (workspace bytes) key on it"""
+    return _option_gen
+
+
 def set_option(key, value):
+    global _option_gen
     check(lib().mpf_set_option(key.encode(), int(value)), f"mpf_set_option({key})")
+    _option_gen += 1
 
 
 def msda_stats(reset=True):

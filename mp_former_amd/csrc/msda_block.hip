@@ -1586,12 +1586,13 @@ __global__ __launch_bounds__(kT) void msda_bwd_spill3_kernel(const float* __rest
                                                              const uint2* __restrict__ ovf, float* __restrict__ grad_value,
                                                              float* __restrict__ grad_loc, float* __restrict__ grad_attn,
                                                              float* __restrict__ grad_raw, GeomB g, unsigned* __restrict__ stats,
-                                                             float* __restrict__ graw_amax)
+                                                             float* __restrict__ graw_amax, float* __restrict__ gv_amax)
 {
     constexpr int LP = NL * kP;
     const int n = *ovf_count;
     const int c = threadIdx.x & 31;
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[6], (unsigned)n);
+    float gvmax = 0.f;
     for (int i = blockIdx.x * (kT / 32) + (threadIdx.x >> 5); i < n; i += gridDim.x * (kT / 32)) {
         const uint2 o = ovf[i];
         const int key = (int)o.x, q = (int)(o.y >> 2), p = (int)(o.y & 3);
@@ -1624,7 +1625,11 @@ __global__ __launch_bounds__(kT) void msda_bwd_spill3_kernel(const float* __rest
             sc[k] = d;
             if (!inimg || px < tx * 4 || px > tx * 4 + 3 || py < ty * 4 || py > ty * 4 + 3) continue;
             const float wgt = fmaxf(0.f, 1.f - fabsf((float)px - x)) * fmaxf(0.f, 1.f - fabsf((float)py - y)) * a;
-            atomicAdd(grad_value + vo, wgt * gq);
+            const float add = wgt * gq;
+            const float before = atomicAdd(grad_value + vo, add);
+            // the tile kernel recorded max |grad_value| BEFORE these adds: |before| + |add| bounds every intermediate
+            // and the final magnitude of the element, and the slot may hold an upper bound
+            gvmax = fmaxf(gvmax, fabsf(before) + fabsf(add));
         }
         if (owned && c == 0) {
             const float lx = x - xf, ly = y - yf, hx = 1.f - lx, hy = 1.f - ly;
@@ -1646,6 +1651,8 @@ __global__ __launch_bounds__(kT) void msda_bwd_spill3_kernel(const float* __rest
             }
         }
     }
+    if (gv_amax && gvmax > 0.f)      // (n == 0: nobody gets here with gvmax > 0; a non-negative float's bit pattern orders like the float)
+        atomicMax(reinterpret_cast<unsigned*>(gv_amax) + (blockIdx.x % kAmaxSub) * kAmaxStride, __float_as_uint(gvmax));
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1934,9 +1941,9 @@ hipError_t launch_bwd3(const float* value, const float* loc, const float* attn, 
                            entries, gv, gl, ga, graw, g, nwg, loc_bytes, g_stats, 0, nullptr, graw_amax, gv_amax);
     mpf::prof_end("msda_bwd_tile_kernel", st, esz * ((double)g.N * g.S * g.M * kD * 2 + n_row + n_samp * 4));
     if (graw)
-        hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, true>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, delta, ovf_count, ovf, gv, gl, ga, graw, g, g_stats, graw_amax);
+        hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, true>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, delta, ovf_count, ovf, gv, gl, ga, graw, g, g_stats, graw_amax, gv_amax);
     else
-        hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, false>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, delta, ovf_count, ovf, gv, gl, ga, graw, g, g_stats, graw_amax);
+        hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, false>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, delta, ovf_count, ovf, gv, gl, ga, graw, g, g_stats, graw_amax, gv_amax);
     return hipGetLastError();
 }
 
@@ -2002,14 +2009,18 @@ size_t msda_block_workspace_bytes(const int64_t* host_shapes, int N, int M, int 
 
 int msda_block_backward(const void* value, const int64_t* host_shapes, const void* loc, const void* attn, const void* go, void* gv,
                         void* gl, void* ga, void* graw, int N, int S, int M, int D, int L, int Lq, int P, int dtype, void* workspace,
-                        size_t workspace_bytes, hipStream_t st, const void* fwd_out, float* graw_amax, float* gv_amax)
+                        size_t workspace_bytes, hipStream_t st, const void* fwd_out, float* graw_amax, float* gv_amax,
+                        bool* amax_recorded)
 {
+    if (amax_recorded) *amax_recorded = false;
     if (!host_shapes || !block_ok(N, S, M, D, L, Lq, P, dtype)) return -1000;
     GeomB g;
     if (!build_geom(g, host_shapes, N, S, M, L, Lq)) return -1000;
     if (workspace_bytes < ws_layout(g).total) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: workspace too small");
-    if ((graw_amax || gv_amax) && !(g_bwd_gen == 3 && graw && fwd_out))
-        return mpf::fail(MPF_E_SHAPE, "msda_backward: the amax outputs belong to the raw form of the bin + tile kernels");
+    // the amax slots are filled by the bin + tile (+ spill) kernels of the raw form; on every other route the caller runs
+    // the amax passes itself (a switch or a geometry outside these kernels must not make the training step fail)
+    if (!(g_bwd_gen == 3 && graw && fwd_out)) graw_amax = gv_amax = nullptr;
+    else if (amax_recorded) *amax_recorded = true;
     if (g_bwd_gen == 3 && (!graw || fwd_out)) {
         mpf::set_kernel("msda_bwd_block(bin+tile)");
         hipError_t e3;

@@ -576,13 +576,24 @@ extern "C" size_t mpf_msda_backward_workspace_bytes(int batch, int num_heads, in
     return binned > blocked ? binned : blocked;
 }
 
+// the amax slots of grad_value / grad_raw by a pass over the data: every route whose kernels do not record them themselves
+static int amax_after(const void* grad_value, const void* grad_raw, int N, int S, int M, int D, int L, int Lq, int P, float* graw_amax,
+                      float* gv_amax, void* stream)
+{
+    if (gv_amax)
+        if (int r = mpf_amax_f32((const float*)grad_value, (int64_t)N * S * M * D, gv_amax, stream)) return r;
+    if (graw_amax && grad_raw)
+        if (int r = mpf_amax_f32((const float*)grad_raw, (int64_t)N * Lq * M * L * P * 3, graw_amax, stream)) return r;
+    return 0;
+}
+
 static int backward_ws_impl(const void* value, const int64_t* host_spatial_shapes,
                             const void* sampling_loc, const void* attn_weight, const void* grad_output,
                             void* grad_value, void* grad_sampling_loc, void* grad_attn_weight, void* grad_raw,
                             int batch, int spatial_size, int num_heads, int channels,
                             int num_levels, int num_query, int num_point, int dtype,
                             void* workspace, size_t workspace_bytes, void* stream, const void* fwd_out = nullptr,
-                            float* graw_amax = nullptr, float* gv_amax = nullptr)
+                            float* graw_amax = nullptr, float* gv_amax = nullptr, bool skip_block = false)
 {
     const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query, P = num_point;
     if (!value || !host_spatial_shapes || !sampling_loc || !attn_weight || !grad_output || !grad_value ||
@@ -590,13 +601,20 @@ static int backward_ws_impl(const void* value, const int64_t* host_spatial_shape
         return mpf::fail(MPF_E_NULL, "msda_backward_ws: NULL buffer");
     if (dtype != MPF_F32 || D != kD) return mpf::fail(MPF_E_DTYPE, "msda_backward_ws: fp32 with 32 channels per head only");
     if (N <= 0 || S <= 0 || M <= 0 || L <= 0 || Lq <= 0 || P <= 0) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: bad sizes");
-    {   // production path: spatially blocked push + MFMA pull (msda_block.hip); -1000 = not its shapes
+    if (!skip_block) {   // production path: destination-side bin + tile kernels (msda_block.hip); -1000 = not its shapes
+        bool recorded = false;
         const int r = mpf::msda_block_backward(value, host_spatial_shapes, sampling_loc, attn_weight, grad_output, grad_value,
                                                grad_sampling_loc, grad_attn_weight, grad_raw, N, S, M, D, L, Lq, P, dtype, workspace,
-                                               workspace_bytes, (hipStream_t)stream, fwd_out, graw_amax, gv_amax);
-        if (r != -1000) return r;
-        if (graw_amax || gv_amax) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws_raw_o: amax outputs need the blocked kernels' shapes");
+                                               workspace_bytes, (hipStream_t)stream, fwd_out, graw_amax, gv_amax, &recorded);
+        if (r != -1000) return (r != 0 || recorded) ? r : amax_after(grad_value, grad_raw, N, S, M, D, L, Lq, P, graw_amax, gv_amax, stream);
     }
+    if (graw_amax || gv_amax) {      // round-1 route: same results, then the two amax passes
+        const int r = backward_ws_impl(value, host_spatial_shapes, sampling_loc, attn_weight, grad_output, grad_value, grad_sampling_loc,
+                                       grad_attn_weight, grad_raw, batch, spatial_size, num_heads, channels, num_levels, num_query,
+                                       num_point, dtype, workspace, workspace_bytes, stream, fwd_out, nullptr, nullptr, true);
+        return r ? r : amax_after(grad_value, grad_raw, N, S, M, D, L, Lq, P, graw_amax, gv_amax, stream);
+    }
+    (void)skip_block;
     Geom g;
     if (!build_geom(g, host_spatial_shapes, N, S, M, L, Lq, P))
         return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: unsupported level geometry (L <= 8, L*P <= 32, sum HW == S)");

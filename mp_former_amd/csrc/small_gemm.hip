@@ -693,7 +693,7 @@ int launch_tall_ws(const void* a, int64_t lda, const void* b, int64_t ldb, const
     // the grid is exactly one residency (LDS: 160 KB per CU; registers: two workgroups), so that no workgroup starts after the
     // others have walked their tiles
     const unsigned per_cu = lds > 80 * 1024 ? 1u : 2u;
-    unsigned gy = (unsigned)(g_tall_ws_wgs ? g_tall_ws_wgs : 256 * per_cu) / gx;
+    unsigned gy = (unsigned)(g_tall_ws_wgs ? g_tall_ws_wgs : mpf::cu_count() * (int)per_cu) / gx;
     gy = gy < 1u ? 1u : (gy > (unsigned)ntiles ? (unsigned)ntiles : gy);
     {
         const void* fn = bias ? (const void*)tall_ws_bf16_kernel<KS, NB, MB, NBUF, true> : (const void*)tall_ws_bf16_kernel<KS, NB, MB, NBUF, false>;

@@ -69,9 +69,13 @@ _scratch_sizes = {}
 
 
 def _scratch_bytes(lib, Qt, N, H, S, F_):
-    key = (Qt, N, H, S, F_)
+    """(layer scratch, attention workspace) bytes of a shape.  The attention workspace depends on run-time options (the key
+    split: attn_nw / attn_kpw), so the cache is keyed on the option generation `_lib.set_option` advances."""
+    key = (Qt, N, H, S, F_, _lib.option_generation())
     hit = _scratch_sizes.get(key)
     if hit is None:
+        if len(_scratch_sizes) > 256:
+            _scratch_sizes.clear()
         hit = _scratch_sizes[key] = (max(lib.mpf_decoder_layer_scratch_bytes(Qt, N, H, S, F_, 0),
                                          lib.mpf_decoder_layer_scratch_bytes(Qt, N, H, S, F_, 1)),
                                      max(lib.mpf_attn_workspace_bytes(Qt, S, N, H), lib.mpf_attn_workspace_bytes(Qt, Qt, N, H)))

@@ -712,6 +712,11 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
                 n_ = self.decoder_norm
                 mlp = [(W[f"mask_embed.layers.{k}.weight"], W[f"mask_embed.layers.{k}.bias"]) for k in range(3)]
                 if (n_.elementwise_affine and n_.bias is not None
+                        # (raw pointers below: everything the native call reads is checked here — ADVICE r4)
+                        and n_.weight.dtype == n_.bias.dtype == torch.float32 and n_.weight.is_contiguous() and n_.bias.is_contiguous()
+                        and n_.weight.device == n_.bias.device == output.device and n_.weight.numel() == 256
+                        and pooled.dtype == torch.bfloat16 and pooled.is_contiguous() and pooled.shape[-1] == 256
+                        and pooled.device == output.device
                         and all(w_.dtype == torch.bfloat16 and w_.shape == (256, 256) and w_.is_contiguous() and b_.is_contiguous()
                                 for w_, b_ in mlp)):
                     return next_attn_mask_native(output, n_, mlp, pooled, mp_rows)

@@ -534,3 +534,40 @@ def test_raw_forms_match_softmax_plus_op(shapes, N, fuse_prep):
         g_off = graw[:, :no].view(N, S, M, L, P, 2)
         torch.testing.assert_close(g_off[smooth], r_off[smooth], rtol=2e-3, atol=2e-3)
         torch.testing.assert_close(graw[:, no:], r.grad[:, no:], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_amax_slots_cover_the_spill_adds_and_survive_the_other_routes(dev):
+    """(a) the spill kernel adds into grad_value AFTER the tile kernel recorded max |grad_value| — with every sample on
+    one spot the runs overflow and the slot must still bound the final tensor; (b) with the blocked kernels switched off
+    (`msda_block_disable`) the raw backward must still fill both slots (by its own amax passes) instead of failing the step."""
+    from mp_former_amd import _lib, msda
+    from mp_former_amd.gemm3 import amax_slots, amax_value
+    z = _decoder_like_problem([(8, 8), (16, 16), (32, 32)], 1, None, "point", seed=11)
+    lv = [tuple(int(v) for v in r) for r in z["shapes"]]
+    ss = msda.attach_host_shapes(torch.as_tensor(z["shapes"], dtype=torch.long, device=dev), lv)
+    lsi = torch.as_tensor(z["level_start"], dtype=torch.long, device=dev)
+    value, loc, attn, go = (torch.as_tensor(z[k], device=dev) for k in ("value", "loc", "attn", "grad_out"))
+    out = msda.ms_deform_attn_forward(value, ss, lsi, loc, attn, 128, ss._mpf_host)
+    _lib.set_option("msda_stats", 1)
+    try:
+        _lib.msda_stats(reset=True)
+        slots = amax_slots(2, dev)
+        gv, graw = msda.ms_deform_attn_backward_raw(value, ss._mpf_host, loc, attn, go, out, slots[0], slots[1])
+        st = _lib.msda_stats(reset=True)
+    finally:
+        _lib.set_option("msda_stats", 0)
+    assert "bin+tile" in _lib.last_kernel() and st["spill_entries"] > 0, (_lib.last_kernel(), st)
+    assert float(amax_value(slots[1])) >= float(gv.abs().max()), (float(amax_value(slots[1])), float(gv.abs().max()))
+    assert float(amax_value(slots[1])) <= 4.0 * float(gv.abs().max())            # (a bound, but not a loose one)
+    assert float(amax_value(slots[0])) == float(graw.abs().max())
+    _lib.set_option("msda_block_disable", 1)
+    try:
+        slots2 = amax_slots(2, dev)
+        gv2, graw2 = msda.ms_deform_attn_backward_raw(value, ss._mpf_host, loc, attn, go, out, slots2[0], slots2[1])
+        assert "block" not in _lib.last_kernel(), _lib.last_kernel()
+    finally:
+        _lib.set_option("msda_block_disable", 0)
+    assert float(amax_value(slots2[0])) == float(graw2.abs().max()) and float(amax_value(slots2[1])) == float(gv2.abs().max())
+    torch.testing.assert_close(gv2, gv, rtol=2e-3, atol=2e-3 * float(gv.abs().max()))
+    torch.testing.assert_close(graw2, graw, rtol=2e-3, atol=2e-3 * float(graw.abs().max()))
