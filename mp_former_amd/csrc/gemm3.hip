@@ -77,6 +77,7 @@ int g_ablate = 0;      // mpf_set_option("gemm3_ablate"): reserved for timing ex
 int g_mixed = 1;       // mpf_set_option("gemm3_mixed_tiles"): 128 x 64 tiles for the last partial round
 int g_two_pass = 256;  // mpf_set_option("gemm3_two_pass"): N >= this and N % 256 == 0 -> 128 x 256 / 96 x 256 two-pass tiles (0 = off)
 int g_two_pass_rows = 0;   // mpf_set_option("gemm3_two_pass_rows"): 0 = pick 128 or 96 rows per tile by rounds, else force
+int g_ws = 512;            // mpf_set_option("gemm3_ws"): K = 256, N % 256 == 0, N >= this: fp16 x 2 products on the weight-stationary kernel (0 = never)
 
 #ifdef G3_TIMING
 // phase timing (build with -DG3_TIMING; tools/bench_gemm3.py --phases): s_memtime deltas of wave 0 of every
@@ -433,20 +434,25 @@ inline void g3_no_bits(G3& p, const float* consts)
 // returns the largest |value| this thread stored (SCALED kernels; 0 otherwise)
 template <int NJ, int NI = 4, typename AccT = Acc<NJ, false>, bool SCALED = false>
 __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int lane, int m_wave, int n_wave, const float inv_a = 1.f,
-                                            const float inv_b = 1.f)
+                                            const float inv_b = 1.f, const int m_end = 0x7fffffff)
 {
     float amax = 0.f;
     const int r16 = lane & 15, g = lane >> 4;
     int64_t mrow[NI];
     bool mok[NI];
-    uint2 gb[NI];                // the wave tile's 64 gate bits of every row (all ones when there is no bit mask)
+    uint2 gb[NI];                // the wave tile's 64 (NJ <= 2: 32) gate bits of every row (all ones when there is no bit mask)
     unsigned wb[NI][2];          // (C > 0) of the same 64 columns, this lane's nibbles
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int m = m_wave + i * 16 + r16;
-        mok[i] = m < p.M;
+        mok[i] = m < p.M && m < m_end;           // m_end: rows from there on belong to another workgroup (gemm3_ws_kernel)
         mrow[i] = min(m, p.M - 1);
-        gb[i] = *reinterpret_cast<const uint2*>(p.gbits + mrow[i] * p.ldgbits + (n_wave >> 3) * p.gbits_cm);
+        if constexpr (NJ <= 2) {                 // a 32-column wave tile: 4 bytes of the row's mask
+            gb[i].x = *reinterpret_cast<const unsigned*>(p.gbits + mrow[i] * p.ldgbits + (n_wave >> 3) * p.gbits_cm);
+            gb[i].y = 0u;
+        } else {
+            gb[i] = *reinterpret_cast<const uint2*>(p.gbits + mrow[i] * p.ldgbits + (n_wave >> 3) * p.gbits_cm);
+        }
         wb[i][0] = wb[i][1] = 0u;
     }
 #pragma unroll
@@ -508,8 +514,10 @@ __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int l
             unsigned lo = wb[i][0], hi = wb[i][1];
             lo |= __shfl_xor(lo, 16); hi |= __shfl_xor(hi, 16);
             lo |= __shfl_xor(lo, 32); hi |= __shfl_xor(hi, 32);
-            if (g == 0 && mok[i] && n_wave < p.N)
-                *reinterpret_cast<uint2*>(p.gbits_out + mrow[i] * p.ldgbits_out + (n_wave >> 3)) = make_uint2(lo, hi);
+            if (g == 0 && mok[i] && n_wave < p.N) {
+                if constexpr (NJ <= 2) *reinterpret_cast<unsigned*>(p.gbits_out + mrow[i] * p.ldgbits_out + (n_wave >> 3)) = lo;
+                else *reinterpret_cast<uint2*>(p.gbits_out + mrow[i] * p.ldgbits_out + (n_wave >> 3)) = make_uint2(lo, hi);
+            }
         }
     }
     return amax;
@@ -527,6 +535,8 @@ __device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(saved) : "v"(voff), "s"(base), "s"(lds_addr) : "memory");
 }
+
+#include "gemm3_ws.h"
 
 // one output tile: 128 rows x BN columns starting at (m0, n0)
 // CV: A is a channel-last image [N_img*H*W][Cin] and K runs over (tap, channel) of a 3x3 window — K step kt reads the
@@ -1592,6 +1602,7 @@ int mpf::set_gemm3_option(const char* key, int v)
     if (!strcmp(key, "gemm3_mixed_tiles")) { g_mixed = v; return 0; }
     if (!strcmp(key, "gemm3_two_pass")) { g_two_pass = v; return 0; }
     if (!strcmp(key, "gemm3_two_pass_rows")) { g_two_pass_rows = v; return 0; }
+    if (!strcmp(key, "gemm3_ws")) { g_ws = v; return 0; }
     if (strcmp(key, "gemm3_ablate") != 0) return 1;
     g_ablate = v;
     return 0;
@@ -1656,6 +1667,36 @@ static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows,
                       int relu, void* stream, const float* a_amax, const float* b_amax, float* out_amax,
                       const unsigned char* gbits = nullptr, int64_t ldgbits = 0, unsigned char* gbits_out = nullptr,
                       int64_t ldgbits_out = 0);
+
+// weight-stationary kernel (gemm3_ws.h): one persistent workgroup per CU; the N / 256 column groups of a row range on one XCD
+static int g3_launch_ws(G3& p, hipStream_t st)
+{
+    const int ncg = p.N / 256;
+    const int cus = mpf::cu_count();
+    int per_xcd = cus / 8 / ncg * ncg;                 // workgroups per XCD: a multiple of the column groups
+    if (per_xcd < ncg) per_xcd = ncg;
+    int workers = per_xcd / ncg * 8;                   // row workers
+    const int tiles16 = (p.M + 15) / 16;
+    if (workers > tiles16) workers = ((tiles16 + 7) / 8) * 8;
+    const int rpw = ((p.M + workers - 1) / workers + 15) / 16 * 16;
+    const int grid = workers * ncg;                    // block b: xcd = b & 7, slot = b >> 3: column group slot % ncg, row worker (slot / ncg) * 8 + xcd
+    const int v = (p.cin_cm ? 2 : 0) + (p.gbits_cm ? 1 : 0);        // (a second addend or an fp32 gate take the tiled kernel: g3_tn_impl)
+    static mpf::LdsAttr attr[4];
+    const void* fns[4] = {(const void*)gemm3_ws_kernel<0, false>, (const void*)gemm3_ws_kernel<0, true>, (const void*)gemm3_ws_kernel<1, false>,
+                          (const void*)gemm3_ws_kernel<1, true>};
+    if (int e = mpf::ensure_dynamic_lds(fns[v], kWsLds, attr[v])) return e;
+    mpf::prof_begin(st);
+    mpf::set_kernel("gemm3_tn_kernel<h2 ws>");
+    const dim3 gr(grid), bl(kWsThreads);
+    switch (v) {
+        case 0: hipLaunchKernelGGL((gemm3_ws_kernel<0, false>), gr, bl, kWsLds, st, p, rpw, ncg); break;
+        case 1: hipLaunchKernelGGL((gemm3_ws_kernel<0, true>), gr, bl, kWsLds, st, p, rpw, ncg); break;
+        case 2: hipLaunchKernelGGL((gemm3_ws_kernel<1, false>), gr, bl, kWsLds, st, p, rpw, ncg); break;
+        default: hipLaunchKernelGGL((gemm3_ws_kernel<1, true>), gr, bl, kWsLds, st, p, rpw, ncg); break;
+    }
+    mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)p.M * p.K + (double)p.M * p.N) + 4.0 * (double)p.N * p.K, 2.0 * p.M * (double)p.N * p.K);
+    return mpf::check(hipGetLastError(), "mpf_gemm3_tn_h2(ws)");
+}
 
 extern "C" int mpf_gemm3_tn(const float* a, int64_t lda, const float* a2, int a2_rows, const void* b_planes,
                             const float* bias, const float* c_in, int64_t ldcin, const float* c_in2, int64_t ldcin2,
@@ -1728,6 +1769,8 @@ static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows,
     p.tiles_n = use96 ? (N + 95) / 96 : (N + 127) / 128;
     p.ntiles = tiles_m * p.tiles_n;
     p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
+    // (N >= g_ws: at N = 256 the 64 MB of weight fragments the workgroups fetch once per launch cost what the tiled kernel's re-reads do)
+    if (a_amax && !a2 && !gate && !c_in2 && g_ws > 0 && N >= g_ws && K == kWsK && N % 256 == 0 && ((uintptr_t)a & 15) == 0) return g3_launch_ws(p, st);
     if (!a2 && g3_launch_two_pass(p, st)) {
         mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + (a_amax ? 4.0 : 6.0) * (double)N * K, 2.0 * M * (double)N * K);
         return mpf::check(hipGetLastError(), "mpf_gemm3_tn");

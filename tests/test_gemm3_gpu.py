@@ -354,3 +354,49 @@ def test_gemm3_nt_grouped_h2_bit_equal_to_single_problems():
         c, ca, _ = gemm3_nt(g, x, rps, want_csum_a=True, amax_ab=am)
         wdw, wdb = nt_reduce(c, ca)
         assert torch.equal(dw, wdw) and torch.equal(db, wdb)
+
+
+@pytest.mark.parametrize("M,N", [(43008, 256), (43008, 1024), (1000, 256), (77, 512), (16, 256), (2731, 1024), (16800, 256)])
+def test_gemm3_ws_kernel_bit_identical_to_the_tiled_kernel(M, N):
+    """The weight-stationary K = 256 kernel (csrc/gemm3_ws.h: weight fragments in registers, A tiles by DMA, one barrier per 64
+    rows) against the two-pass tiled kernel it replaces (`gemm3_ws=0`): same split, same product order per output element —
+    every variant of the epilogue (bias, two addends, ReLU, fp32 gate, bit gate, bit-mask output, output amax) bit for bit,
+    incl. row counts that are no multiple of the 64-row tile / the 16-row granule and a strided A."""
+    import numpy as np
+    from mp_former_amd import _lib
+    from mp_former_amd.gemm3 import amax, amax_slots, amax_value, gemm3_h2, gemm3_h2_bits, split_weights_grouped_h2
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + N)
+    K = 256
+    a_full = _heavy(M, K + 64, dev)
+    a = a_full[:, :K]                                   # row stride 320 floats (16-byte aligned rows)
+    w = torch.randn(N, K, device=dev) / 16
+    b, cin, cin2, gate = torch.randn(N, device=dev), torch.randn(M, N, device=dev), torch.randn(M, N, device=dev), torch.randn(M, N, device=dev)
+    (pl, wam), = split_weights_grouped_h2([([w], False)])
+    am = amax(a.contiguous())
+    res = {}
+    for ws in (0, 1):
+        _lib.set_option("gemm3_ws", 256 if ws else 0)       # (1: every N % 256 == 0; the default takes it from N = 512)
+        try:
+            oam = amax_slots(3, dev)
+            r = [gemm3_h2(a, am, pl, wam)]
+            assert ("ws" in _lib.last_kernel()) == bool(ws), _lib.last_kernel()
+            r.append(gemm3_h2(a, am, pl, wam, b, cin=cin, cin2=cin2, out_amax=oam[0]))          # (two addends: always the tiled kernel)
+            r.insert(2, gemm3_h2(a, am, pl, wam, b, relu=True, gate=gate, out_amax=oam[1]))     # (an fp32 gate: always the tiled kernel)
+            assert "ws" not in _lib.last_kernel()
+            r.append(gemm3_h2(a, am, pl, wam, b, cin=cin, relu=True))
+            h, bits = gemm3_h2_bits(a, am, pl, wam, b, relu=True, out_amax=oam[2], want_bits=True)
+            r += [h, bits, gemm3_h2_bits(a, am, pl, wam, cin=cin, gate_bits=bits)]
+            assert ("ws" in _lib.last_kernel()) == bool(ws), _lib.last_kernel()
+            r += [amax_value(oam[i]).clone() for i in range(3)]
+            res[ws] = r
+        finally:
+            _lib.set_option("gemm3_ws", 512)
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+    assert float(res[1][7]) == float(res[1][1].abs().max())
+    want = np.packbits((res[1][4] > 0).cpu().numpy(), axis=1, bitorder="little")
+    assert np.array_equal(res[1][5].cpu().numpy(), want)
+    ref = a.double() @ w.double().t()
+    den = a.double().abs() @ w.double().abs().t()
+    assert float(((res[1][0].double() - ref).abs() / den).max()) < 1e-6
