@@ -228,3 +228,60 @@ def test_bench_self_launch_starts_one_fresh_process_per_rank(tmp_path):
     stub.write_text(stub.read_text().replace("if '--fail' in sys.argv", "if True"))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_registry_plugin_builds_both_decoders_by_name():
+    """mp_former_amd.d2_plugin against stub registries of detectron2's interface (this image has no detectron2): the reference's
+    build functions (pixel_decoder/fpn.py:21-34, transformer_decoder/maskformer_transformer_decoder.py:21-28) look a class up
+    by the configured NAME and call it with (cfg, ...) — both HIP classes must come back from the registries and construct
+    themselves from a config tree with the reference's keys, with the reference's state-dict keys."""
+    from types import SimpleNamespace as NS
+    from mp_former_amd import d2_plugin
+
+    class Registry:                       # detectron2.utils.registry.Registry (fvcore): register(obj) as call or decorator, get(name)
+        def __init__(self, name):
+            self._name, self._map = name, {}
+
+        def register(self, obj=None):
+            if obj is None:
+                return lambda o: self.register(o) or o
+            assert obj.__name__ not in self._map, f"{obj.__name__} already registered in {self._name}"
+            self._map[obj.__name__] = obj
+            return obj
+
+        def get(self, name):
+            if name not in self._map:
+                raise KeyError(f"No object named '{name}' found in '{self._name}' registry!")
+            return self._map[name]
+
+    assert d2_plugin.registered() is False                      # no detectron2 here: the import-time registration was a no-op
+    sem, trf = Registry("SEM_SEG_HEADS"), Registry("TRANSFORMER_MODULE")
+    assert d2_plugin.register(sem, trf)
+    cfg = NS(MODEL=NS(
+        SEM_SEG_HEAD=NS(IN_FEATURES=["res2", "res3", "res4", "res5"], CONVS_DIM=256, MASK_DIM=256, NORM="GN", TRANSFORMER_ENC_LAYERS=2,
+                        DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES=["res3", "res4", "res5"], COMMON_STRIDE=4, NUM_CLASSES=80,
+                        PIXEL_DECODER_NAME=d2_plugin.PIXEL_DECODER_NAME),
+        MASK_FORMER=NS(DROPOUT=0.0, NHEADS=8, HIDDEN_DIM=256, NUM_OBJECT_QUERIES=100, DIM_FEEDFORWARD=2048, DEC_LAYERS=4, PRE_NORM=False,
+                       ENFORCE_INPUT_PROJ=False, DN_MODE="points", HEAD_DN=False, ALL_LY_DN=True, DN_RATIO=0.5, LB_NOISE_RATIO=0.2,
+                       TRANSFORMER_DECODER_NAME=d2_plugin.TRANSFORMER_DECODER_NAME)))
+    shape = {k: NS(channels=c, stride=s) for k, (c, s) in {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}.items()}
+    # build_pixel_decoder / build_transformer_decoder, restated
+    pix = sem.get(cfg.MODEL.SEM_SEG_HEAD.PIXEL_DECODER_NAME)(cfg, shape)
+    dec = trf.get(cfg.MODEL.MASK_FORMER.TRANSFORMER_DECODER_NAME)(cfg, 256, True)
+    from mp_former_amd.pixel_decoder import MSDeformAttnPixelDecoder
+    from mp_former_amd.transformer_decoder import MultiScaleMaskedTransformerDecoderMaskDN
+    assert isinstance(pix, MSDeformAttnPixelDecoder) and isinstance(dec, MultiScaleMaskedTransformerDecoderMaskDN)
+    assert len(pix.transformer.encoder.layers) == 2 and dec.num_layers == 3 and dec.num_heads == 8
+    assert hasattr(pix, "forward_features") and callable(pix.forward_features)
+    keys = set(pix.state_dict()) | set(dec.state_dict())
+    for k in ("transformer.encoder.layers.0.self_attn.sampling_offsets.weight", "input_proj.0.1.weight", "mask_features.weight",
+              "adapter_1.norm.weight", "layer_1.weight", "query_feat.weight", "label_enc.weight",
+              "transformer_cross_attention_layers.0.multihead_attn.in_proj_weight", "mask_embed.layers.2.bias", "class_embed.weight"):
+        assert k in keys, k
+    # keyword construction (what from_config returns) still works on the registered class, and a second registration of the same
+    # name is refused by the registry as detectron2's does
+    again = sem.get(d2_plugin.PIXEL_DECODER_NAME)(**type(pix).from_config(cfg, shape))
+    assert list(again.state_dict()) == list(pix.state_dict())
+    import pytest
+    with pytest.raises(AssertionError):
+        d2_plugin.register(sem, trf)
