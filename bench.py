@@ -48,21 +48,22 @@ PIXEL_STD = (58.395, 57.120, 57.375)
 
 
 def synth_targets(n, size, num_classes, gen, device):
-    """T_b ~ U{1..20} random axis-aligned rectangles / ellipses as bool masks."""
+    """T_b ~ U{1..20} random axis-aligned rectangles / ellipses as bool masks; size = side or (H, W)."""
     tg = []
-    yy, xx = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")
+    H, W = (size, size) if isinstance(size, int) else size
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
     for _ in range(n):
         T = int(torch.randint(1, 21, (1,), generator=gen))
-        masks = torch.zeros(T, size, size, dtype=torch.bool)
+        masks = torch.zeros(T, H, W, dtype=torch.bool)
         for t in range(T):
-            cy, cx = (torch.rand(2, generator=gen) * size).tolist()
-            hh, ww = (torch.rand(2, generator=gen) * size * 0.3 + 8).tolist()
+            cy, cx = (torch.rand(2, generator=gen) * torch.tensor([H, W], dtype=torch.float32)).tolist()
+            hh, ww = (torch.rand(2, generator=gen) * torch.tensor([H, W], dtype=torch.float32) * 0.3 + 8).tolist()
             if torch.rand(1, generator=gen).item() < 0.5:
                 masks[t] = ((yy - cy).abs() < hh) & ((xx - cx).abs() < ww)
             else:
                 masks[t] = ((yy - cy) / hh) ** 2 + ((xx - cx) / ww) ** 2 < 1.0
             if not masks[t].any():
-                masks[t, int(cy) % size, int(cx) % size] = True
+                masks[t, int(cy) % H, int(cx) % W] = True
         labels = torch.randint(0, num_classes, (T,), generator=gen)
         tg.append({"labels": labels.to(device), "masks": masks.to(device), "boxes": torch.zeros(T, 4, device=device)})
     return tg
@@ -109,6 +110,43 @@ class TrainModel(torch.nn.Module):
             return self.head.total_loss(feats, targets, pd_out)
 
 
+# BASELINE.json configs as head-only workloads (--workload X --head-only): the segmentation head on synthetic backbone features
+# of the configuration's channel counts (SURVEY.md 8(d) allows synthetic features; the backbone is outside the path), per-GPU
+# batch 2 = IMS_PER_BATCH 16 on 8 GPUs in all four configs.  R50: configs/coco/*/maskformer2_R50_bs16_50ep.yaml; Swin-B / ADE20K
+# 640: configs/ade20k/semantic-segmentation/swin/maskformer2_swin_base_384_bs16_160k_res640.yaml; Swin-L / Cityscapes 1024 x 2048,
+# 200 queries: configs/cityscapes/panoptic-segmentation/swin/maskformer2_swin_large_IN21k_384_bs16_90k.yaml:18.
+WORKLOADS = {
+    "B": dict(name="COCO-instance R50", hw=(1024, 1024), chans=(256, 512, 1024, 2048), classes=80, queries=100),
+    "C": dict(name="COCO-panoptic R50", hw=(1024, 1024), chans=(256, 512, 1024, 2048), classes=133, queries=100),
+    "D": dict(name="ADE20K-semantic Swin-B", hw=(640, 640), chans=(128, 256, 512, 1024), classes=150, queries=100),
+    "E": dict(name="Cityscapes-panoptic Swin-L", hw=(1024, 2048), chans=(192, 384, 768, 1536), classes=19, queries=200),
+}
+
+
+class HeadOnlyModel(torch.nn.Module):
+    """pixel decoder + MP decoder + criterion on a dict of backbone feature maps (bf16 channel-last planes, what a bf16 backbone
+    hands over under autocast); the features require gradients, so the backward does everything the full step's head does."""
+    grad_ready_hooks = None
+    trunk = None
+
+    def __init__(self, wl):
+        super().__init__()
+        from mp_former_amd.head import MPFormerHead
+        self.shapes = {f"res{i + 2}": (c, st) for i, (c, st) in enumerate(zip(wl["chans"], (4, 8, 16, 32)))}
+        self.head = MPFormerHead(num_classes=wl["classes"], num_queries=wl["queries"], feature_shapes=self.shapes)
+
+    def forward(self, feats, targets):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return self.head.total_loss(feats, targets)
+
+
+def synth_features(n, hw, shapes, seed, device):
+    gen = torch.Generator().manual_seed(seed)
+    H, W = hw
+    return {k: torch.randn(n, H // st, W // st, c, generator=gen).to(device=device, dtype=torch.bfloat16).permute(0, 3, 1, 2).requires_grad_(True)
+            for k, (c, st) in shapes.items()}
+
+
 def _gemm3_traffic_ratios():
     """{shape: HBM bytes from the PMC counters / algorithmic bytes} of the fp16 x 2 TN kernel (profiles/r03f_gemm3_traffic.json), or None"""
     f = os.path.join(ROOT, "profiles", "r03f_gemm3_traffic.json")
@@ -121,6 +159,8 @@ def _gemm3_traffic_ratios():
 def grad_sync_groups(model):
     """Three flat buckets in the order in which their gradients complete: the head (80 MB), the backbone's res5 + res4
     (88 MB, 94 % of the backbone) and the rest (res3, res2, stem: 6 MB) — only the last one is exchanged after backward()."""
+    if not hasattr(model, "backbone"):                  # --head-only
+        return [list(model.head.parameters())]
     bb = model.backbone
     late = list(bb.res5.parameters()) + list(bb.res4.parameters())
     ids = {id(p) for p in late}
@@ -241,9 +281,17 @@ def main():
                          "launch eager.  Measured on MI355X / ROCm 7.2 (round 4): the replays take the launch thread from 21.6 to ~8 ms per "
                          "step but cost the GPU 4-7 us per graph node (dependent dispatches inside a replay) = +2.5 ms over the ~850 "
                          "captured launches: 23.8 -> 26.3 ms/step while the eager step is GPU-bound")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="B",
+                    help="BASELINE.json configuration (B = the metric's; C, D, E need --head-only: their backbones are outside the path)")
+    ap.add_argument("--head-only", action="store_true",
+                    help="time the segmentation head alone on synthetic backbone features of the workload's channel counts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=1024)
     a = ap.parse_args()
+    if a.workload != "B" and not a.head_only:
+        raise SystemExit("--workload C / D / E are head-only workloads (their backbones are outside the path): add --head-only")
+    wl = WORKLOADS[a.workload]
+    hw = wl["hw"] if (a.head_only and a.workload != "B") else (a.size, a.size)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -268,8 +316,11 @@ def main():
     torch.manual_seed(rank)
     if os.environ.get("MPF_CONV_FIND", "0") == "1":      # let MIOpen time its solvers per conv shape (slow warm-up)
         torch.backends.cudnn.benchmark = True
-    model = TrainModel().to(dev).train()
-    model.backbone.to(memory_format=torch.channels_last)
+    if a.head_only:
+        model = HeadOnlyModel(wl).to(dev).train()
+    else:
+        model = TrainModel().to(dev).train()
+        model.backbone.to(memory_format=torch.channels_last)
 
     def trained_like_offsets():
         """sampling offsets of a mid-training model: per-query scatter of sigma ~ 3 px (weights N(0, 0.18) on the O(1) query
@@ -291,18 +342,25 @@ def main():
     sync = None
     if mdist.distributed() and os.environ.get("MPF_GRAD_SYNC", "flat") == "flat":
         sync = mdist.FlatGradSync(grad_sync_groups(model))
-        model.grad_ready_hooks = {"res5": lambda: sync.launch(0), "res3": lambda: sync.launch(1)}
+        if not a.head_only:
+            model.grad_ready_hooks = {"res5": lambda: sync.launch(0), "res3": lambda: sync.launch(1)}
         ddp = model
     else:
         ddp = mdist.wrap_ddp(model, [dev_index])
     opt = build_optimizer(model)
-    batches = [synth_batch(a.batch, a.size, 80, 1000 * rank + i, dev) for i in range(4)]
+    if a.head_only:
+        batches = []
+        for i in range(4):
+            g_ = torch.Generator().manual_seed(1000 * rank + i)
+            batches.append((synth_features(a.batch, hw, model.shapes, 1000 * rank + i, dev), synth_targets(a.batch, hw, wl["classes"], g_, dev)))
+    else:
+        batches = [synth_batch(a.batch, a.size, 80, 1000 * rank + i, dev) for i in range(4)]
     # the static part of the step (backbone + pixel decoder: fixed shapes at the fixed crop) as HIP graphs: three replays
     # forward, three backward per step instead of ~850 launches.  Captured in-process before the warm-up; a failed capture
     # falls back to the eager path and says so in the JSON line.
     graphs_note = "off (--graphs 0: measured slower on ROCm 7.2 — 4-7 us of GPU time per replayed node; DESIGN.md section 5)"
     trunk = None
-    if a.graphs:
+    if a.graphs and not a.head_only:
         try:
             from mp_former_amd.graphs import GraphedTrunk
             trunk = GraphedTrunk(model.backbone, model.head.pixel_decoder, batches[0][0], pieces=os.environ.get("MPF_GRAPH_PIECES", "abc"))
@@ -379,7 +437,7 @@ def main():
     n_am, ms_am, by_am, _ = prof("amax_kernel")
     fused = {k: prof(k) for k in ("match_cost_fused_kernel", "pair_planes_fwd_kernel", "pair_planes_dfeat_kernel", "pair_planes_dembed_kernel")}
     _lib.profile_enable(False)
-    S_tok = sum((a.size // s) ** 2 for s in (8, 16, 32))
+    S_tok = sum((hw[0] // s) * (hw[1] // s) for s in (8, 16, 32))
     n_b = n_pull                                   # one bin + one tile launch per MSDA backward call
     ms_b = ms_push + ms_pull
     by_b = 1344.0 * 4 * S_tok * a.batch * n_b      # algorithmic bytes: SURVEY.md §8(d), fp32, per call
@@ -389,7 +447,7 @@ def main():
     # null) when the kernels have changed since
     traffic, traffic_note = None, "no PMC file for this shape"
     pmc_file = os.path.join(ROOT, "profiles", "r04_msda_bwd_pmc_configB_N2.json")
-    if a.size == 1024 and a.batch == 2 and os.path.exists(pmc_file):
+    if hw == (1024, 1024) and a.batch == 2 and os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
         src = os.path.join(ROOT, "mp_former_amd", "csrc", "msda_block.hip")
         if pmc.get("source_sha256") == _sha256(src):
@@ -478,16 +536,23 @@ def main():
             return e
 
         fwd_alg = 800.0 * 4 * S_tok * a.batch * n_f            # the forward's own algorithmic bytes
+        if a.head_only:
+            metric = "training images/sec, segmentation head only (synthetic backbone features), %s %dx%d" % (wl["name"], hw[0], hw[1])
+            workload = ("%s, %d queries, %d classes, %dx%d, HEAD ONLY: MSDeformAttn pixel decoder (6 layers) + MP masked decoder (9 layers, "
+                        "NUM_DN 1) + Hungarian matching + 60 losses + backward + clip + AdamW of the head, on synthetic bf16 backbone "
+                        "features with channels %s" % (wl["name"], wl["queries"], wl["classes"], hw[0], hw[1], list(wl["chans"])))
+        else:
+            metric = "training images/sec COCO-instance R50 1024x1024"
+            workload = ("COCO-instance R50, 100 queries, 80 classes, %dx%d: full train step = R50 backbone "
+                        "+ MSDeformAttn pixel decoder (6 layers) + MP masked decoder (9 layers, NUM_DN 1) "
+                        "+ Hungarian matching + 60 losses + backward + grad all-reduce + clip + AdamW" % (a.size, a.size))
         out = {
-            "metric": "training images/sec COCO-instance R50 1024x1024",
+            "metric": metric,
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16 (backbone, decoder) + f32 (pixel decoder, losses), as the reference's AMP",
             "data": "synthetic",
-            "config": {"workload": "COCO-instance R50, 100 queries, 80 classes, %dx%d: full train step = R50 backbone "
-                                   "+ MSDeformAttn pixel decoder (6 layers) + MP masked decoder (9 layers, NUM_DN 1) "
-                                   "+ Hungarian matching + 60 losses + backward + grad all-reduce + clip + AdamW"
-                                   % (a.size, a.size),
+            "config": {"workload": workload, "baseline_config": a.workload, "head_only": bool(a.head_only),
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "tokens_per_image_S": S_tok, "final_loss": round(final_loss, 4),
                        "roofline_steps": P, "msda_offsets": a.msda_offsets, "hip_graphs": graphs_note,
@@ -552,7 +617,7 @@ def main():
         out["config"]["fp32_gemm"] = ("fp16 x 2 split: two pieces per operand, three MFMA products, power-of-two scale from the operand's "
                                       "largest magnitude; error vs fp64 <= the library fp32 GEMM's (tests/test_gemm3_gpu.py)")
         out["config"]["miopen_find_db"] = "mismatch (MIOpen ignored the shipped db)" if _miopen.db_mismatch() else "shipped"
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.head_only:      # (the oracle's step is the config-B / config-A head)
             out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_size)
         print(json.dumps(out), flush=True)
     if mdist.distributed():
