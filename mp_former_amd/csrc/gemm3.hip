@@ -1680,19 +1680,25 @@ static int g3_launch_ws(G3& p, hipStream_t st)
     if (workers > tiles16) workers = ((tiles16 + 7) / 8) * 8;
     const int rpw = ((p.M + workers - 1) / workers + 15) / 16 * 16;
     const int grid = workers * ncg;                    // block b: xcd = b & 7, slot = b >> 3: column group slot % ncg, row worker (slot / ncg) * 8 + xcd
-    const int v = (p.cin_cm ? 2 : 0) + (p.gbits_cm ? 1 : 0);        // (a second addend or an fp32 gate take the tiled kernel: g3_tn_impl)
-    static mpf::LdsAttr attr[4];
-    const void* fns[4] = {(const void*)gemm3_ws_kernel<0, false>, (const void*)gemm3_ws_kernel<0, true>, (const void*)gemm3_ws_kernel<1, false>,
-                          (const void*)gemm3_ws_kernel<1, true>};
-    if (int e = mpf::ensure_dynamic_lds(fns[v], kWsLds, attr[v])) return e;
+    // instantiated epilogues (cin, gate bits, relu, bits out): plain | + addend | ReLU | ReLU + addend | ReLU + mask out | bit-mask gate (+ addend)
+    const int key = (p.cin_cm ? 8 : 0) | (p.gbits_cm ? 4 : 0) | (p.relu ? 2 : 0) | (p.gbits_out ? 1 : 0);
+    const void* fn = nullptr;
+    int slot = 0;
+#define WS_CASE(K_, I_, E_, G_, R_, B_) case K_: fn = (const void*)gemm3_ws_kernel<E_, G_, R_, B_>; slot = I_; break;
+    switch (key) {
+        WS_CASE(0, 0, 0, false, false, false) WS_CASE(8, 1, 1, false, false, false) WS_CASE(2, 2, 0, false, true, false)
+        WS_CASE(10, 3, 1, false, true, false) WS_CASE(3, 4, 0, false, true, true) WS_CASE(4, 5, 0, true, false, false)
+        WS_CASE(12, 6, 1, true, false, false)
+        default: return -1000;          // not instantiated: the tiled kernel
+    }
+#undef WS_CASE
+    static mpf::LdsAttr attr[7];
+    if (int e = mpf::ensure_dynamic_lds(fn, kWsLds, attr[slot])) return e;
     mpf::prof_begin(st);
     mpf::set_kernel("gemm3_tn_kernel<h2 ws>");
-    const dim3 gr(grid), bl(kWsThreads);
-    switch (v) {
-        case 0: hipLaunchKernelGGL((gemm3_ws_kernel<0, false>), gr, bl, kWsLds, st, p, rpw, ncg); break;
-        case 1: hipLaunchKernelGGL((gemm3_ws_kernel<0, true>), gr, bl, kWsLds, st, p, rpw, ncg); break;
-        case 2: hipLaunchKernelGGL((gemm3_ws_kernel<1, false>), gr, bl, kWsLds, st, p, rpw, ncg); break;
-        default: hipLaunchKernelGGL((gemm3_ws_kernel<1, true>), gr, bl, kWsLds, st, p, rpw, ncg); break;
+    {
+        void* args[] = {(void*)&p, (void*)&rpw, (void*)&ncg};
+        if (hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(kWsThreads), args, kWsLds, st); e != hipSuccess) return mpf::check(e, "gemm3_ws_kernel");
     }
     mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)p.M * p.K + (double)p.M * p.N) + 4.0 * (double)p.N * p.K, 2.0 * p.M * (double)p.N * p.K);
     return mpf::check(hipGetLastError(), "mpf_gemm3_tn_h2(ws)");
@@ -1770,7 +1776,10 @@ static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows,
     p.ntiles = tiles_m * p.tiles_n;
     p.tm0 = 0; p.ntiles2 = 0; p.tiles_n2 = 0;
     // (N >= g_ws: at N = 256 the 64 MB of weight fragments the workgroups fetch once per launch cost what the tiled kernel's re-reads do)
-    if (a_amax && !a2 && !gate && !c_in2 && g_ws > 0 && N >= g_ws && K == kWsK && N % 256 == 0 && ((uintptr_t)a & 15) == 0) return g3_launch_ws(p, st);
+    if (a_amax && !a2 && !gate && !c_in2 && g_ws > 0 && N >= g_ws && K == kWsK && N % 256 == 0 && ((uintptr_t)a & 15) == 0) {
+        const int r = g3_launch_ws(p, st);
+        if (r != -1000) return r;
+    }
     if (!a2 && g3_launch_two_pass(p, st)) {
         mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + (a_amax ? 4.0 : 6.0) * (double)N * K, 2.0 * M * (double)N * K);
         return mpf::check(hipGetLastError(), "mpf_gemm3_tn");

@@ -23,7 +23,12 @@
 //     so every output element is BIT-IDENTICAL to gemm3_tn2_kernel's (tests/test_gemm3_gpu.py compares the two);
 //   * ONE barrier per 32-row tile (plane image t + 1 complete, plane image t released); the loop has no B traffic, no LDS
 //     stores beside the 2 KB per wave of the convert, no staging registers;
-//   * the epilogue's operands are template flags (no dummy loads), the addend is requested before the MFMA phase.
+//   * per iteration a wave converts tile t + 1, stores tile t - 1 (its accumulators live across the barrier) and then runs the
+//     MFMA phase of tile t; the epilogue's operands are template flags (no dummy loads, straight-line code).
+// What bounds it (tools/ws_phases.py, tools/ws_prologue.py): the two waves of a SIMD do not overlap — an MFMA-streaming wave
+// starves its partner — so a tile costs the SUM of its phases (~5 900 cycles per 32 rows: MFMA 2 x 1 536, convert, epilogue,
+// barrier skew), and a launch pays ~20 k cycles of prologue for the 256 KB of weight fragments per CU (row-strided 64-byte
+// pieces; a fragment-major plane layout would halve it).
 //
 // Work split: row worker rw (the workgroups that share rows sit on one XCD, so the N / 256 column groups of a row range read
 // it from that XCD's L2) owns rows [rw * rpw, (rw + 1) * rpw), rpw a multiple of 16 chosen so that every CU has work:
@@ -32,14 +37,8 @@
 #ifndef WS_ABL
 #define WS_ABL 0      // timing experiments only (tools/ab_ws_ablate.sh; results wrong): 1 no convert, 2 no MFMAs, 4 no epilogue, 8 no DMA
 #endif
-#ifndef WS_LATE_LOW
-#define WS_LATE_LOW 0
-#endif
-#ifndef WS_EPI_FIRST
-#define WS_EPI_FIRST true
-#endif
-#ifndef WS_PRIO
-#define WS_PRIO 2
+#ifndef WS_TIME_PROLOGUE
+#define WS_TIME_PROLOGUE 0
 #endif
 constexpr int kWsBM = 32;                 // rows per tile
 constexpr int kWsK = 256;                 // contraction length (8 K steps of 32)
@@ -55,8 +54,12 @@ __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // EPI: 0 = bias only; 1 = + cin (a second addend or an fp32 gate operand take the tiled kernel).  ReLU and the bit-mask output
 // are uniform register-only branches as in g3_epilogue.  The operands are template flags because every load of the loop is
 // counted by hand (the row copies are inline asm the compiler's vmcnt bookkeeping does not see).
-// GB: the ReLU gate arrives as a bit mask (p.gbits).
-template <int EPI, bool GB>
+// GB: the ReLU gate arrives as a bit mask (p.gbits).  RELU: max(., 0).  BOUT: the mask of (C > 0) goes to p.gbits_out.
+// (Template flags, not uniform branches: the two waves of a SIMD share its issue slots, an MFMA leaves room for about two other
+// instructions, and the epilogue of a tile had been ~330 VALU instructions per wave against 96 MFMAs — measured: the phases of
+// the wave pair add up instead of overlapping.  Straight-line code, one address computation per row and max3 with |.| source
+// modifiers bring it to ~110.)
+template <int EPI, bool GB, bool RELU, bool BOUT>
 __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, int ncg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
@@ -103,7 +106,11 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
+#if WS_ABL & 128     // (timing only) the same bytes as one contiguous 1 KB per wave instruction
+                    fb[s][j][pl] = *reinterpret_cast<const uint4*>(p.bp + (int64_t)pl * p.plane + (int64_t)n0 * kWsK + ((j * 8 + s) * 64 + lane) * 8);
+#else
                     fb[s][j][pl] = *reinterpret_cast<const uint4*>(bw + (int64_t)pl * p.plane + (int64_t)j * 16 * kWsK + s * 32);
+#endif
     }
     float sc_a, inv_a, sc_b, inv_b;
     h2_scale(amax_read(p.a_amax), &sc_a, &inv_a);
@@ -124,7 +131,6 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
             const float4 u = *reinterpret_cast<const float4*>(st + rr * 1024 + kk * 16);
             const float4 v = *reinterpret_cast<const float4*>(st + rr * 1024 + (32 + kk) * 16);
 #ifdef G3_TIMING
-            if (a == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); G3_T(1); }
 #endif
             uint4 h, l;
 #if WS_ABL & 1
@@ -142,10 +148,23 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
     // tiles 0 and 1 of this wave's rows and the weight fragments have arrived.  The BUILTIN, not inline asm: hipcc's waitcnt pass
     // has to see that its own 40 loads are done, or it drains them with vmcnt(N) waits inside the loop that count the row
     // copies it does not know of — i.e. waits for copies issued a moment ago.  (vmcnt 0, expcnt 7, lgkmcnt 15: gfx9 encoding)
+#ifdef G3_TIMING
+    if (WS_TIME_PROLOGUE) { G3_T(1); }             // everything requested
+#endif
     __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef G3_TIMING
+    if (WS_TIME_PROLOGUE) { G3_T(2); }             // ... and arrived
+#endif
     convert(0);
     dma_rows(2);
     ws_barrier();
+#ifdef G3_TIMING
+    if (WS_TIME_PROLOGUE) {                        // prologue detail: [1] issue, [2] wait, [3] convert + barrier; the loop is not stamped
+        G3_T(3);
+        if (tid == 0) { for (int i = 0; i < 7; ++i) atomicAdd(&g3_dbg[i], tacc[i]); atomicAdd(&g3_dbg[7], 1ull); }
+        for (int i = 0; i < 8; ++i) tacc[i] = 0;
+    }
+#endif
     G3_T(0);
 
     // fragment of (row tile i, plane pl, K step s): row 16 i + r16, chunk (32 pl + ((4 s + g) ^ r16))
@@ -202,119 +221,102 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
     // (4 loads, the youngest).  Loads return in order among loads, so "at most 4 outstanding" means the rows of tile tc have
     // landed whatever the stores are doing; and no load the compiler knows of is followed by a row copy before its use, so
     // the waits hipcc inserts for the addends never wait for copies it cannot see.
-    auto middle = [&](int tc, int te, const bool epi_first) {
-        // this phase is VALU / LDS / VMEM work beside the partner wave's MFMA stream: without priority the YOUNGER wave of the
-        // pair gets only the issue slots the older one's MFMAs leave (measured: its convert 2 400 cycles against 570)
-        __builtin_amdgcn_s_setprio(WS_PRIO);
+    auto middle = [&](int tc, int te) {
 #if !(WS_ABL & 32)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WS_ABL & 8) ? 0 : 4) : "memory");
 #endif
         G3_T(3);
-        float4 ci[2][2], c2[2][2];
+        float4 ci[2][2];
         unsigned gb[2] = {0xffffffffu, 0xffffffffu};
-        int64_t mrow[2];
+        float* crow[2];
         bool mok[2];
         const int m_tile = r0 + max(te, 0) * kWsBM;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m_tile + i * 16 + r16;
             mok[i] = m < r1 && te >= 0;
-            mrow[i] = min(m, r1 - 1);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if constexpr (EPI >= 1) ci[i][j] = *reinterpret_cast<const float4*>(p.cin + mrow[i] * p.ldcin + (nq + 16 * j) * p.cin_cm);
-                if constexpr (EPI >= 2) c2[i][j] = *reinterpret_cast<const float4*>(p.cin2 + mrow[i] * p.ldcin2 + (nq + 16 * j) * p.cin2_cm);
+            const int64_t mr = min(m, r1 - 1);
+            crow[i] = p.c + mr * p.ldc + nq;
+            if constexpr (EPI >= 1) {
+                const float* cr = p.cin + mr * p.ldcin + nq;
+                ci[i][0] = *reinterpret_cast<const float4*>(cr);
+                ci[i][1] = *reinterpret_cast<const float4*>(cr + 16);
             }
-            if constexpr (GB) gb[i] = *reinterpret_cast<const unsigned*>(p.gbits + mrow[i] * p.ldgbits + (n0 >> 3));
+            if constexpr (GB) gb[i] = *reinterpret_cast<const unsigned*>(p.gbits + mr * p.ldgbits + (n0 >> 3));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!epi_first) {
-            convert(tc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        convert(tc);
+        __builtin_amdgcn_sched_barrier(0);
         G3_T(4);
         if (te >= 0) {                      // (uniform)
-        // ---- epilogue (the arithmetic and its order are g3_epilogue's) ---------------------------------------------------
+            // ---- epilogue (the arithmetic and its order are g3_epilogue's; an absent addend is not added: x + 0 differs from x
+            // only in the sign of a zero) -------------------------------------------------------------------------------------
 #if WS_ABL & 4
-        omax = fmaxf(omax, acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] + (float)gb[0]);
+            omax = fmaxf(omax, acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] + (float)gb[0]);
 #else
-        unsigned wb[2] = {0u, 0u};
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float4 bz = j ? bz1 : bz0;
+            unsigned wb[2] = {0u, 0u};
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                o = make_float4(o.x * inv_a * inv_b, o.y * inv_a * inv_b, o.z * inv_a * inv_b, o.w * inv_a * inv_b);
-                o = make_float4(o.x + bz.x, o.y + bz.y, o.z + bz.z, o.w + bz.w);
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 a1 = EPI >= 1 ? ci[i][j] : z4, a2 = EPI >= 2 ? c2[i][j] : z4;
-                o = make_float4(o.x + a1.x, o.y + a1.y, o.z + a1.z, o.w + a1.w);
-                o = make_float4(o.x + a2.x, o.y + a2.y, o.z + a2.z, o.w + a2.w);
-                if (p.relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
-                if constexpr (GB) {
-                    const unsigned nib = gb[i] >> (j * 16 + g * 4);
-                    o = make_float4((nib & 1u) ? o.x : 0.f, (nib & 2u) ? o.y : 0.f, (nib & 4u) ? o.z : 0.f, (nib & 8u) ? o.w : 0.f);
-                }
-                if (p.gbits_out) {
-                    const unsigned pos = (o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u);
-                    wb[i] |= pos << (j * 16 + g * 4);
-                }
-                if (mok[i]) {
-                    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-                    *reinterpret_cast<float4*>(p.c + mrow[i] * p.ldc + nq + 16 * j) = o;
-                }
-            }
-        }
-        if (p.gbits_out) {           // (uniform) the four lane groups of a row hold disjoint nibbles of its 32 bits
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                unsigned w32 = wb[i];
-                w32 |= __shfl_xor(w32, 16);
-                w32 |= __shfl_xor(w32, 32);
-                if (g == 0 && mok[i]) *reinterpret_cast<unsigned*>(p.gbits_out + mrow[i] * p.ldgbits_out + (n0 >> 3)) = w32;
+                for (int j = 0; j < 2; ++j) {
+                    const float4 bz = j ? bz1 : bz0;
+                    float4 o = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    o = make_float4(o.x * inv_a * inv_b, o.y * inv_a * inv_b, o.z * inv_a * inv_b, o.w * inv_a * inv_b);
+                    o = make_float4(o.x + bz.x, o.y + bz.y, o.z + bz.z, o.w + bz.w);
+                    if constexpr (EPI >= 1) o = make_float4(o.x + ci[i][j].x, o.y + ci[i][j].y, o.z + ci[i][j].z, o.w + ci[i][j].w);
+                    if constexpr (RELU) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+                    if constexpr (GB) {
+                        const unsigned nib = gb[i] >> (j * 16 + g * 4);
+                        o = make_float4((nib & 1u) ? o.x : 0.f, (nib & 2u) ? o.y : 0.f, (nib & 4u) ? o.z : 0.f, (nib & 8u) ? o.w : 0.f);
+                    }
+                    if constexpr (BOUT) {
+                        const unsigned pos = (o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u);
+                        wb[i] |= pos << (j * 16 + g * 4);
+                    }
+                    if (mok[i]) {
+                        omax = __builtin_fmaxf(__builtin_fmaxf(omax, __builtin_fmaxf(fabsf(o.x), fabsf(o.y))), __builtin_fmaxf(fabsf(o.z), fabsf(o.w)));
+                        *reinterpret_cast<float4*>(crow[i] + 16 * j) = o;
+                    }
+                }
             }
-        }
+            if constexpr (BOUT) {       // the four lane groups of a row hold disjoint nibbles of its 32 bits
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    unsigned w32 = wb[i];
+                    w32 |= __shfl_xor(w32, 16);
+                    w32 |= __shfl_xor(w32, 32);
+                    if (g == 0 && mok[i])
+                        *reinterpret_cast<unsigned*>(p.gbits_out + (int64_t)min(m_tile + i * 16 + r16, r1 - 1) * p.ldgbits_out + (n0 >> 3)) = w32;
+                }
+            }
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
         G3_T(5);
-        if (epi_first) {
-            convert(tc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_s_setprio(0);
     };
 
-    // The two waves of a SIMD (w and w + 4) run half a tile apart: while one is in its MFMA phase the other converts and
-    // stores — "early" waves compute tile t, then convert tile t + 1 and store tile t; "late" waves convert tile t + 1 and
-    // store tile t - 1 first, then compute tile t (their accumulators live across the barrier).  One barrier per tile: it
-    // publishes plane image t + 1 (written in both halves of iteration t) and retires plane image t.
-    const bool late = WS_LATE_LOW ? wave < 4 : wave >= 4;
+    // Every wave: convert tile t + 1 and store tile t - 1 (accumulators live across the barrier), refill the rows just consumed,
+    // then the MFMA phase of tile t.  One barrier per tile: it publishes plane image t + 1 and retires plane image t.
+    // (Measured and rejected: the two waves of a SIMD half a tile apart — one in its MFMA phase while the other converts and
+    // stores.  A wave that streams MFMAs leaves its SIMD partner almost no issue slots, whatever s_setprio says: the partner's
+    // convert took 2 400 cycles instead of 570 and the pair's phases added up; N = 1024: 100 / 112 us against 86 / 100 in
+    // this order.)
     for (int t = 0; t < ntile; ++t) {
-        if (!late) {
-            compute(t);
-            __builtin_amdgcn_sched_barrier(0);
-            G3_T(2);
-            middle(t + 1, t, false);
-            dma_rows(t + 3);             // into the rows this wave has just converted (after every load the compiler knows of)
-        } else {
-            middle(t + 1, t - 1, WS_EPI_FIRST);
-            dma_rows(t + 3);
-            __builtin_amdgcn_sched_barrier(0);
-            compute(t);
-            __builtin_amdgcn_sched_barrier(0);
-            G3_T(2);
-        }
+        middle(t + 1, t - 1);
+        dma_rows(t + 3);                 // into the rows this wave has just converted (after every load the compiler knows of)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t);
+        __builtin_amdgcn_sched_barrier(0);
+        G3_T(2);
         ws_barrier();                    // plane image t + 1 complete; plane image t free for the convert of tile t + 2
         G3_T(6);
     }
-    if (late) middle(ntile + 1, ntile - 1, false);
+    middle(ntile + 1, ntile - 1);
 #ifdef G3_TIMING
 #ifndef WS_TIME_WAVE
 #define WS_TIME_WAVE 0
 #endif
-    if (tid == WS_TIME_WAVE * 64) {
+    if (tid == WS_TIME_WAVE * 64 && !WS_TIME_PROLOGUE) {
         for (int i = 0; i < 7; ++i) atomicAdd(&g3_dbg[i], tacc[i]);
         atomicAdd(&g3_dbg[7], (unsigned long long)ntile);
     }

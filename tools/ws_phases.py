@@ -26,6 +26,7 @@ fn = lib.mpf_gemm3_debug_read
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 M = 43008
+_lib.set_option("gemm3_ws", 256)
 for N, cinf in ((256, False), (256, True), (1024, False)):
     a = torch.randn(M, 256, device=dev)
     w = torch.randn(N, 256, device=dev) / 16
