@@ -93,21 +93,14 @@ class TrainModel(torch.nn.Module):
     # were created last, so autograd runs all of them before the first backbone node), "res3" = res5 and res4 are done too
     grad_ready_hooks = None
 
-    # mp_former_amd.graphs.GraphedTrunk (backbone + pixel decoder as HIP graphs) or None = every launch issued eagerly
-    trunk = None
-
     def forward(self, images, targets):
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            pd_out = None
-            if self.trunk is not None and torch.is_grad_enabled():
-                feats, pd_out = self.trunk(images)
-            else:
-                feats = self.backbone(images.contiguous(memory_format=torch.channels_last))
+            feats = self.backbone(images.contiguous(memory_format=torch.channels_last))
             if self.grad_ready_hooks and torch.is_grad_enabled():
                 for name, cb in self.grad_ready_hooks.items():
                     if feats[name].requires_grad:
                         feats[name].register_hook(lambda g, cb=cb: cb())     # (returns None: the gradient is unchanged)
-            return self.head.total_loss(feats, targets, pd_out)
+            return self.head.total_loss(feats, targets)
 
 
 # BASELINE.json configs as head-only workloads (--workload X --head-only): the segmentation head on synthetic backbone features
@@ -127,7 +120,6 @@ class HeadOnlyModel(torch.nn.Module):
     """pixel decoder + MP decoder + criterion on a dict of backbone feature maps (bf16 channel-last planes, what a bf16 backbone
     hands over under autocast); the features require gradients, so the backward does everything the full step's head does."""
     grad_ready_hooks = None
-    trunk = None
 
     def __init__(self, wl):
         super().__init__()
@@ -276,11 +268,6 @@ def main():
                          "'trained' = that pattern + N(0, 3 px) noise written into the biases and N(0, 0.02) weights (per-query scatter), "
                          "the regime of a mid-training step")
     ap.add_argument("--trained-steps", type=int, default=10, help="timed steps of the trained-offsets second number (0 = skip)")
-    ap.add_argument("--graphs", type=int, default=int(os.environ.get("MPF_GRAPHS", "0")),
-                    help="1: backbone + pixel decoder (fixed shapes) replayed as HIP graphs (mp_former_amd/graphs.py); 0 (default): every "
-                         "launch eager.  Measured on MI355X / ROCm 7.2 (round 4): the replays take the launch thread from 21.6 to ~8 ms per "
-                         "step but cost the GPU 4-7 us per graph node (dependent dispatches inside a replay) = +2.5 ms over the ~850 "
-                         "captured launches: 23.8 -> 26.3 ms/step while the eager step is GPU-bound")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="B",
                     help="BASELINE.json configuration (B = the metric's; C, D, E need --head-only: their backbones are outside the path)")
     ap.add_argument("--head-only", action="store_true",
@@ -310,8 +297,7 @@ def main():
     _miopen.use_shipped_find_db(check_version=True)      # tuned MIOpen solver choice (private copy; logs a version mismatch)
 
     from mp_former_amd import dropin
-    one_thread = os.environ.get("MPF_AUTOGRAD_ONE_THREAD", "1") == "1"
-    dropin.configure_training_process(single_thread_autograd=one_thread)    # backward on the launch thread (A/B switch: 0)
+    dropin.configure_training_process(single_thread_autograd=True)          # backward on the launch thread (one device per process)
 
     torch.manual_seed(rank)
     if os.environ.get("MPF_CONV_FIND", "0") == "1":      # let MIOpen time its solvers per conv shape (slow warm-up)
@@ -355,22 +341,6 @@ def main():
             batches.append((synth_features(a.batch, hw, model.shapes, 1000 * rank + i, dev), synth_targets(a.batch, hw, wl["classes"], g_, dev)))
     else:
         batches = [synth_batch(a.batch, a.size, 80, 1000 * rank + i, dev) for i in range(4)]
-    # the static part of the step (backbone + pixel decoder: fixed shapes at the fixed crop) as HIP graphs: three replays
-    # forward, three backward per step instead of ~850 launches.  Captured in-process before the warm-up; a failed capture
-    # falls back to the eager path and says so in the JSON line.
-    graphs_note = "off (--graphs 0: measured slower on ROCm 7.2 — 4-7 us of GPU time per replayed node; DESIGN.md section 5)"
-    trunk = None
-    if a.graphs and not a.head_only:
-        try:
-            from mp_former_amd.graphs import GraphedTrunk
-            trunk = GraphedTrunk(model.backbone, model.head.pixel_decoder, batches[0][0], pieces=os.environ.get("MPF_GRAPH_PIECES", "abc"))
-            graphs_note = "backbone (2 pieces) + pixel decoder: forward and backward replayed (torch.cuda.make_graphed_callables)"
-        except Exception as e:                                  # noqa: BLE001 — any capture failure: run eagerly, report it
-            graphs_note = f"capture failed, eager: {type(e).__name__}: {str(e)[:200]}"
-            trunk = None
-            torch.cuda.synchronize()
-    model.trunk = trunk
-
     def step(i):
         images, targets = batches[i % len(batches)]
         opt.zero_grad(set_to_none=True)
@@ -401,12 +371,10 @@ def main():
     # ---- roofline block: a few MORE steps with the in-library launch log on (HIP events recorded on the launch stream
     # around every native kernel; outside the timed region, so the headline does not pay for the event records) --------
     P = a.profile_steps
-    model.trunk = None                       # the launch log records nothing inside a graph replay: these steps run eagerly
     _lib.profile_enable(True)
     for i in range(P):
         step(a.warmup + a.steps + i)
     barrier()
-    model.trunk = trunk
 
     def prof(name):
         n, ms, by = _lib.profile_get(name)
@@ -555,8 +523,8 @@ def main():
             "config": {"workload": workload, "baseline_config": a.workload, "head_only": bool(a.head_only),
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "tokens_per_image_S": S_tok, "final_loss": round(final_loss, 4),
-                       "roofline_steps": P, "msda_offsets": a.msda_offsets, "hip_graphs": graphs_note,
-                       "autograd_threads": "backward on the launch thread" if one_thread else "engine device thread (torch default)",
+                       "roofline_steps": P, "msda_offsets": a.msda_offsets,
+                       "autograd_threads": "backward on the launch thread",
                        "process_group": pg_info},
             # the time-dominant native kernel family: the fp32 GEMMs of the pixel decoder as SIX bf16 MFMA products per fp32
             # product (three 8-bit-mantissa planes per operand, terms >= 2^-16 kept).  achieved = bf16 MFMA flops actually

@@ -350,8 +350,7 @@ class ResNet50(nn.Module):
         return self.forward_stages(x, self.stage_names, stem=True)
 
     def forward_stages(self, x, names, stem=False):
-        """The stem (optional) and the named consecutive stages: {name: feature map}.  forward() is the whole chain; the
-        HIP-graph trunk (mp_former_amd/graphs.py) captures it in two pieces so that the gradient exchange can start between them."""
+        """The stem (optional) and the named consecutive stages: {name: feature map}.  forward() is the whole chain."""
         return run_stages(x, [(n, getattr(self, n)) for n in names], (self.stem_conv, self.stem_norm) if stem else None)
 
 

@@ -10,30 +10,26 @@
 // streams one 16-byte entry per (sample, pixel row) through HBM.  Both ran at L2-gather / issue rates:
 // 0.16 and 0.044 of the HBM roofline (profiles/r01r_*).  Here:
 //
-//   forward / "push" (grad_attn, grad_loc):  a workgroup owns ONE head x a 2-D block of 8x8 spatially
-//     adjacent queries (queries of the pixel decoder ARE the pixels of the levels).  Per level it
-//     decodes its 256 samples (one per thread), reduces their bounding box, and — if the box fits the
-//     LDS budget, which it does whenever the offsets are a few pixels — stages the box's value rows
-//     ONCE with direct global->LDS loads (1 KB per wave instruction) and samples from LDS
-//     (ds_read_b128, 8 lanes x 16 B per row, 8 rows per wave instruction).  A level whose box does not
-//     fit (coarse queries looking into the finest map, adversarial offsets) takes buffer-load gathers
-//     from L2 exactly like the first generation — a per-(workgroup, level) uniform decision, no
-//     per-sample divergence.  Corners outside the image read a zero row (LDS) / an out-of-range buffer
-//     offset (global): no branches, no masking.
+//   forward:  a workgroup owns ONE head x a 2-D block of 8x8 spatially adjacent queries (queries of the pixel decoder ARE
+//     the pixels of the levels).  Per level it decodes its 256 samples (one per thread), reduces their bounding box, and —
+//     if the box fits the LDS budget, which it does whenever the offsets are a few pixels — stages the box's value rows
+//     ONCE with direct global->LDS loads (1 KB per wave instruction) and samples from LDS (ds_read_b128, 8 lanes x 16 B
+//     per row, 8 rows per wave instruction).  A level whose box does not fit (coarse queries looking into the finest map,
+//     adversarial offsets) takes buffer-load gathers from L2 exactly like the first generation — a per-(workgroup, level)
+//     uniform decision, no per-sample divergence.  Corners outside the image read a zero row (LDS) / an out-of-range
+//     buffer offset (global): no branches, no masking.
 //
-//   grad_value:  the scatter-add is re-stated as a tiny dense product per destination tile.  A tile is
-//     4x4 pixels of one (image, head, level).  For the samples s whose 2x2 footprint touches the tile,
+//   backward ("bin" + "tile", round 4; the query-centric push + pull pair of rounds 2-3 was deleted in round 5 — HISTORY.md):
+//     the scatter-add is re-stated as a tiny dense product per destination tile.  A tile is 4x4 pixels of one (image, head,
+//     level).  For the samples s whose 2x2 footprint touches the tile,
 //         grad_value[pixel, :] = sum_s  hat(px - x_s) * hat(py - y_s) * a_s  *  grad_out[q_s, :]
-//     with hat(t) = max(0, 1 - |t|) — the bilinear weight of ANY pixel in closed form (zero outside the
-//     footprint, so no corner bookkeeping and the image border needs no special case).  That is
-//     D[16 px x 32 ch] += A[16 px x 4 samples] * B[4 samples x 32 ch] on v_mfma_f32_16x16x4_f32
-//     (exact fp32 FMA chain, cdna_hip_programming.md §3): each lane computes its A element in ~8 VALU
-//     ops, B is a plain 8-byte load from the sample's grad_out row, accumulators stay in registers —
-//     no LDS accumulators, no atomics, no read-modify-write ordering, every grad_value element is
-//     written once.  The lists "samples per tile" are 4-byte entries (query, point) appended by the
-//     push kernel into fixed-capacity per-tile runs (one returning integer add per (workgroup, tile));
-//     run overflow goes to a spill list that a small atomic kernel applies afterwards (never taken
-//     with pixel-decoder-like offsets; exercised by the tests).
+//     with hat(t) = max(0, 1 - |t|) — the bilinear weight of ANY pixel in closed form (zero outside the footprint, so no
+//     corner bookkeeping and the image border needs no special case).  That is D[16 px x 32 ch] += A[16 px x 4 samples] *
+//     B[4 samples x 32 ch] on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, cdna_hip_programming.md §3): accumulators stay
+//     in registers — no LDS accumulators, no atomics, every grad_value element is written once.  The lists "samples per tile"
+//     are 4-byte entries (query, point) appended by the bin kernel into fixed-capacity per-tile runs (one returning integer
+//     add per (workgroup, tile)); run overflow goes to a spill list that a small atomic kernel applies afterwards (never
+//     taken with pixel-decoder-like offsets; exercised by the tests).  See the section comment above msda_bwd_bin_kernel.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 
@@ -50,7 +46,6 @@ constexpr int kD = 32;
 constexpr int kP = 4;
 constexpr int kMaxL = 4;          // templated level counts 1..4
 constexpr int kMaxBand = 16;      // horizontal bands of the pull kernel's workgroup order
-constexpr int kQB = 64;           // queries per workgroup (8 x 8 block, or 64 consecutive queries)
 constexpr int kSlots = 256;       // LDS hash slots of the push kernel (distinct destination tiles per workgroup)
 constexpr unsigned kEmpty = 0xFFFFFFFFu;
 constexpr int kOobOff = (int)0x80000000u;
@@ -435,562 +430,14 @@ __device__ __forceinline__ int hash_slot(unsigned* keys, unsigned key)
     return -1;
 }
 
-// LDS of the push kernel:
-//   [0, 64)   bounding boxes   [128, 272) the zero row   [512, 9728) grad_out rows of the 64 queries (pitch 144 B)
-//   [9728, 12864)  tile tables (hash keys, counters + dummy, run bases)
-//   [12864, 12864 + cap * 128)  value rows of the current level's box, filled by DMA (16-byte pieces XOR-swizzled, see swz16)
-// Thread = one sample per level, (query tid >> 2, point tid & 3): the thread that decodes a sample also reduces it — it
-// walks the 32 channels of its four corner rows and of its query's grad_out row with 16-byte LDS reads, so grad_attn /
-// grad_loc need no cross-lane reduction and no descriptor round trip through LDS.  Lanes of a 16-lane LDS service group
-// read the SAME piece of DIFFERENT rows: the grad_out rows sit at a 144-B pitch, the box rows (which arrive by DMA and
-// cannot be padded) have their pieces swizzled by the row index, so in both images rows collide only when their indices
-// agree mod 16.
-// Round 3: the boxes go global -> LDS by DMA (like the forward) instead of through 28 staging registers that were kept
-// alive across a level's reduction to overlap the next box's fetch: 155 -> 122 VGPRs and 40.8 -> 40.5 KB of LDS, i.e. FOUR
-// resident workgroups per CU instead of three.  The kernel is bound by the length of a workgroup's dependent chain at low
-// occupancy (tools/experiments/README.md: 102 of its 156 us remain with every byte and flop ablated), so the fourth
-// workgroup buys more than the now exposed round trip per level costs: 157 -> 142 us (N(0, 3 px) offsets: 284 -> 260).
-// The returning adds that reserve the entry runs are consumed at the very end so that their latency hides behind the levels.
-constexpr int kPitch = 144, kPOffZero = 128, kPOffG = 512, kPOffTab = kPOffG + kQB * kPitch;
-// tile tables (keys, counts + dummy, run bases) have their own 3 KB: the first box lands in LDS by DMA while they are in use
-constexpr int kPOffReg = kPOffTab + (3 * kSlots + 16) * 4;
-// value rows of a box: 128 B each (no padding — they arrive by DMA); the eight 16-byte pieces of LDS row r are stored at
-// slot (piece ^ ((r >> 1) & 7)): the swizzle is applied on the SOURCE side of the DMA (lane -> which global piece it fetches),
-// and the per-lane row reads of the reduction (same piece, different rows) collide only for rows equal mod 16
+// value rows in LDS (the tile kernel's grad_out rows): 128 B each (no padding — they arrive by DMA); the eight 16-byte pieces of LDS
+// row r are stored at slot (piece ^ ((r >> 1) & 7)): the swizzle is applied on the SOURCE side of the DMA, and per-lane row reads
+// (same piece, different rows) collide only for rows equal mod 16
 __device__ __forceinline__ int swz16(int r) { return ((r >> 1) & 7) << 4; }
 
-template <int NL>
-__global__ __launch_bounds__(kT) void msda_bwd_push_block_kernel(
-    const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn,
-    const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
-    float* __restrict__ grad_raw, int* __restrict__ tile_count, unsigned* __restrict__ entries,
-    int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB g, int nblocks, int region_cap, unsigned value_bytes, int ablate, unsigned long long* __restrict__ dbg,
-    unsigned* __restrict__ stats)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* s_bb = reinterpret_cast<int*>(smem);
-    constexpr int LP = NL * kP;
-    unsigned* s_keys = reinterpret_cast<unsigned*>(smem + kPOffTab);                 // [kSlots]
-    int* s_cnt = reinterpret_cast<int*>(s_keys + kSlots);                            // [kSlots + 1]: the last one is the dummy
-    int* s_base = s_cnt + kSlots + 8;                                                // [kSlots]
-
-    const int blk = xcd_index(nblocks);
-    if (blk >= nblocks) return;
-    int stamp_i = 0;
-    auto stamp = [&]() {
-        if (dbg && threadIdx.x == 0) dbg[(size_t)blk * 16 + stamp_i] = __builtin_amdgcn_s_memtime();
-        ++stamp_i;
-    };
-    stamp();
-    BlockCtx c;
-    block_of(g, blk, c);
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < kMaxL * 4) s_bb[tid] = (tid & 2) ? INT_MIN : INT_MAX;
-    if (tid >= 64 && tid < 64 + kPitch / 4) reinterpret_cast<float*>(smem + kPOffZero)[tid - 64] = 0.f;
-    s_keys[tid] = kEmpty; s_cnt[tid] = 0;                      // kSlots == kT
-    if (tid == 0) s_cnt[kSlots] = 0;
-
-    const int qi_d = tid >> 2, p_d = tid & 3;
-    const int q_d = query_of(g, c, qi_d);
-    float2 xy[NL];
-    float at[NL];
-    {
-        const int64_t gi0 = ((int64_t)(c.b * g.Lq + max(q_d, 0)) * g.M + c.m) * LP + p_d;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            if (ablate & 16) {
-                xy[l] = make_float2(((float)(tid & 7) + 0.5f + p_d) / (float)g.W[l] + 0.3f, (tid >> 5) / (float)g.H[l] + 0.4f);
-                at[l] = 0.08f;
-            } else {
-                xy[l] = reinterpret_cast<const float2*>(loc)[gi0 + l * kP];
-                at[l] = attn[gi0 + l * kP];
-            }
-        }
-    }
-    // grad_out rows of the block's queries: 512 pieces, two per thread
-    f4v gst0, gst1;
-    {
-        const int q0 = max(query_of(g, c, tid >> 3), 0), q1 = max(query_of(g, c, (tid + kT) >> 3), 0);
-        gst0 = *reinterpret_cast<const f4v*>(grad_out + ((int64_t)(c.b * g.Lq + q0) * g.M + c.m) * kD + (tid & 7) * 4);
-        gst1 = *reinterpret_cast<const f4v*>(grad_out + ((int64_t)(c.b * g.Lq + q1) * g.M + c.m) * kD + (tid & 7) * 4);
-    }
-    stamp();     // 1: prologue + loads issued
-    __syncthreads();
-    stamp();     // 2: first barrier (loads of loc / attn not yet awaited)
-    // grad_out rows -> LDS (their loads went out together with loc / attn)
-    *reinterpret_cast<f4v*>(smem + kPOffG + (tid >> 3) * kPitch + (tid & 7) * 16) = gst0;
-    *reinterpret_cast<f4v*>(smem + kPOffG + ((tid + kT) >> 3) * kPitch + (tid & 7) * 16) = gst1;
-    const int bm = c.b * g.M + c.m;
-    int x0[NL], y0[NL];
-    float lx[NL], ly[NL];
-    unsigned in_mask = 0;
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        const Dec d = decode(xy[l], g.H[l], g.W[l], q_d >= 0);
-        x0[l] = d.x0; y0[l] = d.y0; lx[l] = d.lx; ly[l] = d.ly;
-        in_mask |= d.in ? (1u << l) : 0u;
-        const int H = g.H[l], W = g.W[l];
-        const int xa = d.in ? max(d.x0, 0) : INT_MAX, ya = d.in ? max(d.y0, 0) : INT_MAX;
-        const int xb = d.in ? min(d.x0 + 1, W - 1) : INT_MIN, yb = d.in ? min(d.y0 + 1, H - 1) : INT_MIN;
-        const int x_lo = wave_min(xa), y_lo = wave_min(ya), x_hi = wave_max(xb), y_hi = wave_max(yb);
-        if (lane == 0) {
-            atomicMin(&s_bb[l * 4 + 0], x_lo); atomicMin(&s_bb[l * 4 + 1], y_lo);
-            atomicMax(&s_bb[l * 4 + 2], x_hi); atomicMax(&s_bb[l * 4 + 3], y_hi);
-        }
-    }
-    __syncthreads();
-
-    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(value), 0, value_bytes, 0x00020000);
-    auto box = [&](int l, int& xmin, int& ymin, int& rw, int& rows, bool& lds_path) {
-        xmin = s_bb[l * 4 + 0]; ymin = s_bb[l * 4 + 1];
-        const int xmax = s_bb[l * 4 + 2], ymax = s_bb[l * 4 + 3];
-        rw = xmax - xmin + 1;
-        rows = xmax >= xmin ? rw * (ymax - ymin + 1) : 0;
-        lds_path = rows <= region_cap;
-    };
-    // box of level l -> LDS by DMA: a wave instruction moves 8 rows; lane (row, slot) fetches global piece slot ^ swizzle(row)
-    auto fetch = [&](int l) {
-        int xmin, ymin, rw, rows;
-        bool lds_path;
-        box(l, xmin, ymin, rw, rows, lds_path);
-        if (!lds_path || (ablate & 4)) rows = 0;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const float inv_rw = 1.0f / (float)max(rw, 1);
-        const int nchunk = (rows + 31) >> 5;
-        const int W = g.W[l];
-        const float* base = value + ((int64_t)(c.b * g.S + g.start[l]) * g.M + c.m) * kD;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int rr = ch * 32 + wave * 8 + (lane >> 3);             // LDS row of this lane
-            const int r = min(rr, rows - 1);
-            const int ry = (int)(((float)r + 0.5f) * inv_rw), rx = r - ry * rw;
-            const int piece = (lane & 7) ^ ((rr >> 1) & 7);
-            const float* src = base + (int64_t)((ymin + ry) * W + (xmin + rx)) * (g.M * kD) + piece * 4;
-            unsigned char* dst = smem + kPOffReg + (ch * 32 + wave * 8) * 128;
-            if (rr < region_cap)          // (the buffer holds region_cap rows, not whole 32-row passes)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-    stamp();     // 3: decode + box reduction (waited for loc/attn/g)
-    fetch(0);
-    stamp();     // 4: first box requested
-
-    // ---- destination tiles of every sample: one LDS counter per tile -------------------------------------------------
-    // per level up to 4 tiles; tpk = (slot << 16 | index in the workgroup's run), -1 = no entry.  The tiles under the
-    // workgroup's boxes are enumerated directly (slot = level offset + position inside the box's tile grid): every sample
-    // issues its four counter adds unconditionally (absent tiles add 0 to a dummy slot), i.e. back to back instead of one
-    // dependent LDS round trip per branch.  Only when the boxes cover more than kSlots tiles (scattered samples) does the
-    // compare-and-swap hash take over; a full hash takes the position from the tile's global counter.
-    int tpk[NL][4];
-    int tbx[NL], tby[NL], tbw[NL], tof[NL + 1];
-    tof[0] = 0;
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        const int xmin = s_bb[l * 4 + 0], ymin = s_bb[l * 4 + 1], xmax = s_bb[l * 4 + 2], ymax = s_bb[l * 4 + 3];
-        const bool any = xmax >= xmin;
-        tbx[l] = xmin >> 2; tby[l] = ymin >> 2;
-        tbw[l] = any ? (xmax >> 2) - tbx[l] + 1 : 0;
-        tof[l + 1] = tof[l] + (any ? tbw[l] * ((ymax >> 2) - tby[l] + 1) : 0);
-    }
-    const bool direct = tof[NL] <= kSlots;             // workgroup-uniform
-    if (stats && tid == 0) atomicAdd(&stats[direct ? 4 : 5], 1u);
-    int* s_cnt1 = s_cnt;                               // [kSlots + 1]: the last one is the dummy
-    if (direct) {
-        int ret[NL][4];
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const bool in = (in_mask >> l) & 1;
-            const int H = g.H[l], W = g.W[l];
-            const int txa = max(x0[l], 0) >> 2, txb = min(x0[l] + 1, W - 1) >> 2, tya = max(y0[l], 0) >> 2, tyb = min(y0[l] + 1, H - 1) >> 2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ty = (e >> 1) ? tyb : tya, tx = (e & 1) ? txb : txa;
-                const bool act = in && !((e & 1) && txb == txa) && !((e >> 1) && tyb == tya) && !(ablate & 1);
-                const int slot = act ? tof[l] + (ty - tby[l]) * tbw[l] + (tx - tbx[l]) : kSlots;
-                tpk[l][e] = act ? slot : -1;
-                ret[l][e] = atomicAdd(&s_cnt1[slot], act ? 1 : 0);
-            }
-        }
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tpk[l][e] = tpk[l][e] >= 0 ? ((tpk[l][e] << 16) | ret[l][e]) : -1;
-    } else {
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const bool in = (in_mask >> l) & 1;
-            const int H = g.H[l], W = g.W[l];
-            const int txa = max(x0[l], 0) >> 2, txb = min(x0[l] + 1, W - 1) >> 2, tya = max(y0[l], 0) >> 2, tyb = min(y0[l] + 1, H - 1) >> 2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ty = (e >> 1) ? tyb : tya, tx = (e & 1) ? txb : txa;
-                const bool act = in && !((e & 1) && txb == txa) && !((e >> 1) && tyb == tya) && !(ablate & 1);
-                tpk[l][e] = -1;
-                if (act) {
-                    const int key = bm * g.tiles_per_bm + g.tile_base[l] + ty * g.ntx[l] + tx;
-                    const int slot = hash_slot(s_keys, (unsigned)key);
-                    if (slot >= 0) {
-                        tpk[l][e] = (slot << 16) | atomicAdd(&s_cnt[slot], 1);
-                    } else {
-                        // table full: position straight from the tile's global counter, entry written now
-                        const int pos = atomicAdd(&tile_count[key], 1);
-                        const unsigned ent = ((unsigned)q_d << 2) | (unsigned)p_d;
-                        if (pos < g.cap[l]) {
-                            entries[(int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)(ty * g.ntx[l] + tx) * g.cap[l] + pos] = ent;
-                        } else {
-                            const int k = atomicAdd(ovf_count, 1);
-                            ovf[k] = make_uint2((unsigned)key, ent);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    stamp();     // 5: tile counting
-    __syncthreads();
-    // one returning add per touched tile reserves the workgroup's run; the result is needed only at the very end
-    int my_base = 0;
-    {
-        unsigned key = s_keys[tid];
-        if (direct) {
-            // slot -> tile: level by offset, then row / column inside the box's tile grid
-            int l = 0;
-#pragma unroll
-            for (int k = 1; k < NL; ++k) l = tid >= tof[k] ? k : l;
-            int bx_ = tbx[0], by_ = tby[0], bw_ = tbw[0], of_ = 0, tb_ = g.tile_base[0], nt_ = g.ntx[0];
-#pragma unroll
-            for (int k = 1; k < NL; ++k)
-                if (l == k) { bx_ = tbx[k]; by_ = tby[k]; bw_ = tbw[k]; of_ = tof[k]; tb_ = g.tile_base[k]; nt_ = g.ntx[k]; }
-            const int rel = tid - of_, ry = rel / max(bw_, 1), rx = rel - ry * bw_;
-            key = tid < tof[NL] && s_cnt[tid] > 0 ? (unsigned)(bm * g.tiles_per_bm + tb_ + (by_ + ry) * nt_ + bx_ + rx) : kEmpty;
-        }
-        if (key != kEmpty) my_base = atomicAdd(&tile_count[key], s_cnt[tid]);
-    }
-    __syncthreads();
-    stamp();     // 6: reservation issued
-    // the first box (requested before the tile counting) has landed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    stamp();     // 7: first box in LDS
-
-    const int g_base = kPOffG + qi_d * kPitch;
-    float ra[NL], rx[NL], ry[NL];
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        int xmin, ymin, rw, rows;
-        bool lds_path;
-        box(l, xmin, ymin, rw, rows, lds_path);
-        if (stats && tid == 0 && rows > 0) atomicAdd(&stats[lds_path ? 2 : 3], 1u);
-        const bool in = (in_mask >> l) & 1;
-        const int H = g.H[l], W = g.W[l];
-        const bool y0v = in && y0[l] >= 0, y1v = in && y0[l] + 1 <= H - 1, x0v = in && x0[l] >= 0, x1v = in && x0[l] + 1 <= W - 1;
-        f2v t0 = {0.f, 0.f}, t1 = {0.f, 0.f}, t2 = {0.f, 0.f}, t3 = {0.f, 0.f};
-        if (ablate & 2) {
-        } else if (lds_path) {
-            const int r0 = (y0[l] - ymin) * rw + (x0[l] - xmin);
-            const int o0 = (y0v && x0v) ? kPOffReg + r0 * 128 : kPOffZero, o1 = (y0v && x1v) ? kPOffReg + (r0 + 1) * 128 : kPOffZero;
-            const int o2 = (y1v && x0v) ? kPOffReg + (r0 + rw) * 128 : kPOffZero, o3 = (y1v && x1v) ? kPOffReg + (r0 + rw + 1) * 128 : kPOffZero;
-            const int s0 = swz16(r0), s1 = swz16(r0 + 1), s2 = swz16(r0 + rw), s3 = swz16(r0 + rw + 1);    // (zero row: any piece is zero)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const f4v gk = *reinterpret_cast<const f4v*>(smem + g_base + k * 16);
-                const f4v v0 = *reinterpret_cast<const f4v*>(smem + o0 + ((k * 16) ^ s0));
-                const f4v v1 = *reinterpret_cast<const f4v*>(smem + o1 + ((k * 16) ^ s1));
-                const f4v v2 = *reinterpret_cast<const f4v*>(smem + o2 + ((k * 16) ^ s2));
-                const f4v v3 = *reinterpret_cast<const f4v*>(smem + o3 + ((k * 16) ^ s3));
-                t0 = __builtin_elementwise_fma(gk.xy, v0.xy, t0); t0 = __builtin_elementwise_fma(gk.zw, v0.zw, t0);
-                t1 = __builtin_elementwise_fma(gk.xy, v1.xy, t1); t1 = __builtin_elementwise_fma(gk.zw, v1.zw, t1);
-                t2 = __builtin_elementwise_fma(gk.xy, v2.xy, t2); t2 = __builtin_elementwise_fma(gk.zw, v2.zw, t2);
-                t3 = __builtin_elementwise_fma(gk.xy, v3.xy, t3); t3 = __builtin_elementwise_fma(gk.zw, v3.zw, t3);
-                if (k & 1) __builtin_amdgcn_sched_barrier(0);      // 10 row pieces in flight per lane, not 40
-            }
-        } else {
-            // box too large for LDS: the four corner rows come from L2, out-of-image corners read 0 through the bounds check
-            const int sx = g.M * 128, sy = W * sx;
-            const int base = ((c.b * g.S + g.start[l]) * g.M + c.m) * 128 + y0[l] * sy + x0[l] * sx;
-            const int o0 = (y0v && x0v) ? base : kOobOff, o1 = (y0v && x1v) ? base + sx : kOobOff;
-            const int o2 = (y1v && x0v) ? base + sy : kOobOff, o3 = (y1v && x1v) ? base + sy + sx : kOobOff;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const f4v gk = *reinterpret_cast<const f4v*>(smem + g_base + k * 16);
-                const float4 a0 = buf_row(vrs, o0 + k * 16), a1 = buf_row(vrs, o1 + k * 16);
-                const float4 a2 = buf_row(vrs, o2 + k * 16), a3 = buf_row(vrs, o3 + k * 16);
-                const f4v v0 = {a0.x, a0.y, a0.z, a0.w}, v1 = {a1.x, a1.y, a1.z, a1.w};
-                const f4v v2 = {a2.x, a2.y, a2.z, a2.w}, v3 = {a3.x, a3.y, a3.z, a3.w};
-                t0 = __builtin_elementwise_fma(gk.xy, v0.xy, t0); t0 = __builtin_elementwise_fma(gk.zw, v0.zw, t0);
-                t1 = __builtin_elementwise_fma(gk.xy, v1.xy, t1); t1 = __builtin_elementwise_fma(gk.zw, v1.zw, t1);
-                t2 = __builtin_elementwise_fma(gk.xy, v2.xy, t2); t2 = __builtin_elementwise_fma(gk.zw, v2.zw, t2);
-                t3 = __builtin_elementwise_fma(gk.xy, v3.xy, t3); t3 = __builtin_elementwise_fma(gk.zw, v3.zw, t3);
-                if (k & 1) __builtin_amdgcn_sched_barrier(0);      // at most 8 row loads in flight per lane (registers)
-            }
-        }
-        {
-            const float s0 = t0.x + t0.y, s1 = t1.x + t1.y, s2 = t2.x + t2.y, s3 = t3.x + t3.y;
-            const float lx_ = lx[l], ly_ = ly[l], hx = 1.f - lx_, hy = 1.f - ly_;
-            const float a = in ? at[l] : 0.f;
-            ra[l] = hy * (hx * s0 + lx_ * s1) + ly_ * (hx * s2 + lx_ * s3);
-            rx[l] = (float)W * a * (hy * (s1 - s0) + ly_ * (s3 - s2));
-            ry[l] = (float)H * a * (hx * (s2 - s0) + lx_ * (s3 - s1));
-        }
-        stamp();                                       // 8, 10, 12: level reduced
-        __syncthreads();                               // every reader is done with this box
-        if (l + 1 < NL) {
-            fetch(l + 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        stamp();                                       // 9, 11, 13: next box in LDS
-    }
-
-    // ---- entries: (query << 2 | point) appended to the run of every destination tile ----------------------------------
-    s_base[tid] = my_base;
-    __syncthreads();
-    stamp();     // 14: run bases known
-    if (q_d < 0) return;
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        const int txa = max(x0[l], 0) >> 2, txb = min(x0[l] + 1, g.W[l] - 1) >> 2;
-        const int tya = max(y0[l], 0) >> 2, tyb = min(y0[l] + 1, g.H[l] - 1) >> 2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (tpk[l][e] < 0) continue;
-            const int local = ((e >> 1) ? tyb : tya) * g.ntx[l] + ((e & 1) ? txb : txa);
-            const int pos = s_base[tpk[l][e] >> 16] + (tpk[l][e] & 0xFFFF);
-            const unsigned ent = ((unsigned)q_d << 2) | (unsigned)p_d;
-            if (pos < g.cap[l]) {
-                entries[(int64_t)bm * g.ent_per_bm + g.ent_base[l] + (int64_t)local * g.cap[l] + pos] = ent;
-            } else {
-                const int k = atomicAdd(ovf_count, 1);
-                ovf[k] = make_uint2((unsigned)(bm * g.tiles_per_bm + g.tile_base[l] + local), ent);
-            }
-        }
-    }
-
-    // ---- per-sample gradients out -------------------------------------------------------------------------
-    if ((ablate & 8) && ra[0] != 12345.f) return;
-    if (grad_raw) {
-        // module-level form: gradients wrt the raw projection outputs [M*L*P*2 offsets | M*L*P logits]:
-        //   loc = ref + off / (W_l, H_l)  =>  d off = d loc / (W_l, H_l);  attn = softmax  =>  d logit = a (dA - sum_j a_j dA_j)
-        float dot = 0.f;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) dot += at[l] * ra[l];
-        dot = dpp_addf<0xB1>(dot);            // + the other three points of the query (quad)
-        dot = dpp_addf<0x4E>(dot);
-        const int no = g.M * LP * 2, nr = g.M * LP * 3;
-        float* row = grad_raw + (int64_t)(c.b * g.Lq + q_d) * nr;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const int lp = l * kP + p_d;
-            reinterpret_cast<float2*>(row + c.m * LP * 2)[lp] = make_float2(rx[l] / (float)g.W[l], ry[l] / (float)g.H[l]);
-            row[no + c.m * LP + lp] = at[l] * (ra[l] - dot);
-        }
-        return;
-    }
-    const int64_t gi0 = ((int64_t)(c.b * g.Lq + q_d) * g.M + c.m) * LP + p_d;
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        grad_attn[gi0 + l * kP] = ra[l];
-        reinterpret_cast<float2*>(grad_loc)[gi0 + l * kP] = make_float2(rx[l], ry[l]);
-    }
-}
-
-// --------------------------------------------------------------------------------------------------
-// backward, kernel 2 ("pull"): grad_value of one 4x4-pixel tile = hat-weight matrix x grad_out rows (fp32 MFMA)
-// --------------------------------------------------------------------------------------------------
-// Work decomposition.  A unit = (tile, part): one WAVE walks every wpt-th step (4 entries) of the tile's run, so the
-// heavy tiles of the coarse levels (16x the samples of a fine tile) are split over wpt = 16 / 4 / 1 waves and every
-// wave of the launch has a similar trip count.  A workgroup is 16 waves = 16 / wpt tiles; partial tiles are summed
-// through LDS.  Workgroups are ordered (image, head) -> horizontal band of the image -> level, so the grad_out rows and
-// the loc / attn records of a band (shared by the tiles of ALL levels that cover it) are fetched from HBM once and
-// then hit in the XCD's L2; each XCD walks a contiguous range of that order.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kTP = 256;          // pull workgroup: kWP waves
+constexpr int kTP = 256;          // tile-kernel workgroup: kWP waves
 constexpr int kWP = kTP / 64;
-
-template <int NL>
-__global__ __launch_bounds__(kTP) void msda_bwd_pull_mfma_kernel(
-    const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
-    const int* __restrict__ tile_count, const unsigned* __restrict__ entries, float* __restrict__ grad_value, GeomB g, int nwg,
-    unsigned loc_bytes, unsigned go_bytes, unsigned* __restrict__ stats)
-{
-    __shared__ float s_red[kWP - 1][8][64];            // partial accumulators of the waves with part > 0
-    __shared__ float4 s_rec[kWP][64];                   // per wave: the 64 sample records of the current chunk
-    const int wg = xcd_index(nwg);
-    if (wg >= nwg) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroup -> (bm, band, level)
-    const int bm = wg / g.wg_per_bm;
-    const int r = wg - bm * g.wg_per_bm;
-    // (band, level) group of this workgroup: the lanes compare r with the group bases in parallel (a scalar loop would
-    // be one dependent kernarg load per group — thousands of cycles per wave)
-    int slot, slot_base;
-    {
-        const int nslot = g.nband * NL;
-        const int base_k = g.band_wg_base[min(lane, nslot - 1)];
-        const unsigned long long ge = __ballot(lane < nslot && r >= base_k);
-        slot = __builtin_amdgcn_readfirstlane(__popcll(ge) - 1);
-        slot_base = __builtin_amdgcn_readlane(base_k, slot);
-    }
-    const int band = slot / NL, l = slot - band * NL;
-    const int wpt = sel(g.wpt, l);
-    const int W = sel(g.W, l), H = sel(g.H, l);
-    const int nty = (H + 3) >> 2, ntx = sel(g.ntx, l);
-    const int tile_base = sel(g.tile_base, l), cap = sel(g.cap, l), ent_base = sel(g.ent_base, l), start = sel(g.start, l);
-    const int row0 = band * nty / g.nband, row1 = (band + 1) * nty / g.nband;
-    const int unit = (r - slot_base) * kWP + wave;
-    const int part = unit % wpt, tb = unit / wpt;             // tile inside the (band, level) group
-    const bool live = tb < (row1 - row0) * ntx;
-    const int ty = row0 + tb / ntx, tx = tb - (tb / ntx) * ntx;
-    const int local = ty * ntx + tx;
-    const int b = bm / g.M, m = bm - b * g.M;
-    constexpr int LP = NL * kP;
-    const int MLP = g.M * LP;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int kgrp = lane >> 4, j = lane & 15;
-    int n = 0;
-    if (live) n = min(tile_count[bm * g.tiles_per_bm + tile_base + local], cap);
-    const int nchunks = (n + 63) >> 6;
-    if (part < nchunks) {
-        // Two lane roles.  "Sample role" (once per chunk of 64 entries): lane = entry; one coalesced load of the entries,
-        // one gather of loc / attn per lane (64 samples in flight per instruction), pixel coordinates computed once per
-        // sample, the record {x, y, a, grad_out row offset} parked in LDS.  "MFMA role" (16 steps of 4 samples): lane =
-        // (pixel i = lane & 15, sample k = lane >> 4) reads its sample's record back (one 16-byte LDS read, a broadcast
-        // inside the 16-lane group), loads its 8 bytes of the sample's grad_out row and forms its hat weight.
-        const unsigned* ent = entries + (int64_t)bm * g.ent_per_bm + ent_base + (int64_t)local * cap;   // this tile's run
-        const float fpx = (float)(tx * 4 + (j & 3)), fpy = (float)(ty * 4 + (j >> 2));
-        const float fW = (float)W, fH = (float)H;
-        const __amdgpu_buffer_rsrc_t rs_ent = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(ent), 0, (unsigned)n * 4u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_loc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(loc), 0, loc_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_att = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(attn), 0, loc_bytes >> 1, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_out), 0, go_bytes, 0x00020000);
-        const int gi_base = (b * g.Lq * g.M + m) * LP + l * kP;              // sample index of (q = 0, p = 0)
-        const int so_loc = gi_base * 8, so_att = gi_base * 4;
-        const int so_go = (b * g.Lq * g.M + m) * (kD * 4);
-        const int M128 = g.M * (kD * 4);
-        // entries beyond n read as 0 through the buffer's bounds check (num_records = n * 4) — no branch around the load
-        auto load_entry = [&](int c) { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_ent, (c * 64 + lane) * 4, 0, 0); };
-        struct LA { float x, y, a; };
-        auto gather_la = [&](unsigned e) {
-            const int si = (int)(e >> 2) * MLP + (int)(e & 3);
-            const auto v2 = __builtin_amdgcn_raw_buffer_load_b64(rs_loc, si * 8, so_loc, 0);
-            LA t;
-            t.x = __int_as_float(v2[0]); t.y = __int_as_float(v2[1]);
-            t.a = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_att, si * 4, so_att, 0));
-            return t;
-        };
-        const char* rec_base = reinterpret_cast<const char*>(&s_rec[wave][0]) + kgrp * 16;
-        int c = part;
-        unsigned e_cur = load_entry(c);
-        unsigned e_nxt = load_entry(c + wpt);
-        LA la = gather_la(e_cur);
-#pragma unroll 1
-        for (; c < nchunks; c += wpt) {
-            // next chunk: gathers and the entries after it go out before this chunk's 16 steps
-            const LA la_n = gather_la(e_nxt);
-            const unsigned e_nn = load_entry(c + 2 * wpt);
-            {
-                const bool valid = c * 64 + lane < n;
-                float4 rec;
-                rec.x = fmaf(la.x, fW, -0.5f);
-                rec.y = fmaf(la.y, fH, -0.5f);
-                rec.z = valid ? la.a : 0.f;
-                rec.w = __int_as_float(valid ? (int)(e_cur >> 2) * M128 + j * 0 : kOobOff);
-                s_rec[wave][lane] = rec;
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int nst = min(16, (n - c * 64 + 3) >> 2);
-            // all 16 grad_out row loads of the chunk go out first (row offsets only), then the steps read their record
-            float2 gq[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int goff = *reinterpret_cast<const int*>(rec_base + s * 64 + 12);
-                const auto g2 = __builtin_amdgcn_raw_buffer_load_b64(rs_go, goff + j * 8, so_go, 0);
-                gq[s] = make_float2(__int_as_float(g2[0]), __int_as_float(g2[1]));
-            }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (s < nst) {
-                    const float4 rec = *reinterpret_cast<const float4*>(rec_base + s * 64);
-                    // hat weights: zero for every pixel outside the 2x2 footprint, hence also for out-of-range samples
-                    const float wx = fmaxf(0.f, 1.f - fabsf(fpx - rec.x)), wy = fmaxf(0.f, 1.f - fabsf(fpy - rec.y));
-                    const float wgt = wy * wx * rec.z;
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, gq[s].x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, gq[s].y, acc1, 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-            e_cur = e_nxt; e_nxt = e_nn; la = la_n;
-        }
-    }
-    if (stats && lane == 0 && live && part == 0 && n > 0) atomicAdd(&stats[wpt > 1 ? 7 : 8], 1u);
-    if (wpt > 1) {
-        // tiles of coarse levels are split over the waves of the workgroup: sum the partial tiles
-        if (part > 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { s_red[wave - 1][q][lane] = acc0[q]; s_red[wave - 1][4 + q][lane] = acc1[q]; }
-        }
-        __syncthreads();
-        if (part == 0) {
-            for (int k = 1; k < wpt; ++k) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { acc0[q] += s_red[wave + k - 1][q][lane]; acc1[q] += s_red[wave + k - 1][4 + q][lane]; }
-            }
-        }
-    }
-    if (!live || part != 0) return;
-    // D layout: lane holds pixels i = 4 * (lane >> 4) + r (r = 0..3), column j = lane & 15 -> channels 2j (acc0), 2j + 1 (acc1)
-    const int py = ty * 4 + kgrp;
-    if (py < H) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int px = tx * 4 + q;
-            if (px < W)
-                *reinterpret_cast<float2*>(grad_value + ((int64_t)(b * g.S + start + py * W + px) * g.M + m) * kD + j * 2) =
-                    make_float2(acc0[q], acc1[q]);
-        }
-    }
-}
-
-// spill entries (run overflow): plain atomics, after the pull kernel has written the tiles
-template <int NL>
-__global__ __launch_bounds__(kT) void msda_bwd_spill_kernel(const float* __restrict__ loc, const float* __restrict__ attn,
-                                                            const float* __restrict__ grad_out, const int* __restrict__ ovf_count,
-                                                            const uint2* __restrict__ ovf, float* __restrict__ grad_value, GeomB g,
-                                                            unsigned* __restrict__ stats)
-{
-    constexpr int LP = NL * kP;
-    const int n = *ovf_count;
-    const int c = threadIdx.x & 31;
-    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[6], (unsigned)n);
-    for (int i = blockIdx.x * (kT / 32) + (threadIdx.x >> 5); i < n; i += gridDim.x * (kT / 32)) {
-        const uint2 o = ovf[i];
-        const int key = (int)o.x, q = (int)(o.y >> 2), p = (int)(o.y & 3);
-        const int bm = key / g.tiles_per_bm;
-        int r = key - bm * g.tiles_per_bm, l = 0;
-#pragma unroll
-        for (int k = 1; k < NL; ++k) if (r >= g.tile_base[k]) l = k;
-        r -= g.tile_base[l];
-        const int ty = r / g.ntx[l], tx = r - ty * g.ntx[l];
-        const int b = bm / g.M, m = bm - b * g.M;
-        const int W = g.W[l], H = g.H[l];
-        const int64_t gi = ((int64_t)(b * g.Lq + q) * g.M + m) * LP + l * kP + p;
-        const float2 xy = reinterpret_cast<const float2*>(loc)[gi];
-        const float a = attn[gi];
-        const float x = pix(xy.x, W), y = pix(xy.y, H);
-        if (!(y > -1.f && x > -1.f && y < (float)H && x < (float)W)) continue;
-        const float gq = grad_out[((int64_t)(b * g.Lq + q) * g.M + m) * kD + c];
-        const int x0 = (int)floorf(x), y0 = (int)floorf(y);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int px = x0 + (k & 1), py = y0 + (k >> 1);
-            if (px < tx * 4 || px > tx * 4 + 3 || py < ty * 4 || py > ty * 4 + 3 || px > W - 1 || py > H - 1) continue;
-            const float wgt = fmaxf(0.f, 1.f - fabsf((float)px - x)) * fmaxf(0.f, 1.f - fabsf((float)py - y)) * a;
-            atomicAdd(grad_value + ((int64_t)(b * g.S + g.start[l] + py * W + px) * g.M + m) * kD + c, wgt * gq);
-        }
-    }
-}
 
 // --------------------------------------------------------------------------------------------------
 // backward, third generation: "bin" + "tile"  (round 4)
@@ -1659,14 +1106,12 @@ __global__ __launch_bounds__(kT) void msda_bwd_spill3_kernel(const float* __rest
 // host side
 // --------------------------------------------------------------------------------------------------
 int g_region_rows = 217;      // forward: usable rows of the staged box (the buffer is rounded up to whole 32-row stage passes)
-int g_push_rows = 216;        // push: rows of its box buffer (128 B each): 12864 + 216 * 128 = 40512 B -> four workgroups per CU
 int g_block_disable = 0;
 int g_fuse_prep = 1;        // mpf_set_option("msda_fuse_prep"): softmax / location arithmetic inside the forward kernel
 unsigned long long* g_dbg = nullptr;   // benchmarking only: s_memtime phase stamps of the push kernel, [workgroup][16]
 int g_push_ablate = 0;       // benchmarking only: 1 = no tile entries, 2 = no reduction, 4 = no box staging
 int g_bwd_sorted = 0;        // mpf_set_option("msda_bwd_sorted"): sort every tile run before the tile kernel (bit-reproducible grad_value)
 int g_bin_reverse = 0;       // tests: bin kernel walks the query blocks backwards (another arrival order)
-int g_bwd_gen = 3;           // mpf_set_option("msda_bwd_gen"): 3 = bin + tile kernels (round 4), 2 = push + pull (rounds 2-3)
 // tests only (mpf_set_option("msda_stats", 1) / mpf_msda_stats): which route every (workgroup, level) took.
 //   [0] forward: boxes staged in LDS   [1] forward: L2-gather fallback (box larger than the region)
 //   [2] push: boxes staged in LDS      [3] push: L2-gather fallback
@@ -1848,38 +1293,7 @@ WsLayout ws_layout(const GeomB& g)
     return w;
 }
 
-template <int NL>
-hipError_t launch_bwd(const float* value, const float* loc, const float* attn, const float* go, float* gv, float* gl, float* ga,
-                      float* graw, const GeomB& g, void* workspace, hipStream_t st)
-{
-    const WsLayout w = ws_layout(g);
-    char* ws = (char*)workspace;
-    int* tile_count = (int*)(ws + w.off_count);
-    int* ovf_count = (int*)(ws + w.off_ovf_count);
-    unsigned* entries = (unsigned*)(ws + w.off_entries);
-    uint2* ovf = (uint2*)(ws + w.off_ovf);
-    hipError_t err = zero_counters(ws, w.off_ovf_count + 4, st);
-    if (err != hipSuccess) return err;
-    const int nblocks = g.N * g.M * g.blocks_per_b;
-    const int grid = ((nblocks + 7) / 8) * 8;
-    constexpr int LP = NL * kP;
-    const size_t lds = kPOffReg + (size_t)g_push_rows * 128;
-    const double esz = 4.0;
-    mpf::prof_begin(st);
-    hipLaunchKernelGGL(msda_bwd_push_block_kernel<NL>, dim3(grid), dim3(kT), lds, st, value, loc, attn, go, gl, ga, graw, tile_count,
-                       entries, ovf_count, ovf, g, nblocks, g_push_rows, (unsigned)((size_t)g.N * g.S * g.M * kD * 4), g_push_ablate, g_dbg, g_stats);
-    mpf::prof_end("msda_bwd_push_block_kernel", st,
-                  esz * ((double)g.N * g.S * g.M * kD + (double)g.N * g.Lq * g.M * LP * 6 + (double)g.N * g.Lq * g.M * kD));
-    const int nwg = g.N * g.M * g.wg_per_bm;
-    mpf::prof_begin(st);
-    hipLaunchKernelGGL(msda_bwd_pull_mfma_kernel<NL>, dim3(((nwg + 7) / 8) * 8), dim3(kTP), 0, st, loc, attn, go, tile_count, entries,
-                       gv, g, nwg, (unsigned)((size_t)g.N * g.Lq * g.M * LP * 8), (unsigned)((size_t)g.N * g.Lq * g.M * kD * 4), g_stats);
-    mpf::prof_end("msda_bwd_pull_mfma_kernel", st, esz * ((double)g.N * g.Lq * g.M * kD + (double)g.N * g.S * g.M * kD));
-    hipLaunchKernelGGL(msda_bwd_spill_kernel<NL>, dim3(64), dim3(kT), 0, st, loc, attn, go, ovf_count, ovf, gv, g, g_stats);
-    return hipGetLastError();
-}
-
-// third generation: memset -> bin -> tile -> spill3.  fwd_out (the forward result, [N, Lq, M * 32]) is needed by the raw form only.
+// backward: zero counters -> bin -> tile -> spill3.  fwd_out (the forward result, [N, Lq, M * 32]) is needed by the raw form only.
 template <int NL>
 hipError_t launch_bwd3(const float* value, const float* loc, const float* attn, const float* go, const float* fwd_out, float* gv,
                        float* gl, float* ga, float* graw, const GeomB& g, void* workspace, hipStream_t st, float* graw_amax,
@@ -2019,29 +1433,20 @@ int msda_block_backward(const void* value, const int64_t* host_shapes, const voi
     if (workspace_bytes < ws_layout(g).total) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: workspace too small");
     // the amax slots are filled by the bin + tile (+ spill) kernels of the raw form; on every other route the caller runs
     // the amax passes itself (a switch or a geometry outside these kernels must not make the training step fail)
-    if (!(g_bwd_gen == 3 && graw && fwd_out)) graw_amax = gv_amax = nullptr;
+    // the raw form needs the forward result (delta = <grad_out, out>): without it the caller's round-1 kernels run
+    if (graw && !fwd_out) return -1000;
+    if (!graw) graw_amax = gv_amax = nullptr;
     else if (amax_recorded) *amax_recorded = true;
-    if (g_bwd_gen == 3 && (!graw || fwd_out)) {
-        mpf::set_kernel("msda_bwd_block(bin+tile)");
-        hipError_t e3;
-        const float *v_ = (const float*)value, *l_ = (const float*)loc, *a_ = (const float*)attn, *g_ = (const float*)go, *o_ = (const float*)fwd_out;
-        switch (L) {
-            case 1: e3 = launch_bwd3<1>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
-            case 2: e3 = launch_bwd3<2>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
-            case 3: e3 = launch_bwd3<3>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
-            default: e3 = launch_bwd3<4>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
-        }
-        return mpf::check(e3, "msda_bwd_block(bin+tile)");
-    }
-    mpf::set_kernel("msda_bwd_block(push+pull)");
-    hipError_t err;
+    mpf::set_kernel("msda_bwd_block(bin+tile)");
+    hipError_t e3;
+    const float *v_ = (const float*)value, *l_ = (const float*)loc, *a_ = (const float*)attn, *g_ = (const float*)go, *o_ = (const float*)fwd_out;
     switch (L) {
-        case 1: err = launch_bwd<1>((const float*)value, (const float*)loc, (const float*)attn, (const float*)go, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
-        case 2: err = launch_bwd<2>((const float*)value, (const float*)loc, (const float*)attn, (const float*)go, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
-        case 3: err = launch_bwd<3>((const float*)value, (const float*)loc, (const float*)attn, (const float*)go, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
-        default: err = launch_bwd<4>((const float*)value, (const float*)loc, (const float*)attn, (const float*)go, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st); break;
+        case 1: e3 = launch_bwd3<1>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
+        case 2: e3 = launch_bwd3<2>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
+        case 3: e3 = launch_bwd3<3>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
+        default: e3 = launch_bwd3<4>(v_, l_, a_, g_, o_, (float*)gv, (float*)gl, (float*)ga, (float*)graw, g, workspace, st, graw_amax, gv_amax); break;
     }
-    return mpf::check(err, "msda_bwd_block");
+    return mpf::check(e3, "msda_bwd_block(bin+tile)");
 }
 
 int set_block_option(const char* key, int v)
@@ -2051,21 +1456,11 @@ int set_block_option(const char* key, int v)
         g_region_rows = v;
         return 0;
     }
-    if (!strcmp(key, "msda_push_rows")) {
-        if (v < 16 || v > 480) return MPF_E_SHAPE;
-        g_push_rows = v;
-        return 0;
-    }
     if (!strcmp(key, "msda_block_disable")) { g_block_disable = v; return 0; }
     if (!strcmp(key, "msda_fuse_prep")) { g_fuse_prep = v; return 0; }
     if (!strcmp(key, "msda_push_ablate2")) { g_push_ablate = v; return 0; }
     if (!strcmp(key, "msda_bwd_sorted")) { g_bwd_sorted = v != 0; return 0; }
     if (!strcmp(key, "msda_bin_reverse")) { g_bin_reverse = v != 0; return 0; }
-    if (!strcmp(key, "msda_bwd_gen")) {
-        if (v != 2 && v != 3) return MPF_E_SHAPE;
-        g_bwd_gen = v;
-        return 0;
-    }
     if (!strcmp(key, "msda_stats")) {
         if (v && !g_stats) {
             if (hipMalloc((void**)&g_stats, kNStats * sizeof(unsigned)) != hipSuccess) { g_stats = nullptr; return MPF_E_SHAPE; }

@@ -80,11 +80,6 @@ def wrap_ddp(model, device_ids=None):
         return model
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, broadcast_buffers=False,
                                                     gradient_as_bucket_view=True)
-    if os.environ.get("MPF_DDP_BF16_ALLREDUCE", "0") == "1":
-        # optional (off by default: the reference all-reduces fp32 gradients): halves the bytes each xGMI link
-        # carries per step; gradients are rounded to bf16 for the exchange only
-        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-        ddp.register_comm_hook(None, default_hooks.bf16_compress_hook)
     return ddp
 
 

@@ -28,7 +28,6 @@ from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
 from .resln import LnGradGroup, ln256_forward
 
 PARAMS_PER_LAYER = 16
-_GATE_BITS = os.environ.get("MPF_ENC_GATE_BITS", "1") != "0"      # (A/B switch: 0 = the saved activation as the ReLU gate)
 _EPS = 1e-5
 
 
@@ -164,7 +163,7 @@ class EncoderFn(Function):
             s1 = gemm3_h2(ao, ao_am, po, po_am, bo, cin=x)
             x1, mean1, rstd1, _ = ln256_forward(s1, g1, b1, _EPS, y_bound=x1_am)
             # (the ReLU's gate leaves the product as a bit mask: the backward then reads 1 bit instead of 4 bytes per element of h)
-            if p1.shape[1] % 128 == 0 and _GATE_BITS:
+            if p1.shape[1] % 128 == 0:
                 h, hbits = gemm3_h2_bits(x1, x1_am, p1, p1_am, bb1, relu=True, out_amax=h_am, want_bits=True)
             else:
                 h, hbits = gemm3_h2(x1, x1_am, p1, p1_am, bb1, relu=True, out_amax=h_am), None

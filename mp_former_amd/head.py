@@ -87,13 +87,9 @@ class MPFormerHead(nn.Module):
         wd = self.criterion.weight_dict
         return {k: v * wd[k] for k, v in losses.items() if k in wd}, outputs
 
-    def total_loss(self, features, targets, pixel_decoder_out=None):
-        """Sum of the weighted losses without materialising the weighted dict (2 kernels instead of 120).
-        pixel_decoder_out = (mask_features, multi_scale_features) when the pixel decoder already ran (HIP-graph trunk)."""
-        if pixel_decoder_out is not None:
-            mask_features, multi_scale = pixel_decoder_out
-        else:
-            mask_features, _, multi_scale = self.pixel_decoder.forward_features(features)
+    def total_loss(self, features, targets):
+        """Sum of the weighted losses without materialising the weighted dict (2 kernels instead of 120)."""
+        mask_features, _, multi_scale = self.pixel_decoder.forward_features(features)
         dn_args = {"tgt": targets, "scalar": self.scalar, "noise_scale": self.noise_scale}
         outputs = self.predictor(multi_scale, mask_features, None, dn_args)
         return self.criterion.weighted_total(self.criterion(outputs, targets))

@@ -1,51 +1,54 @@
-"""nn.Linear forward/backward with a split-K weight gradient for tall inputs.
+"""nn.Linear for fp32 activations with many rows on the native fp32 GEMM (csrc/gemm3.hip).
 
-The encoder's Linear layers see [N*S, C] activations with N*S = 43 008 rows at 1024x1024: the
-weight-gradient GEMM  dW[out,in] = dY^T[out,rows] . X[rows,in]  has a tiny output (256x1024) and a
-huge reduction dimension, which the library runs as a handful of workgroups (measured 43 TFLOP/s
-fp32).  Splitting the rows into chunks turns it into a batched GEMM that fills the 256 CUs, followed
-by a small sum.  Same math (fp32 accumulation, summation order differs)."""
+The per-layer route of the pixel decoder's encoder — ``MSDeformAttn.forward`` (ops/modules/ms_deform_attn.py:95-124) and the
+FFN of ``MSDeformAttnTransformerEncoderLayer`` (msdeformattn.py:116-131) when they are called as modules instead of through
+the fused encoder node — sees [N * S, C] activations with N * S = 43 008 rows at 1024 x 1024.  Forward and input gradient are
+``gemm3`` (fp32 operands split into bf16 pieces, six products, fp32-class error: tests/test_gemm3_gpu.py), the weight
+gradient is its split-over-rows "NT" form whose staging loop also yields the bias gradient.  Shapes outside the kernels'
+(K % 32, N % 4, fewer than 1 024 rows, non-fp32, CPU) take ``F.linear``."""
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
-
-def _pick_chunks(rows, limit=32):
-    for c in (32, 24, 16, 12, 8, 6, 4, 3, 2):
-        if c <= limit and rows % c == 0 and rows // c >= 1024:
-            return c
-    return 1
+from .gemm3 import gemm3, gemm3_nt, nt_reduce, split_weights_grouped
 
 
-class _LinearSplitK(Function):
+class _LinearFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x2, weight, bias):
+        pf, pb = split_weights_grouped([([weight], False), ([weight], True)])
+        ctx.save_for_backward(x2, pb)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        return gemm3(x2, pf, bias)
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
-        gx = gw = gb = None
-        g2 = gy.reshape(-1, gy.shape[-1])
-        x2 = x.reshape(-1, x.shape[-1])
+        from .encoder_fused import _balanced_rps
+        x2, pb = ctx.saved_tensors
+        g2 = gy if (gy.stride(1) == 1 and gy.stride(0) % 4 == 0) else gy.contiguous()
+        dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            gx = (g2 @ weight).view(x.shape)
-        if ctx.needs_input_grad[1]:
-            rows = g2.shape[0]
-            c = _pick_chunks(rows)
-            if c > 1:
-                gw = torch.bmm(g2.view(c, rows // c, -1).transpose(1, 2), x2.view(c, rows // c, -1)).sum(0)
-            else:
-                gw = g2.t() @ x2
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0)
-        return gx, gw, gb
+            dx = gemm3(g2, pb)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            rps = _balanced_rps(g2.shape[0], g2.shape[1], x2.shape[1], g2.device)
+            c, ca, _ = gemm3_nt(g2, x2, rps, want_csum_a=True)
+            dw, db = nt_reduce(c, ca)
+            if not ctx.has_bias:
+                db = None
+        return dx, dw, db
+
+
+def native_ok(x, weight):
+    rows = x.numel() // max(x.shape[-1], 1)
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and rows >= 1024 and x.shape[-1] % 32 == 0
+            and weight.shape[0] % 4 == 0 and not torch.is_autocast_enabled())
 
 
 def linear_tall(x, weight, bias=None):
-    """F.linear for inputs with many rows; identical forward, split-K weight gradient."""
-    if x.numel() // x.shape[-1] < 8192 or not x.is_cuda:
+    """F.linear for inputs with many rows: the native fp32 GEMM when its shapes apply."""
+    if not native_ok(x, weight):
         return F.linear(x, weight, bias)
-    return _LinearSplitK.apply(x, weight, bias)
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1 or x2.stride(0) % 4 != 0:
+        x2 = x2.contiguous()
+    return _LinearFn.apply(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])

@@ -36,8 +36,6 @@ from .decoder_layer import decoder_layer, split_cols
 from .pixel_decoder import PositionEmbeddingSine, _ConvNorm, _c2_xavier_fill
 
 
-_DEC_ALIAS = os.environ.get("MPF_DEC_ALIAS", "1") != "0"
-_NEXT_MASK_NATIVE = os.environ.get("MPF_NEXT_MASK_NATIVE", "1") != "0"     # (A/B switch: 0 = five python-level ops)
 
 
 class _CastParams(torch.autograd.Function):
@@ -708,7 +706,7 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
         with torch.no_grad():
             amp = W["class_embed.weight"].dtype == torch.bfloat16
             if (pooled is not None and amp and output.dtype == torch.float32 and output.is_contiguous() and output.shape[-1] == 256
-                    and output.shape[0] * output.shape[1] <= 1024 and _NEXT_MASK_NATIVE):
+                    and output.shape[0] * output.shape[1] <= 1024):
                 n_ = self.decoder_norm
                 mlp = [(W[f"mask_embed.layers.{k}.weight"], W[f"mask_embed.layers.{k}.bias"]) for k in range(3)]
                 if (n_.elementwise_affine and n_.bias is not None
@@ -885,8 +883,8 @@ class MultiScaleMaskedTransformerDecoderMaskDN(nn.Module):
                 output, xb = self._layer_by_ops(W, i, level, output, xb, kin, src, attn_mask, tgt_mask, post_norm)
                 out_heads = output
             nxt = (i + 1) % self.num_feature_levels
-            # (the fused layer's second alias of its output, decoder_layer.DecoderLayerFn; MPF_DEC_ALIAS=0: the output itself)
-            streams.append(out_heads if _DEC_ALIAS else output)
+            # (the fused layer's second alias of its output, decoder_layer.DecoderLayerFn)
+            streams.append(out_heads)
             if i + 1 < self.num_layers:
                 attn_mask = self._next_attn_mask(W, output, mask_features, size_list[nxt], rows(nxt, i), pooled[nxt])
             elif mp is not None and callable(mp["rows"]) and _rng.replaying() and (self.all_lys or i < 3):

@@ -33,7 +33,6 @@ def _reset_variants():
     _lib.set_option("msda_fwd_variant", 0)
     _lib.set_option("msda_bwd_variant", 0)
     _lib.set_option("msda_block_disable", 0)
-    _lib.set_option("msda_bwd_gen", 3)
     msda.BWD_MODE = "auto"
 
 
@@ -232,19 +231,17 @@ def _decoder_like_problem(lv, N, Lq=None, mode="near", spread=3.0, seed=0, M=8, 
                 attn=attn.numpy(), grad_out=go.numpy())
 
 
-def _run_with_stats(z, dev, gen=3):
-    """gen: backward generation of the blocked kernels — 3 = bin + tile (destination-side, round 4), 2 = push + pull"""
+def _run_with_stats(z, dev):
+    """forward + backward through the op with the route counters of the blocked kernels (bin + tile backward) on"""
     from mp_former_amd import _lib
     _lib.set_option("msda_stats", 1)
-    _lib.set_option("msda_bwd_gen", gen)
     try:
         _lib.msda_stats(reset=True)
         res, kern = _run(z, torch.float32, dev)
         st = _lib.msda_stats(reset=True)
     finally:
         _lib.set_option("msda_stats", 0)
-        _lib.set_option("msda_bwd_gen", 3)
-    assert ("bin+tile" in kern[1]) == (gen == 3) or "block" not in kern[1], kern
+    assert "bin+tile" in kern[1] or "block" not in kern[1], kern
     return res, kern, st
 
 
@@ -279,32 +276,30 @@ _ROUTE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("gen", [3, 2])
 @pytest.mark.parametrize("case", _ROUTE_CASES, ids=[c[0] for c in _ROUTE_CASES])
-def test_blocked_routes_vs_oracle(dev, oracle_msda, case, gen):
+def test_blocked_routes_vs_oracle(dev, oracle_msda, case):
     """The production kernels on every problem class they branch on (LDS-staged boxes vs L2 gathers, direct-mapped vs
     hashed tile counters, 1..4 levels, odd level sizes, queries that are not the pixels) against the C oracle, with the
     route counters proving which branch ran."""
     name, lv, N, Lq, mode, spread = case
     z = _decoder_like_problem(lv, N, Lq, mode, spread, seed=len(name))
-    res, (kf, kb), st = _run_with_stats(z, dev, gen)
+    res, (kf, kb), st = _run_with_stats(z, dev)
     assert "block" in kf and "block" in kb, (kf, kb)
     _assert_matches_oracle(z, res, oracle_msda)
     assert st["spill_entries"] == 0, st
     assert st["pull_split"] + st["pull_single"] > 0, st
     if mode == "near":
         # decoder-like offsets: the fine-query blocks fit the LDS region in both kernels
-        assert st["fwd_lds"] > 0 and st["push_direct"] > 0 and (gen == 3 or st["push_lds"] > 0), st
+        assert st["fwd_lds"] > 0 and st["push_direct"] > 0 , st
     if name == "queries_not_pixels_300":
-        assert st["fwd_gather"] > 0 and (gen == 3 or st["push_gather"] > 0), st      # 64 consecutive queries scattered over the maps
+        assert st["fwd_gather"] > 0 , st      # 64 consecutive queries scattered over the maps
 
 
-@pytest.mark.parametrize("gen", [3, 2])
-def test_blocked_spill_route_vs_oracle(dev, oracle_msda, gen):
+def test_blocked_spill_route_vs_oracle(dev, oracle_msda):
     """Every sample of the problem on one spot: the fixed-capacity runs of the four tiles around it overflow and the
     spill kernel applies the rest with atomics (ms_deform_im2col_cuda.cuh:92-164 semantics for any multiplicity)."""
     z = _decoder_like_problem([(8, 8), (16, 16), (32, 32)], 1, None, "point", seed=11)
-    res, (kf, kb), st = _run_with_stats(z, dev, gen)
+    res, (kf, kb), st = _run_with_stats(z, dev)
     assert "block" in kb, kb
     assert st["spill_entries"] > 0, st
     out, gv, gl, ga = res
@@ -321,8 +316,7 @@ def test_blocked_spill_route_vs_oracle(dev, oracle_msda, gen):
 @pytest.mark.parametrize("cfg,lv,N,mode,spread", [("B_init", [(32, 32), (64, 64), (128, 128)], 2, "init", 0.5),
                                                   ("B_spread3", [(32, 32), (64, 64), (128, 128)], 1, "near", 3.0),
                                                   ("E_init", [(32, 64), (64, 128), (128, 256)], 1, "init", 0.5)])
-@pytest.mark.parametrize("gen", [3, 2])
-def test_production_route_full_size_vs_oracle(dev, oracle_msda, cfg, lv, N, mode, spread, gen):
+def test_production_route_full_size_vs_oracle(dev, oracle_msda, cfg, lv, N, mode, spread):
     """BASELINE configs B (1024^2, N = 2) and E (1024x2048) with pixel-decoder-like offsets — the route the training
     step takes: boxes staged in LDS by DMA, inter-block halos, multi-band pull with split tiles — against the C oracle
     (grad_value in full, the per-query results on every 5th query to bound the oracle's run time).  "init" = the
@@ -330,7 +324,7 @@ def test_production_route_full_size_vs_oracle(dev, oracle_msda, cfg, lv, N, mode
     coarse queries looking into finer maps); N(0, 3 px) offsets make most boxes overflow it (L2 gathers), so both
     routes meet the oracle at size."""
     z = _decoder_like_problem(lv, N, None, mode, spread, seed=7)
-    res, (kf, kb), st = _run_with_stats(z, dev, gen)
+    res, (kf, kb), st = _run_with_stats(z, dev)
     assert "block" in kf and "block" in kb, (kf, kb)
     nblk = sum(((h + 7) // 8) * ((w + 7) // 8) for h, w in lv) * N * 8
     assert st["fwd_lds"] + st["fwd_gather"] == 3 * nblk, (st, nblk)
@@ -341,8 +335,8 @@ def test_production_route_full_size_vs_oracle(dev, oracle_msda, cfg, lv, N, mode
     if mode == "init":
         assert st["fwd_lds"] > 0.8 * 3 * nblk and (gen == 3 or st["push_lds"] > 0.8 * 3 * nblk), (st, nblk)
     else:
-        assert st["fwd_lds"] > 0 and (gen == 3 or st["push_lds"] > 0) and st["fwd_gather"] > 0.5 * 3 * nblk, (st, nblk)
-    assert st["fwd_gather"] > 0 and (gen == 3 or st["push_gather"] > 0), st            # coarse queries looking into the finest map
+        assert st["fwd_lds"] > 0  and st["fwd_gather"] > 0.5 * 3 * nblk, (st, nblk)
+    assert st["fwd_gather"] > 0 , st            # coarse queries looking into the finest map
     assert st["push_direct"] > 0 and st["pull_split"] > 0 and st["pull_single"] > 0, st
     assert st["spill_entries"] == 0, st
     out, gv, gl, ga = res
@@ -350,7 +344,7 @@ def test_production_route_full_size_vs_oracle(dev, oracle_msda, cfg, lv, N, mode
     np.testing.assert_allclose(gv, rgv, rtol=1e-3, atol=1e-3)
     _assert_matches_oracle(z, res, oracle_msda, sub=slice(0, None, 5))
     # bit-reproducible: exclusive tile ownership, no atomics on this route
-    res2, _, _ = _run_with_stats(z, dev, gen)
+    res2, _, _ = _run_with_stats(z, dev)
     for a, b in zip(res, res2):
         if a is gv:
             continue                                                      # entry order inside a tile's run is not fixed

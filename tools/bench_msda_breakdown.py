@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel breakdown of the MSDA forward + backward at config B, N=2 (in-library HIP-event profiler).
-usage: bench_msda_breakdown.py [init|trained|uniform] [cfg] [N] [backward generation 2|3] [raw]"""
+usage: bench_msda_breakdown.py [init|trained|uniform] [cfg] [N] [-] [raw]     (4th argument: unused, kept for old command lines)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,8 +10,6 @@ dev = torch.device("cuda:0")
 mode = sys.argv[1] if len(sys.argv) > 1 else "init"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "B"
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-if len(sys.argv) > 4:
-    _lib.set_option("msda_bwd_gen", int(sys.argv[4]))       # 3 = bin + tile (default), 2 = push + pull
 value, shapes, lsi, loc, attn, go, S = problem(cfg, N, dev, mode)
 ss = msda.attach_host_shapes(shapes, shapes.tolist(), lsi)
 raw = len(sys.argv) > 5 and sys.argv[5] == "raw"          # the module-level (raw) form the encoder runs: grad_raw + amax slots

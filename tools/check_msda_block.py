@@ -127,7 +127,7 @@ def timing(dev, cfg, N, mode, iters=20, rounds=5):
     for _ in range(5):
         msda.ms_deform_attn_backward(value, ss, lsi, loc, attn, go, 128)
     torch.cuda.synchronize()
-    for k in ("msda_bwd_push_block_kernel", "msda_bwd_pull_mfma_kernel"):
+    for k in ("msda_bwd_bin", "msda_bwd_tile"):
         n, ms, _ = _lib.profile_get(k)
         if n:
             print(f"   {k}: {ms / n * 1e3:.1f} us")

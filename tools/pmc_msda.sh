@@ -47,7 +47,7 @@ for k, v in cal.items():
     else:
         factors[k] = EXPECT / (v["FETCH_SIZE"] * 1024.0)
 # dominant read shape per kernel: 128-B rows fetched as 8 lanes x 16 B (forward, push) or 16 lanes x 8 B (pull)
-shape = {"msda_fwd_block_kernel": "calib_rows16", "msda_bwd_push_block_kernel": "calib_rows16", "msda_bwd_pull_mfma_kernel": "calib_rows8",
+shape = {"msda_fwd_block_kernel": "calib_rows16", 
          "msda_bwd_bin_kernel": "calib_stream16", "msda_bwd_tile_kernel": "calib_rows16"}
 import os
 out = {"config": "B (1024x1024: S = 21504), N = 2, init-like offsets (tools/bench_msda_breakdown.py init)",
