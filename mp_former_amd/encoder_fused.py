@@ -30,6 +30,22 @@ from .resln import LnGradGroup, ln256_forward
 PARAMS_PER_LAYER = 16
 _EPS = 1e-5
 
+# Range audit of the fp16 x 2 operands (tools/soak.py --range-audit): None, or {operand name: int64 [41] device
+# histogram}: bin b counts the rows whose largest magnitude is in [2^-(b+1), 2^-b) of what the operand's amax SLOT holds (the
+# scale's reference — the true maximum or the upper bound of amax.h), bin 40 everything below 2^-40 incl. all-zero rows.
+RANGE_AUDIT = None
+
+
+def _audit(name, t, slot):
+    if RANGE_AUDIT is None:
+        return
+    from .gemm3 import amax_value
+    ref = amax_value(slot).clamp_min(1e-38)
+    r = (t.detach().abs().amax(1) / ref).clamp(2.0 ** -41, 1.0)
+    b = (-torch.floor(torch.log2(r))).clamp(0, 40).long()
+    h = torch.bincount(b, minlength=41)
+    RANGE_AUDIT[name] = h if name not in RANGE_AUDIT else RANGE_AUDIT[name] + h
+
 
 _PARAM_SLOTS = (("self_attn", "sampling_offsets"), ("self_attn", "attention_weights"), ("self_attn", "value_proj"),
                 ("self_attn", "output_proj"), ("norm1",), ("linear1",), ("linear2",), ("norm2",))
@@ -152,14 +168,17 @@ class EncoderFn(Function):
             (pv, pv_am), (po, po_am), (p1, p1_am), (p2, p2_am), (p288, p288_am) = planes2[10 * i:10 * i + 5]
             b288 = b288_all[i]
             ao_am, x1_am, h_am, xn_am, qn_am = am[5 * i:5 * i + 5]
+            _audit("fwd x (value_proj)", x, x_am)
             value = gemm3_h2(x, x_am, pv, pv_am, bv, out_amax=ao_am)
             if q is None:       # layer 0; later layers get src + pos from the previous layer's norm2 pass
                 q = (x.view(N, S, C) + pos_full).view(R, C)
                 amax(q, q_am)
+            _audit("fwd q (offsets | weights)", q, q_am)
             raw = gemm3_h2(q, q_am, p288, p288_am, b288)
             # softmax over the 12 logits, loc = ref + offset / (W_l, H_l) happen inside the MSDA kernel
             ao, loc, attn = ms_deform_attn_forward_raw(value.view(N, S, M, C // M), shapes, lsi, raw, ref, host_shapes)
             ao = ao.view(R, C)
+            _audit("fwd attention output (output_proj)", ao, ao_am)
             s1 = gemm3_h2(ao, ao_am, po, po_am, bo, cin=x)
             x1, mean1, rstd1, _ = ln256_forward(s1, g1, b1, _EPS, y_bound=x1_am)
             # (the ReLU's gate leaves the product as a bit mask: the backward then reads 1 bit instead of 4 bytes per element of h)
@@ -167,6 +186,8 @@ class EncoderFn(Function):
                 h, hbits = gemm3_h2_bits(x1, x1_am, p1, p1_am, bb1, relu=True, out_amax=h_am, want_bits=True)
             else:
                 h, hbits = gemm3_h2(x1, x1_am, p1, p1_am, bb1, relu=True, out_amax=h_am), None
+            _audit("fwd x1 (linear1)", x1, x1_am)
+            _audit("fwd hidden (linear2)", h, h_am)
             s2 = gemm3_h2(h, h_am, p2, p2_am, bb2, cin=x1)
             last = i + 1 == nl
             x2, mean2, rstd2, qn = ln256_forward(s2, g2_, b2, _EPS, padd=None if last else pos_full, y_bound=xn_am,
@@ -217,14 +238,19 @@ class EncoderFn(Function):
                 dh = gemm3_h2_bits(ds2, ds2_am, t2, t2_am, gate_bits=hbits, out_amax=dh_am)
             else:
                 dh = gemm3_h2(ds2, ds2_am, t2, t2_am, gate=h, out_amax=dh_am)
+            _audit("bwd ds2 (d linear2 output)", ds2, ds2_am)
+            _audit("bwd dh (d hidden)", dh, dh_am)
             dx1 = gemm3_h2(dh, dh_am, t1, t1_am, cin=ds2)
             # norm1 <- attention
             ds1 = lng.backward(s1, mean1, rstd1, g1, dx1, ds_amax=ds1_am)
+            _audit("bwd ds1 (d output_proj output)", ds1, ds1_am)
             dao = gemm3_h2(ds1, ds1_am, to, to_am)
             # d(raw): the softmax / offset-normaliser backward is the epilogue of the push kernel
             # (the bin + tile kernels record the largest magnitudes of gv / draw themselves: no amax pass over the two tensors)
             gv, draw = ms_deform_attn_backward_raw(value.view(N, S, M, C // M), host_shapes, loc, attn, dao.view(N, S, C), ao.view(N, S, C),
                                                    draw_am, gv_am)
+            _audit("bwd draw (d offsets | weights)", draw, draw_am)
+            _audit("bwd grad_value (d value_proj output)", gv.view(R, C), gv_am)
             dq = gemm3_h2(draw, draw_am, t288, t288_am)
             # dW288^T = q^T . draw (288 on the 96-wide tile side) + per-split column sums of draw: the
             # bias gradient and, summed per level, the level_embed gradient

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--every", type=int, default=20)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--range-audit", default="", help="JSON file: per fp16 x 2 GEMM operand of the encoder, histogram of each row's largest "
+                                                    "magnitude relative to the operand's amax slot over all steps (VERDICT r4 item 7)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -38,6 +40,9 @@ def main():
     model.backbone.to(memory_format=torch.channels_last)
     opt = bench.build_optimizer(model)
     batches = [bench.synth_batch(a.batch, a.size, 80, i, dev) for i in range(4)]
+    if a.range_audit:
+        from mp_former_amd import encoder_fused
+        encoder_fused.RANGE_AUDIT = {}
     hist = []
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -55,6 +60,25 @@ def main():
     dt = time.perf_counter() - t0
     first = sum(v for _, v in hist[:2]) / 2
     last = sum(v for _, v in hist[-2:]) / 2
+    if a.range_audit:
+        from mp_former_amd import encoder_fused
+        out = {"what": "rows of every fp32 operand of the encoder's fp16 x 2 GEMMs over %d training steps of bench.py's step (config B, N = %d, "
+                       "6 layers): share of rows whose largest magnitude is below 2^-k of the value in the operand's amax slot (the scale's "
+                       "reference; LayerNorm outputs: an upper bound 4-5x above the true maximum)" % (a.steps, a.batch),
+               "note": "h = fp16(s x) keeps 11 bits for any row above 2^-24 of the reference; l stays a normal fp16 number (full 2^-23) down to "
+                       "2^-18; below that a row loses one bit per binade (DESIGN.md: measured 3.3e-5 at 2^-24, 5.4e-4 at 2^-28)",
+               "operands": {}}
+        for k, h in sorted(encoder_fused.RANGE_AUDIT.items()):
+            h = h.double().cpu()
+            tot = float(h.sum())
+            cum = h.flip(0).cumsum(0).flip(0) / tot          # cum[b] = share of rows at or below bin b
+            out["operands"][k] = {"rows": int(tot), "share_below_2^-12": float(cum[12]), "share_below_2^-18": float(cum[18]),
+                                  "share_below_2^-24": float(cum[24]), "share_zero_or_below_2^-40": float(cum[40]),
+                                  "median_bin_log2": int((cum >= 0.5).nonzero().max()), "histogram_log2_bins_0_to_40": [int(v) for v in h]}
+        with open(a.range_audit, "w") as f:
+            json.dump(out, f, indent=1)
+        worst = max(v["share_below_2^-18"] - v["share_zero_or_below_2^-40"] for v in out["operands"].values())
+        print(f"range audit -> {a.range_audit}: largest share of non-zero rows below 2^-18 of the slot: {worst:.5f}")
     print(json.dumps({"steps": a.steps, "first": first, "last": last, "ratio": last / first, "s_total": round(dt, 1),
                       "params_finite": bool(all(torch.isfinite(p).all() for p in model.parameters()))}))
 
