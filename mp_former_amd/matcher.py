@@ -63,6 +63,14 @@ class GTMasks:
 
 
 class HungarianMatcher(nn.Module):
+    # True: the mask / dice costs are sampled from the MATERIALISED prediction maps in the dtype the mask product returns them
+    # in — under bf16 autocast the bf16-ROUNDED maps, interpolated in fp32, which is exactly what the reference's matcher reads
+    # (matcher.py:120-132 after the autocast einsum of mask2former_transformer_decoder.py:1865) — instead of from the factors
+    # (fp32-class logits, csrc/mask_fused.hip).  Costs agree to ~2^-9 relative; an assignment that hinges on less can differ
+    # (tests/test_head_gpu.py::test_amp_matching_on_bf16_rounded_maps_as_the_reference_samples_them measures how many do).
+    # Slower (the [N, Q, H/4, W/4] maps of all outputs are written and sampled): for trajectory comparisons, not for speed.
+    reference_amp_rounding = False
+
     def __init__(self, cost_class: float = 1, cost_mask: float = 1, cost_dice: float = 1, num_points: int = 0):
         super().__init__()
         self.cost_class, self.cost_mask, self.cost_dice = cost_class, cost_mask, cost_dice
@@ -91,7 +99,8 @@ class HungarianMatcher(nn.Module):
         gt_offs = np.tile(np.arange(Tt, dtype=np.int64) * (gt.H * gt.W), L)
         gcrow = (np.repeat(np.arange(L), Tt) * N + np.tile(gt.image_of_row, L)).astype(np.int32)
         masks = [o["pred_masks"] for o in outs]
-        factored = mapset is None and all(isinstance(m, FactoredMasks) and m.same_factors(masks[0]) for m in masks) and Tmax <= 128
+        factored = (mapset is None and not self.reference_amp_rounding and Tmax <= 128
+                    and all(isinstance(m, FactoredMasks) and m.same_factors(masks[0]) for m in masks))
         if factored:
             # the maps are kept as (mask_embed, mask_features): cost straight from the factors (csrc/mask_fused.hip)
             gt_offs_d = upload(gt_offs, dev)

@@ -218,8 +218,29 @@ def _rel_l2(got, want):
     return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
 
 
+# fixtures on which the autocast path's OWN Hungarian assignment reproduces the reference's goldens at the pinned test's tolerances.
+# Measured on MI355X (round 5): head_small, head_ragged, head_noise pass unpinned; head_deep keeps every loss within tolerance but one
+# gradient lands at 0.0712 relative L2 (bar 0.07), head_cfgA (100 freshly initialised near-duplicate queries: 45 of 70 targets matched
+# as in fp32, regret <= 0.8 %) moves d query_feat to 0.16 — those two stay on the pinned form only.
+_OWN_ASSIGNMENT_FIXTURES = ["head_small", "head_ragged", "head_noise"]
+
+
 @pytest.mark.parametrize("name", ["head_small", "head_ragged", "head_deep", "head_noise", "head_cfgA"])
 def test_head_amp_path_matches_reference_golden(name):
+    _amp_golden(name, pin=True)
+
+
+@pytest.mark.parametrize("name", _OWN_ASSIGNMENT_FIXTURES)
+def test_head_amp_path_on_its_own_assignment_matches_reference_golden(name):
+    """The same comparison WITHOUT the pinned assignment: the autocast path solves the matching from its own
+    (bf16-noisy) cost matrices on the device, with the reference's matcher draws replayed, and must still land on the fp32
+    goldens — i.e. on these fixtures the AMP assignment IS the reference's.  The fixtures left to the pinned form only are the
+    ones whose cost matrices tie at bf16 resolution (near-duplicate queries of the toy models; the agreement share and the
+    regret of the flipped pairs are measured in test_amp_path_own_matching_against_the_fp32_matching)."""
+    _amp_golden(name, pin=False)
+
+
+def _amp_golden(name, pin):
     """The path bench.py times — bf16 autocast with every default switch (natively sequenced decoder layers, MFMA
     attention, small-row GEMMs, device-side assignment) — against the PINNED goldens of the imported reference (fp32),
     with the reference's draws replayed: every one of the 6 x (1 + #aux) losses per key, and the gradients of the
@@ -243,16 +264,20 @@ def test_head_amp_path_matches_reference_golden(name):
     matcher = h.criterion.matcher
     solve = matcher.match_many
     pinned = []
-    os.environ["MPF_DEVICE_LSA"] = "0"
+    if pin:
+        os.environ["MPF_DEVICE_LSA"] = "0"
     try:
-        _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
-        matcher.match_many = lambda *a, **k: pinned.append(solve(*a, **k)) or pinned[-1]
-        with torch.no_grad():
-            h(feats, targets)
-        assert len(pinned) == 1 and _rng.remaining() == 0
-        matcher.match_many = lambda *a, **k: pinned[0]
-        # (the matcher's own point draws are not consumed in pass 2)
-        _rng.install_replay({t: d for t, d in fifo_to_tags(replay, cfg, use_dn).items() if not t.startswith("match")})
+        if pin:
+            _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
+            matcher.match_many = lambda *a, **k: pinned.append(solve(*a, **k)) or pinned[-1]
+            with torch.no_grad():
+                h(feats, targets)
+            assert len(pinned) == 1 and _rng.remaining() == 0
+            matcher.match_many = lambda *a, **k: pinned[0]
+            # (the matcher's own point draws are not consumed in pass 2)
+            _rng.install_replay({t: d for t, d in fifo_to_tags(replay, cfg, use_dn).items() if not t.startswith("match")})
+        else:
+            _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))       # own assignment: device solver on the AMP costs, matcher draws replayed
         _lib.profile_enable(True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             losses, _ = h(feats, targets)            # weighted, like maskformer_model.py:226-231
@@ -418,6 +443,66 @@ def test_amp_path_own_matching_against_the_fp32_matching(name):
     # so the bound is on the regret, the agreement share is only required not to collapse
     assert share >= 0.5, (share, regrets)
     assert max(regrets) <= 6e-2 and np.mean(regrets) <= 8e-3, regrets
+
+
+@pytest.mark.parametrize("name", ["head_deep", "head_cfgA", "head_ragged"])
+def test_amp_matching_on_bf16_rounded_maps_as_the_reference_samples_them(name):
+    """``HungarianMatcher.reference_amp_rounding``: under autocast the reference's matcher point-samples the
+    bf16-ROUNDED prediction maps (matcher.py:120-132 after the autocast einsum, mask2former_transformer_decoder.py:1865); the
+    default here samples fp32-class logits from the factors.  With the switch on, the cost matrices come from the materialised
+    bf16 maps.  Same autocast forward, same replayed draws, both cost matrices: the share of (output, image, target) assignments
+    that agree and the regret of one assignment under the other's costs are reported and bounded; the costs themselves agree to
+    bf16's resolution."""
+    from scipy.optimize import linear_sum_assignment
+    from mp_former_amd import _lib, _rng
+    from mp_former_amd.matcher import GTMasks
+    dev = torch.device("cuda:0")
+    z, cfg, pp, dp, feats, targets, replay = load_head_fixture(name)
+    h = _build(cfg, pp, dp, dev)
+    feats = {k: _planes_leaf(v, dev) for k, v in feats.items()}
+    targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+    use_dn = "dn_pred_logits" in z
+    matcher = h.criterion.matcher
+    orig = matcher.cost_matrices
+    got, kern = [], []
+    import os
+    os.environ["MPF_DEVICE_LSA"] = "0"
+    try:
+        matcher.cost_matrices = lambda *a, **k: got.append(orig(*a, **k)) or kern.append(_lib.last_kernel()) or got[-1]
+        for rounding in (False, True):
+            matcher.reference_amp_rounding = rounding
+            _rng.install_replay(fifo_to_tags(replay, cfg, use_dn))
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                h(feats, targets)
+    finally:
+        matcher.cost_matrices = orig
+        matcher.reference_amp_rounding = False
+        _rng.install_replay(None)
+        os.environ.pop("MPF_DEVICE_LSA", None)
+    assert len(got) == 2 and got[0] is not None
+    cf, cr = (c.float().cpu().numpy() for c in got)
+    counts = GTMasks(targets).counts
+    agree, total, regrets, rel = 0, 0, [], []
+    for l in range(cf.shape[0]):
+        for b, t in enumerate(counts):
+            if t == 0:
+                continue
+            a1, a2 = cf[l, b, :, :t], cr[l, b, :, :t]
+            rel.append(float(np.abs(a1 - a2).max() / max(np.abs(a1).max(), 1e-6)))
+            i1, j1 = linear_sum_assignment(a1)
+            i2, j2 = linear_sum_assignment(a2)
+            q1, q2 = np.empty(t, np.int64), np.empty(t, np.int64)
+            q1[j1], q2[j2] = i1, i2
+            agree += int((q1 == q2).sum())
+            total += t
+            best = a2[i2, j2].sum()
+            regrets.append(float((a2[i1, j1].sum() - best) / max(abs(best), 1e-6)))
+    share = agree / max(total, 1)
+    print(f"{name}: factor-sampled vs bf16-map-sampled matching agree on {agree}/{total} targets ({share:.3f}); cost difference max "
+          f"{max(rel):.2e} of the matrix maximum; regret of the default assignment under the reference-rounded costs: max {max(regrets):.4f} "
+          f"mean {np.mean(regrets):.5f}")
+    assert max(rel) <= 2e-2, rel                    # bf16 rounding of the logits: 2^-9 relative per logit, accumulated over 12 544 points
+    assert share >= 0.5 and max(regrets) <= 6e-2, (share, regrets)
 
 
 def test_amp_forward_is_bit_reproducible_run_to_run():
