@@ -77,6 +77,7 @@ int g_ablate = 0;      // mpf_set_option("gemm3_ablate"): reserved for timing ex
 int g_mixed = 1;       // mpf_set_option("gemm3_mixed_tiles"): 128 x 64 tiles for the last partial round
 int g_two_pass = 256;  // mpf_set_option("gemm3_two_pass"): N >= this and N % 256 == 0 -> 128 x 256 / 96 x 256 two-pass tiles (0 = off)
 int g_two_pass_rows = 0;   // mpf_set_option("gemm3_two_pass_rows"): 0 = pick 128 or 96 rows per tile by rounds, else force
+int g_nt2 = 1;             // mpf_set_option("gemm3_nt2"): grouped fp16 x 2 weight gradients with all dimensions % 256 == 0 on 256 x 256 tiles (0 = 128 x 128)
 int g_ws = 512;            // mpf_set_option("gemm3_ws"): K = 256, N % 256 == 0, N >= this: fp16 x 2 products on the weight-stationary kernel (0 = never)
 
 #ifdef G3_TIMING
@@ -1421,6 +1422,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm3_nt_group_kernel(G3NG g)
     gemm3_nt_tile<128, false, false, false, false, H2>(g.it[i], tile - first);
 }
 
+#include "gemm3_nt2.h"
+
 // W[R,C] fp32 -> planes[3][R][C] (transpose = 0) or planes[3][C][R] (transpose = 1), bf16 bits
 __global__ __launch_bounds__(256) void gemm3_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ out,
                                                           int R, int C, int transpose)
@@ -1603,6 +1606,7 @@ int mpf::set_gemm3_option(const char* key, int v)
     if (!strcmp(key, "gemm3_two_pass")) { g_two_pass = v; return 0; }
     if (!strcmp(key, "gemm3_two_pass_rows")) { g_two_pass_rows = v; return 0; }
     if (!strcmp(key, "gemm3_ws")) { g_ws = v; return 0; }
+    if (!strcmp(key, "gemm3_nt2")) { g_nt2 = v; return 0; }
     if (strcmp(key, "gemm3_ablate") != 0) return 1;
     g_ablate = v;
     return 0;
@@ -2052,6 +2056,8 @@ static int g3_nt_grouped_impl(const Item* items, int n_items, int R, int rows_pe
     const int nsplit = (R + rows_per_split - 1) / rows_per_split;
     int tiles = 0;
     double bytes = 0.0, flops = 0.0;
+    bool big = H2 && g_nt2;                          // 256 x 256 tiles (gemm3_nt2.h): every dimension a multiple of 256
+    for (int i = 0; i < n_items && big; ++i) big = items[i].Mdim % 256 == 0 && items[i].Ndim % 256 == 0 && items[i].Mdim > 0 && items[i].Ndim > 0;
     for (int i = 0; i < n_items; ++i) {
         const Item& it = items[i];
         if (!it.a || !it.b || !it.c_part) return mpf::fail(MPF_E_NULL, "gemm3_nt_grouped: NULL buffer");
@@ -2067,8 +2073,8 @@ static int g3_nt_grouped_impl(const Item* items, int n_items, int R, int rows_pe
         if (ab >= (1ull << 32) || bb >= (1ull << 32) || it.lda * 4 >= (1ll << 31) || it.ldb * 4 >= (1ll << 31))
             return mpf::fail(MPF_E_TOO_LARGE, "gemm3_nt_grouped: an operand spans 4 GiB or more");
         p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
-        p.tiles_m = (p.Mdim + kBM - 1) / kBM;
-        p.tiles_n = (p.Ndim + 127) / 128;
+        p.tiles_m = big ? p.Mdim / 256 : (p.Mdim + kBM - 1) / kBM;
+        p.tiles_n = big ? p.Ndim / 256 : (p.Ndim + 127) / 128;
         p.ntiles = p.tiles_m * p.tiles_n * nsplit;
         p.c_ss = p.csa_ss = split_stride; p.csb_ss = 0;
         p.a_amax = nullptr; p.b_amax = nullptr;
@@ -2082,6 +2088,15 @@ static int g3_nt_grouped_impl(const Item* items, int n_items, int R, int rows_pe
         flops += 2.0 * R * (double)p.Mdim * p.Ndim;
     }
     g.n_items = n_items; g.ntiles = tiles;
+    if (big) {
+        static mpf::LdsAttr attr;
+        if (int e = mpf::ensure_dynamic_lds((const void*)gemm3_nt2_group_kernel, kN2Lds, attr)) return e;
+        mpf::prof_begin(st);
+        mpf::set_kernel("gemm3_nt_group_kernel<h2 256x256>");
+        hipLaunchKernelGGL(gemm3_nt2_group_kernel, dim3(((tiles + 7) / 8) * 8), dim3(kN2T), kN2Lds, st, g);
+        mpf::prof_end(mpf_last_kernel(), st, bytes, flops);
+        return mpf::check(hipGetLastError(), "mpf_gemm3_nt_grouped(256x256)");
+    }
     mpf::prof_begin(st);
     mpf::set_kernel(H2 ? "gemm3_nt_group_kernel<h2>" : "gemm3_nt_group_kernel");
     hipLaunchKernelGGL(gemm3_nt_group_kernel<H2>, dim3(((tiles + 7) / 8) * 8), dim3(kThreads), 0, st, g);

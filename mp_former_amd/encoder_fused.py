@@ -126,7 +126,11 @@ def _wgrad_group(pairs, amax_pairs=None):
     if slots is None:
         slots = _slots[dev] = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
     tiles = sum(((g.shape[1] + 127) // 128) * ((x.shape[1] + 127) // 128) for g, x in pairs)
-    if amax_pairs is not None:
+    if amax_pairs is not None and all(g.shape[1] % 256 == 0 and x.shape[1] % 256 == 0 for g, x in pairs):
+        # 256 x 256 tiles (csrc/gemm3_nt2.h): one 8-wave workgroup per CU, half the operand traffic of the 128 x 128 tiles
+        tiles = sum((g.shape[1] // 256) * (x.shape[1] // 256) for g, x in pairs)
+        slots = slots // 2
+    elif amax_pairs is not None:
         slots = slots // 2 * 3        # the fp16 x 2 kernel (159 registers, 32 KB of LDS) is resident three times per CU: measured
     ns = max(1, slots // tiles)       # 1.81 -> 1.45 ms/step against splits sized for two (and 1.86 for four)
     rps = max(128, ((-(-R // ns)) + 31) // 32 * 32)
