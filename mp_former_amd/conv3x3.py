@@ -100,6 +100,9 @@ def _wgrad_native(gy, x, N, H, W, Cin, Cout, has_bias, amax_ab=None):
     tiles = ((Cout + 127) // 128) * (9 * Cin // 128)
     slots = 2 * torch.cuda.get_device_properties(x.device).multi_processor_count
     ns = max(1, (3 * slots) // tiles)                       # ~3 rounds of workgroups: measured best at 256 -> 256 channels
+    if amax_ab is not None and Cout % 256 == 0 and Cin % 256 == 0:
+        # 256 x 256 tiles (csrc/gemm3_nt2.h): one 8-wave workgroup per CU, one round
+        ns = max(1, (slots // 2) // ((Cout // 256) * (9 * Cin // 256)))
     rps = max(128, ((-(-R // ns)) + 31) // 32 * 32)
     ns = -(-R // rps)
     c = torch.empty((ns, Cout, 9 * Cin), dtype=torch.float32, device=x.device)

@@ -2227,8 +2227,20 @@ static int g3_conv_wgrad_impl(const float* dy, const float* x, float* c_part, fl
     p.tiles_n = 9 * Cin / 128;
     p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
     p.c_ss = (int64_t)p.Mdim * p.Ndim; p.csa_ss = p.Mdim; p.csb_ss = p.Ndim;
-    mpf::prof_begin(st);
     p.a_amax = dy_amax; p.b_amax = x_amax;
+    if (dy_amax && g_nt2 && Cout % 256 == 0 && Cin % 256 == 0) {       // 256 x 256 tiles (gemm3_nt2.h): half the operand traffic
+        p.tiles_m = Cout / 256; p.tiles_n = 9 * Cin / 256;
+        p.ntiles = p.tiles_m * p.tiles_n * p.nsplit;
+        static mpf::LdsAttr attr;
+        if (int e = mpf::ensure_dynamic_lds((const void*)gemm3_nt2_conv_kernel, kN2Lds, attr)) return e;
+        mpf::prof_begin(st);
+        mpf::set_kernel("gemm3_nt_kernel<conv3x3 h2 256x256>");
+        hipLaunchKernelGGL(gemm3_nt2_conv_kernel, dim3(((p.ntiles + 7) / 8) * 8), dim3(kN2T), kN2Lds, st, p);
+        mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)p.R * Cout + (double)p.R * Cin + (double)p.nsplit * Cout * 9 * Cin),
+                      2.0 * p.R * (double)Cout * 9 * Cin);
+        return mpf::check(hipGetLastError(), "mpf_gemm3_conv3x3_wgrad(256x256)");
+    }
+    mpf::prof_begin(st);
     mpf::set_kernel(dy_amax ? "gemm3_nt_kernel<conv3x3 h2>" : "gemm3_nt_kernel<conv3x3>");
     if (dy_amax) hipLaunchKernelGGL((gemm3_nt_kernel<128, false, true, false, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);
     else hipLaunchKernelGGL((gemm3_nt_kernel<128, false, true>), dim3(((p.ntiles + 7) / 8) * 8), dim3(kThreads), 0, st, p);

@@ -56,6 +56,10 @@ struct AccN2 {
     }
 };
 
+// CV: the weight gradient of a 3x3 / stride 1 / padding 1 convolution of channel-last images (gemm3_nt_tile's CV mode): the
+// column tile fixes the tap (Cin % 256 == 0), B = the input image read at the rows shifted by the tap, taps off the image zeroed
+// (W % 8 == 0: the 8 rows of a k-chunk lie in one image row).
+template <bool CV>
 __device__ __forceinline__ void gemm3_nt2_tile(const G3N& p, const int tile, unsigned char* lds)
 {
     float sc_a, sc_b, inv_a, inv_b;
@@ -72,8 +76,19 @@ __device__ __forceinline__ void gemm3_nt2_tile(const G3N& p, const int tile, uns
     const int col = tid & 255, kc0 = __builtin_amdgcn_readfirstlane(tid >> 8);
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, p.b_bytes, 0x00020000);
-    const int acolb = (m0 + col) * 4, bcolb = (n0 + col) * 4;
+    const int acolb = (m0 + col) * 4, bcolb = (CV ? (n0 % p.cv_cin) + col : n0 + col) * 4;
     const int ldab = (int)p.lda * 4, ldbb = (int)p.ldb * 4;
+    // CV: tap of this column tile; image coordinates of the first row of the thread's two k-chunks (advanced by 32 rows per step)
+    int cv_dy = 0, cv_dx = 0, cv_sh = 0, cvx0 = 0, cvy0 = 0, cvx1 = 0, cvy1 = 0;
+    if constexpr (CV) {
+        const int tap = n0 / p.cv_cin;
+        cv_dy = tap / 3 - 1; cv_dx = tap % 3 - 1;
+        cv_sh = cv_dy * p.cv_W + cv_dx;
+        const int rb0 = r_begin + kc0 * 8, rb1 = rb0 + 16;
+        cvx0 = rb0 % p.cv_W; cvy0 = (rb0 / p.cv_W) % p.cv_H;
+        cvx1 = rb1 % p.cv_W; cvy1 = (rb1 / p.cv_W) % p.cv_H;
+    }
+    (void)cv_dy; (void)cv_dx; (void)cv_sh;
     // operand values of the NEXT K step (this thread's 2 + 2 items of 8 rows), requested as soon as the split has consumed the
     // current ones.  (Two alternating register sets — loads two steps ahead — were built: 64 + 128 accumulator registers + fragments do
     // not fit 256, 170-210 spilled registers.)
@@ -96,11 +111,21 @@ __device__ __forceinline__ void gemm3_nt2_tile(const G3N& p, const int tile, uns
     {                                                                                                            \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                          \
             const int q0 = (r0) + kc0 * 8 + j, q1 = q0 + 16;                                                     \
-            const int c0 = TAIL ? min(q0, r_end - 1) : q0, c1 = TAIL ? min(q1, r_end - 1) : q1;                  \
+            int c0 = TAIL ? min(q0, r_end - 1) : q0, c1 = TAIL ? min(q1, r_end - 1) : q1;                        \
+            if constexpr (CV) { c0 = min(max(c0 + cv_sh, 0), p.R - 1); c1 = min(max(c1 + cv_sh, 0), p.R - 1); }  \
             float vb0 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, bcolb, c0 * ldbb, 0));          \
             float vb1 = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(brs, bcolb, c1 * ldbb, 0));          \
+            if constexpr (CV) {                                                                                  \
+                const bool ok0 = (unsigned)(cvy0 + cv_dy) < (unsigned)p.cv_H && (unsigned)(cvx0 + j + cv_dx) < (unsigned)p.cv_W; \
+                const bool ok1 = (unsigned)(cvy1 + cv_dy) < (unsigned)p.cv_H && (unsigned)(cvx1 + j + cv_dx) < (unsigned)p.cv_W; \
+                vb0 = ok0 ? vb0 : 0.f; vb1 = ok1 ? vb1 : 0.f;                                                    \
+            }                                                                                                    \
             if (TAIL) { vb0 = q0 < r_end ? vb0 : 0.f; vb1 = q1 < r_end ? vb1 : 0.f; }                            \
             xb0[j] = vb0; xb1[j] = vb1;                                                                          \
+        }                                                                                                        \
+        if constexpr (CV) {      /* the next K step is 32 rows further */                                        \
+            cvx0 += kBK; while (cvx0 >= p.cv_W) { cvx0 -= p.cv_W; cvy0 = cvy0 + 1 == p.cv_H ? 0 : cvy0 + 1; }    \
+            cvx1 += kBK; while (cvx1 >= p.cv_W) { cvx1 -= p.cv_W; cvy1 = cvy1 + 1 == p.cv_H ? 0 : cvy1 + 1; }    \
         }                                                                                                        \
     }
 #define N2_LOAD(r0, TAIL) { N2_LOAD_A(r0, TAIL) N2_LOAD_B(r0, TAIL) }
@@ -178,5 +203,14 @@ __global__ __launch_bounds__(kN2T, 2) void gemm3_nt2_group_kernel(G3NG g)
     int i = 0;
     while (i + 1 < g.n_items && tile >= g.tile_end[i]) ++i;
     const int first = i ? g.tile_end[i - 1] : 0;
-    gemm3_nt2_tile(g.it[i], tile - first, n2_lds);
+    gemm3_nt2_tile<false>(g.it[i], tile - first, n2_lds);
+}
+
+__global__ __launch_bounds__(kN2T, 2) void gemm3_nt2_conv_kernel(G3N p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char n2_lds[];
+    const int per_xcd = (p.ntiles + 7) >> 3;
+    const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (tile >= p.ntiles) return;
+    gemm3_nt2_tile<true>(p, tile, n2_lds);
 }
