@@ -414,7 +414,7 @@ def main():
     # inside the process, so the file carries the hash of the kernel source it was measured on and is REFUSED (traffic =
     # null) when the kernels have changed since
     traffic, traffic_note = None, "no PMC file for this shape"
-    pmc_file = os.path.join(ROOT, "profiles", "r04_msda_bwd_pmc_configB_N2.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r05_msda_bwd_pmc_configB_N2.json")
     if hw == (1024, 1024) and a.batch == 2 and os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
         src = os.path.join(ROOT, "mp_former_amd", "csrc", "msda_block.hip")

@@ -3,7 +3,7 @@
 # prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass), with FETCH_SIZE / WRITE_SIZE calibrated on kernels that
 # move a known byte count in the same access shapes (tools/ubench/fetch_calib.hip).  Run on the GPU box from the repo
 # root; writes gpurun_out/${TAG}_msda_bwd_pmc_configB_N2.json (TAG defaults to r04; copy the file to profiles/).
-TAG=${1:-r04}
+TAG=${1:-r05}
 export PMC_TAG=$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
