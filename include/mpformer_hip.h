@@ -1048,6 +1048,41 @@ int mpf_profile_get(const char* name_substr, int* count, double* total_ms, doubl
 /* summed ALGORITHMIC floating-point operations of the same launches (kernels that are priced against the MFMA peak) */
 int mpf_profile_get_flops(const char* name_substr, double* total_flops);
 
+/*
+ * The forward of the pixel decoder's encoder layers (msdeformattn.py:92-161 x num_layers; ops/modules/ms_deform_attn.py:82-125
+ * inside; dropout inactive, fp32, 8 heads x 32 channels) as ONE call: per layer the fixed sequence value_proj -> 288-wide
+ * offsets | weights projection -> mpf_msda_forward_raw_hs -> output_proj + residual -> norm1 -> linear1 + ReLU (+ bit mask) ->
+ * linear2 + residual -> norm2 (+ q of the next layer), on the entry points above with the arguments the python glue
+ * (mp_former_amd/encoder_fused.py) used to pass one by one.  `layers` is a HOST table [n_layers][MPF_ENC_FIELDS] of device
+ * addresses: weight planes / amax slots (mpf_gemm3_split_grouped_h2), fp32 vectors, the tensors the layer writes (all kept
+ * for the backward) and its amax slots (zeroed by the caller).  Never allocates, never synchronises.
+ */
+enum {
+    MPF_ENC_PV, MPF_ENC_PV_AM, MPF_ENC_PO, MPF_ENC_PO_AM, MPF_ENC_P1, MPF_ENC_P1_AM, MPF_ENC_P2, MPF_ENC_P2_AM, MPF_ENC_P288, MPF_ENC_P288_AM,
+    MPF_ENC_BV, MPF_ENC_BO, MPF_ENC_BB1, MPF_ENC_BB2, MPF_ENC_B288, MPF_ENC_G1, MPF_ENC_B1, MPF_ENC_G2, MPF_ENC_B2,
+    MPF_ENC_VALUE, MPF_ENC_RAW, MPF_ENC_LOC, MPF_ENC_ATTN, MPF_ENC_AO, MPF_ENC_S1, MPF_ENC_MEAN1, MPF_ENC_RSTD1, MPF_ENC_X1, MPF_ENC_H,
+    MPF_ENC_HBITS, MPF_ENC_S2, MPF_ENC_MEAN2, MPF_ENC_RSTD2, MPF_ENC_X2, MPF_ENC_QN,
+    MPF_ENC_AO_AM, MPF_ENC_X1_AM, MPF_ENC_H_AM, MPF_ENC_XN_AM, MPF_ENC_QN_AM,
+    MPF_ENC_FIELDS
+};
+typedef struct MpfEncoderCall {
+    int32_t N, S, M, L, P, nl, F, reserved;   /* images, tokens per image, heads (8), levels, points, layers, ffn width */
+    float eps, pad_;
+    const int64_t* host_shapes;               /* [L][2] (H, W) on the host */
+    const void* shapes_dev;                   /* the same on the device (int64) */
+    const void* lsi_dev;                      /* level_start_index (int64, device) */
+    const float* ref;                         /* reference points [S][2] */
+    const float* pos_full;                    /* [S][256] positional term (sine + level embedding); may be NULL for one layer */
+    const float* pos_am;                      /* its amax slot */
+    const float* x0;                          /* [N*S][256] input of layer 0 */
+    const float* x0_am;
+    const float* q0;                          /* x0 + pos */
+    const float* q0_am;
+    const uint64_t* layers;                   /* HOST table [nl][MPF_ENC_FIELDS] */
+} MpfEncoderCall;
+int mpf_encoder_fields(void);                 /* MPF_ENC_FIELDS of the library (layout check of the binding) */
+int mpf_encoder_forward(const MpfEncoderCall* call, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

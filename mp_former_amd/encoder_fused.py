@@ -17,12 +17,15 @@ Used by ``MSDeformAttnTransformerEncoderOnly`` when the inputs are fp32 CUDA ten
 inactive; ``MPF_FUSED_ENCODER=0`` selects the layer-by-layer modules (same results to fp32 round-off;
 tests/test_encoder_fused_gpu.py).
 """
+import ctypes
 import math
 import os
 
+import numpy as np
 import torch
 from torch.autograd import Function
 
+from . import _lib
 from .gemm3 import amax, amax_slots, gemm3_h2, gemm3_h2_bits, gemm3_nt, gemm3_nt_grouped, nt_reduce_levels, split_weights_grouped_h2
 from .msda import ms_deform_attn_backward_raw, ms_deform_attn_forward_raw
 from .resln import LnGradGroup, ln256_forward
@@ -137,6 +140,93 @@ def _wgrad_group(pairs, amax_pairs=None):
     return gemm3_nt_grouped(pairs, rps, amax_pairs)
 
 
+# ---- native forward: one call for all layers (csrc/encoder_layer.hip) -------------------------------------------------------
+_ENC_FIELDS = ("pv", "pv_am", "po", "po_am", "p1", "p1_am", "p2", "p2_am", "p288", "p288_am", "bv", "bo", "bb1", "bb2", "b288", "g1", "b1",
+               "g2", "b2", "value", "raw", "loc", "attn", "ao", "s1", "mean1", "rstd1", "x1", "h", "hbits", "s2", "mean2", "rstd2", "x2", "qn",
+               "ao_am", "x1_am", "h_am", "xn_am", "qn_am")
+_ENC_IDX = {k: i for i, k in enumerate(_ENC_FIELDS)}
+_NATIVE_FWD = os.environ.get("MPF_ENCODER_NATIVE", "1") != "0"        # (0: the python-sequenced forward the tests compare with)
+
+
+class MpfEncoderCall(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int32), ("S", ctypes.c_int32), ("M", ctypes.c_int32), ("L", ctypes.c_int32), ("P", ctypes.c_int32),
+                ("nl", ctypes.c_int32), ("F", ctypes.c_int32), ("reserved", ctypes.c_int32), ("eps", ctypes.c_float), ("pad_", ctypes.c_float),
+                ("host_shapes", ctypes.c_void_p), ("shapes_dev", ctypes.c_void_p), ("lsi_dev", ctypes.c_void_p), ("ref", ctypes.c_void_p),
+                ("pos_full", ctypes.c_void_p), ("pos_am", ctypes.c_void_p), ("x0", ctypes.c_void_p), ("x0_am", ctypes.c_void_p),
+                ("q0", ctypes.c_void_p), ("q0_am", ctypes.c_void_p), ("layers", ctypes.c_void_p)]
+
+
+_arena_layouts = {}
+
+
+def _arena_layout(R, C, F, no, M, L, P):
+    """float offsets of a layer's results inside its slice of the arena (every tensor 16-byte aligned); -> ({name: (offset, numel)}, floats per layer)"""
+    key = (R, C, F, no, M, L, P)
+    hit = _arena_layouts.get(key)
+    if hit is None:
+        sizes = (("value", R * C), ("raw", R * no), ("loc", R * M * L * P * 2), ("attn", R * M * L * P), ("ao", R * C), ("s1", R * C),
+                 ("mean1", R), ("rstd1", R), ("x1", R * C), ("h", R * F), ("hbits", R * F // 32), ("s2", R * C), ("mean2", R), ("rstd2", R),
+                 ("x2", R * C), ("qn", R * C))
+        offs, tot = {}, 0
+        for name, n in sizes:
+            offs[name] = (tot, n)
+            tot += (n + 3) // 4 * 4
+        hit = _arena_layouts[key] = (offs, tot)
+    return hit
+
+
+def _native_forward(x, q, x_am, q_am, pos_full, pos_am, params, planes2, b288_all, am, meta, nl, dims, F):
+    """The forward of all layers as ONE native call; returns (arena [nl, floats per layer], layout)."""
+    N, S, C = dims
+    R = N * S
+    M, L, P = meta["n_heads"], meta["n_levels"], meta["n_points"]
+    no = M * L * P * 3
+    lib = _lib.lib()
+    if lib.mpf_encoder_fields() != len(_ENC_FIELDS):
+        raise RuntimeError("MpfEncoderCall field table differs between encoder_fused.py and libmpformer_hip.so")
+    offs, per = _arena_layout(R, C, F, no, M, L, P)
+    arena = torch.empty((nl, per), dtype=torch.float32, device=x.device)
+    base = arena.data_ptr()
+    tab = np.zeros((nl, len(_ENC_FIELDS)), dtype=np.uint64)
+    lay = np.asarray([offs[k][0] for k in ("value", "raw", "loc", "attn", "ao", "s1", "mean1", "rstd1", "x1", "h", "hbits", "s2", "mean2",
+                                           "rstd2", "x2", "qn")], dtype=np.uint64) * 4
+    c0 = _ENC_IDX["value"]
+    am0 = am.data_ptr() if isinstance(am, torch.Tensor) else None
+    for i in range(nl):
+        (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2_, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
+        (pv, pv_am), (po, po_am), (p1, p1_am), (p2, p2_am), (p288, p288_am) = planes2[10 * i:10 * i + 5]
+        row = tab[i]
+        row[0:10] = (pv.data_ptr(), pv_am.data_ptr(), po.data_ptr(), po_am.data_ptr(), p1.data_ptr(), p1_am.data_ptr(), p2.data_ptr(),
+                     p2_am.data_ptr(), p288.data_ptr(), p288_am.data_ptr())
+        row[10:19] = (bv.data_ptr(), bo.data_ptr(), bb1.data_ptr(), bb2.data_ptr(), b288_all[i].data_ptr(), g1.data_ptr(), b1.data_ptr(),
+                      g2_.data_ptr(), b2.data_ptr())
+        row[c0:c0 + 16] = np.uint64(base + i * per * 4) + lay
+        row[_ENC_IDX["ao_am"]:_ENC_IDX["ao_am"] + 5] = [am[5 * i + k].data_ptr() for k in range(5)]
+    host_shapes = meta["shapes"]._mpf_host
+    call = MpfEncoderCall(N, S, M, L, P, nl, F, 0, _EPS, 0.0, host_shapes.data_ptr(), meta["shapes"].data_ptr(), meta["lsi"].data_ptr(),
+                          meta["ref"].data_ptr(), pos_full.data_ptr(), pos_am.data_ptr(), x.data_ptr(), x_am.data_ptr(), q.data_ptr(),
+                          q_am.data_ptr(), tab.ctypes.data)
+    with _lib.device_guard(x.device):
+        code = lib.mpf_encoder_forward(ctypes.byref(call), _lib.stream_ptr(x.device))
+    _lib.check(code, "mpf_encoder_forward")
+    del am0
+    return arena, offs
+
+
+def _arena_views(arena, offs, i, R, C, F, no, dims, M, L, P):
+    """the saved tensors of layer i as views of its arena slice"""
+    N, S, _ = dims
+    a = arena[i]
+
+    def v(name, *shape):
+        o, n = offs[name]
+        return a[o:o + n].view(*shape)
+    hb = a[offs["hbits"][0]:offs["hbits"][0] + offs["hbits"][1]].view(torch.uint8).view(R, F // 8)
+    return dict(value=v("value", R, C), loc=v("loc", N, S, M, L, P, 2), attn=v("attn", N, S, M, L, P), ao=v("ao", R, C), s1=v("s1", R, C),
+                mean1=v("mean1", R), rstd1=v("rstd1", R), x1=v("x1", R, C), h=v("h", R, F), hbits=hb, s2=v("s2", R, C), mean2=v("mean2", R),
+                rstd2=v("rstd2", R), x2=v("x2", R, C), qn=v("qn", R, C))
+
+
 class EncoderFn(Function):
     @staticmethod
     def forward(ctx, src, pos_const, level_embed, meta, *params):
@@ -167,6 +257,23 @@ class EncoderFn(Function):
         # attention output bounded by max |value| (a convex combination of value rows), the FFN hidden layer from its GEMM
         am = amax_slots(5 * nl + 3, src.device)          # per layer: ao, x1, h, the next layer's x, the next layer's q
         x_am, q_am, pos_am = amax(x, am[5 * nl]), am[5 * nl + 1], amax(pos_full, am[5 * nl + 2])
+        F_ = params[10].shape[0]                          # ffn width (linear1.weight [F, C])
+        use_native = (_NATIVE_FWD and RANGE_AUDIT is None and host_shapes is not None and C == 256 and M == 8 and F_ % 128 == 0
+                      and all(params[i * PARAMS_PER_LAYER + 10].shape[0] == F_ for i in range(nl)))
+        if use_native:
+            q = (x.view(N, S, C) + pos_full).view(R, C)
+            amax(q, q_am)
+            arena, offs = _native_forward(x, q, x_am, q_am, pos_full, pos_am, params, planes2, b288_all, am, meta, nl, (N, S, C), F_)
+            for i in range(nl):
+                t_ = _arena_views(arena, offs, i, R, C, F_, no * 3 // 2, (N, S, C), M, L, P)
+                ao_am, x1_am, h_am, xn_am, qn_am = am[5 * i:5 * i + 5]
+                saved += [x, q, t_["value"], t_["loc"], t_["attn"], t_["ao"], t_["s1"], t_["mean1"], t_["rstd1"], t_["x1"], t_["h"],
+                          t_["s2"], t_["mean2"], t_["rstd2"], x_am, ao_am, x1_am, h_am, q_am, t_["hbits"]]
+                x, q, x_am, q_am = t_["x2"], t_["qn"], xn_am, qn_am
+            ctx.save_for_backward(pos_full, level_embed, *params, *saved)
+            ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
+            ctx.planes_t = [planes2[10 * i + 5:10 * i + 10] for i in range(nl)]
+            return x.view(N, S, C)
         for i in range(nl):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2_, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             (pv, pv_am), (po, po_am), (p1, p1_am), (p2, p2_am), (p288, p288_am) = planes2[10 * i:10 * i + 5]

@@ -179,3 +179,46 @@ def test_fp16x2_encoder_at_config_B_size_with_learned_offsets():
           (max(v[0] for v in rows.values()), max(v[1] for v in rows.values())))
     bad = {k: v for k, v in rows.items() if not v[0] <= 3 * v[1] + 2e-6}
     assert not bad, f"fp16 x 2 encoder further from fp64 than 3 x the library-fp32 pipeline: {bad}"
+
+
+@pytest.mark.parametrize("shapes,batch,layers", [(((8, 8), (16, 16), (32, 32)), 2, 3), (((5, 7), (10, 14), (20, 28)), 1, 1), (((32, 32), (64, 64), (128, 128)), 2, 6)])
+def test_native_encoder_forward_is_bit_identical_to_the_python_sequenced_one(shapes, batch, layers):
+    """``mpf_encoder_forward`` (csrc/encoder_layer.hip: all layers of the forward as ONE native call writing into one arena)
+    against the python-sequenced forward it replaces (one ctypes call and one allocation per kernel): the same kernels with the
+    same arguments in the same order — the output and every gradient (the backward reads the arena views) bit for bit, incl.
+    config B's size and a single layer (no next-layer q) — the forward bit for bit, the gradients to round-off."""
+    from mp_former_amd import _lib, encoder_fused
+    from mp_former_amd import pixel_decoder as PD
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    enc = PD.MSDeformAttnTransformerEncoderOnly(d_model=256, nhead=8, num_encoder_layers=layers, dim_feedforward=1024, dropout=0.0,
+                                                num_feature_levels=3).to(dev).train()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if "sampling_offsets.weight" in n or "attention_weights" in n:
+                p.normal_(0, 0.05)
+    srcs = [torch.randn(batch, 256, h, w, device=dev) for h, w in shapes]
+    pe = PD.PositionEmbeddingSine(128, normalize=True)
+    pos = [pe(s) for s in srcs]
+    go = torch.randn(batch, sum(h * w for h, w in shapes), 256, device=dev)
+    res = {}
+    _lib.set_option("msda_bwd_sorted", 1)              # (the MSDA backward's grad_value depends on the arrival order of the tile entries otherwise)
+    for native in (False, True):
+        encoder_fused._NATIVE_FWD = native
+        try:
+            _lib.profile_enable(True)
+            res[native] = _run(enc, srcs, pos, go, fused=True)
+            n_calls = _lib.profile_get("gemm3_tn_kernel")[0]
+            _lib.profile_enable(False)
+            assert n_calls > 0
+        finally:
+            encoder_fused._NATIVE_FWD = True
+    _lib.set_option("msda_bwd_sorted", 0)
+    (m0, gx0, gp0), (m1, gx1, gp1) = res[False], res[True]
+    assert torch.equal(m0, m1)                       # the forward: bit for bit
+    # the backward is the same python code on the same saved values (views of the arena instead of separate tensors); it is not
+    # bit-reproducible run to run by itself (fp32 reassociation in the weight-gradient reductions), so: equal to round-off
+    for a, b in zip(gx0, gx1):
+        assert float((a - b).norm() / a.norm()) < 1e-6
+    for n in gp0:
+        assert float((gp0[n] - gp1[n]).norm() / (gp0[n].norm() + 1e-30)) < 1e-5, n
