@@ -1083,6 +1083,46 @@ typedef struct MpfEncoderCall {
 int mpf_encoder_fields(void);                 /* MPF_ENC_FIELDS of the library (layout check of the binding) */
 int mpf_encoder_forward(const MpfEncoderCall* call, void* stream);
 
+/*
+ * The backward of the same layers as ONE call (last layer first).  `layers`: HOST table [n_layers][MPF_ENCB_FIELDS] of device
+ * addresses — what the forward kept (the arena of mpf_encoder_forward), the planes of the TRANSPOSED weights, the layer's amax
+ * slots (zeroed by the caller) and its results: WGRAD = [dW2 | db2 | dW1 | db1 | dWo | dbo | dWv | dbv] (group_stride floats),
+ * DW288 [288][256], LVL [L][288] (per-level column sums of d raw), DB288 [288].  The temporaries are shared by all layers;
+ * g[(layer) & 1] receives the gradient handed to the layer below (g[0] after the call: the gradient of the encoder's input),
+ * dgb_out [2 n_layers][2][256] the LayerNorm parameter gradients in call order (norm2, norm1 of layers n-1 .. 0).
+ * rps288 / rps_group: rows per split of the 288-wide / the grouped weight gradients (multiples of 32; rps288 must not straddle
+ * a level: split_level[s] = level of split s, int64 on the device).
+ */
+enum {
+    MPF_ENCB_X, MPF_ENCB_Q, MPF_ENCB_VALUE, MPF_ENCB_LOC, MPF_ENCB_ATTN, MPF_ENCB_AO, MPF_ENCB_S1, MPF_ENCB_MEAN1, MPF_ENCB_RSTD1, MPF_ENCB_X1,
+    MPF_ENCB_H, MPF_ENCB_HBITS, MPF_ENCB_S2, MPF_ENCB_MEAN2, MPF_ENCB_RSTD2,
+    MPF_ENCB_X_AM, MPF_ENCB_Q_AM, MPF_ENCB_AO_AM, MPF_ENCB_X1_AM, MPF_ENCB_H_AM,
+    MPF_ENCB_G1, MPF_ENCB_G2,
+    MPF_ENCB_TV, MPF_ENCB_TV_AM, MPF_ENCB_TO, MPF_ENCB_TO_AM, MPF_ENCB_T1, MPF_ENCB_T1_AM, MPF_ENCB_T2, MPF_ENCB_T2_AM, MPF_ENCB_T288, MPF_ENCB_T288_AM,
+    MPF_ENCB_DS2_AM, MPF_ENCB_DH_AM, MPF_ENCB_DS1_AM, MPF_ENCB_DRAW_AM, MPF_ENCB_GV_AM,
+    MPF_ENCB_WGRAD, MPF_ENCB_DW288, MPF_ENCB_LVL, MPF_ENCB_DB288,
+    MPF_ENCB_FIELDS
+};
+typedef struct MpfEncoderBwdCall {
+    int32_t N, S, M, L, P, nl, F, rps288, rps_group, reserved;
+    int64_t group_stride;                     /* floats of one split of the grouped weight gradients = of WGRAD */
+    const int64_t* host_shapes;
+    const float* gout;                        /* [N*S][256] gradient of the encoder's output */
+    const int64_t* split_level;               /* device, [ceil(N*S / rps288)] */
+    float *ds2, *dh, *dx1, *ds1, *dao, *gv, *draw;    /* temporaries: [R][256] ([R][F] for dh, [R][288] for draw) */
+    float* dq[2];
+    float* g[2];
+    float *cpart288, *cs288, *part_group;     /* [ns288][288*256], [ns288][288], [ns_group][group_stride] */
+    void* ln_parts;                           /* 2 n_layers slots of ln_stride bytes (mpf_res_ln256_backward_workspace_bytes, 256-aligned) */
+    uint64_t ln_stride;
+    void* msda_ws;                            /* mpf_msda_backward_workspace_bytes */
+    uint64_t msda_ws_bytes;
+    float* dgb_out;
+    const uint64_t* layers;                   /* HOST table [nl][MPF_ENCB_FIELDS] */
+} MpfEncoderBwdCall;
+int mpf_encoder_bwd_fields(void);
+int mpf_encoder_backward(const MpfEncoderBwdCall* call, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

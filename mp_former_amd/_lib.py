@@ -91,6 +91,8 @@ SIGNATURES = {
                                      ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_encoder_fields": (_c_int, []),
     "mpf_encoder_forward": (_c_int, [_c_vp, _c_vp]),
+    "mpf_encoder_bwd_fields": (_c_int, []),
+    "mpf_encoder_backward": (_c_int, [_c_vp, _c_vp]),
     "mpf_decoder_layer_struct_bytes": (ctypes.c_uint64, [_c_int]),
     "mpf_decoder_layer_scratch_bytes": (ctypes.c_uint64, [_c_int] * 6),
     "mpf_decoder_layer_forward": (_c_int, [_c_vp, _c_vp]),

@@ -145,7 +145,8 @@ _ENC_FIELDS = ("pv", "pv_am", "po", "po_am", "p1", "p1_am", "p2", "p2_am", "p288
                "g2", "b2", "value", "raw", "loc", "attn", "ao", "s1", "mean1", "rstd1", "x1", "h", "hbits", "s2", "mean2", "rstd2", "x2", "qn",
                "ao_am", "x1_am", "h_am", "xn_am", "qn_am")
 _ENC_IDX = {k: i for i, k in enumerate(_ENC_FIELDS)}
-_NATIVE_FWD = os.environ.get("MPF_ENCODER_NATIVE", "1") != "0"        # (0: the python-sequenced forward the tests compare with)
+_NATIVE_FWD = os.environ.get("MPF_ENCODER_NATIVE", "1") != "0"        # (0: the python-sequenced forward / backward the tests compare with)
+_NATIVE_BWD = _NATIVE_FWD
 
 
 class MpfEncoderCall(ctypes.Structure):
@@ -225,6 +226,92 @@ def _arena_views(arena, offs, i, R, C, F, no, dims, M, L, P):
     return dict(value=v("value", R, C), loc=v("loc", N, S, M, L, P, 2), attn=v("attn", N, S, M, L, P), ao=v("ao", R, C), s1=v("s1", R, C),
                 mean1=v("mean1", R), rstd1=v("rstd1", R), x1=v("x1", R, C), h=v("h", R, F), hbits=hb, s2=v("s2", R, C), mean2=v("mean2", R),
                 rstd2=v("rstd2", R), x2=v("x2", R, C), qn=v("qn", R, C))
+
+
+_ENCB_FIELDS = ("x", "q", "value", "loc", "attn", "ao", "s1", "mean1", "rstd1", "x1", "h", "hbits", "s2", "mean2", "rstd2",
+                "x_am", "q_am", "ao_am", "x1_am", "h_am", "g1", "g2", "tv", "tv_am", "to", "to_am", "t1", "t1_am", "t2", "t2_am", "t288", "t288_am",
+                "ds2_am", "dh_am", "ds1_am", "draw_am", "gv_am", "wgrad", "dw288", "lvl", "db288")
+
+
+class MpfEncoderBwdCall(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int32), ("S", ctypes.c_int32), ("M", ctypes.c_int32), ("L", ctypes.c_int32), ("P", ctypes.c_int32),
+                ("nl", ctypes.c_int32), ("F", ctypes.c_int32), ("rps288", ctypes.c_int32), ("rps_group", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("group_stride", ctypes.c_int64), ("host_shapes", ctypes.c_void_p), ("gout", ctypes.c_void_p),
+                ("split_level", ctypes.c_void_p), ("ds2", ctypes.c_void_p), ("dh", ctypes.c_void_p), ("dx1", ctypes.c_void_p),
+                ("ds1", ctypes.c_void_p), ("dao", ctypes.c_void_p), ("gv", ctypes.c_void_p), ("draw", ctypes.c_void_p),
+                ("dq", ctypes.c_void_p * 2), ("g", ctypes.c_void_p * 2), ("cpart288", ctypes.c_void_p), ("cs288", ctypes.c_void_p),
+                ("part_group", ctypes.c_void_p), ("ln_parts", ctypes.c_void_p), ("ln_stride", ctypes.c_uint64), ("msda_ws", ctypes.c_void_p),
+                ("msda_ws_bytes", ctypes.c_uint64), ("dgb_out", ctypes.c_void_p), ("layers", ctypes.c_void_p)]
+
+
+def _group_rps(R, C, F, dev):
+    """rows per split of the four plain weight gradients of a layer: what _wgrad_group picks for them (256 x 256 tiles)"""
+    slots = _slots.get(dev)
+    if slots is None:
+        slots = _slots[dev] = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+    tiles = 2 * (F // 256) + 2 * (C // 256) * (C // 256)
+    ns = max(1, (slots // 2) // tiles)
+    return max(128, ((-(-R // ns)) + 31) // 32 * 32)
+
+
+def _native_backward(gout, params, saved, planes_t, meta, nl, dims, F, rps, split_level):
+    """The backward of all layers as ONE native call (csrc/encoder_layer.hip, mpf_encoder_backward): same launches, same
+    arguments as the python-sequenced loop below.  -> (d input [R, C], out arena [nl, per], (o_dw288, o_lvl, o_db288, group stride),
+    dgb [2 nl, 2, 256])"""
+    from .msda import _workspace
+    N, S, C = dims
+    R = N * S
+    M, L, P = meta["n_heads"], meta["n_levels"], meta["n_points"]
+    no3 = M * L * P * 3
+    dev = gout.device
+    lib = _lib.lib()
+    if lib.mpf_encoder_bwd_fields() != len(_ENCB_FIELDS):
+        raise RuntimeError("MpfEncoderBwdCall field table differs between encoder_fused.py and libmpformer_hip.so")
+    rpg = _group_rps(R, C, F, dev)
+    ns288, nsg = (R + rps - 1) // rps, (R + rpg - 1) // rpg
+    gstride = 2 * C * F + C + F + 2 * (C * C + C)
+    # results of every layer: [four weight gradients + biases | dW288^T | per-level column sums | d bias288]
+    o_dw288 = gstride
+    o_lvl = o_dw288 + no3 * C
+    o_db = o_lvl + L * no3
+    per = o_db + no3
+    out = torch.empty((nl, per), dtype=torch.float32, device=dev)
+    # temporaries, shared by all layers
+    sizes = [R * C] * 5 + [R * F, R * no3] + [R * C] * 4 + [ns288 * no3 * C, ns288 * no3, nsg * gstride]
+    tmp = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+    ptrs, o = [], tmp.data_ptr()
+    for n_ in sizes:
+        ptrs.append(o)
+        o += 4 * n_
+    ds2, dx1, ds1, dao, gv, dh, draw, dq0, dq1, g0, g1_, cpart, cs, pgroup = ptrs
+    ln_stride = (int(lib.mpf_res_ln256_backward_workspace_bytes(R)) + 255) & ~255
+    ln_parts = torch.empty(2 * nl * ln_stride, dtype=torch.uint8, device=dev)
+    host_shapes = meta["shapes"]._mpf_host
+    need = lib.mpf_msda_backward_workspace_bytes(N, M, L, S, P, host_shapes.data_ptr())
+    if need == 0:
+        raise RuntimeError("mpf_msda_backward_workspace_bytes rejected the level geometry")
+    ws = _workspace(dev, need)
+    dgb = torch.empty((2 * nl, 2, 256), dtype=torch.float32, device=dev)
+    am = amax_slots(5 * nl, dev)                     # per layer: ds2, dh, ds1, draw, gv
+    tab = np.zeros((nl, len(_ENCB_FIELDS)), dtype=np.uint64)
+    for i in range(nl):
+        g1 = params[i * PARAMS_PER_LAYER + 8]
+        g2 = params[i * PARAMS_PER_LAYER + 14]
+        (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am, hbits) = saved[i * 20:(i + 1) * 20]
+        (tv, tv_am), (to, to_am), (t1, t1_am), (t2, t2_am), (t288, t288_am) = planes_t[i]
+        ob = out.data_ptr() + 4 * i * per
+        tab[i] = [t_.data_ptr() for t_ in (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, hbits, s2, mean2, rstd2, x_am, q_am, ao_am,
+                                           x1_am, h_am, g1, g2, tv, tv_am, to, to_am, t1, t1_am, t2, t2_am, t288, t288_am)] + \
+                 [am[5 * i + k].data_ptr() for k in range(5)] + [ob, ob + 4 * o_dw288, ob + 4 * o_lvl, ob + 4 * o_db]
+    call = MpfEncoderBwdCall(N, S, M, L, P, nl, F, rps, rpg, 0, gstride, host_shapes.data_ptr(), gout.data_ptr(), split_level.data_ptr(),
+                             ds2, dh, dx1, ds1, dao, gv, draw, (ctypes.c_void_p * 2)(dq0, dq1), (ctypes.c_void_p * 2)(g0, g1_), cpart, cs, pgroup,
+                             ln_parts.data_ptr(), ln_stride, ws.data_ptr(), ws.numel(), dgb.data_ptr(), tab.ctypes.data)
+    with _lib.device_guard(dev):
+        code = lib.mpf_encoder_backward(ctypes.byref(call), _lib.stream_ptr(dev))
+    _lib.check(code, "mpf_encoder_backward")
+    o0 = (g0 - tmp.data_ptr()) // 4
+    g = tmp[o0:o0 + R * C].view(R, C)              # g[0]: what layer 0 hands down
+    return g, out, (o_dw288, o_lvl, o_db, gstride), dgb
 
 
 class EncoderFn(Function):
@@ -333,6 +420,22 @@ class EncoderFn(Function):
                 split_level = meta["level_idx"][::rps].repeat(N)          # level of every split's rows
                 meta[key] = split_level
         dparams = [None] * (nl * PARAMS_PER_LAYER)
+        F_ = params[10].shape[0]
+        if (_NATIVE_BWD and RANGE_AUDIT is None and host_shapes is not None and aligned and L <= 4 and C == 256 and M == 8 and F_ % 256 == 0
+                and all(saved[i * 20 + 19] is not None and params[i * PARAMS_PER_LAYER + 10].shape[0] == F_ for i in range(nl))):
+            g, out, (o_dw, o_lvl, o_db, gs), dgb = _native_backward(g, params, saved, ctx.planes_t, meta, nl, (N, S, C), F_, rps, split_level)
+            no3 = M * L * P * 3
+            for i in range(nl):
+                o_, dp = out[i], [None] * PARAMS_PER_LAYER
+                dw288, db288 = o_[o_dw:o_dw + no3 * C].view(no3, C), o_[o_db:o_db + no3]
+                dp[0], dp[1], dp[2], dp[3] = dw288[:no], db288[:no], dw288[no:], db288[no:]
+                k = 0
+                for (wi, bi, m_, n_) in ((12, 13, C, F_), (10, 11, F_, C), (6, 7, C, C), (4, 5, C, C)):
+                    dp[wi], dp[bi] = o_[k:k + m_ * n_].view(m_, n_), o_[k + m_ * n_:k + m_ * n_ + m_]
+                    k += m_ * n_ + m_
+                dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp
+            lvls_all = out[:, o_lvl:o_lvl + L * no3].view(nl, L, no3)
+            return EncoderFn._finish(g, dgb, lvls_all, dparams, params, nl, (N, S, C))
         am = amax_slots(5 * nl, g.device)               # per layer: ds2, dh, ds1, draw, gv
         lvls = [None] * nl
         gq = None
@@ -386,7 +489,13 @@ class EncoderFn(Function):
             (dp[12], dp[13]), (dp[10], dp[11]), (dp[6], dp[7]), (dp[4], dp[5]) = _wgrad_group(
                 [(ds2, h), (dh, x1), (ds1, ao), (gv2, x)], [(ds2_am, h_am), (dh_am, x1_am), (ds1_am, ao_am), (gv_am, x_am)])
             dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp
-        dgb = lng.finish()                                 # [2 nl, 2, 256] in call order: (norm2, norm1) of layers nl - 1 .. 0
+        return EncoderFn._finish(g, lng.finish(), torch.stack(lvls), dparams, params, nl, (N, S, C))
+
+    @staticmethod
+    def _finish(g, dgb, lvls_all, dparams, params, nl, dims):
+        """LayerNorm parameter gradients into their places + d level_embed; dgb [2 nl, 2, 256] in call order: (norm2, norm1) of
+        layers nl - 1 .. 0; lvls_all [nl, L, 288]: per-level column sums of every layer's d raw"""
+        N, S, C = dims
         for z, i in enumerate(reversed(range(nl))):
             base = i * PARAMS_PER_LAYER
             dparams[base + 14], dparams[base + 15] = dgb[2 * z, 0], dgb[2 * z, 1]
@@ -395,5 +504,5 @@ class EncoderFn(Function):
         w288_all = torch.cat([params[i * PARAMS_PER_LAYER + k] for i in range(nl) for k in (0, 2)]).view(nl, -1, C)
         # [nl, L, 288] x [nl, 288, C] summed over the layers: 1.3 M multiply-adds — as a broadcast product + one reduction
         # (the library's batched fp32 GEMM for it was the head's last hipBLASLt launch)
-        d_level = (torch.stack(lvls)[:, :, :, None] * w288_all[:, None, :, :]).sum((0, 2))
+        d_level = (lvls_all[:, :, :, None] * w288_all[:, None, :, :]).sum((0, 2))
         return (g.view(N, S, C), None, d_level, None, *dparams)

@@ -182,7 +182,7 @@ def test_fp16x2_encoder_at_config_B_size_with_learned_offsets():
 
 
 @pytest.mark.parametrize("shapes,batch,layers", [(((8, 8), (16, 16), (32, 32)), 2, 3), (((5, 7), (10, 14), (20, 28)), 1, 1), (((32, 32), (64, 64), (128, 128)), 2, 6)])
-def test_native_encoder_forward_is_bit_identical_to_the_python_sequenced_one(shapes, batch, layers):
+def test_native_encoder_calls_match_the_python_sequenced_ones(shapes, batch, layers):
     """``mpf_encoder_forward`` (csrc/encoder_layer.hip: all layers of the forward as ONE native call writing into one arena)
     against the python-sequenced forward it replaces (one ctypes call and one allocation per kernel): the same kernels with the
     same arguments in the same order — the output and every gradient (the backward reads the arena views) bit for bit, incl.
@@ -203,8 +203,8 @@ def test_native_encoder_forward_is_bit_identical_to_the_python_sequenced_one(sha
     go = torch.randn(batch, sum(h * w for h, w in shapes), 256, device=dev)
     res = {}
     _lib.set_option("msda_bwd_sorted", 1)              # (the MSDA backward's grad_value depends on the arrival order of the tile entries otherwise)
-    for native in (False, True):
-        encoder_fused._NATIVE_FWD = native
+    for native in ((False, False), (True, False), (True, True)):
+        encoder_fused._NATIVE_FWD, encoder_fused._NATIVE_BWD = native
         try:
             _lib.profile_enable(True)
             res[native] = _run(enc, srcs, pos, go, fused=True)
@@ -212,13 +212,16 @@ def test_native_encoder_forward_is_bit_identical_to_the_python_sequenced_one(sha
             _lib.profile_enable(False)
             assert n_calls > 0
         finally:
-            encoder_fused._NATIVE_FWD = True
+            encoder_fused._NATIVE_FWD = encoder_fused._NATIVE_BWD = True
     _lib.set_option("msda_bwd_sorted", 0)
-    (m0, gx0, gp0), (m1, gx1, gp1) = res[False], res[True]
-    assert torch.equal(m0, m1)                       # the forward: bit for bit
-    # the backward is the same python code on the same saved values (views of the arena instead of separate tensors); it is not
-    # bit-reproducible run to run by itself (fp32 reassociation in the weight-gradient reductions), so: equal to round-off
-    for a, b in zip(gx0, gx1):
-        assert float((a - b).norm() / a.norm()) < 1e-6
-    for n in gp0:
-        assert float((gp0[n] - gp1[n]).norm() / (gp0[n].norm() + 1e-30)) < 1e-5, n
+    (m0, gx0, gp0) = res[(False, False)]
+    for key in ((True, False), (True, True)):
+        m1, gx1, gp1 = res[key]
+        assert torch.equal(m0, m1)                       # the forward: bit for bit
+        # the backward runs the same kernels with the same arguments on the same saved values (mpf_encoder_backward: one native
+        # call, shared temporaries); it is not bit-reproducible run to run by itself (fp32 reassociation in the weight-gradient
+        # reductions), so: equal to round-off
+        for a, b in zip(gx0, gx1):
+            assert float((a - b).norm() / a.norm()) < 1e-6, key
+        for n in gp0:
+            assert float((gp0[n] - gp1[n]).norm() / (gp0[n].norm() + 1e-30)) < 1e-5, (key, n)
