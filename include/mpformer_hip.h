@@ -547,6 +547,19 @@ typedef struct MpfDecoderLayerGrad {
     const float* g_x3_plus;
 } MpfDecoderLayerGrad;
 
+/*
+ * Row-local chains of the decoder's query side as ONE kernel each (csrc/row_chain.hip; a workgroup owns 16 rows):
+ *   mpf_lin256_res_ln_forward: s = x + bf16(a W^T + b);  y = LayerNorm(s) — the output projection of an attention block with its
+ *     post-norm residual (mask2former_transformer_decoder.py:42-52, :100-112); a [rows,256] bf16, W [256,256] bf16 (nn.Linear
+ *     layout), b [256] bf16, x fp32; outputs as mpf_res_ln256_forward (s_out, mean, rstd required; y32 / y16 either may be NULL).
+ *   mpf_ln256_mlp3_forward: out = W2 relu(W1 relu(W0 LayerNorm(x) + b0) + b1) + b2 in bf16 — decoder_norm followed by the
+ *     mask_embed MLP (:1859-1866, :190-206), every intermediate rounded to bf16 as the separate Linear layers store it.
+ * Bit-identical to the mpf_small_gemm_bf16 + mpf_res_ln256_forward launches they replace (same contraction order, same row sums).
+ */
+int mpf_lin256_res_ln_forward(const void* a, const void* w, const void* bias, const float* x, const float* gamma, const float* beta,
+                              float* s_out, float* y32, void* y16, float* mean, float* rstd, int rows, float eps, void* stream);
+int mpf_ln256_mlp3_forward(const float* x, const float* gamma, const float* beta, const void* w0, const void* b0, const void* w1,
+                           const void* b1, const void* w2, const void* b2, void* out, int rows, float eps, void* stream);
 uint64_t mpf_decoder_layer_struct_bytes(int which); /* 0: sizeof(MpfDecoderLayer), 1: sizeof(MpfDecoderLayerGrad) */
 uint64_t mpf_decoder_layer_scratch_bytes(int Qt, int N, int H, int S, int ffn_dim, int backward);
 int mpf_decoder_layer_forward(const MpfDecoderLayer* layer, void* stream);

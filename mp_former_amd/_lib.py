@@ -98,6 +98,8 @@ SIGNATURES = {
     "mpf_decoder_layer_forward": (_c_int, [_c_vp, _c_vp]),
     "mpf_next_attn_mask_scratch_bytes": (ctypes.c_size_t, [_c_int, _c_int]),
     "mpf_next_attn_mask": (_c_int, [_c_vp, _c_vp]),
+    "mpf_lin256_res_ln_forward": (_c_int, [_c_vp] * 11 + [_c_int, ctypes.c_float, _c_vp]),
+    "mpf_ln256_mlp3_forward": (_c_int, [_c_vp] * 10 + [_c_int, ctypes.c_float, _c_vp]),
     "mpf_decoder_layer_backward": (_c_int, [_c_vp, _c_vp, _c_vp]),
     "mpf_pool_features": (_c_int, [_c_vp, _c_int, _c_vp] + [_c_int] * 6 + [_c_vp]),
     "mpf_pool_features_cl": (_c_int, [_c_vp, ctypes.c_int64, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),

@@ -154,12 +154,16 @@ namespace {
 // A/B switches (mpf_set_option): decoder_dw_group = 0 issues the weight gradients as separate launches (round-1 form), 1 = one grouped
 // launch on the row-contiguous operands (round 2), 2 = grouped transposes + one grouped launch on contraction-contiguous copies
 int g_dw_group = 2;
+// decoder_row_chain = 0: output projection, residual LayerNorm, decoder_norm and the mask_embed layers as separate launches
+// (the form of rounds 2-4); 1: the row-local chains of row_chain.hip
+int g_row_chain = 1;
 }  // namespace
 
 namespace mpf {
 int set_decoder_option(const char* key, int v)
 {
     if (!strcmp(key, "decoder_dw_group")) { if (v < 0 || v > 2) return -1; g_dw_group = v; return 0; }
+    if (!strcmp(key, "decoder_row_chain")) { if (v < 0 || v > 1) return -1; g_row_chain = v; return 0; }
     return 1;
 }
 }  // namespace mpf
@@ -195,9 +199,14 @@ extern "C" int mpf_decoder_layer_forward(const MpfDecoderLayer* L, void* st)
     MPF_TRY(mpf_attn_transpose2_strided(L->k_c, L->v_c, L->kv_row_stride, L->kv_img_stride, L->kT_c, f.vT_c, S, S, N, kE, st));
     MPF_TRY(mpf_attn_forward_kv(L->q_c, L->k_c, L->kv_row_stride, L->kv_img_stride, f.vT_c, L->mask_c, 1, L->o_c, L->lse_c, Qt, S, N,
                                 H, 32, scale, L->attn_ws, L->attn_ws_bytes, st));
-    MPF_TRY(lin_fwd(L->o_c, L->ca_wo, L->ca_bo, f.t, R, kE, kE, 0, st));
-    MPF_TRY(mpf_res_ln256_forward(L->x0, f.t, MPF_BF16, L->ca_gamma, L->ca_beta, L->s1, f.x1, L->xb1, L->mean1, L->rstd1, R,
-                                  L->eps, nullptr, 0, nullptr, st));
+    if (g_row_chain) {
+        MPF_TRY(mpf_lin256_res_ln_forward(L->o_c, L->ca_wo, L->ca_bo, L->x0, L->ca_gamma, L->ca_beta, L->s1, f.x1, L->xb1, L->mean1, L->rstd1,
+                                          R, L->eps, st));
+    } else {
+        MPF_TRY(lin_fwd(L->o_c, L->ca_wo, L->ca_bo, f.t, R, kE, kE, 0, st));
+        MPF_TRY(mpf_res_ln256_forward(L->x0, f.t, MPF_BF16, L->ca_gamma, L->ca_beta, L->s1, f.x1, L->xb1, L->mean1, L->rstd1, R,
+                                      L->eps, nullptr, 0, nullptr, st));
+    }
     // self-attention (:1791-1795) + post-norm
     const size_t act = (size_t)R * kE * 2;
     if (packed_weights(L) && L->k_s == at(L->q_s, act) && L->v_s == at(L->q_s, 2 * act)) {
@@ -211,9 +220,14 @@ extern "C" int mpf_decoder_layer_forward(const MpfDecoderLayer* L, void* st)
     MPF_TRY(mpf_attn_transpose2(L->k_s, L->v_s, L->kT_s, f.vT_s, Qt, Qt, N, kE, st));
     MPF_TRY(mpf_attn_forward(L->q_s, L->k_s, f.vT_s, L->mask_s, 0, L->o_s, L->lse_s, Qt, Qt, N, H, 32, scale, L->attn_ws,
                              L->attn_ws_bytes, st));
-    MPF_TRY(lin_fwd(L->o_s, L->sa_wo, L->sa_bo, f.t, R, kE, kE, 0, st));
-    MPF_TRY(mpf_res_ln256_forward(f.x1, f.t, MPF_BF16, L->sa_gamma, L->sa_beta, L->s2, f.x2, L->xb2, L->mean2, L->rstd2, R,
-                                  L->eps, nullptr, 0, nullptr, st));
+    if (g_row_chain) {
+        MPF_TRY(mpf_lin256_res_ln_forward(L->o_s, L->sa_wo, L->sa_bo, f.x1, L->sa_gamma, L->sa_beta, L->s2, f.x2, L->xb2, L->mean2, L->rstd2,
+                                          R, L->eps, st));
+    } else {
+        MPF_TRY(lin_fwd(L->o_s, L->sa_wo, L->sa_bo, f.t, R, kE, kE, 0, st));
+        MPF_TRY(mpf_res_ln256_forward(f.x1, f.t, MPF_BF16, L->sa_gamma, L->sa_beta, L->s2, f.x2, L->xb2, L->mean2, L->rstd2, R,
+                                      L->eps, nullptr, 0, nullptr, st));
+    }
     // FFN (:1798-1800) + post-norm
     MPF_TRY(lin_fwd(L->xb2, L->ff_w1, L->ff_b1, L->h, R, F, kE, 1, st));
     MPF_TRY(lin_fwd(L->h, L->ff_w2, L->ff_b2, f.t, R, kE, F, 0, st));
@@ -386,11 +400,15 @@ extern "C" int mpf_next_attn_mask(const MpfNextMask* m, void* st)
     void* e2 = sc + 2 * act;
     float* mean = reinterpret_cast<float*>(sc + 3 * act);
     float* rstd = reinterpret_cast<float*>(sc + 3 * act + vec);
-    MPF_TRY(mpf_res_ln256_forward(m->x, nullptr, 0, m->ln_gamma, m->ln_beta, nullptr, nullptr, d16, mean, rstd, rows, m->eps, nullptr, 0,
-                                  nullptr, st));
-    MPF_TRY(mpf_small_gemm_bf16(d16, kE, 1, nullptr, m->w0, kE, 1, m->b0, nullptr, 0, e1, kE, nullptr, rows, kE, kE, 1, st));
-    MPF_TRY(mpf_small_gemm_bf16(e1, kE, 1, nullptr, m->w1, kE, 1, m->b1, nullptr, 0, e2, kE, nullptr, rows, kE, kE, 1, st));
-    MPF_TRY(mpf_small_gemm_bf16(e2, kE, 1, nullptr, m->w2, kE, 1, m->b2, nullptr, 0, d16, kE, nullptr, rows, kE, kE, 0, st));
+    if (g_row_chain && m->b0 && m->b1 && m->b2) {
+        MPF_TRY(mpf_ln256_mlp3_forward(m->x, m->ln_gamma, m->ln_beta, m->w0, m->b0, m->w1, m->b1, m->w2, m->b2, d16, rows, m->eps, st));
+    } else {
+        MPF_TRY(mpf_res_ln256_forward(m->x, nullptr, 0, m->ln_gamma, m->ln_beta, nullptr, nullptr, d16, mean, rstd, rows, m->eps, nullptr, 0,
+                                      nullptr, st));
+        MPF_TRY(mpf_small_gemm_bf16(d16, kE, 1, nullptr, m->w0, kE, 1, m->b0, nullptr, 0, e1, kE, nullptr, rows, kE, kE, 1, st));
+        MPF_TRY(mpf_small_gemm_bf16(e1, kE, 1, nullptr, m->w1, kE, 1, m->b1, nullptr, 0, e2, kE, nullptr, rows, kE, kE, 1, st));
+        MPF_TRY(mpf_small_gemm_bf16(e2, kE, 1, nullptr, m->w2, kE, 1, m->b2, nullptr, 0, d16, kE, nullptr, rows, kE, kE, 0, st));
+    }
     // mask_embed is sequence-first [Q, N, 256]: image stride 256, query stride N * 256
     return mpf_mask_head_bits(d16, kE, (int64_t)m->N * kE, m->pooled, m->mp_rows, m->pad, m->out, m->flags, m->N, m->Q, m->HW, st);
 }

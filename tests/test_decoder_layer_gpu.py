@@ -170,3 +170,115 @@ def test_round2_switches_do_not_change_the_step(switch):
         if rel > worst[1]:
             worst = (n, rel)
     assert worst[1] < 2e-2, (switch, worst)
+
+
+@pytest.mark.parametrize("rows", [1, 16, 230, 603])
+def test_row_chain_out_projection_residual_layernorm(rows):
+    """``mpf_lin256_res_ln_forward`` (csrc/row_chain.hip: output projection + residual + LayerNorm in one workgroup per 16 rows,
+    mask2former_transformer_decoder.py:42-52) against plain torch fp32 on the same bf16 operands with the same rounding point (the
+    projection's result in bf16), and against the two separate kernels it replaces."""
+    from mp_former_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(rows)
+    a = torch.randn(rows, 256, generator=g).to(dev).bfloat16()
+    w = (torch.randn(256, 256, generator=g) / 16).to(dev).bfloat16()
+    b = torch.randn(256, generator=g).to(dev).bfloat16()
+    x = torch.randn(rows, 256, generator=g).to(dev)
+    gamma = (1 + 0.1 * torch.randn(256, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(256, generator=g)).to(dev)
+    s = torch.empty(rows, 256, device=dev)
+    y32 = torch.empty_like(s)
+    y16 = torch.empty(rows, 256, device=dev, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    lib = _lib.lib()
+    st = _lib.stream_ptr(dev)
+    _lib.check(lib.mpf_lin256_res_ln_forward(a.data_ptr(), w.data_ptr(), b.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             s.data_ptr(), y32.data_ptr(), y16.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, 1e-5, st), "chain")
+    t = (a.float() @ w.float().t() + b.float()).bfloat16().float()
+    s_ref = x + t
+    y_ref = torch.nn.functional.layer_norm(s_ref, (256,), gamma, beta, 1e-5)
+    # the projection in fp32 order-of-summation noise may flip a bf16 rounding of t: one bf16 ulp of |t| <~ 8
+    assert float((s - s_ref).abs().max()) <= 2 ** -5
+    assert float(((s - s_ref).abs() > 1e-6).float().mean()) < 2e-3
+    torch.testing.assert_close(y32, torch.nn.functional.layer_norm(s, (256,), gamma, beta, 1e-5), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(y16.float(), y32.bfloat16().float(), rtol=0, atol=0)
+    torch.testing.assert_close(mean, s.mean(1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rstd, (s.var(1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-5, atol=1e-6)
+    assert float((y32 - y_ref).abs().max()) < 0.1
+    # the separate kernels it replaces: bit for bit (same contraction order, same row sums)
+    t2 = torch.empty(rows, 256, device=dev, dtype=torch.bfloat16)
+    _lib.check(lib.mpf_small_gemm_bf16(a.data_ptr(), 256, 1, None, w.data_ptr(), 256, 1, b.data_ptr(), None, 0, t2.data_ptr(), 256, None,
+                                       rows, 256, 256, 0, st), "gemm")
+    s2, y2, y2h = torch.empty_like(s), torch.empty_like(s), torch.empty_like(y16)
+    m2, r2 = torch.empty_like(mean), torch.empty_like(rstd)
+    _lib.check(lib.mpf_res_ln256_forward(x.data_ptr(), t2.data_ptr(), _lib.MPF_BF16, gamma.data_ptr(), beta.data_ptr(), s2.data_ptr(),
+                                         y2.data_ptr(), y2h.data_ptr(), m2.data_ptr(), r2.data_ptr(), rows, 1e-5, None, 0, None, st), "ln")
+    assert torch.equal(s, s2) and torch.equal(y32, y2) and torch.equal(y16, y2h) and torch.equal(mean, m2) and torch.equal(rstd, r2)
+
+
+@pytest.mark.parametrize("rows", [3, 64, 219, 600])
+def test_row_chain_decoder_norm_mask_embed(rows):
+    """``mpf_ln256_mlp3_forward`` (decoder_norm + the three mask_embed layers in one workgroup per 16 rows,
+    mask2former_transformer_decoder.py:1859-1866) against torch with bf16 rounding of every stored intermediate."""
+    from mp_former_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(100 + rows)
+    x = (2 * torch.randn(rows, 256, generator=g)).to(dev)
+    gamma = (1 + 0.1 * torch.randn(256, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(256, generator=g)).to(dev)
+    ws = [(torch.randn(256, 256, generator=g) / 16).to(dev).bfloat16() for _ in range(3)]
+    bs = [(0.2 * torch.randn(256, generator=g)).to(dev).bfloat16() for _ in range(3)]
+    out = torch.empty(rows, 256, device=dev, dtype=torch.bfloat16)
+    _lib.check(_lib.lib().mpf_ln256_mlp3_forward(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws[0].data_ptr(), bs[0].data_ptr(),
+                                                 ws[1].data_ptr(), bs[1].data_ptr(), ws[2].data_ptr(), bs[2].data_ptr(), out.data_ptr(), rows,
+                                                 1e-5, _lib.stream_ptr(dev)), "mlp3")
+    e = torch.nn.functional.layer_norm(x, (256,), gamma, beta, 1e-5).bfloat16().float()
+    e = torch.relu(e @ ws[0].float().t() + bs[0].float()).bfloat16().float()
+    e = torch.relu(e @ ws[1].float().t() + bs[1].float()).bfloat16().float()
+    e = (e @ ws[2].float().t() + bs[2].float()).bfloat16().float()
+    err = (out.float() - e).abs()
+    # a flipped bf16 rounding of an intermediate moves an output by a fraction of ITS bf16 ulp: a few ulps at most anywhere
+    assert float(err.max()) <= 4 * 2 ** -8 * float(e.abs().max())
+    assert float((err > 0).float().mean()) < 0.05
+    # the four launches it replaces: bit for bit
+    lib, st = _lib.lib(), _lib.stream_ptr(dev)
+    d16, e1, e2 = (torch.empty(rows, 256, device=dev, dtype=torch.bfloat16) for _ in range(3))
+    m2, r2 = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    _lib.check(lib.mpf_res_ln256_forward(x.data_ptr(), None, 0, gamma.data_ptr(), beta.data_ptr(), None, None, d16.data_ptr(), m2.data_ptr(),
+                                         r2.data_ptr(), rows, 1e-5, None, 0, None, st), "ln")
+    for src, dst, k, relu in ((d16, e1, 0, 1), (e1, e2, 1, 1), (e2, d16, 2, 0)):
+        _lib.check(lib.mpf_small_gemm_bf16(src.data_ptr(), 256, 1, None, ws[k].data_ptr(), 256, 1, bs[k].data_ptr(), None, 0, dst.data_ptr(), 256,
+                                           None, rows, 256, 256, relu, st), "gemm")
+    assert torch.equal(out, d16)
+
+
+def test_row_chains_do_not_change_the_step():
+    """lib option ``decoder_row_chain`` (1: csrc/row_chain.hip, 0: separate projection / LayerNorm / MLP launches): same losses, same
+    gradients up to bf16 noise on the AMP path with replayed draws and a pinned assignment."""
+    from mp_former_amd import _lib
+    dev = torch.device("cuda:0")
+    z, cfg, pp, dp, feats, targets, replay = load_head_fixture("head_ragged")
+    h = _build(cfg, pp, dp, dev)
+    feats = {k: v.to(dev) for k, v in feats.items()}
+    targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+    pin = []
+    _lib.profile_enable(True)
+    l_on, g_on = _run(h, feats, targets, replay, cfg, fused=True, pin=pin)
+    torch.cuda.synchronize()
+    n_chain = _lib.profile_get("lin256_res_ln_kernel")[0]
+    _lib.profile_enable(False)
+    assert n_chain > 0
+    _lib.set_option("decoder_row_chain", 0)
+    try:
+        l_off, g_off = _run(h, feats, targets, replay, cfg, fused=True, pin=pin)
+    finally:
+        _lib.set_option("decoder_row_chain", 1)
+    bad = [(k, l_on[k], l_off[k]) for k in l_on if abs(l_on[k] - l_off[k]) > 2e-3 * max(1.0, abs(l_on[k]))]
+    assert not bad, bad[:3]
+    worst = ("", 0.0)
+    for n in g_on:
+        a, b = g_on[n].double().flatten(), g_off[n].double().flatten()
+        rel = (a - b).norm().item() / (a.norm().item() + 1e-12)
+        if rel > worst[1]:
+            worst = (n, rel)
+    assert worst[1] < 2e-2, worst
