@@ -188,6 +188,15 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             if (s + 1 < 8) { WS_LOAD_FRAGS((s + 1) & 1, s + 1) }
+#if !(WS_ABL & 8)
+            if (s & 1) {     // one row copy of tile t + 3 per two K steps (into the rows this wave converted in `middle`): all 32 copies of a
+                             // workgroup requested together right after the barrier queued behind each other in the CU's address unit
+                             // (~500 cycles per tile for the last wave); spread over the MFMA phase the issue waits hide (N = 1024: 88 -> 85 us)
+                const int rl = wave * 4 + (s >> 1);
+                const int row = min(r0 + (t + 3) * kWsBM + rl, r1 - 1);
+                glds16(p.a + (int64_t)row * p.lda, src_off, lds_stage + (unsigned)(((t + 3) & 1) * kWsStage + rl * 1024));
+            }
+#endif
 #if WS_ABL & 2
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -316,7 +325,6 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
     // this order.)
     for (int t = 0; t < ntile; ++t) {
         middle(t + 1, t - 1);
-        dma_rows(t + 3);                 // into the rows this wave has just converted (after every load the compiler knows of)
         __builtin_amdgcn_sched_barrier(0);
         epi_loads(t);                    // consumed by the epilogue of tile t in the next iteration
         __builtin_amdgcn_sched_barrier(0);
