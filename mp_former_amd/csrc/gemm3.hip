@@ -78,6 +78,7 @@ int g_mixed = 1;       // mpf_set_option("gemm3_mixed_tiles"): 128 x 64 tiles fo
 int g_two_pass = 256;  // mpf_set_option("gemm3_two_pass"): N >= this and N % 256 == 0 -> 128 x 256 / 96 x 256 two-pass tiles (0 = off)
 int g_two_pass_rows = 0;   // mpf_set_option("gemm3_two_pass_rows"): 0 = pick 128 or 96 rows per tile by rounds, else force
 int g_nt2 = 1;             // mpf_set_option("gemm3_nt2"): grouped fp16 x 2 weight gradients with all dimensions % 256 == 0 on 256 x 256 tiles (0 = 128 x 128)
+int g_tn3 = 1;             // mpf_set_option("gemm3_tn3"): fp16 x 2 TN products with N % 256 == 0 and >= 2048 rows on 192 x 256 tiles, one 8-wave workgroup per CU
 int g_ws = 512;            // mpf_set_option("gemm3_ws"): K = 256, N % 256 == 0, N >= this: fp16 x 2 products on the weight-stationary kernel (0 = never)
 
 #ifdef G3_TIMING
@@ -538,6 +539,7 @@ __device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned
 }
 
 #include "gemm3_ws.h"
+#include "gemm3_tn3.h"
 
 // one output tile: 128 rows x BN columns starting at (m0, n0)
 // CV: A is a channel-last image [N_img*H*W][Cin] and K runs over (tap, channel) of a 3x3 window — K step kt reads the
@@ -1606,6 +1608,7 @@ int mpf::set_gemm3_option(const char* key, int v)
     if (!strcmp(key, "gemm3_two_pass")) { g_two_pass = v; return 0; }
     if (!strcmp(key, "gemm3_two_pass_rows")) { g_two_pass_rows = v; return 0; }
     if (!strcmp(key, "gemm3_ws")) { g_ws = v; return 0; }
+    if (!strcmp(key, "gemm3_tn3")) { g_tn3 = v; return 0; }
     if (!strcmp(key, "gemm3_nt2")) { g_nt2 = v; return 0; }
     if (strcmp(key, "gemm3_ablate") != 0) return 1;
     g_ablate = v;
@@ -1783,6 +1786,21 @@ static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows,
     if (a_amax && !a2 && !gate && !c_in2 && g_ws > 0 && N >= g_ws && K == kWsK && N % 256 == 0 && ((uintptr_t)a & 15) == 0) {
         const int r = g3_launch_ws(p, st);
         if (r != -1000) return r;
+    }
+    if (a_amax && !a2 && g_tn3 && N % 256 == 0 && M >= 2048 && ((uintptr_t)a & 15) == 0 && lda % 4 == 0) {
+        static mpf::LdsAttr attr;
+        if (int e = mpf::ensure_dynamic_lds((const void*)gemm3_tn3_kernel, kT3Lds, attr)) return e;
+        p.tiles_n = N / 256;
+        p.ntiles = ((M + kT3BM - 1) / kT3BM) * p.tiles_n;
+        mpf::prof_begin(st);
+        mpf::set_kernel("gemm3_tn_kernel<h2 192x256>");
+        {
+            void* args[] = {(void*)&p};
+            if (hipError_t e = hipLaunchKernel((const void*)gemm3_tn3_kernel, dim3(((p.ntiles + 7) / 8) * 8), dim3(kT3T), args, kT3Lds, st); e != hipSuccess)
+                return mpf::check(e, "gemm3_tn3_kernel");
+        }
+        mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + 4.0 * (double)N * K, 2.0 * M * (double)N * K);
+        return mpf::check(hipGetLastError(), "mpf_gemm3_tn_h2(192x256)");
     }
     if (!a2 && g3_launch_two_pass(p, st)) {
         mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + (a_amax ? 4.0 : 6.0) * (double)N * K, 2.0 * M * (double)N * K);

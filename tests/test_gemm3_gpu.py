@@ -402,6 +402,52 @@ def test_gemm3_ws_kernel_bit_identical_to_the_tiled_kernel(M, N):
     assert float(((res[1][0].double() - ref).abs() / den).max()) < 1e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(43008, 256, 256), (43008, 256, 1024), (5000, 256, 288), (2731, 512, 256), (2048, 1024, 64), (21511, 256, 32)])
+def test_gemm3_tn3_kernel_bit_identical_to_the_two_pass_kernel(M, N, K):
+    """The 192 x 256-tile kernel (csrc/gemm3_tn3.h: one 8-wave workgroup per CU, double-buffered plane images, B planes by DMA one K
+    step ahead, one barrier per K step) against the two-pass tiled kernel it replaces (`gemm3_tn3=0`): same split, same product
+    order per output element — every variant of the epilogue bit for bit, incl. row counts that are no multiple of 192 / 16,
+    a strided A, K = 32 (one step) and K = 288."""
+    import numpy as np
+    from mp_former_amd import _lib
+    from mp_former_amd.gemm3 import amax, amax_slots, amax_value, gemm3_h2, gemm3_h2_bits, split_weights_grouped_h2
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + N + K)
+    a_full = _heavy(M, K + 64, dev)
+    a = a_full[:, :K]
+    w = torch.randn(N, K, device=dev) / K ** 0.5
+    b, cin, cin2, gate = torch.randn(N, device=dev), torch.randn(M, N, device=dev), torch.randn(M, N, device=dev), torch.randn(M, N, device=dev)
+    (pl, wam), = split_weights_grouped_h2([([w], False)])
+    am = amax(a.contiguous())
+    res = {}
+    _lib.set_option("gemm3_ws", 0)
+    try:
+        for t3 in (0, 1):
+            _lib.set_option("gemm3_tn3", t3)
+            oam = amax_slots(3, dev)
+            r = [gemm3_h2(a, am, pl, wam)]
+            assert ("192x256" in _lib.last_kernel()) == bool(t3), _lib.last_kernel()
+            r.append(gemm3_h2(a, am, pl, wam, b, cin=cin, cin2=cin2, out_amax=oam[0]))
+            r.append(gemm3_h2(a, am, pl, wam, b, relu=True, gate=gate, out_amax=oam[1]))
+            r.append(gemm3_h2(a, am, pl, wam, b, cin=cin, relu=True))
+            h, bits = gemm3_h2_bits(a, am, pl, wam, b, relu=True, out_amax=oam[2], want_bits=True)
+            r += [h, bits, gemm3_h2_bits(a, am, pl, wam, cin=cin, gate_bits=bits)]
+            assert ("192x256" in _lib.last_kernel()) == bool(t3), _lib.last_kernel()
+            r += [amax_value(oam[i]).clone() for i in range(3)]
+            res[t3] = r
+    finally:
+        _lib.set_option("gemm3_ws", 512)
+        _lib.set_option("gemm3_tn3", 1)
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+    assert float(res[1][7]) == float(res[1][1].abs().max())
+    want = np.packbits((res[1][4] > 0).cpu().numpy(), axis=1, bitorder="little")
+    assert np.array_equal(res[1][5].cpu().numpy(), want)
+    ref = a.double() @ w.double().t()
+    den = a.double().abs() @ w.double().abs().t()
+    assert float(((res[1][0].double() - ref).abs() / den).max()) < 1e-6
+
+
 @pytest.mark.parametrize("rows,cin,cout", [(43008, 256, 288), (5000, 256, 1024), (2048, 1024, 256)])
 def test_linear_tall_native_forward_and_gradients(rows, cin, cout):
     """mp_former_amd.linear.linear_tall — the Linear of the per-layer encoder route and of the MSDeformAttn module
