@@ -140,8 +140,9 @@ def synth_features(n, hw, shapes, seed, device):
 
 
 def _gemm3_traffic_ratios():
-    """{shape: HBM bytes from the PMC counters / algorithmic bytes} of the fp16 x 2 TN kernel (profiles/r03f_gemm3_traffic.json), or None"""
-    f = os.path.join(ROOT, "profiles", "r03f_gemm3_traffic.json")
+    """{shape: HBM bytes from the PMC counters / algorithmic bytes} of the fp16 x 2 TN kernels the routing picks
+    (profiles/r05_gemm3_traffic.json from tools/pmc_gemm3_traffic.sh: gemm3_tn3 for N = 256, gemm3_ws for N = 1024), or None"""
+    f = os.path.join(ROOT, "profiles", "r05_gemm3_traffic.json")
     if not os.path.exists(f):
         return None
     d = json.load(open(f))

@@ -1,8 +1,9 @@
 #!/bin/bash
-# HBM traffic of the two-pass TN kernel (both forms) on the three encoder shapes from rocprofv3 PMC counters: FETCH_SIZE and
+# HBM traffic of the TN kernels the default routing picks (fp16 x 2 form: gemm3_tn3_kernel for the 256-column products, gemm3_ws_kernel
+# for N = 1024; bf16 x 3 form: the two-pass gemm3_tn2_kernel) on the three encoder shapes from rocprofv3 PMC counters: FETCH_SIZE and
 # WRITE_SIZE in separate passes, calibrated on kernels that move a known 512 MiB (tools/ubench/fetch_calib.hip), as
 # tools/pmc_msda.sh does.  Run on the GPU box from the repo root; writes gpurun_out/${TAG}_gemm3_traffic.json.
-TAG=${1:-r03f}
+TAG=${1:-r05}
 export PMC_TAG=$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
@@ -41,19 +42,24 @@ fw = EXPECT / (cal["calib_write16"]["WRITE_SIZE"] * 1024.0)
 M = 43008
 out = {"calibration_bytes_per_counter_byte": {"read (16-byte lanes, streaming)": fr, "write": fw}, "M": M, "shapes": {}}
 for s, (n, k) in enumerate(((256, 256), (1024, 256), (256, 1024))):
-    r = load(f"pg{s}", r"gemm3_tn2_kernel<\d+, false, (true|false)>")
+    r = load(f"pg{s}", r"gemm3_tn3_kernel|gemm3_ws_kernel<0, false, false, false>|gemm3_tn2_kernel<\d+, false, false>")
     e = {}
-    rows = "128" if n == 1024 else "96"          # (the probe also runs the input-gradient GEMM of the shape: the other tile)
+    want16 = "gemm3_ws_kernel" if n == 1024 else "gemm3_tn3_kernel"     # (the probe also runs the input-gradient GEMM of the shape: the other kernel)
+    rows = "128" if n == 1024 else "96"
     for kern, v in r.items():
-        if not kern.startswith("gemm3_tn2_kernel<" + rows):
+        if kern.startswith("gemm3_tn2_kernel"):
+            if not kern.startswith("gemm3_tn2_kernel<" + rows):
+                continue
+            form, planes = "bf16x3", 6
+        elif kern.startswith(want16):
+            form, planes = "fp16x2", 4
+        else:
             continue
-        form = "fp16x2" if "true>" in kern else "bf16x3"
-        planes = 4 if form == "fp16x2" else 6
         alg = 4.0 * (M * k + M * n) + planes * n * k + (4.0 * n)
         rd, wr = v.get("FETCH_SIZE", 0.0) * 1024.0 * fr, v.get("WRITE_SIZE", 0.0) * 1024.0 * fw
         e[form] = {"kernel": kern, "read_bytes": round(rd), "write_bytes": round(wr), "algorithmic_bytes": round(alg),
                    "traffic_over_algorithmic": round((rd + wr) / alg, 3)}
     out["shapes"][f"N={n},K={k}"] = e
-json.dump(out, open("gpurun_out/%s_gemm3_traffic.json" % os.environ.get("PMC_TAG", "r03f"), "w"), indent=1)
+json.dump(out, open("gpurun_out/%s_gemm3_traffic.json" % os.environ.get("PMC_TAG", "r05"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
