@@ -78,7 +78,7 @@ int g_mixed = 1;       // mpf_set_option("gemm3_mixed_tiles"): 128 x 64 tiles fo
 int g_two_pass = 256;  // mpf_set_option("gemm3_two_pass"): N >= this and N % 256 == 0 -> 128 x 256 / 96 x 256 two-pass tiles (0 = off)
 int g_two_pass_rows = 0;   // mpf_set_option("gemm3_two_pass_rows"): 0 = pick 128 or 96 rows per tile by rounds, else force
 int g_nt2 = 1;             // mpf_set_option("gemm3_nt2"): grouped fp16 x 2 weight gradients with all dimensions % 256 == 0 on 256 x 256 tiles (0 = 128 x 128)
-int g_tn3 = 1;             // mpf_set_option("gemm3_tn3"): fp16 x 2 TN products with N % 256 == 0 and >= 2048 rows on 192 x 256 tiles, one 8-wave workgroup per CU
+int g_tn3 = 1;             // mpf_set_option("gemm3_tn3"): fp16 x 2 TN products with N % 256 == 0 on 192 x 256 tiles, one 8-wave workgroup per CU, where the tiles fill the chip (2: wherever M >= 2048; 0: never)
 int g_ws = 512;            // mpf_set_option("gemm3_ws"): K = 256, N % 256 == 0, N >= this: fp16 x 2 products on the weight-stationary kernel (0 = never)
 
 #ifdef G3_TIMING
@@ -1787,7 +1787,15 @@ static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows,
         const int r = g3_launch_ws(p, st);
         if (r != -1000) return r;
     }
-    if (a_amax && !a2 && g_tn3 && N % 256 == 0 && M >= 2048 && ((uintptr_t)a & 15) == 0 && lda % 4 == 0) {
+    // 192 x 256 tiles, ONE workgroup per CU: only where they fill the chip — the last (or only) round of tiles must cover at least
+    // 3/4 of the CUs (43 008 rows: 224 tiles on 256 CUs; 16 800 rows would be 88 tiles against 175 half-size tiles of the
+    // two-pass kernel on two workgroup slots per CU: config D's head measured 11.62 -> 11.79 ms per step with them)
+    bool tn3 = a_amax && !a2 && g_tn3 && N % 256 == 0 && M >= 2048 && ((uintptr_t)a & 15) == 0 && lda % 4 == 0;
+    if (tn3) {
+        const int cus = mpf::cu_count(), nt3 = ((M + kT3BM - 1) / kT3BM) * (N / 256), rem = nt3 % cus;
+        tn3 = g_tn3 == 2 || (nt3 >= cus * 3 / 4 && (rem == 0 || 4 * rem >= 3 * cus || nt3 >= 4 * cus));
+    }
+    if (tn3) {
         static mpf::LdsAttr attr;
         if (int e = mpf::ensure_dynamic_lds((const void*)gemm3_tn3_kernel, kT3Lds, attr)) return e;
         p.tiles_n = N / 256;
