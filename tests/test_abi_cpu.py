@@ -120,3 +120,40 @@ def test_shipped_miopen_find_db_is_wired(monkeypatch, tmp_path):
     monkeypatch.delenv("MIOPEN_USER_DB_PATH")
     monkeypatch.setenv("MPF_MIOPEN_DB", "0")
     assert _miopen.use_shipped_find_db() is None and "MIOPEN_USER_DB_PATH" not in os.environ
+
+
+def test_encoder_call_structs_match_the_header(tmp_path):
+    """The ctypes mirrors of MpfEncoderCall / MpfEncoderBwdCall (mp_former_amd/encoder_fused.py) against the C declarations of
+    include/mpformer_hip.h compiled by gcc: same size, same offset of every member, same number of table fields — the two structs
+    carry ~30 pointers each, a drift between the two sides would be a silent corruption on the GPU."""
+    import ctypes
+    import subprocess
+    from mp_former_amd import encoder_fused as EF
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    members = {"MpfEncoderCall": [n for n, _ in EF.MpfEncoderCall._fields_], "MpfEncoderBwdCall": [n for n, _ in EF.MpfEncoderBwdCall._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mpformer_hip.h"', 'int main(void) {']
+    for st, names in members.items():
+        src.append(f'  printf("{st} size %zu\\n", sizeof({st}));')
+        for n in names:
+            src.append(f'  printf("{st} {n} %zu\\n", offsetof({st}, {n}));')
+    src += ['  printf("fields %d %d\\n", (int)MPF_ENC_FIELDS, (int)MPF_ENCB_FIELDS);', '  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    seen = 0
+    for line in out:
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "fields":
+            assert (int(t[1]), int(t[2])) == (len(EF._ENC_FIELDS), len(EF._ENCB_FIELDS))
+            continue
+        cls = getattr(EF, t[0])
+        if t[1] == "size":
+            assert ctypes.sizeof(cls) == int(t[2]), t
+        else:
+            assert getattr(cls, t[1]).offset == int(t[2]), t
+        seen += 1
+    assert seen == sum(len(v) for v in members.values()) + 2

@@ -285,3 +285,16 @@ def test_registry_plugin_builds_both_decoders_by_name():
     import pytest
     with pytest.raises(AssertionError):
         d2_plugin.register(sem, trf)
+
+
+def test_encoder_arena_layout_is_aligned_and_disjoint():
+    """_arena_layout (encoder_fused.py): the per-layer results of the native encoder forward as slices of ONE allocation — every
+    tensor starts on a 16-byte boundary, none overlaps the next, the bit mask of the FFN gate has a bit per hidden element."""
+    from mp_former_amd.encoder_fused import _arena_layout
+    for (R, F) in ((43008, 1024), (35, 128), (1, 2048)):
+        M, L, P = 8, 3, 4
+        offs, tot = _arena_layout(R, 256, F, M * L * P * 3, M, L, P)
+        spans = sorted(offs.values())
+        for (o, n), (o2, _) in zip(spans, spans[1:] + [(tot, 0)]):
+            assert o % 4 == 0 and o + n <= o2
+        assert offs["hbits"][1] * 32 >= R * F and offs["loc"][1] == R * M * L * P * 2 and offs["x2"][1] == R * 256
