@@ -157,3 +157,20 @@ def test_encoder_call_structs_match_the_header(tmp_path):
             assert getattr(cls, t[1]).offset == int(t[2]), t
         seen += 1
     assert seen == sum(len(v) for v in members.values()) + 2
+
+
+def test_item_table_rows_match_the_header(tmp_path):
+    """The item tables the mirrors build as int64 rows in numpy (grouped weight gradients, FrozenBN fold, assignment problems)
+    against sizeof of the structs they are read as (gcc on include/mpformer_hip.h)."""
+    import subprocess
+    from mp_former_amd import lsa
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = {"MpfNtItem": 8, "MpfNtItemH2": 10, "MpfScaleCastItem": 6, "MpfLsaProblem": len(lsa.FIELDS)}
+    src = ['#include <stdio.h>', '#include "mpformer_hip.h"', 'int main(void) {']
+    src += [f'  printf("{k} %zu\\n", sizeof({k}));' for k in want] + ['  return 0;', '}']
+    c = tmp_path / "items.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "items"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(c), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).strip().split("\n"))
+    assert {k: int(v) for k, v in got.items()} == {k: 8 * n for k, n in want.items()}
