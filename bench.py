@@ -273,6 +273,11 @@ def main():
                     help="BASELINE.json configuration (B = the metric's; C, D, E need --head-only: their backbones are outside the path)")
     ap.add_argument("--head-only", action="store_true",
                     help="time the segmentation head alone on synthetic backbone features of the workload's channel counts")
+    ap.add_argument("--grad-wire", choices=["fp32", "bf16"], default="fp32",
+                    help="dtype of the gradient buckets on the links (N > 1, FlatGradSync): fp32 = what DistributedDataParallel averages (default); "
+                         "bf16 = half the bytes, unpacked and averaged in fp32 (SURVEY.md 8 f4)")
+    ap.add_argument("--head-steps", type=int, default=10,
+                    help="N = 1, full step only: timed HEAD-ONLY steps after everything else (config.head_only; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=1024)
     a = ap.parse_args()
@@ -328,7 +333,7 @@ def main():
     # DistributedDataParallel (per-parameter hooks, 25 MB buckets)
     sync = None
     if mdist.distributed() and os.environ.get("MPF_GRAD_SYNC", "flat") == "flat":
-        sync = mdist.FlatGradSync(grad_sync_groups(model))
+        sync = mdist.FlatGradSync(grad_sync_groups(model), wire_dtype=torch.bfloat16 if a.grad_wire == "bf16" else None)
         if not a.head_only:
             model.grad_ready_hooks = {"res5": lambda: sync.launch(0), "res3": lambda: sync.launch(1)}
         ddp = model
@@ -406,6 +411,29 @@ def main():
     n_am, ms_am, by_am, _ = prof("amax_kernel")
     fused = {k: prof(k) for k in ("match_cost_fused_kernel", "pair_planes_fwd_kernel", "pair_planes_dfeat_kernel", "pair_planes_dembed_kernel")}
     _lib.profile_enable(False)
+    # ---- gradient exchange diagnostics (N > 1, flat buckets): two more steps with events at every bucket launch and around
+    # finish()'s waits, then each bucket's collective alone on the idle device — enough to tell a slow link from a lost
+    # overlap in a SCALE line without a profiler
+    grad_sync_info = None
+    if sync is not None:
+        sync.record_events(True)
+        for i in range(2):
+            step(a.warmup + a.steps + P + i)
+        tim = sync.timing()
+        sync.record_events(False)
+        alone = sync.standalone_allreduce_ms()
+        bb_ = sync.bucket_bytes()
+        w_ = max(world, 1)
+        grad_sync_info = {"buckets_mb": [round(b / 1e6, 2) for b in bb_], "wire_dtype": a.grad_wire,
+                          "allreduce_ms": alone,
+                          # ring all-reduce bus bandwidth: 2 (n - 1) / n x bytes / time
+                          "allreduce_busbw_GBps": [round(2.0 * (w_ - 1) / w_ * b / (t * 1e-3) / 1e9, 1) if t > 0 else None for b, t in zip(bb_, alone)],
+                          "exposed_wait_ms": tim["exposed_wait_ms"], "in_flight_ms": tim["in_flight_ms"],
+                          "launched_under_backbone": bool(all(tim["launched_early"][:-1])) if len(tim["launched_early"]) > 1 else False,
+                          "launched_early": tim["launched_early"],
+                          "what": "allreduce_ms = each bucket's collective alone (median of 5, idle device); exposed_wait_ms = compute-stream time "
+                                  "from finish()'s first wait to its last unpack on a step; in_flight_ms = bucket launch -> wait satisfied (includes "
+                                  "the backbone backward it ran under)"}
     S_tok = sum((hw[0] // s) * (hw[1] // s) for s in (8, 16, 32))
     n_b = n_pull                                   # one bin + one tile launch per MSDA backward call
     ms_b = ms_push + ms_pull
@@ -425,6 +453,43 @@ def main():
         else:
             traffic_note = "PMC file is older than csrc/msda_block.hip: refused"
 
+    # ---- the hot path alone, in the driver's own record: the SAME model, the segmentation head on the
+    # detached feature maps of one cached backbone forward per batch (the features require gradients, so the head's backward
+    # does all the work it does in the full step), clip + AdamW over the head's parameters.  After every other timed region.
+    head_leg = None
+    if world == 1 and not a.head_only and a.head_steps > 0:
+        cached = []
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            for images, targets in batches:
+                f_ = model.backbone(images.contiguous(memory_format=torch.channels_last))
+                cached.append(({k: v.detach().clone().requires_grad_(True) for k, v in f_.items()}, targets))
+        saved_hooks, model.grad_ready_hooks = model.grad_ready_hooks, None
+
+        def head_step(i):
+            feats, targets = cached[i % len(cached)]
+            opt.zero_grad(set_to_none=True)
+            for v in feats.values():
+                v.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                l_ = model.head.total_loss(feats, targets)
+            l_.backward()
+            opt.step()                                  # (parameters without a gradient — the backbone's — are skipped)
+            return l_
+
+        for i in range(3):
+            head_step(i)
+        barrier()
+        t2 = time.perf_counter()
+        for i in range(a.head_steps):
+            head_step(3 + i)
+        barrier()
+        h_ms = (time.perf_counter() - t2) / a.head_steps * 1e3
+        model.grad_ready_hooks = saved_hooks
+        head_leg = {"ms_per_step": round(h_ms, 2), "images_per_sec": round(a.batch / h_ms * 1e3, 2), "steps": a.head_steps,
+                    "msda_offsets": a.msda_offsets,
+                    "what": "hot path only: pixel decoder + MP decoder + matching + 60 losses + backward + clip + AdamW of the head, on the "
+                            "detached bf16 feature maps of a cached backbone forward of the same model and batches"}
+
     # second number: the same step with trained-like sampling offsets (the headline above is iteration 0 of a
     # freshly initialised model); 3 warm-up + 10 timed steps, launch log off
     trained_ms = None
@@ -439,9 +504,10 @@ def main():
         barrier()
         trained_ms = mdist.max_over_ranks(time.perf_counter() - t1, dev) / a.trained_steps * 1e3
 
-    # test-only (MPF_CHECK_SYNC=1): the ranks' parameters must have stayed identical through the averaged updates
+    # replicas check (on by default up to 8 ranks, MPF_CHECK_SYNC=0 turns it off): the ranks' parameters must have stayed
+    # identical through the averaged updates — outside every timed region
     sync_spread = None
-    if mdist.distributed() and os.environ.get("MPF_CHECK_SYNC", "0") == "1":
+    if mdist.distributed() and os.environ.get("MPF_CHECK_SYNC", "1" if world <= 8 else "0") == "1":
         ps_ = list(model.parameters())
         cs = torch.stack([p.detach().double().sum() for p in ps_])                 # signed sum per parameter tensor
         scale = torch.stack([p.detach().double().abs().sum() for p in ps_]) + 1e-30
@@ -523,7 +589,7 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16 (backbone, decoder) + f32 (pixel decoder, losses), as the reference's AMP",
             "data": "synthetic",
-            "config": {"workload": workload, "baseline_config": a.workload, "head_only": bool(a.head_only),
+            "config": {"workload": workload, "baseline_config": a.workload, "head_only_workload": bool(a.head_only),
                        "global_batch": a.batch * world, "per_gpu_batch": a.batch, "parallelism": f"dp{world}",
                        "tokens_per_image_S": S_tok, "final_loss": round(final_loss, 4),
                        "roofline_steps": P, "msda_offsets": a.msda_offsets,
@@ -582,6 +648,10 @@ def main():
                                                      "what": "same step, sampling offsets scattered per query (sigma ~ 3 px): offset weights N(0, 0.18), biases + N(0, 1 px)"}
         if sync_spread is not None:
             out["config"]["param_sync_spread"] = sync_spread
+        if grad_sync_info is not None:
+            out["config"]["grad_sync"] = grad_sync_info
+        if head_leg is not None:
+            out["config"]["head_only"] = head_leg
         out["config"]["fp32_gemm"] = ("fp16 x 2 split: two pieces per operand, three MFMA products, power-of-two scale from the operand's "
                                       "largest magnitude; error vs fp64 <= the library fp32 GEMM's (tests/test_gemm3_gpu.py)")
         out["config"]["miopen_find_db"] = "mismatch (MIOpen ignored the shipped db)" if _miopen.db_mismatch() else "shipped"

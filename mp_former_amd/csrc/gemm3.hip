@@ -81,19 +81,6 @@ int g_nt2 = 1;             // mpf_set_option("gemm3_nt2"): grouped fp16 x 2 weig
 int g_tn3 = 1;             // mpf_set_option("gemm3_tn3"): fp16 x 2 TN products with N % 256 == 0 on 192 x 256 tiles, one 8-wave workgroup per CU, where the tiles fill the chip (2: wherever M >= 2048; 0: never)
 int g_ws = 512;            // mpf_set_option("gemm3_ws"): K = 256, N % 256 == 0, N >= this: fp16 x 2 products on the weight-stationary kernel (0 = never)
 
-#ifdef G3_TIMING
-// phase timing (build with -DG3_TIMING; tools/bench_gemm3.py --phases): s_memtime deltas of wave 0 of every
-// block, summed: [0] barrier-1 wait, [1] split + LDS write, [2] barrier-2 wait, [3] load issue, [4] MFMA step, [5] steps
-__device__ unsigned long long g3_dbg[8];
-#define G3_T(i)                                                       \
-    {                                                                 \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        tacc[i] += now_ - tlast;                                      \
-        tlast = now_;                                                 \
-    }
-#else
-#define G3_T(i)
-#endif
 
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b)       // {b.hi16, a.hi16}
 {
@@ -715,10 +702,6 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
     // loads inside branches hipcc cannot count them and falls back to vmcnt(0) before the LDS writes,
     // which would drain the two-steps-ahead A loads every step.
     const int klast = (nk - 1) * kBK;
-#ifdef G3_TIMING
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long tlast = __builtin_amdgcn_s_memtime();
-#endif
     int vmE = 3, vmO = 3;
     // order of the vector-memory operations of a step: [B DMA of the next step] [A loads two steps ahead].  Memory
     // operations complete in order, so "at most the 4 (ABF: 2) youngest outstanding" = the DMA has landed.
@@ -732,49 +715,33 @@ __device__ __forceinline__ void g3_tn_tile(const G3& p, unsigned char* lds, cons
     __builtin_amdgcn_sched_barrier(0);
     for (int kt = 0; kt < nk; kt += 2) {
         __syncthreads();                            // everyone is done with the A image and with B stage 1
-        G3_T(0);
         G3_WRITE(raE, vmE);
-        G3_T(1);
         G3_WAIT_B();                                // my pieces of B stage 0 (K step kt)
         __syncthreads();
-        G3_T(2);
         G3_LOAD_B(min((kt + 1) * kBK, klast), 1);   // B first: the wait above counts on this order
         __builtin_amdgcn_sched_barrier(0);
         G3_LA(raE, vmE, min((kt + 2) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
-        G3_T(3);
         __builtin_amdgcn_s_setprio(G3_PRIO);
         if constexpr (H2) acc.template step_h2<kAKc, kBKc, true>(lds, a_frag, b_frag, lane);
         else acc.template step<kAKc, kBKc, false, ABF, true>(lds, a_frag, b_frag, lane);
         __builtin_amdgcn_s_setprio(0);
-        G3_T(4);
         if (kt + 1 >= nk) break;
         __syncthreads();
-        G3_T(0);
         G3_WRITE(raO, vmO);
-        G3_T(1);
         G3_WAIT_B();
         __syncthreads();
-        G3_T(2);
         G3_LOAD_B(min((kt + 2) * kBK, klast), 0);
         __builtin_amdgcn_sched_barrier(0);
         G3_LA(raO, vmO, min((kt + 3) * kBK, klast));
         __builtin_amdgcn_sched_barrier(0);
-        G3_T(3);
         __builtin_amdgcn_s_setprio(G3_PRIO);
         if constexpr (H2) acc.template step_h2<kAKc, kBKc, true>(lds, a_frag, b_frag + kBstage, lane);
         else acc.template step<kAKc, kBKc, false, ABF, true>(lds, a_frag, b_frag + kBstage, lane);
         __builtin_amdgcn_s_setprio(0);
-        G3_T(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (surplus DMA pieces of the clamped last steps must not outlive the LDS allocation)
 #undef G3_WAIT_B
-#ifdef G3_TIMING
-    if (tid == 0) {
-        for (int i = 0; i < 5; ++i) atomicAdd(&g3_dbg[i], tacc[i]);
-        atomicAdd(&g3_dbg[5], (unsigned long long)nk);
-    }
-#endif
 
     const float omax = g3_epilogue<NJ, 4, Acc<NJ, false>, H2>(p, acc, lane, m0 + wr * 64, n0 + wc * (BN / 2), inv_a, inv_b);
     if constexpr (H2) {
@@ -2417,14 +2384,3 @@ extern "C" int mpf_gemm3_nt_reduce(const float* c_part, int64_t c_numel, const f
     return mpf::check(hipGetLastError(), "mpf_gemm3_nt_reduce");
 }
 
-#ifdef G3_TIMING
-extern "C" int mpf_gemm3_debug_read(unsigned long long* out8, int reset)
-{
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g3_dbg), 8 * sizeof(unsigned long long));
-    if (e == hipSuccess && reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g3_dbg), z, sizeof(z));
-    }
-    return mpf::check(e, "mpf_gemm3_debug_read");
-}
-#endif

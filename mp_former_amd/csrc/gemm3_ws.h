@@ -34,12 +34,6 @@
 // it from that XCD's L2) owns rows [rw * rpw, (rw + 1) * rpw), rpw a multiple of 16 chosen so that every CU has work:
 // 43 008 rows on 256 CUs = 176 rows each (245 workers) instead of 448 tiles on 512 slots.
 
-#ifndef WS_ABL
-#define WS_ABL 0      // timing experiments only (tools/ab_ws_ablate.sh; results wrong): 1 no convert, 2 no MFMAs, 4 no epilogue, 8 no DMA
-#endif
-#ifndef WS_TIME_PROLOGUE
-#define WS_TIME_PROLOGUE 0
-#endif
 constexpr int kWsBM = 32;                 // rows per tile
 constexpr int kWsK = 256;                 // contraction length (8 K steps of 32)
 constexpr int kWsThreads = 512;           // 8 waves x 32 columns
@@ -80,19 +74,13 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
     // (slots kk and 32 + kk) are conflict-free.  Rows past the worker's range repeat its last row (never stored).
     const unsigned src_off = (unsigned)((((2 * lane) & 63) | (lane >> 5)) * 16);
     auto dma_rows = [&](int t) {
-#if !(WS_ABL & 8)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int rl = wave * 4 + i;
             const int row = min(r0 + t * kWsBM + rl, r1 - 1);
             glds16(p.a + (int64_t)row * p.lda, src_off, lds_stage + (unsigned)((t & 1) * kWsStage + rl * 1024));
         }
-#endif
     };
-#ifdef G3_TIMING
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tlast = __builtin_amdgcn_s_memtime();
-#endif
     dma_rows(0);
     dma_rows(1);
 
@@ -106,11 +94,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
-#if WS_ABL & 128     // (timing only) the same bytes as one contiguous 1 KB per wave instruction
-                    fb[s][j][pl] = *reinterpret_cast<const uint4*>(p.bp + (int64_t)pl * p.plane + (int64_t)n0 * kWsK + ((j * 8 + s) * 64 + lane) * 8);
-#else
                     fb[s][j][pl] = *reinterpret_cast<const uint4*>(bw + (int64_t)pl * p.plane + (int64_t)j * 16 * kWsK + s * 32);
-#endif
     }
     float sc_a, inv_a, sc_b, inv_b;
     h2_scale(amax_read(p.a_amax), &sc_a, &inv_a);
@@ -130,15 +114,8 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
             const int rr = wave * 4 + 2 * a + (lane >> 5);
             const float4 u = *reinterpret_cast<const float4*>(st + rr * 1024 + kk * 16);
             const float4 v = *reinterpret_cast<const float4*>(st + rr * 1024 + (32 + kk) * 16);
-#ifdef G3_TIMING
-#endif
             uint4 h, l;
-#if WS_ABL & 1
-            h = make_uint4(__float_as_uint(u.x), __float_as_uint(u.y), __float_as_uint(u.z), __float_as_uint(u.w));
-            l = make_uint4(__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w));
-#else
             split8h(u, v, sc_a, &h, &l);
-#endif
             const int pos = kk ^ (rr & 15);
             *reinterpret_cast<uint4*>(pb + rr * 1024 + pos * 16) = h;
             *reinterpret_cast<uint4*>(pb + rr * 1024 + (32 + pos) * 16) = l;
@@ -148,24 +125,10 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
     // tiles 0 and 1 of this wave's rows and the weight fragments have arrived.  The BUILTIN, not inline asm: hipcc's waitcnt pass
     // has to see that its own 40 loads are done, or it drains them with vmcnt(N) waits inside the loop that count the row
     // copies it does not know of — i.e. waits for copies issued a moment ago.  (vmcnt 0, expcnt 7, lgkmcnt 15: gfx9 encoding)
-#ifdef G3_TIMING
-    if (WS_TIME_PROLOGUE) { G3_T(1); }             // everything requested
-#endif
     __builtin_amdgcn_s_waitcnt(0x0F70);
-#ifdef G3_TIMING
-    if (WS_TIME_PROLOGUE) { G3_T(2); }             // ... and arrived
-#endif
     convert(0);
     dma_rows(2);
     ws_barrier();
-#ifdef G3_TIMING
-    if (WS_TIME_PROLOGUE) {                        // prologue detail: [1] issue, [2] wait, [3] convert + barrier; the loop is not stamped
-        G3_T(3);
-        if (tid == 0) { for (int i = 0; i < 7; ++i) atomicAdd(&g3_dbg[i], tacc[i]); atomicAdd(&g3_dbg[7], 1ull); }
-        for (int i = 0; i < 8; ++i) tacc[i] = 0;
-    }
-#endif
-    G3_T(0);
 
     // fragment of (row tile i, plane pl, K step s): row 16 i + r16, chunk (32 pl + ((4 s + g) ^ r16))
     const int fbase = r16 * 1024 + (g ^ (r16 & 3)) * 16;
@@ -188,7 +151,6 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             if (s + 1 < 8) { WS_LOAD_FRAGS((s + 1) & 1, s + 1) }
-#if !(WS_ABL & 8)
             if (s & 1) {     // one row copy of tile t + 3 per two K steps (into the rows this wave converted in `middle`): all 32 copies of a
                              // workgroup requested together right after the barrier queued behind each other in the CU's address unit
                              // (~500 cycles per tile for the last wave); spread over the MFMA phase the issue waits hide (N = 1024: 88 -> 85 us)
@@ -196,13 +158,6 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
                 const int row = min(r0 + (t + 3) * kWsBM + rl, r1 - 1);
                 glds16(p.a + (int64_t)row * p.lda, src_off, lds_stage + (unsigned)(((t + 3) & 1) * kWsStage + rl * 1024));
             }
-#endif
-#if WS_ABL & 2
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j][0] += __uint_as_float(fa[s & 1][i][0].x ^ fb[s][j][1].y) + __uint_as_float(fa[s & 1][i][1].z ^ fb[s][j][0].w);
-#else
             // l.h, h.l, h.h — the order of Acc2::pass (smallest first); four independent accumulators per product
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -219,7 +174,6 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_fragh(fb[s][j][0]), as_fragh(fa[s & 1][i][0]), acc[i][j], 0, 0, 0);
-#endif
         }
 #undef WS_LOAD_FRAGS
     };
@@ -252,10 +206,7 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
     auto middle = [&](int tc, int te) {
         // in flight, oldest first: the rows of tile tc, stores of earlier epilogues, the rows of tile tc + 1 (4 loads), the operands
         // of this epilogue (kEpiLoads loads, requested right after those rows): "at most 4 + kEpiLoads outstanding" = rows tc landed
-#if !(WS_ABL & 32)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WS_ABL & 8) ? 0 : 4 + kEpiLoads) : "memory");
-#endif
-        G3_T(3);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + kEpiLoads) : "memory");
         float* crow[2];
         bool mok[2];
         const int m_tile = r0 + max(te, 0) * kWsBM;
@@ -269,13 +220,9 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
         __builtin_amdgcn_sched_barrier(0);
         convert(tc);
         __builtin_amdgcn_sched_barrier(0);
-        G3_T(4);
         if (te >= 0) {                      // (uniform)
             // ---- epilogue (the arithmetic and its order are g3_epilogue's; an absent addend is not added: x + 0 differs from x
             // only in the sign of a zero) -------------------------------------------------------------------------------------
-#if WS_ABL & 4
-            omax = fmaxf(omax, acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] + (float)gb[0]);
-#else
             unsigned wb[2] = {0u, 0u};
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -311,10 +258,8 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
                         *reinterpret_cast<unsigned*>(p.gbits_out + (int64_t)min(m_tile + i * 16 + r16, r1 - 1) * p.ldgbits_out + (n0 >> 3)) = w32;
                 }
             }
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
-        G3_T(5);
     };
 
     // Every wave: convert tile t + 1 and store tile t - 1 (accumulators live across the barrier), refill the rows just consumed,
@@ -330,20 +275,9 @@ __global__ __launch_bounds__(kWsThreads, 2) void gemm3_ws_kernel(G3 p, int rpw, 
         __builtin_amdgcn_sched_barrier(0);
         compute(t);
         __builtin_amdgcn_sched_barrier(0);
-        G3_T(2);
         ws_barrier();                    // plane image t + 1 complete; plane image t free for the convert of tile t + 2
-        G3_T(6);
     }
     middle(ntile + 1, ntile - 1);
-#ifdef G3_TIMING
-#ifndef WS_TIME_WAVE
-#define WS_TIME_WAVE 0
-#endif
-    if (tid == WS_TIME_WAVE * 64 && !WS_TIME_PROLOGUE) {
-        for (int i = 0; i < 7; ++i) atomicAdd(&g3_dbg[i], tacc[i]);
-        atomicAdd(&g3_dbg[7], (unsigned long long)ntile);
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (surplus row copies must not outlive the LDS allocation)
     if (p.out_amax) {                    // (uniform) one atomic per workgroup
 #pragma unroll

@@ -106,8 +106,21 @@ class FlatGradSync:
     tests/test_head_gpu.py::test_head_config_A_runs_and_is_finite), so the two trajectories agree there.
     """
 
-    def __init__(self, groups, broadcast=True):
+    def __init__(self, groups, broadcast=True, wire_dtype=None):
+        """``wire_dtype=torch.bfloat16``: the gradients cross the links as bf16 (half the bytes of a bucket) — each group owns a
+        second flat buffer in that dtype, ``launch`` casts the fresh gradients straight into it, the collective SUMS it, and
+        ``finish`` unpacks into the fp32 buffer the optimizer reads (`flat = wire * 1/world`, the division in fp32).  What the
+        reference's hook point (train_net.py:307-322: the full-model clip wrapper sees the averaged gradients) receives is then a
+        gradient with 8 mantissa bits per element and rank: tests/test_dist_cpu.py bounds the parameter drift against the fp32
+        wire over 5 AdamW steps.  Default None = fp32 on the wire, bit-for-bit what DistributedDataParallel averages."""
         self.world = world_size()
+        if wire_dtype in (None, torch.float32):
+            wire_dtype = None
+        elif wire_dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("FlatGradSync: wire_dtype must be None / torch.float32, torch.bfloat16 or torch.float16")
+        self.wire_dtype = wire_dtype
+        self.record = False               # bench.py: events around the launches / the waits of finish() (timing())
+        self._ev = None
         self.groups = []
         for params in groups:
             params = [p for p in params if p.requires_grad]
@@ -121,12 +134,16 @@ class FlatGradSync:
                 offs.append(total)
                 total += (p.numel() + 63) // 64 * 64                     # 256-byte aligned slots
             flat = torch.zeros(total, dtype=torch.float32, device=dev)
-            views = []
+            wire = torch.zeros(total, dtype=wire_dtype, device=dev) if wire_dtype is not None else None
+            views, wviews = [], []
             for p, o in zip(params, offs):
                 if not (p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))):
                     raise RuntimeError("FlatGradSync: dense parameters only")
                 views.append(flat[o:o + p.numel()].as_strided(p.shape, p.stride()))       # the parameter's own layout
-            self.groups.append({"params": params, "flat": flat, "views": views, "handle": None, "launched": False})
+                if wire is not None:
+                    wviews.append(wire[o:o + p.numel()].as_strided(p.shape, p.stride()))
+            self.groups.append({"params": params, "flat": flat, "views": views, "wire": wire, "wviews": wviews, "handle": None,
+                                "launched": False, "early": False})
         if broadcast and distributed():
             for g in self.groups:
                 for p in g["params"]:
@@ -139,41 +156,122 @@ class FlatGradSync:
             return dist.ReduceOp.SUM
         return dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
 
+    def bucket_bytes(self):
+        """bytes each group's collective moves per rank (the wire buffer when there is one)"""
+        bufs = [g["wire"] if g["wire"] is not None else g["flat"] for g in self.groups]
+        return [int(b.numel() * b.element_size()) for b in bufs]
+
     @torch.no_grad()
     def launch(self, i):
         g = self.groups[i]
         if g["launched"]:
             return
+        wire = g["wire"] is not None
         srcs, dsts = [], []
-        for p, v in zip(g["params"], g["views"]):
+        for p, v in zip(g["params"], g["wviews"] if wire else g["views"]):
             if p.grad is None:
                 v.zero_()                                                 # unused this step: contributes zeros
-            elif p.grad.data_ptr() != v.data_ptr():
+            elif wire or p.grad.data_ptr() != v.data_ptr():
                 srcs.append(p.grad)
                 dsts.append(v)
             p.grad = None            # (finish() puts the averaged view here; anything that shows up before is a late gradient)
         if dsts:
-            torch._foreach_copy_(dsts, srcs)
+            torch._foreach_copy_(dsts, srcs)                              # (casts to the wire dtype where there is one)
+        if self.record and self._ev is not None:
+            self._ev["launch"][i].record()
         if distributed():
-            g["handle"] = dist.all_reduce(g["flat"], op=self._avg_op(), async_op=True)
+            buf = g["wire"] if wire else g["flat"]
+            g["handle"] = dist.all_reduce(buf, op=dist.ReduceOp.SUM if wire else self._avg_op(), async_op=True)
         g["launched"] = True
+        g["early"] = not self._in_finish
+
+    _in_finish = False
 
     @torch.no_grad()
     def finish(self):
+        self._in_finish = True
+        try:
+            for i, g in enumerate(self.groups):
+                if g["launched"]:
+                    late = [j for j, p in enumerate(g["params"]) if p.grad is not None]
+                    if late:
+                        raise RuntimeError(f"FlatGradSync: {len(late)} gradient(s) of group {i} arrived after its all-reduce was "
+                                           "launched — those parameters belong in a later group")
+                else:
+                    self.launch(i)
+        finally:
+            self._in_finish = False
+        rec = self.record and self._ev is not None
+        if rec:
+            self._ev["wait0"].record()
+            self._ev["early"] = [bool(g["early"]) for g in self.groups]
         for i, g in enumerate(self.groups):
-            if g["launched"]:
-                late = [j for j, p in enumerate(g["params"]) if p.grad is not None]
-                if late:
-                    raise RuntimeError(f"FlatGradSync: {len(late)} gradient(s) of group {i} arrived after its all-reduce was "
-                                       "launched — those parameters belong in a later group")
-            else:
-                self.launch(i)
-        for g in self.groups:
             if g["handle"] is not None:
                 g["handle"].wait()
                 g["handle"] = None
-                if self._avg_op() != dist.ReduceOp.AVG and self.world > 1:
+                if g["wire"] is None and self._avg_op() != dist.ReduceOp.AVG and self.world > 1:
+                    g["flat"].mul_(1.0 / self.world)
+            if rec:
+                self._ev["done"][i].record()
+            if g["wire"] is not None:                                     # unpack: fp32 <- wire, averaged in fp32
+                g["flat"].copy_(g["wire"])
+                if self.world > 1:
                     g["flat"].mul_(1.0 / self.world)
             for p, v in zip(g["params"], g["views"]):
                 p.grad = v
             g["launched"] = False
+        if rec:
+            self._ev["wait1"].record()
+            self._ev["n"] += 1
+
+    # ---- diagnostics (bench.py at N > 1; never inside the timed region) ---------------------------------------------------
+    def record_events(self, on=True):
+        """Record events on the current stream at every launch, in front of finish()'s waits and behind each of them.  GPU only."""
+        self.record = bool(on)
+        if on:
+            E = lambda: torch.cuda.Event(enable_timing=True)              # noqa: E731
+            n = len(self.groups)
+            self._ev = {"launch": [E() for _ in range(n)], "done": [E() for _ in range(n)], "wait0": E(), "wait1": E(), "n": 0,
+                        "early": [False] * n}
+
+    def timing(self):
+        """{exposed_wait_ms, in_flight_ms[i], launched_early[i]} of the LAST recorded step (synchronises).  exposed_wait_ms = time the
+        compute stream spends inside finish() from the first wait to the last unpack: what the step pays for the exchange after
+        the overlap; in_flight_ms[i] = launch of bucket i -> its wait satisfied (includes the compute it hid under)."""
+        if not self._ev or not self._ev["n"]:
+            return None
+        torch.cuda.synchronize()
+        ev = self._ev
+        return {"exposed_wait_ms": round(ev["wait0"].elapsed_time(ev["wait1"]), 4),
+                "in_flight_ms": [round(ev["launch"][i].elapsed_time(ev["done"][i]), 4) for i in range(len(self.groups))],
+                "launched_early": list(ev["early"])}
+
+    @torch.no_grad()
+    def standalone_allreduce_ms(self, reps=5):
+        """Each bucket's collective alone on an idle device (events around a blocking all-reduce of the buffer the step sends), median
+        of ``reps``: the figure an N-GPU line needs to tell a slow link from a lost overlap.  The buffers hold stale gradients —
+        call between steps only (the next launch overwrites them)."""
+        out = []
+        for g in self.groups:
+            buf = g["wire"] if g["wire"] is not None else g["flat"]
+            scratch = torch.zeros_like(buf)
+            ts = []
+            for _ in range(reps + 1):
+                if buf.is_cuda:
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    if distributed():
+                        dist.all_reduce(scratch)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                else:
+                    import time
+                    t0 = time.perf_counter()
+                    if distributed():
+                        dist.all_reduce(scratch)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+            ts = sorted(ts[1:])
+            out.append(round(ts[len(ts) // 2], 4))
+        return out

@@ -5,7 +5,7 @@ FFN of ``MSDeformAttnTransformerEncoderLayer`` (msdeformattn.py:116-131) when th
 the fused encoder node — sees [N * S, C] activations with N * S = 43 008 rows at 1024 x 1024.  Forward and input gradient are
 ``gemm3`` (fp32 operands split into bf16 pieces, six products, fp32-class error: tests/test_gemm3_gpu.py), the weight
 gradient is its split-over-rows "NT" form whose staging loop also yields the bias gradient.  Shapes outside the kernels'
-(K % 32, N % 4, fewer than 1 024 rows, non-fp32, CPU) take ``F.linear``."""
+(in / out features not multiples of 32, fewer than 1 024 rows, non-fp32 or non-contiguous weight / bias, CPU) take ``F.linear``."""
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -38,15 +38,20 @@ class _LinearFn(Function):
         return dx, dw, db
 
 
-def native_ok(x, weight):
+def native_ok(x, weight, bias=None):
+    """Both directions must fit the kernels: the forward contracts over in_features, the input gradient (dx = g @ W) over
+    out_features — each a multiple of 32 (mpf_gemm3_tn's K step; ADVICE r5: out % 4 alone let a 72-wide Linear through the
+    forward and fail in backward).  Dense fp32 weight, dense fp32 bias."""
     rows = x.numel() // max(x.shape[-1], 1)
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and rows >= 1024 and x.shape[-1] % 32 == 0
-            and weight.shape[0] % 4 == 0 and not torch.is_autocast_enabled())
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2 and weight.is_contiguous()
+            and rows >= 1024 and x.shape[-1] % 32 == 0 and weight.shape[0] % 32 == 0
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.device == x.device))
+            and not torch.is_autocast_enabled())
 
 
 def linear_tall(x, weight, bias=None):
     """F.linear for inputs with many rows: the native fp32 GEMM when its shapes apply."""
-    if not native_ok(x, weight):
+    if not native_ok(x, weight, bias):
         return F.linear(x, weight, bias)
     x2 = x.reshape(-1, x.shape[-1])
     if x2.stride(1) != 1 or x2.stride(0) % 4 != 0:

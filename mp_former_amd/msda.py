@@ -321,16 +321,13 @@ class MSDeformAttn(nn.Module):
             N, Len_q, self.n_heads, self.n_levels * self.n_points)
         attention_weights = F.softmax(attention_weights, -1).view(
             N, Len_q, self.n_heads, self.n_levels, self.n_points)
-        if reference_points.shape[-1] == 2:
-            offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
-            sampling_locations = reference_points[:, :, None, :, None, :] \
-                + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
-            sampling_locations = reference_points[:, :, None, :, None, :2] \
-                + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
-        else:
-            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+        if reference_points.shape[-1] != 2:
+            # the reference also accepts 4 numbers per point (box-refinement detectors, ms_deform_attn.py:111-113); nothing on the
+            # segmentation path produces them (msdeformattn.py:72-86 builds 2-d points), so that form is not carried here
+            raise ValueError("reference_points must be [N, Len_q, n_levels, 2] on this path, got last dim {}".format(
                 reference_points.shape[-1]))
+        wh = input_spatial_shapes.flip(-1).to(sampling_offsets.dtype)                  # (W_l, H_l): x is normalised by the width
+        sampling_locations = reference_points[:, :, None, :, None, :] + sampling_offsets / wh[None, None, None, :, None, :]
         # strict: no silent fallback
         output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                             sampling_locations.contiguous(), attention_weights,

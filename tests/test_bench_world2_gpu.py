@@ -25,14 +25,14 @@ def _free_port():
     return p
 
 
-def _run_two_ranks(grad_sync, **extra_env):
+def _run_two_ranks(grad_sync, extra_args=(), **extra_env):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MPF_FORCE_DIST"):
         env.pop(k, None)
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MPF_CHECK_SYNC="1", MPF_GRAD_SYNC=grad_sync, **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_bench_world2_child.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--profile-steps", "1", "--trained-steps", "1", "--size", "512", "--no-cpu-baseline"]
+           "--profile-steps", "1", "--trained-steps", "1", "--size", "512", "--no-cpu-baseline"] + list(extra_args)
     return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1400)
 
 
@@ -55,9 +55,11 @@ def test_missing_res3_hook_is_caught_up_by_finish():
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("grad_sync", ["flat", "ddp"])
+@pytest.mark.parametrize("grad_sync", ["flat", "ddp", "flat-bf16"])
 def test_bench_two_ranks_one_device(grad_sync):
-    r = _run_two_ranks(grad_sync)
+    wire = "bf16" if grad_sync.endswith("-bf16") else "fp32"
+    grad_sync = grad_sync.split("-")[0]
+    r = _run_two_ranks(grad_sync, ("--grad-wire", wire))
     assert r.returncode == 0, f"bench.py --gpus 2 failed:\n{r.stdout[-2000:]}\n{r.stderr[-6000:]}"
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, f"exactly one JSON line expected from rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
@@ -74,6 +76,15 @@ def test_bench_two_ranks_one_device(grad_sync):
     # identical parameters on both ranks after 4 averaged updates: per parameter tensor |sum_rank0 - sum_rank1| / sum|p|
     # (a tensor left out of the exchange would differ by >= 1e-5 after four AdamW steps)
     assert out["config"]["param_sync_spread"] <= 1e-7, out["config"]["param_sync_spread"]
+    gs = out["config"].get("grad_sync")
+    if grad_sync == "flat":                                  # the N > 1 line explains its own exchange
+        assert gs["wire_dtype"] == wire and len(gs["buckets_mb"]) == 3 and len(gs["allreduce_ms"]) == 3 and len(gs["in_flight_ms"]) == 3
+        assert all(t > 0 for t in gs["allreduce_ms"]) and gs["exposed_wait_ms"] >= 0
+        assert gs["launched_under_backbone"] is True and gs["launched_early"] == [True, True, False]
+        mb = {"fp32": (80.0, 88.0), "bf16": (40.0, 44.0)}[wire]               # head | res5 + res4 buckets on the wire
+        assert abs(gs["buckets_mb"][0] - mb[0]) < 0.1 * mb[0] and abs(gs["buckets_mb"][1] - mb[1]) < 0.1 * mb[1], gs["buckets_mb"]
+    else:
+        assert gs is None
     assert out["roofline"]["launches_per_step"] > 0         # the split-bf16 GEMMs ran on the profiled step ...
     msda = [e for e in out["roofline"]["also"] if e["kernel"].startswith("MSDA backward")]
     assert msda and msda[0]["launches"] > 0                 # ... and so did the native MSDA backward

@@ -131,6 +131,84 @@ def test_world2_gloo():
     assert res[0]["flat_grads"] == res[1]["flat_grads"]
 
 
+def _wire_worker(rank, world, port, q):
+    """5 clipped AdamW steps of a small two-bucket model, gradients averaged by FlatGradSync over an fp32 and over a bf16 wire
+    (the reference's hook point: train_net.py:307-322 clips the AVERAGED gradients, then AdamW)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from mp_former_amd import dist as mdist
+    mdist.init_from_env("gloo")
+    out = {}
+    for name, wire in (("fp32", None), ("bf16", torch.bfloat16)):
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(12, 32), torch.nn.GELU(), torch.nn.Linear(32, 32), torch.nn.GELU(), torch.nn.Linear(32, 5))
+        p0 = [p.detach().clone() for p in net.parameters()]
+        sync = mdist.FlatGradSync([list(net[4].parameters()) + list(net[2].parameters()), list(net[0].parameters())], wire_dtype=wire)
+        slots = [sum((p.numel() + 63) // 64 * 64 for p in g["params"]) for g in sync.groups]
+        assert sync.bucket_bytes() == [n * (2 if wire else 4) for n in slots]          # half the bytes on the bf16 wire
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-2, weight_decay=0.05)
+        gen = torch.Generator().manual_seed(100 + rank)                  # every rank its own images
+        wire_exact = True
+        for step in range(5):
+            for p in net.parameters():
+                p.grad = None
+            x = torch.randn(16, 12, generator=gen)
+            y = torch.randn(16, 5, generator=gen)
+            (net(x) - y).square().mean().backward()
+            sync.launch(0)                                               # (what the hook does under the backbone's backward)
+            sync.finish()
+            if wire is not None:                                         # the averaged gradient is a sum of bf16 numbers / world
+                for g in sync.groups:
+                    wire_exact &= bool(torch.equal(g["flat"], g["wire"].float() / world))
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 0.5)
+            opt.step()
+        out[name] = [p.detach().clone() for p in net.parameters()]
+        out[name + "_delta"] = [a - b for a, b in zip(out[name], p0)]
+        out[name + "_wire_exact"] = wire_exact
+    q.put((rank, {k: ([t.tolist() for t in v] if isinstance(v, list) else v) for k, v in out.items()}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world2_bf16_wire_drift_is_bounded():
+    """SURVEY.md 8 f4 (second half): bf16 gradient all-reduce.  Over 5 clipped AdamW steps the parameters reached through the bf16
+    wire stay identical on both ranks and within 0.5 % (relative L2 of the total update, per tensor) of those reached through the
+    fp32 wire — bf16 rounds each rank's gradient to 8 bits (2^-9 relative), Adam's normalised update turns that into a
+    same-order perturbation of the step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wire_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["bf16"] == res[1]["bf16"] and res[0]["fp32"] == res[1]["fp32"]          # replicas stay bit-identical
+    assert res[0]["bf16_wire_exact"] and res[1]["bf16_wire_exact"]
+    assert res[0]["bf16"] != res[0]["fp32"]                                                # (the wire really was bf16)
+    worst = 0.0
+    for d16, d32 in zip(res[0]["bf16_delta"], res[0]["fp32_delta"]):
+        d16, d32 = torch.tensor(d16), torch.tensor(d32)
+        worst = max(worst, float((d16 - d32).norm() / d32.norm()))
+    assert worst < 5e-3, worst          # measured 1.7e-3
+    print("bf16-wire drift, worst tensor, relative to the 5-step update:", worst)
+
+
+def test_flat_grad_sync_wire_dtype_world1():
+    """world size 1 (no process group): the bf16 wire still rounds the gradients once (launch casts, finish unpacks)"""
+    from mp_former_amd import dist as mdist
+    lin = torch.nn.Linear(5, 3)
+    sync = mdist.FlatGradSync([list(lin.parameters())], broadcast=False, wire_dtype=torch.bfloat16)
+    lin(torch.randn(4, 5)).square().sum().backward()
+    g = lin.weight.grad.clone()
+    sync.finish()
+    assert torch.equal(lin.weight.grad, g.bfloat16().float())
+    with pytest.raises(ValueError):
+        mdist.FlatGradSync([list(lin.parameters())], broadcast=False, wire_dtype=torch.int8)
+
+
 def test_flat_grad_sync_rejects_late_gradients():
     """a gradient that shows up for a bucket after its all-reduce was launched must not be dropped silently"""
     from mp_former_amd import dist as mdist

@@ -448,6 +448,34 @@ def test_gemm3_tn3_kernel_bit_identical_to_the_two_pass_kernel(M, N, K):
     assert float(((res[1][0].double() - ref).abs() / den).max()) < 1e-6
 
 
+@pytest.mark.parametrize("cout", [72, 100])
+def test_linear_tall_widths_outside_the_kernels_take_the_library_in_both_directions(cout):
+    """out_features % 4 == 0 but % 32 != 0 (heads * levels * points = 72, any 4k width) passed the forward's shape
+    check and then failed in backward, whose dx = g @ W contracts over out_features.  Such widths — and non-contiguous
+    weights / non-fp32 biases — must take F.linear for the whole op: forward AND backward run and match fp64."""
+    from mp_former_amd.linear import linear_tall, native_ok
+    dev = torch.device("cuda:0")
+    torch.manual_seed(cout)
+    x = torch.randn(2, 2048, 256, device=dev, requires_grad=True)
+    w = (torch.randn(cout, 256, device=dev) / 16).requires_grad_(True)
+    b = torch.randn(cout, device=dev, requires_grad=True)
+    assert not native_ok(x, w, b)
+    y = linear_tall(x, w, b)
+    g = torch.randn_like(y)
+    y.backward(g)
+    x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    y64 = torch.nn.functional.linear(x64, w64, b64)
+    y64.backward(g.double())
+    for a_, r_ in ((y, y64), (x.grad, x64.grad), (w.grad, w64.grad), (b.grad, b64.grad)):
+        assert float((a_.double() - r_).abs().max()) <= 1e-5 * float(r_.abs().max()) + 1e-6
+    # a transposed (non-contiguous) weight view and a half-precision bias are refused by the native route as well
+    wt = torch.randn(256, 256, device=dev).t()
+    assert not native_ok(x, wt) and native_ok(x, wt.contiguous())
+    assert not native_ok(x, wt.contiguous(), torch.zeros(256, device=dev, dtype=torch.float16))
+    y2 = linear_tall(x.detach(), wt)
+    assert torch.allclose(y2, torch.nn.functional.linear(x.detach(), wt), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("rows,cin,cout", [(43008, 256, 288), (5000, 256, 1024), (2048, 1024, 256)])
 def test_linear_tall_native_forward_and_gradients(rows, cin, cout):
     """mp_former_amd.linear.linear_tall — the Linear of the per-layer encoder route and of the MSDeformAttn module
