@@ -372,7 +372,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dt = mdist.max_over_ranks(dt, dev)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     # ---- roofline block: a few MORE steps with the in-library launch log on (HIP events recorded on the launch stream
     # around every native kernel; outside the timed region, so the headline does not pay for the event records) --------

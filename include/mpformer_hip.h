@@ -653,6 +653,13 @@ typedef struct MpfSplitItemH2 {
 } MpfSplitItemH2;
 int mpf_amax_f32(const float* x, int64_t n, float* amax, void* stream);
 int mpf_amax_f32_grouped(const MpfAmaxItem* items_device, int n_items, int64_t total_blocks, void* stream);
+/* Run-time range guard of the fp16 x 2 form: the guarantee above is relative to the operand's largest magnitude, so rows far
+ * below it lose bits.  For operand a [rows, cols] (row stride lda) and the slot its consumer scales by:
+ * counters_device[0] += rows with a non-zero element, counters_device[1] += those whose largest magnitude is below
+ * 2^-log2_below of the slot (18: where the second piece stops being a normal fp16 number).  One pass over the operand, no
+ * synchronisation; the caller reads the two 64-bit counters when it wants them (mp_former_amd/encoder_fused.py: every 64th step). */
+int mpf_h2_range_stats(const float* a, int rows, int cols, int64_t lda, const float* amax_slot, int log2_below,
+                       unsigned long long* counters_device, void* stream);
 int mpf_gemm3_split_grouped_h2(const MpfSplitItemH2* items_device, int n_items, int64_t total_blocks, void* stream);
 /* the weight-gradient forms (mpf_gemm3_nt without b2, mpf_gemm3_nt_grouped, mpf_gemm3_conv3x3_wgrad) with both operands split
  * into fp16 pieces on the fly; column sums are taken from the unscaled values; mpf_gemm3_conv3x3_h2: mpf_gemm3_conv3x3 with

@@ -75,6 +75,7 @@ SIGNATURES = {
                            _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mpf_amax_f32": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp]),
     "mpf_amax_f32_grouped": (_c_int, [_c_vp, _c_int, ctypes.c_int64, _c_vp]),
+    "mpf_h2_range_stats": (_c_int, [_c_vp, _c_int, _c_int, ctypes.c_int64, _c_vp, _c_int, _c_vp, _c_vp]),
     "mpf_gemm3_split_grouped_h2": (_c_int, [_c_vp, _c_int, ctypes.c_int64, _c_vp]),
     "mpf_gemm3_tn_h2": (_c_int, [_c_vp, ctypes.c_int64, _c_vp, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64,
                               _c_vp, ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp]),

@@ -1548,6 +1548,54 @@ extern "C" int mpf_amax_f32(const float* x, int64_t n, float* amax, void* stream
     return mpf::check(hipGetLastError(), "mpf_amax_f32");
 }
 
+// Run-time range guard of the fp16 x 2 form.  The split keeps 22 bits of an element while its second piece
+// is a normal fp16 number, i.e. for elements within 2^-18 of the operand's amax slot; a ROW whose largest magnitude lies below
+// that loses one bit per further binade.  This pass counts, for one operand [rows, cols] and the slot its consumer scales by,
+// the non-zero rows and those whose largest magnitude is below 2^-log2_below of the slot: counters[0] += non-zero rows,
+// counters[1] += rows below.  One wave per row (cols % 4 == 0), one pair of atomics per workgroup.  mp_former_amd/encoder_fused.py
+// runs it on a sampled step over every operand of the encoder's GEMMs and warns when a share exceeds 0.1 %.
+__global__ __launch_bounds__(256) void h2_range_stats_kernel(const float* __restrict__ a, int rows, int cols, int64_t lda,
+                                                             const float* __restrict__ amax_slot, int log2_below,
+                                                             unsigned long long* __restrict__ counters)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float ref = __uint_as_float(amax_read(amax_slot));
+    const float thr = ldexpf(ref, -log2_below);
+    unsigned nz = 0, below = 0;
+    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+        const float4* __restrict__ row = reinterpret_cast<const float4*>(a + (int64_t)r * lda);
+        float m = 0.f;
+        for (int c = lane; c < cols / 4; c += 64) {
+            const float4 v = row[c];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        nz += m > 0.f;
+        below += (m > 0.f && m < thr);
+    }
+    __shared__ unsigned red[8];
+    if (lane == 0) { red[wave * 2] = nz; red[wave * 2 + 1] = below; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned v = red[threadIdx.x] + red[2 + threadIdx.x] + red[4 + threadIdx.x] + red[6 + threadIdx.x];
+        if (v) atomicAdd(counters + threadIdx.x, (unsigned long long)v);
+    }
+}
+
+extern "C" int mpf_h2_range_stats(const float* a, int rows, int cols, int64_t lda, const float* amax_slot, int log2_below,
+                                  unsigned long long* counters_device, void* stream)
+{
+    if (!a || !amax_slot || !counters_device) return mpf::fail(MPF_E_NULL, "h2_range_stats: NULL buffer");
+    if (rows <= 0 || cols <= 0 || cols % 4 || lda < cols || lda % 4 || ((uintptr_t)a & 15) || log2_below < 0 || log2_below > 120)
+        return mpf::fail(MPF_E_SHAPE, "h2_range_stats: cols and lda must be multiples of 4, a 16-byte aligned, 0 <= log2_below <= 120");
+    const int blocks = std::min(2048, (rows + 3) / 4);
+    mpf::set_kernel("h2_range_stats_kernel");
+    hipLaunchKernelGGL(h2_range_stats_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, rows, cols, lda, amax_slot, log2_below,
+                       counters_device);
+    return mpf::check(hipGetLastError(), "mpf_h2_range_stats");
+}
+
 extern "C" int mpf_amax_f32_grouped(const MpfAmaxItem* items_device, int n_items, int64_t total_blocks, void* stream)
 {
     if (n_items == 0 || total_blocks == 0) return 0;

@@ -34,18 +34,102 @@ PARAMS_PER_LAYER = 16
 _EPS = 1e-5
 
 # Range audit of the fp16 x 2 operands (tools/soak.py --range-audit): None, or {operand name: int64 [41] device
-# histogram}: bin b counts the rows whose largest magnitude is in [2^-(b+1), 2^-b) of what the operand's amax SLOT holds (the
-# scale's reference — the true maximum or the upper bound of amax.h), bin 40 everything below 2^-40 incl. all-zero rows.
+# histogram}: bin b counts the rows whose largest magnitude r (relative to what the operand's amax SLOT holds: the scale's
+# reference — the true maximum or the upper bound of amax.h) lies in (2^-(b+1), 2^-b], bin 40 everything at or below 2^-40
+# incl. all-zero rows.  (floor(-log2 r), not -floor(log2 r), which put every row one bin too high.)
 RANGE_AUDIT = None
+
+# Run-time range guard: the fp16 x 2 guarantee is relative to each operand's largest magnitude, so what it
+# promises for a ROW depends on how far that row lies below it.  Every RANGE_GUARD_EVERY-th call of the encoder (the third,
+# then every 64th: MPF_H2_RANGE_GUARD_EVERY, 0 = off) runs the python-sequenced route and passes every GEMM operand, forward and
+# backward, through mpf_h2_range_stats (one read of the operand, two device counters per operand, no synchronisation): rows
+# with a non-zero element, and those whose largest magnitude lies below 2^-18 of the slot (where the second piece stops being a
+# normal fp16 number).  The counters are copied to pinned memory at the next guarded call and read at the one after (no wait);
+# a share above RANGE_GUARD_SHARE warns once per process.  range_guard_report(sync=True) reads them now (tools/soak.py, tests).
+RANGE_GUARD_EVERY = int(os.environ.get("MPF_H2_RANGE_GUARD_EVERY", "64"))
+RANGE_GUARD_LOG2 = 18
+RANGE_GUARD_SHARE = 1e-3
+_GUARD_SLOTS = 64
+_guard = {"calls": 0, "active": False, "names": {}, "counters": None, "pending": None, "host": None, "warned": False}
+
+
+def _guard_begin():
+    """-> True when this encoder call is a guarded one (counts the call)."""
+    n = _guard["calls"]
+    _guard["calls"] = n + 1
+    if RANGE_GUARD_EVERY <= 0 or RANGE_AUDIT is not None:
+        return False
+    if not (n == 2 or (n > 2 and (n - 2) % RANGE_GUARD_EVERY == 0) or RANGE_GUARD_EVERY == 1):
+        return False
+    if _guard["pending"] is not None and _guard["pending"][1].query():          # the copy requested at the last guarded call has landed
+        _guard["host"] = _guard["pending"][0].clone()
+        _guard["pending"] = None
+        _guard_check(_guard["host"])
+    if _guard["counters"] is not None and _guard["pending"] is None:
+        pinned = torch.empty((_GUARD_SLOTS, 2), dtype=torch.int64).pin_memory()
+        pinned.copy_(_guard["counters"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _guard["pending"] = (pinned, ev)
+    return True
+
+
+def _guard_shares(host):
+    out = {}
+    for name, i in _guard["names"].items():
+        nz, below = int(host[i, 0]), int(host[i, 1])
+        out[name] = {"rows": nz, "below": below, "share": below / nz if nz else 0.0}
+    return out
+
+
+def _guard_check(host):
+    bad = {k: v for k, v in _guard_shares(host).items() if v["share"] > RANGE_GUARD_SHARE}
+    if bad and not _guard["warned"]:
+        import warnings
+        _guard["warned"] = True
+        worst = max(bad.items(), key=lambda kv: kv[1]["share"])
+        warnings.warn("mp_former_amd: fp16 x 2 GEMM operand '%s' has %.3f %% of its non-zero rows below 2^-%d of the operand's largest "
+                      "magnitude (%d of %d): those rows keep fewer than 22 bits in the pixel decoder's fp32 GEMMs (DESIGN.md section 2); "
+                      "%d operand(s) over the %.1f %% bar" % (worst[0], 100 * worst[1]["share"], RANGE_GUARD_LOG2, worst[1]["below"],
+                                                               worst[1]["rows"], len(bad), 100 * RANGE_GUARD_SHARE))
+
+
+def range_guard_report(sync=False, reset=False):
+    """{operand: {"rows", "below", "share"}} of the guarded calls so far: from the last landed copy, or (sync=True) from the
+    device counters now — which also applies the warning check."""
+    if _guard["counters"] is None:
+        return {}
+    if sync:
+        host = _guard["counters"].cpu()
+        _guard_check(host)
+    else:
+        host = _guard["host"]
+        if host is None:
+            return {}
+    rep = _guard_shares(host)
+    if reset:
+        _guard["counters"].zero_()
+        _guard["host"] = _guard["pending"] = None
+        _guard["warned"] = False
+    return rep
 
 
 def _audit(name, t, slot):
+    if _guard["active"]:
+        if _guard["counters"] is None or _guard["counters"].device != t.device:
+            _guard["counters"] = torch.zeros((_GUARD_SLOTS, 2), dtype=torch.int64, device=t.device)
+        i = _guard["names"].setdefault(name, len(_guard["names"]))
+        if i < _GUARD_SLOTS and t.dim() == 2 and t.stride(1) == 1 and t.shape[1] % 4 == 0 and t.stride(0) % 4 == 0:
+            with _lib.device_guard(t.device):
+                code = _lib.lib().mpf_h2_range_stats(t.data_ptr(), t.shape[0], t.shape[1], t.stride(0), slot.data_ptr(), RANGE_GUARD_LOG2,
+                                                     _guard["counters"][i].data_ptr(), _lib.stream_ptr(t.device))
+            _lib.check(code, "mpf_h2_range_stats")
     if RANGE_AUDIT is None:
         return
     from .gemm3 import amax_value
     ref = amax_value(slot).clamp_min(1e-38)
     r = (t.detach().abs().amax(1) / ref).clamp(2.0 ** -41, 1.0)
-    b = (-torch.floor(torch.log2(r))).clamp(0, 40).long()
+    b = torch.floor(-torch.log2(r)).clamp(0, 40).long()
     h = torch.bincount(b, minlength=41)
     RANGE_AUDIT[name] = h if name not in RANGE_AUDIT else RANGE_AUDIT[name] + h
 
@@ -345,7 +429,8 @@ class EncoderFn(Function):
         am = amax_slots(5 * nl + 3, src.device)          # per layer: ao, x1, h, the next layer's x, the next layer's q
         x_am, q_am, pos_am = amax(x, am[5 * nl]), am[5 * nl + 1], amax(pos_full, am[5 * nl + 2])
         F_ = params[10].shape[0]                          # ffn width (linear1.weight [F, C])
-        use_native = (_NATIVE_FWD and RANGE_AUDIT is None and host_shapes is not None and C == 256 and M == 8 and F_ % 128 == 0
+        ctx.guarded = guarded = _guard_begin()
+        use_native = (_NATIVE_FWD and RANGE_AUDIT is None and not guarded and host_shapes is not None and C == 256 and M == 8 and F_ % 128 == 0
                       and all(params[i * PARAMS_PER_LAYER + 10].shape[0] == F_ for i in range(nl)))
         if use_native:
             q = (x.view(N, S, C) + pos_full).view(R, C)
@@ -361,6 +446,7 @@ class EncoderFn(Function):
             ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
             ctx.planes_t = [planes2[10 * i + 5:10 * i + 10] for i in range(nl)]
             return x.view(N, S, C)
+        _guard["active"] = guarded                   # (the operands of this call go through mpf_h2_range_stats in _audit)
         for i in range(nl):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2_, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             (pv, pv_am), (po, po_am), (p1, p1_am), (p2, p2_am), (p288, p288_am) = planes2[10 * i:10 * i + 5]
@@ -392,6 +478,7 @@ class EncoderFn(Function):
                                                  padd_amax=None if last else pos_am, yplus_bound=None if last else qn_am)
             saved += [x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am, hbits]
             x, q, x_am, q_am = x2, qn, xn_am, qn_am
+        _guard["active"] = False
         ctx.save_for_backward(pos_full, level_embed, *params, *saved)
         ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
         ctx.planes_t = [planes2[10 * i + 5:10 * i + 10] for i in range(nl)]       # (W^T planes, amax) for the backward
@@ -421,7 +508,8 @@ class EncoderFn(Function):
                 meta[key] = split_level
         dparams = [None] * (nl * PARAMS_PER_LAYER)
         F_ = params[10].shape[0]
-        if (_NATIVE_BWD and RANGE_AUDIT is None and host_shapes is not None and aligned and L <= 4 and C == 256 and M == 8 and F_ % 256 == 0
+        guarded = bool(getattr(ctx, "guarded", False))
+        if (_NATIVE_BWD and RANGE_AUDIT is None and not guarded and host_shapes is not None and aligned and L <= 4 and C == 256 and M == 8 and F_ % 256 == 0
                 and all(saved[i * 20 + 19] is not None and params[i * PARAMS_PER_LAYER + 10].shape[0] == F_ for i in range(nl))):
             g, out, (o_dw, o_lvl, o_db, gs), dgb = _native_backward(g, params, saved, ctx.planes_t, meta, nl, (N, S, C), F_, rps, split_level)
             no3 = M * L * P * 3
@@ -440,6 +528,7 @@ class EncoderFn(Function):
         lvls = [None] * nl
         gq = None
         lng = LnGradGroup(2 * nl, R, g.device)           # the 2 nl LayerNorm parameter gradients: one reduce launch at the end
+        _guard["active"] = guarded
         for i in reversed(range(nl)):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]
             (x, q, value, loc, attn, ao, s1, mean1, rstd1, x1, h, s2, mean2, rstd2, x_am, ao_am, x1_am, h_am, q_am, hbits) = saved[i * 20:(i + 1) * 20]
@@ -489,6 +578,7 @@ class EncoderFn(Function):
             (dp[12], dp[13]), (dp[10], dp[11]), (dp[6], dp[7]), (dp[4], dp[5]) = _wgrad_group(
                 [(ds2, h), (dh, x1), (ds1, ao), (gv2, x)], [(ds2_am, h_am), (dh_am, x1_am), (ds1_am, ao_am), (gv_am, x_am)])
             dparams[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER] = dp
+        _guard["active"] = False
         return EncoderFn._finish(g, lng.finish(), torch.stack(lvls), dparams, params, nl, (N, S, C))
 
     @staticmethod

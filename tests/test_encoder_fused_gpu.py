@@ -225,3 +225,47 @@ def test_native_encoder_calls_match_the_python_sequenced_ones(shapes, batch, lay
             assert float((a - b).norm() / a.norm()) < 1e-6, key
         for n in gp0:
             assert float((gp0[n] - gp1[n]).norm() / (gp0[n].norm() + 1e-30)) < 1e-5, (key, n)
+
+
+def test_range_guard_flags_a_skewed_operand_and_stays_quiet_otherwise():
+    """Run-time range guard of the fp16 x 2 GEMMs (encoder_fused.RANGE_GUARD_EVERY; msdeformattn.py:314,320 promise fp32): on a
+    guarded call every GEMM operand of the encoder, forward and backward, is counted by mpf_h2_range_stats.  Ordinary inputs: no
+    operand has rows below 2^-18 of its slot beyond the bar, no warning.  One input level scaled by 2^-22 (its rows of the
+    value_proj operand x then sit far below the other levels'): the report shows it and the process warns once."""
+    import warnings
+    from mp_former_amd import encoder_fused as EF
+    from mp_former_amd import pixel_decoder as PD
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    shapes, batch = ((8, 8), (16, 16), (32, 32)), 2
+    enc = PD.MSDeformAttnTransformerEncoderOnly(d_model=256, nhead=8, num_encoder_layers=2, dim_feedforward=1024,
+                                                dropout=0.0, num_feature_levels=3).to(dev).train()
+    pe = PD.PositionEmbeddingSine(128, normalize=True)
+    go = torch.randn(batch, sum(h * w for h, w in shapes), 256, device=dev)
+    every = EF.RANGE_GUARD_EVERY
+    EF.RANGE_GUARD_EVERY = 1
+    try:
+        def run(scale_level0):
+            EF.range_guard_report(sync=True, reset=True)
+            srcs = [torch.randn(batch, 256, h, w, device=dev) for h, w in shapes]
+            srcs[2] = srcs[2] * scale_level0                       # (levels are flattened coarsest-last: the 32 x 32 map = most rows)
+            xs = [s_.requires_grad_(True) for s_ in srcs]
+            mem, _, _ = enc(xs, [pe(s_) for s_ in srcs])
+            mem.backward(go)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                rep = EF.range_guard_report(sync=True)
+            return rep, [str(x.message) for x in w if "fp16 x 2" in str(x.message)]
+
+        rep, warned = run(1.0)
+        assert len(rep) >= 11, sorted(rep)                          # 5 forward + 6 backward operands
+        assert all(v["rows"] > 0 for v in rep.values())
+        assert max(v["share"] for v in rep.values()) <= EF.RANGE_GUARD_SHARE and not warned, (rep, warned)
+        rep, warned = run(2.0 ** -22)
+        x = rep["fwd x (value_proj)"]
+        # layer 0's operand x IS the flattened input: the 2 * 1024 rows of the scaled level lie below the line (of 2 layers' rows)
+        assert x["below"] == batch * 32 * 32 and x["rows"] == 2 * batch * (64 + 256 + 1024), x
+        assert len(warned) == 1 and "value_proj" in warned[0], warned
+    finally:
+        EF.RANGE_GUARD_EVERY = every
+        EF.range_guard_report(sync=True, reset=True)

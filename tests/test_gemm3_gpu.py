@@ -448,6 +448,42 @@ def test_gemm3_tn3_kernel_bit_identical_to_the_two_pass_kernel(M, N, K):
     assert float(((res[1][0].double() - ref).abs() / den).max()) < 1e-6
 
 
+def test_h2_range_stats_counts_rows_below_the_slot():
+    """mpf_h2_range_stats (the run-time guard of the fp16 x 2 form) on a constructed skewed operand: rows
+    scaled 2^-10 / 2^-19 / 2^-25 below the largest and all-zero rows -> counters = (non-zero rows, rows below 2^-18 of the slot),
+    exactly; accumulates over calls; a row stride larger than the row is honoured."""
+    from mp_former_amd import _lib
+    from mp_former_amd.gemm3 import amax
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    rows, cols = 5000, 256
+    a = torch.randn(rows, 320, device=dev)[:, :cols]                 # lda = 320
+    a[0, 0] = 8.0                                                     # the operand's largest magnitude
+    scale = torch.ones(rows, device=dev)
+    scale[100:400] = 2.0 ** -10
+    scale[400:1000] = 2.0 ** -19
+    scale[1000:1100] = 2.0 ** -25
+    scale[1100:1500] = 0.0
+    a = (a * scale[:, None])
+    a = torch.empty(rows, 320, device=dev).copy_(torch.nn.functional.pad(a, (0, 64)))[:, :cols]
+    slot = amax(a.contiguous())
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+
+    def run():
+        with _lib.device_guard(dev):
+            _lib.check(_lib.lib().mpf_h2_range_stats(a.data_ptr(), rows, cols, a.stride(0), slot.data_ptr(), 18, cnt.data_ptr(),
+                                                     _lib.stream_ptr(dev)), "mpf_h2_range_stats")
+    run()
+    rmax = a.abs().amax(1)
+    ref = float(a.abs().max())
+    want = (int((rmax > 0).sum()), int(((rmax > 0) & (rmax < ref * 2.0 ** -18)).sum()))
+    assert want[0] == rows - 400 and want[1] >= 690            # (the 2^-19 and 2^-25 rows; a few 2^-19 rows' maxima may sit above the line)
+    assert tuple(cnt.tolist()) == want
+    run()
+    assert tuple(cnt.tolist()) == (2 * want[0], 2 * want[1])
+    assert _lib.lib().mpf_h2_range_stats(a.data_ptr(), rows, 255, a.stride(0), slot.data_ptr(), 18, cnt.data_ptr(), _lib.stream_ptr(dev)) != 0
+
+
 @pytest.mark.parametrize("cout", [72, 100])
 def test_linear_tall_widths_outside_the_kernels_take_the_library_in_both_directions(cout):
     """out_features % 4 == 0 but % 32 != 0 (heads * levels * points = 72, any 4k width) passed the forward's shape

@@ -79,6 +79,13 @@ def main():
             json.dump(out, f, indent=1)
         worst = max(v["share_below_2^-18"] - v["share_zero_or_below_2^-40"] for v in out["operands"].values())
         print(f"range audit -> {a.range_audit}: largest share of non-zero rows below 2^-18 of the slot: {worst:.5f}")
+    # the run-time guard's counters (mp_former_amd/encoder_fused.py: every 64th encoder call goes through mpf_h2_range_stats)
+    from mp_former_amd import encoder_fused as _ef
+    rep = _ef.range_guard_report(sync=True)
+    if rep:
+        worst = max(rep.items(), key=lambda kv: kv[1]["share"])
+        print("h2 range guard: %d operands over %d guarded calls; worst share of non-zero rows below 2^-%d of the slot: %.6f (%s)"
+              % (len(rep), 1 + max(0, (a.steps - 3) // max(_ef.RANGE_GUARD_EVERY, 1)), _ef.RANGE_GUARD_LOG2, worst[1]["share"], worst[0]))
     print(json.dumps({"steps": a.steps, "first": first, "last": last, "ratio": last / first, "s_total": round(dt, 1),
                       "params_finite": bool(all(torch.isfinite(p).all() for p in model.parameters()))}))
 
