@@ -96,6 +96,36 @@ int mpf_msda_backward(const void* value, const int64_t* spatial_shapes,
                       int dtype, void* stream);
 
 /*
+ * The production kernels behind the reference's UNCHANGED all-device signature (ops/src/ms_deform_attn.h:25-66: spatial_shapes
+ * and level_start_index are device tensors; ops/functions/ms_deform_attn_func.py:36,46 passes nothing else).  No device->host
+ * copy, no synchronisation: a one-thread prologue kernel derives the launch geometry of the blocked forward / the bin + tile
+ * backward (csrc/msda_block.hip) from the two device arrays into the first KB of `workspace`; the main kernels are launched on
+ * an upper-bound estimate sized from (batch, spatial_size, num_heads, num_levels, num_query) alone, workgroups beyond the real
+ * count return at once, and they stride when an odd pyramid needs more than the estimate.  level_start_index need not be the
+ * running sum of H*W (the level ranges must lie inside value and not overlap; rows of grad_value no level owns are zero).
+ * Shapes the prologue cannot serve (a side > 16384 or <= 0, a level outside value, overlapping levels) leave every output
+ * element NaN — there is no host-visible error without a synchronisation; mpf_msda_dev_geometry reads the record back.
+ *   workspace: mpf_msda_dev_workspace_bytes(..., backward) bytes, 256-byte aligned, owned by the caller for the duration of the
+ *              kernels (forward: 1 KB; backward: tile counters, entry runs and the spill list, ~60 MB at 1024 x 1024, batch 2).
+ * Other dtypes / head widths / point counts / more than 4 levels: mpf_msda_forward / mpf_msda_backward (which read the same two
+ * device arrays themselves), also without a copy.
+ */
+size_t mpf_msda_dev_workspace_bytes(int batch, int spatial_size, int num_heads, int num_levels, int num_query, int num_point,
+                                    int backward);
+int mpf_msda_forward_dev(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const void* sampling_loc,
+                         const void* attn_weight, void* output, int batch, int spatial_size, int num_heads, int channels,
+                         int num_levels, int num_query, int num_point, int dtype, void* workspace, size_t workspace_bytes,
+                         void* stream);
+int mpf_msda_backward_dev(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const void* sampling_loc,
+                          const void* attn_weight, const void* grad_output, void* grad_value, void* grad_sampling_loc,
+                          void* grad_attn_weight, int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                          int num_query, int num_point, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* tests / diagnostics (synchronises): the geometry record a *_dev call left at the start of its workspace.  out[0] = ok,
+ * [1] = level_start_index is the running sum, [2] / [3] = workgroups of the query-block kernels / the tile kernel,
+ * [4] = entries per (image, head), [5] = tiles per (image, head), [6..9] = run capacity per level */
+int mpf_msda_dev_geometry(const void* workspace, int* out, int n);
+
+/*
  * Multi-scale deformable attention, backward, atomics-free ("binned") formulation for fp32 with 32
  * channels per head — the production path of the pixel decoder.  Same results as mpf_msda_backward
  * (grad_value sums are reassociated; no floating-point atomics are used), different contract:

@@ -35,6 +35,10 @@ SIGNATURES = {
     "mpf_pair_planes_backward_workspace_bytes": (ctypes.c_size_t, [_c_int] * 4),
     "mpf_pair_planes_backward": (_c_int, [_c_vp] * 7 + [ctypes.c_int64, _c_vp, ctypes.c_int64, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int,
                                           _c_int, _c_vp, ctypes.c_size_t, _c_vp]),
+    "mpf_msda_dev_workspace_bytes": (ctypes.c_size_t, [_c_int] * 7),
+    "mpf_msda_forward_dev": (_c_int, [_c_vp] * 6 + [_c_int] * 8 + [_c_vp, ctypes.c_size_t, _c_vp]),
+    "mpf_msda_backward_dev": (_c_int, [_c_vp] * 9 + [_c_int] * 8 + [_c_vp, ctypes.c_size_t, _c_vp]),
+    "mpf_msda_dev_geometry": (_c_int, [_c_vp, ctypes.POINTER(_c_int), _c_int]),
     "mpf_msda_stats": (_c_int, [ctypes.POINTER(ctypes.c_ulonglong), _c_int, _c_int]),
     "mpf_profile_enable": (_c_int, [_c_int]),
     "mpf_profile_get_flops": (_c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]),

@@ -69,6 +69,12 @@ struct GeomB {
     // every band has the same number of tile rows of every level (level heights multiples of 4 * nband: the power-of-two maps
     // of the 1024^2 / 512 x 1024 configs): workgroup -> (band, level) is arithmetic, no table lookup in the kernel prologue
     int band_uniform, wg_per_band, lvl_wg_base[kMaxL];
+    // geometry built on the DEVICE (mpf_msda_*_dev: the reference's all-device signature, no host copy of the shapes):
+    //   ok          0 = the shapes cannot be served (sizes out of range, level ranges outside value or overlapping): every
+    //               blocked kernel returns at once and msda_dev_guard_kernel fills the outputs with NaN
+    //   contiguous  level_start_index is the running sum of H*W (else grad_value has rows no level owns: zero-filled first)
+    //   nblk, nwg   workgroups of the query-block kernels / of the tile kernel (the launch is an upper bound; the kernels stride)
+    int ok, contiguous, nblk, nwg;
 };
 
 // a[i] for a run-time i without a run-time kernarg offset: every element is read at its constant offset (hipcc batches
@@ -91,6 +97,23 @@ __device__ __forceinline__ int xcd_index(int n)
 {
     const int per_xcd = (n + 7) >> 3;
     return ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+}
+
+// Which block / workgroup-slot does iteration `it` of this workgroup serve?  Host geometry (!DG): exactly one, the XCD-aware
+// remap of blockIdx.x.  Device geometry: workgroup ids stride by the launch size through the same remap of the REAL count n.
+template <bool DG>
+__device__ __forceinline__ bool dg_next(int it, int n, int& blk)
+{
+    if (!DG) {
+        if (it) return false;
+        blk = xcd_index(n);
+        return blk < n;
+    }
+    const int per_xcd = (n + 7) >> 3;
+    const int64_t bid = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;          // (gridDim.x is a multiple of 8: the XCD stays)
+    if ((bid >> 3) >= per_xcd) return false;
+    blk = (int)(bid & 7) * per_xcd + (int)(bid >> 3);
+    return blk < n;            // (false = a tail slot of the last XCD's share: later ids of this workgroup are larger still)
 }
 
 template <int CTRL, int RM>
@@ -252,20 +275,28 @@ __device__ __forceinline__ float quad_sum(float v)
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
 }
 
-template <int NL, bool RAW>
+// DG ("device geometry", the mpf_msda_*_dev entry points): the geometry is read from `gd` (built by msda_geom_kernel from the
+// device-side spatial_shapes / level_start_index) instead of the kernel argument `gk`, and the workgroup count is only known
+// on the device — the launch is an upper-bound estimate, workgroups past the real count leave at once and, should the
+// estimate have been low (odd level sizes), the others stride over the remainder.
+template <int NL, bool RAW, bool DG = false>
 __global__ __launch_bounds__(kT) void msda_fwd_block_kernel(const float* __restrict__ value, const float* loc_,
-                                                            const float* attn_, float* __restrict__ out, GeomB g,
-                                                            int nblocks, int region_cap, unsigned value_bytes,
+                                                            const float* attn_, float* __restrict__ out, GeomB gk,
+                                                            int nblocks_k, int region_cap, unsigned value_bytes,
                                                             const float* __restrict__ raw, const float* __restrict__ ref,
-                                                            unsigned* __restrict__ stats)
+                                                            unsigned* __restrict__ stats, const GeomB* __restrict__ gd = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4* s_f = reinterpret_cast<float4*>(smem);
     int4* s_o = reinterpret_cast<int4*>(smem + 4096);
     int* s_bb = reinterpret_cast<int*>(smem + kOffBB);
+    const GeomB& g = DG ? *gd : gk;
+    if (DG && !g.ok) return;
+    const int nblocks = DG ? g.nblk : nblocks_k;
 
-    const int blk = xcd_index(nblocks);
-    if (blk >= nblocks) return;
+  for (int it_ = 0;; ++it_) {
+    int blk;
+    if (!dg_next<DG>(it_, nblocks, blk)) break;
     BlockCtx c;
     block_of(g, blk, c);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -412,6 +443,9 @@ __global__ __launch_bounds__(kT) void msda_fwd_block_kernel(const float* __restr
             *reinterpret_cast<float4*>(out + ((int64_t)(c.b * g.Lq + q) * g.M + c.m) * kD + (tid & 7) * 4) =
                 make_float4(acc[qq][0].x, acc[qq][0].y, acc[qq][1].x, acc[qq][1].y);
     }
+    if (!DG) break;
+    __syncthreads();            // (the LDS tables are rebuilt by the next block of this workgroup)
+  }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -465,21 +499,26 @@ constexpr int kTG = 8192, kTV = 3200, kTR = 2048;
 constexpr int kTWave = kTG + kTV + kTR;
 constexpr int kBDummy = 64;                              // lane-private dummy counters of the bin kernel
 
-template <int NL, bool RAW>
+template <int NL, bool RAW, bool DG = false>
 __global__ __launch_bounds__(kT) void msda_bwd_bin_kernel(
     const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out, const float* __restrict__ fwd_out,
     float* __restrict__ grad_loc, float* __restrict__ grad_attn, float* __restrict__ grad_raw, float* __restrict__ delta,
-    int* __restrict__ tile_count, unsigned* __restrict__ entries, int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB g,
-    int nblocks, unsigned* __restrict__ stats, float* __restrict__ graw_amax, int reverse)
+    int* __restrict__ tile_count, unsigned* __restrict__ entries, int* __restrict__ ovf_count, uint2* __restrict__ ovf, GeomB gk,
+    int nblocks_k, unsigned* __restrict__ stats, float* __restrict__ graw_amax, int reverse, const GeomB* __restrict__ gd = nullptr)
 {
     __shared__ int s_bb[kMaxL * 4];
     __shared__ unsigned s_keys[kSlots];
     __shared__ int s_cnt[kSlots + kBDummy];
     __shared__ int s_base[kSlots];
+    __shared__ float ared[4];
     constexpr int LP = NL * kP;
+    const GeomB& g = DG ? *gd : gk;
+    if (DG && !g.ok) return;
+    const int nblocks = DG ? g.nblk : nblocks_k;
+  for (int it_ = 0;; ++it_) {
     // (reverse: tests only — the query blocks in the opposite order, i.e. another arrival order of the entries in their runs)
-    const int blk0 = xcd_index(nblocks);
-    if (blk0 >= nblocks) return;
+    int blk0;
+    if (!dg_next<DG>(it_, nblocks, blk0)) break;
     const int blk = reverse ? nblocks - 1 - blk0 : blk0;
     BlockCtx c;
     block_of(g, blk, c);
@@ -644,26 +683,32 @@ __global__ __launch_bounds__(kT) void msda_bwd_bin_kernel(
     }
     }
     if (RAW && graw_amax) {      // (uniform) one atomic max per workgroup
-        __shared__ float ared[4];
         amax_commit(graw_amax, wmax, ared);
     }
+    if (!DG) break;
+    __syncthreads();
+  }
 }
 
-template <int NL, bool RAW, bool DBG>
+template <int NL, bool RAW, bool DBG, bool DG = false>
 __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
     const float* __restrict__ value, const float* __restrict__ loc, const float* __restrict__ attn, const float* __restrict__ grad_out,
     const float* __restrict__ delta, const int* __restrict__ tile_count, const unsigned* __restrict__ entries,
-    float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn, float* __restrict__ grad_raw, GeomB g,
-    int nwg, unsigned loc_bytes, unsigned* __restrict__ stats, int ablate_, unsigned long long* __restrict__ dbg_,
-    float* __restrict__ graw_amax, float* __restrict__ gv_amax)
+    float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn, float* __restrict__ grad_raw, GeomB gk,
+    int nwg_k, unsigned loc_bytes, unsigned* __restrict__ stats, int ablate_, unsigned long long* __restrict__ dbg_,
+    float* __restrict__ graw_amax, float* __restrict__ gv_amax, const GeomB* __restrict__ gd = nullptr)
 {
     // DBG (benchmarking: mpf_set_option("msda_push_ablate2") / mpf_debug_set_buffer): the ablation switches and phase stamps
     // exist only in that instantiation; the production kernel carries neither their branches nor their registers
     const int ablate = DBG ? ablate_ : 0;
     unsigned long long* const dbg = DBG ? dbg_ : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int wg = xcd_index(nwg);
-    if (wg >= nwg) return;
+    const GeomB& g = DG ? *gd : gk;
+    if (DG && !g.ok) return;
+    const int nwg = DG ? g.nwg : nwg_k;
+  for (int it_ = 0;; ++it_) {
+    int wg;
+    if (!dg_next<DG>(it_, nwg, wg)) break;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // benchmarking only (mpf_debug_set_buffer): per wave [start, loop entry, sum wait, sum dots, sum operands, sum next-chunk, sum mfma, chunks]
     unsigned long long t_prev = 0, t_acc[5] = {0, 0, 0, 0, 0}, t_start = 0, t_loop = 0;
@@ -1022,20 +1067,26 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
             if (slot) atomicMax(reinterpret_cast<unsigned*>(slot) + (blockIdx.x % kAmaxSub) * kAmaxStride, __float_as_uint(mx));
         }
     }
+    if (!DG) break;
+    __syncthreads();            // (every wave is done with its row buffers before the next slot's copies land in them)
+  }
 }
 
 // spill entries of the third generation: as msda_bwd_spill_kernel, plus the per-sample gradients of the entries whose tile OWNS
 // the sample (the tile kernel never saw them).  32 lanes per entry (lane = channel); correctness path.
-template <int NL, bool RAW>
+template <int NL, bool RAW, bool DG = false>
 __global__ __launch_bounds__(kT) void msda_bwd_spill3_kernel(const float* __restrict__ value, const float* __restrict__ loc,
                                                              const float* __restrict__ attn, const float* __restrict__ grad_out,
                                                              const float* __restrict__ delta, const int* __restrict__ ovf_count,
                                                              const uint2* __restrict__ ovf, float* __restrict__ grad_value,
                                                              float* __restrict__ grad_loc, float* __restrict__ grad_attn,
-                                                             float* __restrict__ grad_raw, GeomB g, unsigned* __restrict__ stats,
-                                                             float* __restrict__ graw_amax, float* __restrict__ gv_amax)
+                                                             float* __restrict__ grad_raw, GeomB gk, unsigned* __restrict__ stats,
+                                                             float* __restrict__ graw_amax, float* __restrict__ gv_amax,
+                                                             const GeomB* __restrict__ gd = nullptr)
 {
     constexpr int LP = NL * kP;
+    const GeomB& g = DG ? *gd : gk;
+    if (DG && !g.ok) return;
     const int n = *ovf_count;
     const int c = threadIdx.x & 31;
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[6], (unsigned)n);
@@ -1121,40 +1172,77 @@ int g_bin_reverse = 0;       // tests: bin kernel walks the query blocks backwar
 constexpr int kNStats = 16;
 unsigned* g_stats = nullptr;
 
-bool build_geom(GeomB& g, const int64_t* hs, int N, int S, int M, int L, int Lq)
+// `hs` = [L][2] (H, W) and, for the device form, `lsi` = [L] level starts (nullptr: the running sum).  Host and device run the
+// same code (IEEE double arithmetic, no contraction-sensitive expression), so a geometry built by msda_geom_kernel equals the
+// one the host would have built from a copy of the shapes.  ent_budget / tile_budget (device form; 0 = unlimited): capacity per
+// (image, head) of the entry runs / tile counters the caller allocated from S, L, Lq alone — run capacities are halved until they
+// fit (what does not fit a run spills: correct, slower), a tile count over budget cannot happen (see dev_budgets).
+__host__ __device__ inline bool build_geom(GeomB& g, const int64_t* hs, const int64_t* lsi, int N, int S, int M, int L, int Lq,
+                                           int64_t ent_budget = 0, int64_t tile_budget = 0)
 {
+    g.ok = 0; g.contiguous = 1; g.nblk = 0; g.nwg = 0;
     if (L < 1 || L > kMaxL) return false;
     g.L = L; g.M = M; g.Lq = Lq; g.S = S; g.N = N;
     int64_t start = 0;
-    int tbase = 0, ebase = 0, wgb = 0;
     for (int l = 0; l < kMaxL; ++l) {
         g.H[l] = g.W[l] = 1; g.start[l] = 0; g.ntx[l] = 1; g.tile_base[l] = 0; g.cap[l] = 1; g.ent_base[l] = 0; g.wpt[l] = 1;
         g.qH[l] = g.qW[l] = 1; g.qstart[l] = 0; g.qnbx[l] = 1; g.qblk_base[l] = 0;
     }
+    double expect_l[kMaxL] = {0, 0, 0, 0};
     for (int l = 0; l < L; ++l) {
         const int64_t H = hs[2 * l], W = hs[2 * l + 1];
         if (H <= 0 || W <= 0 || H > 16384 || W > 16384) return false;
-        g.H[l] = (int)H; g.W[l] = (int)W; g.start[l] = (int)start;
+        const int64_t st = lsi ? lsi[l] : start;
+        if (st != start) g.contiguous = 0;
+        if (st < 0 || st + H * W > (int64_t)S) return false;
+        g.H[l] = (int)H; g.W[l] = (int)W; g.start[l] = (int)st;
         start += H * W;
         g.ntx[l] = (int)((W + 3) / 4);
-        const int nty = (int)((H + 3) / 4), ntiles = g.ntx[l] * nty;
         // expected entries of a tile when the samples follow the queries: Lq * P * 16 / (H W) samples, x (5/4)^2 for
         // footprints straddling tile borders; run capacity = twice that + slack, the rest spills
-        const double expect = (double)Lq * kP * 16.0 / ((double)H * W) * 1.5625;
+        const double expect = (double)Lq * kP * 16.0 / ((double)H * (double)W) * 1.5625;
+        expect_l[l] = expect;
         int64_t cap = (int64_t)(2.0 * expect) + 64;
         cap = (cap + 3) & ~(int64_t)3;
+        if (cap > (1 << 28)) cap = 1 << 28;
         g.cap[l] = (int)cap;
-        g.tile_base[l] = tbase; tbase += ntiles;
-        if ((int64_t)ebase + (int64_t)ntiles * cap >= (1ll << 31)) return false;
-        g.ent_base[l] = ebase; ebase += (int)(ntiles * cap);
         // waves per tile: aim at ~2 chunks (128 entries) per wave
-        g.wpt[l] = std::min(kWP, expect > 1400.0 ? 16 : (expect > 700.0 ? 4 : (expect > 350.0 ? 2 : 1)));
+        const int w_ = expect > 1400.0 ? 16 : (expect > 700.0 ? 4 : (expect > 350.0 ? 2 : 1));
+        g.wpt[l] = w_ < kWP ? w_ : kWP;
     }
-    (void)wgb;
-    if (start != S) return false;
+    (void)expect_l;
+    if (!lsi && start != S) return false;
+    if (lsi) {      // level ranges must not overlap (the tile kernel writes every pixel's grad_value row exactly once)
+        for (int a = 0; a < L; ++a)
+            for (int b = a + 1; b < L; ++b) {
+                const int64_t a0 = g.start[a], a1 = a0 + (int64_t)g.H[a] * g.W[a], b0 = g.start[b], b1 = b0 + (int64_t)g.H[b] * g.W[b];
+                if (a0 < b1 && b0 < a1) return false;
+            }
+        if (start != S) g.contiguous = 0;
+    }
+    for (int round = 0;; ++round) {          // tile / entry bases; with a budget: halve the run capacities until the runs fit
+        int64_t tbase = 0, ebase = 0;
+        bool fits = true;
+        for (int l = 0; l < L; ++l) {
+            const int64_t ntiles = (int64_t)g.ntx[l] * ((g.H[l] + 3) / 4);
+            g.tile_base[l] = (int)tbase; tbase += ntiles;
+            if (ebase + ntiles * g.cap[l] >= (1ll << 31)) return false;
+            g.ent_base[l] = (int)ebase; ebase += ntiles * g.cap[l];
+        }
+        if (tile_budget > 0 && tbase > tile_budget) return false;
+        if (ent_budget > 0 && ebase > ent_budget) fits = false;
+        g.tiles_per_bm = (int)tbase; g.ent_per_bm = (int)ebase;
+        if (fits) break;
+        bool shrunk = false;
+        for (int l = 0; l < L; ++l) {
+            const int c2 = ((g.cap[l] / 2) + 3) & ~3;
+            if (c2 >= 4 && c2 < g.cap[l]) { g.cap[l] = c2; shrunk = true; }
+        }
+        if (!shrunk || round > 40) return false;
+    }
     {   // bands = tile rows of the level with the fewest tile rows (at most kMaxBand)
         int nband = kMaxBand;
-        for (int l = 0; l < L; ++l) nband = std::min(nband, (g.H[l] + 3) / 4);
+        for (int l = 0; l < L; ++l) { const int nty = (g.H[l] + 3) / 4; nband = nty < nband ? nty : nband; }
         g.nband = nband;
         int base = 0;
         for (int k = 0; k < kMaxBand * kMaxL; ++k) g.band_wg_base[k] = 0;
@@ -1171,14 +1259,15 @@ bool build_geom(GeomB& g, const int64_t* hs, int N, int S, int M, int L, int Lq)
         g.wg_per_band = g.band_uniform ? base / nband : 0;
         for (int l = 0; l < kMaxL; ++l) g.lvl_wg_base[l] = (g.band_uniform && l < L) ? g.band_wg_base[l] : (1 << 30);
     }
-    g.tiles_per_bm = tbase; g.ent_per_bm = ebase;
-    if ((int64_t)N * M * tbase >= (1ll << 31)) return false;
-    // query blocks
+    if ((int64_t)N * M * g.tiles_per_bm >= (1ll << 31)) return false;
+    // query blocks: the queries ARE the pixels of the levels (stored back to back) when their count says so, else one strip
     int bbase = 0;
-    if (Lq == S) {
+    if ((int64_t)Lq == start) {
         g.nql = L; g.bw_log2 = 3; g.bh = 8;
+        int64_t qs = 0;
         for (int l = 0; l < L; ++l) {
-            g.qH[l] = g.H[l]; g.qW[l] = g.W[l]; g.qstart[l] = g.start[l];
+            g.qH[l] = g.H[l]; g.qW[l] = g.W[l]; g.qstart[l] = (int)qs;
+            qs += (int64_t)g.H[l] * g.W[l];
             g.qnbx[l] = (g.W[l] + 7) / 8;
             g.qblk_base[l] = bbase;
             bbase += g.qnbx[l] * ((g.H[l] + 7) / 8);
@@ -1189,6 +1278,10 @@ bool build_geom(GeomB& g, const int64_t* hs, int N, int S, int M, int L, int Lq)
         bbase = g.qnbx[0];
     }
     g.blocks_per_b = bbase;
+    if ((int64_t)N * M * bbase >= (1ll << 31) || (int64_t)N * M * g.wg_per_bm >= (1ll << 31)) return false;
+    g.nblk = N * M * bbase;
+    g.nwg = N * M * g.wg_per_bm;
+    g.ok = 1;
     return true;
 }
 
@@ -1209,12 +1302,17 @@ int region_bytes() { return ((g_region_rows + 31) / 32) * 32 * 128; }     // who
 
 template <int NL>
 hipError_t launch_fwd(const float* value, const float* loc, const float* attn, float* out, const GeomB& g, hipStream_t st,
-                      const float* raw = nullptr, const float* ref = nullptr)
+                      const float* raw = nullptr, const float* ref = nullptr, const GeomB* gd = nullptr, int dev_grid = 0)
 {
     const int nblocks = g.N * g.M * g.blocks_per_b;
     const int grid = ((nblocks + 7) / 8) * 8;
     const size_t lds = kOffReg + region_bytes();
     const unsigned vb = (unsigned)((size_t)g.N * g.S * g.M * kD * 4);
+    if (gd) {          // geometry on the device: g carries only N, S, M (host arguments)
+        hipLaunchKernelGGL((msda_fwd_block_kernel<NL, false, true>), dim3(dev_grid), dim3(kT), lds, st, value, loc, attn, out, g, 0,
+                           g_region_rows, vb, nullptr, nullptr, g_stats, gd);
+        return hipGetLastError();
+    }
     if (raw)
         hipLaunchKernelGGL((msda_fwd_block_kernel<NL, true>), dim3(grid), dim3(kT), lds, st, value, loc, attn, out, g, nblocks,
                            g_region_rows, vb, raw, ref, g_stats);
@@ -1361,6 +1459,98 @@ hipError_t launch_bwd3(const float* value, const float* loc, const float* attn, 
     return hipGetLastError();
 }
 
+// ---- geometry on the device (the reference's all-device op signature: ms_deform_attn.h:25-66 hands over spatial_shapes and
+// level_start_index as device tensors; nothing here copies them to the host) ------------------------------------------------------
+struct DevBudget {
+    int64_t tiles_bm, ent_bm;          // capacity per (image, head) of the tile counters / entry runs
+    int blk_grid, tile_grid;           // launch sizes (multiples of 8) of the query-block kernels / the tile kernel
+    size_t off_geom, off_count, off_ovf_count, off_entries, off_ovf, total;
+};
+
+// Everything the host can size from (N, S, M, L, Lq) alone.  A level of H x W pixels has ceil(H/4) ceil(W/4) <= H W / 4 + 1
+// tiles (thin maps are the worst case), so S / 4 + L counters per (image, head) always suffice; run capacities are what
+// build_geom derives for maps with sides that are multiples of 4 (12.5 Lq + 67 H W / 16 entries per level) + 25 %, and the
+// device shrinks them when an odd pyramid needs more (the spill list covers every sample).  Launch sizes: the counts of a
+// pyramid with sides that are multiples of 8 + slack; the kernels stride when the real count is larger.
+DevBudget dev_budget(int N, int S, int M, int L, int Lq, bool backward)
+{
+    DevBudget b;
+    b.tiles_bm = (int64_t)S / 4 + L;
+    b.ent_bm = (int64_t)(1.25 * (12.5 * (double)L * (double)Lq + 67.0 * ((double)S / 16.0 + 8.0 * L))) + 1024;
+    if (b.ent_bm < 4 * b.tiles_bm) b.ent_bm = 4 * b.tiles_bm;
+    const int64_t bm = (int64_t)N * M;
+    const int64_t blk = bm * (((int64_t)Lq + 63) / 64 + 2 * L);
+    const int64_t tw = bm * (((int64_t)S / 16 + 1) / 2 + 4 * L);
+    b.blk_grid = (int)std::min<int64_t>(((blk + 7) / 8) * 8, 1 << 30);
+    b.tile_grid = (int)std::min<int64_t>(((tw + 7) / 8) * 8, 1 << 30);
+    b.off_geom = 0;
+    b.off_count = 1024;
+    b.off_ovf_count = b.off_count + (size_t)(bm * b.tiles_bm) * 4;
+    b.off_entries = align256(b.off_ovf_count + 4);
+    b.off_ovf = align256(b.off_entries + (backward ? (size_t)(bm * b.ent_bm) * 4 : 0));
+    b.total = b.off_ovf + (backward ? (size_t)N * Lq * M * L * kP * 4 * 8 : 0);
+    return b;
+}
+static_assert(sizeof(GeomB) <= 1024, "GeomB must fit the workspace header");
+
+__global__ void msda_geom_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, GeomB* __restrict__ out, int N, int S,
+                                 int M, int L, int Lq, long long ent_budget, long long tile_budget)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    GeomB g;
+    const bool ok = build_geom(g, shapes, lsi, N, S, M, L, Lq, ent_budget, tile_budget);
+    g.ok = ok ? 1 : 0;
+    g.L = L; g.M = M; g.Lq = Lq; g.S = S; g.N = N;
+    *out = g;
+}
+
+// After msda_geom_kernel: shapes the blocked kernels cannot serve -> every output element NaN (they all return at once; a
+// result that merely looked plausible would be worse than none), and for a backward whose level ranges leave gaps in value,
+// zeros in grad_value before the tile kernel writes the rows the levels own.  Returns immediately otherwise.
+__global__ __launch_bounds__(256) void msda_dev_guard_kernel(const GeomB* __restrict__ gd, float* __restrict__ o0, int64_t n0, float* __restrict__ o1,
+                                                             int64_t n1, float* __restrict__ o2, int64_t n2, float* __restrict__ grad_value,
+                                                             int64_t nv)
+{
+    const int ok = gd->ok, contiguous = gd->contiguous;
+    if (ok && (contiguous || !grad_value)) return;
+    const int64_t stride = (int64_t)gridDim.x * 256, i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (!ok) {
+        const float nan = __int_as_float(0x7fc00000);
+        for (int64_t i = i0; i < n0; i += stride) o0[i] = nan;
+        for (int64_t i = i0; i < n1; i += stride) o1[i] = nan;
+        for (int64_t i = i0; i < n2; i += stride) o2[i] = nan;
+    } else {
+        for (int64_t i = i0; i < nv; i += stride) grad_value[i] = 0.f;
+    }
+}
+
+template <int NL>
+hipError_t launch_bwd3_dev(const float* value, const float* loc, const float* attn, const float* go, float* gv, float* gl, float* ga,
+                           const GeomB& gh, const GeomB* gd, const DevBudget& b, char* ws, hipStream_t st)
+{
+    int* tile_count = (int*)(ws + b.off_count);
+    int* ovf_count = (int*)(ws + b.off_ovf_count);
+    unsigned* entries = (unsigned*)(ws + b.off_entries);
+    uint2* ovf = (uint2*)(ws + b.off_ovf);
+    hipError_t err = zero_counters(ws + b.off_count, b.off_ovf_count + 4 - b.off_count, st);
+    if (err != hipSuccess) return err;
+    constexpr int LP = NL * kP;
+    const double n_samp = (double)gh.N * gh.Lq * gh.M * LP, n_row = (double)gh.N * gh.Lq * gh.M * kD;
+    mpf::prof_begin(st);
+    hipLaunchKernelGGL((msda_bwd_bin_kernel<NL, false, true>), dim3(b.blk_grid), dim3(kT), 0, st, loc, attn, go, nullptr, gl, ga, nullptr, nullptr,
+                       tile_count, entries, ovf_count, ovf, gh, 0, g_stats, nullptr, 0, gd);
+    mpf::prof_end("msda_bwd_bin_kernel", st, 4.0 * n_samp * 2);
+    const size_t lds = (size_t)kWP * kTWave;
+    const unsigned loc_bytes = (unsigned)((size_t)gh.N * gh.Lq * gh.M * LP * 8);
+    mpf::prof_begin(st);
+    hipLaunchKernelGGL((msda_bwd_tile_kernel<NL, false, false, true>), dim3(b.tile_grid), dim3(kTP), lds, st, value, loc, attn, go, nullptr,
+                       tile_count, entries, gv, gl, ga, nullptr, gh, 0, loc_bytes, g_stats, 0, nullptr, nullptr, nullptr, gd);
+    mpf::prof_end("msda_bwd_tile_kernel", st, 4.0 * ((double)gh.N * gh.S * gh.M * kD * 2 + n_row + n_samp * 4));
+    hipLaunchKernelGGL((msda_bwd_spill3_kernel<NL, false, true>), dim3(64), dim3(kT), 0, st, value, loc, attn, go, nullptr, ovf_count, ovf, gv, gl,
+                       ga, nullptr, gh, g_stats, nullptr, nullptr, gd);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" int mpf_debug_set_buffer(void* p)
@@ -1393,7 +1583,7 @@ int msda_block_forward(const void* value, const int64_t* host_shapes, const void
     if (!host_shapes || !block_ok(N, S, M, D, L, Lq, P, dtype)) return -1000;
     if (raw && (g_fuse_prep == 0 || (int64_t)N * Lq * M * L * P * 12 >= (1ll << 31))) return -1000;
     GeomB g;
-    if (!build_geom(g, host_shapes, N, S, M, L, Lq)) return -1000;
+    if (!build_geom(g, host_shapes, nullptr, N, S, M, L, Lq)) return -1000;
     mpf::prof_begin(st);
     mpf::set_kernel(raw ? "msda_fwd_block_kernel<raw>" : "msda_fwd_block_kernel");
     hipError_t err;
@@ -1417,7 +1607,7 @@ size_t msda_block_workspace_bytes(const int64_t* host_shapes, int N, int M, int 
     int64_t S = 0;
     for (int l = 0; l < L; ++l) S += host_shapes[2 * l] * host_shapes[2 * l + 1];
     GeomB g;
-    if (S >= (1ll << 31) || !build_geom(g, host_shapes, N, (int)S, M, L, Lq)) return 0;
+    if (S >= (1ll << 31) || !build_geom(g, host_shapes, nullptr, N, (int)S, M, L, Lq)) return 0;
     return ws_layout(g).total;
 }
 
@@ -1429,7 +1619,7 @@ int msda_block_backward(const void* value, const int64_t* host_shapes, const voi
     if (amax_recorded) *amax_recorded = false;
     if (!host_shapes || !block_ok(N, S, M, D, L, Lq, P, dtype)) return -1000;
     GeomB g;
-    if (!build_geom(g, host_shapes, N, S, M, L, Lq)) return -1000;
+    if (!build_geom(g, host_shapes, nullptr, N, S, M, L, Lq)) return -1000;
     if (workspace_bytes < ws_layout(g).total) return mpf::fail(MPF_E_SHAPE, "msda_backward_ws: workspace too small");
     // the amax slots are filled by the bin + tile (+ spill) kernels of the raw form; on every other route the caller runs
     // the amax passes itself (a switch or a geometry outside these kernels must not make the training step fail)
@@ -1476,3 +1666,113 @@ int set_block_option(const char* key, int v)
 }
 
 }  // namespace mpf
+
+// ---- the op with the reference's all-device signature on the blocked kernels -------------------------------------------------
+extern "C" size_t mpf_msda_dev_workspace_bytes(int batch, int spatial_size, int num_heads, int num_levels, int num_query, int num_point,
+                                               int backward)
+{
+    if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || num_levels < 1 || num_levels > kMaxL || num_query <= 0 || num_point != kP) return 0;
+    const DevBudget b = dev_budget(batch, spatial_size, num_heads, num_levels, num_query, backward != 0);
+    if ((int64_t)batch * num_heads * b.ent_bm >= (1ll << 31) || (int64_t)batch * num_heads * b.tiles_bm >= (1ll << 31)) return 0;
+    return b.total;
+}
+
+namespace {
+int dev_prologue(const int64_t* shapes, const int64_t* lsi, int N, int S, int M, int L, int Lq, bool backward, void* workspace,
+                 size_t workspace_bytes, DevBudget& b, GeomB& gh, hipStream_t st, const char* who)
+{
+    b = dev_budget(N, S, M, L, Lq, backward);
+    if ((int64_t)N * M * b.ent_bm >= (1ll << 31) || (int64_t)N * M * b.tiles_bm >= (1ll << 31)) return -1000;
+    if (!workspace || workspace_bytes < b.total) return mpf::fail(MPF_E_SHAPE, who);
+    if ((uintptr_t)workspace & 255) return mpf::fail(MPF_E_SHAPE, "msda_*_dev: workspace must be 256-byte aligned");
+    memset(&gh, 0, sizeof(gh));
+    gh.N = N; gh.S = S; gh.M = M; gh.L = L; gh.Lq = Lq;
+    hipLaunchKernelGGL(msda_geom_kernel, dim3(1), dim3(64), 0, st, shapes, lsi, (GeomB*)workspace, N, S, M, L, Lq, (long long)b.ent_bm,
+                       (long long)b.tiles_bm);
+    return mpf::check(hipGetLastError(), "msda_geom_kernel");
+}
+}  // namespace
+
+extern "C" int mpf_msda_forward_dev(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const void* sampling_loc,
+                                    const void* attn_weight, void* output, int batch, int spatial_size, int num_heads, int channels,
+                                    int num_levels, int num_query, int num_point, int dtype, void* workspace, size_t workspace_bytes,
+                                    void* stream)
+{
+    const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query, P = num_point;
+    hipStream_t st = (hipStream_t)stream;
+    if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !output)
+        return mpf::fail(MPF_E_NULL, "msda_forward_dev: NULL buffer");
+    DevBudget b;
+    GeomB gh;
+    int r = block_ok(N, S, M, D, L, Lq, P, dtype) ? dev_prologue(spatial_shapes, level_start_index, N, S, M, L, Lq, false, workspace, workspace_bytes,
+                                                                 b, gh, st, "msda_forward_dev: workspace too small (mpf_msda_dev_workspace_bytes)")
+                                                  : -1000;
+    if (r == -1000)          // other dtypes / head widths / point counts: the kernels that read the shapes themselves
+        return mpf_msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output, N, S, M, D, L, Lq, P, dtype, stream);
+    if (r) return r;
+    const GeomB* gd = (const GeomB*)workspace;
+    hipLaunchKernelGGL(msda_dev_guard_kernel, dim3(256), dim3(256), 0, st, gd, (float*)output, (int64_t)N * Lq * M * D, nullptr, (int64_t)0, nullptr,
+                       (int64_t)0, nullptr, (int64_t)0);
+    mpf::prof_begin(st);
+    mpf::set_kernel("msda_fwd_block_kernel<dev>");
+    hipError_t err;
+    const float *v_ = (const float*)value, *l_ = (const float*)sampling_loc, *a_ = (const float*)attn_weight;
+    switch (L) {
+        case 1: err = launch_fwd<1>(v_, l_, a_, (float*)output, gh, st, nullptr, nullptr, gd, b.blk_grid); break;
+        case 2: err = launch_fwd<2>(v_, l_, a_, (float*)output, gh, st, nullptr, nullptr, gd, b.blk_grid); break;
+        case 3: err = launch_fwd<3>(v_, l_, a_, (float*)output, gh, st, nullptr, nullptr, gd, b.blk_grid); break;
+        default: err = launch_fwd<4>(v_, l_, a_, (float*)output, gh, st, nullptr, nullptr, gd, b.blk_grid); break;
+    }
+    mpf::prof_end("msda_fwd_block_kernel", st, 4.0 * ((double)N * S * M * D + (double)N * Lq * M * L * P * 3 + (double)N * Lq * M * D));
+    return mpf::check(err, "msda_fwd_block_kernel<dev>");
+}
+
+extern "C" int mpf_msda_backward_dev(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const void* sampling_loc,
+                                     const void* attn_weight, const void* grad_output, void* grad_value, void* grad_sampling_loc,
+                                     void* grad_attn_weight, int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                     int num_query, int num_point, int dtype, void* workspace, size_t workspace_bytes, void* stream)
+{
+    const int N = batch, S = spatial_size, M = num_heads, D = channels, L = num_levels, Lq = num_query, P = num_point;
+    hipStream_t st = (hipStream_t)stream;
+    if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !grad_output || !grad_value || !grad_sampling_loc ||
+        !grad_attn_weight)
+        return mpf::fail(MPF_E_NULL, "msda_backward_dev: NULL buffer");
+    DevBudget b;
+    GeomB gh;
+    int r = block_ok(N, S, M, D, L, Lq, P, dtype) ? dev_prologue(spatial_shapes, level_start_index, N, S, M, L, Lq, true, workspace, workspace_bytes,
+                                                                 b, gh, st, "msda_backward_dev: workspace too small (mpf_msda_dev_workspace_bytes)")
+                                                  : -1000;
+    if (r == -1000)
+        return mpf_msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, grad_value, grad_sampling_loc,
+                                 grad_attn_weight, N, S, M, D, L, Lq, P, dtype, stream);
+    if (r) return r;
+    const GeomB* gd = (const GeomB*)workspace;
+    const int64_t n_s = (int64_t)N * Lq * M * L * P;
+    hipLaunchKernelGGL(msda_dev_guard_kernel, dim3(256), dim3(256), 0, st, gd, (float*)grad_value, (int64_t)N * S * M * D, (float*)grad_sampling_loc,
+                       n_s * 2, (float*)grad_attn_weight, n_s, (float*)grad_value, (int64_t)N * S * M * D);
+    mpf::set_kernel("msda_bwd_block(bin+tile)<dev>");
+    hipError_t e3;
+    const float *v_ = (const float*)value, *l_ = (const float*)sampling_loc, *a_ = (const float*)attn_weight, *g_ = (const float*)grad_output;
+    float *gv = (float*)grad_value, *gl = (float*)grad_sampling_loc, *ga = (float*)grad_attn_weight;
+    switch (L) {
+        case 1: e3 = launch_bwd3_dev<1>(v_, l_, a_, g_, gv, gl, ga, gh, gd, b, (char*)workspace, st); break;
+        case 2: e3 = launch_bwd3_dev<2>(v_, l_, a_, g_, gv, gl, ga, gh, gd, b, (char*)workspace, st); break;
+        case 3: e3 = launch_bwd3_dev<3>(v_, l_, a_, g_, gv, gl, ga, gh, gd, b, (char*)workspace, st); break;
+        default: e3 = launch_bwd3_dev<4>(v_, l_, a_, g_, gv, gl, ga, gh, gd, b, (char*)workspace, st); break;
+    }
+    return mpf::check(e3, "msda_bwd_block(bin+tile)<dev>");
+}
+
+// tests / diagnostics: the geometry record a *_dev call left in its workspace (synchronises): out[0] = ok, [1] = contiguous,
+// [2] = query-block workgroups, [3] = tile workgroups, [4] = entries per (image, head), [5] = tiles per (image, head), [6..9] = run capacities
+extern "C" int mpf_msda_dev_geometry(const void* workspace, int* out, int n)
+{
+    if (!workspace || !out || n < 1) return MPF_E_NULL;
+    GeomB g;
+    hipError_t err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipMemcpy(&g, workspace, sizeof(g), hipMemcpyDeviceToHost);
+    if (err != hipSuccess) return mpf::check(err, "mpf_msda_dev_geometry");
+    const int v[10] = {g.ok, g.contiguous, g.nblk, g.nwg, g.ent_per_bm, g.tiles_per_bm, g.cap[0], g.cap[1], g.cap[2], g.cap[3]};
+    for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+    return 0;
+}

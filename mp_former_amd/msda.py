@@ -64,23 +64,32 @@ def _stream(t):
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step,
                            host_shapes=None):
-    """-> output [N, Lq, M*D]; freshly allocated, computed on the current stream.  The spatially blocked
-    production kernel needs the level geometry on the host (`host_shapes`, or the copy attached by
-    `attach_host_shapes`); without it the first-generation gather kernel runs (no device->host copy is
-    ever made here: the forward never blocks)."""
+    """-> output [N, Lq, M*D]; freshly allocated, computed on the current stream.  The spatially blocked production kernel runs
+    either way: with the level geometry from the host (`host_shapes`, or the copy attached by `attach_host_shapes`: one launch),
+    or — the reference's call, device tensors only — with the geometry derived by a prologue kernel on the device
+    (mpf_msda_forward_dev).  No device->host copy is ever made here: the op never blocks."""
     _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
                    ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                    ("attn_weight", attn_weight)])
     N, S, M, D, L, Lq, P = _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     hs = host_shapes if host_shapes is not None else _attached_host_shapes(spatial_shapes, level_start_index)
+    lib = _lib.lib()
     with _lib.device_guard(value.device):
-        code = _lib.lib().mpf_msda_forward_hs(
-            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-            hs.data_ptr() if hs is not None else None,
-            sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
-            N, S, M, D, L, Lq, P, _DTYPES[value.dtype], _stream(value))
-    _lib.check(code, "mpf_msda_forward_hs")
+        if hs is None and _dev_applicable(value, D, L, P):
+            # the reference's call (func.py:36): device tensors only -> geometry derived on the device, same blocked kernel
+            ws = _workspace(value.device, lib.mpf_msda_dev_workspace_bytes(N, S, M, L, Lq, P, 0))
+            code = lib.mpf_msda_forward_dev(
+                value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                attn_weight.data_ptr(), out.data_ptr(), N, S, M, D, L, Lq, P, _DTYPES[value.dtype], ws.data_ptr(), ws.numel(),
+                _stream(value))
+        else:
+            code = lib.mpf_msda_forward_hs(
+                value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                hs.data_ptr() if hs is not None else None,
+                sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
+                N, S, M, D, L, Lq, P, _DTYPES[value.dtype], _stream(value))
+    _lib.check(code, "mpf_msda_forward")
     return out
 
 
@@ -123,15 +132,18 @@ def _attached_host_shapes(spatial_shapes, level_start_index):
 
 
 def _host_shapes(spatial_shapes, level_start_index):
-    """Host copy of spatial_shapes: the attached copy if the caller provided one, else a (blocking)
-    device->host copy — the price of the reference's all-device signature.  Returns None when the
-    levels are not stored back to back (then the blocked / binned paths do not apply)."""
+    """Host copy of spatial_shapes if the caller attached one that vouches for `level_start_index`, else None — never a
+    device->host copy (the backward used to call `.cpu()` here, a blocking copy per call; callers without host
+    shapes now get the geometry built on the device, mpf_msda_*_dev)."""
     hs = _attached_host_shapes(spatial_shapes, level_start_index)
     if hs is not None and getattr(spatial_shapes, "_mpf_lsi", None) is not None:
         return hs
-    hs = spatial_shapes.cpu().contiguous()
-    lsi = level_start_index.cpu()
-    return hs if torch.equal(lsi, _contiguous_starts(hs)) else None
+    return None
+
+
+def _dev_applicable(value, D, L, P):
+    """shapes of the blocked kernels (csrc/msda_block.hip): fp32, 32 channels per head, 4 points, at most 4 levels"""
+    return value.dtype == torch.float32 and D == 32 and P == 4 and 1 <= L <= 4
 
 
 def _workspace(device, nbytes):
@@ -162,8 +174,21 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     hs = None
     if BWD_MODE != "atomic" and _binned_applicable(value, D, L, P):
         hs = host_shapes if host_shapes is not None else _host_shapes(spatial_shapes, level_start_index)
+    if hs is None and BWD_MODE != "atomic" and _dev_applicable(value, D, L, P):
+        # the reference's call (func.py:46): device tensors only -> bin + tile kernels on a geometry built on the device
+        lib = _lib.lib()
+        need = lib.mpf_msda_dev_workspace_bytes(N, S, M, L, Lq, P, 1)
+        if need:
+            ws = _workspace(value.device, need)
+            with _lib.device_guard(value.device):
+                code = lib.mpf_msda_backward_dev(
+                    value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                    attn_weight.data_ptr(), grad_output.data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
+                    N, S, M, D, L, Lq, P, _DTYPES[value.dtype], ws.data_ptr(), ws.numel(), _stream(value))
+            _lib.check(code, "mpf_msda_backward_dev")
+            return [gv, gl, ga]
     if BWD_MODE == "binned" and hs is None:
-        raise RuntimeError("MSDA binned backward requested but not applicable (needs fp32, D=32, L<=8, L*P<=32, contiguous levels)")
+        raise RuntimeError("MSDA binned backward requested but not applicable (needs fp32, D=32, L<=8, L*P<=32, host shapes)")
     if hs is not None:
         lib = _lib.lib()
         need = lib.mpf_msda_backward_workspace_bytes(N, M, L, Lq, P, hs.data_ptr())

