@@ -1493,34 +1493,63 @@ DevBudget dev_budget(int N, int S, int M, int L, int Lq, bool backward)
 }
 static_assert(sizeof(GeomB) <= 1024, "GeomB must fit the workspace header");
 
-__global__ void msda_geom_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, GeomB* __restrict__ out, int N, int S,
-                                 int M, int L, int Lq, long long ent_budget, long long tile_budget)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    GeomB g;
-    const bool ok = build_geom(g, shapes, lsi, N, S, M, L, Lq, ent_budget, tile_budget);
-    g.ok = ok ? 1 : 0;
-    g.L = L; g.M = M; g.Lq = Lq; g.S = S; g.N = N;
-    *out = g;
-}
+// The prologue of a *_dev call, ONE workgroup:
+//   1. the geometry record at the head of the workspace is kept if it was built from exactly these inputs (a key of every
+//      number it depends on: sizes, budgets, the 2 L shape words and the L level starts) — a training loop calls with the same
+//      pyramid every step and the forward's record serves the backward, so the usual prologue is a key comparison (~2 us)
+//      instead of ~10 us of single-thread integer / double arithmetic; any other workspace content fails the comparison;
+//   2. shapes the blocked kernels cannot serve -> every output element NaN (the kernels all return at once; a result that merely
+//      looked plausible would be worse than none) — one workgroup writing tens of MB is slow, and only on that path;
+//   3. a backward whose level ranges leave gaps in value: zeros in grad_value before the tile kernel writes the rows the levels own.
+struct GeomKey {
+    unsigned magic;
+    int N, S, M, L, Lq;
+    long long ent_budget, tile_budget;
+    long long shapes[2 * kMaxL], lsi[kMaxL];
+};
+constexpr unsigned kGeomMagic = 0x4d504647u;          // "MPFG"
+constexpr int kGeomKeyOff = 768;                       // byte offset of the key inside the 1 KB workspace header
+static_assert(sizeof(GeomB) <= kGeomKeyOff && kGeomKeyOff + sizeof(GeomKey) <= 1024, "workspace header layout");
 
-// After msda_geom_kernel: shapes the blocked kernels cannot serve -> every output element NaN (they all return at once; a
-// result that merely looked plausible would be worse than none), and for a backward whose level ranges leave gaps in value,
-// zeros in grad_value before the tile kernel writes the rows the levels own.  Returns immediately otherwise.
-__global__ __launch_bounds__(256) void msda_dev_guard_kernel(const GeomB* __restrict__ gd, float* __restrict__ o0, int64_t n0, float* __restrict__ o1,
-                                                             int64_t n1, float* __restrict__ o2, int64_t n2, float* __restrict__ grad_value,
-                                                             int64_t nv)
+__global__ __launch_bounds__(256) void msda_geom_kernel(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, unsigned char* header,
+                                                        int N, int S, int M, int L, int Lq, long long ent_budget, long long tile_budget,
+                                                        float* __restrict__ o0, int64_t n0, float* __restrict__ o1, int64_t n1,
+                                                        float* __restrict__ o2, int64_t n2, float* __restrict__ grad_value, int64_t nv)
 {
-    const int ok = gd->ok, contiguous = gd->contiguous;
+    __shared__ int s_flags[2];
+    GeomB* out = reinterpret_cast<GeomB*>(header);
+    if (threadIdx.x == 0) {
+        GeomKey* key = reinterpret_cast<GeomKey*>(header + kGeomKeyOff);
+        GeomKey k;
+        k.magic = kGeomMagic; k.N = N; k.S = S; k.M = M; k.L = L; k.Lq = Lq; k.ent_budget = ent_budget; k.tile_budget = tile_budget;
+        for (int l = 0; l < kMaxL; ++l) {
+            k.shapes[2 * l] = l < L ? shapes[2 * l] : 0; k.shapes[2 * l + 1] = l < L ? shapes[2 * l + 1] : 0;
+            k.lsi[l] = l < L ? lsi[l] : 0;
+        }
+        bool same = key->magic == k.magic && key->N == N && key->S == S && key->M == M && key->L == L && key->Lq == Lq &&
+                    key->ent_budget == ent_budget && key->tile_budget == tile_budget;
+        for (int l = 0; l < kMaxL; ++l)
+            same = same && key->shapes[2 * l] == k.shapes[2 * l] && key->shapes[2 * l + 1] == k.shapes[2 * l + 1] && key->lsi[l] == k.lsi[l];
+        if (!same) {
+            GeomB g;
+            const bool ok = build_geom(g, shapes, lsi, N, S, M, L, Lq, ent_budget, tile_budget);
+            g.ok = ok ? 1 : 0;
+            g.L = L; g.M = M; g.Lq = Lq; g.S = S; g.N = N;
+            *out = g;
+            *key = k;
+        }
+        s_flags[0] = out->ok; s_flags[1] = out->contiguous;
+    }
+    __syncthreads();
+    const int ok = s_flags[0], contiguous = s_flags[1];
     if (ok && (contiguous || !grad_value)) return;
-    const int64_t stride = (int64_t)gridDim.x * 256, i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (!ok) {
         const float nan = __int_as_float(0x7fc00000);
-        for (int64_t i = i0; i < n0; i += stride) o0[i] = nan;
-        for (int64_t i = i0; i < n1; i += stride) o1[i] = nan;
-        for (int64_t i = i0; i < n2; i += stride) o2[i] = nan;
+        for (int64_t i = threadIdx.x; i < n0; i += 256) o0[i] = nan;
+        for (int64_t i = threadIdx.x; i < n1; i += 256) o1[i] = nan;
+        for (int64_t i = threadIdx.x; i < n2; i += 256) o2[i] = nan;
     } else {
-        for (int64_t i = i0; i < nv; i += stride) grad_value[i] = 0.f;
+        for (int64_t i = threadIdx.x; i < nv; i += 256) grad_value[i] = 0.f;
     }
 }
 
@@ -1679,7 +1708,8 @@ extern "C" size_t mpf_msda_dev_workspace_bytes(int batch, int spatial_size, int 
 
 namespace {
 int dev_prologue(const int64_t* shapes, const int64_t* lsi, int N, int S, int M, int L, int Lq, bool backward, void* workspace,
-                 size_t workspace_bytes, DevBudget& b, GeomB& gh, hipStream_t st, const char* who)
+                 size_t workspace_bytes, DevBudget& b, GeomB& gh, hipStream_t st, const char* who, float* o0, int64_t n0, float* o1 = nullptr,
+                 int64_t n1 = 0, float* o2 = nullptr, int64_t n2 = 0, float* grad_value = nullptr, int64_t nv = 0)
 {
     b = dev_budget(N, S, M, L, Lq, backward);
     if ((int64_t)N * M * b.ent_bm >= (1ll << 31) || (int64_t)N * M * b.tiles_bm >= (1ll << 31)) return -1000;
@@ -1687,8 +1717,8 @@ int dev_prologue(const int64_t* shapes, const int64_t* lsi, int N, int S, int M,
     if ((uintptr_t)workspace & 255) return mpf::fail(MPF_E_SHAPE, "msda_*_dev: workspace must be 256-byte aligned");
     memset(&gh, 0, sizeof(gh));
     gh.N = N; gh.S = S; gh.M = M; gh.L = L; gh.Lq = Lq;
-    hipLaunchKernelGGL(msda_geom_kernel, dim3(1), dim3(64), 0, st, shapes, lsi, (GeomB*)workspace, N, S, M, L, Lq, (long long)b.ent_bm,
-                       (long long)b.tiles_bm);
+    hipLaunchKernelGGL(msda_geom_kernel, dim3(1), dim3(256), 0, st, shapes, lsi, (unsigned char*)workspace, N, S, M, L, Lq, (long long)b.ent_bm,
+                       (long long)b.tiles_bm, o0, n0, o1, n1, o2, n2, grad_value, nv);
     return mpf::check(hipGetLastError(), "msda_geom_kernel");
 }
 }  // namespace
@@ -1705,14 +1735,13 @@ extern "C" int mpf_msda_forward_dev(const void* value, const int64_t* spatial_sh
     DevBudget b;
     GeomB gh;
     int r = block_ok(N, S, M, D, L, Lq, P, dtype) ? dev_prologue(spatial_shapes, level_start_index, N, S, M, L, Lq, false, workspace, workspace_bytes,
-                                                                 b, gh, st, "msda_forward_dev: workspace too small (mpf_msda_dev_workspace_bytes)")
+                                                                 b, gh, st, "msda_forward_dev: workspace too small (mpf_msda_dev_workspace_bytes)",
+                                                                 (float*)output, (int64_t)N * Lq * M * D)
                                                   : -1000;
     if (r == -1000)          // other dtypes / head widths / point counts: the kernels that read the shapes themselves
         return mpf_msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, output, N, S, M, D, L, Lq, P, dtype, stream);
     if (r) return r;
     const GeomB* gd = (const GeomB*)workspace;
-    hipLaunchKernelGGL(msda_dev_guard_kernel, dim3(256), dim3(256), 0, st, gd, (float*)output, (int64_t)N * Lq * M * D, nullptr, (int64_t)0, nullptr,
-                       (int64_t)0, nullptr, (int64_t)0);
     mpf::prof_begin(st);
     mpf::set_kernel("msda_fwd_block_kernel<dev>");
     hipError_t err;
@@ -1739,17 +1768,17 @@ extern "C" int mpf_msda_backward_dev(const void* value, const int64_t* spatial_s
         return mpf::fail(MPF_E_NULL, "msda_backward_dev: NULL buffer");
     DevBudget b;
     GeomB gh;
+    const int64_t n_s = (int64_t)N * Lq * M * L * P, n_v = (int64_t)N * S * M * D;
     int r = block_ok(N, S, M, D, L, Lq, P, dtype) ? dev_prologue(spatial_shapes, level_start_index, N, S, M, L, Lq, true, workspace, workspace_bytes,
-                                                                 b, gh, st, "msda_backward_dev: workspace too small (mpf_msda_dev_workspace_bytes)")
+                                                                 b, gh, st, "msda_backward_dev: workspace too small (mpf_msda_dev_workspace_bytes)",
+                                                                 (float*)grad_value, n_v, (float*)grad_sampling_loc, n_s * 2,
+                                                                 (float*)grad_attn_weight, n_s, (float*)grad_value, n_v)
                                                   : -1000;
     if (r == -1000)
         return mpf_msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, grad_value, grad_sampling_loc,
                                  grad_attn_weight, N, S, M, D, L, Lq, P, dtype, stream);
     if (r) return r;
     const GeomB* gd = (const GeomB*)workspace;
-    const int64_t n_s = (int64_t)N * Lq * M * L * P;
-    hipLaunchKernelGGL(msda_dev_guard_kernel, dim3(256), dim3(256), 0, st, gd, (float*)grad_value, (int64_t)N * S * M * D, (float*)grad_sampling_loc,
-                       n_s * 2, (float*)grad_attn_weight, n_s, (float*)grad_value, (int64_t)N * S * M * D);
     mpf::set_kernel("msda_bwd_block(bin+tile)<dev>");
     hipError_t e3;
     const float *v_ = (const float*)value, *l_ = (const float*)sampling_loc, *a_ = (const float*)attn_weight, *g_ = (const float*)grad_output;

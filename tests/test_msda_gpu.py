@@ -46,7 +46,7 @@ def _run(z, dtype, dev, variant="auto"):
     t = lambda k: torch.from_numpy(np.ascontiguousarray(z[k])).to(dtype).to(dev)  # noqa: E731
     shapes = torch.from_numpy(z["shapes"]).to(dev)
     lsi = torch.from_numpy(z["level_start"]).to(dev)
-    if variant == "auto":
+    if variant in ("auto", "binned"):      # ("binned" = the first-generation atomics-free backward: host shapes, blocked kernels off)
         msda.attach_host_shapes(shapes, z["shapes"].tolist(), lsi)
     v, loc, a, g = t("value"), t("loc"), t("attn"), t("grad_out")
     out = ms_deform_attn_forward(v, shapes, lsi, loc, a, 128)
