@@ -116,6 +116,18 @@ __device__ __forceinline__ bool dg_next(int it, int n, int& blk)
     return blk < n;            // (false = a tail slot of the last XCD's share: later ids of this workgroup are larger still)
 }
 
+// Inside the strided loop of a DG kernel the compiler hoists everything that does not depend on the iteration (lane / wave
+// arithmetic, LDS addresses) out of the loop and keeps it live across the whole body: +13 VGPRs and scratch spills in the tile
+// kernel.  A zero the compiler cannot see through, added to threadIdx.x per iteration, keeps those values where they are used.
+template <bool DG>
+__device__ __forceinline__ int dg_zero()
+{
+    if (!DG) return 0;
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+
 template <int CTRL, int RM>
 __device__ __forceinline__ int dpp_keep(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xf, false); }
 
@@ -299,7 +311,7 @@ __global__ __launch_bounds__(kT) void msda_fwd_block_kernel(const float* __restr
     if (!dg_next<DG>(it_, nblocks, blk)) break;
     BlockCtx c;
     block_of(g, blk, c);
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x + dg_zero<DG>(), lane = tid & 63;
     if (tid < kMaxL * 4) s_bb[tid] = (tid & 2) ? INT_MIN : INT_MAX;
     if (tid >= 32 && tid < 64) reinterpret_cast<float*>(smem + kOffZero)[tid - 32] = 0.f;
 
@@ -522,7 +534,7 @@ __global__ __launch_bounds__(kT) void msda_bwd_bin_kernel(
     const int blk = reverse ? nblocks - 1 - blk0 : blk0;
     BlockCtx c;
     block_of(g, blk, c);
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x + dg_zero<DG>(), lane = tid & 63;
     if (tid < kMaxL * 4) s_bb[tid] = (tid & 2) ? INT_MIN : INT_MAX;
     s_keys[tid] = kEmpty; s_cnt[tid] = 0;                      // kSlots == kT
     if (tid < kBDummy) s_cnt[kSlots + tid] = 0;
@@ -709,7 +721,7 @@ __global__ __launch_bounds__(kTP, 3) void msda_bwd_tile_kernel(
   for (int it_ = 0;; ++it_) {
     int wg;
     if (!dg_next<DG>(it_, nwg, wg)) break;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x + dg_zero<DG>(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // benchmarking only (mpf_debug_set_buffer): per wave [start, loop entry, sum wait, sum dots, sum operands, sum next-chunk, sum mfma, chunks]
     unsigned long long t_prev = 0, t_acc[5] = {0, 0, 0, 0, 0}, t_start = 0, t_loop = 0;
     int t_chunks = 0;
@@ -1480,7 +1492,9 @@ DevBudget dev_budget(int N, int S, int M, int L, int Lq, bool backward)
     if (b.ent_bm < 4 * b.tiles_bm) b.ent_bm = 4 * b.tiles_bm;
     const int64_t bm = (int64_t)N * M;
     const int64_t blk = bm * (((int64_t)Lq + 63) / 64 + 2 * L);
-    const int64_t tw = bm * (((int64_t)S / 16 + 1) / 2 + 4 * L);
+    // (tile workgroups of a pyramid whose levels shrink 4x: S / 16 tiles x 1/3 — 1, 2, 4 waves per tile from the finest level
+    // down, four waves per workgroup — estimated at 3/8 + slack)
+    const int64_t tw = bm * (((int64_t)S / 16 * 3 + 7) / 8 + 4 * L);
     b.blk_grid = (int)std::min<int64_t>(((blk + 7) / 8) * 8, 1 << 30);
     b.tile_grid = (int)std::min<int64_t>(((tw + 7) / 8) * 8, 1 << 30);
     b.off_geom = 0;

@@ -48,7 +48,9 @@ def _prep(value, shapes, level_start, loc, attn):
     _, Lq, M2, L, P, two = loc.shape
     assert M2 == M and two == 2 and shapes.shape == (L, 2) and level_start.shape == (L,)
     assert attn.shape == (N, Lq, M, L, P)
-    assert int((shapes[:, 0] * shapes[:, 1]).sum()) == S
+    # every level's rows lie inside value (the reference indexes value by level_start_index only — ms_deform_im2col_cuda.cuh:268 —
+    # so levels need not be stored back to back)
+    assert (level_start >= 0).all() and (level_start + shapes[:, 0] * shapes[:, 1] <= S).all()
     return value, shapes, level_start, loc, attn, (N, S, M, D, L, Lq, P)
 
 
