@@ -537,22 +537,37 @@ def main():
 
         FP32_MFMA_PEAK_TFLOPS = 157.0            # native fp32 MFMA peak (MI355X_MICROARCH.md): what a true-fp32 GEMM could reach
 
+        RIDGE = MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)        # 312.5 flop/B
+
         def gemm_entry(name, grp):
-            """`frac` is ALGORITHMIC: bytes 4 (M K + M N) + weight planes against 8 TB/s — every shape of the family is
-            HBM-bound on algorithmic terms (64-115 fp32 flop/B against a ridge of 312); the MFMA products actually issued (three per
-            fp32 product in the fp16 x 2 form) are a separate key."""
+            """`frac` is ALGORITHMIC and taken against the roofline that binds the group: algorithmic flop/B = 2 M N K over
+            4 (M K + M N) + weight planes; below the ridge (312 flop/B: the encoder's Linear layers, 64-115) the group is HBM-bound and
+            frac = algorithmic bytes / time / 8 TB/s; above it (the 3 x 3 FPN convolution as a GEMM with K = 9 Cin: ~570) it is
+            MFMA-bound and frac = fp32-equivalent flops / time / the dense bf16 MFMA peak.  The MFMA products actually issued (three
+            per fp32 product in the fp16 x 2 form) are separate keys either way."""
             n, ms, fl, issued, by = grp
             if not n or ms <= 0:
                 return {"kernel": name, "launches": 0}
             sec = ms * 1e-3
             hf = by / sec / 1e9 / HBM_PEAK_GBPS
-            return {"kernel": name, "launches_per_step": n / max(P, 1), "ms_per_step": round(ms / max(P, 1), 3),
-                    "bound": "hbm", "achieved": round(by / sec / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4),
-                    "algorithmic_tflops_fp32": round(fl / sec / 1e12, 1), "algorithmic_mfma_frac": round(fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "issued_mfma_tflops": round(issued / sec / 1e12, 1), "issued_mfma_frac": round(issued / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                    "x_native_fp32_mfma_peak_157": round(fl / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)}
+            mf = fl / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS
+            mfma_bound = fl / max(by, 1.0) > RIDGE
+            e = {"kernel": name, "launches_per_step": n / max(P, 1), "ms_per_step": round(ms / max(P, 1), 3),
+                 "algorithmic_flop_per_byte": round(fl / max(by, 1.0), 1)}
+            if mfma_bound:
+                e.update({"bound": "mfma", "achieved": round(fl / sec / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(mf, 4),
+                          "hbm_frac": round(hf, 4)})
+            else:
+                e.update({"bound": "hbm", "achieved": round(by / sec / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(hf, 4)})
+            e.update({"algorithmic_tflops_fp32": round(fl / sec / 1e12, 1), "algorithmic_mfma_frac": round(mf, 4),
+                      "issued_mfma_tflops": round(issued / sec / 1e12, 1), "issued_mfma_frac": round(issued / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                      "x_native_fp32_mfma_peak_157": round(fl / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 3)})
+            return e
 
-        gemm_parts = [g_tn, g_nt, g_ng, g_cv, g_cw]
+        # the family figure covers its HBM-bound members (TN, NT, grouped NT: the encoder's Linear layers and their gradients); the
+        # two 3 x 3 convolution groups are MFMA-bound on algorithmic terms and are reported on their own under "also"
+        gemm_parts = [g_tn, g_nt, g_ng]
+        g_ms_all = sum(x[1] for x in (g_tn, g_nt, g_ng, g_cv, g_cw))
         g_n = sum(x[0] for x in gemm_parts)
         g_ms = sum(x[1] for x in gemm_parts)
         g_fl = sum(x[2] for x in gemm_parts)
@@ -598,7 +613,7 @@ def main():
             # the time-dominant native kernel family: the fp32 GEMMs of the pixel decoder as SIX bf16 MFMA products per fp32
             # product (three 8-bit-mantissa planes per operand, terms >= 2^-16 kept).  achieved = bf16 MFMA flops actually
             # issued per second; peak = the dense bf16 MFMA peak
-            "roofline": {"kernel": "gemm3 family (gemm3_tn / gemm3_nt / gemm3_conv: fp32 GEMM as fp16 x 2 (three) or bf16 x 3 (six) MFMA products)",
+            "roofline": {"kernel": "gemm3 family (gemm3_tn / gemm3_nt / gemm3_nt_group: the fp32 Linear layers of the pixel decoder and their gradients as fp16 x 2 (three) or bf16 x 3 (six) MFMA products; the MFMA-bound 3 x 3 convolution groups are listed under also)",
                          # ALGORITHMIC fraction: the family's shapes are HBM-bound on algorithmic terms (64-115 fp32 flop/B,
                          # ridge 312), so achieved = algorithmic bytes / time against 8 TB/s; the MFMA products issued are separate keys
                          "bound": "hbm", "achieved": round(g_by / g_sec / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -608,6 +623,7 @@ def main():
                                          "kernel on the three encoder shapes (tools/pmc_gemm3_traffic.sh) is in tn_traffic_over_algorithmic",
                          "tn_traffic_over_algorithmic": _gemm3_traffic_ratios(),
                          "launches_per_step": g_n / max(P, 1), "ms_per_step": round(g_ms / max(P, 1), 3),
+                         "ms_per_step_incl_conv3x3": round(g_ms_all / max(P, 1), 3),
                          "avg_us": round(g_ms * 1e3 / max(g_n, 1), 1),
                          "issued_mfma_tflops": round(g_issued / g_sec / 1e12, 1), "issued_mfma_frac": round(g_mf, 4),
                          "algorithmic_tflops_fp32": round(g_fl / g_sec / 1e12, 1),

@@ -423,7 +423,7 @@ inline void g3_no_bits(G3& p, const float* consts)
 // returns the largest |value| this thread stored (SCALED kernels; 0 otherwise)
 template <int NJ, int NI = 4, typename AccT = Acc<NJ, false>, bool SCALED = false>
 __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int lane, int m_wave, int n_wave, const float inv_a = 1.f,
-                                            const float inv_b = 1.f, const int m_end = 0x7fffffff)
+                                            const float inv_b = 1.f)
 {
     float amax = 0.f;
     const int r16 = lane & 15, g = lane >> 4;
@@ -434,7 +434,7 @@ __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int l
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int m = m_wave + i * 16 + r16;
-        mok[i] = m < p.M && m < m_end;           // m_end: rows from there on belong to another workgroup (gemm3_ws_kernel)
+        mok[i] = m < p.M;
         mrow[i] = min(m, p.M - 1);
         if constexpr (NJ <= 2) {                 // a 32-column wave tile: 4 bytes of the row's mask
             gb[i].x = *reinterpret_cast<const unsigned*>(p.gbits + mrow[i] * p.ldgbits + (n_wave >> 3) * p.gbits_cm);

@@ -4,7 +4,7 @@
 //   * decoder_norm + the three Linear layers of mask_embed (:1859-1866, MLP :190-206)
 // Every step of these chains was a 4-5 us launch doing < 1 us of work (a kernel boundary costs the drain of the previous kernel,
 // the dispatch and one cold round trip to L2 per operand); inside a workgroup the hand-over is an LDS barrier.
-// A workgroup = 4 waves; wave w owns output columns [64 w, 64 w + 64) of the 16 rows over the whole 256-deep contraction
+// A workgroup = 8 waves; wave w owns output columns [32 w, 32 w + 32) of the 16 rows over the whole 256-deep contraction
 // (v_mfma_f32_16x16x32_bf16, issued as D^T = W . A^T so that a lane owns 4 consecutive columns of one row); the 128 KB of a
 // weight matrix come from L2 (every workgroup reads the same bytes), 32 fragments per lane requested together: one latency per GEMM.
 #include <hip/hip_runtime.h>

@@ -445,7 +445,10 @@ class EncoderFn(Function):
             ctx.save_for_backward(pos_full, level_embed, *params, *saved)
             ctx.meta, ctx.nl, ctx.dims = meta, nl, (N, S, C)
             ctx.planes_t = [planes2[10 * i + 5:10 * i + 10] for i in range(nl)]
-            return x.view(N, S, C)
+            # the last layer's x2 is a view of the arena every layer's saved tensors live in.  When nothing will back-propagate
+            # (eval / no_grad: autograd drops the saved tensors) a view would keep those ~0.6 GB per layer alive for as long as
+            # the caller holds `memory` — hand out a copy then
+            return x.view(N, S, C) if any(ctx.needs_input_grad) else x.view(N, S, C).clone()
         _guard["active"] = guarded                   # (the operands of this call go through mpf_h2_range_stats in _audit)
         for i in range(nl):
             (wso, bso, waw, baw, wv, bv, wo, bo, g1, b1, w1, bb1, w2, bb2, g2_, b2) = params[i * PARAMS_PER_LAYER:(i + 1) * PARAMS_PER_LAYER]

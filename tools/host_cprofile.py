@@ -34,8 +34,8 @@ def step(i):
     opt.step()
 
 
-if os.environ.get("MPF_AUTOGRAD_ONE_THREAD", "0") == "1":    # backward on the calling thread: its python callbacks become visible here
-    torch.autograd.set_multithreading_enabled(False)
+from mp_former_amd import dropin
+dropin.configure_training_process(single_thread_autograd=True)      # backward on the calling thread, as bench.py
 for i in range(4):
     step(i)
 torch.cuda.synchronize()
