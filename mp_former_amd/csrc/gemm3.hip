@@ -79,7 +79,6 @@ int g_two_pass = 256;  // mpf_set_option("gemm3_two_pass"): N >= this and N % 25
 int g_two_pass_rows = 0;   // mpf_set_option("gemm3_two_pass_rows"): 0 = pick 128 or 96 rows per tile by rounds, else force
 int g_nt2 = 1;             // mpf_set_option("gemm3_nt2"): grouped fp16 x 2 weight gradients with all dimensions % 256 == 0 on 256 x 256 tiles (0 = 128 x 128)
 int g_tn3 = 1;             // mpf_set_option("gemm3_tn3"): fp16 x 2 TN products with N % 256 == 0 on 192 x 256 tiles, one 8-wave workgroup per CU, where the tiles fill the chip (2: wherever M >= 2048; 0: never)
-int g_tn4 = 1;             // mpf_set_option("gemm3_tn4"): the 192 x 256 tiles with the two row halves half a K step apart (gemm3_tn4.h); 0 = gemm3_tn3_kernel
 int g_ws = 512;            // mpf_set_option("gemm3_ws"): K = 256, N % 256 == 0, N >= this: fp16 x 2 products on the weight-stationary kernel (0 = never)
 
 
@@ -528,7 +527,6 @@ __device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned
 
 #include "gemm3_ws.h"
 #include "gemm3_tn3.h"
-#include "gemm3_tn4.h"
 
 // one output tile: 128 rows x BN columns starting at (m0, n0)
 // CV: A is a channel-last image [N_img*H*W][Cin] and K runs over (tap, channel) of a 3x3 window — K step kt reads the
@@ -1626,7 +1624,6 @@ int mpf::set_gemm3_option(const char* key, int v)
     if (!strcmp(key, "gemm3_two_pass_rows")) { g_two_pass_rows = v; return 0; }
     if (!strcmp(key, "gemm3_ws")) { g_ws = v; return 0; }
     if (!strcmp(key, "gemm3_tn3")) { g_tn3 = v; return 0; }
-    if (!strcmp(key, "gemm3_tn4")) { g_tn4 = v; return 0; }
     if (!strcmp(key, "gemm3_nt2")) { g_nt2 = v; return 0; }
     if (strcmp(key, "gemm3_ablate") != 0) return 1;
     g_ablate = v;
@@ -1814,16 +1811,15 @@ static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows,
         tn3 = g_tn3 == 2 || (nt3 >= cus * 3 / 4 && (rem == 0 || 4 * rem >= 3 * cus || nt3 >= 4 * cus));
     }
     if (tn3) {
-        static mpf::LdsAttr attr, attr4;
-        const void* kern = g_tn4 ? (const void*)gemm3_tn4_kernel : (const void*)gemm3_tn3_kernel;
-        if (int e = mpf::ensure_dynamic_lds(kern, g_tn4 ? kT4Lds : kT3Lds, g_tn4 ? attr4 : attr)) return e;
+        static mpf::LdsAttr attr;
+        if (int e = mpf::ensure_dynamic_lds((const void*)gemm3_tn3_kernel, kT3Lds, attr)) return e;
         p.tiles_n = N / 256;
         p.ntiles = ((M + kT3BM - 1) / kT3BM) * p.tiles_n;
         mpf::prof_begin(st);
-        mpf::set_kernel(g_tn4 ? "gemm3_tn_kernel<h2 192x256 pp>" : "gemm3_tn_kernel<h2 192x256>");
+        mpf::set_kernel("gemm3_tn_kernel<h2 192x256>");
         {
             void* args[] = {(void*)&p};
-            if (hipError_t e = hipLaunchKernel(kern, dim3(((p.ntiles + 7) / 8) * 8), dim3(kT3T), args, g_tn4 ? kT4Lds : kT3Lds, st); e != hipSuccess)
+            if (hipError_t e = hipLaunchKernel((const void*)gemm3_tn3_kernel, dim3(((p.ntiles + 7) / 8) * 8), dim3(kT3T), args, kT3Lds, st); e != hipSuccess)
                 return mpf::check(e, "gemm3_tn3_kernel");
         }
         mpf::prof_end(mpf_last_kernel(), st, 4.0 * ((double)M * K + (double)M * N) + 4.0 * (double)N * K, 2.0 * M * (double)N * K);

@@ -448,45 +448,6 @@ def test_gemm3_tn3_kernel_bit_identical_to_the_two_pass_kernel(M, N, K):
     assert float(((res[1][0].double() - ref).abs() / den).max()) < 1e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(43008, 256, 256), (43008, 256, 1024), (5000, 256, 288), (2731, 512, 256), (2048, 1024, 64), (21511, 256, 32), (4100, 256, 96)])
-def test_gemm3_tn4_kernel_bit_identical_to_the_lockstep_kernel(M, N, K):
-    """csrc/gemm3_tn4.h (the 192 x 256 tile with its two row halves half a K step apart: one wave of every SIMD in its MFMA phase
-    while its partner stages the next step) against gemm3_tn3_kernel (all eight waves in lockstep): same split, same images, same
-    product order — bit for bit on every epilogue variant, odd and even numbers of K steps (32, 64, 96, 256, 288, 1024), rows
-    that are no multiple of 192 / 96 / 16, a strided A."""
-    from mp_former_amd import _lib
-    from mp_former_amd.gemm3 import amax, amax_slots, amax_value, gemm3_h2, gemm3_h2_bits, split_weights_grouped_h2
-    dev = torch.device("cuda:0")
-    torch.manual_seed(M + N + K + 1)
-    a_full = _heavy(M, K + 64, dev)
-    a = a_full[:, :K]
-    w = torch.randn(N, K, device=dev) / K ** 0.5
-    b, cin, cin2, gate = torch.randn(N, device=dev), torch.randn(M, N, device=dev), torch.randn(M, N, device=dev), torch.randn(M, N, device=dev)
-    (pl, wam), = split_weights_grouped_h2([([w], False)])
-    am = amax(a.contiguous())
-    res = {}
-    _lib.set_option("gemm3_ws", 0)
-    _lib.set_option("gemm3_tn3", 2)
-    try:
-        for t4 in (0, 1):
-            _lib.set_option("gemm3_tn4", t4)
-            oam = amax_slots(3, dev)
-            r = [gemm3_h2(a, am, pl, wam)]
-            assert ("192x256 pp" in _lib.last_kernel()) == bool(t4) and "192x256" in _lib.last_kernel(), _lib.last_kernel()
-            r.append(gemm3_h2(a, am, pl, wam, b, cin=cin, cin2=cin2, out_amax=oam[0]))
-            r.append(gemm3_h2(a, am, pl, wam, b, relu=True, gate=gate, out_amax=oam[1]))
-            h, bits = gemm3_h2_bits(a, am, pl, wam, b, relu=True, out_amax=oam[2], want_bits=True)
-            r += [h, bits, gemm3_h2_bits(a, am, pl, wam, cin=cin, gate_bits=bits)]
-            r += [amax_value(oam[i]).clone() for i in range(3)]
-            res[t4] = r
-    finally:
-        _lib.set_option("gemm3_ws", 512)
-        _lib.set_option("gemm3_tn3", 1)
-        _lib.set_option("gemm3_tn4", 1)
-    for x, y in zip(res[0], res[1]):
-        assert torch.equal(x, y)
-
-
 def test_h2_range_stats_counts_rows_below_the_slot():
     """mpf_h2_range_stats (the run-time guard of the fp16 x 2 form) on a constructed skewed operand: rows
     scaled 2^-10 / 2^-19 / 2^-25 below the largest and all-zero rows -> counters = (non-zero rows, rows below 2^-18 of the slot),
