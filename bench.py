@@ -142,9 +142,11 @@ def synth_features(n, hw, shapes, seed, device):
 def _gemm3_traffic_ratios():
     """{shape: HBM bytes from the PMC counters / algorithmic bytes} of the fp16 x 2 TN kernels the routing picks
     (profiles/r05_gemm3_traffic.json from tools/pmc_gemm3_traffic.sh: gemm3_tn3 for N = 256, gemm3_ws for N = 1024), or None"""
-    f = os.path.join(ROOT, "profiles", "r05_gemm3_traffic.json")
-    if not os.path.exists(f):
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm3_traffic.json")))
+    if not fs:
         return None
+    f = fs[-1]
     d = json.load(open(f))
     return {k: v["fp16x2"]["traffic_over_algorithmic"] for k, v in d.get("shapes", {}).items() if "fp16x2" in v}
 
@@ -443,15 +445,17 @@ def main():
     # inside the process, so the file carries the hash of the kernel source it was measured on and is REFUSED (traffic =
     # null) when the kernels have changed since
     traffic, traffic_note = None, "no PMC file for this shape"
-    pmc_file = os.path.join(ROOT, "profiles", "r05_msda_bwd_pmc_configB_N2.json")
-    if hw == (1024, 1024) and a.batch == 2 and os.path.exists(pmc_file):
+    import glob
+    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_msda_bwd_pmc_configB_N2.json")))       # the newest round's file
+    pmc_file = pmc_files[-1] if pmc_files else ""
+    if hw == (1024, 1024) and a.batch == 2 and pmc_file:
         pmc = json.load(open(pmc_file))
         src = os.path.join(ROOT, "mp_former_amd", "csrc", "msda_block.hip")
         if pmc.get("source_sha256") == _sha256(src):
             traffic = pmc["hbm_bytes_per_call"]
             traffic_note = pmc.get("note", "")
         else:
-            traffic_note = "PMC file is older than csrc/msda_block.hip: refused"
+            traffic_note = os.path.basename(pmc_file) + " is older than csrc/msda_block.hip: refused"
 
     # ---- the hot path alone, in the driver's own record: the SAME model, the segmentation head on the
     # detached feature maps of one cached backbone forward per batch (the features require gradients, so the head's backward
