@@ -203,10 +203,23 @@ def _sub(t, step):
     return t.detach().reshape(-1)[::step].clone().numpy()
 
 
-def gen_head(only=None):
+def gen_head_amp(only=None):
+    """Second golden family: the reference DECODER run under `torch.autocast("cpu", dtype=torch.bfloat16)` on the
+    fp32 pixel-decoder outputs (on the GPU the reference's pixel decoder is fp32 under AMP as well: msdeformattn.py:314,320), same
+    parameters, same replayed draws -> tests/golden/head_<name>_amp.npz with the outputs of every decoder layer as float32.  CPU
+    autocast is not CUDA autocast (its softmax and LayerNorm stay in bf16 where CUDA's run in fp32), so this is A bf16 evaluation
+    of the reference, not THE one a GPU run of the reference would give: the product's autocast path and this family are two
+    bf16-noisy evaluations of the same function (tests/test_head_gpu.py reports the distance of each to the fp32 goldens and to
+    each other)."""
+    gen_head(only=only, amp_family=True)
+
+
+def gen_head(only=None, amp_family=False):
     import det_params as DP
     for name, cfg in HEAD_CFGS.items():
         if only and name not in only:
+            continue
+        if amp_family and name == "nogt":
             continue
         torch.manual_seed(1234)
         pix, d, crit, wd = build_reference_head(cfg)
@@ -230,6 +243,26 @@ def gen_head(only=None):
         orig_heads = d.forward_prediction_heads
         if "draw_seed" in cfg:
             torch.manual_seed(cfg["draw_seed"])
+        rng_before_decoder = torch.get_rng_state()
+        if amp_family:
+            dn_args = {"tgt": targets, "scalar": 1, "noise_scale": cfg.get("noise_scale", 0.0)}
+            with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+                dout = d([z.detach() for z in ms], mf.detach(), None, dn_args)
+            ms_ = cfg.get("mask_step", 1)
+            f32 = lambda t: t.detach().float()          # noqa: E731
+            amp = {"cfg": out["cfg"], "pred_logits": f32(dout["pred_logits"]).numpy(),
+                   "pred_masks": f32(dout["pred_masks"]).numpy() if ms_ == 1 else _sub(f32(dout["pred_masks"]), ms_)}
+            for i, a in enumerate(dout["aux_outputs"]):
+                amp[f"aux{i}_pred_logits"] = f32(a["pred_logits"]).numpy()
+                amp[f"aux{i}_pred_masks_s3"] = _sub(f32(a["pred_masks"]), cfg.get("aux_step", 3))
+            if dout["dn_out"] is not None:
+                amp["dn_pred_logits"] = f32(dout["dn_out"]["pred_logits"]).numpy()
+                amp["dn_pred_masks"] = f32(dout["dn_out"]["pred_masks"]).numpy()
+            amp["dtypes"] = np.array(json.dumps({"pred_logits": str(dout["pred_logits"].dtype), "pred_masks": str(dout["pred_masks"].dtype)}))
+            _save(f"head_{name}_amp", **amp)
+            print(f"    [amp family] {name}: pred_logits {dout['pred_logits'].dtype}, pred_masks {dout['pred_masks'].dtype}")
+            continue
+        del rng_before_decoder
         with R.RandCapture() as cap:
             dn_args = {"tgt": targets, "scalar": 1, "noise_scale": cfg.get("noise_scale", 0.0)}
             dout = d(ms, mf, None, dn_args)
@@ -299,7 +332,9 @@ def main():
     torch.set_num_threads(4)
     for w in what:
         print(f"[{w}]")
-        if w.startswith("head:"):          # e.g. head:deep — one head fixture only
+        if w.startswith("head_amp:"):
+            gen_head_amp(only=w.split(":", 1)[1].split(","))
+        elif w.startswith("head:"):          # e.g. head:deep — one head fixture only
             gen_head(only=w.split(":", 1)[1].split(","))
         else:
             globals()["gen_" + w]()

@@ -84,3 +84,28 @@ def test_msda_core_torch_matches_c_oracle(oracle_msda):
     ref = oracle_msda.msda_forward(z["value"].astype(np.float64), z["shapes"], z["level_start"],
                                    z["loc"].astype(np.float64), z["attn"].astype(np.float64))
     np.testing.assert_allclose(out.numpy(), ref, rtol=1e-10, atol=1e-12)
+
+
+def test_amp_family_fixtures_are_bf16_evaluations_of_the_same_reference():
+    """tests/golden/head_*_amp.npz (make_golden.py head_amp: the reference decoder under CPU bf16 autocast): same outputs, same shapes
+    as the fp32 family, produced in bf16, and within bf16 noise of it — the yardstick the GPU tests hold the product's autocast path
+    against.  The reference's OWN bf16 evaluation sits 1-13 % (relative L2, worst output) from its fp32 evaluation on these
+    fixtures: masked attention thresholds the previous layer's mask logits, so rounding flips attention-mask bits."""
+    import json
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    worst = {}
+    for name in ("small", "ragged", "noise", "deep", "cfgA"):
+        z = np.load(os.path.join(GOLDEN, f"head_{name}.npz"), allow_pickle=True)
+        a = np.load(os.path.join(GOLDEN, f"head_{name}_amp.npz"), allow_pickle=True)
+        assert json.loads(str(a["dtypes"])) == {"pred_logits": "torch.bfloat16", "pred_masks": "torch.bfloat16"}
+        assert str(a["cfg"]) == str(z["cfg"])
+        keys = [k for k in a.files if k not in ("cfg", "dtypes")]
+        assert "pred_logits" in keys and "pred_masks" in keys and "dn_pred_masks" in keys and "aux0_pred_logits" in keys
+        w = 0.0
+        for k in keys:
+            assert a[k].shape == z[k].shape and a[k].dtype == np.float32, k
+            w = max(w, float(np.linalg.norm(a[k].astype(np.float64) - z[k]) / np.linalg.norm(z[k])))
+        worst[name] = w
+    assert all(1e-3 < w < 0.2 for w in worst.values()), worst

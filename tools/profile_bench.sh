@@ -4,7 +4,7 @@
 tag=${1:-run}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o bench -- python3 bench.py --steps 6 --warmup 3 --profile-steps 0 --trained-steps 0 --no-cpu-baseline > gpurun_out/bench_prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o bench -- python3 bench.py --steps 6 --warmup 3 --profile-steps 0 --trained-steps 0 --head-steps 0 --no-cpu-baseline > gpurun_out/bench_prof_$tag.log 2>&1
 mkdir -p gpurun_out/prof_$tag
 trace=$(find /tmp/prof_$tag -name 'bench_kernel_trace.csv' | head -1)
 python3 tools/prof_trace_stats.py "$trace" 3 gpurun_out/prof_$tag/steady_kernel_stats.csv
