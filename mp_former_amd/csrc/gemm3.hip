@@ -71,6 +71,7 @@ struct G3 {
     unsigned char* gbits_out;
     int64_t ldgbits, ldgbits_out;
     int gbits_cm;
+    int t3_bm;                                // gemm3_tn3_kernel: rows per tile, 192 or 176 (the second row half is then 80 rows)
 };
 
 int g_ablate = 0;      // mpf_set_option("gemm3_ablate"): reserved for timing experiments
@@ -79,6 +80,7 @@ int g_two_pass = 256;  // mpf_set_option("gemm3_two_pass"): N >= this and N % 25
 int g_two_pass_rows = 0;   // mpf_set_option("gemm3_two_pass_rows"): 0 = pick 128 or 96 rows per tile by rounds, else force
 int g_nt2 = 1;             // mpf_set_option("gemm3_nt2"): grouped fp16 x 2 weight gradients with all dimensions % 256 == 0 on 256 x 256 tiles (0 = 128 x 128)
 int g_tn3 = 1;             // mpf_set_option("gemm3_tn3"): fp16 x 2 TN products with N % 256 == 0 on 192 x 256 tiles, one 8-wave workgroup per CU, where the tiles fill the chip (2: wherever M >= 2048; 0: never)
+int g_tn3_176 = 1;         // mpf_set_option("gemm3_tn3_176"): gemm3_tn3_kernel on 176-row tiles where that costs no extra round (0 = always 192)
 int g_ws = 512;            // mpf_set_option("gemm3_ws"): K = 256, N % 256 == 0, N >= this: fp16 x 2 products on the weight-stationary kernel (0 = never)
 
 
@@ -423,7 +425,7 @@ inline void g3_no_bits(G3& p, const float* consts)
 // returns the largest |value| this thread stored (SCALED kernels; 0 otherwise)
 template <int NJ, int NI = 4, typename AccT = Acc<NJ, false>, bool SCALED = false>
 __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int lane, int m_wave, int n_wave, const float inv_a = 1.f,
-                                            const float inv_b = 1.f)
+                                            const float inv_b = 1.f, const int m_end = 0x7fffffff)
 {
     float amax = 0.f;
     const int r16 = lane & 15, g = lane >> 4;
@@ -434,7 +436,7 @@ __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int l
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int m = m_wave + i * 16 + r16;
-        mok[i] = m < p.M;
+        mok[i] = m < p.M && m < m_end;           // m_end: rows from there on belong to the next tile (gemm3_tn3_kernel's 176-row tiles)
         mrow[i] = min(m, p.M - 1);
         if constexpr (NJ <= 2) {                 // a 32-column wave tile: 4 bytes of the row's mask
             gb[i].x = *reinterpret_cast<const unsigned*>(p.gbits + mrow[i] * p.ldgbits + (n_wave >> 3) * p.gbits_cm);
@@ -1624,6 +1626,7 @@ int mpf::set_gemm3_option(const char* key, int v)
     if (!strcmp(key, "gemm3_two_pass_rows")) { g_two_pass_rows = v; return 0; }
     if (!strcmp(key, "gemm3_ws")) { g_ws = v; return 0; }
     if (!strcmp(key, "gemm3_tn3")) { g_tn3 = v; return 0; }
+    if (!strcmp(key, "gemm3_tn3_176")) { g_tn3_176 = v; return 0; }
     if (!strcmp(key, "gemm3_nt2")) { g_nt2 = v; return 0; }
     if (strcmp(key, "gemm3_ablate") != 0) return 1;
     g_ablate = v;
@@ -1806,17 +1809,23 @@ static int g3_tn_impl(const float* a, int64_t lda, const float* a2, int a2_rows,
     // 3/4 of the CUs (43 008 rows: 224 tiles on 256 CUs; 16 800 rows would be 88 tiles against 175 half-size tiles of the
     // two-pass kernel on two workgroup slots per CU: config D's head measured 11.62 -> 11.79 ms per step with them)
     bool tn3 = a_amax && !a2 && g_tn3 && N % 256 == 0 && M >= 2048 && ((uintptr_t)a & 15) == 0 && lda % 4 == 0;
+    int t3_bm = kT3BM;
     if (tn3) {
         const int cus = mpf::cu_count(), nt3 = ((M + kT3BM - 1) / kT3BM) * (N / 256), rem = nt3 % cus;
         tn3 = g_tn3 == 2 || (nt3 >= cus * 3 / 4 && (rem == 0 || 4 * rem >= 3 * cus || nt3 >= 4 * cus));
+        // 176-row tiles (96 + 80: the second row half one MFMA row tile shorter) when they need no more rounds of the chip than
+        // 192-row tiles do: a workgroup's time goes with its rows, and 43 008 rows are 245 tiles of 176 on 256 CUs (224 of 192)
+        const int nt176 = ((M + 175) / 176) * (N / 256);
+        if (g_tn3_176 && (nt176 + cus - 1) / cus <= (nt3 + cus - 1) / cus) t3_bm = 176;
     }
     if (tn3) {
         static mpf::LdsAttr attr;
         if (int e = mpf::ensure_dynamic_lds((const void*)gemm3_tn3_kernel, kT3Lds, attr)) return e;
         p.tiles_n = N / 256;
-        p.ntiles = ((M + kT3BM - 1) / kT3BM) * p.tiles_n;
+        p.t3_bm = t3_bm;
+        p.ntiles = ((M + t3_bm - 1) / t3_bm) * p.tiles_n;
         mpf::prof_begin(st);
-        mpf::set_kernel("gemm3_tn_kernel<h2 192x256>");
+        mpf::set_kernel(t3_bm == kT3BM ? "gemm3_tn_kernel<h2 192x256>" : "gemm3_tn_kernel<h2 192x256:176>");
         {
             void* args[] = {(void*)&p};
             if (hipError_t e = hipLaunchKernel((const void*)gemm3_tn3_kernel, dim3(((p.ntiles + 7) / 8) * 8), dim3(kT3T), args, kT3Lds, st); e != hipSuccess)

@@ -52,7 +52,10 @@ __global__ __launch_bounds__(kT3T, 2) void gemm3_tn3_kernel(G3 p)
     const int tile = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (tile >= p.ntiles) return;
     const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
-    const int m0 = tm * kT3BM, n0 = tn * 256;
+    // p.t3_bm = 192, or 176: the second row half (waves 4-7) then owns 80 rows = five MFMA row tiles — the two waves of a SIMD
+    // (w, w + 4) share its matrix pipe, so the SIMD's MFMA time per K step goes with 6 + 5 row tiles, the tile's bytes with 176 rows
+    const int bm = p.t3_bm;
+    const int m0 = tm * bm, n0 = tn * 256, m_end = min(m0 + bm, p.M);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(kT3T, 2) void gemm3_tn3_kernel(G3 p)
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int row = srow + 64 * u;
-        ap[u] = p.a + (int64_t)min(m0 + row, p.M - 1) * p.lda + shc * 4;
+        ap[u] = p.a + (int64_t)min(m0 + row, m_end - 1) * p.lda + shc * 4;          // (rows past the tile repeat its last row: never used)
         const int kc = shc >> 1;
         aoff[u] = kc * kT3AKc + (row ^ (2 * kc)) * 16 + (shc & 1) * 8;
     }
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(kT3T, 2) void gemm3_tn3_kernel(G3 p)
 
     const int nk = p.K / kBK;
     const int klast = (nk - 1) * kBK;
+    const int nrt = wr ? (bm - 96) >> 4 : 6;             // row tiles of this wave (uniform): 6, or 5 in the second half of a 176-row tile
     // fragment addresses: A rows 96 wr + 16 i + r16, chunk g; B columns 64 wc + 16 j + r16, chunk g (swizzled)
     const int a_frag = g * kT3AKc + ((wr * 96 + r16) ^ (2 * g)) * 16;
     const int b_frag = kT3A + (wc * 64 + r16) * 64 + ((g ^ ((0 - (r16 >> 2)) & 3)) * 16);
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(kT3T, 2) void gemm3_tn3_kernel(G3 p)
         _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) _Pragma("unroll") for (int j = 0; j < 4; ++j)                          \
             fb[pl][j] = as_fragh(*reinterpret_cast<const uint4*>(st + b_frag + pl * (256 * 64) + j * 1024));                    \
         _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                                         \
+            if (i == 5 && nrt < 6) break;                                                                                       \
             const f16x8 fh0 = as_fragh(*reinterpret_cast<const uint4*>(st + a_frag + i * 256));                                 \
             const f16x8 fh1 = as_fragh(*reinterpret_cast<const uint4*>(st + a_frag + 4 * kT3AKc + i * 256));                    \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[1][j], fh0, acc[i][j], 0, 0, 0); \
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(kT3T, 2) void gemm3_tn3_kernel(G3 p)
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) out.v[i][j] = acc[hf * 3 + i][j];
-        omax = fmaxf(omax, g3_epilogue<4, 3, decltype(out), true>(p, out, lane, m0 + wr * 96 + hf * 48, n0 + wc * 64, inv_a, inv_b));
+        omax = fmaxf(omax, g3_epilogue<4, 3, decltype(out), true>(p, out, lane, m0 + wr * 96 + hf * 48, n0 + wc * 64, inv_a, inv_b, m_end));
     }
     if (p.out_amax) {                    // (uniform) one atomic per workgroup (8 waves: amax_commit is written for 4)
         float m = omax;

@@ -422,8 +422,9 @@ def test_gemm3_tn3_kernel_bit_identical_to_the_two_pass_kernel(M, N, K):
     res = {}
     _lib.set_option("gemm3_ws", 0)
     try:
-        for t3 in (0, 1):
-            _lib.set_option("gemm3_tn3", 2 * t3)            # (2: every eligible shape, not only those whose tiles fill the chip)
+        for t3 in (0, 1, 2):                                # two-pass kernel | 192-row tiles | 176-row tiles where they cost no extra round
+            _lib.set_option("gemm3_tn3", 2 * min(t3, 1))    # (2: every eligible shape, not only those whose tiles fill the chip)
+            _lib.set_option("gemm3_tn3_176", int(t3 == 2))
             oam = amax_slots(3, dev)
             r = [gemm3_h2(a, am, pl, wam)]
             assert ("192x256" in _lib.last_kernel()) == bool(t3), _lib.last_kernel()
@@ -435,10 +436,15 @@ def test_gemm3_tn3_kernel_bit_identical_to_the_two_pass_kernel(M, N, K):
             assert ("192x256" in _lib.last_kernel()) == bool(t3), _lib.last_kernel()
             r += [amax_value(oam[i]).clone() for i in range(3)]
             res[t3] = r
+            if t3 == 2 and M == 43008:
+                assert "192x256:176" in _lib.last_kernel(), _lib.last_kernel()      # 245 tiles of 176 rows: one round, like 224 of 192
     finally:
         _lib.set_option("gemm3_ws", 512)
         _lib.set_option("gemm3_tn3", 1)
+        _lib.set_option("gemm3_tn3_176", 1)
     for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+    for x, y in zip(res[0], res[2]):
         assert torch.equal(x, y)
     assert float(res[1][7]) == float(res[1][1].abs().max())
     want = np.packbits((res[1][4] > 0).cpu().numpy(), axis=1, bitorder="little")
