@@ -423,7 +423,14 @@ inline void g3_no_bits(G3& p, const float* consts)
 }
 
 // returns the largest |value| this thread stored (SCALED kernels; 0 otherwise)
-template <int NJ, int NI = 4, typename AccT = Acc<NJ, false>, bool SCALED = false>
+// PIPE (round 6): the operands of column tile j + 1 (bias, addends, gate) are REQUESTED BEFORE the stores of column tile j.  On gfx9
+// loads and stores share one counter (vmcnt) and complete in issue order, so a load issued behind stores can only be waited for by
+// waiting for those stores to be acknowledged by memory — in the plain form every column tile of every epilogue call did that
+// (8 drains per wave in gemm3_tn3_kernel), and for the waves that reach their epilogue last, with every CU's stores in flight, a
+// drain is microseconds: phase stamps of waves 4-7 showed the epilogue at 45 % (K = 1 024) to 75 % (K = 256) of the wave's life while
+// waves 0-3, whose stores drain under the others' MFMAs, spent 16 %.  With the next tile's loads older than this tile's stores the
+// wait for them leaves the stores in flight.  Same arithmetic, same order: bit-identical.
+template <int NJ, int NI = 4, typename AccT = Acc<NJ, false>, bool SCALED = false, bool PIPE = false>
 __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int lane, int m_wave, int n_wave, const float inv_a = 1.f,
                                             const float inv_b = 1.f, const int m_end = 0x7fffffff)
 {
@@ -446,19 +453,33 @@ __device__ __forceinline__ float g3_epilogue(const G3& p, const AccT& acc, int l
         }
         wb[i][0] = wb[i][1] = 0u;
     }
+    struct Ops { float4 bz, ci[NI], c2[NI], gt[NI]; };
+    auto load_ops = [&](const int j, Ops& q) {
+        const int nc = min(n_wave + j * 16 + g * 4, p.N - 4);
+        q.bz = *reinterpret_cast<const float4*>(p.bias + nc * p.bias_cm);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            q.ci[i] = *reinterpret_cast<const float4*>(p.cin + mrow[i] * p.ldcin + nc * p.cin_cm);
+            q.c2[i] = *reinterpret_cast<const float4*>(p.cin2 + mrow[i] * p.ldcin2 + nc * p.cin2_cm);
+            q.gt[i] = *reinterpret_cast<const float4*>(p.gate + mrow[i] * p.ldgate + nc * p.gate_cm);
+        }
+    };
+    Ops ops[2];
+    if constexpr (PIPE) load_ops(0, ops[0]);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n_wave + j * 16 + g * 4;
         const bool nok = n < p.N;                    // N % 4 == 0: a quad is inside or outside as a whole
-        const int nc = min(n, p.N - 4);
-        const float4 bz = *reinterpret_cast<const float4*>(p.bias + nc * p.bias_cm);
-        float4 ci[NI], c2[NI], gt[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            ci[i] = *reinterpret_cast<const float4*>(p.cin + mrow[i] * p.ldcin + nc * p.cin_cm);
-            c2[i] = *reinterpret_cast<const float4*>(p.cin2 + mrow[i] * p.ldcin2 + nc * p.cin2_cm);
-            gt[i] = *reinterpret_cast<const float4*>(p.gate + mrow[i] * p.ldgate + nc * p.gate_cm);
+        if constexpr (PIPE) {
+            if (j + 1 < NJ) load_ops(j + 1, ops[(j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);       // (keep the requests of tile j + 1 in front of the stores of tile j)
+        } else {
+            load_ops(j, ops[j & 1]);
         }
+        const float4 bz = ops[j & 1].bz;
+        const float4(&ci)[NI] = ops[j & 1].ci;
+        const float4(&c2)[NI] = ops[j & 1].c2;
+        const float4(&gt)[NI] = ops[j & 1].gt;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             float4 o = make_float4(acc.v[i][j][0], acc.v[i][j][1], acc.v[i][j][2], acc.v[i][j][3]);

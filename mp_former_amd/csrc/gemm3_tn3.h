@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kT3T, 2) void gemm3_tn3_kernel(G3 p)
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) out.v[i][j] = acc[hf * 3 + i][j];
-        omax = fmaxf(omax, g3_epilogue<4, 3, decltype(out), true>(p, out, lane, m0 + wr * 96 + hf * 48, n0 + wc * 64, inv_a, inv_b, m_end));
+        omax = fmaxf(omax, g3_epilogue<4, 3, decltype(out), true, true>(p, out, lane, m0 + wr * 96 + hf * 48, n0 + wc * 64, inv_a, inv_b, m_end));
     }
     if (p.out_amax) {                    // (uniform) one atomic per workgroup (8 waves: amax_commit is written for 4)
         float m = omax;
