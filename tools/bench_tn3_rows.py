@@ -29,7 +29,7 @@ def main():
     torch.manual_seed(0)
     M = int(os.environ.get("M", "43008"))
     res = {}
-    for (N, K, addend) in ((256, 256, False), (256, 256, True), (256, 1024, False), (256, 288, False), (512, 512, False)):
+    for (N, K, addend) in ((256, 32, False), (256, 64, False), (256, 128, False), (256, 256, False), (256, 256, True), (256, 512, False), (256, 1024, False), (256, 288, False), (512, 512, False)):
         a = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) / K ** 0.5
         b = torch.randn(N, device=dev)
