@@ -18,7 +18,7 @@ def main():
     from mp_former_amd import dist as mdist
     from mp_former_amd.head import MPFormerHead
     from mp_former_amd.optim import ClipAdamW
-    if mode in ("ddp", "flat"):
+    if mode in ("ddp", "flat", "flat-bf16"):
         rank, world = mdist.init_from_env("nccl", dev)
         assert (rank, world) == (0, 1) and mdist.distributed(), "process group was not initialised"
         assert torch.distributed.get_backend() == "nccl"
@@ -38,9 +38,10 @@ def main():
 
     model = M().to(dev).train()
     sync = None
-    if mode == "flat":          # two flat buckets, the first launched from an autograd hook (what bench.py does at N > 1)
+    if mode in ("flat", "flat-bf16"):   # two flat buckets (what bench.py does at N > 1); "-bf16": bf16 on the wire (RCCL sums bf16)
         ps = [p for p in model.parameters() if p.requires_grad]
-        sync = mdist.FlatGradSync([ps[:len(ps) // 2], ps[len(ps) // 2:]])
+        sync = mdist.FlatGradSync([ps[:len(ps) // 2], ps[len(ps) // 2:]], wire_dtype=torch.bfloat16 if mode.endswith("bf16") else None)
+        sync.record_events(True)
         ddp = model
     else:
         ddp = mdist.wrap_ddp(model, [0])
@@ -72,7 +73,10 @@ def main():
         losses.append(float(loss.detach()))
     torch.cuda.synchronize()
     checksum = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
-    print("RESULT " + json.dumps({"mode": mode, "losses": losses, "checksum": checksum}), flush=True)
+    extra = {}
+    if sync is not None:        # the diagnostics bench.py prints at N > 1, on real RCCL
+        extra = {"timing": sync.timing(), "allreduce_ms": sync.standalone_allreduce_ms(reps=3), "bucket_bytes": sync.bucket_bytes()}
+    print("RESULT " + json.dumps({"mode": mode, "losses": losses, "checksum": checksum, **extra}), flush=True)
     if mdist.distributed():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

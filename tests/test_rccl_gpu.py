@@ -29,7 +29,7 @@ def _run(mode):
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MPF_FORCE_DIST"):
         env.pop(k, None)
-    if mode in ("ddp", "flat"):
+    if mode in ("ddp", "flat", "flat-bf16"):
         env.update(MPF_FORCE_DIST="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_child.py"), mode], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, f"child ({mode}) failed:\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
@@ -61,3 +61,21 @@ def test_flat_grad_sync_over_rccl_world1_matches_plain_run():
     for a, b in zip(plain["losses"][1:], flat["losses"][1:]):
         assert abs(a - b) <= 1e-2 * max(1.0, abs(a)), (plain, flat)
     assert abs(plain["checksum"] - flat["checksum"]) <= 1e-5 * plain["checksum"], (plain["checksum"], flat["checksum"])
+
+
+@pytest.mark.timeout(900)
+def test_bf16_wire_over_rccl_world1():
+    """FlatGradSync(wire_dtype=bfloat16) on real RCCL (SUM of bf16 buffers, world size 1): the gradients are rounded to bf16 once on
+    their way through the wire buffer, so three clipped AdamW steps stay within bf16 noise of the plain run; the buckets on the wire
+    are half the fp32 bytes; the events / stand-alone collective timings that bench.py prints at N > 1 come back finite."""
+    plain = _run("plain")
+    f32 = _run("flat")
+    b16 = _run("flat-bf16")
+    assert abs(plain["losses"][0] - b16["losses"][0]) <= 1e-5 * max(1.0, abs(plain["losses"][0])), (plain, b16)
+    for a, b in zip(plain["losses"][1:], b16["losses"][1:]):
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(a)), (plain, b16)
+    assert abs(plain["checksum"] - b16["checksum"]) <= 1e-4 * plain["checksum"]
+    assert [2 * x for x in b16["bucket_bytes"]] == f32["bucket_bytes"]
+    for r in (f32, b16):
+        assert len(r["allreduce_ms"]) == 2 and all(t > 0 for t in r["allreduce_ms"])
+        assert r["timing"]["exposed_wait_ms"] >= 0 and len(r["timing"]["in_flight_ms"]) == 2
