@@ -128,8 +128,11 @@ constexpr int kMergePitch = 36;   // floats per query row of a wave's partial in
 constexpr int kMergeWave = 32 * kMergePitch + 64;   // floats per wave: 32 rows of O (or dQ) + (max, sum) per row
 
 // QS = number of 16-row query sub-tiles per wave
-template <int QS, bool AL, bool MK>
-__global__ __launch_bounds__(64 * kMaxNW) void attn_fwd_kernel(AttnParams p)
+// OCC (round 6): minimum waves per SIMD the register allocation must allow.  4 = two 8-wave workgroups per CU (<= 128 registers; the
+// aligned forms fit without spills): these kernels are bound by the dependent instruction stream of a (query tile, key step) unit —
+// their time goes with the number of queries, not with bytes or prefetch depth — so a second workgroup per CU is what hides it.
+template <int QS, bool AL, bool MK, int OCC = 2>
+__global__ __launch_bounds__(64 * kMaxNW, OCC) void attn_fwd_kernel(AttnParams p)
 {
     static_assert(QS == 2, "the LDS merge is laid out for 32 query rows per wave");
     extern __shared__ __attribute__((aligned(16))) float s_merge[];
@@ -819,6 +822,7 @@ __global__ __launch_bounds__(256) void attn_bwd_aux_kernel(const float* __restri
 // workgroup of a query tile and merge through LDS — key axes up to 1 024 need no second pass; beyond that the workgroups'
 // partials go through the workspace and the combine / sum kernels.
 struct AttnSplit { int keys_per_wave, nw, wg_splits; };
+static int g_attn_occ = 4;      // mpf_set_option attn_occ (2 | 4): forward, aligned forms
 static int g_attn_nw = kMaxNW, g_attn_kpw = 0;     // A/B switches (mpf_set_option attn_nw / attn_kpw; 0 = the policy above)
 static AttnSplit attn_split(int Lq, int Lk, int N, int H)
 {
@@ -838,6 +842,7 @@ static AttnSplit attn_split(int Lq, int Lk, int N, int H)
 namespace mpf {
 int set_attn_option(const char* key, int v)
 {
+    if (!strcmp(key, "attn_occ")) { if (v != 2 && v != 4) return -1; g_attn_occ = v; return 0; }
     if (!strcmp(key, "attn_nw")) { if (v < 1 || v > kMaxNW) return -1; g_attn_nw = v; return 0; }
     if (!strcmp(key, "attn_kpw")) { if (v && (v < 64 || (v & 63))) return -1; g_attn_kpw = v; return 0; }
     return 1;
@@ -909,7 +914,9 @@ extern "C" int mpf_attn_forward_kv(const void* q, const void* k, int64_t k_row_s
             return 0;
         };
         int e;
-        if (al && mask) e = launch(attn_fwd_kernel<QS, true, true>);
+        if (al && mask && g_attn_occ == 4) e = launch(attn_fwd_kernel<QS, true, true, 4>);
+        else if (al && g_attn_occ == 4) e = launch(attn_fwd_kernel<QS, true, false, 4>);
+        else if (al && mask) e = launch(attn_fwd_kernel<QS, true, true>);
         else if (al) e = launch(attn_fwd_kernel<QS, true, false>);
         else if (mask) e = launch(attn_fwd_kernel<QS, false, true>);
         else e = launch(attn_fwd_kernel<QS, false, false>);
