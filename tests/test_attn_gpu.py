@@ -60,6 +60,15 @@ def test_attention_forward_matches_fp32_reference(Lq, Lk, N, mask_kind):
     err = (out.float() - ref).abs().max().item()
     assert err < 2e-2 * max(1.0, v.float().abs().max().item()), err
     assert torch.isfinite(out.float()).all()
+    # per (query, image, head) ROW (round 6: a max-abs bound over the tensor cannot see one wrong head or query row): relative L2 of
+    # every 32-wide output row against the fp32 reference — bf16 probabilities and a bf16 output put a row at 2-4e-3; bar 7e-3,
+    # rows of small norm measured against the median row norm
+    d = (out.float() - ref).reshape(Lq, N, 8, 32).norm(dim=-1)
+    rn = ref.reshape(Lq, N, 8, 32).norm(dim=-1)
+    rel = d / torch.maximum(rn, 0.25 * rn.median())
+    assert float(rel.max()) < 7e-3, (float(rel.max()), float(rel.median()))          # measured <= 0.0035 on the 13 cases
+    assert float(rel.median()) < 3.5e-3, float(rel.median())                       # measured 0.0017-0.0018
+    print(f"[attn rows] fwd Lq {Lq} Lk {Lk}: median {float(rel.median()):.4f} max {float(rel.max()):.4f}")
 
 
 @pytest.mark.parametrize("Lq,Lk,N,mask_kind", CASES)
@@ -78,6 +87,16 @@ def test_attention_backward_matches_fp32_autograd(Lq, Lk, N, mask_kind):
         scale = b.abs().max().item()
         err = (a.float() - b).abs().max().item()
         assert err < 3e-2 * scale + 1e-3, (name, err, scale)
+        # per (position, image, head) row, as in the forward test: bf16 P / dS operands and bf16 results
+        L_ = a.shape[0]
+        d = (a.float() - b).reshape(L_, N, 8, 32).norm(dim=-1)
+        rn = b.reshape(L_, N, 8, 32).norm(dim=-1)
+        rel = d / torch.maximum(rn, 0.25 * rn.median())
+        p99 = float(rel.flatten().kthvalue(max(1, int(0.99 * rel.numel()))).values)
+        print(f"[attn rows] {name} Lq {Lq} Lk {Lk}: median {float(rel.median()):.4f} p99 {p99:.4f} max {float(rel.max()):.4f}")
+        # (measured on the 13 cases: median 0.0021-0.0031, 99th percentile <= 0.028; single rows reach 0.05-0.12 where a key / query row's gradient is the small difference of
+        # bf16-rounded terms — dS = P (dP - delta) — so the tail is bounded at the 99th percentile and the maximum only loosely)
+        assert float(rel.median()) < 6e-3 and p99 < 4e-2 and float(rel.max()) < 0.25, (name, float(rel.median()), p99, float(rel.max()))
 
 
 def test_bwd_prep_equals_transpose_plus_delta():
